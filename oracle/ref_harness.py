@@ -1,0 +1,306 @@
+"""ORACLE TOOLING -- build-container only; never imported by the product, never runs on the GPU box.
+
+Imports the reference's own Python from /root/reference so that tests/gen_golden.py can
+(a) check oracle/prosim_oracle.py against it and (b) write the committed golden fixtures.
+
+The reference cannot be imported as shipped in this image:
+pytorch_lightning, torchmetrics, wandb, peft, yacs, trajdata, torch_cluster and
+torch_geometric are absent.  This module registers stand-ins for them in ``sys.modules``:
+
+  * STRUCTURAL stand-ins (no arithmetic): LightningModule = nn.Module, Metric = nn.Module,
+    a minimal yacs CfgNode, empty wandb/peft/trajdata namespaces, package shells for
+    ``prosim.*`` so the reference's ``__init__`` import chains (dataset -> trajdata) do not run.
+  * ARITHMETIC-BEARING stand-ins, written by the builder from torch_cluster's / PyG's
+    documented behaviour (NOT the real libraries -- fixtures that depend on them are
+    labelled ``ref_standins``): ``torch_cluster.{radius, radius_graph, knn, knn_graph}``
+    (brute force; strict d^2 < r^2; first ``max_num_neighbors`` in index order; kNN by
+    (distance, index)) and ``torch_geometric`` ``MessagePassing.propagate(aggr='add',
+    node_dim=0)`` + ``utils.softmax`` (max-shift, / (sum + 1e-16)).
+"""
+from __future__ import annotations
+
+import importlib
+import os
+import sys
+import types
+
+import torch
+import torch.nn as nn
+import yaml
+
+REF_ROOT = "/root/reference"
+
+
+def available() -> bool:
+    return os.path.isdir(os.path.join(REF_ROOT, "prosim"))
+
+
+# --------------------------------------------------------------------------- yacs stand-in
+class CfgNode(dict):
+    def __init__(self, init_dict=None, key_list=None, new_allowed=False):
+        super().__init__()
+        self.__dict__["_frozen"] = False
+        if init_dict:
+            for k, v in init_dict.items():
+                self[k] = CfgNode(v) if isinstance(v, dict) and not isinstance(v, CfgNode) else v
+
+    def __getattr__(self, k):
+        if k in self:
+            return self[k]
+        raise AttributeError(k)
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+    def clone(self):
+        out = type(self)()
+        for k, v in self.items():
+            dict.__setitem__(out, k, v.clone() if isinstance(v, CfgNode) else (list(v) if isinstance(v, list) else v))
+        return out
+
+    def merge_from_other_cfg(self, other):
+        for k, v in other.items():
+            if isinstance(v, dict) and k in self and isinstance(self[k], CfgNode):
+                self[k].merge_from_other_cfg(v if isinstance(v, CfgNode) else CfgNode(v))
+            else:
+                self[k] = CfgNode(v) if isinstance(v, dict) and not isinstance(v, CfgNode) else v
+
+    def merge_from_file(self, path):
+        with open(path) as f:
+            self.merge_from_other_cfg(CfgNode(yaml.safe_load(f)))
+
+    def merge_from_list(self, lst):
+        for k, v in zip(lst[0::2], lst[1::2]):
+            node = self
+            parts = k.split(".")
+            for p in parts[:-1]:
+                node = node[p]
+            node[parts[-1]] = v
+
+    def freeze(self):
+        pass
+
+    def defrost(self):
+        pass
+
+    def register_renamed_key(self, *a, **k):
+        pass
+
+
+# --------------------------------------------------------------------------- torch_cluster stand-in
+def _d2(x, y):
+    dx = x[None, :, 0] - y[:, None, 0]
+    dy = x[None, :, 1] - y[:, None, 1]
+    return dx * dx + dy * dy
+
+
+def _radius(x, y, r, batch_x=None, batch_y=None, max_num_neighbors=32, num_workers=1):
+    if batch_x is None:
+        batch_x = torch.zeros(x.shape[0], dtype=torch.long)
+    if batch_y is None:
+        batch_y = torch.zeros(y.shape[0], dtype=torch.long)
+    d2 = _d2(x.float(), y.float())
+    rr = torch.tensor(float(r), dtype=torch.float32) ** 2
+    ok = (d2 < rr) & (batch_y[:, None] == batch_x[None, :])
+    ok = ok & (torch.cumsum(ok.long(), dim=1) <= max_num_neighbors)
+    yi, xi = ok.nonzero(as_tuple=True)
+    return torch.stack([yi, xi], dim=0)
+
+
+def _radius_graph(x, r, batch=None, loop=False, max_num_neighbors=32, flow="source_to_target", num_workers=1):
+    ei = _radius(x, x, r, batch, batch, max_num_neighbors if loop else max_num_neighbors + 1)
+    row, col = (ei[1], ei[0]) if flow == "source_to_target" else (ei[0], ei[1])
+    if not loop:
+        m = row != col
+        row, col = row[m], col[m]
+    return torch.stack([row, col], dim=0)
+
+
+def _knn(x, y, k, batch_x=None, batch_y=None, cosine=False, num_workers=1):
+    if batch_x is None:
+        batch_x = torch.zeros(x.shape[0], dtype=torch.long)
+    if batch_y is None:
+        batch_y = torch.zeros(y.shape[0], dtype=torch.long)
+    d2 = _d2(x.float(), y.float())
+    same = batch_y[:, None] == batch_x[None, :]
+    d2 = torch.where(same, d2, torch.full_like(d2, float("inf")))
+    order = torch.sort(d2, dim=1, stable=True)[1][:, :min(k, x.shape[0])]
+    yi = torch.arange(y.shape[0])[:, None].expand_as(order)
+    valid = torch.gather(same, 1, order)
+    return torch.stack([yi[valid], order[valid]], dim=0)
+
+
+def _knn_graph(x, k, batch=None, loop=False, flow="source_to_target", cosine=False, num_workers=1):
+    ei = _knn(x, x, k if loop else k + 1, batch, batch)
+    row, col = (ei[1], ei[0]) if flow == "source_to_target" else (ei[0], ei[1])
+    if not loop:
+        m = row != col
+        row, col = row[m], col[m]
+    return torch.stack([row, col], dim=0)
+
+
+# --------------------------------------------------------------------------- torch_geometric stand-in
+def _pyg_softmax(src, index, ptr=None, num_nodes=None, dim=0):
+    if index.numel() == 0:
+        return src
+    n = int(index.max()) + 1 if num_nodes is None else num_nodes
+    idx = index.view(-1, *([1] * (src.dim() - 1))).expand_as(src)
+    smax = torch.full((n,) + src.shape[1:], float("-inf"), dtype=src.dtype)
+    smax = smax.scatter_reduce(0, idx, src.detach(), reduce="amax", include_self=True)
+    out = (src - smax[index]).exp()
+    ssum = torch.zeros((n,) + src.shape[1:], dtype=src.dtype).index_add_(0, index, out) + 1e-16
+    return out / ssum[index]
+
+
+class _MessagePassing(nn.Module):
+    """propagate() for the one usage in the reference (attention_layer.py:117):
+    flow source_to_target, aggr='add', node_dim=0; kwargs ending in _i/_j are gathered by
+    target/source index; ``index`` = target index, ``ptr`` = None."""
+
+    def __init__(self, aggr="add", node_dim=0, **kwargs):
+        super().__init__()
+        assert aggr == "add" and node_dim == 0
+
+    def propagate(self, edge_index, **kwargs):
+        src, dst = edge_index[0], edge_index[1]
+        x_dst = kwargs["x_dst"]
+        msg = self.message(q_i=kwargs["q"][dst], k_j=kwargs["k"][src], v_j=kwargs["v"][src],
+                           r=kwargs["r"], index=dst, ptr=None)
+        out = torch.zeros((x_dst.shape[0],) + msg.shape[1:], dtype=msg.dtype).index_add_(0, dst, msg)
+        return self.update(out, x_dst=x_dst)
+
+
+# --------------------------------------------------------------------------- install
+_INSTALLED = False
+
+
+def _mod(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+def _pkg(name, path):
+    m = types.ModuleType(name)
+    m.__path__ = [path]
+    sys.modules[name] = m
+    return m
+
+
+def install():
+    global _INSTALLED
+    if _INSTALLED:
+        return
+    if not available():
+        raise RuntimeError("reference tree not present (this harness only runs in the build container)")
+
+    class _Lightning(nn.Module):
+        @property
+        def device(self):
+            return torch.device("cpu")
+
+        def log(self, *a, **k):
+            pass
+
+    pl = _mod("pytorch_lightning", LightningModule=_Lightning, Callback=object)
+    _mod("torchmetrics", Metric=nn.Module, MeanMetric=nn.Module)
+    _mod("wandb")
+    _mod("peft")
+    yc = _mod("yacs")
+    yc.config = _mod("yacs.config", CfgNode=CfgNode)
+    _mod("torch_cluster", radius=_radius, radius_graph=_radius_graph, knn=_knn, knn_graph=_knn_graph)
+    tg = _mod("torch_geometric")
+    tg.nn = _mod("torch_geometric.nn")
+    tg.nn.conv = _mod("torch_geometric.nn.conv", MessagePassing=_MessagePassing)
+    tg.utils = _mod("torch_geometric.utils", softmax=_pyg_softmax)
+
+    # package shells: let submodules import without running the reference's __init__ chains
+    root = os.path.join(REF_ROOT, "prosim")
+    for name in ["prosim", "prosim.core", "prosim.config", "prosim.dataset", "prosim.models", "prosim.models.layers",
+                 "prosim.models.utils", "prosim.models.scene_encoder", "prosim.models.decoder",
+                 "prosim.models.policy", "prosim.models.prompt_encoder", "prosim.models.condition_transformer",
+                 "prosim.rollout", "prosim.loss", "prosim.metrics"]:
+        _pkg(name, os.path.join(REF_ROOT, *name.split(".")))
+    # modules of the reference that only drag in absent deps and carry no arithmetic on this path
+    _mod("prosim.models.utils.visualization", vis_agent_traj_pred=None, vis_scene_traj_pred=None,
+         visualization_callback=None)
+    _mod("prosim.rollout.distributed_utils", check_mem_usage=lambda *a, **k: None,
+         print_system_mem_usage=lambda *a, **k: None, get_gpu_memory_usage=lambda *a, **k: None)
+    _mod("prosim.loss.loss_func", loss_func_dict={})
+    _mod("prosim.models.condition_transformer.text_attns", text_attns={})
+    wi = importlib.import_module("prosim.models.utils.weight_init")
+    sys.modules["prosim.models.utils"].weight_init = wi.weight_init
+    # condition_transformer/__init__ is empty in the reference; traj_sam imports the class from the package
+    base = importlib.import_module("prosim.models.condition_transformer.base")
+    sys.modules["prosim.models.condition_transformer"].ConditionTransformer = base.ConditionTransformer
+    _INSTALLED = True
+
+
+def get_config(cond_types=("goal", "v_action_tag"), overrides=None):
+    """The demo config (prosim_demo/cfg/no_text.yaml over config/default.py)."""
+    install()
+    default = importlib.import_module("prosim.config.default")
+    opts = ["PROMPT.CONDITION.TYPES", list(cond_types)]
+    cfg = default.get_config(os.path.join(REF_ROOT, "prosim_demo/cfg/no_text.yaml"), opts + list(overrides or []))
+    return cfg
+
+
+def build_model(cfg):
+    """Instantiate the reference ``ProSim`` (traj_sam.py:14) without Lightning's trainer
+    scaffolding: BaseModel.__init__'s metric/loss wiring is skipped, the sub-modules are the
+    reference's own classes built by its own ``_config_models``."""
+    install()
+    for m in ["prosim.models.scene_encoder.base", "prosim.models.scene_encoder.attn_fusion",
+              "prosim.models.decoder.base", "prosim.models.decoder.sym_coord",
+              "prosim.models.prompt_encoder.base", "prosim.models.policy.base"]:
+        importlib.import_module(m)
+    traj_sam = importlib.import_module("prosim.models.traj_sam")
+
+    class RefProSim(traj_sam.ProSim):
+        def __init__(self, config):
+            nn.Module.__init__(self)
+            self.config = config
+            self.tasks = config.TASK.TYPES
+            self._config_models()
+            self.rollout_steps = config.ROLLOUT.POLICY.REPLAN_FREQ
+            self.rollout_top_k = config.ROLLOUT.POLICY.TOP_K
+            self.rollout_top_k_train = config.ROLLOUT.POLICY.TOP_K_TRAIN
+            self.hist_step = config.DATASET.FORMAT.HISTORY.STEPS
+            self.pred_gmm = config.MODEL.POLICY.ACT_DECODER.TRAJ.PRED_GMM
+            self.pred_vel = config.MODEL.POLICY.ACT_DECODER.TRAJ.PRED_VEL
+
+    return RefProSim(cfg).eval()
+
+
+class Extras:
+    """Stands in for the trajdata batch object: only ``.extras`` is read on this path."""
+
+    def __init__(self, extras):
+        self.extras = extras
+
+
+def make_batch(scene_in, spec):
+    """scene_in (oracle layout, numpy) -> the ``batch.extras`` dict the reference reads
+    (dataset/format_utils.py:798-815)."""
+    t = lambda a, dt=torch.float32: torch.from_numpy(a).to(dt).clone()
+    B, N = scene_in["prompt_mask"].shape
+    ids = [[f"a{n}" for n in range(int(scene_in["prompt_mask"][b].sum()))] for b in range(B)]
+    obs = lambda: dict(input=t(scene_in["obs_input"]), mask=t(scene_in["obs_mask"], torch.bool),
+                       position=t(scene_in["obs_pos"]), heading=t(scene_in["obs_head"]), agent_ids=ids)
+    extras = dict(
+        init_obs=obs(),
+        init_map=dict(input=t(scene_in["map_input"]), mask=t(scene_in["map_mask"], torch.bool),
+                      position=t(scene_in["map_pos"]), heading=t(scene_in["map_head"])),
+        prompt=dict(motion_pred=dict(prompt=t(scene_in["prompt"]), prompt_mask=t(scene_in["prompt_mask"], torch.bool),
+                                     position=t(scene_in["obs_pos"]), heading=t(scene_in["obs_head"])[..., None],
+                                     agent_type=t(scene_in["agent_type"], torch.long), agent_ids=ids)),
+        all_t_indices=torch.tensor(spec.all_t_indices),
+        fut_obs={int(tt_): obs() for tt_ in spec.all_t_indices if tt_ > 0},
+    )
+    cond = {}
+    for k, v in (scene_in.get("cond") or {}).items():
+        cond[k] = dict(input=t(v["input"]), mask=t(v["mask"], torch.bool), prompt_idx=t(v["prompt_idx"], torch.long),
+                       prompt_mask=t(scene_in["prompt_mask"], torch.bool))
+    extras["condition"] = cond
+    return Extras(extras)

@@ -1,0 +1,98 @@
+"""Model spec for the closed-loop rollout path.
+
+A plain dataclass mirror of the ``MODEL.*`` / ``DATASET.FORMAT.*`` / ``ROLLOUT.*``
+values the reference reads on this path (reference: prosim_demo/cfg/no_text.yaml:212-279
+over prosim/config/default.py).  No yacs, no Lightning: the spec is the only
+configuration object the engine, the oracle and the weight initialiser share.
+"""
+from __future__ import annotations
+
+import dataclasses
+from dataclasses import dataclass, field
+from typing import List, Tuple
+
+# V_Action_MotionTag enum order (reference: prosim/dataset/motion_tag_utils.py:4-15).
+V_ACTION_TAGS: Tuple[str, ...] = (
+    "Stopping", "Accelerate", "Decelerate", "KeepSpeed", "LeftLaneChange",
+    "RightLaneChange", "KeepLane", "LeftTurn", "RightTurn", "Straight", "Parked",
+)
+# PROMPT.CONDITION.MOTION_TAG.USED_TAGS order (no_text.yaml:72) -- this is the order in
+# which MotionTagEncoder.forward emits per-tag condition entries
+# (condition_encoders.py:58,108).
+USED_V_ACTION_TAGS: Tuple[str, ...] = (
+    "Accelerate", "Decelerate", "KeepSpeed", "Stopping", "LeftLaneChange",
+    "RightLaneChange", "KeepLane", "LeftTurn", "RightTurn", "Straight", "Parked",
+)
+
+
+@dataclass(frozen=True)
+class ModelSpec:
+    # MODEL.HIDDEN_DIM (no_text.yaml:217)
+    hidden: int = 128
+    # *.ATTN.NUM_HEAD / FF_DIM -- FF_DIM is fed to AttentionLayer(head_dim=...)
+    # (attn_fusion.py:32, act_decoder.py:190, sym_coord.py:29).
+    heads: int = 8
+    head_dim: int = 16
+    # MODEL.SCENE_ENCODER.ATTN (no_text.yaml:226-232)
+    scene_layers: int = 6
+    scene_knn: int = 32                # MAX_NUM_NEIGH; agents use min(4*k, 100) (attn_fusion.py:107)
+    # MODEL.DECODER.ATTN (no_text.yaml:243-251)
+    dec_layers: int = 6
+    dec_prompt_radius: float = 300.0
+    dec_scene_radius: float = 300.0
+    dec_max_neigh: int = 512
+    # MODEL.POLICY.ACT_DECODER.ATTN (no_text.yaml:270-279)
+    pol_layers: int = 6
+    pol_agent_radius: float = 100.0
+    pol_map_radius: float = 50.0
+    pol_max_neigh: int = 768
+    # MODEL.CONDITION_TRANSFORMER (no_text.yaml:281-288, default.py:521-524)
+    cond_layers: int = 3
+    # DATASET.FORMAT.HISTORY (no_text.yaml:195-200): 8 elems + 2 extent + 3 type + 11 time one-hot
+    hist_steps: int = 11
+    obs_dim: int = 24
+    # DATASET.FORMAT.MAP: 4 coords + type + tl + 3 type one-hot + 2 dir (format_utils.py:249-261)
+    map_dim: int = 11
+    # MODEL.{MAP,OBS}_ENCODER.POINTNET (default.py:488-497)
+    map_pre_layers: int = 3
+    map_mlp_layers: int = 5
+    obs_pre_layers: int = 1
+    obs_mlp_layers: int = 3
+    # DATASET.FORMAT.TARGET (no_text.yaml:186-190 + default.py:725-730): x,y,h,xd,yd
+    target_steps: int = 10
+    state_dim: int = 5
+    motion_k: int = 1                  # MODEL.POLICY.ACT_DECODER.TRAJ.K
+    num_agent_types: int = 3           # DATASET.USE_PED_CYCLIST -> anchors K*3 (act_decoder.py:66-68)
+    prompt_dim: int = 7                # v_local(2)+extent(2)+type one-hot(3) (prompt_utils.py:111-150)
+    # ROLLOUT.POLICY (no_text.yaml:44-48)
+    replan_freq: int = 10
+    max_steps: int = 80
+    dt: float = 0.1                    # DATASET.MOTION.DT
+    ln_eps: float = 1e-5
+    fourier_temperature: float = 10000.0
+
+    @property
+    def agent_knn(self) -> int:
+        return min(self.scene_knn * 4, 100)
+
+    @property
+    def all_t_indices(self) -> List[int]:
+        # format_utils.py:699-713 with TAIL_PADDING=True, SAMPLE_RATE=10, split=ROLLOUT
+        return list(range(0, self.max_steps, self.replan_freq))
+
+    @property
+    def n_replans(self) -> int:
+        return len(self.all_t_indices)
+
+    @property
+    def out_dim(self) -> int:
+        return self.target_steps * self.state_dim
+
+    def replace(self, **kw) -> "ModelSpec":
+        return dataclasses.replace(self, **kw)
+
+
+DEMO_SPEC = ModelSpec()
+# Reduced-depth variant used for the committed golden fixtures and fast CPU tests
+# (same kernels, fewer layers).
+SMALL_SPEC = ModelSpec(scene_layers=2, dec_layers=2, pol_layers=2, cond_layers=1)

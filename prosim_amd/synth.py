@@ -1,0 +1,144 @@
+"""Seeded synthetic scenes in the rollout path's input layout.
+
+Layouts follow the reference's batch formatters (dataset/format_utils.py:221-263 map,
+:357-447 history, prompt_utils.py:111-150 prompt, condition_utils.py:126-222 conditions):
+
+  map_input  [B, M, P, 11]  per polyline-local segments: x0,y0,x1,y1, type, tl, type one-hot(3), dir(2)
+  map_mask   [B, M, P]      bool
+  map_pos    [B, M, 2], map_head [B, M]          polyline frame in the scene frame
+  obs_input  [B, N, 11, 24] ego-relative history: x,y,sin,cos,vx,vy,ax,ay, extent(2), type one-hot(3), time one-hot(11)
+  obs_mask   [B, N, 11, 24] bool
+  obs_pos    [B, N, 2], obs_head [B, N]          agent pose at the last history step, scene frame
+  prompt     [B, N, 7]  v_local(2), extent(2), type one-hot(3);  prompt_mask [B, N];  agent_type [B, N] in 1..3
+  cond       {'goal': {input [B,C,3]=(gx,gy,t), mask [B,C], prompt_idx [B,C,1]},
+              'v_action_tag': {input [B,C,3]=(tag_id,t0,t1), mask, prompt_idx}}
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import numpy as np
+
+from .spec import ModelSpec
+
+
+def make_scene(spec: ModelSpec, n_agents: int, n_polylines: int, batch: int = 1, seed: int = 0,
+               square: float = 200.0, points: int = 19, goal: bool = False, tags: bool = False,
+               ragged: bool = False, clustered: bool = False) -> Dict[str, np.ndarray]:
+    """One batch of ``batch`` scenes.  ``ragged``: later scenes in the batch get fewer agents /
+    polylines / points, and some history steps are masked (NaN), to exercise the mask paths.
+    ``clustered``: agents are placed along polylines (realistic density) instead of uniformly."""
+    rng = np.random.RandomState(1234 + seed)
+    B, N, M, P, H = batch, n_agents, n_polylines, points, spec.hist_steps
+    f32 = np.float32
+    half = square / 2
+
+    map_pos = rng.uniform(-half, half, (B, M, 2)).astype(f32)
+    map_head = rng.uniform(-np.pi, np.pi, (B, M)).astype(f32)
+    map_input = np.zeros((B, M, P, spec.map_dim), f32)
+    seg = rng.uniform(-5, 5, (B, M, P, 4)).astype(f32)
+    map_input[..., :4] = seg
+    map_input[..., 4] = 1.0               # lane centre type
+    map_input[..., 5] = 0.0               # traffic light state
+    map_input[..., 6] = 1.0               # one-hot(type == 1)
+    d = seg[..., 2:4] - seg[..., 0:2]
+    map_input[..., 9:11] = d / np.clip(np.linalg.norm(d, axis=-1, keepdims=True), 1e-6, None)
+    map_mask = np.ones((B, M, P), bool)
+
+    if clustered:
+        pick = rng.randint(0, M, (B, N))
+        obs_pos = (np.take_along_axis(map_pos, pick[..., None].repeat(2, -1), 1)
+                   + rng.uniform(-3, 3, (B, N, 2))).astype(f32)
+    else:
+        obs_pos = rng.uniform(-half, half, (B, N, 2)).astype(f32)
+    obs_head = rng.uniform(-np.pi, np.pi, (B, N)).astype(f32)
+    obs_input = np.zeros((B, N, H, spec.obs_dim), f32)
+    obs_input[..., 0:2] = rng.uniform(-2, 2, (B, N, H, 2))
+    dth = rng.uniform(-0.1, 0.1, (B, N, H))
+    obs_input[..., 2] = np.sin(dth)
+    obs_input[..., 3] = np.cos(dth)
+    obs_input[..., 4:8] = rng.uniform(-1, 1, (B, N, H, 4))
+    # last history step is the agent's own frame origin
+    obs_input[:, :, -1, 0:2] = 0.0
+    obs_input[:, :, -1, 2] = 0.0
+    obs_input[:, :, -1, 3] = 1.0
+    agent_type = rng.randint(1, 4, (B, N)).astype(np.int64) if ragged else np.ones((B, N), np.int64)
+    extent = np.array([4.5, 2.0], f32)
+    obs_input[..., 8:10] = extent
+    for tid in (1, 2, 3):
+        obs_input[..., 10 + tid - 1] = (agent_type == tid)[..., None]
+    obs_input[..., 13:13 + H] = np.eye(H, dtype=f32)
+    obs_mask = np.ones((B, N, H, spec.obs_dim), bool)
+
+    prompt_mask = np.ones((B, N), bool)
+    if ragged:
+        for b in range(B):
+            n_b = max(2, N - 3 * b - (1 if b == 0 else 0))
+            m_b = max(4, M - 5 * b - 2)
+            prompt_mask[b, n_b:] = False
+            obs_mask[b, n_b:] = False
+            map_mask[b, m_b:] = False
+            # ragged polylines: trailing points invalid
+            npts = rng.randint(1, P + 1, M)
+            for m in range(M):
+                map_mask[b, m, npts[m]:] = False
+            # early history steps missing for some agents (NaN-padded, as get_center_obs does)
+            miss = rng.randint(0, H // 2, N)
+            for n in range(n_b):
+                obs_mask[b, n, :miss[n], :8] = False
+        obs_input = np.where(obs_mask, obs_input, np.nan).astype(f32)
+        map_input = np.where(map_mask[..., None], map_input, 0.0).astype(f32)
+
+    prompt = np.zeros((B, N, spec.prompt_dim), f32)
+    prompt[..., 0:2] = np.nan_to_num(obs_input[:, :, -1, 4:6])
+    prompt[..., 2:4] = extent
+    for tid in (1, 2, 3):
+        prompt[..., 4 + tid - 1] = agent_type == tid
+
+    scene = dict(map_input=map_input, map_mask=map_mask, map_pos=map_pos, map_head=map_head,
+                 obs_input=obs_input, obs_mask=obs_mask, obs_pos=obs_pos, obs_head=obs_head,
+                 prompt=prompt, prompt_mask=prompt_mask, agent_type=agent_type)
+    cond = {}
+    if goal:
+        g = np.zeros((B, N, 3), f32)
+        g[..., 0:2] = rng.uniform(-50, 50, (B, N, 2))
+        g[..., 2] = float(spec.max_steps)
+        gm = prompt_mask.copy()
+        if ragged:
+            gm &= rng.rand(B, N) < 0.7
+        cond["goal"] = dict(input=g, mask=gm, prompt_idx=np.tile(np.arange(N)[None, :, None], (B, 1, 1)).astype(np.int64))
+    if tags:
+        tg = np.zeros((B, N, 3), f32)
+        tg[..., 0] = rng.randint(0, 11, (B, N))
+        tg[..., 1] = 0.0
+        tg[..., 2] = float(spec.max_steps)
+        tm = prompt_mask.copy()
+        if ragged:
+            tm &= rng.rand(B, N) < 0.6
+        cond["v_action_tag"] = dict(input=tg, mask=tm,
+                                    prompt_idx=np.tile(np.arange(N)[None, :, None], (B, 1, 1)).astype(np.int64))
+    if cond:
+        scene["cond"] = cond
+    return scene
+
+
+# The BASELINE.json configs (index -> generator kwargs).  Config 0's demo_dataset scene needs the
+# trajdata fork's VectorMap protobuf schema to load lanes (absent), so the plumbing config uses
+# a 16-agent synthetic scene of the same shape; config 4 (Waymo-val dense scene, unobtainable
+# offline) is a 256-agent scene in a 100 m square.  Both substitutions are stated in DESIGN.md.
+BASELINE_CONFIGS = [
+    dict(name="cfg0_16a_128p", n_agents=16, n_polylines=128, batch=1),
+    dict(name="cfg1_64a_512p", n_agents=64, n_polylines=512, batch=1),
+    dict(name="cfg2_128a_1024p_goal", n_agents=128, n_polylines=1024, batch=1, goal=True),
+    dict(name="cfg3_8x128a_1024p_goal", n_agents=128, n_polylines=1024, batch=8, goal=True),
+    dict(name="cfg4_256a_1024p_goal_tags_dense", n_agents=256, n_polylines=1024, batch=1, goal=True, tags=True,
+         square=100.0),
+]
+
+
+def baseline_scene(spec: ModelSpec, idx: int, seed: int = 0, batch: Optional[int] = None) -> Dict[str, np.ndarray]:
+    kw = dict(BASELINE_CONFIGS[idx])
+    kw.pop("name")
+    if batch is not None:
+        kw["batch"] = batch
+    return make_scene(spec, seed=seed, **kw)

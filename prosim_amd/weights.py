@@ -1,0 +1,200 @@
+"""Weight container for the rollout path.
+
+Weights are a flat ``{name: float32 ndarray}`` dict keyed exactly like the reference
+``ProSim.state_dict()`` (``scene_encoder.* / decoder.* / policy.act_decoder.* /
+prompt_encoder.motion_pred.* / condition_transformers.policy_decoder.*``; see SURVEY.md
+section 5 "checkpoint / resume"), so a released ``.ckpt`` can be loaded with
+:func:`from_state_dict` and a reference module can ``load_state_dict`` what
+:func:`init_weights` makes (tests/gen_golden.py does exactly that, strict=True).
+
+No trained checkpoint ships with the reference (README.md:58 points to Google Drive), so
+tests, smoke and bench use :func:`init_weights`: a seeded initialiser whose draw order is
+the sorted parameter-name order.  LayerNorm affine terms are perturbed away from (1, 0)
+on purpose -- an identity LayerNorm would hide a wrong gamma/beta in a kernel.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+from typing import Dict, List, Tuple
+
+import numpy as np
+import torch
+
+from .spec import ModelSpec, USED_V_ACTION_TAGS
+
+Shapes = "OrderedDict[str, Tuple[int, ...]]"
+
+
+def _mlp_shapes(out: Dict, prefix: str, dims: List[int], ret_before_act: bool, without_norm: bool) -> None:
+    """Parameter names of the reference ``MLP`` (models/layers/mlp.py:475-494): an
+    nn.Sequential of Linear [, LayerNorm], ReLU per hidden layer."""
+    idx = 0
+    for i in range(len(dims) - 1):
+        out[f"{prefix}.mlp.{idx}.weight"] = (dims[i + 1], dims[i])
+        out[f"{prefix}.mlp.{idx}.bias"] = (dims[i + 1],)
+        idx += 1
+        if i < len(dims) - 2:
+            if not without_norm:
+                out[f"{prefix}.mlp.{idx}.weight"] = (dims[i + 1],)
+                out[f"{prefix}.mlp.{idx}.bias"] = (dims[i + 1],)
+                idx += 1
+            idx += 1  # ReLU
+
+
+def mlp_layout(dims: List[int], ret_before_act: bool, without_norm: bool) -> List[Tuple[int, int]]:
+    """[(linear_seq_idx, ln_seq_idx or -1)] for each Linear of a reference MLP."""
+    res = []
+    idx = 0
+    for i in range(len(dims) - 1):
+        lin = idx
+        idx += 1
+        ln = -1
+        if i < len(dims) - 2:
+            if not without_norm:
+                ln = idx
+                idx += 1
+            idx += 1
+        res.append((lin, ln))
+    return res
+
+
+def _pointnet_shapes(out: Dict, prefix: str, in_dim: int, hidden: int, n_pre: int, n_mlp: int) -> None:
+    # pointnet_encoder.py:19-22
+    _mlp_shapes(out, f"{prefix}.pre_mlps", [in_dim] + [hidden] * n_pre, False, False)
+    _mlp_shapes(out, f"{prefix}.mlps", [hidden * 2] + [hidden] * (n_mlp - n_pre), False, False)
+    _mlp_shapes(out, f"{prefix}.out_mlps", [hidden] * 3, True, True)
+
+
+def _attn_shapes(out: Dict, prefix: str, d: int, hd: int, bipartite: bool) -> None:
+    # attention_layer.py:28-54
+    out[f"{prefix}.to_q.weight"] = (hd, d)
+    out[f"{prefix}.to_q.bias"] = (hd,)
+    out[f"{prefix}.to_k.weight"] = (hd, d)
+    out[f"{prefix}.to_v.weight"] = (hd, d)
+    out[f"{prefix}.to_v.bias"] = (hd,)
+    out[f"{prefix}.to_k_r.weight"] = (hd, d)
+    out[f"{prefix}.to_v_r.weight"] = (hd, d)
+    out[f"{prefix}.to_v_r.bias"] = (hd,)
+    out[f"{prefix}.to_s.weight"] = (hd, d)
+    out[f"{prefix}.to_s.bias"] = (hd,)
+    out[f"{prefix}.to_g.weight"] = (hd, hd + d)
+    out[f"{prefix}.to_g.bias"] = (hd,)
+    out[f"{prefix}.to_out.weight"] = (d, hd)
+    out[f"{prefix}.to_out.bias"] = (d,)
+    out[f"{prefix}.ff_mlp.0.weight"] = (4 * d, d)
+    out[f"{prefix}.ff_mlp.0.bias"] = (4 * d,)
+    out[f"{prefix}.ff_mlp.3.weight"] = (d, 4 * d)
+    out[f"{prefix}.ff_mlp.3.bias"] = (d,)
+    names = ["attn_prenorm_x_src", "attn_prenorm_r", "attn_postnorm", "ff_prenorm", "ff_postnorm"]
+    if bipartite:
+        names.insert(1, "attn_prenorm_x_dst")
+    for n in names:
+        out[f"{prefix}.{n}.weight"] = (d,)
+        out[f"{prefix}.{n}.bias"] = (d,)
+
+
+def param_shapes(spec: ModelSpec) -> "OrderedDict[str, Tuple[int, ...]]":
+    """Every learnable tensor on the rollout path, reference state_dict naming.
+
+    For non-bipartite attention layers the reference registers ONE LayerNorm under two
+    attribute names (attention_layer.py:48-49), so its state_dict carries
+    ``attn_prenorm_x_dst.*`` aliases; they are not separate parameters and are omitted here
+    (:func:`to_reference_state_dict` adds them back).
+    """
+    d = spec.hidden
+    hd = spec.heads * spec.head_dim
+    out: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
+    _pointnet_shapes(out, "scene_encoder.map_encoder", spec.map_dim, d, spec.map_pre_layers, spec.map_mlp_layers)
+    _pointnet_shapes(out, "scene_encoder.obs_encoder", spec.obs_dim, d, spec.obs_pre_layers, spec.obs_mlp_layers)
+    for i in range(spec.scene_layers):
+        _attn_shapes(out, f"scene_encoder.a2a_attn_layers.{i}", d, hd, False)
+        _attn_shapes(out, f"scene_encoder.s2s_attn_layers.{i}", d, hd, False)
+    # prompt_encoder/base.py:23-34
+    _mlp_shapes(out, "prompt_encoder.motion_pred.state_encoder", [spec.prompt_dim, d, d], True, False)
+    for i in range(spec.dec_layers):
+        _attn_shapes(out, f"decoder.p2p_attn_layers.{i}", d, hd, False)
+        _attn_shapes(out, f"decoder.s2p_attn_layers.{i}", d, hd, True)
+    pa = "policy.act_decoder"
+    for i in range(spec.pol_layers):
+        _attn_shapes(out, f"{pa}.a2p_attn_layers.{i}", d, hd, True)
+        _attn_shapes(out, f"{pa}.m2p_attn_layers.{i}", d, hd, True)
+    # act_decoder.py:47-76 (anchor mode, USE_GOAL_PRED_LOSS)
+    _mlp_shapes(out, f"{pa}.motion_head", [d, d, d // 2, spec.out_dim], True, False)
+    for i in range(3):
+        out[f"{pa}.CG_decode.CGs.{i}.MLP.0.weight"] = (d, d)
+        out[f"{pa}.CG_decode.CGs.{i}.MLP.0.bias"] = (d,)
+        out[f"{pa}.CG_decode.CGs.{i}.MLP.1.weight"] = (d,)
+        out[f"{pa}.CG_decode.CGs.{i}.MLP.1.bias"] = (d,)
+    out[f"{pa}.motion_anchors.weight"] = (spec.motion_k * spec.num_agent_types, d)
+    _mlp_shapes(out, f"{pa}.pred_mlp", [d, d, d // 2, 2], True, False)
+    # condition transformer at 'policy_decoder' (traj_sam.py:47-52; condition_encoders.py, condition_attns.py)
+    ct = "condition_transformers.policy_decoder"
+    _mlp_shapes(out, f"{ct}.condition_encoders.goal.goal_encoder", [2, d, d], True, True)
+    for tag in USED_V_ACTION_TAGS:
+        out[f"{ct}.condition_encoders.v_action_tag.tag_encoder.{tag}"] = (d,)
+    for i in range(spec.cond_layers):
+        _attn_shapes(out, f"{ct}.condition_attn.attn_layers.{i}", d, hd, False)
+    return out
+
+
+def init_weights(spec: ModelSpec, seed: int = 0) -> Dict[str, np.ndarray]:
+    """Seeded initialiser (torch CPU generator; identical on every box with this image)."""
+    g = torch.Generator(device="cpu")
+    g.manual_seed(1_000_003 * (seed + 1))
+    shapes = param_shapes(spec)
+    w: Dict[str, np.ndarray] = {}
+    for name in sorted(shapes):
+        shp = shapes[name]
+        is_ln = len(shp) == 1 and name.endswith(".weight") and (
+            "norm" in name or ".MLP.1." in name or _is_mlp_ln(name, shapes))
+        is_ln_bias = len(shp) == 1 and name.endswith(".bias") and (
+            "norm" in name or ".MLP.1." in name or _is_mlp_ln(name[:-5] + ".weight", shapes))
+        if is_ln:
+            t = 1.0 + 0.1 * torch.randn(shp, generator=g)
+        elif is_ln_bias:
+            t = 0.1 * torch.randn(shp, generator=g)
+        elif "motion_anchors" in name or "tag_encoder" in name:
+            t = torch.randn(shp, generator=g)
+        elif len(shp) == 2:
+            bound = 1.0 / np.sqrt(shp[1])
+            t = (torch.rand(shp, generator=g) * 2 - 1) * bound
+        else:  # Linear bias: fan-in of the sibling weight
+            fan_in = shapes[name[:-5] + ".weight"][1]
+            bound = 1.0 / np.sqrt(fan_in)
+            t = (torch.rand(shp, generator=g) * 2 - 1) * bound
+        w[name] = t.to(torch.float32).numpy().copy()
+    return w
+
+
+def _is_mlp_ln(weight_name: str, shapes) -> bool:
+    """A 1-d ``*.mlp.N.weight`` is a LayerNorm scale (Linear weights are 2-d)."""
+    return ".mlp." in weight_name and weight_name in shapes and len(shapes[weight_name]) == 1
+
+
+def from_state_dict(spec: ModelSpec, state_dict) -> Dict[str, np.ndarray]:
+    """Pick the rollout-path tensors out of a reference ``state_dict`` (torch tensors or arrays)."""
+    w = {}
+    for name, shp in param_shapes(spec).items():
+        if name not in state_dict:
+            raise KeyError(f"checkpoint lacks '{name}'")
+        t = state_dict[name]
+        a = t.detach().cpu().numpy() if hasattr(t, "detach") else np.asarray(t)
+        if tuple(a.shape) != tuple(shp):
+            raise ValueError(f"'{name}': checkpoint shape {a.shape} != spec shape {shp}")
+        w[name] = np.ascontiguousarray(a, dtype=np.float32)
+    return w
+
+
+def to_reference_state_dict(spec: ModelSpec, w: Dict[str, np.ndarray]) -> Dict[str, torch.Tensor]:
+    """Our dict + the aliased ``attn_prenorm_x_dst`` keys the reference state_dict carries."""
+    sd = {k: torch.from_numpy(np.array(v)) for k, v in w.items()}
+    for k in list(sd):
+        if ".attn_prenorm_x_src." in k:
+            alias = k.replace(".attn_prenorm_x_src.", ".attn_prenorm_x_dst.")
+            if alias not in sd:
+                sd[alias] = sd[k].clone()
+    return sd
+
+
+def n_params(spec: ModelSpec) -> int:
+    return int(sum(int(np.prod(s)) for s in param_shapes(spec).values()))
