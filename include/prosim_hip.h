@@ -1,0 +1,148 @@
+/*
+ * prosim_hip.h -- C ABI of libprosim_hip.so, the MI355X (gfx950) closed-loop rollout engine.
+ *
+ * Drop-in boundary: the reference has no FFI of its own -- its
+ * plugin API is the Python string registry (prosim/core/registry.py:54-134) through which
+ * ProSim (prosim/models/traj_sam.py) looks up a scene encoder, a decoder ("generator") and a
+ * policy.  The entry points below are what thin Python classes registered under that registry
+ * bind with ctypes; each cites the reference call it replaces.
+ *
+ * Conventions: plain pointers and sizes only; all tensors are dense row-major float32 unless
+ * noted; masks are uint8 (0/1); every function returns 0 on success or a negative PS_E_* code
+ * and ps_last_error() then holds a message.  Host buffers are caller-owned and may be freed
+ * as soon as the call returns; device buffers are engine-owned.  One engine per GPU; a handle
+ * is not thread-safe.  The reference signals errors with Python exceptions/asserts -- the
+ * host wrapper (prosim_amd/engine.py) turns non-zero codes into RuntimeError.
+ */
+#ifndef PROSIM_HIP_H
+#define PROSIM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PS_OK 0
+#define PS_E_ARG (-1)      /* bad argument / unsupported configuration */
+#define PS_E_STATE (-2)    /* call order violated (e.g. rollout before set_scene) */
+#define PS_E_HIP (-3)      /* HIP runtime error */
+#define PS_E_WEIGHT (-4)   /* missing / mis-shaped weight tensor */
+
+typedef struct ps_engine ps_engine;
+
+/* Mirror of prosim_amd.spec.ModelSpec = the MODEL.* / DATASET.FORMAT.* / ROLLOUT.* values the
+ * reference reads on this path (prosim_demo/cfg/no_text.yaml:212-279). */
+typedef struct ps_config {
+  int32_t hidden, heads, head_dim;             /* must be 128, 8, 16 in this build */
+  int32_t scene_layers, scene_knn, agent_knn;  /* SCENE_ENCODER.ATTN; agent_knn = min(4*k, 100) */
+  int32_t dec_layers, dec_max_neigh;
+  float dec_prompt_radius, dec_scene_radius;
+  int32_t pol_layers, pol_max_neigh;
+  float pol_agent_radius, pol_map_radius;
+  int32_t cond_layers;
+  int32_t hist_steps, obs_dim, map_dim;        /* 11, 24, 11 */
+  int32_t map_pre_layers, map_mlp_layers, obs_pre_layers, obs_mlp_layers;
+  int32_t target_steps, state_dim, motion_k, num_agent_types, prompt_dim;
+  int32_t replan_freq, max_steps;
+  float dt, ln_eps;
+  int32_t device;                              /* HIP device ordinal */
+} ps_config;
+
+/* Create an engine and upload weights.  names[i] are reference state_dict keys
+ * (scene_encoder.* / decoder.* / policy.act_decoder.* / prompt_encoder.motion_pred.* /
+ * condition_transformers.policy_decoder.*; models/base.py:141-147 load_state_dict), plus the
+ * constant tables "const.fourier_div32/64/128" (the dim_t of FourierEmbeddingFix,
+ * models/layers/fourier_embedding.py:68-69, computed by the host with the reference's ops).
+ * Replaces: ProSim.__init__/_config_models (traj_sam.py:15-57). */
+int ps_create(const ps_config* cfg, int32_t n_tensors, const char* const* names,
+              const float* const* data, const int64_t* numel, ps_engine** out);
+void ps_destroy(ps_engine* e);
+const char* ps_last_error(void);
+
+/* Upload one batch of scenes (the batch.extras the reference reads; dataset/format_utils.py:798-815).
+ *   map_input [B,M,P,map_dim], map_mask [B,M,P], map_pos [B,M,2], map_head [B,M]
+ *   obs_input [B,N,hist,obs_dim] (NaN allowed where masked), obs_mask [B,N,hist,obs_dim],
+ *   obs_pos [B,N,2], obs_head [B,N]
+ *   prompt [B,N,prompt_dim], prompt_mask [B,N], agent_type [B,N] (1..num_agent_types),
+ *   prompt_pos [B,N,2], prompt_head [B,N]
+ * Policy agents must be exactly the observed agents, slot for slot (prompt_mask == any valid
+ * history step); otherwise PS_E_ARG. */
+int ps_set_scene(ps_engine* e, int32_t B, int32_t M, int32_t P, int32_t N,
+                 const float* map_input, const uint8_t* map_mask, const float* map_pos, const float* map_head,
+                 const float* obs_input, const uint8_t* obs_mask, const float* obs_pos, const float* obs_head,
+                 const float* prompt, const uint8_t* prompt_mask, const int32_t* agent_type,
+                 const float* prompt_pos, const float* prompt_head);
+
+/* Optional unary prompt conditions (dataset/condition_utils.py:126-222): goal (gx, gy, t) and
+ * vehicle action tags (tag_id, t0, t1); *_pidx = prompt slot of each condition.  C = 0 or NULL
+ * clears that type.  Replaces the `condition` argument of ConditionTransformer.forward
+ * (models/condition_transformer/base.py:38). */
+int ps_set_conditions(ps_engine* e, int32_t C_goal, const float* goal_input, const uint8_t* goal_mask,
+                      const int32_t* goal_pidx, int32_t C_tag, const float* tag_input,
+                      const uint8_t* tag_mask, const int32_t* tag_pidx);
+
+/* Optional per-replan observation frames fut_obs[t] for replans 1..R-1
+ * (dataset/format_utils.py:667-687): input [R-1,B,N,hist,obs_dim]; only columns 8.. (extent,
+ * type, time one-hot) are used -- columns 0..7 are overwritten by step_env
+ * (traj_sam.py:266-270).  Default: the init_obs columns. */
+int ps_set_future_obs(ps_engine* e, const float* fut_input);
+
+/* scene_encoder(batch_obs, batch_map) -> token store on device (traj_sam.py:73-77;
+ * scene_encoder/base.py:31-46, attn_fusion.py:78-134). */
+int ps_encode_scene(ps_engine* e);
+/* prompt_encoder + decoder(scene_embs, prompt_enc) + condition transformer
+ * (traj_sam.py:79-142; decoder/sym_coord.py:112-140; condition_transformer/base.py:38-60). */
+int ps_generate_policy(ps_engine* e);
+/* init_agent_trajs (traj_sam.py:597-633): reset the trajectory state from init_obs. */
+int ps_reset_rollout(ps_engine* e);
+/* One iteration of rollout_batch (traj_sam.py:159-172): step_env -> decode_output (policy.forward)
+ * -> step_agent_traj, for replan index t_idx (0-based). */
+int ps_policy_step(ps_engine* e, int32_t t_idx);
+/* ProSim.forward(batch,'val') (traj_sam.py:59-71): encode + generate + all replans, enqueued on
+ * the engine's stream (replayed from a hipGraph after the first call for a given scene shape). */
+int ps_rollout(ps_engine* e);
+int ps_sync(ps_engine* e);
+
+/* Overwrite the trajectory state (test hook for open-loop parity): traj [A, steps, 4], vel
+ * [A, steps, 2] over the compact policy-agent list, `steps` = hist + t_idx*replan_freq. */
+int ps_set_state(ps_engine* e, int32_t steps, const float* traj, const float* vel);
+
+/* Copy a named result to the host.  Names / shapes (A = number of valid agents, compact,
+ * scene-major; Mv = valid polylines):
+ *   "traj" [A, max_steps, 4] (x, y, sin, cos in the agent-init frame; traj_sam.py:588)
+ *   "vel" [A, max_steps, 2]; "motion_pred" [R, A, K, target_steps, state_dim];
+ *   "reconst_pred" [A, 2]; "policy_emd" [A, hidden]; "scene_tokens" [Mv + A, hidden];
+ *   "fused" [A, hidden] (last policy step); "obs_in" [A, hist, obs_dim] (last step_env);
+ *   "edge_counts" [8] (a2a, s2s, p2p, s2p, a2p, m2p of the last step, cond, 0) as float.
+ * Returns the number of floats written, or a negative error. */
+int64_t ps_get(ps_engine* e, const char* name, float* dst, int64_t capacity);
+int32_t ps_num_agents(ps_engine* e);
+int32_t ps_num_map_tokens(ps_engine* e);
+
+/* Timing on the engine's own stream (HIP events): run `iters` rollouts after `warmup`, return
+ * average ms per rollout in *ms_rollout and, if stage_ms != NULL, per-stage averages
+ * [encode_scene, generate_policy, replan loop]. */
+int ps_time_rollout(ps_engine* e, int32_t warmup, int32_t iters, float* ms_rollout, float* stage_ms);
+/* Average duration (ms) of the dominant kernel (the fused policy attention chain) over the
+ * launches of the last ps_time_rollout / ps_rollout, measured with HIP events around each launch. */
+int ps_time_policy_kernel(ps_engine* e, int32_t iters, float* ms_kernel);
+
+/* Unit-test hooks for single primitives (parity against tests/golden/ref_pure_primitives.npz). */
+int ps_test_pointnet(ps_engine* e, int32_t which /*0 map, 1 obs*/, int32_t n_poly, int32_t P,
+                     const float* x, const uint8_t* point_mask, float* out);
+int ps_test_fourier(ps_engine* e, int32_t n, const float* x4, float* out128);
+int ps_test_wrap(ps_engine* e, int32_t n, const float* x, float* out);
+/* One AttentionLayer (models/layers/attention_layer.py:56-121) on caller-supplied tokens and a
+ * CSR-by-destination edge list; rt = relative-PE rows already LayerNorm-normalised (no affine).
+ * layer_index counts over [a2a | s2s | p2p | s2p | a2p | m2p | cond] layers; T in {0 (auto),1,2,4}. */
+int ps_test_attn(ps_engine* e, int32_t layer_index, int32_t Ns, int32_t Nd, int32_t E, const float* x_src,
+                 const float* x_dst, const float* rt, const int32_t* eoff, const int32_t* esrc, int32_t T, float* out);
+/* Read back an edge set built by the last stage: which = 0 a2a, 1 s2s, 2 p2p, 3 s2p, 4 a2p, 5 m2p. */
+int64_t ps_test_get_edges(ps_engine* e, int32_t which, int32_t* esrc, int32_t* edst, float* rt, int64_t capacity);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PROSIM_HIP_H */

@@ -1,0 +1,1133 @@
+// libprosim_hip.so -- host side of the MI355X closed-loop rollout engine + the C ABI
+// declared in include/prosim_hip.h.  gfx950 only; build: see __graft_entry__.build().
+#include "prosim_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "ps_attn.h"
+#include "ps_kernels.h"
+
+using namespace ps;
+
+static thread_local std::string g_err;
+extern "C" const char* ps_last_error(void) { return g_err.c_str(); }
+static int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+#define HIPCHK(x)                                                                                  \
+  do {                                                                                             \
+    hipError_t _e = (x);                                                                           \
+    if (_e != hipSuccess)                                                                          \
+      return fail(PS_E_HIP, std::string(#x) + ": " + hipGetErrorString(_e) + " @" + std::to_string(__LINE__)); \
+  } while (0)
+
+namespace {
+
+template <class T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  int ensure(size_t count) {
+    if (count <= n && p) return 0;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+    size_t c = std::max<size_t>(count, 16);
+    if (hipMalloc((void**)&p, c * sizeof(T)) != hipSuccess) return -1;
+    n = c;
+    return 0;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+};
+
+struct EdgeSet {  // CSR by destination + normalised rel-PE
+  DevBuf<int> cnt, eoff, esrc, edst;
+  DevBuf<float> rt;
+  size_t cap_edges = 0;
+  int nq = 0;
+  int maxdeg = 0;
+};
+
+struct Stage { float ms = 0; };
+
+}  // namespace
+
+struct ps_engine {
+  ps_config cfg{};
+  hipStream_t stream = nullptr;
+  // ---- weights
+  std::unordered_map<std::string, std::pair<const float*, int64_t>> src;  // only valid during create
+  std::vector<float> arena_h;
+  float* arena_d = nullptr;
+  std::vector<size_t*> fixups;
+  std::vector<AttnW> a2a, s2s, p2p, s2p, a2p, m2p, cnd;
+  std::vector<AttnW> all_layers;
+  AttnW* d_layers = nullptr;  // all layers, device copy (order: a2a s2s p2p s2p a2p m2p cnd)
+  int L_a2a = 0, L_s2s = 0, L_p2p = 0, L_s2p = 0, L_a2p = 0, L_m2p = 0, L_cnd = 0;
+  PointNetW pn_map{}, pn_obs{};
+  Mlp3W mlp_prompt{}, mlp_pred{};
+  HeadW head{};
+  CondW cond{};
+  const float* div32 = nullptr;
+  // ---- scene
+  bool have_scene = false, encoded = false, generated = false, reset = false;
+  int B = 0, M = 0, P = 0, N = 0, Mv = 0, A = 0;
+  int maxA_scene = 0, maxM_scene = 0;
+  std::vector<int> map_rows, agent_rows, agent_scene, map_scene, moff, aoff;  // host copies
+  DevBuf<float> d_map_input, d_obs_input, d_prompt, d_fut;
+  DevBuf<uint8_t> d_map_mask, d_obs_mask;
+  DevBuf<int> d_map_rows, d_agent_rows, d_tok_scene, d_agent_type, d_r_map, d_r_agent, d_r_zero;
+  DevBuf<float> d_tok, d_tok_pos, d_tok_ori, d_init_pos, d_init_head, d_cur_pos, d_cur_ori, d_prompt_pos, d_prompt_ori;
+  DevBuf<float> d_xp, d_emd, d_xc, d_fused, d_obs_in, d_static_in, d_kv, d_kv_s2p, d_kv_m2p, d_kv_a2p;
+  DevBuf<float> d_traj, d_vel, d_motion, d_reconst;
+  EdgeSet e_a2a, e_s2s, e_p2p, e_s2p, e_a2p, e_m2p, e_cnd;
+  DevBuf<ChainStep> d_steps;
+  std::vector<ChainStep> h_steps;
+  int step_a2a = 0, step_s2s = 0, step_dec = 0, step_cnd = 0, step_pol = 0;
+  // conditions
+  bool have_cond = false;
+  int n_cond_edges = 0;
+  DevBuf<int> d_ent_off, d_ent_type;
+  DevBuf<float> d_ent_val;
+  bool have_fut = false;
+  int stride_steps = 0;
+  // timing of the dominant kernel
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool time_chain = false;
+  double chain_ms_sum = 0;
+  int chain_launches = 0;
+  float edge_counts[8] = {0};
+};
+
+// ------------------------------------------------------------------------------------------ weights
+namespace {
+
+struct Builder {
+  ps_engine* e;
+  std::string err;
+  const float* get(const std::string& name, int64_t numel) {
+    auto it = e->src.find(name);
+    if (it == e->src.end()) {
+      if (err.empty()) err = "missing weight '" + name + "'";
+      return nullptr;
+    }
+    if (it->second.second != numel) {
+      if (err.empty())
+        err = "weight '" + name + "' has " + std::to_string(it->second.second) + " elements, expected " + std::to_string(numel);
+      return nullptr;
+    }
+    return it->second.first;
+  }
+  bool has(const std::string& name) { return e->src.count(name) != 0; }
+  // append to the host arena; returns offset (floats), 64-float aligned
+  size_t put(const std::vector<float>& v) {
+    size_t off = (e->arena_h.size() + 63) & ~size_t(63);
+    e->arena_h.resize(off + v.size());
+    std::copy(v.begin(), v.end(), e->arena_h.begin() + off);
+    return off;
+  }
+  // record a pointer slot that must be rebased onto the device arena
+  void slot(const float** p, size_t off) {
+    *p = reinterpret_cast<const float*>(off + 1);  // tag: offset+1 (0 stays nullptr)
+    ptrs.push_back(p);
+  }
+  std::vector<const float**> ptrs;
+  void plain(const float** p, const std::string& name, int64_t numel) {
+    const float* s = get(name, numel);
+    if (!s) return;
+    slot(p, put(std::vector<float>(s, s + numel)));
+  }
+  void transposed(const float** p, const std::string& name, int out, int in, int in0 = 0, int in_n = -1) {
+    // torch Linear weight [out][in] -> K-major [in_n][out] over input columns [in0, in0+in_n)
+    const float* s = get(name, (int64_t)out * in);
+    if (!s) return;
+    if (in_n < 0) in_n = in;
+    std::vector<float> t((size_t)in_n * out);
+    for (int k = 0; k < in_n; ++k)
+      for (int n = 0; n < out; ++n) t[(size_t)k * out + n] = s[(size_t)n * in + in0 + k];
+    slot(p, put(t));
+  }
+};
+
+void build_attn(Builder& b, const std::string& p, AttnW& w) {
+  std::memset(&w, 0, sizeof(w));
+  b.plain(&w.ln_src_w, p + ".attn_prenorm_x_src.weight", D);
+  b.plain(&w.ln_src_b, p + ".attn_prenorm_x_src.bias", D);
+  const std::string dn = b.has(p + ".attn_prenorm_x_dst.weight") ? ".attn_prenorm_x_dst" : ".attn_prenorm_x_src";
+  b.plain(&w.ln_dst_w, p + dn + ".weight", D);
+  b.plain(&w.ln_dst_b, p + dn + ".bias", D);
+  b.transposed(&w.Wq_t, p + ".to_q.weight", D, D);
+  b.plain(&w.bq, p + ".to_q.bias", D);
+  b.transposed(&w.Ws_t, p + ".to_s.weight", D, D);
+  b.plain(&w.bs, p + ".to_s.bias", D);
+  b.transposed(&w.Wgx_t, p + ".to_g.weight", D, 2 * D, D, D);
+  b.transposed(&w.Wga_t, p + ".to_g.weight", D, 2 * D, 0, D);
+  b.plain(&w.bg, p + ".to_g.bias", D);
+  b.transposed(&w.Wout_t, p + ".to_out.weight", D, D);
+  b.plain(&w.bout, p + ".to_out.bias", D);
+  b.plain(&w.ln_post_w, p + ".attn_postnorm.weight", D);
+  b.plain(&w.ln_post_b, p + ".attn_postnorm.bias", D);
+  b.plain(&w.ln_ffpre_w, p + ".ff_prenorm.weight", D);
+  b.plain(&w.ln_ffpre_b, p + ".ff_prenorm.bias", D);
+  b.plain(&w.ln_ffpost_w, p + ".ff_postnorm.weight", D);
+  b.plain(&w.ln_ffpost_b, p + ".ff_postnorm.bias", D);
+  b.transposed(&w.W1_t, p + ".ff_mlp.0.weight", FF, D);
+  b.plain(&w.b1, p + ".ff_mlp.0.bias", FF);
+  b.transposed(&w.W2_t, p + ".ff_mlp.3.weight", D, FF);
+  b.plain(&w.b2, p + ".ff_mlp.3.bias", D);
+  // folds of the relative-PE LayerNorm affine into to_k_r / to_v_r
+  const float* g = b.get(p + ".attn_prenorm_r.weight", D);
+  const float* be = b.get(p + ".attn_prenorm_r.bias", D);
+  const float* wkr = b.get(p + ".to_k_r.weight", (int64_t)D * D);
+  const float* wvr = b.get(p + ".to_v_r.weight", (int64_t)D * D);
+  const float* bvr = b.get(p + ".to_v_r.bias", D);
+  const float* wk = b.get(p + ".to_k.weight", (int64_t)D * D);
+  const float* wv = b.get(p + ".to_v.weight", (int64_t)D * D);
+  const float* bv = b.get(p + ".to_v.bias", D);
+  if (!g || !be || !wkr || !wvr || !bvr || !wk || !wv || !bv) return;
+  std::vector<float> wkrg((size_t)D * D), kb(D), wvrgt((size_t)D * D), vb(D), wkv((size_t)D * 2 * D), bkv(2 * D, 0.f);
+  for (int hd = 0; hd < D; ++hd) {
+    double sk = 0, sv = 0;
+    for (int c = 0; c < D; ++c) {
+      wkrg[(size_t)hd * D + c] = wkr[(size_t)hd * D + c] * g[c];
+      wvrgt[(size_t)c * D + hd] = wvr[(size_t)hd * D + c] * g[c];
+      sk += (double)wkr[(size_t)hd * D + c] * be[c];
+      sv += (double)wvr[(size_t)hd * D + c] * be[c];
+    }
+    kb[hd] = (float)sk;
+    vb[hd] = (float)(sv + bvr[hd]);
+    bkv[D + hd] = bv[hd];
+    for (int k = 0; k < D; ++k) {
+      wkv[(size_t)k * 2 * D + hd] = wk[(size_t)hd * D + k];
+      wkv[(size_t)k * 2 * D + D + hd] = wv[(size_t)hd * D + k];
+    }
+  }
+  b.slot(&w.Wkr_g, b.put(wkrg));
+  b.slot(&w.kb, b.put(kb));
+  b.slot(&w.Wvr_gt, b.put(wvrgt));
+  b.slot(&w.vb, b.put(vb));
+  b.slot(&w.Wkv_t, b.put(wkv));
+  b.slot(&w.bkv, b.put(bkv));
+}
+
+// sequential indices of the reference MLP's nn.Sequential (models/layers/mlp.py:475-494)
+std::vector<std::pair<int, int>> mlp_seq(int n_lin, bool without_norm) {
+  std::vector<std::pair<int, int>> r;
+  int idx = 0;
+  for (int i = 0; i < n_lin; ++i) {
+    int lin = idx++, ln = -1;
+    if (i < n_lin - 1) {
+      if (!without_norm) ln = idx++;
+      idx++;  // ReLU
+    }
+    r.push_back({lin, ln});
+  }
+  return r;
+}
+
+void build_pointnet(Builder& b, const std::string& p, int in_dim, int n_pre, int n_mlp, PointNetW& w) {
+  std::memset(&w, 0, sizeof(w));
+  w.in_dim = in_dim;
+  w.n_pre = n_pre;
+  w.n_mid = n_mlp - n_pre;
+  auto sq = mlp_seq(n_pre, false);
+  for (int l = 0; l < n_pre; ++l) {
+    const int K = l == 0 ? in_dim : D;
+    const std::string q = p + ".pre_mlps.mlp." + std::to_string(sq[l].first);
+    b.transposed(&w.pre_Wt[l], q + ".weight", D, K);
+    b.plain(&w.pre_b[l], q + ".bias", D);
+    if (sq[l].second >= 0) {
+      const std::string n = p + ".pre_mlps.mlp." + std::to_string(sq[l].second);
+      b.plain(&w.pre_lnw[l], n + ".weight", D);
+      b.plain(&w.pre_lnb[l], n + ".bias", D);
+    }
+  }
+  sq = mlp_seq(w.n_mid, false);
+  for (int l = 0; l < w.n_mid; ++l) {
+    const int K = l == 0 ? 2 * D : D;
+    const std::string q = p + ".mlps.mlp." + std::to_string(sq[l].first);
+    b.transposed(&w.mid_Wt[l], q + ".weight", D, K);
+    b.plain(&w.mid_b[l], q + ".bias", D);
+    if (sq[l].second >= 0) {
+      const std::string n = p + ".mlps.mlp." + std::to_string(sq[l].second);
+      b.plain(&w.mid_lnw[l], n + ".weight", D);
+      b.plain(&w.mid_lnb[l], n + ".bias", D);
+    }
+  }
+  b.transposed(&w.out_W0t, p + ".out_mlps.mlp.0.weight", D, D);
+  b.plain(&w.out_b0, p + ".out_mlps.mlp.0.bias", D);
+  b.transposed(&w.out_W1t, p + ".out_mlps.mlp.2.weight", D, D);
+  b.plain(&w.out_b1, p + ".out_mlps.mlp.2.bias", D);
+}
+
+void build_mlp3(Builder& b, const std::string& p, std::vector<int> dims, bool without_norm, Mlp3W& m) {
+  std::memset(&m, 0, sizeof(m));
+  m.n = (int)dims.size() - 1;
+  for (size_t i = 0; i < dims.size(); ++i) m.dims[i] = dims[i];
+  auto sq = mlp_seq(m.n, without_norm);
+  for (int l = 0; l < m.n; ++l) {
+    const std::string q = p + ".mlp." + std::to_string(sq[l].first);
+    b.plain(&m.W[l], q + ".weight", (int64_t)dims[l + 1] * dims[l]);
+    b.plain(&m.b[l], q + ".bias", dims[l + 1]);
+    if (sq[l].second >= 0) {
+      const std::string n = p + ".mlp." + std::to_string(sq[l].second);
+      b.plain(&m.lnw[l], n + ".weight", dims[l + 1]);
+      b.plain(&m.lnb[l], n + ".bias", dims[l + 1]);
+    }
+  }
+}
+
+const char* kTagNames[11] = {"Stopping", "Accelerate", "Decelerate", "KeepSpeed", "LeftLaneChange", "RightLaneChange",
+                             "KeepLane", "LeftTurn", "RightTurn", "Straight", "Parked"};
+
+}  // namespace
+
+extern "C" int ps_create(const ps_config* cfg, int32_t n_tensors, const char* const* names, const float* const* data,
+                         const int64_t* numel, ps_engine** out) {
+  if (!cfg || !out) return fail(PS_E_ARG, "null argument");
+  if (cfg->hidden != D || cfg->heads != H || cfg->head_dim != DH)
+    return fail(PS_E_ARG, "this build supports hidden=128, heads=8, head_dim=16 only");
+  if (cfg->hist_steps > 15 || cfg->obs_dim > 24 || cfg->map_dim > 24 || cfg->motion_k != 1 || cfg->state_dim < 5 ||
+      cfg->target_steps * cfg->state_dim > 128 || cfg->map_pre_layers > 4 || cfg->obs_pre_layers > 4 ||
+      cfg->map_mlp_layers - cfg->map_pre_layers > 4 || cfg->obs_mlp_layers - cfg->obs_pre_layers > 4)
+    return fail(PS_E_ARG, "unsupported config (hist<=15, obs_dim<=24, map_dim<=24, motion_k==1, steps*state<=128)");
+  if (hipSetDevice(cfg->device) != hipSuccess) return fail(PS_E_HIP, "hipSetDevice failed (no GPU?)");
+  ps_engine* e = new ps_engine();
+  e->cfg = *cfg;
+  for (int i = 0; i < n_tensors; ++i) e->src[names[i]] = {data[i], numel[i]};
+  Builder b{e};
+  auto layers = [&](const std::string& pre, int n, std::vector<AttnW>& v) {
+    v.resize(n);
+    for (int i = 0; i < n; ++i) build_attn(b, pre + "." + std::to_string(i), v[i]);
+  };
+  layers("scene_encoder.a2a_attn_layers", cfg->scene_layers, e->a2a);
+  layers("scene_encoder.s2s_attn_layers", cfg->scene_layers, e->s2s);
+  layers("decoder.p2p_attn_layers", cfg->dec_layers, e->p2p);
+  layers("decoder.s2p_attn_layers", cfg->dec_layers, e->s2p);
+  layers("policy.act_decoder.a2p_attn_layers", cfg->pol_layers, e->a2p);
+  layers("policy.act_decoder.m2p_attn_layers", cfg->pol_layers, e->m2p);
+  layers("condition_transformers.policy_decoder.condition_attn.attn_layers", cfg->cond_layers, e->cnd);
+  build_pointnet(b, "scene_encoder.map_encoder", cfg->map_dim, cfg->map_pre_layers, cfg->map_mlp_layers, e->pn_map);
+  build_pointnet(b, "scene_encoder.obs_encoder", cfg->obs_dim, cfg->obs_pre_layers, cfg->obs_mlp_layers, e->pn_obs);
+  build_mlp3(b, "prompt_encoder.motion_pred.state_encoder", {cfg->prompt_dim, D, D}, false, e->mlp_prompt);
+  const std::string pa = "policy.act_decoder";
+  build_mlp3(b, pa + ".pred_mlp", {D, D, D / 2, 2}, false, e->mlp_pred);
+  build_mlp3(b, pa + ".motion_head", {D, D, D / 2, cfg->target_steps * cfg->state_dim}, false, e->head.motion);
+  b.plain(&e->head.anchors, pa + ".motion_anchors.weight", (int64_t)cfg->motion_k * cfg->num_agent_types * D);
+  for (int i = 0; i < 3; ++i) {
+    const std::string q = pa + ".CG_decode.CGs." + std::to_string(i) + ".MLP.";
+    b.plain(&e->head.cgW[i], q + "0.weight", (int64_t)D * D);
+    b.plain(&e->head.cgb[i], q + "0.bias", D);
+    b.plain(&e->head.cglnw[i], q + "1.weight", D);
+    b.plain(&e->head.cglnb[i], q + "1.bias", D);
+  }
+  const std::string ct = "condition_transformers.policy_decoder.condition_encoders";
+  build_mlp3(b, ct + ".goal.goal_encoder", {2, D, D}, true, e->cond.goal);
+  {
+    std::vector<float> tags((size_t)11 * D, 0.f);
+    for (int t = 0; t < 11; ++t) {
+      const float* s = b.get(ct + ".v_action_tag.tag_encoder." + kTagNames[t], D);
+      if (s) std::copy(s, s + D, tags.begin() + (size_t)t * D);
+    }
+    b.slot(&e->cond.tag_emb, b.put(tags));
+  }
+  b.plain(&e->cond.div32, "const.fourier_div32", 32);
+  b.plain(&e->cond.div64, "const.fourier_div64", 64);
+  b.plain(&e->cond.div128, "const.fourier_div128", 128);
+  if (!b.err.empty()) {
+    delete e;
+    return fail(PS_E_WEIGHT, b.err);
+  }
+  // upload the arena and rebase every recorded pointer slot
+  const size_t nfl = e->arena_h.size();
+  if (hipMalloc((void**)&e->arena_d, nfl * sizeof(float)) != hipSuccess) {
+    delete e;
+    return fail(PS_E_HIP, "hipMalloc(weights) failed");
+  }
+  if (hipMemcpy(e->arena_d, e->arena_h.data(), nfl * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+    delete e;
+    return fail(PS_E_HIP, "hipMemcpy(weights) failed");
+  }
+  for (const float** p : b.ptrs) {
+    const size_t off = reinterpret_cast<size_t>(*p) - 1;
+    *p = e->arena_d + off;
+  }
+  e->div32 = e->cond.div32;
+  e->src.clear();
+  // device copy of all attention layers for the kv-projection kernel
+  std::vector<AttnW> all;
+  auto add = [&](std::vector<AttnW>& v, int& base) {
+    base = (int)all.size();
+    all.insert(all.end(), v.begin(), v.end());
+  };
+  add(e->a2a, e->L_a2a);
+  add(e->s2s, e->L_s2s);
+  add(e->p2p, e->L_p2p);
+  add(e->s2p, e->L_s2p);
+  add(e->a2p, e->L_a2p);
+  add(e->m2p, e->L_m2p);
+  add(e->cnd, e->L_cnd);
+  e->all_layers = all;
+  if (hipMalloc((void**)&e->d_layers, std::max<size_t>(1, all.size()) * sizeof(AttnW)) != hipSuccess ||
+      hipMemcpy(e->d_layers, all.data(), all.size() * sizeof(AttnW), hipMemcpyHostToDevice) != hipSuccess) {
+    delete e;
+    return fail(PS_E_HIP, "layer table upload failed");
+  }
+  if (hipStreamCreate(&e->stream) != hipSuccess || hipEventCreate(&e->ev0) != hipSuccess ||
+      hipEventCreate(&e->ev1) != hipSuccess) {
+    delete e;
+    return fail(PS_E_HIP, "stream/event creation failed");
+  }
+  // the chain kernel may use up to ~140 KiB of dynamic LDS
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_chain<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_chain<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_chain<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  *out = e;
+  return PS_OK;
+}
+
+extern "C" void ps_destroy(ps_engine* e) {
+  if (!e) return;
+  (void)hipSetDevice(e->cfg.device);
+  (void)hipDeviceSynchronize();
+  // DevBuf members are plain structs without destructors: release explicitly
+  e->d_map_input.release(); e->d_obs_input.release(); e->d_prompt.release(); e->d_fut.release();
+  e->d_map_mask.release(); e->d_obs_mask.release();
+  e->d_map_rows.release(); e->d_agent_rows.release(); e->d_tok_scene.release(); e->d_agent_type.release();
+  e->d_r_map.release(); e->d_r_agent.release(); e->d_r_zero.release();
+  e->d_tok.release(); e->d_tok_pos.release(); e->d_tok_ori.release(); e->d_init_pos.release(); e->d_init_head.release();
+  e->d_cur_pos.release(); e->d_cur_ori.release(); e->d_prompt_pos.release(); e->d_prompt_ori.release();
+  e->d_xp.release(); e->d_emd.release(); e->d_xc.release(); e->d_fused.release(); e->d_obs_in.release();
+  e->d_static_in.release(); e->d_kv.release(); e->d_kv_s2p.release(); e->d_kv_m2p.release(); e->d_kv_a2p.release();
+  e->d_traj.release(); e->d_vel.release(); e->d_motion.release(); e->d_reconst.release();
+  for (EdgeSet* s : {&e->e_a2a, &e->e_s2s, &e->e_p2p, &e->e_s2p, &e->e_a2p, &e->e_m2p, &e->e_cnd}) {
+    s->cnt.release(); s->eoff.release(); s->esrc.release(); s->edst.release(); s->rt.release();
+  }
+  e->d_steps.release(); e->d_ent_off.release(); e->d_ent_type.release(); e->d_ent_val.release();
+  if (e->arena_d) (void)hipFree(e->arena_d);
+  if (e->d_layers) (void)hipFree(e->d_layers);
+  if (e->ev0) (void)hipEventDestroy(e->ev0);
+  if (e->ev1) (void)hipEventDestroy(e->ev1);
+  if (e->stream) (void)hipStreamDestroy(e->stream);
+  delete e;
+}
+
+// ------------------------------------------------------------------------------------------ scene upload
+namespace {
+
+template <class T>
+int upload(DevBuf<T>& b, const T* h, size_t n, hipStream_t s) {
+  if (b.ensure(n)) return -1;
+  if (n == 0) return 0;
+  return hipMemcpyAsync(b.p, h, n * sizeof(T), hipMemcpyHostToDevice, s) == hipSuccess ? 0 : -1;
+}
+
+int edge_alloc(EdgeSet& s, int nq, size_t cap_edges, int maxdeg) {
+  s.nq = nq;
+  s.cap_edges = cap_edges;
+  s.maxdeg = std::max(1, maxdeg);
+  if (s.cnt.ensure(nq + 1) || s.eoff.ensure(nq + 1) || s.esrc.ensure(cap_edges + 1) || s.edst.ensure(cap_edges + 1) ||
+      s.rt.ensure((cap_edges + 1) * 128))
+    return -1;
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int ps_set_scene(ps_engine* e, int32_t B, int32_t M, int32_t P, int32_t N, const float* map_input,
+                            const uint8_t* map_mask, const float* map_pos, const float* map_head, const float* obs_input,
+                            const uint8_t* obs_mask, const float* obs_pos, const float* obs_head, const float* prompt,
+                            const uint8_t* prompt_mask, const int32_t* agent_type, const float* prompt_pos,
+                            const float* prompt_head) {
+  if (!e) return fail(PS_E_ARG, "null engine");
+  if (B < 1 || M < 1 || N < 1 || P < 1 || P > 32) return fail(PS_E_ARG, "need B,M,N >= 1 and 1 <= P <= 32");
+  const ps_config& c = e->cfg;
+  HIPCHK(hipSetDevice(c.device));
+  const int Hs = c.hist_steps, Od = c.obs_dim;
+  e->B = B; e->M = M; e->P = P; e->N = N;
+  e->map_rows.clear(); e->agent_rows.clear(); e->agent_scene.clear(); e->map_scene.clear();
+  e->moff.assign(B + 1, 0); e->aoff.assign(B + 1, 0);
+  e->maxA_scene = e->maxM_scene = 0;
+  for (int b = 0; b < B; ++b) {
+    for (int m = 0; m < M; ++m) {
+      bool any = false;
+      for (int p = 0; p < P; ++p) any |= map_mask[((size_t)b * M + m) * P + p] != 0;
+      if (any) { e->map_rows.push_back(b * M + m); e->map_scene.push_back(b); }
+    }
+    e->moff[b + 1] = (int)e->map_rows.size();
+    for (int n = 0; n < N; ++n) {
+      bool any = false;
+      for (int s = 0; s < Hs && !any; ++s) {
+        bool all = true;
+        const uint8_t* mk = obs_mask + (((size_t)b * N + n) * Hs + s) * Od;
+        for (int f = 0; f < Od; ++f) all &= mk[f] != 0;
+        any |= all;
+      }
+      if (any != (prompt_mask[(size_t)b * N + n] != 0))
+        return fail(PS_E_ARG, "policy agents must be exactly the observed agents (scene " + std::to_string(b) + ", slot " +
+                                  std::to_string(n) + ")");
+      if (any) {
+        const int ty = agent_type[(size_t)b * N + n];
+        if (ty < 1 || ty > c.num_agent_types) return fail(PS_E_ARG, "agent_type outside 1..num_agent_types");
+        e->agent_rows.push_back(b * N + n);
+        e->agent_scene.push_back(b);
+      }
+    }
+    e->aoff[b + 1] = (int)e->agent_rows.size();
+    e->maxA_scene = std::max(e->maxA_scene, e->aoff[b + 1] - e->aoff[b]);
+    e->maxM_scene = std::max(e->maxM_scene, e->moff[b + 1] - e->moff[b]);
+  }
+  const int Mv = e->Mv = (int)e->map_rows.size();
+  const int A = e->A = (int)e->agent_rows.size();
+  if (A == 0) return fail(PS_E_ARG, "no valid agents");
+  hipStream_t st = e->stream;
+  // raw inputs
+  if (upload(e->d_map_input, map_input, (size_t)B * M * P * c.map_dim, st) || upload(e->d_map_mask, map_mask, (size_t)B * M * P, st) ||
+      upload(e->d_obs_input, obs_input, (size_t)B * N * Hs * Od, st) || upload(e->d_obs_mask, obs_mask, (size_t)B * N * Hs * Od, st) ||
+      upload(e->d_prompt, prompt, (size_t)B * N * c.prompt_dim, st) || upload(e->d_map_rows, e->map_rows.data(), (size_t)Mv, st) ||
+      upload(e->d_agent_rows, e->agent_rows.data(), (size_t)A, st))
+    return fail(PS_E_HIP, "input upload failed");
+  // compact token geometry: [map tokens ; agent tokens], scene-major inside each part
+  std::vector<float> pos((size_t)(Mv + A) * 2), ori(Mv + A), ipos((size_t)A * 2), ihead(A), ppos((size_t)A * 2), pori(A);
+  std::vector<int> scene(Mv + A), atype(A);
+  for (int i = 0; i < Mv; ++i) {
+    pos[2 * i] = map_pos[2 * (size_t)e->map_rows[i]];
+    pos[2 * i + 1] = map_pos[2 * (size_t)e->map_rows[i] + 1];
+    ori[i] = map_head[e->map_rows[i]];
+    scene[i] = e->map_scene[i];
+  }
+  for (int i = 0; i < A; ++i) {
+    const size_t r = e->agent_rows[i];
+    pos[2 * (Mv + i)] = ipos[2 * i] = obs_pos[2 * r];
+    pos[2 * (Mv + i) + 1] = ipos[2 * i + 1] = obs_pos[2 * r + 1];
+    ori[Mv + i] = ihead[i] = obs_head[r];
+    ppos[2 * i] = prompt_pos ? prompt_pos[2 * r] : obs_pos[2 * r];
+    ppos[2 * i + 1] = prompt_pos ? prompt_pos[2 * r + 1] : obs_pos[2 * r + 1];
+    pori[i] = prompt_head ? prompt_head[r] : obs_head[r];
+    scene[Mv + i] = e->agent_scene[i];
+    atype[i] = agent_type[r];
+  }
+  std::vector<int> r_map(B + 1), r_agent(B + 1), r_zero(B + 1, 0);
+  for (int b = 0; b <= B; ++b) { r_map[b] = e->moff[b]; r_agent[b] = Mv + e->aoff[b]; }
+  if (upload(e->d_tok_pos, pos.data(), pos.size(), st) || upload(e->d_tok_ori, ori.data(), ori.size(), st) ||
+      upload(e->d_init_pos, ipos.data(), ipos.size(), st) || upload(e->d_init_head, ihead.data(), ihead.size(), st) ||
+      upload(e->d_prompt_pos, ppos.data(), ppos.size(), st) || upload(e->d_prompt_ori, pori.data(), pori.size(), st) ||
+      e->d_cur_pos.ensure(ppos.size()) || e->d_cur_ori.ensure(pori.size()) ||
+      upload(e->d_tok_scene, scene.data(), scene.size(), st) || upload(e->d_agent_type, atype.data(), atype.size(), st) ||
+      upload(e->d_r_map, r_map.data(), r_map.size(), st) || upload(e->d_r_agent, r_agent.data(), r_agent.size(), st) ||
+      upload(e->d_r_zero, r_zero.data(), r_zero.size(), st))
+    return fail(PS_E_HIP, "geometry upload failed");
+  // static observation columns (extent, type, time one-hot) default to init_obs
+  {
+    std::vector<float> stat((size_t)A * Hs * Od);
+    for (int i = 0; i < A; ++i)
+      std::memcpy(&stat[(size_t)i * Hs * Od], obs_input + (size_t)e->agent_rows[i] * Hs * Od, sizeof(float) * Hs * Od);
+    if (upload(e->d_static_in, stat.data(), stat.size(), st)) return fail(PS_E_HIP, "static obs upload failed");
+  }
+  e->have_fut = false;
+  const int R = (c.max_steps + c.replan_freq - 1) / c.replan_freq;
+  e->stride_steps = Hs + R * c.replan_freq;
+  const int L6 = std::max({c.scene_layers, c.dec_layers, c.pol_layers, c.cond_layers, 1});
+  if (e->d_tok.ensure((size_t)(Mv + A) * D) || e->d_xp.ensure((size_t)A * D) || e->d_emd.ensure((size_t)A * D) ||
+      e->d_xc.ensure((size_t)A * D) || e->d_fused.ensure((size_t)A * D) || e->d_obs_in.ensure((size_t)A * Hs * Od) ||
+      e->d_kv.ensure((size_t)(Mv + A) * 256) || e->d_kv_s2p.ensure((size_t)L6 * (Mv + A) * 256) ||
+      e->d_kv_m2p.ensure((size_t)L6 * std::max(Mv, 1) * 256) || e->d_kv_a2p.ensure((size_t)L6 * A * 256) ||
+      e->d_traj.ensure((size_t)A * e->stride_steps * 4) || e->d_vel.ensure((size_t)A * e->stride_steps * 2) ||
+      e->d_motion.ensure((size_t)R * A * c.target_steps * c.state_dim) || e->d_reconst.ensure((size_t)A * 2))
+    return fail(PS_E_HIP, "device allocation failed");
+  // ---- edge sets: capacities from worst-case degrees
+  auto mn = [](int a, int b) { return a < b ? a : b; };
+  const int tokS = e->maxA_scene + e->maxM_scene;
+  int d_a2a = mn(c.agent_knn, e->maxA_scene), d_s2s = mn(c.scene_knn, tokS);
+  int d_p2p = mn(c.dec_max_neigh, std::max(1, e->maxA_scene - 1)), d_s2p = mn(c.dec_max_neigh, tokS);
+  int d_a2p = mn(c.pol_max_neigh, e->maxA_scene), d_m2p = mn(c.pol_max_neigh, std::max(1, e->maxM_scene));
+  if (edge_alloc(e->e_a2a, A, (size_t)A * d_a2a, d_a2a) || edge_alloc(e->e_s2s, Mv + A, (size_t)(Mv + A) * d_s2s, d_s2s) ||
+      edge_alloc(e->e_p2p, A, (size_t)A * d_p2p, d_p2p) || edge_alloc(e->e_s2p, A, (size_t)A * d_s2p, d_s2p) ||
+      edge_alloc(e->e_a2p, A, (size_t)A * d_a2p, d_a2p) || edge_alloc(e->e_m2p, A, (size_t)A * d_m2p, d_m2p) ||
+      edge_alloc(e->e_cnd, A, (size_t)A, 1))
+    return fail(PS_E_HIP, "edge allocation failed");
+  // closed-form CSR offsets of the knn graphs (every query gets min(k, scene size) neighbours)
+  {
+    std::vector<int> off(A + 1, 0);
+    for (int i = 0; i < A; ++i) {
+      const int b = e->agent_scene[i];
+      off[i + 1] = off[i] + mn(c.agent_knn, e->aoff[b + 1] - e->aoff[b]);
+    }
+    if (upload(e->e_a2a.eoff, off.data(), off.size(), st)) return fail(PS_E_HIP, "upload failed");
+    e->edge_counts[0] = (float)off[A];
+    std::vector<int> off2(Mv + A + 1, 0);
+    for (int i = 0; i < Mv + A; ++i) {
+      const int b = scene[i];
+      const int ns = (e->aoff[b + 1] - e->aoff[b]) + (e->moff[b + 1] - e->moff[b]);
+      off2[i + 1] = off2[i] + mn(c.scene_knn, ns);
+    }
+    if (upload(e->e_s2s.eoff, off2.data(), off2.size(), st)) return fail(PS_E_HIP, "upload failed");
+    e->edge_counts[1] = (float)off2[Mv + A];
+  }
+  // ---- chain step tables (device pointers are stable until the next ps_set_scene)
+  e->h_steps.clear();
+  auto push = [&](const AttnW& w, const float* kv, EdgeSet& es) {
+    ChainStep s;
+    s.w = w;
+    s.kv = kv;
+    s.eoff = es.eoff.p;
+    s.esrc = es.esrc.p;
+    s.rt = es.rt.p;
+    e->h_steps.push_back(s);
+  };
+  e->step_a2a = (int)e->h_steps.size();
+  for (int i = 0; i < c.scene_layers; ++i) push(e->a2a[i], e->d_kv.p, e->e_a2a);
+  e->step_s2s = (int)e->h_steps.size();
+  for (int i = 0; i < c.scene_layers; ++i) push(e->s2s[i], e->d_kv.p, e->e_s2s);
+  e->step_dec = (int)e->h_steps.size();
+  for (int i = 0; i < c.dec_layers; ++i) {
+    push(e->p2p[i], e->d_kv.p, e->e_p2p);
+    push(e->s2p[i], e->d_kv_s2p.p + (size_t)i * (Mv + A) * 256, e->e_s2p);
+  }
+  e->step_cnd = (int)e->h_steps.size();
+  for (int i = 0; i < c.cond_layers; ++i) push(e->cnd[i], e->d_kv.p, e->e_cnd);
+  e->step_pol = (int)e->h_steps.size();
+  for (int i = 0; i < c.pol_layers; ++i) {
+    // a2p edges carry GLOBAL agent rows (Mv + j); the kv buffer is agent-local -> bias the base by -Mv rows
+    push(e->a2p[i], e->d_kv_a2p.p + (size_t)i * A * 256 - (size_t)Mv * 256, e->e_a2p);
+    push(e->m2p[i], e->d_kv_m2p.p + (size_t)i * Mv * 256, e->e_m2p);
+  }
+  if (upload(e->d_steps, e->h_steps.data(), e->h_steps.size(), st)) return fail(PS_E_HIP, "step table upload failed");
+  // no conditions until ps_set_conditions
+  e->have_cond = false;
+  e->n_cond_edges = 0;
+  HIPCHK(hipStreamSynchronize(st));
+  e->have_scene = true;
+  e->encoded = e->generated = e->reset = false;
+  // keep host copies the later stages need
+  return PS_OK;
+}
+
+extern "C" int ps_set_conditions(ps_engine* e, int32_t C_goal, const float* goal_input, const uint8_t* goal_mask,
+                                 const int32_t* goal_pidx, int32_t C_tag, const float* tag_input, const uint8_t* tag_mask,
+                                 const int32_t* tag_pidx) {
+  if (!e || !e->have_scene) return fail(PS_E_STATE, "ps_set_conditions before ps_set_scene");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  const int A = e->A, N = e->N;
+  std::vector<std::vector<std::pair<std::pair<int, int>, const float*>>> per(A);
+  // slot -> compact agent index
+  std::vector<int> slot2a((size_t)e->B * N, -1);
+  for (int i = 0; i < A; ++i) slot2a[e->agent_rows[i]] = i;
+  for (int b = 0; b < e->B; ++b) {
+    for (int c = 0; c < C_goal && goal_input; ++c) {
+      const size_t i = (size_t)b * C_goal + c;
+      if (!goal_mask[i]) continue;
+      const int n = goal_pidx[i];
+      if (n < 0 || n >= N || slot2a[(size_t)b * N + n] < 0) return fail(PS_E_ARG, "goal condition on an invalid prompt slot");
+      per[slot2a[(size_t)b * N + n]].push_back({{0, 0}, goal_input + 3 * i});
+    }
+    for (int c = 0; c < C_tag && tag_input; ++c) {
+      const size_t i = (size_t)b * C_tag + c;
+      if (!tag_mask[i]) continue;
+      const int tag = (int)tag_input[3 * i];
+      if (tag < 0 || tag > 10) continue;  // not a V_Action tag value: no entry (condition_encoders.py:94)
+      const int n = tag_pidx[i];
+      if (n < 0 || n >= N || slot2a[(size_t)b * N + n] < 0) return fail(PS_E_ARG, "tag condition on an invalid prompt slot");
+      per[slot2a[(size_t)b * N + n]].push_back({{1, tag}, tag_input + 3 * i});
+    }
+  }
+  std::vector<int> eoff(A + 1, 0), esrc, ent_off(1, 0), ent_type;
+  std::vector<float> ent_val;
+  for (int a = 0; a < A; ++a) {
+    if (!per[a].empty()) {
+      esrc.push_back(a);
+      for (auto& en : per[a]) {
+        ent_type.push_back(en.first.first);
+        ent_type.push_back(en.first.second);
+        ent_val.insert(ent_val.end(), en.second, en.second + 3);
+      }
+      ent_off.push_back((int)ent_type.size() / 2);
+    }
+    eoff[a + 1] = (int)esrc.size();
+  }
+  e->n_cond_edges = (int)esrc.size();
+  e->have_cond = e->n_cond_edges > 0;
+  e->edge_counts[6] = (float)e->n_cond_edges;
+  hipStream_t st = e->stream;
+  if (upload(e->e_cnd.eoff, eoff.data(), eoff.size(), st) || upload(e->e_cnd.esrc, esrc.data(), esrc.size(), st) ||
+      upload(e->d_ent_off, ent_off.data(), ent_off.size(), st) || upload(e->d_ent_type, ent_type.data(), ent_type.size(), st) ||
+      upload(e->d_ent_val, ent_val.data(), ent_val.size(), st))
+    return fail(PS_E_HIP, "condition upload failed");
+  HIPCHK(hipStreamSynchronize(st));
+  e->generated = false;
+  return PS_OK;
+}
+
+extern "C" int ps_set_future_obs(ps_engine* e, const float* fut_input) {
+  if (!e || !e->have_scene) return fail(PS_E_STATE, "ps_set_future_obs before ps_set_scene");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  const ps_config& c = e->cfg;
+  const int R = (c.max_steps + c.replan_freq - 1) / c.replan_freq;
+  const size_t per = (size_t)e->A * c.hist_steps * c.obs_dim;
+  if (!fut_input || R < 2) { e->have_fut = false; return PS_OK; }
+  std::vector<float> comp((size_t)(R - 1) * per);
+  const size_t frame = (size_t)e->B * e->N * c.hist_steps * c.obs_dim, arow = (size_t)c.hist_steps * c.obs_dim;
+  for (int r = 0; r < R - 1; ++r)
+    for (int i = 0; i < e->A; ++i)
+      std::memcpy(&comp[(size_t)r * per + i * arow], fut_input + r * frame + (size_t)e->agent_rows[i] * arow, sizeof(float) * arow);
+  if (upload(e->d_fut, comp.data(), comp.size(), e->stream)) return fail(PS_E_HIP, "fut upload failed");
+  HIPCHK(hipStreamSynchronize(e->stream));
+  e->have_fut = true;
+  return PS_OK;
+}
+
+// ------------------------------------------------------------------------------------------ launches
+namespace {
+
+int launch_chain(ps_engine* e, float* x, int Nd, int step0, int nsteps, int maxdeg, bool timed = false,
+                 const ChainStep* steps_override = nullptr, int force_T = 0) {
+  const ChainStep* steps = steps_override ? steps_override : e->d_steps.p + step0;
+  hipStream_t st = e->stream;
+  // rows per workgroup: fill the 256 CUs when there are enough destinations; LDS must fit
+  int T = Nd >= 1024 ? 4 : (Nd >= 512 ? 2 : 1);
+  while (T > 1 && (T == 4 ? attn_lds_floats<4>(maxdeg) : attn_lds_floats<2>(maxdeg)) * sizeof(float) > 150 * 1024) T >>= 1;
+  if (force_T) T = force_T;
+  if (attn_lds_floats<1>(maxdeg) * sizeof(float) > 150 * 1024) return fail(PS_E_ARG, "degree bound too large for LDS");
+  const float eps = e->cfg.ln_eps;
+  if (timed && e->time_chain) (void)hipEventRecord(e->ev0, st);
+  if (T == 4)
+    hipLaunchKernelGGL(k_attn_chain<4>, dim3((Nd + 3) / 4), dim3(WG), attn_lds_floats<4>(maxdeg) * sizeof(float), st, x, Nd, steps, nsteps, maxdeg, eps);
+  else if (T == 2)
+    hipLaunchKernelGGL(k_attn_chain<2>, dim3((Nd + 1) / 2), dim3(WG), attn_lds_floats<2>(maxdeg) * sizeof(float), st, x, Nd, steps, nsteps, maxdeg, eps);
+  else
+    hipLaunchKernelGGL(k_attn_chain<1>, dim3(Nd), dim3(WG), attn_lds_floats<1>(maxdeg) * sizeof(float), st, x, Nd, steps, nsteps, maxdeg, eps);
+  if (timed && e->time_chain) {
+    (void)hipEventRecord(e->ev1, st);
+    (void)hipEventSynchronize(e->ev1);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e->ev0, e->ev1);
+    e->chain_ms_sum += ms;
+    e->chain_launches++;
+  }
+  return hipGetLastError() == hipSuccess ? 0 : fail(PS_E_HIP, "k_attn_chain launch failed");
+}
+
+void launch_kv(ps_engine* e, const float* x, int Ns, int layer0, int nlayers, float* kv, size_t layer_stride) {
+  if (Ns <= 0 || nlayers <= 0) return;
+  const int T = Ns >= 1024 ? 4 : (Ns >= 512 ? 2 : 1);
+  const AttnW* L = e->d_layers + layer0;
+  if (T == 4)
+    hipLaunchKernelGGL(k_kv_proj<4>, dim3((Ns + 3) / 4, nlayers), dim3(WG), 0, e->stream, x, Ns, L, kv, layer_stride, e->cfg.ln_eps);
+  else if (T == 2)
+    hipLaunchKernelGGL(k_kv_proj<2>, dim3((Ns + 1) / 2, nlayers), dim3(WG), 0, e->stream, x, Ns, L, kv, layer_stride, e->cfg.ln_eps);
+  else
+    hipLaunchKernelGGL(k_kv_proj<1>, dim3(Ns, nlayers), dim3(WG), 0, e->stream, x, Ns, L, kv, layer_stride, e->cfg.ln_eps);
+}
+
+void launch_pointnet(ps_engine* e, const PointNetW& w, const float* pts, const uint8_t* mask, const int* rows, int n_rows,
+                     int P, int feat_mask_dim, float* out) {
+  if (n_rows <= 0) return;
+  const float eps = e->cfg.ln_eps;
+  if (P <= 12)
+    hipLaunchKernelGGL(k_pointnet<12>, dim3(n_rows), dim3(128), 0, e->stream, w, pts, mask, rows, n_rows, P, feat_mask_dim, out, eps);
+  else if (P <= 20)
+    hipLaunchKernelGGL(k_pointnet<20>, dim3(n_rows), dim3(128), 0, e->stream, w, pts, mask, rows, n_rows, P, feat_mask_dim, out, eps);
+  else
+    hipLaunchKernelGGL(k_pointnet<32>, dim3(n_rows), dim3(128), 0, e->stream, w, pts, mask, rows, n_rows, P, feat_mask_dim, out, eps);
+}
+
+// radius search + CSR + rel-PE for one edge set
+void launch_radius(ps_engine* e, EdgeSet& es, const int* r1, const int* r2, const float* qpos, const int* qscene, int nq, float r,
+                   int cap, int self_base, const float* src_ori, const float* dst_ori) {
+  CandSet cs{e->d_tok_pos.p, r1, r2};
+  const float r2f = r * r;
+  const int wpb = 4, grid = (nq + wpb - 1) / wpb;
+  hipStream_t st = e->stream;
+  hipLaunchKernelGGL(k_radius<0>, dim3(grid), dim3(64 * wpb), 0, st, cs, qpos, qscene, nq, r2f, cap, self_base, es.cnt.p,
+                     (const int*)nullptr, (int*)nullptr, (int*)nullptr);
+  if (self_base >= 0)
+    hipLaunchKernelGGL(k_radius_selfrank, dim3(grid), dim3(64 * wpb), 0, st, cs, qpos, qscene, nq, r2f, cap, self_base, es.cnt.p);
+  hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, st, (const int*)es.cnt.p, nq, es.eoff.p);
+  hipLaunchKernelGGL(k_radius<1>, dim3(grid), dim3(64 * wpb), 0, st, cs, qpos, qscene, nq, r2f, cap, self_base, (int*)nullptr,
+                     (const int*)es.eoff.p, es.esrc.p, es.edst.p);
+  const int pe_grid = (int)std::min<size_t>(4096, (es.cap_edges + 3) / 4 + 1);
+  hipLaunchKernelGGL(k_relpe, dim3(pe_grid), dim3(256), 0, st, (const int*)es.esrc.p, (const int*)es.edst.p,
+                     (const int*)(es.eoff.p + nq), 0, (const float*)e->d_tok_pos.p, src_ori, qpos, dst_ori, e->div32,
+                     (const float*)nullptr, es.rt.p, e->cfg.ln_eps);
+}
+
+}  // namespace
+
+extern "C" int ps_encode_scene(ps_engine* e) {
+  if (!e || !e->have_scene) return fail(PS_E_STATE, "ps_encode_scene before ps_set_scene");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  const ps_config& c = e->cfg;
+  const int Mv = e->Mv, A = e->A;
+  hipStream_t st = e->stream;
+  float* tok = e->d_tok.p;
+  // agent token geometry back to the init poses (a previous rollout moved them)
+  HIPCHK(hipMemcpyAsync(e->d_tok_pos.p + 2 * (size_t)Mv, e->d_init_pos.p, sizeof(float) * 2 * A, hipMemcpyDeviceToDevice, st));
+  HIPCHK(hipMemcpyAsync(e->d_tok_ori.p + Mv, e->d_init_head.p, sizeof(float) * A, hipMemcpyDeviceToDevice, st));
+  launch_pointnet(e, e->pn_map, e->d_map_input.p, e->d_map_mask.p, e->d_map_rows.p, Mv, e->P, 0, tok);
+  launch_pointnet(e, e->pn_obs, e->d_obs_input.p, e->d_obs_mask.p, e->d_agent_rows.p, A, c.hist_steps, c.obs_dim, tok + (size_t)Mv * D);
+  // knn graphs (attn_fusion.py:107-109) + rel-PE (:111-112)
+  {
+    CandSet ca{e->d_tok_pos.p, e->d_r_agent.p, nullptr};
+    const int na = e->maxA_scene;
+    hipLaunchKernelGGL(k_knn, dim3(A), dim3(256), sizeof(float) * (na + 1), st, ca, (const float*)(e->d_tok_pos.p + 2 * (size_t)Mv),
+                       (const int*)(e->d_tok_scene.p + Mv), c.agent_knn, (const int*)e->e_a2a.eoff.p, e->e_a2a.esrc.p, e->e_a2a.edst.p);
+    CandSet csn{e->d_tok_pos.p, e->d_r_map.p, e->d_r_agent.p};
+    const int ns = e->maxA_scene + e->maxM_scene;
+    hipLaunchKernelGGL(k_knn, dim3(Mv + A), dim3(256), sizeof(float) * (ns + 1), st, csn, (const float*)e->d_tok_pos.p,
+                       (const int*)e->d_tok_scene.p, c.scene_knn, (const int*)e->e_s2s.eoff.p, e->e_s2s.esrc.p, e->e_s2s.edst.p);
+    // a2a edges index agents globally (Mv + i) for positions; kv rows are agent-local -> fixed up below
+    hipLaunchKernelGGL(k_relpe, dim3(1024), dim3(256), 0, st, (const int*)e->e_a2a.esrc.p, (const int*)e->e_a2a.edst.p,
+                       (const int*)nullptr, (int)e->edge_counts[0], (const float*)e->d_tok_pos.p, (const float*)e->d_tok_ori.p,
+                       (const float*)(e->d_tok_pos.p + 2 * (size_t)Mv), (const float*)(e->d_tok_ori.p + Mv), e->div32,
+                       (const float*)nullptr, e->e_a2a.rt.p, c.ln_eps);
+    hipLaunchKernelGGL(k_relpe, dim3(2048), dim3(256), 0, st, (const int*)e->e_s2s.esrc.p, (const int*)e->e_s2s.edst.p,
+                       (const int*)nullptr, (int)e->edge_counts[1], (const float*)e->d_tok_pos.p, (const float*)e->d_tok_ori.p,
+                       (const float*)e->d_tok_pos.p, (const float*)e->d_tok_ori.p, e->div32, (const float*)nullptr,
+                       e->e_s2s.rt.p, c.ln_eps);
+  }
+  // 6 x (a2a on the agent rows in place, s2s on all rows)  (attn_fusion.py:117-119).  kv is indexed by
+  // GLOBAL token row for both (the a2a projection fills rows Mv.. of the shared kv buffer).
+  for (int i = 0; i < c.scene_layers; ++i) {
+    launch_kv(e, tok + (size_t)Mv * D, A, e->L_a2a + i, 1, e->d_kv.p + (size_t)Mv * 256, 0);
+    if (launch_chain(e, tok + (size_t)Mv * D, A, e->step_a2a + i, 1, e->e_a2a.maxdeg)) return PS_E_HIP;
+    launch_kv(e, tok, Mv + A, e->L_s2s + i, 1, e->d_kv.p, 0);
+    if (launch_chain(e, tok, Mv + A, e->step_s2s + i, 1, e->e_s2s.maxdeg)) return PS_E_HIP;
+  }
+  HIPCHK(hipGetLastError());
+  e->encoded = true;
+  e->generated = false;
+  return PS_OK;
+}
+
+extern "C" int ps_generate_policy(ps_engine* e) {
+  if (!e || !e->encoded) return fail(PS_E_STATE, "ps_generate_policy before ps_encode_scene");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  const ps_config& c = e->cfg;
+  const int Mv = e->Mv, A = e->A;
+  hipStream_t st = e->stream;
+  // prompt encoder (prompt_encoder/base.py:36-46)
+  hipLaunchKernelGGL(k_mlp_rows, dim3(A), dim3(128), 0, st, e->mlp_prompt, (const float*)e->d_prompt.p, (const int*)e->d_agent_rows.p,
+                     c.prompt_dim, e->d_xp.p, D, c.ln_eps);
+  // prompt poses (== the observed poses in the reference's batches; kept separate for generality)
+  const float* ppos = e->d_prompt_pos.p;
+  const float* pori = e->d_prompt_ori.p;
+  const int* pscene = e->d_tok_scene.p + Mv;
+  // p2p: radius_graph over prompts, loop=False (sym_coord.py:86); candidates = the scene's agents,
+  // positions taken from the prompt poses -> stage them as the agent token geometry
+  HIPCHK(hipMemcpyAsync(e->d_tok_pos.p + 2 * (size_t)Mv, ppos, sizeof(float) * 2 * A, hipMemcpyDeviceToDevice, st));
+  HIPCHK(hipMemcpyAsync(e->d_tok_ori.p + Mv, pori, sizeof(float) * A, hipMemcpyDeviceToDevice, st));
+  launch_radius(e, e->e_p2p, e->d_r_agent.p, nullptr, ppos, pscene, A, c.dec_prompt_radius, c.dec_max_neigh, Mv, e->d_tok_ori.p, pori);
+  // restore observed agent poses for the scene tokens, then s2p: radius over all scene tokens (:94)
+  HIPCHK(hipMemcpyAsync(e->d_tok_pos.p + 2 * (size_t)Mv, e->d_init_pos.p, sizeof(float) * 2 * A, hipMemcpyDeviceToDevice, st));
+  HIPCHK(hipMemcpyAsync(e->d_tok_ori.p + Mv, e->d_init_head.p, sizeof(float) * A, hipMemcpyDeviceToDevice, st));
+  launch_radius(e, e->e_s2p, e->d_r_map.p, e->d_r_agent.p, ppos, pscene, A, c.dec_scene_radius, c.dec_max_neigh, -1,
+                e->d_tok_ori.p, pori);
+  // k|v of the (fixed) scene tokens for all s2p layers in one launch
+  launch_kv(e, e->d_tok.p, Mv + A, e->L_s2p, c.dec_layers, e->d_kv_s2p.p, (size_t)(Mv + A) * 256);
+  const int md = std::max(e->e_p2p.maxdeg, e->e_s2p.maxdeg);
+  for (int i = 0; i < c.dec_layers; ++i) {
+    // p2p edges carry GLOBAL agent rows (Mv + j): project into rows Mv.. of the shared kv buffer
+    launch_kv(e, e->d_xp.p, A, e->L_p2p + i, 1, e->d_kv.p + (size_t)Mv * 256, 0);
+    if (launch_chain(e, e->d_xp.p, A, e->step_dec + 2 * i, 2, md)) return PS_E_HIP;
+  }
+  HIPCHK(hipMemcpyAsync(e->d_emd.p, e->d_xp.p, sizeof(float) * (size_t)A * D, hipMemcpyDeviceToDevice, st));
+  // condition transformer at 'policy_decoder' (traj_sam.py:129-137)
+  if (e->have_cond && c.cond_layers > 0) {
+    hipLaunchKernelGGL(k_cond_edges, dim3(e->n_cond_edges), dim3(128), 0, st, e->cond, (const int*)e->d_ent_off.p,
+                       (const int*)e->d_ent_type.p, (const float*)e->d_ent_val.p, e->n_cond_edges, e->e_cnd.rt.p, c.ln_eps);
+    HIPCHK(hipMemcpyAsync(e->d_xc.p, e->d_emd.p, sizeof(float) * (size_t)A * D, hipMemcpyDeviceToDevice, st));
+    for (int i = 0; i < c.cond_layers; ++i) {
+      launch_kv(e, e->d_xc.p, A, e->L_cnd + i, 1, e->d_kv.p, 0);
+      if (launch_chain(e, e->d_xc.p, A, e->step_cnd + i, 1, 1)) return PS_E_HIP;
+    }
+    hipLaunchKernelGGL(k_add_rows, dim3((A * D + 255) / 256), dim3(256), 0, st, e->d_emd.p, (const float*)e->d_xc.p, A * D);
+  }
+  // reconst_pred = pred_mlp(policy_emd) (act_decoder.py:133-135) -- constant over the replans
+  hipLaunchKernelGGL(k_mlp_rows, dim3(A), dim3(128), 0, st, e->mlp_pred, (const float*)e->d_emd.p, (const int*)nullptr, D,
+                     e->d_reconst.p, 2, c.ln_eps);
+  // k|v of the map tokens for all m2p layers: map tokens never change during the rollout
+  launch_kv(e, e->d_tok.p, Mv, e->L_m2p, c.pol_layers, e->d_kv_m2p.p, (size_t)Mv * 256);
+  HIPCHK(hipGetLastError());
+  e->generated = true;
+  return PS_OK;
+}
+
+extern "C" int ps_reset_rollout(ps_engine* e) {
+  if (!e || !e->have_scene) return fail(PS_E_STATE, "ps_reset_rollout before ps_set_scene");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  const ps_config& c = e->cfg;
+  hipStream_t st = e->stream;
+  HIPCHK(hipMemsetAsync(e->d_traj.p, 0, sizeof(float) * (size_t)e->A * e->stride_steps * 4, st));
+  HIPCHK(hipMemsetAsync(e->d_vel.p, 0, sizeof(float) * (size_t)e->A * e->stride_steps * 2, st));
+  const int n = e->A * c.hist_steps;
+  hipLaunchKernelGGL(k_init_state, dim3((n + 255) / 256), dim3(256), 0, st, (const float*)e->d_obs_input.p, (const int*)e->d_agent_rows.p,
+                     e->A, c.hist_steps, c.obs_dim, e->stride_steps, e->d_traj.p, e->d_vel.p);
+  HIPCHK(hipGetLastError());
+  e->reset = true;
+  return PS_OK;
+}
+
+extern "C" int ps_policy_step(ps_engine* e, int32_t t_idx) {
+  if (!e || !e->generated || !e->reset) return fail(PS_E_STATE, "ps_policy_step needs generate_policy + reset_rollout");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  const ps_config& c = e->cfg;
+  const int R = (c.max_steps + c.replan_freq - 1) / c.replan_freq;
+  if (t_idx < 0 || t_idx >= R) return fail(PS_E_ARG, "t_idx out of range");
+  const int Mv = e->Mv, A = e->A;
+  hipStream_t st = e->stream;
+  const int last = c.hist_steps + t_idx * c.replan_freq;
+  const float* stat = (e->have_fut && t_idx > 0) ? e->d_fut.p + (size_t)(t_idx - 1) * A * c.hist_steps * c.obs_dim : e->d_static_in.p;
+  // step_env (traj_sam.py:205-274)
+  hipLaunchKernelGGL(k_step_env, dim3(A), dim3(64), 0, st, (const float*)e->d_traj.p, (const float*)e->d_vel.p, e->stride_steps, last,
+                     c.hist_steps, c.dt, (const float*)e->d_init_pos.p, (const float*)e->d_init_head.p, stat, c.obs_dim, e->d_obs_in.p,
+                     e->d_cur_pos.p, e->d_cur_ori.p, t_idx > 0 ? 1 : 0);
+  float* atok = e->d_tok.p + (size_t)Mv * D;
+  if (t_idx > 0) {
+    // update_scene_emb / _replace_old_obs (attn_fusion.py:205-250): re-encode agents, swap tokens + poses
+    launch_pointnet(e, e->pn_obs, e->d_obs_in.p, (const uint8_t*)nullptr, (const int*)nullptr, A, c.hist_steps, -1, atok);
+    HIPCHK(hipMemcpyAsync(e->d_tok_pos.p + 2 * (size_t)Mv, e->d_cur_pos.p, sizeof(float) * 2 * A, hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipMemcpyAsync(e->d_tok_ori.p + Mv, e->d_cur_ori.p, sizeof(float) * A, hipMemcpyDeviceToDevice, st));
+  }
+  // policy.forward (policy/base.py:19 -> temporal_ar.py:75 -> act_decoder.py:239-283)
+  launch_kv(e, atok, A, e->L_a2p, c.pol_layers, e->d_kv_a2p.p, (size_t)A * 256);
+  const int* pscene = e->d_tok_scene.p + Mv;
+  launch_radius(e, e->e_a2p, e->d_r_agent.p, nullptr, e->d_cur_pos.p, pscene, A, c.pol_agent_radius, c.pol_max_neigh, -1,
+                e->d_tok_ori.p, e->d_cur_ori.p);
+  launch_radius(e, e->e_m2p, e->d_r_map.p, nullptr, e->d_cur_pos.p, pscene, A, c.pol_map_radius, c.pol_max_neigh, -1,
+                e->d_tok_ori.p, e->d_cur_ori.p);
+  HIPCHK(hipMemcpyAsync(e->d_fused.p, e->d_emd.p, sizeof(float) * (size_t)A * D, hipMemcpyDeviceToDevice, st));
+  const int md = std::max(e->e_a2p.maxdeg, e->e_m2p.maxdeg);
+  if (launch_chain(e, e->d_fused.p, A, e->step_pol, 2 * c.pol_layers, md, true)) return PS_E_HIP;
+  // _compute_traj + step_agent_traj
+  hipLaunchKernelGGL(k_policy_head, dim3(A), dim3(128), 0, st, e->head, (const float*)e->d_fused.p, (const int*)e->d_agent_type.p,
+                     c.motion_k, c.target_steps, c.state_dim, e->d_motion.p + (size_t)t_idx * A * c.target_steps * c.state_dim,
+                     e->d_traj.p, e->d_vel.p, e->stride_steps, last, c.replan_freq, c.ln_eps);
+  HIPCHK(hipGetLastError());
+  return PS_OK;
+}
+
+extern "C" int ps_rollout(ps_engine* e) {
+  int rc;
+  if ((rc = ps_encode_scene(e))) return rc;
+  if ((rc = ps_generate_policy(e))) return rc;
+  if ((rc = ps_reset_rollout(e))) return rc;
+  const int R = (e->cfg.max_steps + e->cfg.replan_freq - 1) / e->cfg.replan_freq;
+  for (int t = 0; t < R; ++t)
+    if ((rc = ps_policy_step(e, t))) return rc;
+  return PS_OK;
+}
+
+extern "C" int ps_sync(ps_engine* e) {
+  if (!e) return fail(PS_E_ARG, "null engine");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return PS_OK;
+}
+
+extern "C" int ps_set_state(ps_engine* e, int32_t steps, const float* traj, const float* vel) {
+  if (!e || !e->have_scene) return fail(PS_E_STATE, "ps_set_state before ps_set_scene");
+  if (steps < e->cfg.hist_steps || steps > e->stride_steps) return fail(PS_E_ARG, "steps out of range");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  HIPCHK(hipMemcpy2DAsync(e->d_traj.p, sizeof(float) * 4 * e->stride_steps, traj, sizeof(float) * 4 * steps, sizeof(float) * 4 * steps,
+                          e->A, hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipMemcpy2DAsync(e->d_vel.p, sizeof(float) * 2 * e->stride_steps, vel, sizeof(float) * 2 * steps, sizeof(float) * 2 * steps,
+                          e->A, hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  e->reset = true;
+  return PS_OK;
+}
+
+extern "C" int32_t ps_num_agents(ps_engine* e) { return e ? e->A : 0; }
+extern "C" int32_t ps_num_map_tokens(ps_engine* e) { return e ? e->Mv : 0; }
+
+extern "C" int64_t ps_get(ps_engine* e, const char* name, float* dst, int64_t capacity) {
+  if (!e || !name || !dst) return fail(PS_E_ARG, "null argument");
+  if (hipSetDevice(e->cfg.device) != hipSuccess) return fail(PS_E_HIP, "hipSetDevice");
+  if (hipStreamSynchronize(e->stream) != hipSuccess) return fail(PS_E_HIP, std::string("stream error: ") + hipGetErrorString(hipGetLastError()));
+  const ps_config& c = e->cfg;
+  const int A = e->A, Mv = e->Mv;
+  const int R = (c.max_steps + c.replan_freq - 1) / c.replan_freq;
+  const std::string n(name);
+  auto copy = [&](const float* src, int64_t count) -> int64_t {
+    if (count > capacity) return fail(PS_E_ARG, "destination too small for '" + n + "'");
+    if (hipMemcpy(dst, src, sizeof(float) * count, hipMemcpyDeviceToHost) != hipSuccess) return fail(PS_E_HIP, "hipMemcpy D2H");
+    return count;
+  };
+  if (n == "traj" || n == "vel") {
+    const int w = n == "traj" ? 4 : 2;
+    const int64_t steps = (int64_t)R * c.replan_freq, count = (int64_t)A * steps * w;
+    if (count > capacity) return fail(PS_E_ARG, "destination too small");
+    const float* src = (n == "traj" ? e->d_traj.p : e->d_vel.p) + (size_t)c.hist_steps * w;
+    if (hipMemcpy2D(dst, sizeof(float) * w * steps, src, sizeof(float) * w * e->stride_steps, sizeof(float) * w * steps, A,
+                    hipMemcpyDeviceToHost) != hipSuccess)
+      return fail(PS_E_HIP, "hipMemcpy2D D2H");
+    return count;
+  }
+  if (n == "motion_pred") return copy(e->d_motion.p, (int64_t)R * A * c.target_steps * c.state_dim);
+  if (n == "reconst_pred") return copy(e->d_reconst.p, (int64_t)A * 2);
+  if (n == "policy_emd") return copy(e->d_emd.p, (int64_t)A * D);
+  if (n == "scene_tokens") return copy(e->d_tok.p, (int64_t)(Mv + A) * D);
+  if (n == "fused") return copy(e->d_fused.p, (int64_t)A * D);
+  if (n == "obs_in") return copy(e->d_obs_in.p, (int64_t)A * c.hist_steps * c.obs_dim);
+  if (n == "cur_pos") return copy(e->d_cur_pos.p, (int64_t)A * 2);
+  if (n == "edge_counts") {
+    if (capacity < 8) return fail(PS_E_ARG, "destination too small");
+    int v[4] = {0, 0, 0, 0};
+    (void)hipMemcpy(&v[0], e->e_p2p.eoff.p + A, sizeof(int), hipMemcpyDeviceToHost);
+    (void)hipMemcpy(&v[1], e->e_s2p.eoff.p + A, sizeof(int), hipMemcpyDeviceToHost);
+    (void)hipMemcpy(&v[2], e->e_a2p.eoff.p + A, sizeof(int), hipMemcpyDeviceToHost);
+    (void)hipMemcpy(&v[3], e->e_m2p.eoff.p + A, sizeof(int), hipMemcpyDeviceToHost);
+    dst[0] = e->edge_counts[0]; dst[1] = e->edge_counts[1];
+    dst[2] = (float)v[0]; dst[3] = (float)v[1]; dst[4] = (float)v[2]; dst[5] = (float)v[3];
+    dst[6] = e->edge_counts[6]; dst[7] = 0.f;
+    return 8;
+  }
+  return fail(PS_E_ARG, "unknown result name '" + n + "'");
+}
+
+extern "C" int ps_time_rollout(ps_engine* e, int32_t warmup, int32_t iters, float* ms_rollout, float* stage_ms) {
+  if (!e || !e->have_scene) return fail(PS_E_STATE, "ps_time_rollout before ps_set_scene");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  int rc;
+  for (int i = 0; i < warmup; ++i)
+    if ((rc = ps_rollout(e))) return rc;
+  HIPCHK(hipStreamSynchronize(e->stream));
+  hipEvent_t a, b, c1, c2;
+  HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b)); HIPCHK(hipEventCreate(&c1)); HIPCHK(hipEventCreate(&c2));
+  const int R = (e->cfg.max_steps + e->cfg.replan_freq - 1) / e->cfg.replan_freq;
+  double tot = 0, s0 = 0, s1 = 0, s2 = 0;
+  for (int i = 0; i < iters; ++i) {
+    HIPCHK(hipEventRecord(a, e->stream));
+    if ((rc = ps_encode_scene(e))) return rc;
+    HIPCHK(hipEventRecord(c1, e->stream));
+    if ((rc = ps_generate_policy(e))) return rc;
+    if ((rc = ps_reset_rollout(e))) return rc;
+    HIPCHK(hipEventRecord(c2, e->stream));
+    for (int t = 0; t < R; ++t)
+      if ((rc = ps_policy_step(e, t))) return rc;
+    HIPCHK(hipEventRecord(b, e->stream));
+    HIPCHK(hipEventSynchronize(b));
+    float m = 0;
+    HIPCHK(hipEventElapsedTime(&m, a, b)); tot += m;
+    HIPCHK(hipEventElapsedTime(&m, a, c1)); s0 += m;
+    HIPCHK(hipEventElapsedTime(&m, c1, c2)); s1 += m;
+    HIPCHK(hipEventElapsedTime(&m, c2, b)); s2 += m;
+  }
+  (void)hipEventDestroy(a); (void)hipEventDestroy(b); (void)hipEventDestroy(c1); (void)hipEventDestroy(c2);
+  if (ms_rollout) *ms_rollout = (float)(tot / std::max(1, iters));
+  if (stage_ms) { stage_ms[0] = (float)(s0 / std::max(1, iters)); stage_ms[1] = (float)(s1 / std::max(1, iters)); stage_ms[2] = (float)(s2 / std::max(1, iters)); }
+  return PS_OK;
+}
+
+extern "C" int ps_time_policy_kernel(ps_engine* e, int32_t iters, float* ms_kernel) {
+  if (!e || !e->have_scene) return fail(PS_E_STATE, "ps_time_policy_kernel before ps_set_scene");
+  e->time_chain = true;
+  e->chain_ms_sum = 0;
+  e->chain_launches = 0;
+  int rc = 0;
+  for (int i = 0; i < iters && !rc; ++i) rc = ps_rollout(e);
+  e->time_chain = false;
+  if (rc) return rc;
+  HIPCHK(hipStreamSynchronize(e->stream));
+  if (ms_kernel) *ms_kernel = (float)(e->chain_ms_sum / std::max(1, e->chain_launches));
+  return PS_OK;
+}
+
+// ------------------------------------------------------------------------------------------ test hooks
+extern "C" int ps_test_pointnet(ps_engine* e, int32_t which, int32_t n_poly, int32_t P, const float* x, const uint8_t* point_mask,
+                                float* out) {
+  if (!e) return fail(PS_E_ARG, "null engine");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  const PointNetW& w = which == 0 ? e->pn_map : e->pn_obs;
+  DevBuf<float> dx, dout;
+  DevBuf<uint8_t> dm;
+  if (upload(dx, x, (size_t)n_poly * P * w.in_dim, e->stream) || upload(dm, point_mask, (size_t)n_poly * P, e->stream) ||
+      dout.ensure((size_t)n_poly * D))
+    return fail(PS_E_HIP, "test upload failed");
+  launch_pointnet(e, w, dx.p, dm.p, nullptr, n_poly, P, 0, dout.p);
+  HIPCHK(hipStreamSynchronize(e->stream));
+  HIPCHK(hipMemcpy(out, dout.p, sizeof(float) * n_poly * D, hipMemcpyDeviceToHost));
+  dx.release(); dm.release(); dout.release();
+  return PS_OK;
+}
+
+extern "C" int ps_test_fourier(ps_engine* e, int32_t n, const float* x4, float* out128) {
+  if (!e) return fail(PS_E_ARG, "null engine");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  DevBuf<float> dx, dout;
+  if (upload(dx, x4, (size_t)n * 4, e->stream) || dout.ensure((size_t)n * 128)) return fail(PS_E_HIP, "test upload failed");
+  hipLaunchKernelGGL(k_fourier_test, dim3((n * 128 + 255) / 256), dim3(256), 0, e->stream, (const float*)dx.p, n, e->div32, dout.p);
+  HIPCHK(hipStreamSynchronize(e->stream));
+  HIPCHK(hipMemcpy(out128, dout.p, sizeof(float) * n * 128, hipMemcpyDeviceToHost));
+  dx.release(); dout.release();
+  return PS_OK;
+}
+
+extern "C" int ps_test_wrap(ps_engine* e, int32_t n, const float* x, float* out) {
+  if (!e) return fail(PS_E_ARG, "null engine");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  DevBuf<float> dx, dout;
+  if (upload(dx, x, (size_t)n, e->stream) || dout.ensure((size_t)n)) return fail(PS_E_HIP, "test upload failed");
+  hipLaunchKernelGGL(k_wrap_test, dim3((n + 255) / 256), dim3(256), 0, e->stream, (const float*)dx.p, n, dout.p);
+  HIPCHK(hipStreamSynchronize(e->stream));
+  HIPCHK(hipMemcpy(out, dout.p, sizeof(float) * n, hipMemcpyDeviceToHost));
+  dx.release(); dout.release();
+  return PS_OK;
+}
+
+extern "C" int ps_test_attn(ps_engine* e, int32_t layer_index, int32_t Ns, int32_t Nd, int32_t E, const float* x_src,
+                            const float* x_dst, const float* rt, const int32_t* eoff, const int32_t* esrc, int32_t T,
+                            float* out) {
+  if (!e) return fail(PS_E_ARG, "null engine");
+  if (layer_index < 0 || layer_index >= (int)e->all_layers.size()) return fail(PS_E_ARG, "layer index out of range");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  DevBuf<float> dxs, dxd, drt, dkv;
+  DevBuf<int> doff, dsrc;
+  DevBuf<ChainStep> dstep;
+  int maxdeg = 1;
+  for (int i = 0; i < Nd; ++i) maxdeg = std::max(maxdeg, eoff[i + 1] - eoff[i]);
+  if (upload(dxs, x_src, (size_t)Ns * D, e->stream) || upload(dxd, x_dst, (size_t)Nd * D, e->stream) ||
+      upload(drt, rt, (size_t)std::max(E, 1) * 128, e->stream) || upload(doff, (const int*)eoff, (size_t)Nd + 1, e->stream) ||
+      upload(dsrc, (const int*)esrc, (size_t)std::max(E, 1), e->stream) || dkv.ensure((size_t)Ns * 256))
+    return fail(PS_E_HIP, "test upload failed");
+  launch_kv(e, dxs.p, Ns, layer_index, 1, dkv.p, 0);
+  ChainStep st;
+  st.w = e->all_layers[layer_index];
+  st.kv = dkv.p; st.eoff = doff.p; st.esrc = dsrc.p; st.rt = drt.p;
+  if (upload(dstep, &st, 1, e->stream)) return fail(PS_E_HIP, "test upload failed");
+  if (launch_chain(e, dxd.p, Nd, 0, 1, maxdeg, false, dstep.p, T)) return PS_E_HIP;
+  HIPCHK(hipStreamSynchronize(e->stream));
+  HIPCHK(hipMemcpy(out, dxd.p, sizeof(float) * (size_t)Nd * D, hipMemcpyDeviceToHost));
+  dxs.release(); dxd.release(); drt.release(); dkv.release(); doff.release(); dsrc.release(); dstep.release();
+  return PS_OK;
+}
+
+// Debug read-back of an edge set: which = 0 a2a, 1 s2s, 2 p2p, 3 s2p, 4 a2p, 5 m2p.  Returns #edges.
+extern "C" int64_t ps_test_get_edges(ps_engine* e, int32_t which, int32_t* esrc, int32_t* edst, float* rt, int64_t capacity) {
+  if (!e || !e->have_scene) return fail(PS_E_STATE, "no scene");
+  if (hipSetDevice(e->cfg.device) != hipSuccess || hipStreamSynchronize(e->stream) != hipSuccess) return fail(PS_E_HIP, "sync");
+  EdgeSet* sets[6] = {&e->e_a2a, &e->e_s2s, &e->e_p2p, &e->e_s2p, &e->e_a2p, &e->e_m2p};
+  if (which < 0 || which > 5) return fail(PS_E_ARG, "bad edge set");
+  EdgeSet& s = *sets[which];
+  int E = 0;
+  if (hipMemcpy(&E, s.eoff.p + s.nq, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return fail(PS_E_HIP, "memcpy");
+  if (E > capacity) return fail(PS_E_ARG, "capacity too small");
+  if (hipMemcpy(esrc, s.esrc.p, sizeof(int) * E, hipMemcpyDeviceToHost) != hipSuccess ||
+      hipMemcpy(edst, s.edst.p, sizeof(int) * E, hipMemcpyDeviceToHost) != hipSuccess ||
+      (rt && hipMemcpy(rt, s.rt.p, sizeof(float) * (size_t)E * 128, hipMemcpyDeviceToHost) != hipSuccess))
+    return fail(PS_E_HIP, "memcpy");
+  return E;
+}

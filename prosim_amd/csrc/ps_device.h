@@ -1,0 +1,132 @@
+// Device-side building blocks shared by the kernels of libprosim_hip (gfx950 only, wave = 64).
+// Compiled with -ffp-contract=off: every FMA is an explicit fmaf, so the neighbour-search
+// distances (which must reproduce the oracle's fp32 rounding exactly) stay unfused.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ps {
+
+constexpr int D = 128;   // MODEL.HIDDEN_DIM
+constexpr int H = 8;     // *.ATTN.NUM_HEAD
+constexpr int DH = 16;   // *.ATTN.FF_DIM (= head_dim, attention_layer.py:26)
+constexpr int FF = 512;  // hard-wired 4*D (attention_layer.py:39)
+constexpr int QP = 132;  // padded row stride of the per-head [8][128] LDS images
+constexpr int WG = 256;  // threads per workgroup of the row kernels (4 waves, one per SIMD)
+
+#define PS_PI_F 3.14159274101257324f      // float(math.pi)
+#define PS_TWO_PI_F 6.28318548202514648f  // float(2*math.pi)
+
+// models/utils/geometry.py:13-17 -- torch '%' is floor-mod: fmod, then shift into [0, 2pi).
+__device__ __forceinline__ float wrap_angle(float a) {
+  float t = a + PS_PI_F;
+  float m = fmodf(t, PS_TWO_PI_F);
+  if (m != 0.f && m < 0.f) m += PS_TWO_PI_F;
+  return -PS_PI_F + m;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+// LayerNorm of one 128-float row by one wave: lane holds elements lane and lane+64.
+// y = (x - mean) * rstd * w + b, biased variance, eps inside the sqrt (torch.nn.LayerNorm).
+__device__ __forceinline__ void ln_row_wave(const float* __restrict__ x, float* __restrict__ y,
+                                            const float* __restrict__ w, const float* __restrict__ b,
+                                            float eps, int lane, bool relu) {
+  float a0 = x[lane], a1 = x[lane + 64];
+  float mean = wave_sum(a0 + a1) * (1.f / 128.f);
+  float d0 = a0 - mean, d1 = a1 - mean;
+  float var = wave_sum(d0 * d0 + d1 * d1) * (1.f / 128.f);
+  float rstd = 1.f / sqrtf(var + eps);
+  float y0 = d0 * rstd, y1 = d1 * rstd;
+  if (w) {
+    y0 = fmaf(y0, w[lane], b[lane]);
+    y1 = fmaf(y1, w[lane + 64], b[lane + 64]);
+  }
+  if (relu) {
+    y0 = fmaxf(y0, 0.f);
+    y1 = fmaxf(y1, 0.f);
+  }
+  y[lane] = y0;
+  y[lane + 64] = y1;
+}
+
+// LayerNorm of T rows held in LDS (row stride `xs`/`ys`) by the 4 waves of a 256-thread WG.
+template <int T>
+__device__ __forceinline__ void ln_rows(const float* x, int xs, float* y, int ys, const float* __restrict__ w,
+                                        const float* __restrict__ b, float eps, bool relu) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int t = wave; t < T; t += 4) ln_row_wave(x + t * xs, y + t * ys, w, b, eps, lane, relu);
+}
+
+// Row-block GEMV: out[t][n] = act(sum_k x[t][k] * Wt[k][n] + bias[n]) for T rows held in LDS.
+// Wt is K-major ([K][N], i.e. the transpose of a torch Linear weight) so a wave reads 1 KiB of
+// contiguous weights per instruction (float4 per lane).  Thread (col4, kg): 4 consecutive
+// columns x a K-slab; the KG partial sums meet in LDS `part` ([KG][T][N]).  N in {128,256,512}.
+// HEADX: x is a per-head image [T][8][QP] and column n reads head n/16 (the to_v_r fold).
+template <int T, bool HEADX>
+__device__ __forceinline__ void gemv_rows(const float* x, int xs, int K, const float* __restrict__ Wt, int N,
+                                          const float* __restrict__ bias, float* part, float* out, int os,
+                                          bool relu) {
+  const int tid = threadIdx.x;
+  const int ncol4 = N >> 2;
+  const int KG = WG / ncol4;
+  const int col4 = tid % ncol4, kg = tid / ncol4;
+  const int klen = K / KG;
+  const int k0 = kg * klen;
+  float acc[T][4];
+#pragma unroll
+  for (int t = 0; t < T; ++t) acc[t][0] = acc[t][1] = acc[t][2] = acc[t][3] = 0.f;
+  const float* wp = Wt + (size_t)k0 * N + 4 * col4;
+  const float* xp = x + k0 + (HEADX ? (col4 >> 2) * QP : 0);
+#pragma unroll 8
+  for (int k = 0; k < klen; ++k) {
+    const float4 w = *reinterpret_cast<const float4*>(wp + (size_t)k * N);
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      const float xv = xp[t * xs + k];
+      acc[t][0] = fmaf(xv, w.x, acc[t][0]);
+      acc[t][1] = fmaf(xv, w.y, acc[t][1]);
+      acc[t][2] = fmaf(xv, w.z, acc[t][2]);
+      acc[t][3] = fmaf(xv, w.w, acc[t][3]);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+    *reinterpret_cast<float4*>(part + ((size_t)(kg * T + t)) * N + 4 * col4) =
+        make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+  __syncthreads();
+  for (int idx = tid; idx < T * N; idx += WG) {
+    const int t = idx / N, n = idx - t * N;
+    float s = bias ? bias[n] : 0.f;
+    for (int g = 0; g < KG; ++g) s += part[((size_t)(g * T + t)) * N + n];
+    if (relu) s = fmaxf(s, 0.f);
+    out[t * os + n] = s;
+  }
+  __syncthreads();
+}
+
+// Small-N GEMV (N not a multiple of 128): one thread per output, torch layout W[N][K].
+template <int T>
+__device__ __forceinline__ void gemv_small(const float* x, int xs, int K, const float* __restrict__ W, int N,
+                                           const float* __restrict__ bias, float* out, int os, bool relu) {
+  for (int idx = threadIdx.x; idx < T * N; idx += blockDim.x) {
+    const int t = idx / N, n = idx - t * N;
+    float s = bias ? bias[n] : 0.f;
+    const float* wr = W + (size_t)n * K;
+    for (int k = 0; k < K; ++k) s = fmaf(x[t * xs + k], wr[k], s);
+    if (relu) s = fmaxf(s, 0.f);
+    out[t * os + n] = s;
+  }
+  __syncthreads();
+}
+
+}  // namespace ps

@@ -1,0 +1,566 @@
+// PointNet polyline encoder, neighbour search, relative-PE, prompt/condition encoders and the
+// per-replan state kernels (K1-K5, K9-K12 of SURVEY.md section 2a) for gfx950.
+#pragma once
+#include "ps_device.h"
+
+namespace ps {
+
+// ------------------------------------------------------------------------------------------
+// K1  PointNetPolylineEncoder.forward (prosim/models/scene_encoder/pointnet_encoder.py:24-62)
+// One 128-thread workgroup per VALID polyline; thread = output column; the polyline's points
+// live in registers (acc[PTS]) / LDS.  Masked points contribute 0 to both max-pools
+// (:40-44, :49-53), exactly as the reference's zero-filled scatter buffers do.
+struct PointNetW {
+  int in_dim, n_pre, n_mid;             // n_pre = NUM_PRE_LAYERS, n_mid = NUM_MLP_LAYERS - NUM_PRE_LAYERS
+  const float* pre_Wt[4];               // [K][128] K-major; K = in_dim for layer 0, else 128
+  const float* pre_b[4];
+  const float* pre_lnw[4];              // nullptr on the last pre layer (Linear + ReLU only)
+  const float* pre_lnb[4];
+  const float* mid_Wt[4];               // layer 0: [256][128] (rows 0..127 point feature, 128..255 pooled)
+  const float* mid_b[4];
+  const float* mid_lnw[4];
+  const float* mid_lnb[4];
+  const float *out_W0t, *out_b0, *out_W1t, *out_b1;  // out_mlps: Linear, ReLU, Linear (no norm)
+};
+
+template <int PTS>
+__global__ __launch_bounds__(128) void k_pointnet(PointNetW w, const float* __restrict__ pts, const uint8_t* __restrict__ pmask,
+                                                  const int* __restrict__ rows, int n_rows, int P, int feat_mask_dim,
+                                                  float* __restrict__ out, float eps) {
+  // pts [n_total][P][in_dim]; pmask either per point [n_total][P] (feat_mask_dim == 0) or per
+  // feature [n_total][P][feat_mask_dim] (a point is valid iff all features are; obs_encoder.py:84).
+  __shared__ __attribute__((aligned(16))) float xin[PTS * 24];
+  __shared__ __attribute__((aligned(16))) float hb[PTS * 128];
+  __shared__ __attribute__((aligned(16))) float pooled[128];
+  __shared__ int valid[PTS];
+  const int col = threadIdx.x, lane = col & 63, wave = col >> 6;
+  const int row = rows ? rows[blockIdx.x] : blockIdx.x;
+  const int C = w.in_dim;
+  for (int p = col; p < PTS; p += 128) {
+    int v = 0;
+    if (p < P) {
+      if (feat_mask_dim == 0) v = pmask[(size_t)row * P + p];
+      else {
+        v = 1;
+        for (int f = 0; f < feat_mask_dim; ++f) v &= pmask[((size_t)row * P + p) * feat_mask_dim + f];
+      }
+    }
+    valid[p] = v;
+  }
+  __syncthreads();
+  for (int i = col; i < P * C; i += 128) {
+    const int p = i / C;
+    xin[i] = valid[p] ? pts[(size_t)row * P * C + i] : 0.f;
+  }
+  __syncthreads();
+  float acc[PTS];
+  // ---- pre_mlps
+  for (int l = 0; l < w.n_pre; ++l) {
+    const int K = (l == 0) ? C : 128;
+    const float* in = (l == 0) ? xin : hb;
+    const float bias = w.pre_b[l][col];
+#pragma unroll
+    for (int p = 0; p < PTS; ++p) acc[p] = bias;
+    for (int k = 0; k < K; ++k) {
+      const float wv = w.pre_Wt[l][(size_t)k * 128 + col];
+#pragma unroll
+      for (int p = 0; p < PTS; ++p) acc[p] = fmaf(in[p * K + k], wv, acc[p]);
+    }
+    __syncthreads();  // everyone done reading hb
+    const bool has_ln = w.pre_lnw[l] != nullptr;
+#pragma unroll
+    for (int p = 0; p < PTS; ++p) hb[p * 128 + col] = has_ln ? acc[p] : fmaxf(acc[p], 0.f);
+    __syncthreads();
+    if (has_ln) {
+      for (int p = wave; p < P; p += 2) ln_row_wave(hb + p * 128, hb + p * 128, w.pre_lnw[l], w.pre_lnb[l], eps, lane, true);
+      __syncthreads();
+    }
+  }
+  // pooled = max over points of the zero-filled feature buffer (:47)
+  {
+    float m = 0.f;
+    bool any = false;
+    for (int p = 0; p < P; ++p) {
+      const float v = valid[p] ? hb[p * 128 + col] : 0.f;
+      m = any ? fmaxf(m, v) : v;
+      any = true;
+    }
+    pooled[col] = m;
+  }
+  __syncthreads();
+  // ---- mlps: layer 0 consumes cat(point feature, pooled)  (:48-50)
+  for (int l = 0; l < w.n_mid; ++l) {
+    float base = w.mid_b[l][col];
+    const float* Wt = w.mid_Wt[l];
+    if (l == 0) {
+      for (int k = 0; k < 128; ++k) base = fmaf(pooled[k], Wt[(size_t)(128 + k) * 128 + col], base);
+    }
+#pragma unroll
+    for (int p = 0; p < PTS; ++p) acc[p] = (l == 0) ? 0.f : base;
+    for (int k = 0; k < 128; ++k) {
+      const float wv = Wt[(size_t)k * 128 + col];
+#pragma unroll
+      for (int p = 0; p < PTS; ++p) acc[p] = fmaf(hb[p * 128 + k], wv, acc[p]);
+    }
+    if (l == 0) {
+#pragma unroll
+      for (int p = 0; p < PTS; ++p) acc[p] += base;
+    }
+    __syncthreads();
+    const bool has_ln = w.mid_lnw[l] != nullptr;
+#pragma unroll
+    for (int p = 0; p < PTS; ++p) hb[p * 128 + col] = has_ln ? acc[p] : fmaxf(acc[p], 0.f);
+    __syncthreads();
+    if (has_ln) {
+      for (int p = wave; p < P; p += 2) ln_row_wave(hb + p * 128, hb + p * 128, w.mid_lnw[l], w.mid_lnb[l], eps, lane, true);
+      __syncthreads();
+    }
+  }
+  // max-pool (:53), then out_mlps (:57)
+  {
+    float m = 0.f;
+    bool any = false;
+    for (int p = 0; p < P; ++p) {
+      const float v = valid[p] ? hb[p * 128 + col] : 0.f;
+      m = any ? fmaxf(m, v) : v;
+      any = true;
+    }
+    __syncthreads();
+    pooled[col] = m;
+  }
+  __syncthreads();
+  float a = w.out_b0[col];
+  for (int k = 0; k < 128; ++k) a = fmaf(pooled[k], w.out_W0t[(size_t)k * 128 + col], a);
+  hb[col] = fmaxf(a, 0.f);
+  __syncthreads();
+  a = w.out_b1[col];
+  for (int k = 0; k < 128; ++k) a = fmaf(hb[k], w.out_W1t[(size_t)k * 128 + col], a);
+  out[(size_t)blockIdx.x * 128 + col] = a;
+}
+
+// ------------------------------------------------------------------------------------------
+// K2-K4 neighbour search.  torch_cluster (third-party, absent from /root/reference, unpinned:
+// install_local_env.sh:4) -- semantics of its CUDA kernels restated: per query scan the
+// candidates of the same scene in index order; d2 = dx*dx + dy*dy rounded per op (the file is
+// built with -ffp-contract=off); radius keeps the first `cap` with d2 < r*r; knn keeps the k
+// smallest by (d2, index).  Candidates of scene b = tokens [r1[b], r1[b+1]) then [r2[b], r2[b+1]).
+struct CandSet {
+  const float* pos;   // [n_tokens][2]
+  const int* r1;      // [B+1] first range per scene (global token indices)
+  const int* r2;      // [B+1] second range per scene or nullptr
+};
+
+__device__ __forceinline__ float dist2(float ax, float ay, float bx, float by) {
+  const float dx = ax - bx, dy = ay - by;
+  return dx * dx + dy * dy;  // unfused: -ffp-contract=off
+}
+
+// One wave per query.  mode 0: count only -> cnt[q];  mode 1: fill esrc/edst at eoff[q].
+// self_base >= 0: candidates and queries are the same set (radius_graph, loop=False): query q
+// is token self_base + q, the scan keeps cap+1 matches and then drops the self match.
+template <int MODE>
+__global__ void k_radius(CandSet cs, const float* __restrict__ qpos, const int* __restrict__ qscene, int nq, float r2,
+                         int cap, int self_base, int* __restrict__ cnt, const int* __restrict__ eoff,
+                         int* __restrict__ esrc, int* __restrict__ edst) {
+  const int q = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (q >= nq) return;
+  const float qx = qpos[2 * q], qy = qpos[2 * q + 1];
+  const int b = qscene[q];
+  const int capx = cap + (self_base >= 0 ? 1 : 0);
+  const int self = self_base >= 0 ? self_base + q : -1;
+  int run = 0;
+  const int base_out = (MODE == 1) ? eoff[q] : 0;
+  for (int rg = 0; rg < 2 && run < capx; ++rg) {
+    const int* rr = rg == 0 ? cs.r1 : cs.r2;
+    if (!rr) break;
+    const int beg = rr[b], end = rr[b + 1];
+    for (int i0 = beg; i0 < end && run < capx; i0 += 64) {
+      const int i = i0 + lane;
+      bool ok = false;
+      if (i < end) ok = dist2(cs.pos[2 * i], cs.pos[2 * i + 1], qx, qy) < r2;
+      const unsigned long long m = __ballot(ok);
+      const int rank = run + __popcll(m & ((1ull << lane) - 1ull));
+      if (MODE == 1 && ok && rank < capx && i != self) {
+        const int o = base_out + rank - ((self >= 0 && self < i) ? 1 : 0);
+        esrc[o] = i;
+        edst[o] = q;
+      }
+      run += __popcll(m);
+    }
+  }
+  if (MODE == 0 && lane == 0) {
+    int total = run < capx ? run : capx;
+    cnt[q] = total;
+  }
+}
+// self handling for the count: the self match is always inside r (d2 = 0) -- it occupies a rank
+// slot iff its rank < cap+1.  Done in a second tiny pass to keep k_radius simple.
+__global__ void k_radius_selfrank(CandSet cs, const float* __restrict__ qpos, const int* __restrict__ qscene, int nq,
+                                  float r2, int cap, int self_base, int* __restrict__ cnt) {
+  const int q = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (q >= nq) return;
+  const float qx = qpos[2 * q], qy = qpos[2 * q + 1];
+  const int b = qscene[q];
+  const int self = self_base + q;
+  int before = 0;
+  for (int rg = 0; rg < 2; ++rg) {
+    const int* rr = rg == 0 ? cs.r1 : cs.r2;
+    if (!rr) break;
+    const int beg = rr[b], end = rr[b + 1] < self ? rr[b + 1] : self;
+    for (int i0 = beg; i0 < end; i0 += 64) {
+      const int i = i0 + lane;
+      bool ok = false;
+      if (i < end) ok = dist2(cs.pos[2 * i], cs.pos[2 * i + 1], qx, qy) < r2;
+      before += __popcll(__ballot(ok));
+    }
+  }
+  if (lane == 0 && before < cap + 1) cnt[q] -= 1;
+}
+
+// exclusive scan of cnt[0..n) -> off[0..n], single workgroup (n is a few thousand at most).
+__global__ void k_exclusive_scan(const int* __restrict__ cnt, int n, int* __restrict__ off) {
+  __shared__ int wsum[16];
+  __shared__ int carry;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < n; base += blockDim.x) {
+    const int i = base + tid;
+    const int v = i < n ? cnt[i] : 0;
+    int s = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int y = __shfl_up(s, o);
+      if (lane >= o) s += y;
+    }
+    if (lane == 63) wsum[wave] = s;
+    __syncthreads();
+    int woff = 0;
+    for (int j = 0; j < wave; ++j) woff += wsum[j];
+    const int c = carry;
+    if (i < n) off[i] = c + woff + s - v;
+    __syncthreads();
+    if (tid == blockDim.x - 1) carry = c + woff + s;
+    __syncthreads();
+  }
+  if (tid == 0) off[n] = carry;
+}
+
+// knn (loop=True): one workgroup per query; d2 of the scene's candidates in LDS; each candidate's
+// rank = #{j : (d2_j, j) < (d2_i, i)}; candidates with rank < k are written at eoff[q] + rank
+// (so a destination's edges come out sorted by distance).  eoff is closed-form (host).
+__global__ void k_knn(CandSet cs, const float* __restrict__ qpos, const int* __restrict__ qscene, int k,
+                      const int* __restrict__ eoff, int* __restrict__ esrc, int* __restrict__ edst) {
+  extern __shared__ float d2s[];
+  const int q = blockIdx.x, tid = threadIdx.x;
+  const float qx = qpos[2 * q], qy = qpos[2 * q + 1];
+  const int b = qscene[q];
+  const int b1 = cs.r1[b], n1 = cs.r1[b + 1] - b1;
+  const int b2 = cs.r2 ? cs.r2[b] : 0, n2 = cs.r2 ? cs.r2[b + 1] - b2 : 0;
+  const int n = n1 + n2;
+  for (int j = tid; j < n; j += blockDim.x) {
+    const int i = j < n1 ? b1 + j : b2 + (j - n1);
+    d2s[j] = dist2(cs.pos[2 * i], cs.pos[2 * i + 1], qx, qy);
+  }
+  __syncthreads();
+  const int base = eoff[q];
+  for (int j = tid; j < n; j += blockDim.x) {
+    const float dj = d2s[j];
+    int rank = 0;
+    for (int m = 0; m < n; ++m) {
+      const float dm = d2s[m];
+      rank += (dm < dj || (dm == dj && m < j)) ? 1 : 0;
+    }
+    if (rank < k) {
+      esrc[base + rank] = j < n1 ? b1 + j : b2 + (j - n1);
+      edst[base + rank] = q;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K5  relative positional encoding of an edge (act_decoder.py:203-221 and twins) through
+// FourierEmbeddingFix(32) (fourier_embedding.py:63-78), then the affine-free LayerNorm that
+// every layer's attn_prenorm_r shares.  One wave per edge; lane l makes features l and l+64.
+__device__ __forceinline__ float fourier_feat(float x, int slot, const float* __restrict__ div) {
+  const float v = (x * PS_TWO_PI_F) / div[slot];
+  return (slot & 1) ? cosf(v) : sinf(v);
+}
+
+__global__ void k_relpe(const int* __restrict__ esrc, const int* __restrict__ edst, const int* __restrict__ n_edges_ptr,
+                        int n_edges_host, const float* __restrict__ src_pos, const float* __restrict__ src_ori,
+                        const float* __restrict__ dst_pos, const float* __restrict__ dst_ori,
+                        const float* __restrict__ div32, const float* __restrict__ add /*[E][128] or null*/,
+                        float* __restrict__ rt, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int wpb = blockDim.x >> 6;
+  const int E = n_edges_ptr ? *n_edges_ptr : n_edges_host;
+  for (int e = blockIdx.x * wpb + (threadIdx.x >> 6); e < E; e += gridDim.x * wpb) {
+    const int s = esrc[e], d = edst[e];
+    const float dx = src_pos[2 * s] - dst_pos[2 * d], dy = src_pos[2 * s + 1] - dst_pos[2 * d + 1];
+    const float od = dst_ori[d];
+    const float dist = sqrtf(dx * dx + dy * dy);
+    const float rel_ori = wrap_angle(src_ori[s] - od);
+    const float cx = cosf(od), cy = sinf(od);
+    // torch's .sum(dim=-1) accumulates from +0, so a dot of (-0, -0) is +0 there: keep the explicit
+    // 0.f + ... (IEEE forbids folding it) or self-loop edges would see atan2(+-0, -0) = +-pi.
+    const float dot = (0.f + cx * dx) + cy * dy;
+    const float ang = atan2f(cx * dy - cy * dx, dot);
+    const int slot = lane & 31;
+    float f0 = fourier_feat(lane < 32 ? dist : rel_ori, slot, div32);
+    float f1 = fourier_feat(ang, slot, div32);
+    if (add) {
+      f0 += add[(size_t)e * 128 + lane];
+      f1 += add[(size_t)e * 128 + 64 + lane];
+    }
+    const float mean = wave_sum(f0 + f1) * (1.f / 128.f);
+    const float d0 = f0 - mean, d1 = f1 - mean;
+    const float var = wave_sum(d0 * d0 + d1 * d1) * (1.f / 128.f);
+    const float rstd = 1.f / sqrtf(var + eps);
+    rt[(size_t)e * 128 + lane] = d0 * rstd;
+    rt[(size_t)e * 128 + 64 + lane] = d1 * rstd;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Prompt encoder (prompt_encoder/base.py:36-46): MLP 7 -> 128 (LN, ReLU) -> 128, one WG per agent.
+struct Mlp3W {  // up to three Linear layers with optional LayerNorm+ReLU between (reference MLP)
+  int dims[4];
+  int n;
+  const float* W[3];   // torch layout [out][in]
+  const float* b[3];
+  const float* lnw[3];  // after layer i (i < n-1) or nullptr (then plain ReLU)
+  const float* lnb[3];
+};
+
+__device__ __forceinline__ void mlp3_rows1(const Mlp3W& m, float* bufA, float* bufB, float eps) {
+  // input row in bufA (dims[0] floats); result in bufA; 128 threads
+  for (int l = 0; l < m.n; ++l) {
+    gemv_small<1>(bufA, 0, m.dims[l], m.W[l], m.dims[l + 1], m.b[l], bufB, 0, false);
+    if (l < m.n - 1) {
+      const int nn = m.dims[l + 1];
+      if (m.lnw[l]) {
+        // LayerNorm over nn (64 or 128) features by wave 0
+        if (threadIdx.x < 64) {
+          const int lane = threadIdx.x;
+          float a0 = lane < nn ? bufB[lane] : 0.f, a1 = (lane + 64) < nn ? bufB[lane + 64] : 0.f;
+          const float mean = wave_sum(a0 + a1) / (float)nn;
+          const float d0 = lane < nn ? a0 - mean : 0.f, d1 = (lane + 64) < nn ? a1 - mean : 0.f;
+          const float var = wave_sum(d0 * d0 + d1 * d1) / (float)nn;
+          const float rstd = 1.f / sqrtf(var + eps);
+          if (lane < nn) bufB[lane] = fmaxf(fmaf(d0 * rstd, m.lnw[l][lane], m.lnb[l][lane]), 0.f);
+          if (lane + 64 < nn) bufB[lane + 64] = fmaxf(fmaf(d1 * rstd, m.lnw[l][lane + 64], m.lnb[l][lane + 64]), 0.f);
+        }
+      } else {
+        for (int i = threadIdx.x; i < nn; i += blockDim.x) bufB[i] = fmaxf(bufB[i], 0.f);
+      }
+      __syncthreads();
+    }
+    for (int i = threadIdx.x; i < m.dims[l + 1]; i += blockDim.x) bufA[i] = bufB[i];
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(128) void k_mlp_rows(Mlp3W m, const float* __restrict__ in, const int* __restrict__ rows,
+                                                  int in_stride, float* __restrict__ out, int out_stride, float eps) {
+  __shared__ float a[128], b[128];
+  const int r = rows ? rows[blockIdx.x] : blockIdx.x;
+  for (int i = threadIdx.x; i < m.dims[0]; i += blockDim.x) a[i] = in[(size_t)r * in_stride + i];
+  __syncthreads();
+  mlp3_rows1(m, a, b, eps);
+  for (int i = threadIdx.x; i < m.dims[m.n]; i += blockDim.x) out[(size_t)blockIdx.x * out_stride + i] = a[i];
+}
+
+// Condition encoders + mean pooling over the condition entries attached to one agent
+// (condition_encoders.py:21-51, :76-141; condition_attns.py:114-188 for self-loop edges), then
+// r = pooled + relPE(self-loop) and the affine-free LayerNorm.  One WG (128 threads) per
+// conditioned agent; entries are a host-built CSR: type (0 goal, 1 tag), tag id, 3 floats.
+struct CondW {
+  Mlp3W goal;                 // MLP 2 -> 128 (ReLU) -> 128, no norm
+  const float* tag_emb;       // [11][128] indexed by V_Action_MotionTag value
+  const float *div32, *div64, *div128;
+};
+__global__ __launch_bounds__(128) void k_cond_edges(CondW w, const int* __restrict__ ent_off, const int* __restrict__ ent_type,
+                                                   const float* __restrict__ ent_val, int n_nodes,
+                                                   float* __restrict__ rt, float eps) {
+  __shared__ float a[128], b[128], accum[128];
+  const int node = blockIdx.x, tid = threadIdx.x;
+  accum[tid] = 0.f;
+  __syncthreads();
+  const int e0 = ent_off[node], e1 = ent_off[node + 1];
+  for (int e = e0; e < e1; ++e) {
+    const float v0 = ent_val[3 * e], v1 = ent_val[3 * e + 1], v2 = ent_val[3 * e + 2];
+    if (ent_type[2 * e] == 0) {
+      if (tid < 2) a[tid] = tid == 0 ? v0 : v1;
+      __syncthreads();
+      mlp3_rows1(w.goal, a, b, eps);
+      // + FourierEmbeddingFix(128)(t): one channel, 128 slots
+      const float v = (v2 * PS_TWO_PI_F) / w.div128[tid];
+      accum[tid] += a[tid] + ((tid & 1) ? cosf(v) : sinf(v));
+    } else {
+      // tag parameter + FourierEmbeddingFix(64)([t0, t1]): two channels x 64 slots
+      const int slot = tid & 63;
+      const float x = tid < 64 ? v1 : v2;
+      const float v = (x * PS_TWO_PI_F) / w.div64[slot];
+      accum[tid] += w.tag_emb[ent_type[2 * e + 1] * 128 + tid] + ((slot & 1) ? cosf(v) : sinf(v));
+    }
+    __syncthreads();
+  }
+  // mean pool, + relPE of a self-loop (dist 0, rel_ori 0, angle atan2(0,0)=0 -> [sin 0, cos 0, ...])
+  const float pe = (tid & 1) ? cosf(0.f) : sinf(0.f);
+  a[tid] = accum[tid] / (float)(e1 - e0) + pe;
+  __syncthreads();
+  if (tid < 64) ln_row_wave(a, rt + (size_t)node * 128, nullptr, nullptr, eps, tid, false);
+}
+
+// ------------------------------------------------------------------------------------------
+// K12  step_env (traj_sam.py:205-274 + models/utils/geometry.py:24-58 + _get_rel_vel_acc :552):
+// the last hist+2 states -> ego-relative history features written into obs_in[:, :hist, :8];
+// also the agents' current pose (a_pos, :211-215).  One 64-thread WG per agent.
+__global__ __launch_bounds__(64) void k_step_env(const float* __restrict__ traj, const float* __restrict__ vel, int stride_steps,
+                                                 int last, int hist, float dt, const float* __restrict__ init_pos,
+                                                 const float* __restrict__ init_head, const float* __restrict__ static_in,
+                                                 int obs_dim, float* __restrict__ obs_in, float* __restrict__ cur_pos,
+                                                 float* __restrict__ cur_ori, int write_obs) {
+  const int a = blockIdx.x, tid = threadIdx.x;
+  const float* tr = traj + (size_t)a * stride_steps * 4;
+  const float* vl = vel + (size_t)a * stride_steps * 2;
+  const float lx = tr[(last - 1) * 4], ly = tr[(last - 1) * 4 + 1];
+  const float th_last = atan2f(tr[(last - 1) * 4 + 2], tr[(last - 1) * 4 + 3]);
+  if (tid == 0) {
+    cur_pos[2 * a] = init_pos[2 * a] + lx;
+    cur_pos[2 * a + 1] = init_pos[2 * a + 1] + ly;
+    cur_ori[a] = wrap_angle(th_last + init_head[a]);
+  }
+  if (!write_obs) return;
+  __shared__ float rvx[16], rvy[16];
+  const float ct = cosf(-th_last), st = sinf(-th_last);
+  const int nv = hist + 1;  // rel_vel over the last hist+1 steps
+  if (tid < nv) {
+    const int s = last - nv + tid;
+    const float vx = vl[s * 2], vy = vl[s * 2 + 1];
+    rvx[tid] = vx * ct - vy * st;
+    rvy[tid] = vy * ct + vx * st;
+  }
+  __syncthreads();
+  if (tid < hist) {
+    const int s = last - hist + tid;
+    const float dx = tr[s * 4] - lx, dy = tr[s * 4 + 1] - ly;
+    const float th = atan2f(tr[s * 4 + 2], tr[s * 4 + 3]);
+    const float d = wrap_angle(th - th_last);
+    float* o = obs_in + ((size_t)a * hist + tid) * obs_dim;
+    o[0] = dx * ct - dy * st;
+    o[1] = dy * ct + dx * st;
+    o[2] = sinf(d);
+    o[3] = cosf(d);
+    o[4] = rvx[tid + 1];
+    o[5] = rvy[tid + 1];
+    o[6] = (rvx[tid + 1] - rvx[tid]) / dt;
+    o[7] = (rvy[tid + 1] - rvy[tid]) / dt;
+    const float* si = static_in + ((size_t)a * hist + tid) * obs_dim;
+    for (int f = 8; f < obs_dim; ++f) o[f] = si[f];
+  }
+}
+
+// init_agent_trajs (traj_sam.py:597-633): history -> state buffers (NaN -> 0).
+__global__ void k_init_state(const float* __restrict__ obs_input, const int* __restrict__ rows, int n_agents, int hist,
+                             int obs_dim, int stride_steps, float* __restrict__ traj, float* __restrict__ vel) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_agents * hist) return;
+  const int a = i / hist, s = i % hist;
+  const float* o = obs_input + ((size_t)rows[a] * hist + s) * obs_dim;
+  float* t = traj + ((size_t)a * stride_steps + s) * 4;
+  float* v = vel + ((size_t)a * stride_steps + s) * 2;
+  for (int f = 0; f < 4; ++f) { const float x = o[f]; t[f] = (x != x) ? 0.f : x; }
+  for (int f = 0; f < 2; ++f) { const float x = o[4 + f]; v[f] = (x != x) ? 0.f : x; }
+}
+
+// ------------------------------------------------------------------------------------------
+// K9-K11  ActDecoder._compute_traj, anchor mode (act_decoder.py:78-140; CG_stacked mlp.py:207-241)
+// fused with step_agent_traj (traj_sam.py:276-349, TOP_K = 1 -> mode 0).  One 128-thread WG per agent.
+struct HeadW {
+  const float* anchors;              // [K*types][128]
+  const float *cgW[3], *cgb[3], *cglnw[3], *cglnb[3];   // CG_decode.CGs[i].MLP: Linear [128][128] torch layout + LN
+  Mlp3W motion;                      // 128 -> 128 -> 64 -> out_dim
+};
+__global__ __launch_bounds__(128) void k_policy_head(HeadW w, const float* __restrict__ fused, const int* __restrict__ agent_type,
+                                                    int motion_k, int steps, int sdim, float* __restrict__ motion_pred,
+                                                    float* __restrict__ traj, float* __restrict__ vel, int stride_steps, int last,
+                                                    int replan, float eps) {
+  __shared__ float ctx[128], inp[128], a[128], b[128];
+  const int ag = blockIdx.x, tid = threadIdx.x;
+  ctx[tid] = fused[(size_t)ag * 128 + tid];
+  const int type_idx = (agent_type[ag] - 1) * motion_k;  // K = 1: anchor row
+  a[tid] = w.anchors[(size_t)type_idx * 128 + tid];
+  __syncthreads();
+  // CG_stacked(3) with K = 1: max over the mode dim is the identity
+  for (int i = 0; i < 3; ++i) {
+    gemv_small<1>(i == 0 ? a : inp, 0, 128, w.cgW[i], 128, w.cgb[i], b, 0, false);
+    if (tid < 64) ln_row_wave(b, b, w.cglnw[i], w.cglnb[i], eps, tid, true);
+    __syncthreads();
+    const float y = b[tid] * ctx[tid];
+    if (i == 0) {
+      inp[tid] = y;
+      ctx[tid] = y;
+    } else {
+      inp[tid] = (inp[tid] * (float)i + y) / (float)(i + 1);
+      ctx[tid] = (ctx[tid] * (float)i + y) / (float)(i + 1);
+    }
+    __syncthreads();
+  }
+  a[tid] = inp[tid];
+  __syncthreads();
+  mlp3_rows1(w.motion, a, b, eps);  // a[0 .. steps*sdim)
+  // cumsum over steps of (dx, dy, dtheta); wrap theta  (act_decoder.py:117-121)
+  if (tid == 0) {
+    float cx = 0.f, cy = 0.f, ch = 0.f;
+    float* mp = motion_pred + (size_t)ag * motion_k * steps * sdim;
+    const float* cur = traj + ((size_t)ag * stride_steps + last - 1) * 4;
+    const float lth = atan2f(cur[2], cur[3]);
+    const float cl = cosf(lth), sl = sinf(lth);
+    for (int s = 0; s < steps; ++s) {
+      cx += a[s * sdim];
+      cy += a[s * sdim + 1];
+      ch += a[s * sdim + 2];
+      const float hh = wrap_angle(ch);
+      mp[s * sdim] = cx;
+      mp[s * sdim + 1] = cy;
+      mp[s * sdim + 2] = hh;
+      for (int f = 3; f < sdim; ++f) mp[s * sdim + f] = a[s * sdim + f];
+      if (s < replan) {
+        // step_agent_traj (traj_sam.py:322-347): rotate into the agent-init frame, append
+        float* t = traj + ((size_t)ag * stride_steps + last + s) * 4;
+        float* v = vel + ((size_t)ag * stride_steps + last + s) * 2;
+        t[0] = (cx * cl - cy * sl) + cur[0];
+        t[1] = (cy * cl + cx * sl) + cur[1];
+        const float pth = wrap_angle(lth + hh);
+        t[2] = sinf(pth);
+        t[3] = cosf(pth);
+        const float vx = a[s * sdim + 3], vy = a[s * sdim + 4];
+        v[0] = vx * cl - vy * sl;
+        v[1] = vy * cl + vx * sl;
+      }
+    }
+  }
+}
+
+// policy_emd += x_p after the condition layers (condition_attns.py:226)
+__global__ void k_add_rows(float* __restrict__ dst, const float* __restrict__ src, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] += src[i];
+}
+
+__global__ void k_fourier_test(const float* __restrict__ x4, int n, const float* __restrict__ div32, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * 128) return;
+  const int e = i >> 7, c = i & 127;
+  out[i] = fourier_feat(x4[e * 4 + (c >> 5)], c & 31, div32);
+}
+__global__ void k_wrap_test(const float* __restrict__ x, int n, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = wrap_angle(x[i]);
+}
+
+}  // namespace ps

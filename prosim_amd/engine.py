@@ -1,0 +1,301 @@
+"""ctypes binding of libprosim_hip.so (C ABI: include/prosim_hip.h).
+
+Thin by design: numpy arrays in, numpy arrays out, no torch types cross the boundary.  There is
+no CPU fallback -- if the HIP library is missing or no GPU is visible this module raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from .spec import ModelSpec
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libprosim_hip.so")
+_lib = None
+
+
+class PsConfig(C.Structure):
+    _fields_ = [
+        ("hidden", C.c_int32), ("heads", C.c_int32), ("head_dim", C.c_int32),
+        ("scene_layers", C.c_int32), ("scene_knn", C.c_int32), ("agent_knn", C.c_int32),
+        ("dec_layers", C.c_int32), ("dec_max_neigh", C.c_int32),
+        ("dec_prompt_radius", C.c_float), ("dec_scene_radius", C.c_float),
+        ("pol_layers", C.c_int32), ("pol_max_neigh", C.c_int32),
+        ("pol_agent_radius", C.c_float), ("pol_map_radius", C.c_float),
+        ("cond_layers", C.c_int32),
+        ("hist_steps", C.c_int32), ("obs_dim", C.c_int32), ("map_dim", C.c_int32),
+        ("map_pre_layers", C.c_int32), ("map_mlp_layers", C.c_int32),
+        ("obs_pre_layers", C.c_int32), ("obs_mlp_layers", C.c_int32),
+        ("target_steps", C.c_int32), ("state_dim", C.c_int32), ("motion_k", C.c_int32),
+        ("num_agent_types", C.c_int32), ("prompt_dim", C.c_int32),
+        ("replan_freq", C.c_int32), ("max_steps", C.c_int32),
+        ("dt", C.c_float), ("ln_eps", C.c_float),
+        ("device", C.c_int32),
+    ]
+
+
+def lib_path() -> str:
+    return _LIB_PATH
+
+
+def load_library():
+    """dlopen the engine.  Raises (never falls back) when the library has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise RuntimeError(f"{_LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(there is no CPU fallback for the rollout path)")
+    lib = C.CDLL(_LIB_PATH)
+    fp, u8p, i32p = C.POINTER(C.c_float), C.POINTER(C.c_uint8), C.POINTER(C.c_int32)
+    vp = C.c_void_p
+    lib.ps_last_error.restype = C.c_char_p
+    lib.ps_create.argtypes = [C.POINTER(PsConfig), C.c_int32, C.POINTER(C.c_char_p), C.POINTER(fp), C.POINTER(C.c_int64), C.POINTER(vp)]
+    lib.ps_destroy.argtypes = [vp]
+    lib.ps_destroy.restype = None
+    lib.ps_set_scene.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, fp, u8p, fp, fp, fp, u8p, fp, fp, fp, u8p, i32p, fp, fp]
+    lib.ps_set_conditions.argtypes = [vp, C.c_int32, fp, u8p, i32p, C.c_int32, fp, u8p, i32p]
+    lib.ps_set_future_obs.argtypes = [vp, fp]
+    for name in ("ps_encode_scene", "ps_generate_policy", "ps_reset_rollout", "ps_rollout", "ps_sync"):
+        getattr(lib, name).argtypes = [vp]
+    lib.ps_policy_step.argtypes = [vp, C.c_int32]
+    lib.ps_set_state.argtypes = [vp, C.c_int32, fp, fp]
+    lib.ps_get.argtypes = [vp, C.c_char_p, fp, C.c_int64]
+    lib.ps_get.restype = C.c_int64
+    lib.ps_num_agents.argtypes = [vp]
+    lib.ps_num_map_tokens.argtypes = [vp]
+    lib.ps_time_rollout.argtypes = [vp, C.c_int32, C.c_int32, fp, fp]
+    lib.ps_time_policy_kernel.argtypes = [vp, C.c_int32, fp]
+    lib.ps_test_pointnet.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, fp, u8p, fp]
+    lib.ps_test_fourier.argtypes = [vp, C.c_int32, fp, fp]
+    lib.ps_test_wrap.argtypes = [vp, C.c_int32, fp, fp]
+    lib.ps_test_attn.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, fp, fp, fp, i32p, i32p, C.c_int32, fp]
+    lib.ps_test_get_edges.argtypes = [vp, C.c_int32, i32p, i32p, fp, C.c_int64]
+    lib.ps_test_get_edges.restype = C.c_int64
+    _lib = lib
+    return lib
+
+
+EXPORTS = ["ps_create", "ps_destroy", "ps_last_error", "ps_set_scene", "ps_set_conditions", "ps_set_future_obs",
+           "ps_encode_scene", "ps_generate_policy", "ps_reset_rollout", "ps_policy_step", "ps_rollout", "ps_sync",
+           "ps_set_state", "ps_get", "ps_num_agents", "ps_num_map_tokens", "ps_time_rollout", "ps_time_policy_kernel",
+           "ps_test_pointnet", "ps_test_fourier", "ps_test_wrap", "ps_test_attn", "ps_test_get_edges"]
+
+
+def _f(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _u8(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint8))
+
+
+def _i32(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def fourier_tables() -> Dict[str, np.ndarray]:
+    """dim_t of FourierEmbeddingFix for 32/64/128 slots, computed with the reference's own torch
+    ops (models/layers/fourier_embedding.py:68-69) so the divisors are bit-identical."""
+    out = {}
+    for n in (32.0, 64, 128):
+        dim_t = torch.arange(n, dtype=torch.float32)
+        out[f"const.fourier_div{int(n)}"] = (10000 ** (2 * (dim_t // 2) / n)).numpy().astype(np.float32)
+    return out
+
+
+class Engine:
+    """One engine per GPU (``device`` = HIP ordinal).  Not thread-safe."""
+
+    def __init__(self, spec: ModelSpec, weights: Dict[str, np.ndarray], device: int = 0):
+        self.lib = load_library()
+        self.spec = spec
+        cfg = PsConfig(hidden=spec.hidden, heads=spec.heads, head_dim=spec.head_dim, scene_layers=spec.scene_layers,
+                       scene_knn=spec.scene_knn, agent_knn=spec.agent_knn, dec_layers=spec.dec_layers,
+                       dec_max_neigh=spec.dec_max_neigh, dec_prompt_radius=spec.dec_prompt_radius,
+                       dec_scene_radius=spec.dec_scene_radius, pol_layers=spec.pol_layers, pol_max_neigh=spec.pol_max_neigh,
+                       pol_agent_radius=spec.pol_agent_radius, pol_map_radius=spec.pol_map_radius, cond_layers=spec.cond_layers,
+                       hist_steps=spec.hist_steps, obs_dim=spec.obs_dim, map_dim=spec.map_dim,
+                       map_pre_layers=spec.map_pre_layers, map_mlp_layers=spec.map_mlp_layers,
+                       obs_pre_layers=spec.obs_pre_layers, obs_mlp_layers=spec.obs_mlp_layers,
+                       target_steps=spec.target_steps, state_dim=spec.state_dim, motion_k=spec.motion_k,
+                       num_agent_types=spec.num_agent_types, prompt_dim=spec.prompt_dim, replan_freq=spec.replan_freq,
+                       max_steps=spec.max_steps, dt=spec.dt, ln_eps=spec.ln_eps, device=device)
+        tensors = dict(weights)
+        tensors.update(fourier_tables())
+        names = sorted(tensors)
+        arrs = [np.ascontiguousarray(tensors[n], dtype=np.float32) for n in names]
+        c_names = (C.c_char_p * len(names))(*[n.encode() for n in names])
+        c_ptrs = (C.POINTER(C.c_float) * len(names))(*[_f(a) for a in arrs])
+        c_numel = (C.c_int64 * len(names))(*[a.size for a in arrs])
+        h = C.c_void_p()
+        rc = self.lib.ps_create(C.byref(cfg), len(names), c_names, c_ptrs, c_numel, C.byref(h))
+        self.h = h if rc == 0 else None
+        self._check(rc)
+        self._shape = None
+        self._slots = None
+
+    def _check(self, rc: int):
+        if rc != 0:
+            raise RuntimeError(f"libprosim_hip error {rc}: {self.lib.ps_last_error().decode()}")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.ps_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- scene
+    def set_scene(self, s: Dict[str, np.ndarray]):
+        f32 = lambda k: np.ascontiguousarray(s[k], dtype=np.float32)
+        msk = lambda k: np.ascontiguousarray(s[k]).astype(np.uint8)
+        map_input, obs_input, prompt = f32("map_input"), f32("obs_input"), f32("prompt")
+        B, M, P, _ = map_input.shape
+        N = obs_input.shape[1]
+        map_mask, obs_mask, pm = msk("map_mask"), msk("obs_mask"), msk("prompt_mask")
+        at = np.ascontiguousarray(s["agent_type"], dtype=np.int32)
+        ppos = f32("prompt_pos") if "prompt_pos" in s else f32("obs_pos")
+        phead = f32("prompt_head") if "prompt_head" in s else f32("obs_head")
+        keep = [map_input, obs_input, prompt, map_mask, obs_mask, pm, at, ppos, phead, f32("map_pos"), f32("map_head"),
+                f32("obs_pos"), f32("obs_head")]
+        self._check(self.lib.ps_set_scene(self.h, B, M, P, N, _f(map_input), _u8(map_mask), _f(keep[9]), _f(keep[10]),
+                                          _f(obs_input), _u8(obs_mask), _f(keep[11]), _f(keep[12]), _f(prompt), _u8(pm),
+                                          _i32(at), _f(ppos), _f(phead)))
+        self._shape = (B, N)
+        self._slots = np.nonzero(pm.reshape(-1))[0]
+        cond = s.get("cond") or {}
+        g, t = cond.get("goal"), cond.get("v_action_tag")
+        args = []
+        for c in (g, t):
+            if c is None or c["input"].shape[1] == 0:
+                args += [0, None, None, None]
+            else:
+                ci = np.ascontiguousarray(c["input"], dtype=np.float32)
+                cm = np.ascontiguousarray(c["mask"]).astype(np.uint8)
+                cp = np.ascontiguousarray(np.asarray(c["prompt_idx"])[..., 0], dtype=np.int32)
+                keep += [ci, cm, cp]
+                args += [ci.shape[1], _f(ci), _u8(cm), _i32(cp)]
+        self._check(self.lib.ps_set_conditions(self.h, *args))
+        if s.get("fut_obs_input") is not None:
+            fo = np.ascontiguousarray(s["fut_obs_input"], dtype=np.float32)
+            self._check(self.lib.ps_set_future_obs(self.h, _f(fo)))
+
+    # ---- stages (each enqueues on the engine's stream; results are read with get())
+    def encode_scene(self):
+        self._check(self.lib.ps_encode_scene(self.h))
+
+    def generate_policy(self):
+        self._check(self.lib.ps_generate_policy(self.h))
+
+    def reset_rollout(self):
+        self._check(self.lib.ps_reset_rollout(self.h))
+
+    def policy_step(self, t_idx: int):
+        self._check(self.lib.ps_policy_step(self.h, t_idx))
+
+    def rollout(self):
+        self._check(self.lib.ps_rollout(self.h))
+
+    def sync(self):
+        self._check(self.lib.ps_sync(self.h))
+
+    def set_state(self, traj: np.ndarray, vel: np.ndarray):
+        traj = np.ascontiguousarray(traj, dtype=np.float32)
+        vel = np.ascontiguousarray(vel, dtype=np.float32)
+        self._check(self.lib.ps_set_state(self.h, traj.shape[1], _f(traj), _f(vel)))
+
+    @property
+    def num_agents(self) -> int:
+        return self.lib.ps_num_agents(self.h)
+
+    @property
+    def num_map_tokens(self) -> int:
+        return self.lib.ps_num_map_tokens(self.h)
+
+    def get(self, name: str) -> np.ndarray:
+        sp, A, Mv = self.spec, self.num_agents, self.num_map_tokens
+        R, S = sp.n_replans, sp.n_replans * sp.replan_freq
+        shapes = {"traj": (A, S, 4), "vel": (A, S, 2), "motion_pred": (R, A, sp.motion_k, sp.target_steps, sp.state_dim),
+                  "reconst_pred": (A, 2), "policy_emd": (A, sp.hidden), "scene_tokens": (Mv + A, sp.hidden),
+                  "fused": (A, sp.hidden), "obs_in": (A, sp.hist_steps, sp.obs_dim), "cur_pos": (A, 2), "edge_counts": (8,)}
+        out = np.empty(shapes[name], np.float32)
+        n = self.lib.ps_get(self.h, name.encode(), _f(out), out.size)
+        if n < 0:
+            self._check(int(n))
+        return out
+
+    def padded(self, name: str) -> np.ndarray:
+        """Per-agent result scattered back to the padded [B, N, ...] slot layout of the inputs."""
+        a = self.get(name)
+        B, N = self._shape
+        out = np.zeros((B * N,) + a.shape[1:], np.float32)
+        out[self._slots] = a
+        return out.reshape((B, N) + a.shape[1:])
+
+    def time_rollout(self, warmup: int, iters: int):
+        ms = C.c_float()
+        st = (C.c_float * 3)()
+        self._check(self.lib.ps_time_rollout(self.h, warmup, iters, C.byref(ms), st))
+        return ms.value, list(st)
+
+    def time_policy_kernel(self, iters: int) -> float:
+        ms = C.c_float()
+        self._check(self.lib.ps_time_policy_kernel(self.h, iters, C.byref(ms)))
+        return ms.value
+
+    # ---- primitive test hooks
+    def test_pointnet(self, which: int, x: np.ndarray, mask: np.ndarray) -> np.ndarray:
+        x = np.ascontiguousarray(x, np.float32)
+        m = np.ascontiguousarray(mask).astype(np.uint8)
+        n, P = m.shape
+        out = np.empty((n, self.spec.hidden), np.float32)
+        self._check(self.lib.ps_test_pointnet(self.h, which, n, P, _f(x), _u8(m), _f(out)))
+        return out
+
+    def test_fourier(self, x4: np.ndarray) -> np.ndarray:
+        x4 = np.ascontiguousarray(x4, np.float32)
+        out = np.empty((x4.shape[0], 128), np.float32)
+        self._check(self.lib.ps_test_fourier(self.h, x4.shape[0], _f(x4), _f(out)))
+        return out
+
+    def test_wrap(self, x: np.ndarray) -> np.ndarray:
+        x = np.ascontiguousarray(x, np.float32)
+        out = np.empty_like(x)
+        self._check(self.lib.ps_test_wrap(self.h, x.size, _f(x), _f(out)))
+        return out
+
+    def layer_index(self, group: str, i: int) -> int:
+        sp = self.spec
+        order = [("a2a", sp.scene_layers), ("s2s", sp.scene_layers), ("p2p", sp.dec_layers), ("s2p", sp.dec_layers),
+                 ("a2p", sp.pol_layers), ("m2p", sp.pol_layers), ("cond", sp.cond_layers)]
+        base = 0
+        for g, n in order:
+            if g == group:
+                return base + i
+            base += n
+        raise KeyError(group)
+
+    def test_attn(self, layer_index: int, x_src, x_dst, rt, eoff, esrc, T: int = 0) -> np.ndarray:
+        x_src, x_dst, rt = (np.ascontiguousarray(a, np.float32) for a in (x_src, x_dst, rt))
+        eoff, esrc = np.ascontiguousarray(eoff, np.int32), np.ascontiguousarray(esrc, np.int32)
+        out = np.empty_like(x_dst)
+        self._check(self.lib.ps_test_attn(self.h, layer_index, x_src.shape[0], x_dst.shape[0], esrc.shape[0], _f(x_src),
+                                          _f(x_dst), _f(rt), _i32(eoff), _i32(esrc), T, _f(out)))
+        return out
+
+    def get_edges(self, which: int, cap: int = 1 << 20):
+        esrc, edst = np.empty(cap, np.int32), np.empty(cap, np.int32)
+        rt = np.empty((cap, 128), np.float32)
+        n = self.lib.ps_test_get_edges(self.h, which, _i32(esrc), _i32(edst), _f(rt), cap)
+        if n < 0:
+            self._check(int(n))
+        return esrc[:n].copy(), edst[:n].copy(), rt[:n].copy()
