@@ -118,6 +118,11 @@ int ps_set_state(ps_engine* e, int32_t steps, const float* traj, const float* ve
  *   "edge_counts" [8] (a2a, s2s, p2p, s2p, a2p, m2p of the last step, cond, 0) as float.
  * Returns the number of floats written, or a negative error. */
 int64_t ps_get(ps_engine* e, const char* name, float* dst, int64_t capacity);
+/* Per-agent rollout ADE / FDE (metrics/motion_pred.py:31-76, 125-143) computed on device into a
+ * caller-owned DEVICE buffer out_dev [A, 2] (e.g. a torch tensor handed to an RCCL all-gather);
+ * gt_dev [A, max_steps, 2] is a device pointer to the ground-truth future in the agent-init frame,
+ * or NULL for displacement from the origin.  Enqueued on the engine's stream. */
+int ps_rollout_metric(ps_engine* e, const float* gt_dev, float* out_dev);
 int32_t ps_num_agents(ps_engine* e);
 int32_t ps_num_map_tokens(ps_engine* e);
 

@@ -552,7 +552,9 @@ extern "C" int ps_set_scene(ps_engine* e, int32_t B, int32_t M, int32_t P, int32
   auto mn = [](int a, int b) { return a < b ? a : b; };
   const int tokS = e->maxA_scene + e->maxM_scene;
   int d_a2a = mn(c.agent_knn, e->maxA_scene), d_s2s = mn(c.scene_knn, tokS);
-  int d_p2p = mn(c.dec_max_neigh, std::max(1, e->maxA_scene - 1)), d_s2p = mn(c.dec_max_neigh, tokS);
+  // radius_graph(loop=False) scans cap+1 matches and then drops the self match: a query whose own
+  // index is not among the first cap+1 keeps all cap+1 of them
+  int d_p2p = mn(c.dec_max_neigh + 1, std::max(1, e->maxA_scene - 1)), d_s2p = mn(c.dec_max_neigh, tokS);
   int d_a2p = mn(c.pol_max_neigh, e->maxA_scene), d_m2p = mn(c.pol_max_neigh, std::max(1, e->maxM_scene));
   if (edge_alloc(e->e_a2a, A, (size_t)A * d_a2a, d_a2a) || edge_alloc(e->e_s2s, Mv + A, (size_t)(Mv + A) * d_s2s, d_s2s) ||
       edge_alloc(e->e_p2p, A, (size_t)A * d_p2p, d_p2p) || edge_alloc(e->e_s2p, A, (size_t)A * d_s2p, d_s2p) ||
@@ -947,6 +949,18 @@ extern "C" int ps_set_state(ps_engine* e, int32_t steps, const float* traj, cons
                           e->A, hipMemcpyHostToDevice, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
   e->reset = true;
+  return PS_OK;
+}
+
+extern "C" int ps_rollout_metric(ps_engine* e, const float* gt_dev, float* out_dev) {
+  if (!e || !e->reset) return fail(PS_E_STATE, "ps_rollout_metric before a rollout");
+  if (!out_dev) return fail(PS_E_ARG, "null output");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  const ps_config& c = e->cfg;
+  const int R = (c.max_steps + c.replan_freq - 1) / c.replan_freq;
+  hipLaunchKernelGGL(k_rollout_metric, dim3((e->A + 127) / 128), dim3(128), 0, e->stream, (const float*)e->d_traj.p, e->stride_steps,
+                     c.hist_steps, R * c.replan_freq, gt_dev, e->A, out_dev);
+  HIPCHK(hipGetLastError());
   return PS_OK;
 }
 

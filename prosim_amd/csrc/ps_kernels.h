@@ -546,6 +546,27 @@ __global__ __launch_bounds__(128) void k_policy_head(HeadW w, const float* __res
   }
 }
 
+// Rollout metric (metrics/motion_pred.py:31-76, rollout ADE / FDE): per-agent mean and final L2
+// displacement between the rolled-out xy and a ground-truth future (nullptr -> the origin, i.e.
+// distance travelled in the agent-init frame).  out [A][2] may be any device buffer (e.g. a torch
+// tensor that is then all-gathered over RCCL).
+__global__ void k_rollout_metric(const float* __restrict__ traj, int stride_steps, int hist, int steps,
+                                 const float* __restrict__ gt /*[A][steps][2] or null*/, int n_agents,
+                                 float* __restrict__ out) {
+  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= n_agents) return;
+  float sum = 0.f, last = 0.f;
+  for (int s = 0; s < steps; ++s) {
+    const float* t = traj + ((size_t)a * stride_steps + hist + s) * 4;
+    const float gx = gt ? gt[((size_t)a * steps + s) * 2] : 0.f, gy = gt ? gt[((size_t)a * steps + s) * 2 + 1] : 0.f;
+    const float dx = t[0] - gx, dy = t[1] - gy;
+    last = sqrtf(dx * dx + dy * dy);
+    sum += last;
+  }
+  out[2 * a] = sum / (float)steps;
+  out[2 * a + 1] = last;
+}
+
 // policy_emd += x_p after the condition layers (condition_attns.py:226)
 __global__ void k_add_rows(float* __restrict__ dst, const float* __restrict__ src, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;

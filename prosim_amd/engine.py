@@ -66,6 +66,7 @@ def load_library():
     lib.ps_set_state.argtypes = [vp, C.c_int32, fp, fp]
     lib.ps_get.argtypes = [vp, C.c_char_p, fp, C.c_int64]
     lib.ps_get.restype = C.c_int64
+    lib.ps_rollout_metric.argtypes = [vp, vp, vp]
     lib.ps_num_agents.argtypes = [vp]
     lib.ps_num_map_tokens.argtypes = [vp]
     lib.ps_time_rollout.argtypes = [vp, C.c_int32, C.c_int32, fp, fp]
@@ -82,7 +83,7 @@ def load_library():
 
 EXPORTS = ["ps_create", "ps_destroy", "ps_last_error", "ps_set_scene", "ps_set_conditions", "ps_set_future_obs",
            "ps_encode_scene", "ps_generate_policy", "ps_reset_rollout", "ps_policy_step", "ps_rollout", "ps_sync",
-           "ps_set_state", "ps_get", "ps_num_agents", "ps_num_map_tokens", "ps_time_rollout", "ps_time_policy_kernel",
+           "ps_set_state", "ps_get", "ps_rollout_metric", "ps_num_agents", "ps_num_map_tokens", "ps_time_rollout", "ps_time_policy_kernel",
            "ps_test_pointnet", "ps_test_fourier", "ps_test_wrap", "ps_test_attn", "ps_test_get_edges"]
 
 
@@ -240,6 +241,10 @@ class Engine:
         out = np.zeros((B * N,) + a.shape[1:], np.float32)
         out[self._slots] = a
         return out.reshape((B, N) + a.shape[1:])
+
+    def rollout_metric(self, out_dev_ptr: int, gt_dev_ptr: int = 0):
+        """Per-agent (ADE, FDE) into a caller-owned device buffer [A, 2] (pass tensor.data_ptr())."""
+        self._check(self.lib.ps_rollout_metric(self.h, C.c_void_p(gt_dev_ptr or None), C.c_void_p(out_dev_ptr)))
 
     def time_rollout(self, warmup: int, iters: int):
         ms = C.c_float()
