@@ -145,6 +145,8 @@ int ps_test_wrap(ps_engine* e, int32_t n, const float* x, float* out);
 int ps_test_attn(ps_engine* e, int32_t layer_index, int32_t Ns, int32_t Nd, int32_t E, const float* x_src,
                  const float* x_dst, const float* rt, const int32_t* eoff, const int32_t* esrc, int32_t T, float* out);
 /* Read back an edge set built by the last stage: which = 0 a2a, 1 s2s, 2 p2p, 3 s2p, 4 a2p, 5 m2p. */
+/* Micro-benchmark: nwg workgroups stream the same mbytes buffer (depth x 16 float4 in flight per thread). */
+int ps_test_stream(ps_engine* e, int32_t mbytes, int32_t nwg, int32_t depth, int32_t iters, float* ms_out);
 int64_t ps_test_get_edges(ps_engine* e, int32_t which, int32_t* esrc, int32_t* edst, float* rt, int64_t capacity);
 
 #ifdef __cplusplus

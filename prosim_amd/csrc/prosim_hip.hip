@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <unordered_map>
@@ -221,6 +222,31 @@ void build_attn(Builder& b, const std::string& p, AttnW& w) {
   b.slot(&w.vb, b.put(vb));
   b.slot(&w.Wkv_t, b.put(wkv));
   b.slot(&w.bkv, b.put(bkv));
+  // packed small vectors (ps_attn.h SP_* offsets)
+  {
+    std::vector<float> sp(SP_SIZE, 0.f);
+    auto cp = [&](int off, const std::string& name, int n) {
+      const float* s_ = b.get(name, n);
+      if (s_) std::copy(s_, s_ + n, sp.begin() + off);
+    };
+    cp(SP_LN_DST_W, p + dn + ".weight", D);
+    cp(SP_LN_DST_B, p + dn + ".bias", D);
+    cp(SP_BQ, p + ".to_q.bias", D);
+    cp(SP_BS, p + ".to_s.bias", D);
+    cp(SP_BG, p + ".to_g.bias", D);
+    std::copy(kb.begin(), kb.end(), sp.begin() + SP_KB);
+    std::copy(vb.begin(), vb.end(), sp.begin() + SP_VB);
+    cp(SP_BOUT, p + ".to_out.bias", D);
+    cp(SP_LN_POST_W, p + ".attn_postnorm.weight", D);
+    cp(SP_LN_POST_B, p + ".attn_postnorm.bias", D);
+    cp(SP_LN_FFPRE_W, p + ".ff_prenorm.weight", D);
+    cp(SP_LN_FFPRE_B, p + ".ff_prenorm.bias", D);
+    cp(SP_B1, p + ".ff_mlp.0.bias", FF);
+    cp(SP_B2, p + ".ff_mlp.3.bias", D);
+    cp(SP_LN_FFPOST_W, p + ".ff_postnorm.weight", D);
+    cp(SP_LN_FFPOST_B, p + ".ff_postnorm.bias", D);
+    b.slot(&w.sp, b.put(sp));
+  }
 }
 
 // sequential indices of the reference MLP's nn.Sequential (models/layers/mlp.py:475-494)
@@ -704,13 +730,14 @@ int launch_chain(ps_engine* e, float* x, int Nd, int step0, int nsteps, int maxd
   if (force_T) T = force_T;
   if (attn_lds_floats<1>(maxdeg) * sizeof(float) > 150 * 1024) return fail(PS_E_ARG, "degree bound too large for LDS");
   const float eps = e->cfg.ln_eps;
+  static const int flags = getenv("PS_CHAIN_FLAGS") ? atoi(getenv("PS_CHAIN_FLAGS")) : 0;  // ablation only
   if (timed && e->time_chain) (void)hipEventRecord(e->ev0, st);
   if (T == 4)
-    hipLaunchKernelGGL(k_attn_chain<4>, dim3((Nd + 3) / 4), dim3(WG), attn_lds_floats<4>(maxdeg) * sizeof(float), st, x, Nd, steps, nsteps, maxdeg, eps);
+    hipLaunchKernelGGL(k_attn_chain<4>, dim3((Nd + 3) / 4), dim3(WG), attn_lds_floats<4>(maxdeg) * sizeof(float), st, x, Nd, steps, nsteps, maxdeg, eps, flags);
   else if (T == 2)
-    hipLaunchKernelGGL(k_attn_chain<2>, dim3((Nd + 1) / 2), dim3(WG), attn_lds_floats<2>(maxdeg) * sizeof(float), st, x, Nd, steps, nsteps, maxdeg, eps);
+    hipLaunchKernelGGL(k_attn_chain<2>, dim3((Nd + 1) / 2), dim3(WG), attn_lds_floats<2>(maxdeg) * sizeof(float), st, x, Nd, steps, nsteps, maxdeg, eps, flags);
   else
-    hipLaunchKernelGGL(k_attn_chain<1>, dim3(Nd), dim3(WG), attn_lds_floats<1>(maxdeg) * sizeof(float), st, x, Nd, steps, nsteps, maxdeg, eps);
+    hipLaunchKernelGGL(k_attn_chain<1>, dim3(Nd), dim3(WG), attn_lds_floats<1>(maxdeg) * sizeof(float), st, x, Nd, steps, nsteps, maxdeg, eps, flags);
   if (timed && e->time_chain) {
     (void)hipEventRecord(e->ev1, st);
     (void)hipEventSynchronize(e->ev1);
@@ -1144,4 +1171,46 @@ extern "C" int64_t ps_test_get_edges(ps_engine* e, int32_t which, int32_t* esrc,
       (rt && hipMemcpy(rt, s.rt.p, sizeof(float) * (size_t)E * 128, hipMemcpyDeviceToHost) != hipSuccess))
     return fail(PS_E_HIP, "memcpy");
   return E;
+}
+
+// ---- micro-benchmark hook: how fast can `nwg` workgroups (256 threads each) stream the SAME
+// `mbytes` buffer through their CUs with plain float4 loads, `depth` x 16 loads in flight per thread?
+namespace {
+template <int DEPTH>
+__global__ __launch_bounds__(256, 1) void k_stream_test(const float* __restrict__ buf, size_t n4, float* out) {
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  const size_t stride = 256;
+  for (size_t i = threadIdx.x; i + (16 * DEPTH - 1) * stride < n4; i += 16 * DEPTH * stride) {
+    float4 v[16 * DEPTH];
+#pragma unroll
+    for (int j = 0; j < 16 * DEPTH; ++j) v[j] = ldg4(buf + 4 * (i + j * stride));
+#pragma unroll
+    for (int j = 0; j < 16 * DEPTH; ++j) { acc.x += v[j].x; acc.y += v[j].y; acc.z += v[j].z; acc.w += v[j].w; }
+  }
+  if (acc.x + acc.y + acc.z + acc.w == 12345.678f) out[blockIdx.x] = acc.x;
+}
+}  // namespace
+extern "C" int ps_test_stream(ps_engine* e, int32_t mbytes, int32_t nwg, int32_t depth, int32_t iters, float* ms_out) {
+  if (!e) return fail(PS_E_ARG, "null engine");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  DevBuf<float> buf, out;
+  const size_t n = (size_t)mbytes * 1024 * 1024 / 4;
+  if (buf.ensure(n) || out.ensure(4096)) return fail(PS_E_HIP, "alloc");
+  HIPCHK(hipMemsetAsync(buf.p, 0, n * 4, e->stream));
+  hipEvent_t a, b;
+  HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
+  for (int it = -1; it < iters; ++it) {
+    if (it == 0) HIPCHK(hipEventRecord(a, e->stream));
+    if (depth == 1) hipLaunchKernelGGL(k_stream_test<1>, dim3(nwg), dim3(256), 0, e->stream, (const float*)buf.p, n / 4, out.p);
+    else if (depth == 2) hipLaunchKernelGGL(k_stream_test<2>, dim3(nwg), dim3(256), 0, e->stream, (const float*)buf.p, n / 4, out.p);
+    else hipLaunchKernelGGL(k_stream_test<3>, dim3(nwg), dim3(256), 0, e->stream, (const float*)buf.p, n / 4, out.p);
+  }
+  HIPCHK(hipEventRecord(b, e->stream));
+  HIPCHK(hipEventSynchronize(b));
+  float ms = 0;
+  HIPCHK(hipEventElapsedTime(&ms, a, b));
+  *ms_out = ms / iters;
+  (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+  buf.release(); out.release();
+  return PS_OK;
 }

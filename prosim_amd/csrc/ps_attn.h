@@ -30,7 +30,13 @@ struct AttnW {
   const float *ln_post_w, *ln_post_b, *ln_ffpre_w, *ln_ffpre_b;
   const float *W1_t, *b1, *W2_t, *b2, *ln_ffpost_w, *ln_ffpost_b;
   const float *Wkv_t, *bkv;                         // [128][256] K-major (k | v), [256]
+  const float* sp;                                  // packed small vectors, SP_* offsets below (2432 floats)
 };
+// offsets (floats) inside AttnW::sp -- one coalesced load per layer stages them in LDS, so no
+// bias / LayerNorm-parameter load ever sits on the layer's dependency chain
+enum : int { SP_LN_DST_W = 0, SP_LN_DST_B = 128, SP_BQ = 256, SP_BS = 384, SP_BG = 512, SP_KB = 640, SP_VB = 768,
+             SP_BOUT = 896, SP_LN_POST_W = 1024, SP_LN_POST_B = 1152, SP_LN_FFPRE_W = 1280, SP_LN_FFPRE_B = 1408,
+             SP_B1 = 1536, SP_B2 = 2048, SP_LN_FFPOST_W = 2176, SP_LN_FFPOST_B = 2304, SP_SIZE = 2432 };
 
 struct ChainStep {
   AttnW w;
@@ -41,12 +47,13 @@ struct ChainStep {
 };
 
 // LDS plan (floats): rows 6*128*T + 512*T | big 4*8*QP (q~ image, then per-wave partial a_r)
-// | un = max(1024*T partial sums, 8*maxdeg*T scores) | avp 4*128 | ml 4*16 | cq 8*T
+// | un = max(3*512*T partial sums, 8*maxdeg*T scores) | avp 4*128 | ml 4*16 | cq 8*T
 template <int T>
 __host__ __device__ constexpr size_t attn_lds_floats(int maxdeg) {
-  size_t un = (size_t)1024 * T;
+  size_t un = (size_t)1536 * T;
   size_t sc = (size_t)8 * maxdeg * T;
-  return (size_t)(6 * 128 + 512) * T + 4 * 8 * QP + (un > sc ? un : sc) + 4 * 128 + 4 * 16 + 8 * T + 64;
+  return (size_t)(6 * 128 + 512) * T + 4 * 8 * QP + (un > sc ? un : sc) + 4 * 128 + 4 * 16 + 8 * T + 64 +
+         2 * SP_SIZE + (size_t)maxdeg * T;
 }
 
 // 8 partial sums (one per head) held by each of 8 consecutive lanes -> lane cc ends with the
@@ -69,9 +76,63 @@ __device__ __forceinline__ float reduce8_to_lane(const float (&a)[8], int cc) {
   return keep + __shfl_xor(send, 1);
 }
 
+// ---- weight streaming.  With one destination row per workgroup a layer is GEMV work: 960 KB of
+// fp32 weights stream through each CU per layer and nothing is reused, so the kernel is bound by
+// how many bytes it keeps in flight and by the length of its dependency chain.
+//  * Weights do not depend on activations: every 16-row weight chunk (16 x float4 per thread =
+//    64 KB per workgroup) is requested one full chunk AHEAD of the chunk being multiplied, into the
+//    other of two register sets (plain global loads survive s_barrier; the compiler's in-order
+//    vmcnt lets the older set complete while the newer flies).
+//  * Every GEMV is WAVE-LOCAL: a wave owns a block of output columns and all of K, its lanes split
+//    K, and the partial sums meet by shuffles -- no LDS partial buffer, one barrier per stage.
+struct WC {
+  float4 w[16];
+};
+__device__ __forceinline__ void wload(WC& c, const float* __restrict__ p, int N) {
+#pragma unroll
+  for (int i = 0; i < 16; ++i) c.w[i] = ldg4(p + (size_t)i * N);
+}
+template <int T>
+__device__ __forceinline__ void wfma(const WC& c, const float* x, int xs, float (&acc)[T][4]) {
+  // row-outer: 16 x-values (4 x ds_read_b128) live at a time, not 16*T
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    float xv[16];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float4 v = *reinterpret_cast<const float4*>(x + t * xs + 4 * i);
+      xv[4 * i] = v.x; xv[4 * i + 1] = v.y; xv[4 * i + 2] = v.z; xv[4 * i + 3] = v.w;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      acc[t][0] = fmaf(xv[i], c.w[i].x, acc[t][0]);
+      acc[t][1] = fmaf(xv[i], c.w[i].y, acc[t][1]);
+      acc[t][2] = fmaf(xv[i], c.w[i].z, acc[t][2]);
+      acc[t][3] = fmaf(xv[i], c.w[i].w, acc[t][3]);
+    }
+  }
+}
+template <int T>
+__device__ __forceinline__ void zero_acc(float (&acc)[T][4]) {
+#pragma unroll
+  for (int t = 0; t < T; ++t) acc[t][0] = acc[t][1] = acc[t][2] = acc[t][3] = 0.f;
+}
+// sum the partials of the lanes that share output columns: lane bits >= LOWBITS index the k-group
+template <int T, int LOW>
+__device__ __forceinline__ void fold_kgroups(float (&acc)[T][4]) {
+#pragma unroll
+  for (int o = LOW; o < 64; o <<= 1) {
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[t][j] += __shfl_xor(acc[t][j], o);
+    }
+  }
+}
+
 template <int T>
 __global__ __launch_bounds__(WG, 1) void k_attn_chain(float* __restrict__ x, int Nd, const ChainStep* __restrict__ steps,
-                                                     int nsteps, int maxdeg, float eps) {
+                                                     int nsteps, int maxdeg, float eps, int flags) {
   constexpr int W = 4 / T;  // waves per destination in the edge phase
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* xs = smem;                 // [T][128] residual stream
@@ -79,73 +140,131 @@ __global__ __launch_bounds__(WG, 1) void k_attn_chain(float* __restrict__ x, int
   float* qb = xn + 128 * T;         // [T][128] q
   float* sb = qb + 128 * T;         // [T][128] to_s(x_dst)
   float* gb = sb + 128 * T;         // [T][128] to_g's x_dst half (+bias)
-  float* ag = gb + 128 * T;         // [T][128] aggregated message
+  float* ag = gb + 128 * T;         // [T][128] aggregated message, then the gated update u
   float* f1 = ag + 128 * T;         // [T][512]
   float* big = f1 + 512 * T;        // [4][8][QP]
-  const size_t un_sz = ((size_t)1024 * T > (size_t)8 * maxdeg * T) ? (size_t)1024 * T : (size_t)8 * maxdeg * T;
-  float* un = big + 4 * 8 * QP;     // partial sums | scores
+  const size_t un_sz = ((size_t)1536 * T > (size_t)8 * maxdeg * T) ? (size_t)1536 * T : (size_t)8 * maxdeg * T;
+  float* un = big + 4 * 8 * QP;     // scores
   float* avp = un + un_sz;          // [4][128]
   float* ml = avp + 4 * 128;        // [4][16]: per wave (max[8] | sum[8])
   float* cq = ml + 4 * 16;          // [T][8]
+  float* spb = cq + 8 * T + 56;     // [2][SP_SIZE] small per-layer vectors, double-buffered
+  int* esl = reinterpret_cast<int*>(spb + 2 * SP_SIZE);  // [T][maxdeg] source rows of the current edge lists
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  // N = 128 GEMVs: wave -> 32 output columns; lane -> (c8: 4 columns, kgl: 16-row k-group)
+  const int c8 = lane & 7, kgl = lane >> 3;
+  const int ncol = wave * 32 + 4 * c8;
+  const size_t woff = (size_t)(kgl * 16) * 128 + ncol;
+  // N = 512 (FFN up): wave -> 128 columns; lane -> (c32: 4 columns, k2: 64-row half)
+  const int c32 = lane & 31, k2 = lane >> 5;
+  const int ncol5 = wave * 128 + 4 * c32;
   const int row0 = blockIdx.x * T;
+  // two register sets, one chunk in flight behind the one being multiplied.  (Three sets / two
+  // chunks in flight measured no faster -- a CU's 4 waves already pull ~100 GB/s, the per-CU
+  // L2->register ceiling measured by ps_test_stream -- and spill at T = 4.)
+  WC wA, wB;
+  wload(wA, steps[0].w.Wq_t + woff, 128);
+  // small vectors of layer 0 -> LDS buffer 0 (608 float4: threads take float4 tid, tid+256, tid+512)
+  float4 spr[3];
+  auto sp_load = [&](const float* __restrict__ sp) {
+    spr[0] = ldg4(sp + 4 * tid);
+    spr[1] = ldg4(sp + 4 * (tid + 256));
+    if (tid + 512 < SP_SIZE / 4) spr[2] = ldg4(sp + 4 * (tid + 512));
+  };
+  auto sp_store = [&](float* dst) {
+    *reinterpret_cast<float4*>(dst + 4 * tid) = spr[0];
+    *reinterpret_cast<float4*>(dst + 4 * (tid + 256)) = spr[1];
+    if (tid + 512 < SP_SIZE / 4) *reinterpret_cast<float4*>(dst + 4 * (tid + 512)) = spr[2];
+  };
+  sp_load(steps[0].w.sp);
   // load the T residual rows (rows past Nd are zero-filled and never stored)
   for (int i = tid; i < T * 128; i += WG) {
     const int t = i >> 7, r = row0 + t;
-    xs[i] = (r < Nd) ? x[(size_t)r * 128 + (i & 127)] : 0.f;
+    xs[i] = (r < Nd) ? ldg1(x + (size_t)r * 128 + (i & 127)) : 0.f;
   }
+  sp_store(spb);
+  __syncthreads();
+  ln_rows<T>(xs, 128, xn, 128, spb + SP_LN_DST_W, spb + SP_LN_DST_B, eps, false);
   __syncthreads();
 
   for (int s = 0; s < nsteps; ++s) {
     const ChainStep& st = steps[s];
     const AttnW& w = st.w;
-    // ---- pre-norm of the destination rows + q / s / gate(x) projections (:61-69, :106-107, :114)
-    ln_rows<T>(xs, 128, xn, 128, w.ln_dst_w, w.ln_dst_b, eps, false);
+    const float* sp = spb + (s & 1) * SP_SIZE;          // this layer's small vectors (LDS)
+    float* sp_next = spb + ((s + 1) & 1) * SP_SIZE;     // filled mid-layer for the next one
+    if (s + 1 < nsteps) sp_load(steps[s + 1].w.sp);
+    // ---- edge list of each destination -> LDS (source rows), so the row gathers below never wait on an index
+    const int t = wave / W, wi = wave % W;
+    const int r = row0 + t;
+    const int e_beg = (r < Nd) ? ldgi(st.eoff + r) : 0;
+    const int deg = ((r < Nd) && !(flags & 1)) ? (ldgi(st.eoff + r + 1) - e_beg) : 0;
+    int* el = esl + t * maxdeg;
+    for (int e = wi * 64 + lane; e < deg; e += 64 * W) el[e] = ldgi(st.esrc + e_beg + e);
+    // ---- q / s / gate(x) projections of the pre-normed rows (:61-69, :106-107, :114); xn = LN_dst(x)
+    {
+      float acc[T][4];
+      zero_acc<T>(acc);
+      wload(wB, w.Ws_t + woff, 128);
+      wfma<T>(wA, xn + kgl * 16, 128, acc);                                             // Wq
+      fold_kgroups<T, 8>(acc);
+      if (kgl == 0) {
+#pragma unroll
+        for (int tt = 0; tt < T; ++tt)
+          *reinterpret_cast<float4*>(qb + tt * 128 + ncol) =
+              make_float4(acc[tt][0] + sp[SP_BQ + ncol], acc[tt][1] + sp[SP_BQ + ncol + 1], acc[tt][2] + sp[SP_BQ + ncol + 2],
+                          acc[tt][3] + sp[SP_BQ + ncol + 3]);
+      }
+      zero_acc<T>(acc);
+      wload(wA, w.Wgx_t + woff, 128);
+      wfma<T>(wB, xn + kgl * 16, 128, acc);                                             // Ws
+      fold_kgroups<T, 8>(acc);
+      if (kgl == 0) {
+#pragma unroll
+        for (int tt = 0; tt < T; ++tt)
+          *reinterpret_cast<float4*>(sb + tt * 128 + ncol) =
+              make_float4(acc[tt][0] + sp[SP_BS + ncol], acc[tt][1] + sp[SP_BS + ncol + 1], acc[tt][2] + sp[SP_BS + ncol + 2],
+                          acc[tt][3] + sp[SP_BS + ncol + 3]);
+      }
+      zero_acc<T>(acc);
+      // q~ chunk: wave -> heads 2*wave, 2*wave+1; lane -> (k2 = lane >> 5, 4 columns c32); rows 16*head..
+      wload(wB, w.Wkr_g + (size_t)((2 * wave + k2) * 16) * 128 + 4 * c32, 128);
+      wfma<T>(wA, xn + kgl * 16, 128, acc);                                             // Wgx
+      fold_kgroups<T, 8>(acc);
+      if (kgl == 0) {
+#pragma unroll
+        for (int tt = 0; tt < T; ++tt)
+          *reinterpret_cast<float4*>(gb + tt * 128 + ncol) =
+              make_float4(acc[tt][0] + sp[SP_BG + ncol], acc[tt][1] + sp[SP_BG + ncol + 1], acc[tt][2] + sp[SP_BG + ncol + 2],
+                          acc[tt][3] + sp[SP_BG + ncol + 3]);
+      }
+    }
     __syncthreads();
-    gemv_rows<T, false>(xn, 128, 128, w.Wq_t, 128, w.bq, un, qb, 128, false);
-    gemv_rows<T, false>(xn, 128, 128, w.Ws_t, 128, w.bs, un, sb, 128, false);
-    gemv_rows<T, false>(xn, 128, 128, w.Wgx_t, 128, w.bg, un, gb, 128, false);
     // ---- q~[t][h][c] = sum_d q[t][16h+d] * Wkr_g[16h+d][c];  cq[t][h] = <q_h, kb_h>
     {
-      const int h = tid >> 5, c4 = tid & 31;
+      const int h = 2 * wave + k2;
       float acc[T][4];
+      zero_acc<T>(acc);
+      wfma<T>(wB, qb + h * 16, 128, acc);                                               // Wkr_g
 #pragma unroll
-      for (int t = 0; t < T; ++t) acc[t][0] = acc[t][1] = acc[t][2] = acc[t][3] = 0.f;
-#pragma unroll
-      for (int d = 0; d < DH; ++d) {
-        const float4 wv = *reinterpret_cast<const float4*>(w.Wkr_g + (size_t)(h * DH + d) * 128 + 4 * c4);
-#pragma unroll
-        for (int t = 0; t < T; ++t) {
-          const float qv = qb[t * 128 + h * DH + d];
-          acc[t][0] = fmaf(qv, wv.x, acc[t][0]);
-          acc[t][1] = fmaf(qv, wv.y, acc[t][1]);
-          acc[t][2] = fmaf(qv, wv.z, acc[t][2]);
-          acc[t][3] = fmaf(qv, wv.w, acc[t][3]);
-        }
-      }
-#pragma unroll
-      for (int t = 0; t < T; ++t)
-        *reinterpret_cast<float4*>(big + (size_t)(t * 8 + h) * QP + 4 * c4) =
-            make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+      for (int tt = 0; tt < T; ++tt)
+        *reinterpret_cast<float4*>(big + (size_t)(tt * 8 + h) * QP + 4 * c32) =
+            make_float4(acc[tt][0], acc[tt][1], acc[tt][2], acc[tt][3]);
       if (tid < 8 * T) {
-        const int t = tid >> 3, hh = tid & 7;
+        const int tt = tid >> 3, hh = tid & 7;
         float a = 0.f;
-        for (int d = 0; d < DH; ++d) a = fmaf(qb[t * 128 + hh * DH + d], w.kb[hh * DH + d], a);
+        for (int d = 0; d < DH; ++d) a = fmaf(qb[tt * 128 + hh * DH + d], sp[SP_KB + hh * DH + d], a);
         cq[tid] = a;
       }
     }
     __syncthreads();
 
-    // ---- edge phase: wave -> (destination t, sub-wave wi); lane -> (edge slot es, 16-column chunk cc)
-    const int t = wave / W, wi = wave % W;
-    const int r = row0 + t;
-    const int e_beg = (r < Nd) ? st.eoff[r] : 0;
-    const int deg = (r < Nd) ? (st.eoff[r + 1] - e_beg) : 0;
-    const int es = lane >> 3, cc = lane & 7;
+    // ---- edge phase: wave -> (destination t, sub-wave wi)
     float* sc = un + (size_t)t * maxdeg * 8;
     {
       // pass 1: scores s[e][h] = (<q_h, k_src,h> + <q~_h, r~_e> + cq_h) * Dh^-0.5   (:88-90)
+      // lane -> (edge slot es of 8, 16-column chunk cc of 8); the 8 heads' partials meet by a transposing reduce
+      const int es = lane >> 3, cc = lane & 7;
       float qt[8][16];
 #pragma unroll
       for (int h = 0; h < 8; ++h)
@@ -158,25 +277,36 @@ __global__ __launch_bounds__(WG, 1) void k_attn_chain(float* __restrict__ x, int
 #pragma unroll
       for (int d = 0; d < 16; ++d) qh[d] = qb[t * 128 + cc * DH + d];
       const float cqh = cq[t * 8 + cc];
-      for (int e0 = wi * 8; e0 < deg; e0 += 8 * W) {
-        const int e = e0 + es;
-        const bool ok = e < deg;
-        const int ee = ok ? e : deg - 1;
-        const int src = st.esrc[e_beg + ee];
+      float4 rn[4], kn[4];
+      auto gather1 = [&](int e0) {
+        const int e = e0 + es, ee = e < deg ? e : deg - 1;
         const float* rr = st.rt + (size_t)(e_beg + ee) * 128;
-        const float* kr = st.kv + (size_t)src * 256 + cc * DH;
-        float rv[16];
+        const float* kr = st.kv + (size_t)el[ee] * 256 + cc * DH;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const float4 v = *reinterpret_cast<const float4*>(rr + 4 * (cc + 8 * i));
-          rv[4 * i] = v.x; rv[4 * i + 1] = v.y; rv[4 * i + 2] = v.z; rv[4 * i + 3] = v.w;
+          rn[i] = ldg4(rr + 4 * (cc + 8 * i));
+          kn[i] = ldg4(kr + 4 * i);
         }
+      };
+      int e0 = wi * 8;
+      if (e0 < deg) gather1(e0);
+      while (e0 < deg) {
+        const int e = e0 + es;
+        const bool ok = e < deg;
+        float rv[16];
+        float4 kc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          rv[4 * i] = rn[i].x; rv[4 * i + 1] = rn[i].y; rv[4 * i + 2] = rn[i].z; rv[4 * i + 3] = rn[i].w;
+          kc[i] = kn[i];
+        }
+        e0 += 8 * W;
+        if (e0 < deg) gather1(e0);   // next edges' rows fly while these are multiplied
         float qk = 0.f;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const float4 v = *reinterpret_cast<const float4*>(kr + 4 * i);
-          qk = fmaf(qh[4 * i], v.x, qk); qk = fmaf(qh[4 * i + 1], v.y, qk);
-          qk = fmaf(qh[4 * i + 2], v.z, qk); qk = fmaf(qh[4 * i + 3], v.w, qk);
+          qk = fmaf(qh[4 * i], kc[i].x, qk); qk = fmaf(qh[4 * i + 1], kc[i].y, qk);
+          qk = fmaf(qh[4 * i + 2], kc[i].z, qk); qk = fmaf(qh[4 * i + 3], kc[i].w, qk);
         }
         float p[8];
 #pragma unroll
@@ -190,6 +320,8 @@ __global__ __launch_bounds__(WG, 1) void k_attn_chain(float* __restrict__ x, int
         if (ok) sc[(size_t)e * 8 + cc] = (tot + qk + cqh) * 0.25f;
       }
     }
+    // pass 1 is done with the registers: the to_v_r fold's weights leave now and land under the softmax and pass 2
+    wload(wA, w.Wvr_gt + woff, 128);
     __syncthreads();
     // softmax over the destination's edges, per head (torch_geometric.utils.softmax: max-shift,
     // exp, / (sum + 1e-16)); lanes over edges.  Every wave of the destination finds the max
@@ -231,65 +363,47 @@ __global__ __launch_bounds__(WG, 1) void k_attn_chain(float* __restrict__ x, int
     __syncthreads();
     {
       // pass 2: a_r[h][c] = sum_e p_e,h r~_e[c],  a_v[hd] = sum_e p_e,h v_src[hd]   (:100, aggr='add')
-      float ar[8][16], av[16];
+      // lane -> columns (2*lane, 2*lane+1) of r~ and of v (head lane>>3); the wave walks its share of the
+      // edges with fully coalesced 512-byte row reads, 4 edges in flight; no cross-lane fold at all.
+      float ar[8][2], av0 = 0.f, av1 = 0.f;
 #pragma unroll
-      for (int h = 0; h < 8; ++h)
+      for (int h = 0; h < 8; ++h) ar[h][0] = ar[h][1] = 0.f;
+      const int hl = lane >> 3;
+      const float* rbase = st.rt + (size_t)e_beg * 128 + 2 * lane;
+      const float* vbase = st.kv + 128 + 2 * lane;
+      for (int eb = wi * 4; eb < deg; eb += 4 * W) {
+        float2 rr[4], vv[4];
+        int ee[4];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) ar[h][i] = 0.f;
+        for (int j = 0; j < 4; ++j) {
+          ee[j] = (eb + j < deg) ? eb + j : deg - 1;
+          rr[j] = ldg2(rbase + (size_t)ee[j] * 128);
+          vv[j] = ldg2(vbase + (size_t)el[ee[j]] * 256);
+        }
 #pragma unroll
-      for (int d = 0; d < 16; ++d) av[d] = 0.f;
-      for (int e0 = wi * 8; e0 < deg; e0 += 8 * W) {
-        const int e = e0 + es;
-        const bool ok = e < deg;
-        const int ee = ok ? e : deg - 1;
-        const int src = st.esrc[e_beg + ee];
-        const float* rr = st.rt + (size_t)(e_beg + ee) * 128;
-        const float* vr = st.kv + (size_t)src * 256 + 128 + cc * DH;
-        float4 pa = *reinterpret_cast<const float4*>(sc + (size_t)ee * 8);
-        float4 pb = *reinterpret_cast<const float4*>(sc + (size_t)ee * 8 + 4);
-        if (!ok) { pa = make_float4(0.f, 0.f, 0.f, 0.f); pb = pa; }
-        const float p[8] = {pa.x, pa.y, pa.z, pa.w, pb.x, pb.y, pb.z, pb.w};
-        float ph = p[0];
+        for (int j = 0; j < 4; ++j) {
+          float4 pa = *reinterpret_cast<const float4*>(sc + (size_t)ee[j] * 8);
+          float4 pb = *reinterpret_cast<const float4*>(sc + (size_t)ee[j] * 8 + 4);
+          if (eb + j >= deg) { pa = make_float4(0.f, 0.f, 0.f, 0.f); pb = pa; }
+          const float p[8] = {pa.x, pa.y, pa.z, pa.w, pb.x, pb.y, pb.z, pb.w};
+          float ph = p[0];
 #pragma unroll
-        for (int h = 1; h < 8; ++h) ph = (cc == h) ? p[h] : ph;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float4 v = *reinterpret_cast<const float4*>(rr + 4 * (cc + 8 * i));
+          for (int h = 1; h < 8; ++h) ph = (hl == h) ? p[h] : ph;
 #pragma unroll
           for (int h = 0; h < 8; ++h) {
-            ar[h][4 * i] = fmaf(p[h], v.x, ar[h][4 * i]);
-            ar[h][4 * i + 1] = fmaf(p[h], v.y, ar[h][4 * i + 1]);
-            ar[h][4 * i + 2] = fmaf(p[h], v.z, ar[h][4 * i + 2]);
-            ar[h][4 * i + 3] = fmaf(p[h], v.w, ar[h][4 * i + 3]);
+            ar[h][0] = fmaf(p[h], rr[j].x, ar[h][0]);
+            ar[h][1] = fmaf(p[h], rr[j].y, ar[h][1]);
           }
-          const float4 vv = *reinterpret_cast<const float4*>(vr + 4 * i);
-          av[4 * i] = fmaf(ph, vv.x, av[4 * i]); av[4 * i + 1] = fmaf(ph, vv.y, av[4 * i + 1]);
-          av[4 * i + 2] = fmaf(ph, vv.z, av[4 * i + 2]); av[4 * i + 3] = fmaf(ph, vv.w, av[4 * i + 3]);
+          av0 = fmaf(ph, vv[j].x, av0);
+          av1 = fmaf(ph, vv[j].y, av1);
         }
       }
-      // fold the 8 edge slots of the wave (lane bits 3..5), then publish the wave's partials
 #pragma unroll
-      for (int o = 8; o < 64; o <<= 1) {
-#pragma unroll
-        for (int h = 0; h < 8; ++h)
-#pragma unroll
-          for (int i = 0; i < 16; ++i) ar[h][i] += __shfl_xor(ar[h][i], o);
-#pragma unroll
-        for (int d = 0; d < 16; ++d) av[d] += __shfl_xor(av[d], o);
-      }
-      if (es == 0) {
-#pragma unroll
-        for (int h = 0; h < 8; ++h)
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-            *reinterpret_cast<float4*>(big + (size_t)(wave * 8 + h) * QP + 4 * (cc + 8 * i)) =
-                make_float4(ar[h][4 * i], ar[h][4 * i + 1], ar[h][4 * i + 2], ar[h][4 * i + 3]);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-          *reinterpret_cast<float4*>(avp + wave * 128 + cc * DH + 4 * i) =
-              make_float4(av[4 * i], av[4 * i + 1], av[4 * i + 2], av[4 * i + 3]);
-      }
+      for (int h = 0; h < 8; ++h)
+        *reinterpret_cast<float2*>(big + (size_t)(wave * 8 + h) * QP + 2 * lane) = make_float2(ar[h][0], ar[h][1]);
+      *reinterpret_cast<float2*>(avp + wave * 128 + 2 * lane) = make_float2(av0, av1);
     }
+    if (s + 1 < nsteps) sp_store(sp_next);   // layer s-1's buffer is dead: park the next layer's vectors there
     __syncthreads();
     if (W > 1) {  // sum the W sub-wave partials of each destination into its first slot
       for (int i = tid; i < T * 8 * 128; i += WG) {
@@ -307,40 +421,136 @@ __global__ __launch_bounds__(WG, 1) void k_attn_chain(float* __restrict__ x, int
       __syncthreads();
     }
     // ---- agg = (a_v + Wvr_g^T a_r + l * vb) / (l + 1e-16)   (to_v_r fold; :89, :100)
-    gemv_rows<T, true>(big, W * 8 * QP, 128, w.Wvr_gt, 128, nullptr, un, ag, 128, false);
-    for (int i = tid; i < T * 128; i += WG) {
-      const int tt = i >> 7, c = i & 127, h = c >> 4;
-      float l = 0.f;
-      for (int j = 0; j < W; ++j) l += ml[(tt * W + j) * 16 + 8 + h];
-      const int rr_ = row0 + tt;
-      const bool has = (rr_ < Nd) && (st.eoff[rr_ + 1] > st.eoff[rr_]);
-      const float a = (avp[(tt * W) * 128 + c] + ag[i] + l * w.vb[c]) / (l + 1e-16f);
-      ag[i] = has ? a : 0.f;
+    //      columns ncol.. belong to head ncol/16 = 2*wave + (c8 >> 2)
+    {
+      float acc[T][4];
+      zero_acc<T>(acc);
+      wload(wB, w.Wga_t + woff, 128);
+      wfma<T>(wA, big + (size_t)(2 * wave + (c8 >> 2)) * QP + kgl * 16, W * 8 * QP, acc);   // Wvr
+      fold_kgroups<T, 8>(acc);
+      if (kgl == 0) {
+        const int h = 2 * wave + (c8 >> 2);
+#pragma unroll
+        for (int tt = 0; tt < T; ++tt) {
+          float l = 0.f;
+          for (int j = 0; j < W; ++j) l += ml[(tt * W + j) * 16 + 8 + h];
+          const float inv = 1.f / (l + 1e-16f);
+          float o[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            o[j] = (avp[(tt * W) * 128 + ncol + j] + acc[tt][j] + l * sp[SP_VB + ncol + j]) * inv;
+          *reinterpret_cast<float4*>(ag + tt * 128 + ncol) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+      }
     }
     __syncthreads();
     // ---- gated update (:106-107): g = sigmoid(Wg [agg | x_dst] + bg); u = agg + g * (to_s(x_dst) - agg)
-    gemv_rows<T, false>(ag, 128, 128, w.Wga_t, 128, nullptr, un, f1, 512, false);
-    for (int i = tid; i < T * 128; i += WG) {
-      const int tt = i >> 7, c = i & 127;
-      const float g = 1.f / (1.f + expf(-(f1[tt * 512 + c] + gb[i])));
-      const float a = ag[i];
-      ag[i] = a + g * (sb[i] - a);
+    {
+      float acc[T][4];
+      zero_acc<T>(acc);
+      wload(wA, w.Wout_t + woff, 128);
+      wfma<T>(wB, ag + kgl * 16, 128, acc);                                             // Wga
+      fold_kgroups<T, 8>(acc);
+      if (kgl == 0) {
+#pragma unroll
+        for (int tt = 0; tt < T; ++tt) {
+          float o[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int i = tt * 128 + ncol + j;
+            const float g = 1.f / (1.f + expf(-(acc[tt][j] + gb[i])));
+            const float a = ag[i];
+            o[j] = a + g * (sb[i] - a);
+          }
+          *reinterpret_cast<float4*>(f1 + tt * 128 + ncol) = make_float4(o[0], o[1], o[2], o[3]);   // u parked in f1
+        }
+      }
     }
     __syncthreads();
-    // ---- x = x + LN_post(to_out(u))  (:76)
-    gemv_rows<T, false>(ag, 128, 128, w.Wout_t, 128, w.bout, un, xn, 128, false);
-    ln_rows<T>(xn, 128, xn, 128, w.ln_post_w, w.ln_post_b, eps, false);
+    // ---- x = x + LN_post(to_out(u))  (:76), then xn = LN_ffpre(x)  (:77)
+    {
+      float acc[T][4];
+      zero_acc<T>(acc);
+      wload(wB, w.W1_t + (size_t)(k2 * 64) * 512 + ncol5, 512);
+      wfma<T>(wA, f1 + kgl * 16, 128, acc);                                             // Wout
+      fold_kgroups<T, 8>(acc);
+      if (kgl == 0) {
+#pragma unroll
+        for (int tt = 0; tt < T; ++tt)
+          *reinterpret_cast<float4*>(xn + tt * 128 + ncol) =
+              make_float4(acc[tt][0] + sp[SP_BOUT + ncol], acc[tt][1] + sp[SP_BOUT + ncol + 1],
+                          acc[tt][2] + sp[SP_BOUT + ncol + 2], acc[tt][3] + sp[SP_BOUT + ncol + 3]);
+      }
+    }
     __syncthreads();
-    for (int i = tid; i < T * 128; i += WG) xs[i] += xn[i];
+    for (int tt = wave; tt < T; tt += 4) {
+      // one wave per row: LN_post, residual add, LN_ffpre, all in registers
+      float* xr = xs + tt * 128;
+      float* nr = xn + tt * 128;
+      ln_row_wave(nr, nr, sp + SP_LN_POST_W, sp + SP_LN_POST_B, eps, lane, false);
+      const float x0 = xr[lane] + nr[lane], x1 = xr[lane + 64] + nr[lane + 64];
+      xr[lane] = x0;
+      xr[lane + 64] = x1;
+      ln_row_wave(xr, nr, sp + SP_LN_FFPRE_W, sp + SP_LN_FFPRE_B, eps, lane, false);
+    }
     __syncthreads();
-    // ---- x = x + LN_ffpost(W2 relu(W1 LN_ffpre(x) + b1) + b2)  (:77)
-    ln_rows<T>(xs, 128, xn, 128, w.ln_ffpre_w, w.ln_ffpre_b, eps, false);
+    // ---- FFN up: f1 = relu(W1 xn + b1)   N = 512: wave -> 128 columns, lane (c32, k2), 4 chunks of 16 rows
+    {
+      float acc[T][4];
+      zero_acc<T>(acc);
+      const float* w1 = w.W1_t + (size_t)(k2 * 64) * 512 + ncol5;
+      const float* w2 = w.W2_t + (size_t)(kgl * 64) * 128 + ncol;
+      wload(wA, w1 + (size_t)16 * 512, 512);
+      wfma<T>(wB, xn + k2 * 64, 128, acc);
+      wload(wB, w1 + (size_t)32 * 512, 512);
+      wfma<T>(wA, xn + k2 * 64 + 16, 128, acc);
+      wload(wA, w1 + (size_t)48 * 512, 512);
+      wfma<T>(wB, xn + k2 * 64 + 32, 128, acc);
+      wload(wB, w2, 128);
+      wfma<T>(wA, xn + k2 * 64 + 48, 128, acc);
+      fold_kgroups<T, 32>(acc);
+      if (k2 == 0) {
+#pragma unroll
+        for (int tt = 0; tt < T; ++tt)
+          *reinterpret_cast<float4*>(f1 + tt * 512 + ncol5) =
+              make_float4(fmaxf(acc[tt][0] + sp[SP_B1 + ncol5], 0.f), fmaxf(acc[tt][1] + sp[SP_B1 + ncol5 + 1], 0.f),
+                          fmaxf(acc[tt][2] + sp[SP_B1 + ncol5 + 2], 0.f), fmaxf(acc[tt][3] + sp[SP_B1 + ncol5 + 3], 0.f));
+      }
+    }
     __syncthreads();
-    gemv_rows<T, false>(xn, 128, 128, w.W1_t, 512, w.b1, un, f1, 512, true);
-    gemv_rows<T, false>(f1, 512, 512, w.W2_t, 128, w.b2, un, xn, 128, false);
-    ln_rows<T>(xn, 128, xn, 128, w.ln_ffpost_w, w.ln_ffpost_b, eps, false);
+    // ---- FFN down: xn = W2 f1 + b2   K = 512: 4 chunks of 16 rows per k-group
+    {
+      float acc[T][4];
+      zero_acc<T>(acc);
+      const float* w2 = w.W2_t + (size_t)(kgl * 64) * 128 + ncol;
+      wload(wA, w2 + (size_t)16 * 128, 128);
+      wfma<T>(wB, f1 + kgl * 64, 512, acc);
+      wload(wB, w2 + (size_t)32 * 128, 128);
+      wfma<T>(wA, f1 + kgl * 64 + 16, 512, acc);
+      wload(wA, w2 + (size_t)48 * 128, 128);
+      wfma<T>(wB, f1 + kgl * 64 + 32, 512, acc);
+      wfma<T>(wA, f1 + kgl * 64 + 48, 512, acc);
+      // the next layer's first chunk leaves now; it lands during the fold and the two norms
+      if (s + 1 < nsteps) wload(wA, steps[s + 1].w.Wq_t + woff, 128);
+      fold_kgroups<T, 8>(acc);
+      if (kgl == 0) {
+#pragma unroll
+        for (int tt = 0; tt < T; ++tt)
+          *reinterpret_cast<float4*>(xn + tt * 128 + ncol) =
+              make_float4(acc[tt][0] + sp[SP_B2 + ncol], acc[tt][1] + sp[SP_B2 + ncol + 1], acc[tt][2] + sp[SP_B2 + ncol + 2],
+                          acc[tt][3] + sp[SP_B2 + ncol + 3]);
+      }
+    }
     __syncthreads();
-    for (int i = tid; i < T * 128; i += WG) xs[i] += xn[i];
+    for (int tt = wave; tt < T; tt += 4) {
+      // x = x + LN_ffpost(ffn); then the NEXT layer's pre-norm, in registers
+      float* xr = xs + tt * 128;
+      float* nr = xn + tt * 128;
+      ln_row_wave(nr, nr, sp + SP_LN_FFPOST_W, sp + SP_LN_FFPOST_B, eps, lane, false);
+      xr[lane] += nr[lane];
+      xr[lane + 64] += nr[lane + 64];
+      if (s + 1 < nsteps) ln_row_wave(xr, nr, sp_next + SP_LN_DST_W, sp_next + SP_LN_DST_B, eps, lane, false);
+    }
     __syncthreads();
   }
   for (int i = tid; i < T * 128; i += WG) {

@@ -17,6 +17,26 @@ constexpr int WG = 256;  // threads per workgroup of the row kernels (4 waves, o
 #define PS_PI_F 3.14159274101257324f      // float(math.pi)
 #define PS_TWO_PI_F 6.28318548202514648f  // float(2*math.pi)
 
+// Pointers that reach a kernel inside a struct (weight tables, chain steps) are GENERIC to the
+// compiler, which then emits flat_load: flat loads count on lgkmcnt as well as vmcnt, so every LDS
+// wait would also drain the weight prefetch.  These helpers pin the global address space.
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(1))) const v4f g_cv4f;
+typedef __attribute__((address_space(1))) const v2f g_cv2f;
+typedef __attribute__((address_space(1))) const float g_cf1;
+typedef __attribute__((address_space(1))) const int g_ci1;
+__device__ __forceinline__ float4 ldg4(const float* p) {
+  const v4f v = *(g_cv4f*)p;
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ float2 ldg2(const float* p) {
+  const v2f v = *(g_cv2f*)p;
+  return make_float2(v.x, v.y);
+}
+__device__ __forceinline__ float ldg1(const float* p) { return *(g_cf1*)p; }
+__device__ __forceinline__ int ldgi(const int* p) { return *(g_ci1*)p; }
+
 // models/utils/geometry.py:13-17 -- torch '%' is floor-mod: fmod, then shift into [0, 2pi).
 __device__ __forceinline__ float wrap_angle(float a) {
   float t = a + PS_PI_F;

@@ -77,6 +77,7 @@ def load_library():
     lib.ps_test_attn.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, fp, fp, fp, i32p, i32p, C.c_int32, fp]
     lib.ps_test_get_edges.argtypes = [vp, C.c_int32, i32p, i32p, fp, C.c_int64]
     lib.ps_test_get_edges.restype = C.c_int64
+    lib.ps_test_stream.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, fp]
     _lib = lib
     return lib
 
@@ -84,7 +85,7 @@ def load_library():
 EXPORTS = ["ps_create", "ps_destroy", "ps_last_error", "ps_set_scene", "ps_set_conditions", "ps_set_future_obs",
            "ps_encode_scene", "ps_generate_policy", "ps_reset_rollout", "ps_policy_step", "ps_rollout", "ps_sync",
            "ps_set_state", "ps_get", "ps_rollout_metric", "ps_num_agents", "ps_num_map_tokens", "ps_time_rollout", "ps_time_policy_kernel",
-           "ps_test_pointnet", "ps_test_fourier", "ps_test_wrap", "ps_test_attn", "ps_test_get_edges"]
+           "ps_test_pointnet", "ps_test_fourier", "ps_test_wrap", "ps_test_attn", "ps_test_get_edges", "ps_test_stream"]
 
 
 def _f(a):
@@ -304,3 +305,8 @@ class Engine:
         if n < 0:
             self._check(int(n))
         return esrc[:n].copy(), edst[:n].copy(), rt[:n].copy()
+
+    def test_stream(self, mbytes: int, nwg: int, depth: int, iters: int = 5) -> float:
+        ms = C.c_float()
+        self._check(self.lib.ps_test_stream(self.h, mbytes, nwg, depth, iters, C.byref(ms)))
+        return ms.value
