@@ -46,13 +46,14 @@ struct ChainStep {
   const float* rt;    // [E][128] normalised relative-PE (no affine)
 };
 
+// Edge lists are walked in chunks of CH edges per destination with an online (running max / sum)
+// softmax, so the LDS score tile is 8*CH*T floats whatever the degree.
+constexpr int CH = 256;
 // LDS plan (floats): rows 6*128*T + 512*T | big 4*8*QP (q~ image, then per-wave partial a_r)
-// | un = max(3*512*T partial sums, 8*maxdeg*T scores) | avp 4*128 | ml 4*16 | cq 8*T
+// | sc 8*CH*T scores | avp 4*128 | ml 4*16 | cq 8*T | sp 2*SP_SIZE | esl maxdeg*T
 template <int T>
 __host__ __device__ constexpr size_t attn_lds_floats(int maxdeg) {
-  size_t un = (size_t)1536 * T;
-  size_t sc = (size_t)8 * maxdeg * T;
-  return (size_t)(6 * 128 + 512) * T + 4 * 8 * QP + (un > sc ? un : sc) + 4 * 128 + 4 * 16 + 8 * T + 64 +
+  return (size_t)(6 * 128 + 512) * T + 4 * 8 * QP + (size_t)8 * CH * T + 4 * 128 + 4 * 16 + 8 * T + 64 +
          2 * SP_SIZE + (size_t)maxdeg * T;
 }
 
@@ -143,43 +144,40 @@ __global__ __launch_bounds__(WG, 1) void k_attn_chain(float* __restrict__ x, int
   float* ag = gb + 128 * T;         // [T][128] aggregated message, then the gated update u
   float* f1 = ag + 128 * T;         // [T][512]
   float* big = f1 + 512 * T;        // [4][8][QP]
-  const size_t un_sz = ((size_t)1536 * T > (size_t)8 * maxdeg * T) ? (size_t)1536 * T : (size_t)8 * maxdeg * T;
-  float* un = big + 4 * 8 * QP;     // scores
-  float* avp = un + un_sz;          // [4][128]
+  float* un = big + 4 * 8 * QP;     // [T][CH][8] score tile
+  float* avp = un + (size_t)8 * CH * T;  // [4][128]
   float* ml = avp + 4 * 128;        // [4][16]: per wave (max[8] | sum[8])
   float* cq = ml + 4 * 16;          // [T][8]
   float* spb = cq + 8 * T + 56;     // [2][SP_SIZE] small per-layer vectors, double-buffered
   int* esl = reinterpret_cast<int*>(spb + 2 * SP_SIZE);  // [T][maxdeg] source rows of the current edge lists
 
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tid_o = threadIdx.x, wave_o = tid_o >> 6, lane_o = tid_o & 63;
   // N = 128 GEMVs: wave -> 32 output columns; lane -> (c8: 4 columns, kgl: 16-row k-group)
-  const int c8 = lane & 7, kgl = lane >> 3;
-  const int ncol = wave * 32 + 4 * c8;
-  const size_t woff = (size_t)(kgl * 16) * 128 + ncol;
+  const int c8_o = lane_o & 7, kgl_o = lane_o >> 3;
+  const int ncol_o = wave_o * 32 + 4 * c8_o;
+  const size_t woff_o = (size_t)(kgl_o * 16) * 128 + ncol_o;
   // N = 512 (FFN up): wave -> 128 columns; lane -> (c32: 4 columns, k2: 64-row half)
-  const int c32 = lane & 31, k2 = lane >> 5;
-  const int ncol5 = wave * 128 + 4 * c32;
   const int row0 = blockIdx.x * T;
   // two register sets, one chunk in flight behind the one being multiplied.  (Three sets / two
   // chunks in flight measured no faster -- a CU's 4 waves already pull ~100 GB/s, the per-CU
   // L2->register ceiling measured by ps_test_stream -- and spill at T = 4.)
   WC wA, wB;
-  wload(wA, steps[0].w.Wq_t + woff, 128);
+  wload(wA, steps[0].w.Wq_t + woff_o, 128);
   // small vectors of layer 0 -> LDS buffer 0 (608 float4: threads take float4 tid, tid+256, tid+512)
   float4 spr[3];
   auto sp_load = [&](const float* __restrict__ sp) {
-    spr[0] = ldg4(sp + 4 * tid);
-    spr[1] = ldg4(sp + 4 * (tid + 256));
-    if (tid + 512 < SP_SIZE / 4) spr[2] = ldg4(sp + 4 * (tid + 512));
+    spr[0] = ldg4(sp + 4 * tid_o);
+    spr[1] = ldg4(sp + 4 * (tid_o + 256));
+    if (tid_o + 512 < SP_SIZE / 4) spr[2] = ldg4(sp + 4 * (tid_o + 512));
   };
   auto sp_store = [&](float* dst) {
-    *reinterpret_cast<float4*>(dst + 4 * tid) = spr[0];
-    *reinterpret_cast<float4*>(dst + 4 * (tid + 256)) = spr[1];
-    if (tid + 512 < SP_SIZE / 4) *reinterpret_cast<float4*>(dst + 4 * (tid + 512)) = spr[2];
+    *reinterpret_cast<float4*>(dst + 4 * tid_o) = spr[0];
+    *reinterpret_cast<float4*>(dst + 4 * (tid_o + 256)) = spr[1];
+    if (tid_o + 512 < SP_SIZE / 4) *reinterpret_cast<float4*>(dst + 4 * (tid_o + 512)) = spr[2];
   };
   sp_load(steps[0].w.sp);
   // load the T residual rows (rows past Nd are zero-filled and never stored)
-  for (int i = tid; i < T * 128; i += WG) {
+  for (int i = tid_o; i < T * 128; i += WG) {
     const int t = i >> 7, r = row0 + t;
     xs[i] = (r < Nd) ? ldg1(x + (size_t)r * 128 + (i & 127)) : 0.f;
   }
@@ -191,6 +189,17 @@ __global__ __launch_bounds__(WG, 1) void k_attn_chain(float* __restrict__ x, int
   for (int s = 0; s < nsteps; ++s) {
     const ChainStep& st = steps[s];
     const AttnW& w = st.w;
+    // Lane-derived indices are re-materialised behind an opaque asm every layer: otherwise LICM hoists
+    // hundreds of loop-invariant LDS/global addresses out of the layer loop and they spill (T >= 2).
+    int tid_v = threadIdx.x;
+    asm volatile("" : "+v"(tid_v));
+    const int tid = tid_v, lane = tid_v & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid_v >> 6);   // wave-uniform: pointer math on the SALU
+    const int c8 = lane & 7, kgl = lane >> 3;
+    const int ncol = wave * 32 + 4 * c8;
+    const size_t woff = (size_t)(kgl * 16) * 128 + ncol;
+    const int c32 = lane & 31, k2 = lane >> 5;
+    const int ncol5 = wave * 128 + 4 * c32;
     const float* sp = spb + (s & 1) * SP_SIZE;          // this layer's small vectors (LDS)
     float* sp_next = spb + ((s + 1) & 1) * SP_SIZE;     // filled mid-layer for the next one
     if (s + 1 < nsteps) sp_load(steps[s + 1].w.sp);
@@ -259,149 +268,180 @@ __global__ __launch_bounds__(WG, 1) void k_attn_chain(float* __restrict__ x, int
     }
     __syncthreads();
 
-    // ---- edge phase: wave -> (destination t, sub-wave wi)
-    float* sc = un + (size_t)t * maxdeg * 8;
+    // ---- edge phase: wave -> (destination t, sub-wave wi); lane -> columns (2*lane, 2*lane+1)
+    // Chunks of CH edges; per chunk: scores (pass 1) -> running max / rescale -> exp -> weighted sums (pass 2).
+    // Every row read is a fully coalesced 512-byte line per wave (r~ rows, k rows, v rows).
     {
-      // pass 1: scores s[e][h] = (<q_h, k_src,h> + <q~_h, r~_e> + cq_h) * Dh^-0.5   (:88-90)
-      // lane -> (edge slot es of 8, 16-column chunk cc of 8); the 8 heads' partials meet by a transposing reduce
-      const int es = lane >> 3, cc = lane & 7;
-      float qt[8][16];
+      float* sc = un + (size_t)t * CH * 8;
+      const int hl = lane >> 3, jl = lane & 7;
+      const float* rbase = st.rt + (size_t)e_beg * 128 + 2 * lane;
+      const float* kbase = st.kv + 2 * lane;
+      float q0[8], q1[8];
 #pragma unroll
-      for (int h = 0; h < 8; ++h)
+      for (int h = 0; h < 8; ++h) {
+        const float2 v = *reinterpret_cast<const float2*>(big + (size_t)(t * 8 + h) * QP + 2 * lane);
+        q0[h] = v.x;
+        q1[h] = v.y;
+      }
+      const float2 qv = *reinterpret_cast<const float2*>(qb + t * 128 + 2 * lane);
+      const float cqL = cq[t * 8 + hl];
+      float ar[8][2], av0 = 0.f, av1 = 0.f, m_run[8], l_run[8];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float4 v = *reinterpret_cast<const float4*>(big + (size_t)(t * 8 + h) * QP + 4 * (cc + 8 * i));
-          qt[h][4 * i] = v.x; qt[h][4 * i + 1] = v.y; qt[h][4 * i + 2] = v.z; qt[h][4 * i + 3] = v.w;
+      for (int h = 0; h < 8; ++h) { ar[h][0] = ar[h][1] = 0.f; m_run[h] = -INFINITY; l_run[h] = 0.f; }
+      // the chunk count must be uniform over the workgroup (barriers inside): max degree of its T rows
+      int dmax = 0;
+#pragma unroll
+      for (int tt = 0; tt < T; ++tt) {
+        const int rr_ = row0 + tt;
+        const int d_ = ((rr_ < Nd) && !(flags & 1)) ? (ldgi(st.eoff + rr_ + 1) - ldgi(st.eoff + rr_)) : 0;
+        dmax = d_ > dmax ? d_ : dmax;
+      }
+      for (int c0 = 0; c0 < dmax; c0 += CH) {
+        const int cn = (deg - c0) < CH ? (deg - c0) : CH;   // edges of this destination in the chunk (may be <= 0)
+        // pass 1: s[e][h] = (<q_h, k_src,h> + <q~_h, r~_e> + cq_h) * Dh^-0.5   (:88-90), 8 edges per wave step
+        float2 r2n[8], k2n[8];
+        auto gather1 = [&](int eb) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int ee = c0 + ((eb + j < cn) ? eb + j : cn - 1);
+            r2n[j] = ldg2(rbase + (size_t)ee * 128);
+            k2n[j] = ldg2(kbase + (size_t)el[ee] * 256);
+          }
+        };
+        if (wi * 8 < cn) gather1(wi * 8);
+        for (int eb = wi * 8; eb < cn; eb += 8 * W) {
+          float2 r2[8], k2[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { r2[j] = r2n[j]; k2[j] = k2n[j]; }
+          if (eb + 8 * W < cn) gather1(eb + 8 * W);   // the next 8 edges' rows fly under this step's arithmetic
+          float part[64];
+#pragma unroll
+          for (int h = 0; h < 8; ++h)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) part[h * 8 + j] = fmaf(q1[h], r2[j].y, q0[h] * r2[j].x);
+          float qk[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) qk[j] = fmaf(qv.y, k2[j].y, qv.x * k2[j].x);
+          // transposing reduction 64 values x 64 lanes -> lane L holds the total of value L = (head L>>3, edge L&7)
+#pragma unroll
+          for (int i = 0; i < 32; ++i) part[i] = swap_add32(part[i], part[i + 32]);
+#pragma unroll
+          for (int i = 0; i < 16; ++i) part[i] = swap_add16(part[i], part[i + 16]);
+          const bool b8 = lane & 8, b4 = lane & 4, b2 = lane & 2, b1 = lane & 1;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) part[i] = PS_TSTEP(part[i], part[i + 8], b8, dpp_xor8);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float lo = part[i], hi = part[i + 4];
+            part[i] = (b4 ? hi : lo) + __shfl_xor(b4 ? lo : hi, 4);
+            const float lk = qk[i], hk = qk[i + 4];
+            qk[i] = (b4 ? hk : lk) + __shfl_xor(b4 ? lk : hk, 4);
+          }
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            part[i] = PS_TSTEP(part[i], part[i + 2], b2, dpp_xor2);
+            qk[i] = PS_TSTEP(qk[i], qk[i + 2], b2, dpp_xor2);
+          }
+          const float tot = PS_TSTEP(part[0], part[1], b1, dpp_xor1);
+          const float qkt = PS_TSTEP(qk[0], qk[1], b1, dpp_xor1);
+          if (eb + jl < cn) sc[(size_t)(eb + jl) * 8 + hl] = (tot + qkt + cqL) * 0.25f;
         }
-      float qh[16];
+        __syncthreads();
+        // online softmax over the destination's edges, per head (torch_geometric.utils.softmax:
+        // max-shift, exp, / (sum + 1e-16)); every wave of the destination finds the chunk max
+        float mc[8];
 #pragma unroll
-      for (int d = 0; d < 16; ++d) qh[d] = qb[t * 128 + cc * DH + d];
-      const float cqh = cq[t * 8 + cc];
-      float4 rn[4], kn[4];
-      auto gather1 = [&](int e0) {
-        const int e = e0 + es, ee = e < deg ? e : deg - 1;
-        const float* rr = st.rt + (size_t)(e_beg + ee) * 128;
-        const float* kr = st.kv + (size_t)el[ee] * 256 + cc * DH;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          rn[i] = ldg4(rr + 4 * (cc + 8 * i));
-          kn[i] = ldg4(kr + 4 * i);
+        for (int h = 0; h < 8; ++h) mc[h] = m_run[h];
+        for (int e = lane; e < cn; e += 64) {
+          const float4 a = *reinterpret_cast<const float4*>(sc + (size_t)e * 8);
+          const float4 b = *reinterpret_cast<const float4*>(sc + (size_t)e * 8 + 4);
+          mc[0] = fmaxf(mc[0], a.x); mc[1] = fmaxf(mc[1], a.y); mc[2] = fmaxf(mc[2], a.z); mc[3] = fmaxf(mc[3], a.w);
+          mc[4] = fmaxf(mc[4], b.x); mc[5] = fmaxf(mc[5], b.y); mc[6] = fmaxf(mc[6], b.z); mc[7] = fmaxf(mc[7], b.w);
         }
-      };
-      int e0 = wi * 8;
-      if (e0 < deg) gather1(e0);
-      while (e0 < deg) {
-        const int e = e0 + es;
-        const bool ok = e < deg;
-        float rv[16];
-        float4 kc[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          rv[4 * i] = rn[i].x; rv[4 * i + 1] = rn[i].y; rv[4 * i + 2] = rn[i].z; rv[4 * i + 3] = rn[i].w;
-          kc[i] = kn[i];
-        }
-        e0 += 8 * W;
-        if (e0 < deg) gather1(e0);   // next edges' rows fly while these are multiplied
-        float qk = 0.f;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          qk = fmaf(qh[4 * i], kc[i].x, qk); qk = fmaf(qh[4 * i + 1], kc[i].y, qk);
-          qk = fmaf(qh[4 * i + 2], kc[i].z, qk); qk = fmaf(qh[4 * i + 3], kc[i].w, qk);
-        }
-        float p[8];
+        float scl[8];
 #pragma unroll
         for (int h = 0; h < 8; ++h) {
-          float a = 0.f;
-#pragma unroll
-          for (int i = 0; i < 16; ++i) a = fmaf(qt[h][i], rv[i], a);
-          p[h] = a;
+          mc[h] = wave_max(mc[h]);
+          scl[h] = (m_run[h] == -INFINITY) ? 0.f : expf(m_run[h] - mc[h]);   // rescale of what is already accumulated
+          m_run[h] = mc[h];
         }
-        const float tot = reduce8_to_lane(p, cc);
-        if (ok) sc[(size_t)e * 8 + cc] = (tot + qk + cqh) * 0.25f;
-      }
-    }
-    // pass 1 is done with the registers: the to_v_r fold's weights leave now and land under the softmax and pass 2
-    wload(wA, w.Wvr_gt + woff, 128);
-    __syncthreads();
-    // softmax over the destination's edges, per head (torch_geometric.utils.softmax: max-shift,
-    // exp, / (sum + 1e-16)); lanes over edges.  Every wave of the destination finds the max
-    // (redundantly), then exponentiates its own slice and publishes its partial sum.
-    {
-      float m[8];
+        __syncthreads();  // all waves have read the raw scores before any wave overwrites them
+        float ls[8];
 #pragma unroll
-      for (int h = 0; h < 8; ++h) m[h] = -INFINITY;
-      for (int e = lane; e < deg; e += 64) {
-        const float4 a = *reinterpret_cast<const float4*>(sc + (size_t)e * 8);
-        const float4 b = *reinterpret_cast<const float4*>(sc + (size_t)e * 8 + 4);
-        m[0] = fmaxf(m[0], a.x); m[1] = fmaxf(m[1], a.y); m[2] = fmaxf(m[2], a.z); m[3] = fmaxf(m[3], a.w);
-        m[4] = fmaxf(m[4], b.x); m[5] = fmaxf(m[5], b.y); m[6] = fmaxf(m[6], b.z); m[7] = fmaxf(m[7], b.w);
-      }
-#pragma unroll
-      for (int h = 0; h < 8; ++h) m[h] = wave_max(m[h]);
-      __syncthreads();  // all waves have read the raw scores before any wave overwrites them
-      float l[8];
-#pragma unroll
-      for (int h = 0; h < 8; ++h) l[h] = 0.f;
-      for (int e = wi * 64 + lane; e < deg; e += 64 * W) {
-        float4 a = *reinterpret_cast<const float4*>(sc + (size_t)e * 8);
-        float4 b = *reinterpret_cast<const float4*>(sc + (size_t)e * 8 + 4);
-        a.x = expf(a.x - m[0]); a.y = expf(a.y - m[1]); a.z = expf(a.z - m[2]); a.w = expf(a.w - m[3]);
-        b.x = expf(b.x - m[4]); b.y = expf(b.y - m[5]); b.z = expf(b.z - m[6]); b.w = expf(b.w - m[7]);
-        l[0] += a.x; l[1] += a.y; l[2] += a.z; l[3] += a.w; l[4] += b.x; l[5] += b.y; l[6] += b.z; l[7] += b.w;
-        *reinterpret_cast<float4*>(sc + (size_t)e * 8) = a;
-        *reinterpret_cast<float4*>(sc + (size_t)e * 8 + 4) = b;
-      }
-#pragma unroll
-      for (int h = 0; h < 8; ++h) l[h] = wave_sum(l[h]);
-      if (lane < 8) {
-        float v = l[0];
-#pragma unroll
-        for (int h = 1; h < 8; ++h) v = (lane == h) ? l[h] : v;
-        ml[wave * 16 + 8 + lane] = v;
-      }
-    }
-    __syncthreads();
-    {
-      // pass 2: a_r[h][c] = sum_e p_e,h r~_e[c],  a_v[hd] = sum_e p_e,h v_src[hd]   (:100, aggr='add')
-      // lane -> columns (2*lane, 2*lane+1) of r~ and of v (head lane>>3); the wave walks its share of the
-      // edges with fully coalesced 512-byte row reads, 4 edges in flight; no cross-lane fold at all.
-      float ar[8][2], av0 = 0.f, av1 = 0.f;
-#pragma unroll
-      for (int h = 0; h < 8; ++h) ar[h][0] = ar[h][1] = 0.f;
-      const int hl = lane >> 3;
-      const float* rbase = st.rt + (size_t)e_beg * 128 + 2 * lane;
-      const float* vbase = st.kv + 128 + 2 * lane;
-      for (int eb = wi * 4; eb < deg; eb += 4 * W) {
-        float2 rr[4], vv[4];
-        int ee[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          ee[j] = (eb + j < deg) ? eb + j : deg - 1;
-          rr[j] = ldg2(rbase + (size_t)ee[j] * 128);
-          vv[j] = ldg2(vbase + (size_t)el[ee[j]] * 256);
+        for (int h = 0; h < 8; ++h) ls[h] = 0.f;
+        for (int e = wi * 64 + lane; e < cn; e += 64 * W) {
+          float4 a = *reinterpret_cast<const float4*>(sc + (size_t)e * 8);
+          float4 b = *reinterpret_cast<const float4*>(sc + (size_t)e * 8 + 4);
+          a.x = expf(a.x - mc[0]); a.y = expf(a.y - mc[1]); a.z = expf(a.z - mc[2]); a.w = expf(a.w - mc[3]);
+          b.x = expf(b.x - mc[4]); b.y = expf(b.y - mc[5]); b.z = expf(b.z - mc[6]); b.w = expf(b.w - mc[7]);
+          ls[0] += a.x; ls[1] += a.y; ls[2] += a.z; ls[3] += a.w; ls[4] += b.x; ls[5] += b.y; ls[6] += b.z; ls[7] += b.w;
+          *reinterpret_cast<float4*>(sc + (size_t)e * 8) = a;
+          *reinterpret_cast<float4*>(sc + (size_t)e * 8 + 4) = b;
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          float4 pa = *reinterpret_cast<const float4*>(sc + (size_t)ee[j] * 8);
-          float4 pb = *reinterpret_cast<const float4*>(sc + (size_t)ee[j] * 8 + 4);
-          if (eb + j >= deg) { pa = make_float4(0.f, 0.f, 0.f, 0.f); pb = pa; }
-          const float p[8] = {pa.x, pa.y, pa.z, pa.w, pb.x, pb.y, pb.z, pb.w};
-          float ph = p[0];
+        for (int h = 0; h < 8; ++h) {
+          l_run[h] = l_run[h] * scl[h] + wave_sum(ls[h]);
+          ar[h][0] *= scl[h];
+          ar[h][1] *= scl[h];
+        }
+        {
+          float sh = scl[0];
 #pragma unroll
-          for (int h = 1; h < 8; ++h) ph = (hl == h) ? p[h] : ph;
+          for (int h = 1; h < 8; ++h) sh = (hl == h) ? scl[h] : sh;
+          av0 *= sh;
+          av1 *= sh;
+        }
+        __syncthreads();
+        // pass 2: a_r[h][c] += sum_e p_e,h r~_e[c],  a_v[hd] += sum_e p_e,h v_src[hd]   (:100, aggr='add'), 8 + 8 edges in flight
+        const float* vbase = st.kv + 128 + 2 * lane;
+        float2 rrn[8], vvn[8];
+        auto gather2 = [&](int eb) {
 #pragma unroll
-          for (int h = 0; h < 8; ++h) {
-            ar[h][0] = fmaf(p[h], rr[j].x, ar[h][0]);
-            ar[h][1] = fmaf(p[h], rr[j].y, ar[h][1]);
+          for (int j = 0; j < 8; ++j) {
+            const int ee = (eb + j < cn) ? eb + j : cn - 1;
+            rrn[j] = ldg2(rbase + (size_t)(c0 + ee) * 128);
+            vvn[j] = ldg2(vbase + (size_t)el[c0 + ee] * 256);
           }
-          av0 = fmaf(ph, vv[j].x, av0);
-          av1 = fmaf(ph, vv[j].y, av1);
+        };
+        if (wi * 8 < cn) gather2(wi * 8);
+        for (int eb = wi * 8; eb < cn; eb += 8 * W) {
+          float2 rr[8], vv[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { rr[j] = rrn[j]; vv[j] = vvn[j]; }
+          if (eb + 8 * W < cn) gather2(eb + 8 * W);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int ee = (eb + j < cn) ? eb + j : cn - 1;
+            float4 pa = *reinterpret_cast<const float4*>(sc + (size_t)ee * 8);
+            float4 pb = *reinterpret_cast<const float4*>(sc + (size_t)ee * 8 + 4);
+            if (eb + j >= cn) { pa = make_float4(0.f, 0.f, 0.f, 0.f); pb = pa; }
+            const float p[8] = {pa.x, pa.y, pa.z, pa.w, pb.x, pb.y, pb.z, pb.w};
+            float ph = p[0];
+#pragma unroll
+            for (int h = 1; h < 8; ++h) ph = (hl == h) ? p[h] : ph;
+#pragma unroll
+            for (int h = 0; h < 8; ++h) {
+              ar[h][0] = fmaf(p[h], rr[j].x, ar[h][0]);
+              ar[h][1] = fmaf(p[h], rr[j].y, ar[h][1]);
+            }
+            av0 = fmaf(ph, vv[j].x, av0);
+            av1 = fmaf(ph, vv[j].y, av1);
+          }
         }
+        if (c0 + CH < dmax) __syncthreads();   // the next chunk's pass 1 overwrites the score tile
       }
+      // the to_v_r fold's weights leave now and land while the partials are published
+      wload(wA, w.Wvr_gt + woff, 128);
 #pragma unroll
       for (int h = 0; h < 8; ++h)
         *reinterpret_cast<float2*>(big + (size_t)(wave * 8 + h) * QP + 2 * lane) = make_float2(ar[h][0], ar[h][1]);
       *reinterpret_cast<float2*>(avp + wave * 128 + 2 * lane) = make_float2(av0, av1);
+      if (lane < 8) {
+        float v = l_run[0];
+#pragma unroll
+        for (int h = 1; h < 8; ++h) v = (lane == h) ? l_run[h] : v;
+        ml[wave * 16 + 8 + lane] = v;
+      }
     }
     if (s + 1 < nsteps) sp_store(sp_next);   // layer s-1's buffer is dead: park the next layer's vectors there
     __syncthreads();
@@ -553,7 +593,7 @@ __global__ __launch_bounds__(WG, 1) void k_attn_chain(float* __restrict__ x, int
     }
     __syncthreads();
   }
-  for (int i = tid; i < T * 128; i += WG) {
+  for (int i = tid_o; i < T * 128; i += WG) {
     const int t = i >> 7, r = row0 + t;
     if (r < Nd) x[(size_t)r * 128 + (i & 127)] = xs[i];
   }
