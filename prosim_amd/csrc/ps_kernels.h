@@ -248,35 +248,64 @@ __global__ void k_exclusive_scan(const int* __restrict__ cnt, int n, int* __rest
   if (tid == 0) off[n] = carry;
 }
 
-// knn (loop=True): one workgroup per query; d2 of the scene's candidates in LDS; each candidate's
-// rank = #{j : (d2_j, j) < (d2_i, i)}; candidates with rank < k are written at eoff[q] + rank
-// (so a destination's edges come out sorted by distance).  eoff is closed-form (host).
-__global__ void k_knn(CandSet cs, const float* __restrict__ qpos, const int* __restrict__ qscene, int k,
+// knn (loop=True): one WAVE per query.  Each lane keeps up to KNN_SLOTS candidates' d2 in registers
+// (non-negative floats order like their bit patterns); the k-th smallest key v_k is found by a
+// 32-step bitwise bisection (count(key < trial) via ballots), then every key < v_k is kept and the
+// ties at v_k are kept in index order until k are out -- i.e. the k smallest by (d2, index).
+// Edges of a destination come out in candidate-index order.  eoff is closed-form (host).
+constexpr int KNN_SLOTS = 40;   // up to 64*40 = 2560 candidates per scene (2048 polylines + 256 agents fits)
+__global__ void k_knn(CandSet cs, const float* __restrict__ qpos, const int* __restrict__ qscene, int nq, int k,
                       const int* __restrict__ eoff, int* __restrict__ esrc, int* __restrict__ edst) {
-  extern __shared__ float d2s[];
-  const int q = blockIdx.x, tid = threadIdx.x;
+  const int q = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (q >= nq) return;
   const float qx = qpos[2 * q], qy = qpos[2 * q + 1];
   const int b = qscene[q];
   const int b1 = cs.r1[b], n1 = cs.r1[b + 1] - b1;
   const int b2 = cs.r2 ? cs.r2[b] : 0, n2 = cs.r2 ? cs.r2[b + 1] - b2 : 0;
   const int n = n1 + n2;
-  for (int j = tid; j < n; j += blockDim.x) {
-    const int i = j < n1 ? b1 + j : b2 + (j - n1);
-    d2s[j] = dist2(cs.pos[2 * i], cs.pos[2 * i + 1], qx, qy);
+  unsigned key[KNN_SLOTS];
+#pragma unroll
+  for (int s = 0; s < KNN_SLOTS; ++s) {
+    const int j = s * 64 + lane;   // candidate order = global index order (range 1 then range 2)
+    unsigned kk = 0xffffffffu;     // padding sorts last (real keys are finite floats < 0x7f800000)
+    if (j < n) {
+      const int i = j < n1 ? b1 + j : b2 + (j - n1);
+      kk = __float_as_uint(dist2(cs.pos[2 * i], cs.pos[2 * i + 1], qx, qy));
+    }
+    key[s] = kk;
   }
-  __syncthreads();
-  const int base = eoff[q];
-  for (int j = tid; j < n; j += blockDim.x) {
-    const float dj = d2s[j];
-    int rank = 0;
-    for (int m = 0; m < n; ++m) {
-      const float dm = d2s[m];
-      rank += (dm < dj || (dm == dj && m < j)) ? 1 : 0;
+  const int kk_ = k < n ? k : n;
+  // v_k = largest x with count(key < x) < k
+  unsigned vk = 0;
+  for (int bit = 31; bit >= 0; --bit) {
+    const unsigned trial = vk | (1u << bit);
+    int c = 0;
+#pragma unroll
+    for (int s = 0; s < KNN_SLOTS; ++s) c += __popcll(__ballot(key[s] < trial));
+    if (c < kk_) vk = trial;
+  }
+  int c_lt = 0;
+#pragma unroll
+  for (int s = 0; s < KNN_SLOTS; ++s) c_lt += __popcll(__ballot(key[s] < vk));
+  int ties_left = kk_ - c_lt;   // how many keys == v_k still go out, in index order
+  int out = eoff[q];
+#pragma unroll
+  for (int s = 0; s < KNN_SLOTS; ++s) {
+    const int j = s * 64 + lane;
+    const bool lt = key[s] < vk, eq = key[s] == vk && j < n;
+    const unsigned long long meq = __ballot(eq);
+    const int eq_rank = __popcll(meq & ((1ull << lane) - 1ull));
+    const bool take = lt || (eq && eq_rank < ties_left);
+    const unsigned long long mt = __ballot(take);
+    if (take) {
+      const int o = out + __popcll(mt & ((1ull << lane) - 1ull));
+      esrc[o] = j < n1 ? b1 + j : b2 + (j - n1);
+      edst[o] = q;
     }
-    if (rank < k) {
-      esrc[base + rank] = j < n1 ? b1 + j : b2 + (j - n1);
-      edst[base + rank] = q;
-    }
+    out += __popcll(mt);
+    const int neq = __popcll(meq);
+    ties_left -= neq < ties_left ? neq : ties_left;
   }
 }
 
@@ -479,66 +508,127 @@ __global__ void k_init_state(const float* __restrict__ obs_input, const int* __r
 
 // ------------------------------------------------------------------------------------------
 // K9-K11  ActDecoder._compute_traj, anchor mode (act_decoder.py:78-140; CG_stacked mlp.py:207-241)
-// fused with step_agent_traj (traj_sam.py:276-349, TOP_K = 1 -> mode 0).  One 128-thread WG per agent.
+// fused with step_agent_traj (traj_sam.py:276-349, TOP_K = 1 -> mode 0).  HG agents per 128-thread
+// workgroup, thread = output column, K-major weights (coalesced 512-byte rows shared by the HG rows).
+constexpr int HG = 4;
 struct HeadW {
-  const float* anchors;              // [K*types][128]
-  const float *cgW[3], *cgb[3], *cglnw[3], *cglnb[3];   // CG_decode.CGs[i].MLP: Linear [128][128] torch layout + LN
-  Mlp3W motion;                      // 128 -> 128 -> 64 -> out_dim
+  const float* anchors;                                   // [K*types][128]
+  const float *cgWt[3], *cgb[3], *cglnw[3], *cglnb[3];    // CG_decode.CGs[i].MLP: Linear K-major [128][128] + LN
+  const float *m0t, *m0b, *m0lnw, *m0lnb;                 // motion_head: 128 -> 128 (LN, ReLU)
+  const float *m1t, *m1b, *m1lnw, *m1lnb;                 //              128 -> 64  (LN, ReLU), K-major [128][64]
+  const float *m2t, *m2b;                                 //              64 -> out, K-major [64][64] (zero-padded)
+  Mlp3W motion;                                           // (torch layout, kept for reference/tests)
 };
+
+// out[g][col] = bias[col] + sum_k in[g][k] * Wt[k][col]   (col = threadIdx.x < N)
+template <int G>
+__device__ __forceinline__ void head_dense(const float* in, int in_stride, int K, const float* __restrict__ Wt, int N,
+                                           const float* __restrict__ bias, float (&acc)[G]) {
+  const int col = threadIdx.x;
+  const float b = (col < N) ? ldg1(bias + col) : 0.f;
+#pragma unroll
+  for (int g = 0; g < G; ++g) acc[g] = b;
+  if (col < N) {
+#pragma unroll 8
+    for (int k = 0; k < K; ++k) {
+      const float wv = ldg1(Wt + (size_t)k * N + col);
+#pragma unroll
+      for (int g = 0; g < G; ++g) acc[g] = fmaf(in[g * in_stride + k], wv, acc[g]);
+    }
+  }
+}
+
 __global__ __launch_bounds__(128) void k_policy_head(HeadW w, const float* __restrict__ fused, const int* __restrict__ agent_type,
-                                                    int motion_k, int steps, int sdim, float* __restrict__ motion_pred,
+                                                    int n_agents, int motion_k, int steps, int sdim, float* __restrict__ motion_pred,
                                                     float* __restrict__ traj, float* __restrict__ vel, int stride_steps, int last,
                                                     int replan, float eps) {
-  __shared__ float ctx[128], inp[128], a[128], b[128];
-  const int ag = blockIdx.x, tid = threadIdx.x;
-  ctx[tid] = fused[(size_t)ag * 128 + tid];
-  const int type_idx = (agent_type[ag] - 1) * motion_k;  // K = 1: anchor row
-  a[tid] = w.anchors[(size_t)type_idx * 128 + tid];
+  __shared__ float ctx[HG][128], inp[HG][128], a[HG][128], b[HG][128];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ag0 = blockIdx.x * HG;
+  for (int g = 0; g < HG; ++g) {
+    const int ag = ag0 + g < n_agents ? ag0 + g : n_agents - 1;
+    ctx[g][tid] = fused[(size_t)ag * 128 + tid];
+    a[g][tid] = w.anchors[(size_t)((agent_type[ag] - 1) * motion_k) * 128 + tid];   // K = 1: anchor row of the type
+  }
   __syncthreads();
+  float acc[HG];
   // CG_stacked(3) with K = 1: max over the mode dim is the identity
   for (int i = 0; i < 3; ++i) {
-    gemv_small<1>(i == 0 ? a : inp, 0, 128, w.cgW[i], 128, w.cgb[i], b, 0, false);
-    if (tid < 64) ln_row_wave(b, b, w.cglnw[i], w.cglnb[i], eps, tid, true);
+    head_dense<HG>(i == 0 ? &a[0][0] : &inp[0][0], 128, 128, w.cgWt[i], 128, w.cgb[i], acc);
+#pragma unroll
+    for (int g = 0; g < HG; ++g) b[g][tid] = acc[g];
     __syncthreads();
-    const float y = b[tid] * ctx[tid];
-    if (i == 0) {
-      inp[tid] = y;
-      ctx[tid] = y;
-    } else {
-      inp[tid] = (inp[tid] * (float)i + y) / (float)(i + 1);
-      ctx[tid] = (ctx[tid] * (float)i + y) / (float)(i + 1);
+    for (int g = wave; g < HG; g += 2) ln_row_wave(b[g], b[g], w.cglnw[i], w.cglnb[i], eps, lane, true);
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < HG; ++g) {
+      const float y = b[g][tid] * ctx[g][tid];
+      if (i == 0) {
+        inp[g][tid] = y;
+        ctx[g][tid] = y;
+      } else {
+        inp[g][tid] = (inp[g][tid] * (float)i + y) / (float)(i + 1);
+        ctx[g][tid] = (ctx[g][tid] * (float)i + y) / (float)(i + 1);
+      }
     }
     __syncthreads();
   }
-  a[tid] = inp[tid];
+  // motion_head: 128 -> 128 (LN, ReLU) -> 64 (LN, ReLU) -> steps*sdim
+  head_dense<HG>(&inp[0][0], 128, 128, w.m0t, 128, w.m0b, acc);
+#pragma unroll
+  for (int g = 0; g < HG; ++g) a[g][tid] = acc[g];
   __syncthreads();
-  mlp3_rows1(w.motion, a, b, eps);  // a[0 .. steps*sdim)
-  // cumsum over steps of (dx, dy, dtheta); wrap theta  (act_decoder.py:117-121)
-  if (tid == 0) {
+  for (int g = wave; g < HG; g += 2) ln_row_wave(a[g], a[g], w.m0lnw, w.m0lnb, eps, lane, true);
+  __syncthreads();
+  head_dense<HG>(&a[0][0], 128, 128, w.m1t, 64, w.m1b, acc);
+  if (tid < 64) {
+#pragma unroll
+    for (int g = 0; g < HG; ++g) b[g][tid] = acc[g];
+  }
+  __syncthreads();
+  for (int g = wave; g < HG; g += 2) {   // LayerNorm over 64 features by one wave
+    const float v = b[g][lane];
+    const float mean = wave_sum(v) * (1.f / 64.f);
+    const float d = v - mean;
+    const float var = wave_sum(d * d) * (1.f / 64.f);
+    b[g][lane] = fmaxf(fmaf(d * (1.f / sqrtf(var + eps)), w.m1lnw[lane], w.m1lnb[lane]), 0.f);
+  }
+  __syncthreads();
+  head_dense<HG>(&b[0][0], 128, 64, w.m2t, 64, w.m2b, acc);
+  if (tid < 64) {
+#pragma unroll
+    for (int g = 0; g < HG; ++g) a[g][tid] = acc[g];
+  }
+  __syncthreads();
+  // cumsum over steps of (dx, dy, dtheta); wrap theta (act_decoder.py:117-121); one thread per agent
+  if (tid < HG && ag0 + tid < n_agents) {
+    const int ag = ag0 + tid;
+    const float* o = a[tid];
     float cx = 0.f, cy = 0.f, ch = 0.f;
     float* mp = motion_pred + (size_t)ag * motion_k * steps * sdim;
     const float* cur = traj + ((size_t)ag * stride_steps + last - 1) * 4;
+    const float c0 = cur[0], c1 = cur[1];
     const float lth = atan2f(cur[2], cur[3]);
     const float cl = cosf(lth), sl = sinf(lth);
     for (int s = 0; s < steps; ++s) {
-      cx += a[s * sdim];
-      cy += a[s * sdim + 1];
-      ch += a[s * sdim + 2];
+      cx += o[s * sdim];
+      cy += o[s * sdim + 1];
+      ch += o[s * sdim + 2];
       const float hh = wrap_angle(ch);
       mp[s * sdim] = cx;
       mp[s * sdim + 1] = cy;
       mp[s * sdim + 2] = hh;
-      for (int f = 3; f < sdim; ++f) mp[s * sdim + f] = a[s * sdim + f];
+      for (int f = 3; f < sdim; ++f) mp[s * sdim + f] = o[s * sdim + f];
       if (s < replan) {
         // step_agent_traj (traj_sam.py:322-347): rotate into the agent-init frame, append
         float* t = traj + ((size_t)ag * stride_steps + last + s) * 4;
         float* v = vel + ((size_t)ag * stride_steps + last + s) * 2;
-        t[0] = (cx * cl - cy * sl) + cur[0];
-        t[1] = (cy * cl + cx * sl) + cur[1];
+        t[0] = (cx * cl - cy * sl) + c0;
+        t[1] = (cy * cl + cx * sl) + c1;
         const float pth = wrap_angle(lth + hh);
         t[2] = sinf(pth);
         t[3] = cosf(pth);
-        const float vx = a[s * sdim + 3], vy = a[s * sdim + 4];
+        const float vx = o[s * sdim + 3], vy = o[s * sdim + 4];
         v[0] = vx * cl - vy * sl;
         v[1] = vy * cl + vx * sl;
       }

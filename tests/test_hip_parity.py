@@ -237,6 +237,7 @@ def test_batch_independence_and_determinism(demo_engine):
     eng.set_scene(scene)
     eng.rollout()
     traj = eng.padded("traj")
+    mp0 = eng.padded("policy_emd")
     eng.rollout()
     assert np.array_equal(traj, eng.padded("traj"))
     for b in range(3):
@@ -244,7 +245,10 @@ def test_batch_independence_and_determinism(demo_engine):
                for k, v in scene.items()}
         eng.set_scene(one)
         eng.rollout()
-        assert err(eng.padded("traj")[0], traj[b]) < 2e-5      # same maths, different tile shapes
+        # same maths, different tile shapes (rows per workgroup, waves per destination): open-loop
+        # quantities agree to rounding, the closed loop to the amplified-rounding bound
+        assert err(eng.padded("policy_emd")[0], mp0[b]) < 5e-5
+        assert err(eng.padded("traj")[0], traj[b]) < 2e-3
     assert np.isfinite(traj).all()
     t = traj[scene["prompt_mask"].astype(bool)]
     assert err(t[..., 2] ** 2 + t[..., 3] ** 2, 1.0) < 1e-5   # (sin, cos) stays on the unit circle
