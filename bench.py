@@ -5,9 +5,12 @@
   N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One "step" = one full closed-loop rollout (scene encode + policy generator + 8 replans x 10 steps)
-of S synthetic scenes per GPU, inputs resident in HBM.  metric = agent-steps/s over all ranks.
-Scenes shard one batch per GPU with no data-path collective; after each rollout the per-agent
-(ADE, FDE) metric vector is all-gathered over RCCL (the only exchange the path has).
+of S synthetic 128-agent / 1024-polyline scenes per GPU, inputs resident in HBM.  Default S = 8 is
+BASELINE.json configs[3]'s per-GPU share (64 scenes sharded 8 per GPU; at --gpus 8 the job IS configs[3]);
+every scene is a configs[2] scene (goal-point prompts).  metric = agent-steps/s over all ranks; the
+single-scene (S = 1, latency-bound) figure is measured in the same run and reported alongside.
+Scenes shard by index over ranks (i % world, rollout/callbacks.py:76) with no data-path collective;
+after each rollout the per-agent (ADE, FDE) vector is all-gathered over RCCL (the path's only exchange).
 """
 from __future__ import annotations
 
@@ -67,7 +70,7 @@ def cpu_baseline(spec, w, scene, reps: int = 3):
     A = int(scene["prompt_mask"].sum())
     med = float(np.median(ts))
     return dict(value=A * spec.max_steps / med, unit="agent-steps/s", cores=cores, kind="port",
-                sample=f"{reps} full rollouts of the same workload (median {med:.3f} s each), torch {torch.__version__} fp32, "
+                sample=f"{reps} full rollouts of ONE scene of the batch (CPU throughput does not depend on the batch; median {med:.3f} s each), torch {torch.__version__} fp32, "
                        f"{cores} intra-op threads")
 
 
@@ -76,7 +79,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--scenes-per-gpu", type=int, default=1)
+    ap.add_argument("--scenes-per-gpu", type=int, default=8)
     ap.add_argument("--config", type=int, default=2, help="BASELINE.json config index used as the per-scene workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -96,23 +99,31 @@ def main():
     if world > 1:
         dist.barrier()
     from prosim_amd.engine import Engine
+    from prosim_amd.distributed import shard_scenes, gather_scene_metrics, reduce_metrics
 
     spec = DEMO_SPEC
     w = weights.init_weights(spec, 0)
     S = args.scenes_per_gpu
-    scene = synth.baseline_scene(spec, args.config, seed=rank, batch=S)
+    n_scenes = S * world
+    my_scenes = shard_scenes(n_scenes, rank, world)
+    # scene i of the job is seed i of the generator; this rank's batch = its shard, in shard order
+    parts = [synth.baseline_scene(spec, args.config, seed=i, batch=1) for i in my_scenes]
+    scene = {k: (np.concatenate([p[k] for p in parts]) if not isinstance(parts[0][k], dict) else
+                 {ck: {f: np.concatenate([p[k][ck][f] for p in parts]) for f in parts[0][k][ck]} for ck in parts[0][k]})
+             for k in parts[0]}
     eng = Engine(spec, w, device=local_rank)
     eng.set_scene(scene)
     A = eng.num_agents
+    N = scene["prompt_mask"].shape[1]
     metric_local = torch.zeros(A, 2, device="cuda")
-    metric_all = torch.zeros(world * A, 2, device="cuda") if world > 1 else None
 
     def step():
         eng.rollout()
         eng.rollout_metric(metric_local.data_ptr())
         if world > 1:
             eng.sync()  # engine stream -> host; the gather runs on torch's stream
-            dist.all_gather_into_tensor(metric_all, metric_local)
+            return gather_scene_metrics(metric_local.view(S, N, 2), my_scenes, n_scenes, N)
+        return metric_local.view(S, N, 2)
 
     for _ in range(args.warmup):
         step()
@@ -137,6 +148,7 @@ def main():
         total_agents = A
     ms_per_step = 1e3 * dt / args.steps
     value = total_agents * spec.max_steps / (dt / args.steps)
+    metrics = reduce_metrics(step())
 
     if rank == 0:
         # dominant kernel: the fused policy attention chain (one launch per replan), timed with HIP
@@ -144,6 +156,11 @@ def main():
         ms_chain = eng.time_policy_kernel(3)
         ec = eng.get("edge_counts")
         ms_roll, stages = eng.time_rollout(1, 5)
+        # single-scene latency of the same workload (S = 1), same engine, same run
+        eng.set_scene(parts[0])
+        ms_single, stages1 = eng.time_rollout(2, 10)
+        ms_chain1 = eng.time_policy_kernel(2)
+        A1 = eng.num_agents
         fl_alg = algorithmic_flops_chain(A, float(ec[4]), float(ec[5]), spec.pol_layers)
         fl_exe = executed_flops_chain(A, float(ec[4]), float(ec[5]), spec.pol_layers)
         peak = 157.3  # TFLOP/s: dense fp32 MFMA peak = fp32 vector peak (MI355X_MICROARCH.md)
@@ -152,8 +169,8 @@ def main():
             "metric": "agent-steps/sec closed-loop rollout", "value": value, "unit": "agent-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[{args.config}]: {synth.BASELINE_CONFIGS[args.config]['name']}, "
-                                   f"80-step closed-loop rollout (8 replans), seeded random-init weights",
+            "config": {"workload": f"{S} x BASELINE configs[{args.config}] scenes per GPU ({synth.BASELINE_CONFIGS[args.config]['name']}; "
+                                   f"S=8 is configs[3]'s per-GPU share), 80-step closed-loop rollout (8 replans), seeded random-init weights",
                        "agents_per_scene": int(scene['prompt_mask'][0].sum()), "polylines_per_scene": int(scene['map_mask'].shape[1]),
                        "scenes_per_gpu": S, "parallelism": f"scene-sharded x{world}, RCCL all-gather of per-agent ADE/FDE"},
             "roofline": {"bound": "mfma", "kernel": "k_attn_chain (policy: 12 fused attention layers per launch)",
@@ -162,9 +179,13 @@ def main():
                          "executed_tflops": fl_exe / (ms_chain * 1e-3) / 1e12, "avg_launch_ms": ms_chain,
                          "edges_per_launch": {"a2p": float(ec[4]), "m2p": float(ec[5])}},
             "stage_ms": {"rollout_events": ms_roll, "encode_scene": stages[0], "generate_policy": stages[1], "replan_loop": stages[2]},
+            "single_scene": {"ms_per_rollout": ms_single, "agent_steps_per_s": A1 * spec.max_steps / (ms_single * 1e-3),
+                             "policy_chain_launch_ms": ms_chain1,
+                             "stage_ms": {"encode_scene": stages1[0], "generate_policy": stages1[1], "replan_loop": stages1[2]}},
+            "rollout_metrics": metrics,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(spec, w, scene)
+            out["cpu_baseline"] = cpu_baseline(spec, w, parts[0])
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
     eng.close()

@@ -75,6 +75,12 @@ int ps_set_scene(ps_engine* e, int32_t B, int32_t M, int32_t P, int32_t N,
                  const float* prompt, const uint8_t* prompt_mask, const int32_t* agent_type,
                  const float* prompt_pos, const float* prompt_head);
 
+/* Replace only the prompt side of the uploaded batch (prompt [B,N,prompt_dim], prompt_pos [B,N,2],
+ * prompt_head [B,N], agent_type [B,N]); prompt_mask must be unchanged.  Lets the decoder be called
+ * after the scene encoder with its own prompt_enc argument (decoder/sym_coord.py:112). */
+int ps_set_prompt(ps_engine* e, const float* prompt, const float* prompt_pos, const float* prompt_head,
+                  const int32_t* agent_type);
+
 /* Optional unary prompt conditions (dataset/condition_utils.py:126-222): goal (gx, gy, t) and
  * vehicle action tags (tag_id, t0, t1); *_pidx = prompt slot of each condition.  C = 0 or NULL
  * clears that type.  Replaces the `condition` argument of ConditionTransformer.forward
@@ -104,6 +110,18 @@ int ps_policy_step(ps_engine* e, int32_t t_idx);
  * the engine's stream (replayed from a hipGraph after the first call for a given scene shape). */
 int ps_rollout(ps_engine* e);
 int ps_sync(ps_engine* e);
+
+/* Stateless policy.forward -- the drop-in for Policy_RelPE_Temporal.forward(policy_emd, batch_obs,
+ * batch_map, batch_pos, pair_names, latent_state) (policy/base.py:19; act_decoder.py:239-283, :78-140) on
+ * caller-supplied tokens: the flattened VALID agent / map tokens in the reference's scene-major order
+ * (what _process_scene_token makes of batch_obs / batch_map, act_decoder.py:224-237) and the A policy
+ * rows (policy_emd['emd'], batch_pos, agent_type, batch_idx).  motion_pred [A, K, target_steps, state_dim],
+ * fused [A, hidden] (may be NULL).  Synchronous. */
+int ps_policy_forward(ps_engine* e, int32_t n_scenes, int32_t Na, const float* a_tok, const float* a_pos,
+                      const float* a_ori, const int32_t* a_scene, int32_t Nm, const float* m_tok,
+                      const float* m_pos, const float* m_ori, const int32_t* m_scene, int32_t A,
+                      const float* p_emd, const float* p_pos, const float* p_ori, const int32_t* p_type,
+                      const int32_t* p_scene, float* motion_pred, float* fused_out);
 
 /* Overwrite the trajectory state (test hook for open-loop parity): traj [A, steps, 4], vel
  * [A, steps, 2] over the compact policy-agent list, `steps` = hist + t_idx*replan_freq. */

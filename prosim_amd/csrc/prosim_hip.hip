@@ -679,6 +679,32 @@ extern "C" int ps_set_scene(ps_engine* e, int32_t B, int32_t M, int32_t P, int32
   return PS_OK;
 }
 
+extern "C" int ps_set_prompt(ps_engine* e, const float* prompt, const float* prompt_pos, const float* prompt_head,
+                             const int32_t* agent_type) {
+  if (!e || !e->have_scene) return fail(PS_E_STATE, "ps_set_prompt before ps_set_scene");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  const ps_config& c = e->cfg;
+  const int A = e->A;
+  std::vector<float> ppos((size_t)A * 2), pori(A);
+  std::vector<int> atype(A);
+  for (int i = 0; i < A; ++i) {
+    const size_t r = e->agent_rows[i];
+    ppos[2 * i] = prompt_pos[2 * r];
+    ppos[2 * i + 1] = prompt_pos[2 * r + 1];
+    pori[i] = prompt_head[r];
+    atype[i] = agent_type[r];
+    if (atype[i] < 1 || atype[i] > c.num_agent_types) return fail(PS_E_ARG, "agent_type outside 1..num_agent_types");
+  }
+  if (upload(e->d_prompt, prompt, (size_t)e->B * e->N * c.prompt_dim, e->stream) ||
+      upload(e->d_prompt_pos, ppos.data(), ppos.size(), e->stream) || upload(e->d_prompt_ori, pori.data(), pori.size(), e->stream) ||
+      upload(e->d_agent_type, atype.data(), atype.size(), e->stream))
+    return fail(PS_E_HIP, "prompt upload failed");
+  HIPCHK(hipStreamSynchronize(e->stream));
+  e->generated = false;
+  drop_graph(e);
+  return PS_OK;
+}
+
 extern "C" int ps_set_conditions(ps_engine* e, int32_t C_goal, const float* goal_input, const uint8_t* goal_mask,
                                  const int32_t* goal_pidx, int32_t C_tag, const float* tag_input, const uint8_t* tag_mask,
                                  const int32_t* tag_pidx) {
@@ -1302,4 +1328,105 @@ extern "C" int ps_test_stream(ps_engine* e, int32_t mbytes, int32_t nwg, int32_t
   (void)hipEventDestroy(a); (void)hipEventDestroy(b);
   buf.release(); out.release();
   return PS_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Stateless policy.forward: Policy_RelPE_Temporal.forward(policy_emd, batch_obs, batch_map, batch_pos,
+// pair_names, latent_state) (policy/base.py:19 -> temporal_ar.py:75-92 -> act_decoder.py:239-283, :78-140)
+// on caller-supplied tokens.  Token arrays are the flattened VALID tokens in the reference's order
+// (scene-major): agents [Na,128] + pos/ori/scene, map [Nm,128] + pos/ori/scene, policies [A,128] + pose/type/scene.
+// Returns motion_pred [A, K, steps, state_dim] (cum-xy, wrapped cum-theta, vx, vy) and the fused feature.
+extern "C" int ps_policy_forward(ps_engine* e, int32_t n_scenes, int32_t Na, const float* a_tok, const float* a_pos,
+                                 const float* a_ori, const int32_t* a_scene, int32_t Nm, const float* m_tok,
+                                 const float* m_pos, const float* m_ori, const int32_t* m_scene, int32_t A,
+                                 const float* p_emd, const float* p_pos, const float* p_ori, const int32_t* p_type,
+                                 const int32_t* p_scene, float* motion_pred, float* fused_out) {
+  if (!e) return fail(PS_E_ARG, "null engine");
+  if (A < 1 || Na < 0 || Nm < 0 || n_scenes < 1) return fail(PS_E_ARG, "bad sizes");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  const ps_config& c = e->cfg;
+  hipStream_t st = e->stream;
+  // token geometry in the engine's [map ; agents] order
+  std::vector<float> pos((size_t)(Nm + Na) * 2), ori(Nm + Na);
+  std::vector<int> r_map(n_scenes + 1, 0), r_agent(n_scenes + 1, 0), pscene(A);
+  for (int i = 0; i < Nm; ++i) {
+    pos[2 * i] = m_pos[2 * i]; pos[2 * i + 1] = m_pos[2 * i + 1]; ori[i] = m_ori[i];
+    if (m_scene[i] < 0 || m_scene[i] >= n_scenes || (i && m_scene[i] < m_scene[i - 1])) return fail(PS_E_ARG, "map tokens must be scene-major");
+    r_map[m_scene[i] + 1]++;
+  }
+  for (int i = 0; i < Na; ++i) {
+    pos[2 * (Nm + i)] = a_pos[2 * i]; pos[2 * (Nm + i) + 1] = a_pos[2 * i + 1]; ori[Nm + i] = a_ori[i];
+    if (a_scene[i] < 0 || a_scene[i] >= n_scenes || (i && a_scene[i] < a_scene[i - 1])) return fail(PS_E_ARG, "agent tokens must be scene-major");
+    r_agent[a_scene[i] + 1]++;
+  }
+  int maxA = 1, maxM = 1;
+  for (int b = 0; b < n_scenes; ++b) {
+    maxA = std::max(maxA, r_agent[b + 1]);
+    maxM = std::max(maxM, r_map[b + 1]);
+    r_map[b + 1] += r_map[b];
+    r_agent[b + 1] += r_agent[b];
+  }
+  for (int b = 0; b <= n_scenes; ++b) r_agent[b] += Nm;
+  for (int i = 0; i < A; ++i) {
+    if (p_type[i] < 1 || p_type[i] > c.num_agent_types) return fail(PS_E_ARG, "agent_type outside 1..num_agent_types");
+    if (p_scene[i] < 0 || p_scene[i] >= n_scenes) return fail(PS_E_ARG, "policy batch_idx out of range");
+    pscene[i] = p_scene[i];
+  }
+  DevBuf<float> d_pos, d_ori, d_atok, d_mtok, d_ppos, d_pori, d_x, d_kva, d_kvm, d_motion, d_traj, d_vel;
+  DevBuf<int> d_rmap, d_ragent, d_pscene, d_ptype;
+  EdgeSet ea, em;
+  DevBuf<ChainStep> d_steps;
+  auto mn = [](int a, int b) { return a < b ? a : b; };
+  const int da = mn(c.pol_max_neigh, maxA), dm = mn(c.pol_max_neigh, maxM);
+  const int L = c.pol_layers;
+  const int OUT = c.target_steps * c.state_dim;
+  std::vector<int> ptype(p_type, p_type + A);
+  if (upload(d_pos, pos.data(), pos.size(), st) || upload(d_ori, ori.data(), ori.size(), st) ||
+      upload(d_atok, a_tok, (size_t)std::max(Na, 1) * D, st) || upload(d_mtok, m_tok, (size_t)std::max(Nm, 1) * D, st) ||
+      upload(d_ppos, p_pos, (size_t)A * 2, st) || upload(d_pori, p_ori, (size_t)A, st) || upload(d_x, p_emd, (size_t)A * D, st) ||
+      upload(d_rmap, r_map.data(), r_map.size(), st) || upload(d_ragent, r_agent.data(), r_agent.size(), st) ||
+      upload(d_pscene, pscene.data(), pscene.size(), st) || upload(d_ptype, ptype.data(), ptype.size(), st) ||
+      d_kva.ensure((size_t)L * std::max(Na, 1) * 256) || d_kvm.ensure((size_t)L * std::max(Nm, 1) * 256) ||
+      d_motion.ensure((size_t)A * OUT) || d_traj.ensure((size_t)A * 16 * 4) || d_vel.ensure((size_t)A * 16 * 2) ||
+      edge_alloc(ea, A, (size_t)A * da, da) || edge_alloc(em, A, (size_t)A * dm, dm))
+    return fail(PS_E_HIP, "ps_policy_forward: upload/alloc failed");
+  // the launch helpers read token geometry from the engine: swap in the caller's arrays for this call
+  std::swap(e->d_tok_pos, d_pos);
+  launch_kv(e, d_atok.p, Na, e->L_a2p, L, d_kva.p, (size_t)Na * 256);
+  launch_kv(e, d_mtok.p, Nm, e->L_m2p, L, d_kvm.p, (size_t)Nm * 256);
+  launch_radius(e, ea, d_ragent.p, nullptr, d_ppos.p, d_pscene.p, A, c.pol_agent_radius, c.pol_max_neigh, -1, d_ori.p, d_pori.p);
+  launch_radius(e, em, d_rmap.p, nullptr, d_ppos.p, d_pscene.p, A, c.pol_map_radius, c.pol_max_neigh, -1, d_ori.p, d_pori.p);
+  std::vector<ChainStep> hs;
+  for (int i = 0; i < L; ++i) {
+    ChainStep s1;
+    s1.w = e->a2p[i]; s1.kv = d_kva.p + (size_t)i * Na * 256 - (size_t)Nm * 256; s1.eoff = ea.eoff.p; s1.esrc = ea.esrc.p; s1.rt = ea.rt.p;
+    hs.push_back(s1);
+    ChainStep s2;
+    s2.w = e->m2p[i]; s2.kv = d_kvm.p + (size_t)i * Nm * 256; s2.eoff = em.eoff.p; s2.esrc = em.esrc.p; s2.rt = em.rt.p;
+    hs.push_back(s2);
+  }
+  int rc = 0;
+  if (upload(d_steps, hs.data(), hs.size(), st)) rc = fail(PS_E_HIP, "step upload failed");
+  if (!rc) rc = launch_chain(e, d_x.p, A, 0, 2 * L, std::max(da, dm), false, d_steps.p);
+  if (!rc) {
+    // head with a neutral state (last pose = origin, heading 0): only motion_pred is read back
+    (void)hipMemsetAsync(d_traj.p, 0, sizeof(float) * (size_t)A * 16 * 4, st);
+    std::vector<float> unit((size_t)A * 16 * 4, 0.f);
+    for (size_t i = 0; i < (size_t)A * 16; ++i) unit[i * 4 + 3] = 1.f;
+    (void)hipMemcpyAsync(d_traj.p, unit.data(), sizeof(float) * unit.size(), hipMemcpyHostToDevice, st);
+    hipLaunchKernelGGL(k_policy_head, dim3((A + HG - 1) / HG), dim3(128), 0, st, e->head, (const float*)d_x.p, (const int*)d_ptype.p, A,
+                       c.motion_k, c.target_steps, c.state_dim, d_motion.p, d_traj.p, d_vel.p, 16, 1, 0, c.ln_eps);
+    if (hipStreamSynchronize(st) != hipSuccess) rc = fail(PS_E_HIP, "ps_policy_forward: kernel failure");
+  }
+  std::swap(e->d_tok_pos, d_pos);
+  if (!rc) {
+    if (hipMemcpy(motion_pred, d_motion.p, sizeof(float) * (size_t)A * OUT, hipMemcpyDeviceToHost) != hipSuccess ||
+        (fused_out && hipMemcpy(fused_out, d_x.p, sizeof(float) * (size_t)A * D, hipMemcpyDeviceToHost) != hipSuccess))
+      rc = fail(PS_E_HIP, "ps_policy_forward: D2H failed");
+  }
+  for (DevBuf<float>* b : {&d_pos, &d_ori, &d_atok, &d_mtok, &d_ppos, &d_pori, &d_x, &d_kva, &d_kvm, &d_motion, &d_traj, &d_vel}) b->release();
+  for (DevBuf<int>* b : {&d_rmap, &d_ragent, &d_pscene, &d_ptype}) b->release();
+  for (EdgeSet* s_ : {&ea, &em}) { s_->cnt.release(); s_->eoff.release(); s_->esrc.release(); s_->edst.release(); s_->rt.release(); }
+  d_steps.release();
+  return rc;
 }

@@ -58,6 +58,9 @@ def load_library():
     lib.ps_destroy.argtypes = [vp]
     lib.ps_destroy.restype = None
     lib.ps_set_scene.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, fp, u8p, fp, fp, fp, u8p, fp, fp, fp, u8p, i32p, fp, fp]
+    lib.ps_set_prompt.argtypes = [vp, fp, fp, fp, i32p]
+    lib.ps_policy_forward.argtypes = [vp, C.c_int32, C.c_int32, fp, fp, fp, i32p, C.c_int32, fp, fp, fp, i32p, C.c_int32,
+                                      fp, fp, fp, i32p, i32p, fp, fp]
     lib.ps_set_conditions.argtypes = [vp, C.c_int32, fp, u8p, i32p, C.c_int32, fp, u8p, i32p]
     lib.ps_set_future_obs.argtypes = [vp, fp]
     for name in ("ps_encode_scene", "ps_generate_policy", "ps_reset_rollout", "ps_rollout", "ps_sync"):
@@ -82,7 +85,7 @@ def load_library():
     return lib
 
 
-EXPORTS = ["ps_create", "ps_destroy", "ps_last_error", "ps_set_scene", "ps_set_conditions", "ps_set_future_obs",
+EXPORTS = ["ps_create", "ps_destroy", "ps_last_error", "ps_set_scene", "ps_set_prompt", "ps_policy_forward", "ps_set_conditions", "ps_set_future_obs",
            "ps_encode_scene", "ps_generate_policy", "ps_reset_rollout", "ps_policy_step", "ps_rollout", "ps_sync",
            "ps_set_state", "ps_get", "ps_rollout_metric", "ps_num_agents", "ps_num_map_tokens", "ps_time_rollout", "ps_time_policy_kernel",
            "ps_test_pointnet", "ps_test_fourier", "ps_test_wrap", "ps_test_attn", "ps_test_get_edges", "ps_test_stream"]
@@ -190,6 +193,28 @@ class Engine:
         if s.get("fut_obs_input") is not None:
             fo = np.ascontiguousarray(s["fut_obs_input"], dtype=np.float32)
             self._check(self.lib.ps_set_future_obs(self.h, _f(fo)))
+
+    def set_prompt(self, prompt, prompt_pos, prompt_head, agent_type):
+        a = [np.ascontiguousarray(prompt, np.float32), np.ascontiguousarray(prompt_pos, np.float32),
+             np.ascontiguousarray(prompt_head, np.float32).reshape(self._shape), np.ascontiguousarray(agent_type, np.int32)]
+        self._check(self.lib.ps_set_prompt(self.h, _f(a[0]), _f(a[1]), _f(a[2]), _i32(a[3])))
+
+    def policy_forward(self, n_scenes, a_tok, a_pos, a_ori, a_scene, m_tok, m_pos, m_ori, m_scene, p_emd, p_pos, p_ori,
+                       p_type, p_scene):
+        """Stateless policy.forward on explicit (valid, scene-major) tokens -> (motion_pred [A,K,S,D], fused [A,128])."""
+        f = lambda x, shp: np.ascontiguousarray(x, np.float32).reshape(shp)
+        i = lambda x: np.ascontiguousarray(x, np.int32).reshape(-1)
+        Na, Nm, A = len(i(a_scene)), len(i(m_scene)), len(i(p_scene))
+        arrs = [f(a_tok, (Na, 128)), f(a_pos, (Na, 2)), f(a_ori, (Na,)), i(a_scene), f(m_tok, (Nm, 128)), f(m_pos, (Nm, 2)),
+                f(m_ori, (Nm,)), i(m_scene), f(p_emd, (A, 128)), f(p_pos, (A, 2)), f(p_ori, (A,)), i(p_type), i(p_scene)]
+        sp = self.spec
+        mp = np.empty((A, sp.motion_k, sp.target_steps, sp.state_dim), np.float32)
+        fused = np.empty((A, 128), np.float32)
+        P = lambda a: _f(a) if a.dtype == np.float32 else _i32(a)
+        self._check(self.lib.ps_policy_forward(self.h, n_scenes, Na, P(arrs[0]), P(arrs[1]), P(arrs[2]), P(arrs[3]), Nm, P(arrs[4]),
+                                               P(arrs[5]), P(arrs[6]), P(arrs[7]), A, P(arrs[8]), P(arrs[9]), P(arrs[10]),
+                                               P(arrs[11]), P(arrs[12]), _f(mp), _f(fused)))
+        return mp, fused
 
     # ---- stages (each enqueues on the engine's stream; results are read with get())
     def encode_scene(self):

@@ -1,0 +1,282 @@
+"""Host-side mirror of the reference's plugin interface for the rollout path.
+
+The reference looks its components up by string from a registry (prosim/core/registry.py:54-134):
+``MODEL.SCENE_ENCODER.TYPE`` (traj_sam.py:30), ``MODEL.DECODER.TYPE`` (:40), ``MODEL.POLICY.TYPE`` (:56),
+``MODEL.TYPE`` (trainer.py:160).  The classes below register under the SAME names and keep the same
+call signatures, argument meaning and error behaviour (Python exceptions), so the engine drops into
+``ProSim`` for this path:
+
+  scene_encoder(batch_obs, batch_map) -> dict            (traj_sam.py:77; keys attn_fusion.py:121-134)
+  scene_encoder.update_scene_emb(scene_embs, batch_obs_new, old_obs_agent_ids) -> dict   (:550)
+  decoder(scene_embs, prompt_enc) -> {'emd': [B,N,D], 'agent_type'}                       (:127)
+  policy(policy_emd, batch_obs, batch_map, batch_pos, pair_names, latent_state) -> dict   (:640)
+  ProSimHip.forward(batch, mode) -> {'motion_pred': {...}}                                 (:59)
+
+All arithmetic runs in libprosim_hip.so through prosim_amd.engine (ctypes); torch tensors are only
+the I/O format the reference's callers expect.  There is no CPU fallback.
+"""
+from __future__ import annotations
+
+import collections
+from typing import Any, Callable, Dict, List, Optional
+
+import numpy as np
+import torch
+
+from .engine import Engine
+from .spec import ModelSpec, DEMO_SPEC
+
+
+class Registry:
+    """Same surface as the reference's Registry (core/registry.py:25-134) for the kinds this path uses."""
+    mapping: Dict[str, Dict[str, Any]] = collections.defaultdict(dict)
+
+    @classmethod
+    def _register(cls, kind: str, name: Optional[str]) -> Callable:
+        def wrap(obj):
+            cls.mapping[kind][obj.__name__ if name is None else name] = obj
+            return obj
+        return wrap
+
+    @classmethod
+    def _get(cls, kind: str, name: str):
+        return cls.mapping[kind].get(name, None)
+
+
+for _kind in ("model", "scene_encoder", "decoder", "policy", "prompt_encoder", "metric"):
+    setattr(Registry, f"register_{_kind}", classmethod(lambda cls, to_register=None, *, name=None, _k=_kind:
+                                                         cls._register(_k, name) if to_register is None else cls._register(_k, name)(to_register)))
+    setattr(Registry, f"get_{_kind}", classmethod(lambda cls, name, _k=_kind: cls._get(_k, name)))
+registry = Registry()
+
+
+def _g(obj, key):
+    """The reference's batch containers are dict-like (InputMaskData, dataset/format_utils.py:31)."""
+    try:
+        return obj[key]
+    except (TypeError, KeyError, IndexError):
+        return getattr(obj, key)
+
+
+def _np(t, dtype=np.float32):
+    if isinstance(t, torch.Tensor):
+        t = t.detach().cpu().numpy()
+    return np.ascontiguousarray(t, dtype=dtype)
+
+
+class _Shared:
+    """One Engine shared by the components of one model (the token store lives on the device)."""
+
+    def __init__(self, spec: ModelSpec, weights: Dict[str, np.ndarray], device: int = 0):
+        self.spec = spec
+        self.engine = Engine(spec, weights, device=device)
+        self.scene: Optional[Dict[str, np.ndarray]] = None
+
+
+def scene_from_extras(extras, spec: ModelSpec, task: str = "motion_pred") -> Dict[str, np.ndarray]:
+    """``batch.extras`` (dataset/format_utils.py:798-815) -> the engine's input dict.  Raises if the
+    policy agents are not exactly the observed agents slot for slot (the layout the BASELINE configs
+    and the M-replica rollout use); log-replay agents are a 'next' row."""
+    obs, mp, pr = extras["init_obs"], extras["init_map"], extras["prompt"][task]
+    ids_o, ids_p = _g(obs, "agent_ids"), _g(pr, "agent_ids")
+    if ids_o is not None and ids_p is not None and [list(a) for a in ids_o] != [list(a) for a in ids_p]:
+        raise NotImplementedError("policy agents must be the observed agents in the same order")
+    head = _np(_g(pr, "heading"))
+    scene = dict(map_input=_np(_g(mp, "input")), map_mask=_np(_g(mp, "mask"), bool), map_pos=_np(_g(mp, "position")),
+                 map_head=_np(_g(mp, "heading")), obs_input=_np(_g(obs, "input")), obs_mask=_np(_g(obs, "mask"), bool),
+                 obs_pos=_np(_g(obs, "position")), obs_head=_np(_g(obs, "heading")), prompt=_np(_g(pr, "prompt")),
+                 prompt_mask=_np(_g(pr, "prompt_mask"), bool), agent_type=_np(_g(pr, "agent_type"), np.int64),
+                 prompt_pos=_np(_g(pr, "position")), prompt_head=head.reshape(head.shape[0], head.shape[1]))
+    cond = extras.get("condition") if hasattr(extras, "get") else None
+    if cond:
+        out = {}
+        for k in ("goal", "v_action_tag"):
+            if k in cond.keys() and _g(cond[k], "input").shape[1] > 0:
+                out[k] = dict(input=_np(_g(cond[k], "input")), mask=_np(_g(cond[k], "mask"), bool),
+                              prompt_idx=_np(_g(cond[k], "prompt_idx"), np.int64))
+        unsupported = [k for k in cond.keys() if k not in ("goal", "v_action_tag") and _g(cond[k], "input").shape[1] > 0]
+        if unsupported:
+            raise NotImplementedError(f"condition types {unsupported} are outside this round's scope (unary goal / v_action_tag only)")
+        if out:
+            scene["cond"] = out
+    fut = extras.get("fut_obs") if hasattr(extras, "get") else None
+    if fut:
+        ts = sorted(int(t) for t in fut.keys())
+        scene["fut_obs_input"] = np.stack([_np(_g(fut[t], "input")) for t in ts])
+    return scene
+
+
+@registry.register_scene_encoder(name="attn_fusion_relpe")
+class HipSceneEncoder:
+    """AttentionSceneEncoderRelPE (scene_encoder/attn_fusion.py:11) on the HIP engine."""
+
+    def __init__(self, shared: _Shared):
+        self.s = shared
+
+    def _result(self, scene) -> Dict[str, Any]:
+        eng = self.s.engine
+        mm = torch.from_numpy(scene["map_mask"].astype(bool)).any(-1)
+        om = torch.from_numpy(scene["prompt_mask"].astype(bool))
+        B = mm.shape[0]
+        flat = lambda m: torch.arange(B).unsqueeze(1).repeat(1, m.shape[1]).view(-1)[m.view(-1)]
+        mb, ob = flat(mm), flat(om)
+        Mv = int(mm.sum())
+        return dict(obs_mask=om, map_mask=mm, scene_batch_idx=torch.cat([mb, ob]),
+                    scene_type=torch.cat([torch.zeros_like(mb), torch.ones_like(ob)]),
+                    scene_pos=torch.cat([torch.from_numpy(scene["map_pos"])[mm], torch.from_numpy(scene["obs_pos"])[om]]),
+                    scene_ori=torch.cat([torch.from_numpy(scene["map_head"])[mm], torch.from_numpy(scene["obs_head"])[om]])[:, None],
+                    scene_tokens=torch.from_numpy(eng.get("scene_tokens")), max_map_num=mm.shape[1], max_agent_num=om.shape[1],
+                    _hip_resident=True, _n_map_tokens=Mv)
+
+    def __call__(self, batch_obs, batch_map):
+        return self.forward(batch_obs, batch_map)
+
+    def forward(self, batch_obs, batch_map) -> Dict[str, Any]:
+        spec = self.s.spec
+        obs_in, obs_mask = _np(_g(batch_obs, "input")), _np(_g(batch_obs, "mask"), bool)
+        B, N = obs_in.shape[:2]
+        valid = obs_mask.all(-1).any(-1)
+        scene = dict(map_input=_np(_g(batch_map, "input")), map_mask=_np(_g(batch_map, "mask"), bool),
+                     map_pos=_np(_g(batch_map, "position")), map_head=_np(_g(batch_map, "heading")), obs_input=obs_in,
+                     obs_mask=obs_mask, obs_pos=_np(_g(batch_obs, "position")), obs_head=_np(_g(batch_obs, "heading")),
+                     # the prompt side arrives with decoder(); placeholders keep the engine's batch consistent
+                     prompt=np.zeros((B, N, spec.prompt_dim), np.float32), prompt_mask=valid, agent_type=np.ones((B, N), np.int64))
+        self.s.scene = scene
+        self.s.engine.set_scene(scene)
+        self.s.engine.encode_scene()
+        return self._result(scene)
+
+    def update_scene_emb(self, scene_embs, batch_obs, old_obs_agent_ids):
+        raise NotImplementedError("per-replan observation refresh runs inside ps_policy_step / ProSimHip.forward "
+                                  "(step_env + obs PointNet + token swap happen on the device)")
+
+
+@registry.register_decoder(name="attn_fusion_relpe")
+class HipDecoder:
+    """SymCoordDecoder (decoder/sym_coord.py:15) + the condition transformer at 'policy_decoder' (traj_sam.py:129-137)."""
+
+    def __init__(self, shared: _Shared):
+        self.s = shared
+
+    def __call__(self, scene_emb, prompt_enc, condition=None):
+        return self.forward(scene_emb, prompt_enc, condition)
+
+    def forward(self, scene_emb, prompt_enc, condition=None) -> Dict[str, Any]:
+        if not scene_emb.get("_hip_resident"):
+            raise ValueError("scene_emb must come from HipSceneEncoder (tokens are device-resident)")
+        sc, eng = self.s.scene, self.s.engine
+        pm = _np(_g(prompt_enc, "prompt_mask"), bool)
+        if not np.array_equal(pm, sc["prompt_mask"]):
+            raise NotImplementedError("prompt agents must be the observed agents")
+        head = _np(_g(prompt_enc, "heading"))
+        eng.set_prompt(_np(_g(prompt_enc, "prompt")), _np(_g(prompt_enc, "position")), head.reshape(pm.shape),
+                       _np(_g(prompt_enc, "agent_type"), np.int32))
+        if condition:
+            g, t = condition.get("goal"), condition.get("v_action_tag")
+            from .engine import _f, _u8, _i32
+            args, keep = [], []
+            for c in (g, t):
+                if c is None or np.asarray(c["input"]).shape[1] == 0:
+                    args += [0, None, None, None]
+                else:
+                    ci, cm = _np(c["input"]), _np(c["mask"], bool).astype(np.uint8)
+                    cp = np.ascontiguousarray(_np(c["prompt_idx"], np.int64)[..., 0], dtype=np.int32)
+                    keep += [ci, cm, cp]
+                    args += [ci.shape[1], _f(ci), _u8(cm), _i32(cp)]
+            eng._check(eng.lib.ps_set_conditions(eng.h, *args))
+        eng.generate_policy()
+        return dict(emd=torch.from_numpy(eng.padded("policy_emd")), agent_type=torch.from_numpy(_np(_g(prompt_enc, "agent_type"), np.int64)))
+
+
+@registry.register_policy(name="rel_pe_temporal")
+class HipPolicy:
+    """Policy_RelPE_Temporal / PolicyNoRNN (policy/base.py:9, temporal_ar.py:64) on the HIP engine."""
+
+    def __init__(self, shared: _Shared):
+        self.s = shared
+
+    def format_latent_state(self, latent_state_dict, all_batch_pair_names):
+        return None   # policy_no_rnn keeps no state (temporal_ar.py:70-72)
+
+    def __call__(self, *a, **k):
+        return self.forward(*a, **k)
+
+    def forward(self, policy_emd, batch_obs, batch_map, batch_pos, pair_names, latent_state) -> Dict[str, Any]:
+        def flat(bs):
+            m = _np(_g(bs, "mask"), bool)
+            BT = m.shape[0]
+            idx = np.repeat(np.arange(BT), m.shape[1]).reshape(m.shape)[m]
+            return (_np(_g(bs, "input"))[m], _np(_g(bs, "pos"))[m], _np(_g(bs, "ori"))[m].reshape(-1), idx, BT)
+        a_tok, a_pos, a_ori, a_b, BT = flat(batch_obs)
+        m_tok, m_pos, m_ori, m_b, _ = flat(batch_map)
+        emd = _np(_g(policy_emd, "emd"))
+        mp, fused = self.s.engine.policy_forward(BT, a_tok, a_pos, a_ori, a_b, m_tok, m_pos, m_ori, m_b, emd,
+                                                 _np(_g(batch_pos, "position")), _np(_g(batch_pos, "heading")).reshape(-1),
+                                                 _np(_g(policy_emd, "agent_type"), np.int32), _np(_g(policy_emd, "batch_idx"), np.int32))
+        if len(pair_names) != emd.shape[0]:
+            raise AssertionError("pair_names must name every policy row")     # the reference indexes by it (temporal_ar.py:22-35)
+        mp = torch.from_numpy(mp)
+        return dict(motion_pred=mp, motion_prob=torch.ones(mp.shape[0], mp.shape[1]), latent_state=latent_state,
+                    fused=torch.from_numpy(fused))
+
+
+@registry.register_model(name="prosim_policy_relpe_T_step_temporal_close_loop")
+class ProSimHip:
+    """``ProSim.forward(batch, 'val')`` (models/traj_sam.py:59-71) with the whole closed loop on the device."""
+
+    def __init__(self, spec: ModelSpec = DEMO_SPEC, weights: Optional[Dict[str, np.ndarray]] = None, device: int = 0):
+        if weights is None:
+            raise ValueError("weights required (prosim_amd.weights.from_state_dict(ckpt['state_dict']) or init_weights)")
+        self.spec = spec
+        self.tasks = ["motion_pred"]
+        self._shared = _Shared(spec, weights, device)
+        self.scene_encoder = registry.get_scene_encoder("attn_fusion_relpe")(self._shared)
+        self.decoder = registry.get_decoder("attn_fusion_relpe")(self._shared)
+        self.policy = registry.get_policy("rel_pe_temporal")(self._shared)
+
+    @property
+    def engine(self) -> Engine:
+        return self._shared.engine
+
+    def eval(self):
+        return self   # inference only: dropout never runs on this path
+
+    def __call__(self, batch, mode="val"):
+        return self.forward(batch, mode)
+
+    def forward(self, batch, mode="val") -> Dict[str, Any]:
+        if mode == "train":
+            raise NotImplementedError("training is out of scope (DESIGN.md)")
+        extras = batch.extras if hasattr(batch, "extras") else batch
+        spec, eng = self.spec, self.engine
+        scene = scene_from_extras(extras, spec)
+        eng.set_scene(scene)
+        eng.rollout()
+        B, N = scene["prompt_mask"].shape
+        pm = scene["prompt_mask"].astype(bool)
+        ids = _g(extras["prompt"]["motion_pred"], "agent_ids")
+        if ids is None:
+            ids = [[str(n) for n in range(int(pm[b].sum()))] for b in range(B)]
+        traj, vel = eng.padded("traj"), eng.padded("vel")
+        mp = torch.from_numpy(eng.get("motion_pred"))             # [R, A, K, S, D]
+        R, A = mp.shape[0], mp.shape[1]
+        slots = [(b, n) for b in range(B) for n in range(N) if pm[b, n]]
+        local = {}
+        for b in range(B):
+            local[b] = 0
+        names = []
+        for t in spec.all_t_indices:
+            cnt = {b: 0 for b in range(B)}
+            for (b, n) in slots:
+                names.append(f"{b}-{ids[b][cnt[b]]}-{t}")
+                cnt[b] += 1
+        out = {"motion_pred": mp.reshape(R * A, *mp.shape[2:]), "motion_prob": torch.ones(R * A, mp.shape[2]),
+               "pair_names": names, "reconst_pred": torch.from_numpy(eng.get("reconst_pred")).repeat(R, 1), "rollout_trajs": {}}
+        cnt = {b: 0 for b in range(B)}
+        for (b, n) in slots:
+            key = f"{b}-{ids[b][cnt[b]]}"
+            cnt[b] += 1
+            out["rollout_trajs"][key] = dict(traj=torch.from_numpy(traj[b, n]), vel=torch.from_numpy(vel[b, n]),
+                                             init_pos=torch.from_numpy(scene["obs_pos"][b, n]),
+                                             init_heading=torch.from_numpy(scene["obs_head"][b, n:n + 1]))
+        return {"motion_pred": out}

@@ -1,0 +1,106 @@
+"""GPU tests of the host-side mirror of the reference plugin interface (prosim_amd/modules.py):
+same registry names, same call signatures, same output dict layout as prosim/models/traj_sam.py."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from prosim_amd import synth, weights
+from prosim_amd.spec import SMALL_SPEC
+from oracle import prosim_oracle as orc
+from oracle.ref_harness import make_batch
+from gen_golden import FULL_CASES, SPECS
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def err(a, b):
+    return float(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max())
+
+
+@pytest.fixture(scope="module")
+def model():
+    from prosim_amd import modules
+    cls = modules.registry.get_model("prosim_policy_relpe_T_step_temporal_close_loop")   # MODEL.TYPE (trainer.py:160)
+    m = cls(SMALL_SPEC, weights.init_weights(SMALL_SPEC, 0)).eval()
+    yield m
+    m.engine.close()
+
+
+def test_registry_names_match_reference():
+    from prosim_amd import modules
+    r = modules.registry
+    assert r.get_scene_encoder("attn_fusion_relpe") is modules.HipSceneEncoder      # attn_fusion.py:11
+    assert r.get_decoder("attn_fusion_relpe") is modules.HipDecoder                # sym_coord.py:15
+    assert r.get_policy("rel_pe_temporal") is modules.HipPolicy                    # policy/base.py:9
+    assert r.get_policy("nope") is None
+
+
+def test_forward_output_contract_vs_fixture(model):
+    """ProSim.forward(batch,'val') drop-in: same keys/shapes as traj_sam.py:562-595 and the values of
+    the reference fixture (reference Python + stand-ins)."""
+    name = "small_ragged_b2"
+    sname, kw, wseed = FULL_CASES[name]
+    spec = SPECS[sname]
+    g = np.load(os.path.join(GOLD, f"ref_standins_{name}.npz"))
+    scene = synth.make_scene(spec, **kw)
+    batch = make_batch(scene, spec)
+    out = model(batch, "val")["motion_pred"]
+    assert set(out) >= {"motion_pred", "motion_prob", "pair_names", "reconst_pred", "rollout_trajs"}
+    A = int(scene["prompt_mask"].sum())
+    assert out["motion_pred"].shape == (spec.n_replans * A, 1, 10, 5) and len(out["pair_names"]) == spec.n_replans * A
+    assert out["pair_names"][0] == "0-a0-0" and out["pair_names"][-1].endswith("-70")
+    assert err(out["motion_pred"][:A].numpy(), g["motion_pred"][:A]) < 1e-4
+    floor = g["fp32_floor"][0]
+    for b in range(2):
+        for n in range(int(scene["prompt_mask"][b].sum())):
+            r = out["rollout_trajs"][f"{b}-a{n}"]
+            assert r["traj"].shape == (80, 4) and r["vel"].shape == (80, 2) and r["init_pos"].shape == (2,) and r["init_heading"].shape == (1,)
+            assert err(r["traj"].numpy(), g["traj"][b, n]) < 3 * floor + 1e-4
+    with pytest.raises(NotImplementedError):
+        model(batch, "train")
+
+
+def test_staged_components_and_stateless_policy(model):
+    """scene_encoder(...) -> decoder(...) -> policy(...) with the reference's argument layouts."""
+    spec = SMALL_SPEC
+    scene = synth.make_scene(spec, 12, 40, batch=2, seed=4, ragged=True)
+    w = weights.init_weights(spec, 0)
+    with torch.no_grad():
+        o = orc.rollout(w, spec, scene, dtype=torch.float64, collect=True)
+    batch = make_batch(scene, spec).extras
+    se = model.scene_encoder(batch["init_obs"], batch["init_map"])
+    for k in ("obs_mask", "map_mask", "scene_batch_idx", "scene_type", "scene_pos", "scene_ori", "scene_tokens", "max_map_num", "max_agent_num"):
+        assert k in se                                                           # attn_fusion.py:121-134
+    assert err(se["scene_tokens"].numpy(), o["trace"]["scene_tokens"].numpy()) < 1e-4
+    assert torch.equal(se["scene_type"], (torch.arange(se["scene_type"].numel()) >= se["_n_map_tokens"]).long())
+    pe = model.decoder(se, batch["prompt"]["motion_pred"])
+    assert err(pe["emd"].numpy(), o["policy_emd"].numpy()) < 1e-4 and pe["emd"].shape == (2, 12, 128)
+    # policy.forward on reference-style padded tokens (traj_sam.py:356-400 layout), replan 0
+    pm = torch.from_numpy(scene["prompt_mask"].astype(bool))
+    B, N = pm.shape
+    Mv = se["_n_map_tokens"]
+    def padded(tok, pos, ori, bidx, S):
+        inp, mask = torch.zeros(B, S, 128), torch.zeros(B, S, dtype=torch.bool)
+        p, o_ = torch.zeros(B, S, 2), torch.zeros(B, S, 1)
+        for b in range(B):
+            sel = bidx == b
+            n = int(sel.sum())
+            inp[b, :n], p[b, :n], o_[b, :n], mask[b, :n] = tok[sel], pos[sel], ori[sel], True
+        return dict(input=inp, mask=mask, pos=p, ori=o_)
+    tok = se["scene_tokens"]
+    bo = padded(tok[Mv:], se["scene_pos"][Mv:], se["scene_ori"][Mv:], se["scene_batch_idx"][Mv:], N)
+    bm = padded(tok[:Mv], se["scene_pos"][:Mv], se["scene_ori"][:Mv], se["scene_batch_idx"][:Mv], scene["map_mask"].shape[1])
+    bidx = orc._flat_batch_idx(pm)
+    pol_emd = dict(emd=pe["emd"][pm], agent_type=torch.from_numpy(scene["agent_type"])[pm], batch_idx=bidx)
+    pos = dict(position=torch.from_numpy(scene["obs_pos"])[pm], heading=orc.wrap_angle(torch.from_numpy(scene["obs_head"])[pm])[:, None])
+    names = [f"{int(b)}-x{i}-0" for i, b in enumerate(bidx)]
+    out = model.policy(pol_emd, bo, bm, pos, names, None)
+    A = int(pm.sum())
+    assert out["latent_state"] is None and model.policy.format_latent_state({}, [names]) is None
+    assert err(out["motion_pred"].numpy(), o["motion_pred"][:A].numpy()) < 1e-4
+    assert torch.equal(out["motion_prob"], torch.ones(A, 1))
+    with pytest.raises(AssertionError):
+        model.policy(pol_emd, bo, bm, pos, names[:-1], None)
