@@ -52,16 +52,25 @@ def executed_flops_chain(A: int, e_a2p: float, e_m2p: float, layers: int) -> flo
 def cpu_baseline(spec, w, scene, reps: int = 3):
     """The oracle (CPU restatement, oracle/prosim_oracle.py) timed on this box's host cores."""
     from oracle import prosim_oracle as orc
-    cores = os.cpu_count() or 1
+    phys = os.cpu_count() or 1
     try:
         import psutil
-        cores = psutil.cpu_count(logical=False) or cores
+        phys = psutil.cpu_count(logical=False) or phys
     except Exception:
         pass
-    cores = min(cores, 64)
-    torch.set_num_threads(cores)
+    # torch's CPU kernels on these small graphs stop scaling (and then regress) well before all cores:
+    # sweep a few thread counts once and time the best one -- the strongest CPU number we can produce
+    best, cores = None, 1
     with torch.no_grad():
-        orc.rollout(w, spec, scene)  # warm-up
+        for nt in sorted({c for c in (8, 16, 32, phys) if c <= phys}):
+            torch.set_num_threads(nt)
+            orc.rollout(w, spec, scene)  # warm-up at this thread count
+            t0 = time.perf_counter()
+            orc.rollout(w, spec, scene)
+            dt_ = time.perf_counter() - t0
+            if best is None or dt_ < best:
+                best, cores = dt_, nt
+        torch.set_num_threads(cores)
         ts = []
         for _ in range(reps):
             t0 = time.perf_counter()
@@ -71,7 +80,7 @@ def cpu_baseline(spec, w, scene, reps: int = 3):
     med = float(np.median(ts))
     return dict(value=A * spec.max_steps / med, unit="agent-steps/s", cores=cores, kind="port",
                 sample=f"{reps} full rollouts of ONE scene of the batch (CPU throughput does not depend on the batch; median {med:.3f} s each), torch {torch.__version__} fp32, "
-                       f"{cores} intra-op threads")
+                       f"{cores} intra-op threads (best of a sweep over 8/16/32/all {phys} physical cores)")
 
 
 def main():
