@@ -57,6 +57,7 @@ struct DevBuf {
 struct EdgeSet {  // CSR by destination + normalised rel-PE
   DevBuf<int> cnt, eoff, esrc, edst;
   DevBuf<float> rt;
+  DevBuf<_Float16> rthl;
   size_t cap_edges = 0;
   int nq = 0;
   int maxdeg = 0;
@@ -94,6 +95,7 @@ struct ps_engine {
   DevBuf<float> d_tok, d_tok_pos, d_tok_ori, d_init_pos, d_init_head, d_cur_pos, d_cur_ori, d_prompt_pos, d_prompt_ori;
   DevBuf<float> d_xp, d_emd, d_xc, d_fused, d_obs_in, d_static_in, d_kv, d_kv_s2p, d_kv_m2p, d_kv_a2p;
   DevBuf<float> d_traj, d_vel, d_motion, d_reconst;
+  DevBuf<_Float16> d_kh, d_kh_s2p, d_kh_m2p, d_kh_a2p;   // split-fp16 k rows beside each kv buffer
   EdgeSet e_a2a, e_s2s, e_p2p, e_s2p, e_a2p, e_m2p, e_cnd;
   DevBuf<ChainStep> d_steps;
   std::vector<ChainStep> h_steps;
@@ -470,8 +472,9 @@ extern "C" void ps_destroy(ps_engine* e) {
   e->d_xp.release(); e->d_emd.release(); e->d_xc.release(); e->d_fused.release(); e->d_obs_in.release();
   e->d_static_in.release(); e->d_kv.release(); e->d_kv_s2p.release(); e->d_kv_m2p.release(); e->d_kv_a2p.release();
   e->d_traj.release(); e->d_vel.release(); e->d_motion.release(); e->d_reconst.release();
+  e->d_kh.release(); e->d_kh_s2p.release(); e->d_kh_m2p.release(); e->d_kh_a2p.release();
   for (EdgeSet* s : {&e->e_a2a, &e->e_s2s, &e->e_p2p, &e->e_s2p, &e->e_a2p, &e->e_m2p, &e->e_cnd}) {
-    s->cnt.release(); s->eoff.release(); s->esrc.release(); s->edst.release(); s->rt.release();
+    s->cnt.release(); s->eoff.release(); s->esrc.release(); s->edst.release(); s->rt.release(); s->rthl.release();
   }
   e->d_steps.release(); e->d_ent_off.release(); e->d_ent_type.release(); e->d_ent_val.release();
   drop_graph(e);
@@ -498,7 +501,7 @@ int edge_alloc(EdgeSet& s, int nq, size_t cap_edges, int maxdeg) {
   s.cap_edges = cap_edges;
   s.maxdeg = std::max(1, maxdeg);
   if (s.cnt.ensure(nq + 1) || s.eoff.ensure(nq + 1) || s.esrc.ensure(cap_edges + 1) || s.edst.ensure(cap_edges + 1) ||
-      s.rt.ensure((cap_edges + 1) * 128))
+      s.rt.ensure((cap_edges + 1) * 128) || s.rthl.ensure((cap_edges + 1) * 256))
     return -1;
   return 0;
 }
@@ -605,6 +608,8 @@ extern "C" int ps_set_scene(ps_engine* e, int32_t B, int32_t M, int32_t P, int32
       e->d_xc.ensure((size_t)A * D) || e->d_fused.ensure((size_t)A * D) || e->d_obs_in.ensure((size_t)A * Hs * Od) ||
       e->d_kv.ensure((size_t)(Mv + A) * 256) || e->d_kv_s2p.ensure((size_t)L6 * (Mv + A) * 256) ||
       e->d_kv_m2p.ensure((size_t)L6 * std::max(Mv, 1) * 256) || e->d_kv_a2p.ensure((size_t)L6 * A * 256) ||
+      e->d_kh.ensure((size_t)(Mv + A) * 256) || e->d_kh_s2p.ensure((size_t)L6 * (Mv + A) * 256) ||
+      e->d_kh_m2p.ensure((size_t)L6 * std::max(Mv, 1) * 256) || e->d_kh_a2p.ensure((size_t)L6 * A * 256) ||
       e->d_traj.ensure((size_t)A * e->stride_steps * 4) || e->d_vel.ensure((size_t)A * e->stride_steps * 2) ||
       e->d_motion.ensure((size_t)R * A * c.target_steps * c.state_dim) || e->d_reconst.ensure((size_t)A * 2))
     return fail(PS_E_HIP, "device allocation failed");
@@ -641,31 +646,33 @@ extern "C" int ps_set_scene(ps_engine* e, int32_t B, int32_t M, int32_t P, int32
   }
   // ---- chain step tables (device pointers are stable until the next ps_set_scene)
   e->h_steps.clear();
-  auto push = [&](const AttnW& w, const float* kv, EdgeSet& es) {
+  auto push = [&](const AttnW& w, const float* kv, const _Float16* khl, EdgeSet& es) {
     ChainStep s;
     s.w = w;
     s.kv = kv;
+    s.khl = khl;
+    s.rthl = es.rthl.p;
     s.eoff = es.eoff.p;
     s.esrc = es.esrc.p;
     s.rt = es.rt.p;
     e->h_steps.push_back(s);
   };
   e->step_a2a = (int)e->h_steps.size();
-  for (int i = 0; i < c.scene_layers; ++i) push(e->a2a[i], e->d_kv.p, e->e_a2a);
+  for (int i = 0; i < c.scene_layers; ++i) push(e->a2a[i], e->d_kv.p, e->d_kh.p, e->e_a2a);
   e->step_s2s = (int)e->h_steps.size();
-  for (int i = 0; i < c.scene_layers; ++i) push(e->s2s[i], e->d_kv.p, e->e_s2s);
+  for (int i = 0; i < c.scene_layers; ++i) push(e->s2s[i], e->d_kv.p, e->d_kh.p, e->e_s2s);
   e->step_dec = (int)e->h_steps.size();
   for (int i = 0; i < c.dec_layers; ++i) {
-    push(e->p2p[i], e->d_kv.p, e->e_p2p);
-    push(e->s2p[i], e->d_kv_s2p.p + (size_t)i * (Mv + A) * 256, e->e_s2p);
+    push(e->p2p[i], e->d_kv.p, e->d_kh.p, e->e_p2p);
+    push(e->s2p[i], e->d_kv_s2p.p + (size_t)i * (Mv + A) * 256, e->d_kh_s2p.p + (size_t)i * (Mv + A) * 256, e->e_s2p);
   }
   e->step_cnd = (int)e->h_steps.size();
-  for (int i = 0; i < c.cond_layers; ++i) push(e->cnd[i], e->d_kv.p, e->e_cnd);
+  for (int i = 0; i < c.cond_layers; ++i) push(e->cnd[i], e->d_kv.p, e->d_kh.p, e->e_cnd);
   e->step_pol = (int)e->h_steps.size();
   for (int i = 0; i < c.pol_layers; ++i) {
     // a2p edges carry GLOBAL agent rows (Mv + j); the kv buffer is agent-local -> bias the base by -Mv rows
-    push(e->a2p[i], e->d_kv_a2p.p + (size_t)i * A * 256 - (size_t)Mv * 256, e->e_a2p);
-    push(e->m2p[i], e->d_kv_m2p.p + (size_t)i * Mv * 256, e->e_m2p);
+    push(e->a2p[i], e->d_kv_a2p.p + (size_t)i * A * 256 - (size_t)Mv * 256, e->d_kh_a2p.p + (size_t)i * A * 256 - (size_t)Mv * 256, e->e_a2p);
+    push(e->m2p[i], e->d_kv_m2p.p + (size_t)i * Mv * 256, e->d_kh_m2p.p + (size_t)i * Mv * 256, e->e_m2p);
   }
   if (upload(e->d_steps, e->h_steps.data(), e->h_steps.size(), st)) return fail(PS_E_HIP, "step table upload failed");
   // no conditions until ps_set_conditions
@@ -812,16 +819,16 @@ int launch_chain(ps_engine* e, float* x, int Nd, int step0, int nsteps, int maxd
   return hipGetLastError() == hipSuccess ? 0 : fail(PS_E_HIP, "k_attn_chain launch failed");
 }
 
-void launch_kv(ps_engine* e, const float* x, int Ns, int layer0, int nlayers, float* kv, size_t layer_stride) {
+void launch_kv(ps_engine* e, const float* x, int Ns, int layer0, int nlayers, float* kv, _Float16* khl, size_t layer_stride) {
   if (Ns <= 0 || nlayers <= 0) return;
   const int T = Ns >= 1024 ? 4 : (Ns >= 512 ? 2 : 1);
   const AttnW* L = e->d_layers + layer0;
   if (T == 4)
-    hipLaunchKernelGGL(k_kv_proj<4>, dim3((Ns + 3) / 4, nlayers), dim3(WG), 0, e->stream, x, Ns, L, kv, layer_stride, e->cfg.ln_eps);
+    hipLaunchKernelGGL(k_kv_proj<4>, dim3((Ns + 3) / 4, nlayers), dim3(WG), 0, e->stream, x, Ns, L, kv, khl, layer_stride, e->cfg.ln_eps);
   else if (T == 2)
-    hipLaunchKernelGGL(k_kv_proj<2>, dim3((Ns + 1) / 2, nlayers), dim3(WG), 0, e->stream, x, Ns, L, kv, layer_stride, e->cfg.ln_eps);
+    hipLaunchKernelGGL(k_kv_proj<2>, dim3((Ns + 1) / 2, nlayers), dim3(WG), 0, e->stream, x, Ns, L, kv, khl, layer_stride, e->cfg.ln_eps);
   else
-    hipLaunchKernelGGL(k_kv_proj<1>, dim3(Ns, nlayers), dim3(WG), 0, e->stream, x, Ns, L, kv, layer_stride, e->cfg.ln_eps);
+    hipLaunchKernelGGL(k_kv_proj<1>, dim3(Ns, nlayers), dim3(WG), 0, e->stream, x, Ns, L, kv, khl, layer_stride, e->cfg.ln_eps);
 }
 
 void launch_pointnet(ps_engine* e, const PointNetW& w, const float* pts, const uint8_t* mask, const int* rows, int n_rows,
@@ -853,7 +860,7 @@ void launch_radius(ps_engine* e, EdgeSet& es, const int* r1, const int* r2, cons
   const int pe_grid = (int)std::min<size_t>(4096, (es.cap_edges + 3) / 4 + 1);
   hipLaunchKernelGGL(k_relpe, dim3(pe_grid), dim3(256), 0, st, (const int*)es.esrc.p, (const int*)es.edst.p,
                      (const int*)(es.eoff.p + nq), 0, (const float*)e->d_tok_pos.p, src_ori, qpos, dst_ori, e->div32,
-                     (const float*)nullptr, es.rt.p, e->cfg.ln_eps);
+                     (const float*)nullptr, es.rt.p, es.rthl.p, e->cfg.ln_eps);
 }
 
 }  // namespace
@@ -882,18 +889,18 @@ extern "C" int ps_encode_scene(ps_engine* e) {
     hipLaunchKernelGGL(k_relpe, dim3(1024), dim3(256), 0, st, (const int*)e->e_a2a.esrc.p, (const int*)e->e_a2a.edst.p,
                        (const int*)nullptr, (int)e->edge_counts[0], (const float*)e->d_tok_pos.p, (const float*)e->d_tok_ori.p,
                        (const float*)(e->d_tok_pos.p + 2 * (size_t)Mv), (const float*)(e->d_tok_ori.p + Mv), e->div32,
-                       (const float*)nullptr, e->e_a2a.rt.p, c.ln_eps);
+                       (const float*)nullptr, e->e_a2a.rt.p, e->e_a2a.rthl.p, c.ln_eps);
     hipLaunchKernelGGL(k_relpe, dim3(2048), dim3(256), 0, st, (const int*)e->e_s2s.esrc.p, (const int*)e->e_s2s.edst.p,
                        (const int*)nullptr, (int)e->edge_counts[1], (const float*)e->d_tok_pos.p, (const float*)e->d_tok_ori.p,
                        (const float*)e->d_tok_pos.p, (const float*)e->d_tok_ori.p, e->div32, (const float*)nullptr,
-                       e->e_s2s.rt.p, c.ln_eps);
+                       e->e_s2s.rt.p, e->e_s2s.rthl.p, c.ln_eps);
   }
   // 6 x (a2a on the agent rows in place, s2s on all rows)  (attn_fusion.py:117-119).  kv is indexed by
   // GLOBAL token row for both (the a2a projection fills rows Mv.. of the shared kv buffer).
   for (int i = 0; i < c.scene_layers; ++i) {
-    launch_kv(e, tok + (size_t)Mv * D, A, e->L_a2a + i, 1, e->d_kv.p + (size_t)Mv * 256, 0);
+    launch_kv(e, tok + (size_t)Mv * D, A, e->L_a2a + i, 1, e->d_kv.p + (size_t)Mv * 256, e->d_kh.p + (size_t)Mv * 256, 0);
     if (launch_chain(e, tok + (size_t)Mv * D, A, e->step_a2a + i, 1, e->e_a2a.maxdeg)) return PS_E_HIP;
-    launch_kv(e, tok, Mv + A, e->L_s2s + i, 1, e->d_kv.p, 0);
+    launch_kv(e, tok, Mv + A, e->L_s2s + i, 1, e->d_kv.p, e->d_kh.p, 0);
     if (launch_chain(e, tok, Mv + A, e->step_s2s + i, 1, e->e_s2s.maxdeg)) return PS_E_HIP;
   }
   HIPCHK(hipGetLastError());
@@ -926,21 +933,21 @@ extern "C" int ps_generate_policy(ps_engine* e) {
   launch_radius(e, e->e_s2p, e->d_r_map.p, e->d_r_agent.p, ppos, pscene, A, c.dec_scene_radius, c.dec_max_neigh, -1,
                 e->d_tok_ori.p, pori);
   // k|v of the (fixed) scene tokens for all s2p layers in one launch
-  launch_kv(e, e->d_tok.p, Mv + A, e->L_s2p, c.dec_layers, e->d_kv_s2p.p, (size_t)(Mv + A) * 256);
+  launch_kv(e, e->d_tok.p, Mv + A, e->L_s2p, c.dec_layers, e->d_kv_s2p.p, e->d_kh_s2p.p, (size_t)(Mv + A) * 256);
   const int md = std::max(e->e_p2p.maxdeg, e->e_s2p.maxdeg);
   for (int i = 0; i < c.dec_layers; ++i) {
     // p2p edges carry GLOBAL agent rows (Mv + j): project into rows Mv.. of the shared kv buffer
-    launch_kv(e, e->d_xp.p, A, e->L_p2p + i, 1, e->d_kv.p + (size_t)Mv * 256, 0);
+    launch_kv(e, e->d_xp.p, A, e->L_p2p + i, 1, e->d_kv.p + (size_t)Mv * 256, e->d_kh.p + (size_t)Mv * 256, 0);
     if (launch_chain(e, e->d_xp.p, A, e->step_dec + 2 * i, 2, md)) return PS_E_HIP;
   }
   HIPCHK(hipMemcpyAsync(e->d_emd.p, e->d_xp.p, sizeof(float) * (size_t)A * D, hipMemcpyDeviceToDevice, st));
   // condition transformer at 'policy_decoder' (traj_sam.py:129-137)
   if (e->have_cond && c.cond_layers > 0) {
     hipLaunchKernelGGL(k_cond_edges, dim3(e->n_cond_edges), dim3(128), 0, st, e->cond, (const int*)e->d_ent_off.p,
-                       (const int*)e->d_ent_type.p, (const float*)e->d_ent_val.p, e->n_cond_edges, e->e_cnd.rt.p, c.ln_eps);
+                       (const int*)e->d_ent_type.p, (const float*)e->d_ent_val.p, e->n_cond_edges, e->e_cnd.rt.p, e->e_cnd.rthl.p, c.ln_eps);
     HIPCHK(hipMemcpyAsync(e->d_xc.p, e->d_emd.p, sizeof(float) * (size_t)A * D, hipMemcpyDeviceToDevice, st));
     for (int i = 0; i < c.cond_layers; ++i) {
-      launch_kv(e, e->d_xc.p, A, e->L_cnd + i, 1, e->d_kv.p, 0);
+      launch_kv(e, e->d_xc.p, A, e->L_cnd + i, 1, e->d_kv.p, e->d_kh.p, 0);
       if (launch_chain(e, e->d_xc.p, A, e->step_cnd + i, 1, 1)) return PS_E_HIP;
     }
     hipLaunchKernelGGL(k_add_rows, dim3((A * D + 255) / 256), dim3(256), 0, st, e->d_emd.p, (const float*)e->d_xc.p, A * D);
@@ -949,7 +956,7 @@ extern "C" int ps_generate_policy(ps_engine* e) {
   hipLaunchKernelGGL(k_mlp_rows, dim3(A), dim3(128), 0, st, e->mlp_pred, (const float*)e->d_emd.p, (const int*)nullptr, D,
                      e->d_reconst.p, 2, c.ln_eps);
   // k|v of the map tokens for all m2p layers: map tokens never change during the rollout
-  launch_kv(e, e->d_tok.p, Mv, e->L_m2p, c.pol_layers, e->d_kv_m2p.p, (size_t)Mv * 256);
+  launch_kv(e, e->d_tok.p, Mv, e->L_m2p, c.pol_layers, e->d_kv_m2p.p, e->d_kh_m2p.p, (size_t)Mv * 256);
   HIPCHK(hipGetLastError());
   e->generated = true;
   return PS_OK;
@@ -992,7 +999,7 @@ extern "C" int ps_policy_step(ps_engine* e, int32_t t_idx) {
     HIPCHK(hipMemcpyAsync(e->d_tok_ori.p + Mv, e->d_cur_ori.p, sizeof(float) * A, hipMemcpyDeviceToDevice, st));
   }
   // policy.forward (policy/base.py:19 -> temporal_ar.py:75 -> act_decoder.py:239-283)
-  launch_kv(e, atok, A, e->L_a2p, c.pol_layers, e->d_kv_a2p.p, (size_t)A * 256);
+  launch_kv(e, atok, A, e->L_a2p, c.pol_layers, e->d_kv_a2p.p, e->d_kh_a2p.p, (size_t)A * 256);
   const int* pscene = e->d_tok_scene.p + Mv;
   launch_radius(e, e->e_a2p, e->d_r_agent.p, nullptr, e->d_cur_pos.p, pscene, A, c.pol_agent_radius, c.pol_max_neigh, -1,
                 e->d_tok_ori.p, e->d_cur_ori.p);
@@ -1251,23 +1258,26 @@ extern "C" int ps_test_attn(ps_engine* e, int32_t layer_index, int32_t Ns, int32
   if (layer_index < 0 || layer_index >= (int)e->all_layers.size()) return fail(PS_E_ARG, "layer index out of range");
   HIPCHK(hipSetDevice(e->cfg.device));
   DevBuf<float> dxs, dxd, drt, dkv;
+  DevBuf<_Float16> drth, dkh;
   DevBuf<int> doff, dsrc;
   DevBuf<ChainStep> dstep;
   int maxdeg = 1;
   for (int i = 0; i < Nd; ++i) maxdeg = std::max(maxdeg, eoff[i + 1] - eoff[i]);
   if (upload(dxs, x_src, (size_t)Ns * D, e->stream) || upload(dxd, x_dst, (size_t)Nd * D, e->stream) ||
       upload(drt, rt, (size_t)std::max(E, 1) * 128, e->stream) || upload(doff, (const int*)eoff, (size_t)Nd + 1, e->stream) ||
-      upload(dsrc, (const int*)esrc, (size_t)std::max(E, 1), e->stream) || dkv.ensure((size_t)Ns * 256))
+      upload(dsrc, (const int*)esrc, (size_t)std::max(E, 1), e->stream) || dkv.ensure((size_t)Ns * 256) ||
+      drth.ensure((size_t)std::max(E, 1) * 256) || dkh.ensure((size_t)Ns * 256))
     return fail(PS_E_HIP, "test upload failed");
-  launch_kv(e, dxs.p, Ns, layer_index, 1, dkv.p, 0);
+  launch_kv(e, dxs.p, Ns, layer_index, 1, dkv.p, dkh.p, 0);
+  hipLaunchKernelGGL(k_split_rows, dim3((std::max(E, 1) * 128 + 255) / 256), dim3(256), 0, e->stream, (const float*)drt.p, std::max(E, 1), drth.p);
   ChainStep st;
   st.w = e->all_layers[layer_index];
-  st.kv = dkv.p; st.eoff = doff.p; st.esrc = dsrc.p; st.rt = drt.p;
+  st.kv = dkv.p; st.eoff = doff.p; st.esrc = dsrc.p; st.rt = drt.p; st.rthl = drth.p; st.khl = dkh.p;
   if (upload(dstep, &st, 1, e->stream)) return fail(PS_E_HIP, "test upload failed");
   if (launch_chain(e, dxd.p, Nd, 0, 1, maxdeg, false, dstep.p, T)) return PS_E_HIP;
   HIPCHK(hipStreamSynchronize(e->stream));
   HIPCHK(hipMemcpy(out, dxd.p, sizeof(float) * (size_t)Nd * D, hipMemcpyDeviceToHost));
-  dxs.release(); dxd.release(); drt.release(); dkv.release(); doff.release(); dsrc.release(); dstep.release();
+  dxs.release(); dxd.release(); drt.release(); dkv.release(); doff.release(); dsrc.release(); dstep.release(); drth.release(); dkh.release();
   return PS_OK;
 }
 
@@ -1373,6 +1383,7 @@ extern "C" int ps_policy_forward(ps_engine* e, int32_t n_scenes, int32_t Na, con
     pscene[i] = p_scene[i];
   }
   DevBuf<float> d_pos, d_ori, d_atok, d_mtok, d_ppos, d_pori, d_x, d_kva, d_kvm, d_motion, d_traj, d_vel;
+  DevBuf<_Float16> d_kha, d_khm;
   DevBuf<int> d_rmap, d_ragent, d_pscene, d_ptype;
   EdgeSet ea, em;
   DevBuf<ChainStep> d_steps;
@@ -1387,22 +1398,23 @@ extern "C" int ps_policy_forward(ps_engine* e, int32_t n_scenes, int32_t Na, con
       upload(d_rmap, r_map.data(), r_map.size(), st) || upload(d_ragent, r_agent.data(), r_agent.size(), st) ||
       upload(d_pscene, pscene.data(), pscene.size(), st) || upload(d_ptype, ptype.data(), ptype.size(), st) ||
       d_kva.ensure((size_t)L * std::max(Na, 1) * 256) || d_kvm.ensure((size_t)L * std::max(Nm, 1) * 256) ||
+      d_kha.ensure((size_t)L * std::max(Na, 1) * 256) || d_khm.ensure((size_t)L * std::max(Nm, 1) * 256) ||
       d_motion.ensure((size_t)A * OUT) || d_traj.ensure((size_t)A * 16 * 4) || d_vel.ensure((size_t)A * 16 * 2) ||
       edge_alloc(ea, A, (size_t)A * da, da) || edge_alloc(em, A, (size_t)A * dm, dm))
     return fail(PS_E_HIP, "ps_policy_forward: upload/alloc failed");
   // the launch helpers read token geometry from the engine: swap in the caller's arrays for this call
   std::swap(e->d_tok_pos, d_pos);
-  launch_kv(e, d_atok.p, Na, e->L_a2p, L, d_kva.p, (size_t)Na * 256);
-  launch_kv(e, d_mtok.p, Nm, e->L_m2p, L, d_kvm.p, (size_t)Nm * 256);
+  launch_kv(e, d_atok.p, Na, e->L_a2p, L, d_kva.p, d_kha.p, (size_t)Na * 256);
+  launch_kv(e, d_mtok.p, Nm, e->L_m2p, L, d_kvm.p, d_khm.p, (size_t)Nm * 256);
   launch_radius(e, ea, d_ragent.p, nullptr, d_ppos.p, d_pscene.p, A, c.pol_agent_radius, c.pol_max_neigh, -1, d_ori.p, d_pori.p);
   launch_radius(e, em, d_rmap.p, nullptr, d_ppos.p, d_pscene.p, A, c.pol_map_radius, c.pol_max_neigh, -1, d_ori.p, d_pori.p);
   std::vector<ChainStep> hs;
   for (int i = 0; i < L; ++i) {
     ChainStep s1;
-    s1.w = e->a2p[i]; s1.kv = d_kva.p + (size_t)i * Na * 256 - (size_t)Nm * 256; s1.eoff = ea.eoff.p; s1.esrc = ea.esrc.p; s1.rt = ea.rt.p;
+    s1.w = e->a2p[i]; s1.kv = d_kva.p + (size_t)i * Na * 256 - (size_t)Nm * 256; s1.eoff = ea.eoff.p; s1.esrc = ea.esrc.p; s1.rt = ea.rt.p; s1.rthl = ea.rthl.p; s1.khl = d_kha.p + (size_t)i * Na * 256 - (size_t)Nm * 256;
     hs.push_back(s1);
     ChainStep s2;
-    s2.w = e->m2p[i]; s2.kv = d_kvm.p + (size_t)i * Nm * 256; s2.eoff = em.eoff.p; s2.esrc = em.esrc.p; s2.rt = em.rt.p;
+    s2.w = e->m2p[i]; s2.kv = d_kvm.p + (size_t)i * Nm * 256; s2.eoff = em.eoff.p; s2.esrc = em.esrc.p; s2.rt = em.rt.p; s2.rthl = em.rthl.p; s2.khl = d_khm.p + (size_t)i * Nm * 256;
     hs.push_back(s2);
   }
   int rc = 0;
@@ -1426,7 +1438,8 @@ extern "C" int ps_policy_forward(ps_engine* e, int32_t n_scenes, int32_t Na, con
   }
   for (DevBuf<float>* b : {&d_pos, &d_ori, &d_atok, &d_mtok, &d_ppos, &d_pori, &d_x, &d_kva, &d_kvm, &d_motion, &d_traj, &d_vel}) b->release();
   for (DevBuf<int>* b : {&d_rmap, &d_ragent, &d_pscene, &d_ptype}) b->release();
-  for (EdgeSet* s_ : {&ea, &em}) { s_->cnt.release(); s_->eoff.release(); s_->esrc.release(); s_->edst.release(); s_->rt.release(); }
+  d_kha.release(); d_khm.release();
+  for (EdgeSet* s_ : {&ea, &em}) { s_->cnt.release(); s_->eoff.release(); s_->esrc.release(); s_->edst.release(); s_->rt.release(); s_->rthl.release(); }
   d_steps.release();
   return rc;
 }

@@ -44,6 +44,8 @@ struct ChainStep {
   const int* eoff;    // [Nd+1] CSR offsets by destination
   const int* esrc;    // [E] source row in kv
   const float* rt;    // [E][128] normalised relative-PE (no affine)
+  const _Float16* rthl;   // [E][256]: the same rows as split fp16 (hi[128] | lo[128]) for the score MFMAs
+  const _Float16* khl;    // [Ns][256]: the k rows of kv as split fp16 (hi | lo)
 };
 
 // Edge lists are walked in chunks of CH edges per destination with an online (running max / sum)
@@ -131,10 +133,20 @@ __device__ __forceinline__ void fold_kgroups(float (&acc)[T][4]) {
   }
 }
 
+// stage helper: with PF the chunk in CUR was requested a stage ago and NXT is requested now; without PF
+// CUR is requested here and used straight away (one register set live)
+#define PS_STAGE(CUR, CURP, CURN, NXT, NXTP, NXTN, X, XS) \
+  do {                                                    \
+    if (PF) wload(NXT, NXTP, NXTN);                       \
+    else wload(CUR, CURP, CURN);                          \
+    wfma<T>(CUR, X, XS, acc);                             \
+  } while (0)
+
 template <int T>
 __global__ __launch_bounds__(WG, 1) void k_attn_chain(float* __restrict__ x, int Nd, const ChainStep* __restrict__ steps,
                                                      int nsteps, int maxdeg, float eps, int flags) {
   constexpr int W = 4 / T;  // waves per destination in the edge phase
+  constexpr bool PF = (T == 1);  // weight prefetch one chunk ahead only where the registers allow it
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* xs = smem;                 // [T][128] residual stream
   float* xn = xs + 128 * T;         // [T][128] normed / scratch row
@@ -162,7 +174,7 @@ __global__ __launch_bounds__(WG, 1) void k_attn_chain(float* __restrict__ x, int
   // chunks in flight measured no faster -- a CU's 4 waves already pull ~100 GB/s, the per-CU
   // L2->register ceiling measured by ps_test_stream -- and spill at T = 4.)
   WC wA, wB;
-  wload(wA, steps[0].w.Wq_t + woff_o, 128);
+  if (PF) wload(wA, steps[0].w.Wq_t + woff_o, 128);
   // small vectors of layer 0 -> LDS buffer 0 (608 float4: threads take float4 tid, tid+256, tid+512)
   float4 spr[3];
   auto sp_load = [&](const float* __restrict__ sp) {
@@ -214,8 +226,7 @@ __global__ __launch_bounds__(WG, 1) void k_attn_chain(float* __restrict__ x, int
     {
       float acc[T][4];
       zero_acc<T>(acc);
-      wload(wB, w.Ws_t + woff, 128);
-      wfma<T>(wA, xn + kgl * 16, 128, acc);                                             // Wq
+      PS_STAGE(wA, w.Wq_t + woff, 128, wB, w.Ws_t + woff, 128, xn + kgl * 16, 128);    // Wq
       fold_kgroups<T, 8>(acc);
       if (kgl == 0) {
 #pragma unroll
@@ -225,8 +236,7 @@ __global__ __launch_bounds__(WG, 1) void k_attn_chain(float* __restrict__ x, int
                           acc[tt][3] + sp[SP_BQ + ncol + 3]);
       }
       zero_acc<T>(acc);
-      wload(wA, w.Wgx_t + woff, 128);
-      wfma<T>(wB, xn + kgl * 16, 128, acc);                                             // Ws
+      PS_STAGE(wB, w.Ws_t + woff, 128, wA, w.Wgx_t + woff, 128, xn + kgl * 16, 128);   // Ws
       fold_kgroups<T, 8>(acc);
       if (kgl == 0) {
 #pragma unroll
@@ -237,8 +247,7 @@ __global__ __launch_bounds__(WG, 1) void k_attn_chain(float* __restrict__ x, int
       }
       zero_acc<T>(acc);
       // q~ chunk: wave -> heads 2*wave, 2*wave+1; lane -> (k2 = lane >> 5, 4 columns c32); rows 16*head..
-      wload(wB, w.Wkr_g + (size_t)((2 * wave + k2) * 16) * 128 + 4 * c32, 128);
-      wfma<T>(wA, xn + kgl * 16, 128, acc);                                             // Wgx
+      PS_STAGE(wA, w.Wgx_t + woff, 128, wB, w.Wkr_g + (size_t)((2 * wave + k2) * 16) * 128 + 4 * c32, 128, xn + kgl * 16, 128);   // Wgx
       fold_kgroups<T, 8>(acc);
       if (kgl == 0) {
 #pragma unroll
@@ -254,6 +263,7 @@ __global__ __launch_bounds__(WG, 1) void k_attn_chain(float* __restrict__ x, int
       const int h = 2 * wave + k2;
       float acc[T][4];
       zero_acc<T>(acc);
+      if (!PF) wload(wB, w.Wkr_g + (size_t)(h * 16) * 128 + 4 * c32, 128);
       wfma<T>(wB, qb + h * 16, 128, acc);                                               // Wkr_g
 #pragma unroll
       for (int tt = 0; tt < T; ++tt)
@@ -275,16 +285,31 @@ __global__ __launch_bounds__(WG, 1) void k_attn_chain(float* __restrict__ x, int
       float* sc = un + (size_t)t * CH * 8;
       const int hl = lane >> 3, jl = lane & 7;
       const float* rbase = st.rt + (size_t)e_beg * 128 + 2 * lane;
-      const float* kbase = st.kv + 2 * lane;
-      float q0[8], q1[8];
+      // B operands of the score MFMAs, built once per destination and layer: lane -> column n = lane & 15
+      // (head n & 7, hi half for n < 8 / lo half for n >= 8), k-block lane >> 4 (8 consecutive columns)
+      half8 bq[4], bk[4];
+      {
+        const int n = lane & 15, hB = n & 7, kqB = lane >> 4;
+        const bool lo = n >= 8;
 #pragma unroll
-      for (int h = 0; h < 8; ++h) {
-        const float2 v = *reinterpret_cast<const float2*>(big + (size_t)(t * 8 + h) * QP + 2 * lane);
-        q0[h] = v.x;
-        q1[h] = v.y;
+        for (int ks = 0; ks < 4; ++ks) {
+          const float* qp = big + (size_t)(t * 8 + hB) * QP + 32 * ks + 8 * kqB;
+          const float4 v0 = *reinterpret_cast<const float4*>(qp), v1 = *reinterpret_cast<const float4*>(qp + 4);
+          const float qv_[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+          // k rows: column block 32*ks + 8*kq lies inside head 2*ks + (kq >> 1); only that head's q is non-zero
+          const bool mine = (2 * ks + (kqB >> 1)) == hB;
+          const float* kp = qb + t * 128 + 32 * ks + 8 * kqB;
+          const float4 w0 = *reinterpret_cast<const float4*>(kp), w1 = *reinterpret_cast<const float4*>(kp + 4);
+          const float kv_[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            bq[ks][j] = lo ? f16_lo(qv_[j]) : f16_hi(qv_[j]);
+            const float kk = mine ? kv_[j] : 0.f;
+            bk[ks][j] = lo ? f16_lo(kk) : f16_hi(kk);
+          }
+        }
       }
-      const float2 qv = *reinterpret_cast<const float2*>(qb + t * 128 + 2 * lane);
-      const float cqL = cq[t * 8 + hl];
+      const float cqm = cq[t * 8 + (lane & 7)];
       float ar[8][2], av0 = 0.f, av1 = 0.f, m_run[8], l_run[8];
 #pragma unroll
       for (int h = 0; h < 8; ++h) { ar[h][0] = ar[h][1] = 0.f; m_run[h] = -INFINITY; l_run[h] = 0.f; }
@@ -298,53 +323,47 @@ __global__ __launch_bounds__(WG, 1) void k_attn_chain(float* __restrict__ x, int
       }
       for (int c0 = 0; c0 < dmax; c0 += CH) {
         const int cn = (deg - c0) < CH ? (deg - c0) : CH;   // edges of this destination in the chunk (may be <= 0)
-        // pass 1: s[e][h] = (<q_h, k_src,h> + <q~_h, r~_e> + cq_h) * Dh^-0.5   (:88-90), 8 edges per wave step
-        float2 r2n[8], k2n[8];
-        auto gather1 = [&](int eb) {
+        // pass 1 on the matrix cores: S[16 edges][8 heads] = R~[16 x 128] Q~^T + K[16 x 128] blockdiag(q)   (:88-90)
+        // v_mfma_f32_16x16x32_f16 with split-fp16 operands: the 16-wide N carries (q hi | q lo) for the 8
+        // heads and A runs over (r~ hi, r~ lo, k hi, k lo), so all four hi/lo cross terms are summed in the
+        // fp32 accumulator: 16 MFMAs + 16 16-byte loads per 16 edges, no conversion work in the loop.
+        {
+          const int mi = lane & 15, kq = lane >> 4;
+          half8 nrh[4], nrl[4], nkh[4], nkl[4];
+          auto gather1 = [&](int eb) {
+            const int e = (eb + mi < cn) ? eb + mi : cn - 1;
+            const size_t ge = (size_t)(e_beg + c0 + e) * 256 + 8 * kq;
+            const size_t gs = (size_t)el[c0 + e] * 256 + 8 * kq;
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const int ee = c0 + ((eb + j < cn) ? eb + j : cn - 1);
-            r2n[j] = ldg2(rbase + (size_t)ee * 128);
-            k2n[j] = ldg2(kbase + (size_t)el[ee] * 256);
+            for (int ks = 0; ks < 4; ++ks) {
+              nrh[ks] = ldgh8(st.rthl + ge + 32 * ks);
+              nrl[ks] = ldgh8(st.rthl + ge + 128 + 32 * ks);
+              nkh[ks] = ldgh8(st.khl + gs + 32 * ks);
+              nkl[ks] = ldgh8(st.khl + gs + 128 + 32 * ks);
+            }
+          };
+          if (wi * 16 < cn && !(flags & 16)) gather1(wi * 16);
+          for (int eb = wi * 16; eb < cn && !(flags & 16); eb += 16 * W) {
+            half8 arh[4], arl[4], akh[4], akl[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) { arh[ks] = nrh[ks]; arl[ks] = nrl[ks]; akh[ks] = nkh[ks]; akl[ks] = nkl[ks]; }
+            if (eb + 16 * W < cn) gather1(eb + 16 * W);   // the next tile's rows fly under this tile's MFMAs
+            floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+              acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(arh[ks], bq[ks], acc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(arl[ks], bq[ks], acc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(akh[ks], bk[ks], acc, 0, 0, 0);
+              acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(akl[ks], bk[ks], acc, 0, 0, 0);
+            }
+            // D[row = 4*(lane>>4) + r][col = lane & 15]: columns h and h + 8 (the lo half of q) meet by row_ror:8
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+              const float v = acc[r4] + dpp_xor8(acc[r4]);
+              const int er = eb + 4 * kq + r4;
+              if (mi < 8 && er < cn) sc[(size_t)er * 8 + mi] = (v + cqm) * 0.25f;
+            }
           }
-        };
-        if (wi * 8 < cn) gather1(wi * 8);
-        for (int eb = wi * 8; eb < cn; eb += 8 * W) {
-          float2 r2[8], k2[8];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) { r2[j] = r2n[j]; k2[j] = k2n[j]; }
-          if (eb + 8 * W < cn) gather1(eb + 8 * W);   // the next 8 edges' rows fly under this step's arithmetic
-          float part[64];
-#pragma unroll
-          for (int h = 0; h < 8; ++h)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) part[h * 8 + j] = fmaf(q1[h], r2[j].y, q0[h] * r2[j].x);
-          float qk[8];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) qk[j] = fmaf(qv.y, k2[j].y, qv.x * k2[j].x);
-          // transposing reduction 64 values x 64 lanes -> lane L holds the total of value L = (head L>>3, edge L&7)
-#pragma unroll
-          for (int i = 0; i < 32; ++i) part[i] = swap_add32(part[i], part[i + 32]);
-#pragma unroll
-          for (int i = 0; i < 16; ++i) part[i] = swap_add16(part[i], part[i + 16]);
-          const bool b8 = lane & 8, b4 = lane & 4, b2 = lane & 2, b1 = lane & 1;
-#pragma unroll
-          for (int i = 0; i < 8; ++i) part[i] = PS_TSTEP(part[i], part[i + 8], b8, dpp_xor8);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const float lo = part[i], hi = part[i + 4];
-            part[i] = (b4 ? hi : lo) + __shfl_xor(b4 ? lo : hi, 4);
-            const float lk = qk[i], hk = qk[i + 4];
-            qk[i] = (b4 ? hk : lk) + __shfl_xor(b4 ? lk : hk, 4);
-          }
-#pragma unroll
-          for (int i = 0; i < 2; ++i) {
-            part[i] = PS_TSTEP(part[i], part[i + 2], b2, dpp_xor2);
-            qk[i] = PS_TSTEP(qk[i], qk[i + 2], b2, dpp_xor2);
-          }
-          const float tot = PS_TSTEP(part[0], part[1], b1, dpp_xor1);
-          const float qkt = PS_TSTEP(qk[0], qk[1], b1, dpp_xor1);
-          if (eb + jl < cn) sc[(size_t)(eb + jl) * 8 + hl] = (tot + qkt + cqL) * 0.25f;
         }
         __syncthreads();
         // online softmax over the destination's edges, per head (torch_geometric.utils.softmax:
@@ -404,7 +423,7 @@ __global__ __launch_bounds__(WG, 1) void k_attn_chain(float* __restrict__ x, int
           }
         };
         if (wi * 8 < cn) gather2(wi * 8);
-        for (int eb = wi * 8; eb < cn; eb += 8 * W) {
+        for (int eb = wi * 8; eb < cn && !(flags & 8); eb += 8 * W) {
           float2 rr[8], vv[8];
 #pragma unroll
           for (int j = 0; j < 8; ++j) { rr[j] = rrn[j]; vv[j] = vvn[j]; }
@@ -416,9 +435,7 @@ __global__ __launch_bounds__(WG, 1) void k_attn_chain(float* __restrict__ x, int
             float4 pb = *reinterpret_cast<const float4*>(sc + (size_t)ee * 8 + 4);
             if (eb + j >= cn) { pa = make_float4(0.f, 0.f, 0.f, 0.f); pb = pa; }
             const float p[8] = {pa.x, pa.y, pa.z, pa.w, pb.x, pb.y, pb.z, pb.w};
-            float ph = p[0];
-#pragma unroll
-            for (int h = 1; h < 8; ++h) ph = (hl == h) ? p[h] : ph;
+            const float ph = (eb + j < cn) ? sc[(size_t)ee * 8 + hl] : 0.f;
 #pragma unroll
             for (int h = 0; h < 8; ++h) {
               ar[h][0] = fmaf(p[h], rr[j].x, ar[h][0]);
@@ -431,7 +448,7 @@ __global__ __launch_bounds__(WG, 1) void k_attn_chain(float* __restrict__ x, int
         if (c0 + CH < dmax) __syncthreads();   // the next chunk's pass 1 overwrites the score tile
       }
       // the to_v_r fold's weights leave now and land while the partials are published
-      wload(wA, w.Wvr_gt + woff, 128);
+      if (PF) wload(wA, w.Wvr_gt + woff, 128);
 #pragma unroll
       for (int h = 0; h < 8; ++h)
         *reinterpret_cast<float2*>(big + (size_t)(wave * 8 + h) * QP + 2 * lane) = make_float2(ar[h][0], ar[h][1]);
@@ -465,8 +482,7 @@ __global__ __launch_bounds__(WG, 1) void k_attn_chain(float* __restrict__ x, int
     {
       float acc[T][4];
       zero_acc<T>(acc);
-      wload(wB, w.Wga_t + woff, 128);
-      wfma<T>(wA, big + (size_t)(2 * wave + (c8 >> 2)) * QP + kgl * 16, W * 8 * QP, acc);   // Wvr
+      PS_STAGE(wA, w.Wvr_gt + woff, 128, wB, w.Wga_t + woff, 128, big + (size_t)(2 * wave + (c8 >> 2)) * QP + kgl * 16, W * 8 * QP);   // Wvr
       fold_kgroups<T, 8>(acc);
       if (kgl == 0) {
         const int h = 2 * wave + (c8 >> 2);
@@ -488,8 +504,7 @@ __global__ __launch_bounds__(WG, 1) void k_attn_chain(float* __restrict__ x, int
     {
       float acc[T][4];
       zero_acc<T>(acc);
-      wload(wA, w.Wout_t + woff, 128);
-      wfma<T>(wB, ag + kgl * 16, 128, acc);                                             // Wga
+      PS_STAGE(wB, w.Wga_t + woff, 128, wA, w.Wout_t + woff, 128, ag + kgl * 16, 128);   // Wga
       fold_kgroups<T, 8>(acc);
       if (kgl == 0) {
 #pragma unroll
@@ -511,8 +526,7 @@ __global__ __launch_bounds__(WG, 1) void k_attn_chain(float* __restrict__ x, int
     {
       float acc[T][4];
       zero_acc<T>(acc);
-      wload(wB, w.W1_t + (size_t)(k2 * 64) * 512 + ncol5, 512);
-      wfma<T>(wA, f1 + kgl * 16, 128, acc);                                             // Wout
+      PS_STAGE(wA, w.Wout_t + woff, 128, wB, w.W1_t + (size_t)(k2 * 64) * 512 + ncol5, 512, f1 + kgl * 16, 128);   // Wout
       fold_kgroups<T, 8>(acc);
       if (kgl == 0) {
 #pragma unroll
@@ -540,14 +554,10 @@ __global__ __launch_bounds__(WG, 1) void k_attn_chain(float* __restrict__ x, int
       zero_acc<T>(acc);
       const float* w1 = w.W1_t + (size_t)(k2 * 64) * 512 + ncol5;
       const float* w2 = w.W2_t + (size_t)(kgl * 64) * 128 + ncol;
-      wload(wA, w1 + (size_t)16 * 512, 512);
-      wfma<T>(wB, xn + k2 * 64, 128, acc);
-      wload(wB, w1 + (size_t)32 * 512, 512);
-      wfma<T>(wA, xn + k2 * 64 + 16, 128, acc);
-      wload(wA, w1 + (size_t)48 * 512, 512);
-      wfma<T>(wB, xn + k2 * 64 + 32, 128, acc);
-      wload(wB, w2, 128);
-      wfma<T>(wA, xn + k2 * 64 + 48, 128, acc);
+      PS_STAGE(wB, w1, 512, wA, w1 + (size_t)16 * 512, 512, xn + k2 * 64, 128);
+      PS_STAGE(wA, w1 + (size_t)16 * 512, 512, wB, w1 + (size_t)32 * 512, 512, xn + k2 * 64 + 16, 128);
+      PS_STAGE(wB, w1 + (size_t)32 * 512, 512, wA, w1 + (size_t)48 * 512, 512, xn + k2 * 64 + 32, 128);
+      PS_STAGE(wA, w1 + (size_t)48 * 512, 512, wB, w2, 128, xn + k2 * 64 + 48, 128);
       fold_kgroups<T, 32>(acc);
       if (k2 == 0) {
 #pragma unroll
@@ -563,15 +573,13 @@ __global__ __launch_bounds__(WG, 1) void k_attn_chain(float* __restrict__ x, int
       float acc[T][4];
       zero_acc<T>(acc);
       const float* w2 = w.W2_t + (size_t)(kgl * 64) * 128 + ncol;
-      wload(wA, w2 + (size_t)16 * 128, 128);
-      wfma<T>(wB, f1 + kgl * 64, 512, acc);
-      wload(wB, w2 + (size_t)32 * 128, 128);
-      wfma<T>(wA, f1 + kgl * 64 + 16, 512, acc);
-      wload(wA, w2 + (size_t)48 * 128, 128);
-      wfma<T>(wB, f1 + kgl * 64 + 32, 512, acc);
+      PS_STAGE(wB, w2, 128, wA, w2 + (size_t)16 * 128, 128, f1 + kgl * 64, 512);
+      PS_STAGE(wA, w2 + (size_t)16 * 128, 128, wB, w2 + (size_t)32 * 128, 128, f1 + kgl * 64 + 16, 512);
+      PS_STAGE(wB, w2 + (size_t)32 * 128, 128, wA, w2 + (size_t)48 * 128, 128, f1 + kgl * 64 + 32, 512);
+      if (!PF) wload(wA, w2 + (size_t)48 * 128, 128);
       wfma<T>(wA, f1 + kgl * 64 + 48, 512, acc);
       // the next layer's first chunk leaves now; it lands during the fold and the two norms
-      if (s + 1 < nsteps) wload(wA, steps[s + 1].w.Wq_t + woff, 128);
+      if (PF && s + 1 < nsteps) wload(wA, steps[s + 1].w.Wq_t + woff, 128);
       fold_kgroups<T, 8>(acc);
       if (kgl == 0) {
 #pragma unroll
@@ -603,7 +611,7 @@ __global__ __launch_bounds__(WG, 1) void k_attn_chain(float* __restrict__ x, int
 // kv[l][n][128:256] = Wv LN_src(x_n) + bv   (attention_layer.py:61,65,115-116).  grid (ceil(Ns/T), L).
 template <int T>
 __global__ __launch_bounds__(WG) void k_kv_proj(const float* __restrict__ x, int Ns, const AttnW* __restrict__ layers,
-                                                float* __restrict__ kv, size_t layer_stride, float eps) {
+                                                float* __restrict__ kv, _Float16* __restrict__ khl, size_t layer_stride, float eps) {
   __shared__ __attribute__((aligned(16))) float xs[T * 128];
   __shared__ __attribute__((aligned(16))) float xn[T * 128];
   __shared__ __attribute__((aligned(16))) float part[4 * T * 256];
@@ -619,9 +627,16 @@ __global__ __launch_bounds__(WG) void k_kv_proj(const float* __restrict__ x, int
   __syncthreads();
   gemv_rows<T, false>(xn, 128, 128, w.Wkv_t, 256, w.bkv, part, ob, 256, false);
   float* out = kv + blockIdx.y * layer_stride;
+  _Float16* outh = khl + blockIdx.y * layer_stride;
   for (int i = tid; i < T * 256; i += WG) {
-    const int r = row0 + (i >> 8);
-    if (r < Ns) out[(size_t)r * 256 + (i & 255)] = ob[i];
+    const int r = row0 + (i >> 8), c = i & 255;
+    if (r < Ns) {
+      out[(size_t)r * 256 + c] = ob[i];
+      if (c < 128) {   // k half of the row also as split fp16 (hi | lo) for the score MFMAs
+        outh[(size_t)r * 256 + c] = f16_hi(ob[i]);
+        outh[(size_t)r * 256 + 128 + c] = f16_lo(ob[i]);
+      }
+    }
   }
 }
 

@@ -45,6 +45,17 @@ __device__ __forceinline__ float wrap_angle(float a) {
   return -PS_PI_F + m;
 }
 
+// ---- split-fp16 operands for the matrix cores.  x ~= hi + lo with hi = fp16(x), lo = fp16(x - hi):
+// 22 mantissa bits survive, so hi*hi + hi*lo + lo*hi + lo*lo accumulated in fp32 by
+// v_mfma_f32_16x16x32_f16 is fp32-class (error ~2^-21 per product) -- unlike a bf16 product (2^-9),
+// which the 1e-4 closed-loop bar cannot absorb.
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) const half8 g_chalf8;
+__device__ __forceinline__ half8 ldgh8(const _Float16* p) { return *(g_chalf8*)p; }
+__device__ __forceinline__ _Float16 f16_hi(float x) { return (_Float16)x; }
+__device__ __forceinline__ _Float16 f16_lo(float x) { return (_Float16)(x - (float)(_Float16)x); }
+
 // ---- cross-lane exchange without the LDS pipe (gfx950): v_permlane32/16_swap exchange half-waves /
 // odd-even rows between TWO registers, DPP covers xor 8 / 2 / 1 inside a row of 16.
 // swap_add32(lo, hi): lanes 0-31 get lo[l] + lo[l+32], lanes 32-63 get hi[l-32] + hi[l] -- one

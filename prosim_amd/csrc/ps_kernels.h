@@ -322,7 +322,7 @@ __global__ void k_relpe(const int* __restrict__ esrc, const int* __restrict__ ed
                         int n_edges_host, const float* __restrict__ src_pos, const float* __restrict__ src_ori,
                         const float* __restrict__ dst_pos, const float* __restrict__ dst_ori,
                         const float* __restrict__ div32, const float* __restrict__ add /*[E][128] or null*/,
-                        float* __restrict__ rt, float eps) {
+                        float* __restrict__ rt, _Float16* __restrict__ rthl, float eps) {
   const int lane = threadIdx.x & 63;
   const int wpb = blockDim.x >> 6;
   const int E = n_edges_ptr ? *n_edges_ptr : n_edges_host;
@@ -348,8 +348,15 @@ __global__ void k_relpe(const int* __restrict__ esrc, const int* __restrict__ ed
     const float d0 = f0 - mean, d1 = f1 - mean;
     const float var = wave_sum(d0 * d0 + d1 * d1) * (1.f / 128.f);
     const float rstd = 1.f / sqrtf(var + eps);
-    rt[(size_t)e * 128 + lane] = d0 * rstd;
-    rt[(size_t)e * 128 + 64 + lane] = d1 * rstd;
+    const float y0 = d0 * rstd, y1 = d1 * rstd;
+    rt[(size_t)e * 128 + lane] = y0;
+    rt[(size_t)e * 128 + 64 + lane] = y1;
+    // the same row as split fp16 (hi[128] | lo[128]) for the score MFMAs of k_attn_chain
+    _Float16* h = rthl + (size_t)e * 256;
+    h[lane] = f16_hi(y0);
+    h[64 + lane] = f16_hi(y1);
+    h[128 + lane] = f16_lo(y0);
+    h[192 + lane] = f16_lo(y1);
   }
 }
 
@@ -413,7 +420,7 @@ struct CondW {
 };
 __global__ __launch_bounds__(128) void k_cond_edges(CondW w, const int* __restrict__ ent_off, const int* __restrict__ ent_type,
                                                    const float* __restrict__ ent_val, int n_nodes,
-                                                   float* __restrict__ rt, float eps) {
+                                                   float* __restrict__ rt, _Float16* __restrict__ rthl, float eps) {
   __shared__ float a[128], b[128], accum[128];
   const int node = blockIdx.x, tid = threadIdx.x;
   accum[tid] = 0.f;
@@ -442,6 +449,19 @@ __global__ __launch_bounds__(128) void k_cond_edges(CondW w, const int* __restri
   a[tid] = accum[tid] / (float)(e1 - e0) + pe;
   __syncthreads();
   if (tid < 64) ln_row_wave(a, rt + (size_t)node * 128, nullptr, nullptr, eps, tid, false);
+  __syncthreads();
+  const float y = rt[(size_t)node * 128 + tid];
+  rthl[(size_t)node * 256 + tid] = f16_hi(y);
+  rthl[(size_t)node * 256 + 128 + tid] = f16_lo(y);
+}
+
+// fp32 rows [n][128] -> split fp16 rows [n][256] (hi | lo); used by the test hooks
+__global__ void k_split_rows(const float* __restrict__ in, int n, _Float16* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * 128) return;
+  const int r = i >> 7, c = i & 127;
+  out[(size_t)r * 256 + c] = f16_hi(in[i]);
+  out[(size_t)r * 256 + 128 + c] = f16_lo(in[i]);
 }
 
 // ------------------------------------------------------------------------------------------
