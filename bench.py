@@ -98,10 +98,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise RuntimeError("bench.py needs a GPU: the rollout path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    # test hook: PS_BENCH_BACKEND=gloo PS_BENCH_SAME_DEVICE=1 runs an N-rank job on ONE GPU (both ranks on
+    # cuda:0, metric gather through gloo on CPU copies) to exercise the N > 1 code path on a 1-GPU box
+    backend = os.environ.get("PS_BENCH_BACKEND", "nccl")
+    dev_index = 0 if os.environ.get("PS_BENCH_SAME_DEVICE") else local_rank
+    torch.cuda.set_device(dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
     import __graft_entry__ as ge
     if rank == 0:
         ge.build()
@@ -120,7 +127,7 @@ def main():
     scene = {k: (np.concatenate([p[k] for p in parts]) if not isinstance(parts[0][k], dict) else
                  {ck: {f: np.concatenate([p[k][ck][f] for p in parts]) for f in parts[0][k][ck]} for ck in parts[0][k]})
              for k in parts[0]}
-    eng = Engine(spec, w, device=local_rank)
+    eng = Engine(spec, w, device=dev_index)
     eng.set_scene(scene)
     A = eng.num_agents
     N = scene["prompt_mask"].shape[1]
@@ -131,7 +138,8 @@ def main():
         eng.rollout_metric(metric_local.data_ptr())
         if world > 1:
             eng.sync()  # engine stream -> host; the gather runs on torch's stream
-            return gather_scene_metrics(metric_local.view(S, N, 2), my_scenes, n_scenes, N)
+            m = metric_local.view(S, N, 2)
+            return gather_scene_metrics(m if backend == "nccl" else m.cpu(), my_scenes, n_scenes, N)
         return metric_local.view(S, N, 2)
 
     for _ in range(args.warmup):
@@ -147,10 +155,11 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        red_dev = "cuda" if backend == "nccl" else "cpu"
+        tmax = torch.tensor([dt], device=red_dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-        agents = torch.tensor([A], device="cuda", dtype=torch.float64)
+        agents = torch.tensor([A], device=red_dev, dtype=torch.float64)
         dist.all_reduce(agents)
         total_agents = int(agents.item())
     else:
@@ -173,17 +182,26 @@ def main():
         fl_alg = algorithmic_flops_chain(A, float(ec[4]), float(ec[5]), spec.pol_layers)
         fl_exe = executed_flops_chain(A, float(ec[4]), float(ec[5]), spec.pol_layers)
         peak = 157.3  # TFLOP/s: dense fp32 MFMA peak = fp32 vector peak (MI355X_MICROARCH.md)
+        # HBM traffic of the dominant kernel comes from a separate rocprofv3 --pmc run (counters cannot be
+        # read from inside this process); the committed summary is only valid for the default workload
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_policy_chain.json")
+        if os.path.exists(pmc) and S == 8 and args.config == 2:
+            with open(pmc) as f:
+                traffic = json.load(f)["hbm_bytes_per_launch_lower"]
         achieved = fl_alg / (ms_chain * 1e-3) / 1e12
         out = {
             "metric": "agent-steps/sec closed-loop rollout", "value": value, "unit": "agent-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32",  # fp32 throughout; the score GEMMs run as split-fp16 MFMA with fp32 accumulate (fp32-class) "data": "synthetic",
             "config": {"workload": f"{S} x BASELINE configs[{args.config}] scenes per GPU ({synth.BASELINE_CONFIGS[args.config]['name']}; "
                                    f"S=8 is configs[3]'s per-GPU share), 80-step closed-loop rollout (8 replans), seeded random-init weights",
                        "agents_per_scene": int(scene['prompt_mask'][0].sum()), "polylines_per_scene": int(scene['map_mask'].shape[1]),
                        "scenes_per_gpu": S, "parallelism": f"scene-sharded x{world}, RCCL all-gather of per-agent ADE/FDE"},
             "roofline": {"bound": "mfma", "kernel": "k_attn_chain (policy: 12 fused attention layers per launch)",
-                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
+                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
+                         "traffic_note": "HBM bytes per launch, FETCH_SIZE+WRITE_SIZE lower bound (profiles/r01_pmc_policy_chain.json)",
                          "algorithmic_flops_per_launch": fl_alg, "executed_flops_per_launch": fl_exe,
                          "executed_tflops": fl_exe / (ms_chain * 1e-3) / 1e12, "avg_launch_ms": ms_chain,
                          "edges_per_launch": {"a2p": float(ec[4]), "m2p": float(ec[5])}},
