@@ -794,9 +794,13 @@ int launch_chain(ps_engine* e, float* x, int Nd, int step0, int nsteps, int maxd
                  const ChainStep* steps_override = nullptr, int force_T = 0) {
   const ChainStep* steps = steps_override ? steps_override : e->d_steps.p + step0;
   hipStream_t st = e->stream;
-  // rows per workgroup: fill the 256 CUs when there are enough destinations; LDS must fit
-  int T = Nd >= 1024 ? 4 : (Nd >= 512 ? 2 : 1);
+  // rows per workgroup: T = 2 (2 workgroups per CU: <=128 registers' worth of pressure relief from the
+  // co-resident workgroup, 72 KB LDS each) once there are enough destinations to fill the chip twice;
+  // measured 742 us vs 836 us (T = 4, one workgroup per CU) for the 1024-agent policy launch.  LDS must fit.
+  int T = Nd >= 512 ? 2 : 1;
   while (T > 1 && (T == 4 ? attn_lds_floats<4>(maxdeg) : attn_lds_floats<2>(maxdeg)) * sizeof(float) > 150 * 1024) T >>= 1;
+  static const int env_T = getenv("PS_CHAIN_T") ? atoi(getenv("PS_CHAIN_T")) : 0;   // experiments only
+  if (env_T && Nd >= 512) T = env_T;
   if (force_T) T = force_T;
   if (attn_lds_floats<1>(maxdeg) * sizeof(float) > 150 * 1024) return fail(PS_E_ARG, "degree bound too large for LDS");
   const float eps = e->cfg.ln_eps;

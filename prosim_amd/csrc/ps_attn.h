@@ -143,10 +143,13 @@ __device__ __forceinline__ void fold_kgroups(float (&acc)[T][4]) {
   } while (0)
 
 template <int T>
-__global__ __launch_bounds__(WG, 1) void k_attn_chain(float* __restrict__ x, int Nd, const ChainStep* __restrict__ steps,
+__global__ __launch_bounds__(WG, (T >= 2 ? 2 : 1)) void k_attn_chain(float* __restrict__ x, int Nd, const ChainStep* __restrict__ steps,
                                                      int nsteps, int maxdeg, float eps, int flags) {
   constexpr int W = 4 / T;  // waves per destination in the edge phase
-  constexpr bool PF = (T == 1);  // weight prefetch one chunk ahead only where the registers allow it
+  // T == 1: one workgroup per CU with the full register file -> software prefetch (weights one chunk ahead,
+  // edge rows one tile ahead).  T >= 2: compiled for 2 workgroups per CU (__launch_bounds__(256, 2), <= 256
+  // registers): the co-resident workgroup hides the latency instead and nothing is double-buffered.
+  constexpr bool PF = (T == 1);
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* xs = smem;                 // [T][128] residual stream
   float* xn = xs + 128 * T;         // [T][128] normed / scratch row
@@ -342,12 +345,13 @@ __global__ __launch_bounds__(WG, 1) void k_attn_chain(float* __restrict__ x, int
               nkl[ks] = ldgh8(st.khl + gs + 128 + 32 * ks);
             }
           };
-          if (wi * 16 < cn && !(flags & 16)) gather1(wi * 16);
+          if (PF && wi * 16 < cn && !(flags & 16)) gather1(wi * 16);
           for (int eb = wi * 16; eb < cn && !(flags & 16); eb += 16 * W) {
+            if (!PF) gather1(eb);   // two workgroups per CU hide the latency instead of a second register set
             half8 arh[4], arl[4], akh[4], akl[4];
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) { arh[ks] = nrh[ks]; arl[ks] = nrl[ks]; akh[ks] = nkh[ks]; akl[ks] = nkl[ks]; }
-            if (eb + 16 * W < cn) gather1(eb + 16 * W);   // the next tile's rows fly under this tile's MFMAs
+            if (PF && eb + 16 * W < cn) gather1(eb + 16 * W);   // the next tile's rows fly under this tile's MFMAs
             floatx4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
@@ -422,12 +426,13 @@ __global__ __launch_bounds__(WG, 1) void k_attn_chain(float* __restrict__ x, int
             vvn[j] = ldg2(vbase + (size_t)el[c0 + ee] * 256);
           }
         };
-        if (wi * 8 < cn) gather2(wi * 8);
+        if (PF && wi * 8 < cn) gather2(wi * 8);
         for (int eb = wi * 8; eb < cn && !(flags & 8); eb += 8 * W) {
+          if (!PF) gather2(eb);
           float2 rr[8], vv[8];
 #pragma unroll
           for (int j = 0; j < 8; ++j) { rr[j] = rrn[j]; vv[j] = vvn[j]; }
-          if (eb + 8 * W < cn) gather2(eb + 8 * W);
+          if (PF && eb + 8 * W < cn) gather2(eb + 8 * W);
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             const int ee = (eb + j < cn) ? eb + j : cn - 1;

@@ -291,3 +291,29 @@ def test_errors_are_loud(small_engine):
     bad["agent_type"] = scene["agent_type"] * 0
     with pytest.raises(RuntimeError, match="agent_type"):
         small_engine.set_scene(bad)
+
+
+def test_future_obs_frames_and_conditions_subset(small_engine):
+    """fut_obs[t] supplies the static observation columns (extent, type, time one-hot) of replans 1..R-1
+    (dataset/format_utils.py:667-687; columns 0..7 are overwritten by step_env, traj_sam.py:266-270), and
+    conditions may cover only some agents (condition_utils.py masks)."""
+    spec = SMALL_SPEC
+    scene = synth.make_scene(spec, 10, 48, batch=2, seed=21, goal=True, tags=True, ragged=True)
+    rng = np.random.RandomState(0)
+    R = spec.n_replans
+    fut = np.repeat(np.nan_to_num(scene["obs_input"])[None], R - 1, axis=0).copy()
+    fut[..., 8:10] += rng.uniform(-0.2, 0.2, fut[..., 8:10].shape).astype(np.float32)    # extents drift per frame
+    scene["fut_obs_input"] = fut
+    w = weights.init_weights(spec, 0)
+    small_engine.set_scene(scene)
+    small_engine.rollout()
+    with torch.no_grad():
+        o = orc.rollout(w, spec, scene, dtype=torch.float64)
+        o_nofut = orc.rollout(w, spec, {k: v for k, v in scene.items() if k != "fut_obs_input"}, dtype=torch.float64)
+    A = small_engine.num_agents
+    mp = small_engine.get("motion_pred")
+    assert err(mp[0], o["motion_pred"][:A].numpy()) < TOL
+    assert err(mp[1], o["motion_pred"][A:2 * A].numpy()) < 2 * TOL           # first replan that sees a fut frame
+    assert err(o["motion_pred"][A:2 * A].numpy(), o_nofut["motion_pred"][A:2 * A].numpy()) > 1e-3   # the frames matter
+    d = np.abs(small_engine.padded("traj") - o["traj"].numpy())[scene["prompt_mask"].astype(bool)].reshape(A, -1).max(1)
+    assert (d < 1e-3).mean() >= 0.9
