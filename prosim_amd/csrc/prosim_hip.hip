@@ -794,10 +794,11 @@ int launch_chain(ps_engine* e, float* x, int Nd, int step0, int nsteps, int maxd
                  const ChainStep* steps_override = nullptr, int force_T = 0) {
   const ChainStep* steps = steps_override ? steps_override : e->d_steps.p + step0;
   hipStream_t st = e->stream;
-  // rows per workgroup: T = 2 (2 workgroups per CU: <=128 registers' worth of pressure relief from the
-  // co-resident workgroup, 72 KB LDS each) once there are enough destinations to fill the chip twice;
-  // measured 742 us vs 836 us (T = 4, one workgroup per CU) for the 1024-agent policy launch.  LDS must fit.
-  int T = Nd >= 512 ? 2 : 1;
+  // rows per workgroup.  T >= 2 kernels are built for two workgroups per CU (<= 256 registers, <= 78 KB LDS):
+  // take the largest T that still leaves >= 2 workgroups per CU, so weights are shared by more rows AND a
+  // co-resident workgroup hides the latency.  Measured on the 1024-agent policy launch: T=2 (512 WGs) 739 us,
+  // T=4 (256 WGs, one per CU) 851 us; on the 9216-token s2s layers T=4 (2304 WGs) wins (encode 3.25 vs 3.78 ms).
+  int T = Nd >= 2048 ? 4 : (Nd >= 512 ? 2 : 1);
   while (T > 1 && (T == 4 ? attn_lds_floats<4>(maxdeg) : attn_lds_floats<2>(maxdeg)) * sizeof(float) > 150 * 1024) T >>= 1;
   static const int env_T = getenv("PS_CHAIN_T") ? atoi(getenv("PS_CHAIN_T")) : 0;   // experiments only
   if (env_T && Nd >= 512) T = env_T;

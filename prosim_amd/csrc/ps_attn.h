@@ -50,13 +50,15 @@ struct ChainStep {
 
 // Edge lists are walked in chunks of CH edges per destination with an online (running max / sum)
 // softmax, so the LDS score tile is 8*CH*T floats whatever the degree.
-constexpr int CH = 256;
-// LDS plan (floats): rows 6*128*T + 512*T | big 4*8*QP (q~ image, then per-wave partial a_r)
-// | sc 8*CH*T scores | avp 4*128 | ml 4*16 | cq 8*T | sp 2*SP_SIZE | esl maxdeg*T
+// The chunk is 256 edges (128 at T = 4, so that two 4-row workgroups fit the 160 KB of a CU).
 template <int T>
-__host__ __device__ constexpr size_t attn_lds_floats(int maxdeg) {
-  return (size_t)(6 * 128 + 512) * T + 4 * 8 * QP + (size_t)8 * CH * T + 4 * 128 + 4 * 16 + 8 * T + 64 +
-         2 * SP_SIZE + (size_t)maxdeg * T;
+__host__ __device__ constexpr int chunk_edges() { return T >= 4 ? 128 : 256; }
+// LDS plan (floats): rows 6*128*T + 512*T | big 4*8*QP (q~ image, then per-wave partial a_r)
+// | sc 8*CH*T scores | avp 4*128 | ml 4*16 | cq 8*T | sp 2*SP_SIZE | esl CH*T (source rows of the chunk)
+template <int T>
+__host__ __device__ constexpr size_t attn_lds_floats(int /*maxdeg*/) {
+  return (size_t)(6 * 128 + 512) * T + 4 * 8 * QP + (size_t)8 * chunk_edges<T>() * T + 4 * 128 + 4 * 16 + 8 * T + 64 +
+         2 * SP_SIZE + (size_t)chunk_edges<T>() * T;
 }
 
 // 8 partial sums (one per head) held by each of 8 consecutive lanes -> lane cc ends with the
@@ -146,6 +148,7 @@ template <int T>
 __global__ __launch_bounds__(WG, (T >= 2 ? 2 : 1)) void k_attn_chain(float* __restrict__ x, int Nd, const ChainStep* __restrict__ steps,
                                                      int nsteps, int maxdeg, float eps, int flags) {
   constexpr int W = 4 / T;  // waves per destination in the edge phase
+  constexpr int CH = chunk_edges<T>();
   // T == 1: one workgroup per CU with the full register file -> software prefetch (weights one chunk ahead,
   // edge rows one tile ahead).  T >= 2: compiled for 2 workgroups per CU (__launch_bounds__(256, 2), <= 256
   // registers): the co-resident workgroup hides the latency instead and nothing is double-buffered.
@@ -164,7 +167,7 @@ __global__ __launch_bounds__(WG, (T >= 2 ? 2 : 1)) void k_attn_chain(float* __re
   float* ml = avp + 4 * 128;        // [4][16]: per wave (max[8] | sum[8])
   float* cq = ml + 4 * 16;          // [T][8]
   float* spb = cq + 8 * T + 56;     // [2][SP_SIZE] small per-layer vectors, double-buffered
-  int* esl = reinterpret_cast<int*>(spb + 2 * SP_SIZE);  // [T][maxdeg] source rows of the current edge lists
+  int* esl = reinterpret_cast<int*>(spb + 2 * SP_SIZE);  // [T][CH] source rows of the current chunk of each edge list
 
   const int tid_o = threadIdx.x, wave_o = tid_o >> 6, lane_o = tid_o & 63;
   // N = 128 GEMVs: wave -> 32 output columns; lane -> (c8: 4 columns, kgl: 16-row k-group)
@@ -223,8 +226,8 @@ __global__ __launch_bounds__(WG, (T >= 2 ? 2 : 1)) void k_attn_chain(float* __re
     const int r = row0 + t;
     const int e_beg = (r < Nd) ? ldgi(st.eoff + r) : 0;
     const int deg = ((r < Nd) && !(flags & 1)) ? (ldgi(st.eoff + r + 1) - e_beg) : 0;
-    int* el = esl + t * maxdeg;
-    for (int e = wi * 64 + lane; e < deg; e += 64 * W) el[e] = ldgi(st.esrc + e_beg + e);
+    int* el = esl + t * CH;
+    for (int e = wi * 64 + lane; e < deg && e < CH; e += 64 * W) el[e] = ldgi(st.esrc + e_beg + e);   // first chunk
     // ---- q / s / gate(x) projections of the pre-normed rows (:61-69, :106-107, :114); xn = LN_dst(x)
     {
       float acc[T][4];
@@ -326,6 +329,10 @@ __global__ __launch_bounds__(WG, (T >= 2 ? 2 : 1)) void k_attn_chain(float* __re
       }
       for (int c0 = 0; c0 < dmax; c0 += CH) {
         const int cn = (deg - c0) < CH ? (deg - c0) : CH;   // edges of this destination in the chunk (may be <= 0)
+        if (c0 > 0) {   // source rows of a later chunk (the barrier that closed the previous chunk freed `el`)
+          for (int e = wi * 64 + lane; e < cn; e += 64 * W) el[e] = ldgi(st.esrc + e_beg + c0 + e);
+          __syncthreads();
+        }
         // pass 1 on the matrix cores: S[16 edges][8 heads] = R~[16 x 128] Q~^T + K[16 x 128] blockdiag(q)   (:88-90)
         // v_mfma_f32_16x16x32_f16 with split-fp16 operands: the 16-wide N carries (q hi | q lo) for the 8
         // heads and A runs over (r~ hi, r~ lo, k hi, k lo), so all four hi/lo cross terms are summed in the
@@ -336,7 +343,7 @@ __global__ __launch_bounds__(WG, (T >= 2 ? 2 : 1)) void k_attn_chain(float* __re
           auto gather1 = [&](int eb) {
             const int e = (eb + mi < cn) ? eb + mi : cn - 1;
             const size_t ge = (size_t)(e_beg + c0 + e) * 256 + 8 * kq;
-            const size_t gs = (size_t)el[c0 + e] * 256 + 8 * kq;
+            const size_t gs = (size_t)el[e] * 256 + 8 * kq;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
               nrh[ks] = ldgh8(st.rthl + ge + 32 * ks);
@@ -423,7 +430,7 @@ __global__ __launch_bounds__(WG, (T >= 2 ? 2 : 1)) void k_attn_chain(float* __re
           for (int j = 0; j < 8; ++j) {
             const int ee = (eb + j < cn) ? eb + j : cn - 1;
             rrn[j] = ldg2(rbase + (size_t)(c0 + ee) * 128);
-            vvn[j] = ldg2(vbase + (size_t)el[c0 + ee] * 256);
+            vvn[j] = ldg2(vbase + (size_t)el[ee] * 256);
           }
         };
         if (PF && wi * 8 < cn) gather2(wi * 8);
