@@ -55,9 +55,8 @@ struct DevBuf {
 };
 
 struct EdgeSet {  // CSR by destination + normalised rel-PE
-  DevBuf<int> cnt, eoff, esrc, edst;
-  DevBuf<float> rt;
-  DevBuf<_Float16> rthl;
+  DevBuf<int> cnt, eoff, toff, esrc, edst;   // toff: offsets in 32-edge tiles (sum of ceil(deg/32))
+  DevBuf<_Float16> rthl, rtA, rtT;            // rel-PE rows (hi|lo) and their two MFMA operand images (32-edge tiles)
   size_t cap_edges = 0;
   int nq = 0;
   int maxdeg = 0;
@@ -474,7 +473,7 @@ extern "C" void ps_destroy(ps_engine* e) {
   e->d_traj.release(); e->d_vel.release(); e->d_motion.release(); e->d_reconst.release();
   e->d_kh.release(); e->d_kh_s2p.release(); e->d_kh_m2p.release(); e->d_kh_a2p.release();
   for (EdgeSet* s : {&e->e_a2a, &e->e_s2s, &e->e_p2p, &e->e_s2p, &e->e_a2p, &e->e_m2p, &e->e_cnd}) {
-    s->cnt.release(); s->eoff.release(); s->esrc.release(); s->edst.release(); s->rt.release(); s->rthl.release();
+    s->cnt.release(); s->eoff.release(); s->esrc.release(); s->edst.release(); s->toff.release(); s->rthl.release(); s->rtA.release(); s->rtT.release();
   }
   e->d_steps.release(); e->d_ent_off.release(); e->d_ent_type.release(); e->d_ent_val.release();
   drop_graph(e);
@@ -500,8 +499,9 @@ int edge_alloc(EdgeSet& s, int nq, size_t cap_edges, int maxdeg) {
   s.nq = nq;
   s.cap_edges = cap_edges;
   s.maxdeg = std::max(1, maxdeg);
-  if (s.cnt.ensure(nq + 1) || s.eoff.ensure(nq + 1) || s.esrc.ensure(cap_edges + 1) || s.edst.ensure(cap_edges + 1) ||
-      s.rt.ensure((cap_edges + 1) * 128) || s.rthl.ensure((cap_edges + 1) * 256))
+  if (s.cnt.ensure(nq + 1) || s.eoff.ensure(nq + 1) || s.toff.ensure(nq + 1) || s.esrc.ensure(cap_edges + 1) ||
+      s.edst.ensure(cap_edges + 1) || s.rthl.ensure((cap_edges + 1) * 256) ||
+      s.rtA.ensure((cap_edges / 32 + (size_t)nq + 1) * 8192) || s.rtT.ensure((cap_edges / 32 + (size_t)nq + 1) * 8192))
     return -1;
   return 0;
 }
@@ -628,20 +628,26 @@ extern "C" int ps_set_scene(ps_engine* e, int32_t B, int32_t M, int32_t P, int32
     return fail(PS_E_HIP, "edge allocation failed");
   // closed-form CSR offsets of the knn graphs (every query gets min(k, scene size) neighbours)
   {
-    std::vector<int> off(A + 1, 0);
+    std::vector<int> off(A + 1, 0), tof(A + 1, 0);
     for (int i = 0; i < A; ++i) {
       const int b = e->agent_scene[i];
-      off[i + 1] = off[i] + mn(c.agent_knn, e->aoff[b + 1] - e->aoff[b]);
+      const int dg = mn(c.agent_knn, e->aoff[b + 1] - e->aoff[b]);
+      off[i + 1] = off[i] + dg;
+      tof[i + 1] = tof[i] + (dg + 31) / 32;
     }
-    if (upload(e->e_a2a.eoff, off.data(), off.size(), st)) return fail(PS_E_HIP, "upload failed");
+    if (upload(e->e_a2a.eoff, off.data(), off.size(), st) || upload(e->e_a2a.toff, tof.data(), tof.size(), st))
+      return fail(PS_E_HIP, "upload failed");
     e->edge_counts[0] = (float)off[A];
-    std::vector<int> off2(Mv + A + 1, 0);
+    std::vector<int> off2(Mv + A + 1, 0), tof2(Mv + A + 1, 0);
     for (int i = 0; i < Mv + A; ++i) {
       const int b = scene[i];
       const int ns = (e->aoff[b + 1] - e->aoff[b]) + (e->moff[b + 1] - e->moff[b]);
-      off2[i + 1] = off2[i] + mn(c.scene_knn, ns);
+      const int dg = mn(c.scene_knn, ns);
+      off2[i + 1] = off2[i] + dg;
+      tof2[i + 1] = tof2[i] + (dg + 31) / 32;
     }
-    if (upload(e->e_s2s.eoff, off2.data(), off2.size(), st)) return fail(PS_E_HIP, "upload failed");
+    if (upload(e->e_s2s.eoff, off2.data(), off2.size(), st) || upload(e->e_s2s.toff, tof2.data(), tof2.size(), st))
+      return fail(PS_E_HIP, "upload failed");
     e->edge_counts[1] = (float)off2[Mv + A];
   }
   // ---- chain step tables (device pointers are stable until the next ps_set_scene)
@@ -651,10 +657,11 @@ extern "C" int ps_set_scene(ps_engine* e, int32_t B, int32_t M, int32_t P, int32
     s.w = w;
     s.kv = kv;
     s.khl = khl;
-    s.rthl = es.rthl.p;
+    s.rtA = es.rtA.p;
     s.eoff = es.eoff.p;
     s.esrc = es.esrc.p;
-    s.rt = es.rt.p;
+    s.toff = es.toff.p;
+    s.rtT = es.rtT.p;
     e->h_steps.push_back(s);
   };
   e->step_a2a = (int)e->h_steps.size();
@@ -758,7 +765,9 @@ extern "C" int ps_set_conditions(ps_engine* e, int32_t C_goal, const float* goal
   e->have_cond = e->n_cond_edges > 0;
   e->edge_counts[6] = (float)e->n_cond_edges;
   hipStream_t st = e->stream;
-  if (upload(e->e_cnd.eoff, eoff.data(), eoff.size(), st) || upload(e->e_cnd.esrc, esrc.data(), esrc.size(), st) ||
+  // at most one self-loop edge per destination: tile offsets coincide with edge offsets
+  if (upload(e->e_cnd.eoff, eoff.data(), eoff.size(), st) || upload(e->e_cnd.toff, eoff.data(), eoff.size(), st) ||
+      upload(e->e_cnd.esrc, esrc.data(), esrc.size(), st) ||
       upload(e->d_ent_off, ent_off.data(), ent_off.size(), st) || upload(e->d_ent_type, ent_type.data(), ent_type.size(), st) ||
       upload(e->d_ent_val, ent_val.data(), ent_val.size(), st))
     return fail(PS_E_HIP, "condition upload failed");
@@ -806,18 +815,37 @@ int launch_chain(ps_engine* e, float* x, int Nd, int step0, int nsteps, int maxd
   if (attn_lds_floats<1>(maxdeg) * sizeof(float) > 150 * 1024) return fail(PS_E_ARG, "degree bound too large for LDS");
   const float eps = e->cfg.ln_eps;
   static const int flags = getenv("PS_CHAIN_FLAGS") ? atoi(getenv("PS_CHAIN_FLAGS")) : 0;  // ablation only
+  // phase clocks (tools/gpu_phase.py): PS_CHAIN_PROF=1 makes the timed policy launches accumulate cycles per phase
+  static const bool want_prof = getenv("PS_CHAIN_PROF") != nullptr;
+  static unsigned long long* d_prof = nullptr;
+  unsigned long long* prof = nullptr;
+  if (want_prof && timed && e->time_chain) {
+    if (!d_prof && hipMalloc(&d_prof, 16 * sizeof(unsigned long long)) != hipSuccess) d_prof = nullptr;
+    if (d_prof) (void)hipMemsetAsync(d_prof, 0, 16 * sizeof(unsigned long long), st);
+    prof = d_prof;
+  }
   if (timed && e->time_chain) (void)hipEventRecord(e->ev0, st);
   if (T == 4)
-    hipLaunchKernelGGL(k_attn_chain<4>, dim3((Nd + 3) / 4), dim3(WG), attn_lds_floats<4>(maxdeg) * sizeof(float), st, x, Nd, steps, nsteps, maxdeg, eps, flags);
+    hipLaunchKernelGGL(k_attn_chain<4>, dim3((Nd + 3) / 4), dim3(WG), attn_lds_floats<4>(maxdeg) * sizeof(float), st, x, Nd, steps, nsteps, maxdeg, eps, flags, prof);
   else if (T == 2)
-    hipLaunchKernelGGL(k_attn_chain<2>, dim3((Nd + 1) / 2), dim3(WG), attn_lds_floats<2>(maxdeg) * sizeof(float), st, x, Nd, steps, nsteps, maxdeg, eps, flags);
+    hipLaunchKernelGGL(k_attn_chain<2>, dim3((Nd + 1) / 2), dim3(WG), attn_lds_floats<2>(maxdeg) * sizeof(float), st, x, Nd, steps, nsteps, maxdeg, eps, flags, prof);
   else
-    hipLaunchKernelGGL(k_attn_chain<1>, dim3(Nd), dim3(WG), attn_lds_floats<1>(maxdeg) * sizeof(float), st, x, Nd, steps, nsteps, maxdeg, eps, flags);
+    hipLaunchKernelGGL(k_attn_chain<1>, dim3(Nd), dim3(WG), attn_lds_floats<1>(maxdeg) * sizeof(float), st, x, Nd, steps, nsteps, maxdeg, eps, flags, prof);
   if (timed && e->time_chain) {
     (void)hipEventRecord(e->ev1, st);
     (void)hipEventSynchronize(e->ev1);
     float ms = 0;
     (void)hipEventElapsedTime(&ms, e->ev0, e->ev1);
+    if (prof) {
+      unsigned long long h[16];
+      (void)hipMemcpy(h, prof, sizeof(h), hipMemcpyDeviceToHost);
+      const int nwg = (Nd + T - 1) / T;
+      double tot = 0;
+      for (int i = 0; i < 14; ++i) tot += (double)h[i];
+      fprintf(stderr, "[chain prof] T=%d wgs=%d %.1f us; mean cycles per workgroup per phase (share):", T, nwg, ms * 1e3);
+      for (int i = 0; i < 14; ++i) fprintf(stderr, " %d:%.0f(%.1f%%)", i, (double)h[i] / nwg, 100.0 * h[i] / tot);
+      fprintf(stderr, " total %.0f\n", tot / nwg);
+    }
     e->chain_ms_sum += ms;
     e->chain_launches++;
   }
@@ -848,6 +876,13 @@ void launch_pointnet(ps_engine* e, const PointNetW& w, const float* pts, const u
     hipLaunchKernelGGL(k_pointnet<32>, dim3(n_rows), dim3(128), 0, e->stream, w, pts, mask, rows, n_rows, P, feat_mask_dim, out, eps);
 }
 
+// edge-minor tile image of an edge set's rel-PE rows (device-side tile count, grid-stride)
+void launch_tiles(EdgeSet& es, hipStream_t st) {
+  const int grid = (int)std::min<size_t>(2048, es.cap_edges / 32 + (size_t)es.nq + 1);
+  hipLaunchKernelGGL(k_tile_transpose, dim3(grid), dim3(256), 0, st, (const int*)es.eoff.p, (const int*)es.toff.p, es.nq,
+                     (const _Float16*)es.rthl.p, es.rtA.p, es.rtT.p);
+}
+
 // radius search + CSR + rel-PE for one edge set
 void launch_radius(ps_engine* e, EdgeSet& es, const int* r1, const int* r2, const float* qpos, const int* qscene, int nq, float r,
                    int cap, int self_base, const float* src_ori, const float* dst_ori) {
@@ -859,13 +894,14 @@ void launch_radius(ps_engine* e, EdgeSet& es, const int* r1, const int* r2, cons
                      (const int*)nullptr, (int*)nullptr, (int*)nullptr);
   if (self_base >= 0)
     hipLaunchKernelGGL(k_radius_selfrank, dim3(grid), dim3(64 * wpb), 0, st, cs, qpos, qscene, nq, r2f, cap, self_base, es.cnt.p);
-  hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, st, (const int*)es.cnt.p, nq, es.eoff.p);
+  hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, st, (const int*)es.cnt.p, nq, es.eoff.p, es.toff.p);
   hipLaunchKernelGGL(k_radius<1>, dim3(grid), dim3(64 * wpb), 0, st, cs, qpos, qscene, nq, r2f, cap, self_base, (int*)nullptr,
                      (const int*)es.eoff.p, es.esrc.p, es.edst.p);
   const int pe_grid = (int)std::min<size_t>(4096, (es.cap_edges + 3) / 4 + 1);
   hipLaunchKernelGGL(k_relpe, dim3(pe_grid), dim3(256), 0, st, (const int*)es.esrc.p, (const int*)es.edst.p,
                      (const int*)(es.eoff.p + nq), 0, (const float*)e->d_tok_pos.p, src_ori, qpos, dst_ori, e->div32,
-                     (const float*)nullptr, es.rt.p, es.rthl.p, e->cfg.ln_eps);
+                     (const float*)nullptr, es.rthl.p, e->cfg.ln_eps);
+  launch_tiles(es, st);
 }
 
 }  // namespace
@@ -894,11 +930,13 @@ extern "C" int ps_encode_scene(ps_engine* e) {
     hipLaunchKernelGGL(k_relpe, dim3(1024), dim3(256), 0, st, (const int*)e->e_a2a.esrc.p, (const int*)e->e_a2a.edst.p,
                        (const int*)nullptr, (int)e->edge_counts[0], (const float*)e->d_tok_pos.p, (const float*)e->d_tok_ori.p,
                        (const float*)(e->d_tok_pos.p + 2 * (size_t)Mv), (const float*)(e->d_tok_ori.p + Mv), e->div32,
-                       (const float*)nullptr, e->e_a2a.rt.p, e->e_a2a.rthl.p, c.ln_eps);
+                       (const float*)nullptr, e->e_a2a.rthl.p, c.ln_eps);
+    launch_tiles(e->e_a2a, st);
     hipLaunchKernelGGL(k_relpe, dim3(2048), dim3(256), 0, st, (const int*)e->e_s2s.esrc.p, (const int*)e->e_s2s.edst.p,
                        (const int*)nullptr, (int)e->edge_counts[1], (const float*)e->d_tok_pos.p, (const float*)e->d_tok_ori.p,
                        (const float*)e->d_tok_pos.p, (const float*)e->d_tok_ori.p, e->div32, (const float*)nullptr,
-                       e->e_s2s.rt.p, e->e_s2s.rthl.p, c.ln_eps);
+                       e->e_s2s.rthl.p, c.ln_eps);
+    launch_tiles(e->e_s2s, st);
   }
   // 6 x (a2a on the agent rows in place, s2s on all rows)  (attn_fusion.py:117-119).  kv is indexed by
   // GLOBAL token row for both (the a2a projection fills rows Mv.. of the shared kv buffer).
@@ -949,7 +987,7 @@ extern "C" int ps_generate_policy(ps_engine* e) {
   // condition transformer at 'policy_decoder' (traj_sam.py:129-137)
   if (e->have_cond && c.cond_layers > 0) {
     hipLaunchKernelGGL(k_cond_edges, dim3(e->n_cond_edges), dim3(128), 0, st, e->cond, (const int*)e->d_ent_off.p,
-                       (const int*)e->d_ent_type.p, (const float*)e->d_ent_val.p, e->n_cond_edges, e->e_cnd.rt.p, e->e_cnd.rthl.p, c.ln_eps);
+                       (const int*)e->d_ent_type.p, (const float*)e->d_ent_val.p, e->n_cond_edges, e->e_cnd.rtA.p, e->e_cnd.rtT.p, c.ln_eps);
     HIPCHK(hipMemcpyAsync(e->d_xc.p, e->d_emd.p, sizeof(float) * (size_t)A * D, hipMemcpyDeviceToDevice, st));
     for (int i = 0; i < c.cond_layers; ++i) {
       launch_kv(e, e->d_xc.p, A, e->L_cnd + i, 1, e->d_kv.p, e->d_kh.p, 0);
@@ -1263,26 +1301,35 @@ extern "C" int ps_test_attn(ps_engine* e, int32_t layer_index, int32_t Ns, int32
   if (layer_index < 0 || layer_index >= (int)e->all_layers.size()) return fail(PS_E_ARG, "layer index out of range");
   HIPCHK(hipSetDevice(e->cfg.device));
   DevBuf<float> dxs, dxd, drt, dkv;
-  DevBuf<_Float16> drth, dkh;
-  DevBuf<int> doff, dsrc;
+  DevBuf<_Float16> drth, dkh, drtA, drtT;
+  DevBuf<int> doff, dsrc, dtoff;
   DevBuf<ChainStep> dstep;
   int maxdeg = 1;
-  for (int i = 0; i < Nd; ++i) maxdeg = std::max(maxdeg, eoff[i + 1] - eoff[i]);
+  std::vector<int> toff((size_t)Nd + 1, 0);
+  for (int i = 0; i < Nd; ++i) {
+    maxdeg = std::max(maxdeg, eoff[i + 1] - eoff[i]);
+    toff[i + 1] = toff[i] + (eoff[i + 1] - eoff[i] + 31) / 32;
+  }
   if (upload(dxs, x_src, (size_t)Ns * D, e->stream) || upload(dxd, x_dst, (size_t)Nd * D, e->stream) ||
       upload(drt, rt, (size_t)std::max(E, 1) * 128, e->stream) || upload(doff, (const int*)eoff, (size_t)Nd + 1, e->stream) ||
       upload(dsrc, (const int*)esrc, (size_t)std::max(E, 1), e->stream) || dkv.ensure((size_t)Ns * 256) ||
-      drth.ensure((size_t)std::max(E, 1) * 256) || dkh.ensure((size_t)Ns * 256))
+      drth.ensure((size_t)std::max(E, 1) * 256) || dkh.ensure((size_t)Ns * 256) ||
+      upload(dtoff, toff.data(), toff.size(), e->stream) || drtA.ensure((size_t)(toff[Nd] + 1) * 8192) || drtT.ensure((size_t)(toff[Nd] + 1) * 8192))
     return fail(PS_E_HIP, "test upload failed");
   launch_kv(e, dxs.p, Ns, layer_index, 1, dkv.p, dkh.p, 0);
   hipLaunchKernelGGL(k_split_rows, dim3((std::max(E, 1) * 128 + 255) / 256), dim3(256), 0, e->stream, (const float*)drt.p, std::max(E, 1), drth.p);
+  if (Nd > 0)
+    hipLaunchKernelGGL(k_tile_transpose, dim3(std::max(1, std::min(toff[Nd], 2048))), dim3(256), 0, e->stream, (const int*)doff.p,
+                       (const int*)dtoff.p, Nd, (const _Float16*)drth.p, drtA.p, drtT.p);
   ChainStep st;
   st.w = e->all_layers[layer_index];
-  st.kv = dkv.p; st.eoff = doff.p; st.esrc = dsrc.p; st.rt = drt.p; st.rthl = drth.p; st.khl = dkh.p;
+  st.kv = dkv.p; st.eoff = doff.p; st.esrc = dsrc.p; st.toff = dtoff.p; st.rtT = drtT.p; st.rtA = drtA.p; st.khl = dkh.p;
   if (upload(dstep, &st, 1, e->stream)) return fail(PS_E_HIP, "test upload failed");
   if (launch_chain(e, dxd.p, Nd, 0, 1, maxdeg, false, dstep.p, T)) return PS_E_HIP;
   HIPCHK(hipStreamSynchronize(e->stream));
   HIPCHK(hipMemcpy(out, dxd.p, sizeof(float) * (size_t)Nd * D, hipMemcpyDeviceToHost));
   dxs.release(); dxd.release(); drt.release(); dkv.release(); doff.release(); dsrc.release(); dstep.release(); drth.release(); dkh.release();
+  dtoff.release(); drtT.release(); drtA.release();
   return PS_OK;
 }
 
@@ -1297,9 +1344,14 @@ extern "C" int64_t ps_test_get_edges(ps_engine* e, int32_t which, int32_t* esrc,
   if (hipMemcpy(&E, s.eoff.p + s.nq, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return fail(PS_E_HIP, "memcpy");
   if (E > capacity) return fail(PS_E_ARG, "capacity too small");
   if (hipMemcpy(esrc, s.esrc.p, sizeof(int) * E, hipMemcpyDeviceToHost) != hipSuccess ||
-      hipMemcpy(edst, s.edst.p, sizeof(int) * E, hipMemcpyDeviceToHost) != hipSuccess ||
-      (rt && hipMemcpy(rt, s.rt.p, sizeof(float) * (size_t)E * 128, hipMemcpyDeviceToHost) != hipSuccess))
+      hipMemcpy(edst, s.edst.p, sizeof(int) * E, hipMemcpyDeviceToHost) != hipSuccess)
     return fail(PS_E_HIP, "memcpy");
+  if (rt) {   // the engine keeps the rows as split fp16 only: hi + lo restores them to ~2^-22
+    std::vector<_Float16> hl((size_t)E * 256);
+    if (hipMemcpy(hl.data(), s.rthl.p, sizeof(_Float16) * hl.size(), hipMemcpyDeviceToHost) != hipSuccess) return fail(PS_E_HIP, "memcpy");
+    for (size_t i = 0; i < (size_t)E; ++i)
+      for (int c = 0; c < 128; ++c) rt[i * 128 + c] = (float)hl[i * 256 + c] + (float)hl[i * 256 + 128 + c];
+  }
   return E;
 }
 
@@ -1416,10 +1468,10 @@ extern "C" int ps_policy_forward(ps_engine* e, int32_t n_scenes, int32_t Na, con
   std::vector<ChainStep> hs;
   for (int i = 0; i < L; ++i) {
     ChainStep s1;
-    s1.w = e->a2p[i]; s1.kv = d_kva.p + (size_t)i * Na * 256 - (size_t)Nm * 256; s1.eoff = ea.eoff.p; s1.esrc = ea.esrc.p; s1.rt = ea.rt.p; s1.rthl = ea.rthl.p; s1.khl = d_kha.p + (size_t)i * Na * 256 - (size_t)Nm * 256;
+    s1.w = e->a2p[i]; s1.kv = d_kva.p + (size_t)i * Na * 256 - (size_t)Nm * 256; s1.eoff = ea.eoff.p; s1.esrc = ea.esrc.p; s1.toff = ea.toff.p; s1.rtT = ea.rtT.p; s1.rtA = ea.rtA.p; s1.khl = d_kha.p + (size_t)i * Na * 256 - (size_t)Nm * 256;
     hs.push_back(s1);
     ChainStep s2;
-    s2.w = e->m2p[i]; s2.kv = d_kvm.p + (size_t)i * Nm * 256; s2.eoff = em.eoff.p; s2.esrc = em.esrc.p; s2.rt = em.rt.p; s2.rthl = em.rthl.p; s2.khl = d_khm.p + (size_t)i * Nm * 256;
+    s2.w = e->m2p[i]; s2.kv = d_kvm.p + (size_t)i * Nm * 256; s2.eoff = em.eoff.p; s2.esrc = em.esrc.p; s2.toff = em.toff.p; s2.rtT = em.rtT.p; s2.rtA = em.rtA.p; s2.khl = d_khm.p + (size_t)i * Nm * 256;
     hs.push_back(s2);
   }
   int rc = 0;
@@ -1444,7 +1496,7 @@ extern "C" int ps_policy_forward(ps_engine* e, int32_t n_scenes, int32_t Na, con
   for (DevBuf<float>* b : {&d_pos, &d_ori, &d_atok, &d_mtok, &d_ppos, &d_pori, &d_x, &d_kva, &d_kvm, &d_motion, &d_traj, &d_vel}) b->release();
   for (DevBuf<int>* b : {&d_rmap, &d_ragent, &d_pscene, &d_ptype}) b->release();
   d_kha.release(); d_khm.release();
-  for (EdgeSet* s_ : {&ea, &em}) { s_->cnt.release(); s_->eoff.release(); s_->esrc.release(); s_->edst.release(); s_->rt.release(); s_->rthl.release(); }
+  for (EdgeSet* s_ : {&ea, &em}) { s_->cnt.release(); s_->eoff.release(); s_->esrc.release(); s_->edst.release(); s_->toff.release(); s_->rthl.release(); s_->rtA.release(); s_->rtT.release(); }
   d_steps.release();
   return rc;
 }

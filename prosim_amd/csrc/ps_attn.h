@@ -43,8 +43,11 @@ struct ChainStep {
   const float* kv;    // [Ns][256] projected sources (k | v) for this layer
   const int* eoff;    // [Nd+1] CSR offsets by destination
   const int* esrc;    // [E] source row in kv
-  const float* rt;    // [E][128] normalised relative-PE (no affine)
-  const _Float16* rthl;   // [E][256]: the same rows as split fp16 (hi[128] | lo[128]) for the score MFMAs
+  const int* toff;    // [Nd+1] offsets in 32-edge tiles (sum of ceil(deg/32)) into rtT
+  // normalised relative-PE rows (no affine) as split fp16 (hi | lo), cut into 32-edge tiles per destination and
+  // stored twice, once per MFMA operand shape (layouts: k_tile_transpose in ps_kernels.h)
+  const _Float16* rtA;    // [tiles][8192]: score pass A operand (edge-major fragments, 1 KB contiguous per load)
+  const _Float16* rtT;    // [tiles][8192]: aggregation pass B operand (edge-minor)
   const _Float16* khl;    // [Ns][256]: the k rows of kv as split fp16 (hi | lo)
 };
 
@@ -146,9 +149,25 @@ __device__ __forceinline__ void fold_kgroups(float (&acc)[T][4]) {
 
 template <int T>
 __global__ __launch_bounds__(WG, (T >= 2 ? 2 : 1)) void k_attn_chain(float* __restrict__ x, int Nd, const ChainStep* __restrict__ steps,
-                                                     int nsteps, int maxdeg, float eps, int flags) {
+                                                     int nsteps, int maxdeg, float eps, int flags,
+                                                     unsigned long long* __restrict__ prof) {
+  // phase clocks for tools/gpu_phase.py (prof == nullptr in every product launch): thread 0 of each
+  // workgroup charges the core-clock cycles since the previous mark to phase i
+  long long tprev = prof ? clock64() : 0;
+#define PS_MARK(i)                                                        \
+  do {                                                                    \
+    if (prof && threadIdx.x == 0) {                                       \
+      const long long now_ = clock64();                                   \
+      atomicAdd(prof + (i), (unsigned long long)(now_ - tprev));          \
+      tprev = now_;                                                       \
+    }                                                                     \
+  } while (0)
   constexpr int W = 4 / T;  // waves per destination in the edge phase
   constexpr int CH = chunk_edges<T>();
+  if ((flags >> 8) && blockIdx.x >= gridDim.x / 2) {   // experiment: de-phase the two workgroups of a CU
+    const long long t0 = clock64(), dl = (long long)(flags >> 8) << 10;
+    while (clock64() - t0 < dl) __builtin_amdgcn_s_sleep(32);
+  }
   // T == 1: one workgroup per CU with the full register file -> software prefetch (weights one chunk ahead,
   // edge rows one tile ahead).  T >= 2: compiled for 2 workgroups per CU (__launch_bounds__(256, 2), <= 256
   // registers): the co-resident workgroup hides the latency instead and nothing is double-buffered.
@@ -264,6 +283,7 @@ __global__ __launch_bounds__(WG, (T >= 2 ? 2 : 1)) void k_attn_chain(float* __re
       }
     }
     __syncthreads();
+    PS_MARK(0);
     // ---- q~[t][h][c] = sum_d q[t][16h+d] * Wkr_g[16h+d][c];  cq[t][h] = <q_h, kb_h>
     {
       const int h = 2 * wave + k2;
@@ -283,6 +303,7 @@ __global__ __launch_bounds__(WG, (T >= 2 ? 2 : 1)) void k_attn_chain(float* __re
       }
     }
     __syncthreads();
+    PS_MARK(1);
 
     // ---- edge phase: wave -> (destination t, sub-wave wi); lane -> columns (2*lane, 2*lane+1)
     // Chunks of CH edges; per chunk: scores (pass 1) -> running max / rescale -> exp -> weighted sums (pass 2).
@@ -290,7 +311,7 @@ __global__ __launch_bounds__(WG, (T >= 2 ? 2 : 1)) void k_attn_chain(float* __re
     {
       float* sc = un + (size_t)t * CH * 8;
       const int hl = lane >> 3, jl = lane & 7;
-      const float* rbase = st.rt + (size_t)e_beg * 128 + 2 * lane;
+      const int t_beg = (r < Nd) ? ldgi(st.toff + r) : 0;
       // B operands of the score MFMAs, built once per destination and layer: lane -> column n = lane & 15
       // (head n & 7, hi half for n < 8 / lo half for n >= 8), k-block lane >> 4 (8 consecutive columns)
       half8 bq[4], bk[4];
@@ -316,9 +337,11 @@ __global__ __launch_bounds__(WG, (T >= 2 ? 2 : 1)) void k_attn_chain(float* __re
         }
       }
       const float cqm = cq[t * 8 + (lane & 7)];
-      float ar[8][2], av0 = 0.f, av1 = 0.f, m_run[8], l_run[8];
+      __syncthreads();   // q~ (in `big`) is in registers now: the k staging area [f1, big) may overwrite it
+      float av0 = 0.f, av1 = 0.f, m_run[8], l_run[8];
+      floatx4 ar[8];   // a_r as MFMA accumulators: [column block][row 4*(lane>>4)+r = (p hi | p lo) x head]
 #pragma unroll
-      for (int h = 0; h < 8; ++h) { ar[h][0] = ar[h][1] = 0.f; m_run[h] = -INFINITY; l_run[h] = 0.f; }
+      for (int h = 0; h < 8; ++h) { ar[h] = floatx4{0.f, 0.f, 0.f, 0.f}; m_run[h] = -INFINITY; l_run[h] = 0.f; }
       // the chunk count must be uniform over the workgroup (barriers inside): max degree of its T rows
       int dmax = 0;
 #pragma unroll
@@ -327,6 +350,7 @@ __global__ __launch_bounds__(WG, (T >= 2 ? 2 : 1)) void k_attn_chain(float* __re
         const int d_ = ((rr_ < Nd) && !(flags & 1)) ? (ldgi(st.eoff + rr_ + 1) - ldgi(st.eoff + rr_)) : 0;
         dmax = d_ > dmax ? d_ : dmax;
       }
+      PS_MARK(2);
       for (int c0 = 0; c0 < dmax; c0 += CH) {
         const int cn = (deg - c0) < CH ? (deg - c0) : CH;   // edges of this destination in the chunk (may be <= 0)
         if (c0 > 0) {   // source rows of a later chunk (the barrier that closed the previous chunk freed `el`)
@@ -339,34 +363,55 @@ __global__ __launch_bounds__(WG, (T >= 2 ? 2 : 1)) void k_attn_chain(float* __re
         // fp32 accumulator: 16 MFMAs + 16 16-byte loads per 16 edges, no conversion work in the loop.
         {
           const int mi = lane & 15, kq = lane >> 4;
+          // k rows are gathered by source.  Loaded straight into the A-fragment shape (lane = edge + 16*kq) the
+          // 4 lanes of a quad would read 4 different rows and the load issues at a quarter of the rate; so the
+          // gather uses lane = 4*row + piece (each quad reads 64 contiguous bytes) and the 16 x 256 B half rows
+          // turn into fragments through a wave-private LDS staging area (row stride 272 B).
+          const int rq = lane >> 2, pq = lane & 3;
+          half8* stw = reinterpret_cast<half8*>(f1 + wave * 1088) + rq * 17 + pq;
+          const half8* str = reinterpret_cast<const half8*>(f1 + wave * 1088) + mi * 17 + kq;
           half8 nrh[4], nrl[4], nkh[4], nkl[4];
           auto gather1 = [&](int eb) {
-            const int e = (eb + mi < cn) ? eb + mi : cn - 1;
-            const size_t ge = (size_t)(e_beg + c0 + e) * 256 + 8 * kq;
-            const size_t gs = (size_t)el[e] * 256 + 8 * kq;
+            const int blk = (c0 + eb) >> 4;
+            const _Float16* ra = (flags & 32) ? st.rtA + (size_t)((t_beg + (blk >> 1)) & 7) * 8192 + (blk & 1) * 4096 + lane * 8
+                                              : st.rtA + (size_t)(t_beg + (blk >> 1)) * 8192 + (blk & 1) * 4096 + lane * 8;
+            const int e = (eb + rq < cn) ? eb + rq : cn - 1;
+            const _Float16* kp = st.khl + (size_t)el[e] * 256 + 8 * pq;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-              nrh[ks] = ldgh8(st.rthl + ge + 32 * ks);
-              nrl[ks] = ldgh8(st.rthl + ge + 128 + 32 * ks);
-              nkh[ks] = ldgh8(st.khl + gs + 32 * ks);
-              nkl[ks] = ldgh8(st.khl + gs + 128 + 32 * ks);
+              nrh[ks] = ldgh8(ra + 512 * ks);
+              nrl[ks] = ldgh8(ra + 2048 + 512 * ks);
+              nkh[ks] = ldgh8(kp + 32 * ks);
+              nkl[ks] = ldgh8(kp + 128 + 32 * ks);
             }
           };
           if (PF && wi * 16 < cn && !(flags & 16)) gather1(wi * 16);
           for (int eb = wi * 16; eb < cn && !(flags & 16); eb += 16 * W) {
             if (!PF) gather1(eb);   // two workgroups per CU hide the latency instead of a second register set
+            // all 16 row loads are in flight before anything waits (left alone, the scheduler sinks each load
+            // next to its use: one round trip per MFMA)
+            __builtin_amdgcn_sched_barrier(0);
             half8 arh[4], arl[4], akh[4], akl[4];
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) { arh[ks] = nrh[ks]; arl[ks] = nrl[ks]; akh[ks] = nkh[ks]; akl[ks] = nkl[ks]; }
+            for (int ks = 0; ks < 4; ++ks) { arh[ks] = nrh[ks]; arl[ks] = nrl[ks]; }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) stw[4 * ks] = nkh[ks];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) akh[ks] = str[4 * ks];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) stw[4 * ks] = nkl[ks];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) akl[ks] = str[4 * ks];
             if (PF && eb + 16 * W < cn) gather1(eb + 16 * W);   // the next tile's rows fly under this tile's MFMAs
-            floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+            floatx4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
               acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(arh[ks], bq[ks], acc, 0, 0, 0);
+              acc2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(akh[ks], bk[ks], acc2, 0, 0, 0);
               acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(arl[ks], bq[ks], acc, 0, 0, 0);
-              acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(akh[ks], bk[ks], acc, 0, 0, 0);
-              acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(akl[ks], bk[ks], acc, 0, 0, 0);
+              acc2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(akl[ks], bk[ks], acc2, 0, 0, 0);
             }
+            acc += acc2;
             // D[row = 4*(lane>>4) + r][col = lane & 15]: columns h and h + 8 (the lo half of q) meet by row_ror:8
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
@@ -376,7 +421,9 @@ __global__ __launch_bounds__(WG, (T >= 2 ? 2 : 1)) void k_attn_chain(float* __re
             }
           }
         }
+        PS_MARK(3);
         __syncthreads();
+        PS_MARK(4);
         // online softmax over the destination's edges, per head (torch_geometric.utils.softmax:
         // max-shift, exp, / (sum + 1e-16)); every wave of the destination finds the chunk max
         float mc[8];
@@ -409,10 +456,12 @@ __global__ __launch_bounds__(WG, (T >= 2 ? 2 : 1)) void k_attn_chain(float* __re
           *reinterpret_cast<float4*>(sc + (size_t)e * 8 + 4) = b;
         }
 #pragma unroll
-        for (int h = 0; h < 8; ++h) {
-          l_run[h] = l_run[h] * scl[h] + wave_sum(ls[h]);
-          ar[h][0] *= scl[h];
-          ar[h][1] *= scl[h];
+        for (int h = 0; h < 8; ++h) l_run[h] = l_run[h] * scl[h] + wave_sum(ls[h]);
+        {
+          const bool up = (lane >> 4) & 1;   // accumulator row 4*(lane>>4)+r belongs to head 4*((lane>>4)&1)+r
+          const float s0 = up ? scl[4] : scl[0], s1 = up ? scl[5] : scl[1], s2 = up ? scl[6] : scl[2], s3 = up ? scl[7] : scl[3];
+#pragma unroll
+          for (int cb = 0; cb < 8; ++cb) { ar[cb][0] *= s0; ar[cb][1] *= s1; ar[cb][2] *= s2; ar[cb][3] *= s3; }
         }
         {
           float sh = scl[0];
@@ -422,48 +471,77 @@ __global__ __launch_bounds__(WG, (T >= 2 ? 2 : 1)) void k_attn_chain(float* __re
           av1 *= sh;
         }
         __syncthreads();
-        // pass 2: a_r[h][c] += sum_e p_e,h r~_e[c],  a_v[hd] += sum_e p_e,h v_src[hd]   (:100, aggr='add'), 8 + 8 edges in flight
+        PS_MARK(5);
+        // pass 2a on the matrix cores: a_r[h][c] += sum_e p_e,h r~_e[c]   (:100, aggr='add').  Per 32-edge tile:
+        // A[m][k] = (p hi | p lo)[head m & 7][edge k] from the LDS score tile, B[k][n] = r~ (hi, then lo) of 16
+        // columns from the edge-minor image (one 16-byte load per fragment, 1 KB contiguous per wave);
+        // 8 column blocks x (hi, lo) = 16 MFMAs per tile, all four hi/lo cross terms land in the fp32 accumulators.
+        if (!(flags & 8)) {
+          const int mA = lane & 15, kqA = lane >> 4;
+          const bool loA = mA >= 8;
+          const _Float16* tb = st.rtT + (size_t)(t_beg + (c0 >> 5)) * 8192 + mA * 32 + kqA * 8;
+          for (int eb = wi * 32; eb < cn; eb += 32 * W) {
+            const _Float16* tp = (flags & 32) ? st.rtT + (size_t)((t_beg + ((c0 + eb) >> 5)) & 7) * 8192 + mA * 32 + kqA * 8
+                                              : tb + (size_t)(eb >> 5) * 8192;
+            half8 bh[8], bl[8];
+#pragma unroll
+            for (int cb = 0; cb < 8; ++cb) {
+              bh[cb] = ldgh8(tp + cb * 512);
+              bl[cb] = ldgh8(tp + 4096 + cb * 512);
+            }
+            half8 ap;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const int ee = eb + 8 * kqA + j;
+              const float pv = (ee < cn) ? sc[(size_t)ee * 8 + (mA & 7)] : 0.f;
+              ap[j] = loA ? f16_lo(pv) : f16_hi(pv);
+            }
+#pragma unroll
+            for (int cb = 0; cb < 8; ++cb) {
+              ar[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ap, bh[cb], ar[cb], 0, 0, 0);
+              ar[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ap, bl[cb], ar[cb], 0, 0, 0);
+            }
+          }
+        }
+        PS_MARK(6);
+        // pass 2b: a_v[hd] += sum_e p_e,h v_src[hd]: v rows are gathered by SOURCE (no edge-minor image), 8 edges in flight
         const float* vbase = st.kv + 128 + 2 * lane;
-        float2 rrn[8], vvn[8];
+        float2 vvn[8];
         auto gather2 = [&](int eb) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             const int ee = (eb + j < cn) ? eb + j : cn - 1;
-            rrn[j] = ldg2(rbase + (size_t)(c0 + ee) * 128);
             vvn[j] = ldg2(vbase + (size_t)el[ee] * 256);
           }
         };
         if (PF && wi * 8 < cn) gather2(wi * 8);
         for (int eb = wi * 8; eb < cn && !(flags & 8); eb += 8 * W) {
           if (!PF) gather2(eb);
-          float2 rr[8], vv[8];
+          float2 vv[8];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) { rr[j] = rrn[j]; vv[j] = vvn[j]; }
+          for (int j = 0; j < 8; ++j) vv[j] = vvn[j];
           if (PF && eb + 8 * W < cn) gather2(eb + 8 * W);
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
-            const int ee = (eb + j < cn) ? eb + j : cn - 1;
-            float4 pa = *reinterpret_cast<const float4*>(sc + (size_t)ee * 8);
-            float4 pb = *reinterpret_cast<const float4*>(sc + (size_t)ee * 8 + 4);
-            if (eb + j >= cn) { pa = make_float4(0.f, 0.f, 0.f, 0.f); pb = pa; }
-            const float p[8] = {pa.x, pa.y, pa.z, pa.w, pb.x, pb.y, pb.z, pb.w};
-            const float ph = (eb + j < cn) ? sc[(size_t)ee * 8 + hl] : 0.f;
-#pragma unroll
-            for (int h = 0; h < 8; ++h) {
-              ar[h][0] = fmaf(p[h], rr[j].x, ar[h][0]);
-              ar[h][1] = fmaf(p[h], rr[j].y, ar[h][1]);
-            }
+            const float ph = (eb + j < cn) ? sc[(size_t)(eb + j) * 8 + hl] : 0.f;
             av0 = fmaf(ph, vv[j].x, av0);
             av1 = fmaf(ph, vv[j].y, av1);
           }
         }
+        PS_MARK(7);
         if (c0 + CH < dmax) __syncthreads();   // the next chunk's pass 1 overwrites the score tile
       }
       // the to_v_r fold's weights leave now and land while the partials are published
       if (PF) wload(wA, w.Wvr_gt + woff, 128);
+      // rows h (p hi) and h + 8 (p lo) sit 32 lanes apart: one half-wave swap folds two column blocks at a time
 #pragma unroll
-      for (int h = 0; h < 8; ++h)
-        *reinterpret_cast<float2*>(big + (size_t)(wave * 8 + h) * QP + 2 * lane) = make_float2(ar[h][0], ar[h][1]);
+      for (int cb = 0; cb < 8; cb += 2) {
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const float v = swap_add32(ar[cb][r4], ar[cb + 1][r4]);   // lanes < 32: block cb, lanes >= 32: block cb + 1
+          big[(size_t)(wave * 8 + 4 * ((lane >> 4) & 1) + r4) * QP + (cb + (lane >> 5)) * 16 + (lane & 15)] = v;
+        }
+      }
       *reinterpret_cast<float2*>(avp + wave * 128 + 2 * lane) = make_float2(av0, av1);
       if (lane < 8) {
         float v = l_run[0];
@@ -473,7 +551,9 @@ __global__ __launch_bounds__(WG, (T >= 2 ? 2 : 1)) void k_attn_chain(float* __re
       }
     }
     if (s + 1 < nsteps) sp_store(sp_next);   // layer s-1's buffer is dead: park the next layer's vectors there
+    PS_MARK(8);
     __syncthreads();
+    PS_MARK(9);
     if (W > 1) {  // sum the W sub-wave partials of each destination into its first slot
       for (int i = tid; i < T * 8 * 128; i += WG) {
         const int tt = i / 1024, hc = i % 1024, h = hc >> 7, c = hc & 127;
@@ -489,6 +569,7 @@ __global__ __launch_bounds__(WG, (T >= 2 ? 2 : 1)) void k_attn_chain(float* __re
       }
       __syncthreads();
     }
+    PS_MARK(10);
     // ---- agg = (a_v + Wvr_g^T a_r + l * vb) / (l + 1e-16)   (to_v_r fold; :89, :100)
     //      columns ncol.. belong to head ncol/16 = 2*wave + (c8 >> 2)
     {
@@ -534,6 +615,7 @@ __global__ __launch_bounds__(WG, (T >= 2 ? 2 : 1)) void k_attn_chain(float* __re
       }
     }
     __syncthreads();
+    PS_MARK(11);
     // ---- x = x + LN_post(to_out(u))  (:76), then xn = LN_ffpre(x)  (:77)
     {
       float acc[T][4];
@@ -560,6 +642,7 @@ __global__ __launch_bounds__(WG, (T >= 2 ? 2 : 1)) void k_attn_chain(float* __re
       ln_row_wave(xr, nr, sp + SP_LN_FFPRE_W, sp + SP_LN_FFPRE_B, eps, lane, false);
     }
     __syncthreads();
+    PS_MARK(12);
     // ---- FFN up: f1 = relu(W1 xn + b1)   N = 512: wave -> 128 columns, lane (c32, k2), 4 chunks of 16 rows
     {
       float acc[T][4];
@@ -612,11 +695,13 @@ __global__ __launch_bounds__(WG, (T >= 2 ? 2 : 1)) void k_attn_chain(float* __re
       if (s + 1 < nsteps) ln_row_wave(xr, nr, sp_next + SP_LN_DST_W, sp_next + SP_LN_DST_B, eps, lane, false);
     }
     __syncthreads();
+    PS_MARK(13);
   }
   for (int i = tid_o; i < T * 128; i += WG) {
     const int t = i >> 7, r = row0 + t;
     if (r < Nd) x[(size_t)r * 128 + (i & 127)] = xs[i];
   }
+#undef PS_MARK
 }
 
 // k | v projection of source tokens for L layers: kv[l][n][0:128] = Wk LN_src(x_n),

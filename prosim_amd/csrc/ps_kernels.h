@@ -219,33 +219,85 @@ __global__ void k_radius_selfrank(CandSet cs, const float* __restrict__ qpos, co
   if (lane == 0 && before < cap + 1) cnt[q] -= 1;
 }
 
-// exclusive scan of cnt[0..n) -> off[0..n], single workgroup (n is a few thousand at most).
-__global__ void k_exclusive_scan(const int* __restrict__ cnt, int n, int* __restrict__ off) {
-  __shared__ int wsum[16];
-  __shared__ int carry;
+// exclusive scan of cnt[0..n) -> off[0..n] and of ceil(cnt/32) -> toff[0..n] (32-edge tiles of the
+// transposed rel-PE image), single workgroup (n is a few thousand at most).
+__global__ void k_exclusive_scan(const int* __restrict__ cnt, int n, int* __restrict__ off, int* __restrict__ toff) {
+  __shared__ int wsum[16], wsum2[16];
+  __shared__ int carry, carry2;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
-  if (tid == 0) carry = 0;
+  if (tid == 0) { carry = 0; carry2 = 0; }
   __syncthreads();
   for (int base = 0; base < n; base += blockDim.x) {
     const int i = base + tid;
     const int v = i < n ? cnt[i] : 0;
-    int s = v;
+    const int v2 = (v + 31) >> 5;
+    int s = v, s2 = v2;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
-      const int y = __shfl_up(s, o);
-      if (lane >= o) s += y;
+      const int y = __shfl_up(s, o), y2 = __shfl_up(s2, o);
+      if (lane >= o) { s += y; s2 += y2; }
     }
-    if (lane == 63) wsum[wave] = s;
+    if (lane == 63) { wsum[wave] = s; wsum2[wave] = s2; }
     __syncthreads();
-    int woff = 0;
-    for (int j = 0; j < wave; ++j) woff += wsum[j];
-    const int c = carry;
-    if (i < n) off[i] = c + woff + s - v;
+    int woff = 0, woff2 = 0;
+    for (int j = 0; j < wave; ++j) { woff += wsum[j]; woff2 += wsum2[j]; }
+    const int c = carry, c2 = carry2;
+    if (i < n) { off[i] = c + woff + s - v; toff[i] = c2 + woff2 + s2 - v2; }
     __syncthreads();
-    if (tid == blockDim.x - 1) carry = c + woff + s;
+    if (tid == blockDim.x - 1) { carry = c + woff + s; carry2 = c2 + woff2 + s2; }
     __syncthreads();
   }
-  if (tid == 0) off[n] = carry;
+  if (tid == 0) { off[n] = carry; toff[n] = carry2; }
+}
+
+// MFMA operand images of the split-fp16 rel-PE rows.  The edges of a destination are cut into tiles of 32
+// (the last one zero-padded); tile tau owns 8192 halfs in each image:
+//  * rtA (score pass, A operand: lane = edge m + 16*kq holds 8 consecutive columns):
+//      [sub 2 (edges 0-15 | 16-31)][part 2 (hi | lo)][ks 4][lane 64][8] -- one wave load instruction reads
+//      1 KB CONTIGUOUS.  (Read from row-major rows the same fragment is 16 rows x 64 B: adjacent lanes hit
+//      different cache lines and the texture-address unit issues it 4x slower -- tools/mb/mb_gather.)
+//  * rtT (aggregation pass, B operand: lane = column n + 16*kq holds 8 consecutive EDGES of one column):
+//      [part 2][column 128][edge 32].
+// One 256-thread workgroup per tile.
+__global__ __launch_bounds__(256) void k_tile_transpose(const int* __restrict__ eoff, const int* __restrict__ toff, int nq,
+                                                       const _Float16* __restrict__ rthl, _Float16* __restrict__ rtA,
+                                                       _Float16* __restrict__ rtT) {
+  __shared__ __attribute__((aligned(16))) _Float16 buf[32][264];
+  const int tid = threadIdx.x;
+  const int ntiles = toff[nq];
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    int lo = 0, hi = nq - 1;   // largest d with toff[d] <= tile (destinations without edges share a toff value)
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (toff[mid] <= tile) lo = mid; else hi = mid - 1;
+    }
+    while (toff[lo + 1] <= tile) ++lo;   // skip empty destinations (cannot run past nq: tile < toff[nq])
+    const int e0 = eoff[lo] + (tile - toff[lo]) * 32;
+    const int n = min(32, eoff[lo + 1] - e0);
+    __syncthreads();
+    for (int i = tid; i < 32 * 32; i += 256) {   // 32 rows x 32 chunks of 8 halfs
+      const int r = i >> 5, ch = i & 31;
+      half8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (r < n) v = ldgh8(rthl + (size_t)(e0 + r) * 256 + 8 * ch);
+      *reinterpret_cast<half8*>(&buf[r][8 * ch]) = v;
+    }
+    __syncthreads();
+    // A image: piece P = ((sub*2 + part)*4 + ks)*64 + kq*16 + m  <-  row sub*16 + m, halfs part*128 + ks*32 + kq*8 ..+8
+    for (int P = tid; P < 1024; P += 256) {
+      const int m = P & 15, kq = (P >> 4) & 3, ks = (P >> 6) & 3, part_ = (P >> 8) & 1, sub = P >> 9;
+      *reinterpret_cast<half8*>(rtA + (size_t)tile * 8192 + (size_t)P * 8) =
+          *reinterpret_cast<const half8*>(&buf[sub * 16 + m][part_ * 128 + ks * 32 + kq * 8]);
+    }
+    const int part = tid >> 7, c = tid & 127;
+    _Float16* o = rtT + (size_t)tile * 8192 + part * 4096 + c * 32;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      half8 v;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = buf[8 * g + j][part * 128 + c];
+      *reinterpret_cast<half8*>(o + 8 * g) = v;
+    }
+  }
 }
 
 // knn (loop=True): one WAVE per query.  Each lane keeps up to KNN_SLOTS candidates' d2 in registers
@@ -322,7 +374,7 @@ __global__ void k_relpe(const int* __restrict__ esrc, const int* __restrict__ ed
                         int n_edges_host, const float* __restrict__ src_pos, const float* __restrict__ src_ori,
                         const float* __restrict__ dst_pos, const float* __restrict__ dst_ori,
                         const float* __restrict__ div32, const float* __restrict__ add /*[E][128] or null*/,
-                        float* __restrict__ rt, _Float16* __restrict__ rthl, float eps) {
+                        _Float16* __restrict__ rthl, float eps) {
   const int lane = threadIdx.x & 63;
   const int wpb = blockDim.x >> 6;
   const int E = n_edges_ptr ? *n_edges_ptr : n_edges_host;
@@ -349,9 +401,7 @@ __global__ void k_relpe(const int* __restrict__ esrc, const int* __restrict__ ed
     const float var = wave_sum(d0 * d0 + d1 * d1) * (1.f / 128.f);
     const float rstd = 1.f / sqrtf(var + eps);
     const float y0 = d0 * rstd, y1 = d1 * rstd;
-    rt[(size_t)e * 128 + lane] = y0;
-    rt[(size_t)e * 128 + 64 + lane] = y1;
-    // the same row as split fp16 (hi[128] | lo[128]) for the score MFMAs of k_attn_chain
+    // the row as split fp16 (hi[128] | lo[128]): what the score MFMAs of k_attn_chain read
     _Float16* h = rthl + (size_t)e * 256;
     h[lane] = f16_hi(y0);
     h[64 + lane] = f16_hi(y1);
@@ -420,7 +470,7 @@ struct CondW {
 };
 __global__ __launch_bounds__(128) void k_cond_edges(CondW w, const int* __restrict__ ent_off, const int* __restrict__ ent_type,
                                                    const float* __restrict__ ent_val, int n_nodes,
-                                                   float* __restrict__ rt, _Float16* __restrict__ rthl, float eps) {
+                                                   _Float16* __restrict__ rtA, _Float16* __restrict__ rtT, float eps) {
   __shared__ float a[128], b[128], accum[128];
   const int node = blockIdx.x, tid = threadIdx.x;
   accum[tid] = 0.f;
@@ -448,11 +498,26 @@ __global__ __launch_bounds__(128) void k_cond_edges(CondW w, const int* __restri
   const float pe = (tid & 1) ? cosf(0.f) : sinf(0.f);
   a[tid] = accum[tid] / (float)(e1 - e0) + pe;
   __syncthreads();
-  if (tid < 64) ln_row_wave(a, rt + (size_t)node * 128, nullptr, nullptr, eps, tid, false);
+  if (tid < 64) ln_row_wave(a, b, nullptr, nullptr, eps, tid, false);
   __syncthreads();
-  const float y = rt[(size_t)node * 128 + tid];
-  rthl[(size_t)node * 256 + tid] = f16_hi(y);
-  rthl[(size_t)node * 256 + 128 + tid] = f16_lo(y);
+  const float y = b[tid];
+  // edge `node` is the only edge of its destination: tile `node`, slot 0 of both operand images (see
+  // k_tile_transpose); every other slot of the tile is zero
+  {
+    const int ks = tid >> 5, kq = (tid >> 3) & 3, j = tid & 7;
+    _Float16* ta = rtA + (size_t)node * 8192;
+    for (int i = tid; i < 1024; i += 128) *reinterpret_cast<half8*>(ta + (size_t)i * 8) = half8{0, 0, 0, 0, 0, 0, 0, 0};
+    __syncthreads();
+    ta[(size_t)((0 * 4 + ks) * 64 + kq * 16) * 8 + j] = f16_hi(y);   // sub 0, part hi, lane (m = 0, kq)
+    ta[(size_t)((1 * 4 + ks) * 64 + kq * 16) * 8 + j] = f16_lo(y);   // sub 0, part lo
+  }
+  half8 z = {0, 0, 0, 0, 0, 0, 0, 0}, vh = z, vl = z;
+  vh[0] = f16_hi(y);
+  vl[0] = f16_lo(y);
+  half8* oh = reinterpret_cast<half8*>(rtT + (size_t)node * 8192 + tid * 32);
+  half8* ol = reinterpret_cast<half8*>(rtT + (size_t)node * 8192 + 4096 + tid * 32);
+  oh[0] = vh; oh[1] = z; oh[2] = z; oh[3] = z;
+  ol[0] = vl; ol[1] = z; ol[2] = z; ol[3] = z;
 }
 
 // fp32 rows [n][128] -> split fp16 rows [n][256] (hi | lo); used by the test hooks

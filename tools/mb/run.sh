@@ -1,0 +1,11 @@
+#!/bin/bash
+cd "$(dirname "$0")"
+for pat in 0 1 2; do
+ for mb in 4 512; do
+  for wgs in 1 256 512; do
+   for nl in 8 16 32; do
+     ./mb_gather $pat $mb $wgs $nl 64 1
+   done
+  done
+ done
+done
