@@ -55,8 +55,8 @@ struct DevBuf {
 };
 
 struct EdgeSet {  // CSR by destination + normalised rel-PE
-  DevBuf<int> cnt, eoff, toff, esrc, edst;   // toff: offsets in 32-edge tiles (sum of ceil(deg/32))
-  DevBuf<_Float16> rthl, rtA, rtT;            // rel-PE rows (hi|lo) and their two MFMA operand images (32-edge tiles)
+  DevBuf<int> cnt, eoff, toff, tdst, esrc, edst;   // toff: offsets in 32-edge tiles (sum of ceil(deg/32)); tdst: tile -> destination
+  DevBuf<_Float16> rtA, rtT;                  // rel-PE rows (split fp16) as the two MFMA operand images (32-edge tiles)
   size_t cap_edges = 0;
   int nq = 0;
   int maxdeg = 0;
@@ -453,6 +453,7 @@ extern "C" int ps_create(const ps_config* cfg, int32_t n_tensors, const char* co
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_chain<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_chain<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_chain<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_chain<4, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   *out = e;
   return PS_OK;
 }
@@ -473,7 +474,7 @@ extern "C" void ps_destroy(ps_engine* e) {
   e->d_traj.release(); e->d_vel.release(); e->d_motion.release(); e->d_reconst.release();
   e->d_kh.release(); e->d_kh_s2p.release(); e->d_kh_m2p.release(); e->d_kh_a2p.release();
   for (EdgeSet* s : {&e->e_a2a, &e->e_s2s, &e->e_p2p, &e->e_s2p, &e->e_a2p, &e->e_m2p, &e->e_cnd}) {
-    s->cnt.release(); s->eoff.release(); s->esrc.release(); s->edst.release(); s->toff.release(); s->rthl.release(); s->rtA.release(); s->rtT.release();
+    s->cnt.release(); s->eoff.release(); s->esrc.release(); s->edst.release(); s->toff.release(); s->tdst.release(); s->rtA.release(); s->rtT.release();
   }
   e->d_steps.release(); e->d_ent_off.release(); e->d_ent_type.release(); e->d_ent_val.release();
   drop_graph(e);
@@ -499,8 +500,9 @@ int edge_alloc(EdgeSet& s, int nq, size_t cap_edges, int maxdeg) {
   s.nq = nq;
   s.cap_edges = cap_edges;
   s.maxdeg = std::max(1, maxdeg);
-  if (s.cnt.ensure(nq + 1) || s.eoff.ensure(nq + 1) || s.toff.ensure(nq + 1) || s.esrc.ensure(cap_edges + 1) ||
-      s.edst.ensure(cap_edges + 1) || s.rthl.ensure((cap_edges + 1) * 256) ||
+  if (s.cnt.ensure(nq + 1) || s.eoff.ensure(nq + 1) || s.toff.ensure(nq + 1) || s.tdst.ensure(cap_edges / 32 + (size_t)nq + 1) ||
+      s.esrc.ensure(cap_edges + 1) ||
+      s.edst.ensure(cap_edges + 1) ||
       s.rtA.ensure((cap_edges / 32 + (size_t)nq + 1) * 8192) || s.rtT.ensure((cap_edges / 32 + (size_t)nq + 1) * 8192))
     return -1;
   return 0;
@@ -628,25 +630,29 @@ extern "C" int ps_set_scene(ps_engine* e, int32_t B, int32_t M, int32_t P, int32
     return fail(PS_E_HIP, "edge allocation failed");
   // closed-form CSR offsets of the knn graphs (every query gets min(k, scene size) neighbours)
   {
-    std::vector<int> off(A + 1, 0), tof(A + 1, 0);
+    std::vector<int> off(A + 1, 0), tof(A + 1, 0), tds;
     for (int i = 0; i < A; ++i) {
       const int b = e->agent_scene[i];
       const int dg = mn(c.agent_knn, e->aoff[b + 1] - e->aoff[b]);
       off[i + 1] = off[i] + dg;
       tof[i + 1] = tof[i] + (dg + 31) / 32;
+      tds.insert(tds.end(), (dg + 31) / 32, i);
     }
-    if (upload(e->e_a2a.eoff, off.data(), off.size(), st) || upload(e->e_a2a.toff, tof.data(), tof.size(), st))
+    if (upload(e->e_a2a.eoff, off.data(), off.size(), st) || upload(e->e_a2a.toff, tof.data(), tof.size(), st) ||
+        upload(e->e_a2a.tdst, tds.data(), tds.size(), st))
       return fail(PS_E_HIP, "upload failed");
     e->edge_counts[0] = (float)off[A];
-    std::vector<int> off2(Mv + A + 1, 0), tof2(Mv + A + 1, 0);
+    std::vector<int> off2(Mv + A + 1, 0), tof2(Mv + A + 1, 0), tds2;
     for (int i = 0; i < Mv + A; ++i) {
       const int b = scene[i];
       const int ns = (e->aoff[b + 1] - e->aoff[b]) + (e->moff[b + 1] - e->moff[b]);
       const int dg = mn(c.scene_knn, ns);
       off2[i + 1] = off2[i] + dg;
       tof2[i + 1] = tof2[i] + (dg + 31) / 32;
+      tds2.insert(tds2.end(), (dg + 31) / 32, i);
     }
-    if (upload(e->e_s2s.eoff, off2.data(), off2.size(), st) || upload(e->e_s2s.toff, tof2.data(), tof2.size(), st))
+    if (upload(e->e_s2s.eoff, off2.data(), off2.size(), st) || upload(e->e_s2s.toff, tof2.data(), tof2.size(), st) ||
+        upload(e->e_s2s.tdst, tds2.data(), tds2.size(), st))
       return fail(PS_E_HIP, "upload failed");
     e->edge_counts[1] = (float)off2[Mv + A];
   }
@@ -803,12 +809,11 @@ int launch_chain(ps_engine* e, float* x, int Nd, int step0, int nsteps, int maxd
                  const ChainStep* steps_override = nullptr, int force_T = 0) {
   const ChainStep* steps = steps_override ? steps_override : e->d_steps.p + step0;
   hipStream_t st = e->stream;
-  // rows per workgroup.  T >= 2 kernels are built for two workgroups per CU (<= 256 registers, <= 78 KB LDS):
-  // take the largest T that still leaves >= 2 workgroups per CU, so weights are shared by more rows AND a
-  // co-resident workgroup hides the latency.  Measured on the 1024-agent policy launch: T=2 (512 WGs) 739 us,
-  // T=4 (256 WGs, one per CU) 851 us; on the 9216-token s2s layers T=4 (2304 WGs) wins (encode 3.25 vs 3.78 ms).
+  // rows per workgroup (T).  More rows per workgroup share each weight load; the T >= 2 kernels are built for
+  // two workgroups per CU (<= 256 registers, <= 78 KB LDS) so a co-resident workgroup hides latency: take the
+  // largest T that still leaves >= 2 workgroups per CU.  Measured on the 1024-agent policy launch: T=2 (512
+  // WGs) 645 us, T=4 (256 WGs) 770 us, 4 rows on one 8-wave workgroup per CU (code 84) 733 us.
   int T = Nd >= 2048 ? 4 : (Nd >= 512 ? 2 : 1);
-  while (T > 1 && (T == 4 ? attn_lds_floats<4>(maxdeg) : attn_lds_floats<2>(maxdeg)) * sizeof(float) > 150 * 1024) T >>= 1;
   static const int env_T = getenv("PS_CHAIN_T") ? atoi(getenv("PS_CHAIN_T")) : 0;   // experiments only
   if (env_T && Nd >= 512) T = env_T;
   if (force_T) T = force_T;
@@ -825,12 +830,15 @@ int launch_chain(ps_engine* e, float* x, int Nd, int step0, int nsteps, int maxd
     prof = d_prof;
   }
   if (timed && e->time_chain) (void)hipEventRecord(e->ev0, st);
-  if (T == 4)
-    hipLaunchKernelGGL(k_attn_chain<4>, dim3((Nd + 3) / 4), dim3(WG), attn_lds_floats<4>(maxdeg) * sizeof(float), st, x, Nd, steps, nsteps, maxdeg, eps, flags, prof);
+  const size_t lds84 = attn_lds_floats<4, 8>(maxdeg) * sizeof(float);
+  if (T == 84)
+    hipLaunchKernelGGL((k_attn_chain<4, 8>), dim3((Nd + 3) / 4), dim3(512), lds84, st, x, Nd, steps, nsteps, maxdeg, eps, flags, prof);
+  else if (T == 4)
+    hipLaunchKernelGGL((k_attn_chain<4, 4>), dim3((Nd + 3) / 4), dim3(WG), attn_lds_floats<4>(maxdeg) * sizeof(float), st, x, Nd, steps, nsteps, maxdeg, eps, flags, prof);
   else if (T == 2)
-    hipLaunchKernelGGL(k_attn_chain<2>, dim3((Nd + 1) / 2), dim3(WG), attn_lds_floats<2>(maxdeg) * sizeof(float), st, x, Nd, steps, nsteps, maxdeg, eps, flags, prof);
+    hipLaunchKernelGGL((k_attn_chain<2, 4>), dim3((Nd + 1) / 2), dim3(WG), attn_lds_floats<2>(maxdeg) * sizeof(float), st, x, Nd, steps, nsteps, maxdeg, eps, flags, prof);
   else
-    hipLaunchKernelGGL(k_attn_chain<1>, dim3(Nd), dim3(WG), attn_lds_floats<1>(maxdeg) * sizeof(float), st, x, Nd, steps, nsteps, maxdeg, eps, flags, prof);
+    hipLaunchKernelGGL((k_attn_chain<1, 4>), dim3(Nd), dim3(WG), attn_lds_floats<1>(maxdeg) * sizeof(float), st, x, Nd, steps, nsteps, maxdeg, eps, flags, prof);
   if (timed && e->time_chain) {
     (void)hipEventRecord(e->ev1, st);
     (void)hipEventSynchronize(e->ev1);
@@ -839,7 +847,7 @@ int launch_chain(ps_engine* e, float* x, int Nd, int step0, int nsteps, int maxd
     if (prof) {
       unsigned long long h[16];
       (void)hipMemcpy(h, prof, sizeof(h), hipMemcpyDeviceToHost);
-      const int nwg = (Nd + T - 1) / T;
+      const int Tr = T == 84 ? 4 : T, nwg = (Nd + Tr - 1) / Tr;
       double tot = 0;
       for (int i = 0; i < 14; ++i) tot += (double)h[i];
       fprintf(stderr, "[chain prof] T=%d wgs=%d %.1f us; mean cycles per workgroup per phase (share):", T, nwg, ms * 1e3);
@@ -876,11 +884,12 @@ void launch_pointnet(ps_engine* e, const PointNetW& w, const float* pts, const u
     hipLaunchKernelGGL(k_pointnet<32>, dim3(n_rows), dim3(128), 0, e->stream, w, pts, mask, rows, n_rows, P, feat_mask_dim, out, eps);
 }
 
-// edge-minor tile image of an edge set's rel-PE rows (device-side tile count, grid-stride)
-void launch_tiles(EdgeSet& es, hipStream_t st) {
-  const int grid = (int)std::min<size_t>(2048, es.cap_edges / 32 + (size_t)es.nq + 1);
-  hipLaunchKernelGGL(k_tile_transpose, dim3(grid), dim3(256), 0, st, (const int*)es.eoff.p, (const int*)es.toff.p, es.nq,
-                     (const _Float16*)es.rthl.p, es.rtA.p, es.rtT.p);
+// rel-PE of an edge set as the two MFMA operand images (device-side tile count, grid-stride over tiles)
+void launch_relpe(ps_engine* e, EdgeSet& es, const float* src_ori, const float* dst_pos, const float* dst_ori) {
+  const int grid = (int)std::min<size_t>(4096, es.cap_edges / 32 + (size_t)es.nq + 1);
+  hipLaunchKernelGGL(k_relpe_tiles, dim3(grid), dim3(256), 0, e->stream, (const int*)es.esrc.p, (const int*)es.eoff.p,
+                     (const int*)es.toff.p, (const int*)es.tdst.p, es.nq, (const float*)e->d_tok_pos.p, src_ori, dst_pos, dst_ori, e->div32, es.rtA.p,
+                     es.rtT.p, e->cfg.ln_eps);
 }
 
 // radius search + CSR + rel-PE for one edge set
@@ -891,17 +900,13 @@ void launch_radius(ps_engine* e, EdgeSet& es, const int* r1, const int* r2, cons
   const int wpb = 4, grid = (nq + wpb - 1) / wpb;
   hipStream_t st = e->stream;
   hipLaunchKernelGGL(k_radius<0>, dim3(grid), dim3(64 * wpb), 0, st, cs, qpos, qscene, nq, r2f, cap, self_base, es.cnt.p,
-                     (const int*)nullptr, (int*)nullptr, (int*)nullptr);
+                     (const int*)nullptr, (int*)nullptr, (int*)nullptr, (const int*)nullptr, (int*)nullptr);
   if (self_base >= 0)
     hipLaunchKernelGGL(k_radius_selfrank, dim3(grid), dim3(64 * wpb), 0, st, cs, qpos, qscene, nq, r2f, cap, self_base, es.cnt.p);
   hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, st, (const int*)es.cnt.p, nq, es.eoff.p, es.toff.p);
   hipLaunchKernelGGL(k_radius<1>, dim3(grid), dim3(64 * wpb), 0, st, cs, qpos, qscene, nq, r2f, cap, self_base, (int*)nullptr,
-                     (const int*)es.eoff.p, es.esrc.p, es.edst.p);
-  const int pe_grid = (int)std::min<size_t>(4096, (es.cap_edges + 3) / 4 + 1);
-  hipLaunchKernelGGL(k_relpe, dim3(pe_grid), dim3(256), 0, st, (const int*)es.esrc.p, (const int*)es.edst.p,
-                     (const int*)(es.eoff.p + nq), 0, (const float*)e->d_tok_pos.p, src_ori, qpos, dst_ori, e->div32,
-                     (const float*)nullptr, es.rthl.p, e->cfg.ln_eps);
-  launch_tiles(es, st);
+                     (const int*)es.eoff.p, es.esrc.p, es.edst.p, (const int*)es.toff.p, es.tdst.p);
+  launch_relpe(e, es, src_ori, qpos, dst_ori);
 }
 
 }  // namespace
@@ -927,16 +932,8 @@ extern "C" int ps_encode_scene(ps_engine* e) {
     hipLaunchKernelGGL(k_knn, dim3((Mv + A + 3) / 4), dim3(256), 0, st, csn, (const float*)e->d_tok_pos.p,
                        (const int*)e->d_tok_scene.p, Mv + A, c.scene_knn, (const int*)e->e_s2s.eoff.p, e->e_s2s.esrc.p, e->e_s2s.edst.p);
     // a2a edges index agents globally (Mv + i) for positions; kv rows are agent-local -> fixed up below
-    hipLaunchKernelGGL(k_relpe, dim3(1024), dim3(256), 0, st, (const int*)e->e_a2a.esrc.p, (const int*)e->e_a2a.edst.p,
-                       (const int*)nullptr, (int)e->edge_counts[0], (const float*)e->d_tok_pos.p, (const float*)e->d_tok_ori.p,
-                       (const float*)(e->d_tok_pos.p + 2 * (size_t)Mv), (const float*)(e->d_tok_ori.p + Mv), e->div32,
-                       (const float*)nullptr, e->e_a2a.rthl.p, c.ln_eps);
-    launch_tiles(e->e_a2a, st);
-    hipLaunchKernelGGL(k_relpe, dim3(2048), dim3(256), 0, st, (const int*)e->e_s2s.esrc.p, (const int*)e->e_s2s.edst.p,
-                       (const int*)nullptr, (int)e->edge_counts[1], (const float*)e->d_tok_pos.p, (const float*)e->d_tok_ori.p,
-                       (const float*)e->d_tok_pos.p, (const float*)e->d_tok_ori.p, e->div32, (const float*)nullptr,
-                       e->e_s2s.rthl.p, c.ln_eps);
-    launch_tiles(e->e_s2s, st);
+    launch_relpe(e, e->e_a2a, e->d_tok_ori.p, e->d_tok_pos.p + 2 * (size_t)Mv, e->d_tok_ori.p + Mv);
+    launch_relpe(e, e->e_s2s, e->d_tok_ori.p, e->d_tok_pos.p, e->d_tok_ori.p);
   }
   // 6 x (a2a on the agent rows in place, s2s on all rows)  (attn_fusion.py:117-119).  kv is indexed by
   // GLOBAL token row for both (the a2a projection fills rows Mv.. of the shared kv buffer).
@@ -1346,11 +1343,25 @@ extern "C" int64_t ps_test_get_edges(ps_engine* e, int32_t which, int32_t* esrc,
   if (hipMemcpy(esrc, s.esrc.p, sizeof(int) * E, hipMemcpyDeviceToHost) != hipSuccess ||
       hipMemcpy(edst, s.edst.p, sizeof(int) * E, hipMemcpyDeviceToHost) != hipSuccess)
     return fail(PS_E_HIP, "memcpy");
-  if (rt) {   // the engine keeps the rows as split fp16 only: hi + lo restores them to ~2^-22
-    std::vector<_Float16> hl((size_t)E * 256);
-    if (hipMemcpy(hl.data(), s.rthl.p, sizeof(_Float16) * hl.size(), hipMemcpyDeviceToHost) != hipSuccess) return fail(PS_E_HIP, "memcpy");
-    for (size_t i = 0; i < (size_t)E; ++i)
-      for (int c = 0; c < 128; ++c) rt[i * 128 + c] = (float)hl[i * 256 + c] + (float)hl[i * 256 + 128 + c];
+  if (rt) {   // the engine keeps the rows as split-fp16 operand images only: hi + lo restores them to ~2^-22
+    std::vector<int> eo((size_t)s.nq + 1), to((size_t)s.nq + 1);
+    if (hipMemcpy(eo.data(), s.eoff.p, sizeof(int) * eo.size(), hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(to.data(), s.toff.p, sizeof(int) * to.size(), hipMemcpyDeviceToHost) != hipSuccess)
+      return fail(PS_E_HIP, "memcpy");
+    std::vector<_Float16> img((size_t)to[s.nq] * 8192);
+    if (!img.empty() && hipMemcpy(img.data(), s.rtA.p, sizeof(_Float16) * img.size(), hipMemcpyDeviceToHost) != hipSuccess)
+      return fail(PS_E_HIP, "memcpy");
+    for (int d = 0; d < s.nq; ++d)
+      for (int i = 0; i < eo[d + 1] - eo[d]; ++i) {
+        const size_t tile = (size_t)to[d] + i / 32;
+        const int sub = (i % 32) / 16, m = i % 16;
+        for (int c = 0; c < 128; ++c) {
+          const int ks = c / 32, kq = (c % 32) / 8, j = c % 8;
+          const size_t hi_ = tile * 8192 + (size_t)((sub * 2 + 0) * 4 + ks) * 512 + (kq * 16 + m) * 8 + j;
+          const size_t lo_ = tile * 8192 + (size_t)((sub * 2 + 1) * 4 + ks) * 512 + (kq * 16 + m) * 8 + j;
+          rt[(size_t)(eo[d] + i) * 128 + c] = (float)img[hi_] + (float)img[lo_];
+        }
+      }
   }
   return E;
 }
@@ -1496,7 +1507,7 @@ extern "C" int ps_policy_forward(ps_engine* e, int32_t n_scenes, int32_t Na, con
   for (DevBuf<float>* b : {&d_pos, &d_ori, &d_atok, &d_mtok, &d_ppos, &d_pori, &d_x, &d_kva, &d_kvm, &d_motion, &d_traj, &d_vel}) b->release();
   for (DevBuf<int>* b : {&d_rmap, &d_ragent, &d_pscene, &d_ptype}) b->release();
   d_kha.release(); d_khm.release();
-  for (EdgeSet* s_ : {&ea, &em}) { s_->cnt.release(); s_->eoff.release(); s_->esrc.release(); s_->edst.release(); s_->toff.release(); s_->rthl.release(); s_->rtA.release(); s_->rtT.release(); }
+  for (EdgeSet* s_ : {&ea, &em}) { s_->cnt.release(); s_->eoff.release(); s_->esrc.release(); s_->edst.release(); s_->toff.release(); s_->tdst.release(); s_->rtA.release(); s_->rtT.release(); }
   d_steps.release();
   return rc;
 }

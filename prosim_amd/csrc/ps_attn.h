@@ -56,11 +56,11 @@ struct ChainStep {
 // The chunk is 256 edges (128 at T = 4, so that two 4-row workgroups fit the 160 KB of a CU).
 template <int T>
 __host__ __device__ constexpr int chunk_edges() { return T >= 4 ? 128 : 256; }
-// LDS plan (floats): rows 6*128*T + 512*T | big 4*8*QP (q~ image, then per-wave partial a_r)
-// | sc 8*CH*T scores | avp 4*128 | ml 4*16 | cq 8*T | sp 2*SP_SIZE | esl CH*T (source rows of the chunk)
-template <int T>
+// LDS plan (floats), NW = waves per workgroup: rows 6*128*T + 512*T | big NW*8*QP (q~ image, then per-wave
+// partial a_r) | sc 8*CH*T scores | avp NW*128 | ml NW*16 | cq 8*T | sp 2*SP_SIZE | esl CH*T (source rows of the chunk)
+template <int T, int NW = 4>
 __host__ __device__ constexpr size_t attn_lds_floats(int /*maxdeg*/) {
-  return (size_t)(6 * 128 + 512) * T + 4 * 8 * QP + (size_t)8 * chunk_edges<T>() * T + 4 * 128 + 4 * 16 + 8 * T + 64 +
+  return (size_t)(6 * 128 + 512) * T + NW * 8 * QP + (size_t)8 * chunk_edges<T>() * T + NW * 128 + NW * 16 + 8 * T + 64 +
          2 * SP_SIZE + (size_t)chunk_edges<T>() * T;
 }
 
@@ -93,26 +93,28 @@ __device__ __forceinline__ float reduce8_to_lane(const float (&a)[8], int cc) {
 //    vmcnt lets the older set complete while the newer flies).
 //  * Every GEMV is WAVE-LOCAL: a wave owns a block of output columns and all of K, its lanes split
 //    K, and the partial sums meet by shuffles -- no LDS partial buffer, one barrier per stage.
+template <int R>   // R weight rows x 4 columns per lane: 16 with 4 waves per workgroup, 8 with 8
 struct WC {
-  float4 w[16];
+  float4 w[R];
 };
-__device__ __forceinline__ void wload(WC& c, const float* __restrict__ p, int N) {
+template <int R>
+__device__ __forceinline__ void wload(WC<R>& c, const float* __restrict__ p, int N) {
 #pragma unroll
-  for (int i = 0; i < 16; ++i) c.w[i] = ldg4(p + (size_t)i * N);
+  for (int i = 0; i < R; ++i) c.w[i] = ldg4(p + (size_t)i * N);
 }
-template <int T>
-__device__ __forceinline__ void wfma(const WC& c, const float* x, int xs, float (&acc)[T][4]) {
-  // row-outer: 16 x-values (4 x ds_read_b128) live at a time, not 16*T
+template <int T, int R>
+__device__ __forceinline__ void wfma(const WC<R>& c, const float* x, int xs, float (&acc)[T][4]) {
+  // row-outer: R x-values (ds_read_b128s) live at a time, not R*T
 #pragma unroll
   for (int t = 0; t < T; ++t) {
-    float xv[16];
+    float xv[R];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < R / 4; ++i) {
       const float4 v = *reinterpret_cast<const float4*>(x + t * xs + 4 * i);
       xv[4 * i] = v.x; xv[4 * i + 1] = v.y; xv[4 * i + 2] = v.z; xv[4 * i + 3] = v.w;
     }
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
+    for (int i = 0; i < R; ++i) {
       acc[t][0] = fmaf(xv[i], c.w[i].x, acc[t][0]);
       acc[t][1] = fmaf(xv[i], c.w[i].y, acc[t][1]);
       acc[t][2] = fmaf(xv[i], c.w[i].z, acc[t][2]);
@@ -144,11 +146,16 @@ __device__ __forceinline__ void fold_kgroups(float (&acc)[T][4]) {
   do {                                                    \
     if (PF) wload(NXT, NXTP, NXTN);                       \
     else wload(CUR, CURP, CURN);                          \
-    wfma<T>(CUR, X, XS, acc);                             \
+    wfma<T, RK>(CUR, X, XS, acc);                         \
   } while (0)
 
-template <int T>
-__global__ __launch_bounds__(WG, (T >= 2 ? 2 : 1)) void k_attn_chain(float* __restrict__ x, int Nd, const ChainStep* __restrict__ steps,
+// NW waves per workgroup.  NW = 8 (T = 4) is ONE 512-thread workgroup per CU instead of two 256-thread ones:
+// the same 8 waves and registers, and a layer's weights cross the CU's L1 once for 4 rows instead of twice for
+// 2 + 2.  Measured on the 1024-row policy launch it is SLOWER (733 vs 645 us): the node phase is bound by the
+// per-stage load->fma->fold->barrier latency chain, not by L1 bytes, and 8-wave barriers cost more.  Kept as
+// the experiment variant PS_CHAIN_T=84 (parity-tested), not selected by launch_chain.
+template <int T, int NW = 4>
+__global__ __launch_bounds__(64 * NW, ((T >= 2 && NW == 4) ? 2 : 1)) void k_attn_chain(float* __restrict__ x, int Nd, const ChainStep* __restrict__ steps,
                                                      int nsteps, int maxdeg, float eps, int flags,
                                                      unsigned long long* __restrict__ prof) {
   // phase clocks for tools/gpu_phase.py (prof == nullptr in every product launch): thread 0 of each
@@ -162,7 +169,13 @@ __global__ __launch_bounds__(WG, (T >= 2 ? 2 : 1)) void k_attn_chain(float* __re
       tprev = now_;                                                       \
     }                                                                     \
   } while (0)
-  constexpr int W = 4 / T;  // waves per destination in the edge phase
+  constexpr int NT = 64 * NW;   // threads
+  constexpr int W = NW / T;     // waves per destination in the edge phase
+  // N = 128 GEMVs: wave -> CW output columns; lane -> (LQ column quads) x (KG k-groups of RK weight rows)
+  constexpr int CW = 128 / NW, LQ = CW / 4, KG = 64 / LQ, RK = 128 / KG;
+  // N = 512 (FFN up): wave -> 512/NW columns; lane -> (L5 column quads) x (64/L5 k-groups of 4*RK rows)
+  constexpr int L5 = 128 / NW;
+  static_assert(KG * RK == 128 && (64 / L5) * 4 * RK == 128, "GEMV tiling");
   constexpr int CH = chunk_edges<T>();
   if ((flags >> 8) && blockIdx.x >= gridDim.x / 2) {   // experiment: de-phase the two workgroups of a CU
     const long long t0 = clock64(), dl = (long long)(flags >> 8) << 10;
@@ -171,7 +184,8 @@ __global__ __launch_bounds__(WG, (T >= 2 ? 2 : 1)) void k_attn_chain(float* __re
   // T == 1: one workgroup per CU with the full register file -> software prefetch (weights one chunk ahead,
   // edge rows one tile ahead).  T >= 2: compiled for 2 workgroups per CU (__launch_bounds__(256, 2), <= 256
   // registers): the co-resident workgroup hides the latency instead and nothing is double-buffered.
-  constexpr bool PF = (T == 1);
+  constexpr bool PF = (T == 1);                // weight chunks one stage ahead (second register set; spills at T >= 2)
+  constexpr bool PFE = (T == 1);               // edge rows one tile ahead
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* xs = smem;                 // [T][128] residual stream
   float* xn = xs + 128 * T;         // [T][128] normed / scratch row
@@ -180,47 +194,46 @@ __global__ __launch_bounds__(WG, (T >= 2 ? 2 : 1)) void k_attn_chain(float* __re
   float* gb = sb + 128 * T;         // [T][128] to_g's x_dst half (+bias)
   float* ag = gb + 128 * T;         // [T][128] aggregated message, then the gated update u
   float* f1 = ag + 128 * T;         // [T][512]
-  float* big = f1 + 512 * T;        // [4][8][QP]
-  float* un = big + 4 * 8 * QP;     // [T][CH][8] score tile
-  float* avp = un + (size_t)8 * CH * T;  // [4][128]
-  float* ml = avp + 4 * 128;        // [4][16]: per wave (max[8] | sum[8])
-  float* cq = ml + 4 * 16;          // [T][8]
+  float* big = f1 + 512 * T;        // [NW][8][QP]
+  float* un = big + NW * 8 * QP;    // [T][CH][8] score tile
+  float* avp = un + (size_t)8 * CH * T;  // [NW][128]
+  float* ml = avp + NW * 128;       // [NW][16]: per wave (max[8] | sum[8])
+  float* cq = ml + NW * 16;         // [T][8]
   float* spb = cq + 8 * T + 56;     // [2][SP_SIZE] small per-layer vectors, double-buffered
   int* esl = reinterpret_cast<int*>(spb + 2 * SP_SIZE);  // [T][CH] source rows of the current chunk of each edge list
 
   const int tid_o = threadIdx.x, wave_o = tid_o >> 6, lane_o = tid_o & 63;
-  // N = 128 GEMVs: wave -> 32 output columns; lane -> (c8: 4 columns, kgl: 16-row k-group)
-  const int c8_o = lane_o & 7, kgl_o = lane_o >> 3;
-  const int ncol_o = wave_o * 32 + 4 * c8_o;
-  const size_t woff_o = (size_t)(kgl_o * 16) * 128 + ncol_o;
-  // N = 512 (FFN up): wave -> 128 columns; lane -> (c32: 4 columns, k2: 64-row half)
+  const int c8_o = lane_o % LQ, kgl_o = lane_o / LQ;
+  const int ncol_o = wave_o * CW + 4 * c8_o;
+  const size_t woff_o = (size_t)(kgl_o * RK) * 128 + ncol_o;
   const int row0 = blockIdx.x * T;
   // two register sets, one chunk in flight behind the one being multiplied.  (Three sets / two
   // chunks in flight measured no faster -- a CU's 4 waves already pull ~100 GB/s, the per-CU
   // L2->register ceiling measured by ps_test_stream -- and spill at T = 4.)
-  WC wA, wB;
+  WC<RK> wA, wB;
   if (PF) wload(wA, steps[0].w.Wq_t + woff_o, 128);
-  // small vectors of layer 0 -> LDS buffer 0 (608 float4: threads take float4 tid, tid+256, tid+512)
-  float4 spr[3];
+  // small vectors of layer 0 -> LDS buffer 0 (608 float4: threads take float4 tid, tid+NT, ...)
+  constexpr int NSP = (SP_SIZE / 4 + NT - 1) / NT;
+  float4 spr[NSP];
   auto sp_load = [&](const float* __restrict__ sp) {
-    spr[0] = ldg4(sp + 4 * tid_o);
-    spr[1] = ldg4(sp + 4 * (tid_o + 256));
-    if (tid_o + 512 < SP_SIZE / 4) spr[2] = ldg4(sp + 4 * (tid_o + 512));
+#pragma unroll
+    for (int i = 0; i < NSP; ++i)
+      if (tid_o + i * NT < SP_SIZE / 4) spr[i] = ldg4(sp + 4 * (tid_o + i * NT));
   };
   auto sp_store = [&](float* dst) {
-    *reinterpret_cast<float4*>(dst + 4 * tid_o) = spr[0];
-    *reinterpret_cast<float4*>(dst + 4 * (tid_o + 256)) = spr[1];
-    if (tid_o + 512 < SP_SIZE / 4) *reinterpret_cast<float4*>(dst + 4 * (tid_o + 512)) = spr[2];
+#pragma unroll
+    for (int i = 0; i < NSP; ++i)
+      if (tid_o + i * NT < SP_SIZE / 4) *reinterpret_cast<float4*>(dst + 4 * (tid_o + i * NT)) = spr[i];
   };
   sp_load(steps[0].w.sp);
   // load the T residual rows (rows past Nd are zero-filled and never stored)
-  for (int i = tid_o; i < T * 128; i += WG) {
+  for (int i = tid_o; i < T * 128; i += NT) {
     const int t = i >> 7, r = row0 + t;
     xs[i] = (r < Nd) ? ldg1(x + (size_t)r * 128 + (i & 127)) : 0.f;
   }
   sp_store(spb);
   __syncthreads();
-  ln_rows<T>(xs, 128, xn, 128, spb + SP_LN_DST_W, spb + SP_LN_DST_B, eps, false);
+  for (int tt = wave_o; tt < T; tt += NW) ln_row_wave(xs + tt * 128, xn + tt * 128, spb + SP_LN_DST_W, spb + SP_LN_DST_B, eps, lane_o, false);
   __syncthreads();
 
   for (int s = 0; s < nsteps; ++s) {
@@ -232,11 +245,12 @@ __global__ __launch_bounds__(WG, (T >= 2 ? 2 : 1)) void k_attn_chain(float* __re
     asm volatile("" : "+v"(tid_v));
     const int tid = tid_v, lane = tid_v & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid_v >> 6);   // wave-uniform: pointer math on the SALU
-    const int c8 = lane & 7, kgl = lane >> 3;
-    const int ncol = wave * 32 + 4 * c8;
-    const size_t woff = (size_t)(kgl * 16) * 128 + ncol;
-    const int c32 = lane & 31, k2 = lane >> 5;
-    const int ncol5 = wave * 128 + 4 * c32;
+    const int c8 = lane % LQ, kgl = lane / LQ;
+    const int ncol = wave * CW + 4 * c8;
+    const size_t woff = (size_t)(kgl * RK) * 128 + ncol;
+    const int c32 = lane & 31, k2 = lane >> 5;                 // q~ stage: 4 columns x (head | K half)
+    const int c5 = lane % L5, k5 = lane / L5;                  // FFN up: 4 columns x k-group
+    const int ncol5 = wave * (512 / NW) + 4 * c5;
     const float* sp = spb + (s & 1) * SP_SIZE;          // this layer's small vectors (LDS)
     float* sp_next = spb + ((s + 1) & 1) * SP_SIZE;     // filled mid-layer for the next one
     if (s + 1 < nsteps) sp_load(steps[s + 1].w.sp);
@@ -251,8 +265,8 @@ __global__ __launch_bounds__(WG, (T >= 2 ? 2 : 1)) void k_attn_chain(float* __re
     {
       float acc[T][4];
       zero_acc<T>(acc);
-      PS_STAGE(wA, w.Wq_t + woff, 128, wB, w.Ws_t + woff, 128, xn + kgl * 16, 128);    // Wq
-      fold_kgroups<T, 8>(acc);
+      PS_STAGE(wA, w.Wq_t + woff, 128, wB, w.Ws_t + woff, 128, xn + kgl * RK, 128);    // Wq
+      fold_kgroups<T, LQ>(acc);
       if (kgl == 0) {
 #pragma unroll
         for (int tt = 0; tt < T; ++tt)
@@ -261,8 +275,8 @@ __global__ __launch_bounds__(WG, (T >= 2 ? 2 : 1)) void k_attn_chain(float* __re
                           acc[tt][3] + sp[SP_BQ + ncol + 3]);
       }
       zero_acc<T>(acc);
-      PS_STAGE(wB, w.Ws_t + woff, 128, wA, w.Wgx_t + woff, 128, xn + kgl * 16, 128);   // Ws
-      fold_kgroups<T, 8>(acc);
+      PS_STAGE(wB, w.Ws_t + woff, 128, wA, w.Wgx_t + woff, 128, xn + kgl * RK, 128);   // Ws
+      fold_kgroups<T, LQ>(acc);
       if (kgl == 0) {
 #pragma unroll
         for (int tt = 0; tt < T; ++tt)
@@ -271,9 +285,11 @@ __global__ __launch_bounds__(WG, (T >= 2 ? 2 : 1)) void k_attn_chain(float* __re
                           acc[tt][3] + sp[SP_BS + ncol + 3]);
       }
       zero_acc<T>(acc);
-      // q~ chunk: wave -> heads 2*wave, 2*wave+1; lane -> (k2 = lane >> 5, 4 columns c32); rows 16*head..
-      PS_STAGE(wA, w.Wgx_t + woff, 128, wB, w.Wkr_g + (size_t)((2 * wave + k2) * 16) * 128 + 4 * c32, 128, xn + kgl * 16, 128);   // Wgx
-      fold_kgroups<T, 8>(acc);
+      // q~ chunk: NW = 4: wave -> heads 2*wave + k2, all 16 rows of the head; NW = 8: wave -> head `wave`,
+      // k2 -> its 8-row half.  lane & 31 -> 4 columns.
+      const float* wkr = w.Wkr_g + (size_t)(NW == 4 ? (2 * wave + k2) * 16 : wave * 16 + 8 * k2) * 128 + 4 * c32;
+      PS_STAGE(wA, w.Wgx_t + woff, 128, wB, wkr, 128, xn + kgl * RK, 128);   // Wgx
+      fold_kgroups<T, LQ>(acc);
       if (kgl == 0) {
 #pragma unroll
         for (int tt = 0; tt < T; ++tt)
@@ -286,15 +302,19 @@ __global__ __launch_bounds__(WG, (T >= 2 ? 2 : 1)) void k_attn_chain(float* __re
     PS_MARK(0);
     // ---- q~[t][h][c] = sum_d q[t][16h+d] * Wkr_g[16h+d][c];  cq[t][h] = <q_h, kb_h>
     {
-      const int h = 2 * wave + k2;
+      const int h = NW == 4 ? 2 * wave + k2 : wave;
+      const int hr = NW == 4 ? h * 16 : h * 16 + 8 * k2;   // first of this lane's RK rows of Wkr_g / elements of q_h
       float acc[T][4];
       zero_acc<T>(acc);
-      if (!PF) wload(wB, w.Wkr_g + (size_t)(h * 16) * 128 + 4 * c32, 128);
-      wfma<T>(wB, qb + h * 16, 128, acc);                                               // Wkr_g
+      if (!PF) wload(wB, w.Wkr_g + (size_t)hr * 128 + 4 * c32, 128);
+      wfma<T, RK>(wB, qb + hr, 128, acc);                                               // Wkr_g
+      if (NW == 8) fold_kgroups<T, 32>(acc);
+      if (NW == 4 || k2 == 0) {
 #pragma unroll
-      for (int tt = 0; tt < T; ++tt)
-        *reinterpret_cast<float4*>(big + (size_t)(tt * 8 + h) * QP + 4 * c32) =
-            make_float4(acc[tt][0], acc[tt][1], acc[tt][2], acc[tt][3]);
+        for (int tt = 0; tt < T; ++tt)
+          *reinterpret_cast<float4*>(big + (size_t)(tt * 8 + h) * QP + 4 * c32) =
+              make_float4(acc[tt][0], acc[tt][1], acc[tt][2], acc[tt][3]);
+      }
       if (tid < 8 * T) {
         const int tt = tid >> 3, hh = tid & 7;
         float a = 0.f;
@@ -385,9 +405,9 @@ __global__ __launch_bounds__(WG, (T >= 2 ? 2 : 1)) void k_attn_chain(float* __re
               nkl[ks] = ldgh8(kp + 128 + 32 * ks);
             }
           };
-          if (PF && wi * 16 < cn && !(flags & 16)) gather1(wi * 16);
+          if (PFE && wi * 16 < cn && !(flags & 16)) gather1(wi * 16);
           for (int eb = wi * 16; eb < cn && !(flags & 16); eb += 16 * W) {
-            if (!PF) gather1(eb);   // two workgroups per CU hide the latency instead of a second register set
+            if (!PFE) gather1(eb);   // two workgroups per CU hide the latency instead of a second register set
             // all 16 row loads are in flight before anything waits (left alone, the scheduler sinks each load
             // next to its use: one round trip per MFMA)
             __builtin_amdgcn_sched_barrier(0);
@@ -402,7 +422,7 @@ __global__ __launch_bounds__(WG, (T >= 2 ? 2 : 1)) void k_attn_chain(float* __re
             for (int ks = 0; ks < 4; ++ks) stw[4 * ks] = nkl[ks];
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) akl[ks] = str[4 * ks];
-            if (PF && eb + 16 * W < cn) gather1(eb + 16 * W);   // the next tile's rows fly under this tile's MFMAs
+            if (PFE && eb + 16 * W < cn) gather1(eb + 16 * W);   // the next tile's rows fly under this tile's MFMAs
             floatx4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
@@ -514,13 +534,13 @@ __global__ __launch_bounds__(WG, (T >= 2 ? 2 : 1)) void k_attn_chain(float* __re
             vvn[j] = ldg2(vbase + (size_t)el[ee] * 256);
           }
         };
-        if (PF && wi * 8 < cn) gather2(wi * 8);
+        if (PFE && wi * 8 < cn) gather2(wi * 8);
         for (int eb = wi * 8; eb < cn && !(flags & 8); eb += 8 * W) {
-          if (!PF) gather2(eb);
+          if (!PFE) gather2(eb);
           float2 vv[8];
 #pragma unroll
           for (int j = 0; j < 8; ++j) vv[j] = vvn[j];
-          if (PF && eb + 8 * W < cn) gather2(eb + 8 * W);
+          if (PFE && eb + 8 * W < cn) gather2(eb + 8 * W);
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             const float ph = (eb + j < cn) ? sc[(size_t)(eb + j) * 8 + hl] : 0.f;
@@ -555,13 +575,13 @@ __global__ __launch_bounds__(WG, (T >= 2 ? 2 : 1)) void k_attn_chain(float* __re
     __syncthreads();
     PS_MARK(9);
     if (W > 1) {  // sum the W sub-wave partials of each destination into its first slot
-      for (int i = tid; i < T * 8 * 128; i += WG) {
+      for (int i = tid; i < T * 8 * 128; i += NT) {
         const int tt = i / 1024, hc = i % 1024, h = hc >> 7, c = hc & 127;
         float a = 0.f;
         for (int j = 0; j < W; ++j) a += big[(size_t)((tt * W + j) * 8 + h) * QP + c];
         big[(size_t)((tt * W) * 8 + h) * QP + c] = a;
       }
-      for (int i = tid; i < T * 128; i += WG) {
+      for (int i = tid; i < T * 128; i += NT) {
         const int tt = i >> 7, c = i & 127;
         float a = 0.f;
         for (int j = 0; j < W; ++j) a += avp[(tt * W + j) * 128 + c];
@@ -571,14 +591,14 @@ __global__ __launch_bounds__(WG, (T >= 2 ? 2 : 1)) void k_attn_chain(float* __re
     }
     PS_MARK(10);
     // ---- agg = (a_v + Wvr_g^T a_r + l * vb) / (l + 1e-16)   (to_v_r fold; :89, :100)
-    //      columns ncol.. belong to head ncol/16 = 2*wave + (c8 >> 2)
+    //      columns ncol.. belong to head ncol/16
     {
       float acc[T][4];
       zero_acc<T>(acc);
-      PS_STAGE(wA, w.Wvr_gt + woff, 128, wB, w.Wga_t + woff, 128, big + (size_t)(2 * wave + (c8 >> 2)) * QP + kgl * 16, W * 8 * QP);   // Wvr
-      fold_kgroups<T, 8>(acc);
+      PS_STAGE(wA, w.Wvr_gt + woff, 128, wB, w.Wga_t + woff, 128, big + (size_t)(ncol >> 4) * QP + kgl * RK, W * 8 * QP);   // Wvr
+      fold_kgroups<T, LQ>(acc);
       if (kgl == 0) {
-        const int h = 2 * wave + (c8 >> 2);
+        const int h = ncol >> 4;
 #pragma unroll
         for (int tt = 0; tt < T; ++tt) {
           float l = 0.f;
@@ -597,8 +617,8 @@ __global__ __launch_bounds__(WG, (T >= 2 ? 2 : 1)) void k_attn_chain(float* __re
     {
       float acc[T][4];
       zero_acc<T>(acc);
-      PS_STAGE(wB, w.Wga_t + woff, 128, wA, w.Wout_t + woff, 128, ag + kgl * 16, 128);   // Wga
-      fold_kgroups<T, 8>(acc);
+      PS_STAGE(wB, w.Wga_t + woff, 128, wA, w.Wout_t + woff, 128, ag + kgl * RK, 128);   // Wga
+      fold_kgroups<T, LQ>(acc);
       if (kgl == 0) {
 #pragma unroll
         for (int tt = 0; tt < T; ++tt) {
@@ -620,8 +640,8 @@ __global__ __launch_bounds__(WG, (T >= 2 ? 2 : 1)) void k_attn_chain(float* __re
     {
       float acc[T][4];
       zero_acc<T>(acc);
-      PS_STAGE(wA, w.Wout_t + woff, 128, wB, w.W1_t + (size_t)(k2 * 64) * 512 + ncol5, 512, f1 + kgl * 16, 128);   // Wout
-      fold_kgroups<T, 8>(acc);
+      PS_STAGE(wA, w.Wout_t + woff, 128, wB, w.W1_t + (size_t)(k5 * 4 * RK) * 512 + ncol5, 512, f1 + kgl * RK, 128);   // Wout
+      fold_kgroups<T, LQ>(acc);
       if (kgl == 0) {
 #pragma unroll
         for (int tt = 0; tt < T; ++tt)
@@ -631,7 +651,7 @@ __global__ __launch_bounds__(WG, (T >= 2 ? 2 : 1)) void k_attn_chain(float* __re
       }
     }
     __syncthreads();
-    for (int tt = wave; tt < T; tt += 4) {
+    for (int tt = wave; tt < T; tt += NW) {
       // one wave per row: LN_post, residual add, LN_ffpre, all in registers
       float* xr = xs + tt * 128;
       float* nr = xn + tt * 128;
@@ -643,18 +663,19 @@ __global__ __launch_bounds__(WG, (T >= 2 ? 2 : 1)) void k_attn_chain(float* __re
     }
     __syncthreads();
     PS_MARK(12);
-    // ---- FFN up: f1 = relu(W1 xn + b1)   N = 512: wave -> 128 columns, lane (c32, k2), 4 chunks of 16 rows
+    // ---- FFN up: f1 = relu(W1 xn + b1)   N = 512: wave -> 512/NW columns, lane (c5, k5), 4 chunks of RK rows
     {
       float acc[T][4];
       zero_acc<T>(acc);
-      const float* w1 = w.W1_t + (size_t)(k2 * 64) * 512 + ncol5;
-      const float* w2 = w.W2_t + (size_t)(kgl * 64) * 128 + ncol;
-      PS_STAGE(wB, w1, 512, wA, w1 + (size_t)16 * 512, 512, xn + k2 * 64, 128);
-      PS_STAGE(wA, w1 + (size_t)16 * 512, 512, wB, w1 + (size_t)32 * 512, 512, xn + k2 * 64 + 16, 128);
-      PS_STAGE(wB, w1 + (size_t)32 * 512, 512, wA, w1 + (size_t)48 * 512, 512, xn + k2 * 64 + 32, 128);
-      PS_STAGE(wA, w1 + (size_t)48 * 512, 512, wB, w2, 128, xn + k2 * 64 + 48, 128);
-      fold_kgroups<T, 32>(acc);
-      if (k2 == 0) {
+      const float* w1 = w.W1_t + (size_t)(k5 * 4 * RK) * 512 + ncol5;
+      const float* w2 = w.W2_t + (size_t)(kgl * 4 * RK) * 128 + ncol;
+      const float* xk = xn + k5 * 4 * RK;
+      PS_STAGE(wB, w1, 512, wA, w1 + (size_t)RK * 512, 512, xk, 128);
+      PS_STAGE(wA, w1 + (size_t)RK * 512, 512, wB, w1 + (size_t)2 * RK * 512, 512, xk + RK, 128);
+      PS_STAGE(wB, w1 + (size_t)2 * RK * 512, 512, wA, w1 + (size_t)3 * RK * 512, 512, xk + 2 * RK, 128);
+      PS_STAGE(wA, w1 + (size_t)3 * RK * 512, 512, wB, w2, 128, xk + 3 * RK, 128);
+      fold_kgroups<T, L5>(acc);
+      if (k5 == 0) {
 #pragma unroll
         for (int tt = 0; tt < T; ++tt)
           *reinterpret_cast<float4*>(f1 + tt * 512 + ncol5) =
@@ -663,19 +684,20 @@ __global__ __launch_bounds__(WG, (T >= 2 ? 2 : 1)) void k_attn_chain(float* __re
       }
     }
     __syncthreads();
-    // ---- FFN down: xn = W2 f1 + b2   K = 512: 4 chunks of 16 rows per k-group
+    // ---- FFN down: xn = W2 f1 + b2   K = 512: 4 chunks of RK rows per k-group
     {
       float acc[T][4];
       zero_acc<T>(acc);
-      const float* w2 = w.W2_t + (size_t)(kgl * 64) * 128 + ncol;
-      PS_STAGE(wB, w2, 128, wA, w2 + (size_t)16 * 128, 128, f1 + kgl * 64, 512);
-      PS_STAGE(wA, w2 + (size_t)16 * 128, 128, wB, w2 + (size_t)32 * 128, 128, f1 + kgl * 64 + 16, 512);
-      PS_STAGE(wB, w2 + (size_t)32 * 128, 128, wA, w2 + (size_t)48 * 128, 128, f1 + kgl * 64 + 32, 512);
-      if (!PF) wload(wA, w2 + (size_t)48 * 128, 128);
-      wfma<T>(wA, f1 + kgl * 64 + 48, 512, acc);
+      const float* w2 = w.W2_t + (size_t)(kgl * 4 * RK) * 128 + ncol;
+      const float* fk = f1 + kgl * 4 * RK;
+      PS_STAGE(wB, w2, 128, wA, w2 + (size_t)RK * 128, 128, fk, 512);
+      PS_STAGE(wA, w2 + (size_t)RK * 128, 128, wB, w2 + (size_t)2 * RK * 128, 128, fk + RK, 512);
+      PS_STAGE(wB, w2 + (size_t)2 * RK * 128, 128, wA, w2 + (size_t)3 * RK * 128, 128, fk + 2 * RK, 512);
+      if (!PF) wload(wA, w2 + (size_t)3 * RK * 128, 128);
+      wfma<T, RK>(wA, fk + 3 * RK, 512, acc);
       // the next layer's first chunk leaves now; it lands during the fold and the two norms
       if (PF && s + 1 < nsteps) wload(wA, steps[s + 1].w.Wq_t + woff, 128);
-      fold_kgroups<T, 8>(acc);
+      fold_kgroups<T, LQ>(acc);
       if (kgl == 0) {
 #pragma unroll
         for (int tt = 0; tt < T; ++tt)
@@ -685,7 +707,7 @@ __global__ __launch_bounds__(WG, (T >= 2 ? 2 : 1)) void k_attn_chain(float* __re
       }
     }
     __syncthreads();
-    for (int tt = wave; tt < T; tt += 4) {
+    for (int tt = wave; tt < T; tt += NW) {
       // x = x + LN_ffpost(ffn); then the NEXT layer's pre-norm, in registers
       float* xr = xs + tt * 128;
       float* nr = xn + tt * 128;
@@ -697,7 +719,7 @@ __global__ __launch_bounds__(WG, (T >= 2 ? 2 : 1)) void k_attn_chain(float* __re
     __syncthreads();
     PS_MARK(13);
   }
-  for (int i = tid_o; i < T * 128; i += WG) {
+  for (int i = tid_o; i < T * 128; i += NT) {
     const int t = i >> 7, r = row0 + t;
     if (r < Nd) x[(size_t)r * 128 + (i & 127)] = xs[i];
   }

@@ -161,10 +161,14 @@ __device__ __forceinline__ float dist2(float ax, float ay, float bx, float by) {
 template <int MODE>
 __global__ void k_radius(CandSet cs, const float* __restrict__ qpos, const int* __restrict__ qscene, int nq, float r2,
                          int cap, int self_base, int* __restrict__ cnt, const int* __restrict__ eoff,
-                         int* __restrict__ esrc, int* __restrict__ edst) {
+                         int* __restrict__ esrc, int* __restrict__ edst, const int* __restrict__ toff, int* __restrict__ tdst) {
   const int q = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (q >= nq) return;
+  if (MODE == 1) {   // tile -> destination map of the rel-PE operand images (<= 25 tiles per destination)
+    const int t0 = toff[q], nt = toff[q + 1] - t0;
+    if (lane < nt) tdst[t0 + lane] = q;
+  }
   const float qx = qpos[2 * q], qy = qpos[2 * q + 1];
   const int b = qscene[q];
   const int capx = cap + (self_base >= 0 ? 1 : 0);
@@ -258,7 +262,8 @@ __global__ void k_exclusive_scan(const int* __restrict__ cnt, int n, int* __rest
 //      different cache lines and the texture-address unit issues it 4x slower -- tools/mb/mb_gather.)
 //  * rtT (aggregation pass, B operand: lane = column n + 16*kq holds 8 consecutive EDGES of one column):
 //      [part 2][column 128][edge 32].
-// One 256-thread workgroup per tile.
+// One 256-thread workgroup per tile.  (The engine makes both images straight from the geometry, in
+// the fused rel-PE kernel further down; this row-major -> images variant serves the ps_test_attn hook.)
 __global__ __launch_bounds__(256) void k_tile_transpose(const int* __restrict__ eoff, const int* __restrict__ toff, int nq,
                                                        const _Float16* __restrict__ rthl, _Float16* __restrict__ rtA,
                                                        _Float16* __restrict__ rtT) {
@@ -364,49 +369,80 @@ __global__ void k_knn(CandSet cs, const float* __restrict__ qpos, const int* __r
 // ------------------------------------------------------------------------------------------
 // K5  relative positional encoding of an edge (act_decoder.py:203-221 and twins) through
 // FourierEmbeddingFix(32) (fourier_embedding.py:63-78), then the affine-free LayerNorm that
-// every layer's attn_prenorm_r shares.  One wave per edge; lane l makes features l and l+64.
+// every layer's attn_prenorm_r shares.  Feature 0..31: dist, 32..63: rel_ori, 64..127: angle twice;
+// feature c uses div32[c & 31], sin for even c, cos for odd c.
 __device__ __forceinline__ float fourier_feat(float x, int slot, const float* __restrict__ div) {
   const float v = (x * PS_TWO_PI_F) / div[slot];
   return (slot & 1) ? cosf(v) : sinf(v);
 }
 
-__global__ void k_relpe(const int* __restrict__ esrc, const int* __restrict__ edst, const int* __restrict__ n_edges_ptr,
-                        int n_edges_host, const float* __restrict__ src_pos, const float* __restrict__ src_ori,
-                        const float* __restrict__ dst_pos, const float* __restrict__ dst_ori,
-                        const float* __restrict__ div32, const float* __restrict__ add /*[E][128] or null*/,
-                        _Float16* __restrict__ rthl, float eps) {
-  const int lane = threadIdx.x & 63;
-  const int wpb = blockDim.x >> 6;
-  const int E = n_edges_ptr ? *n_edges_ptr : n_edges_host;
-  for (int e = blockIdx.x * wpb + (threadIdx.x >> 6); e < E; e += gridDim.x * wpb) {
-    const int s = esrc[e], d = edst[e];
-    const float dx = src_pos[2 * s] - dst_pos[2 * d], dy = src_pos[2 * s + 1] - dst_pos[2 * d + 1];
-    const float od = dst_ori[d];
-    const float dist = sqrtf(dx * dx + dy * dy);
-    const float rel_ori = wrap_angle(src_ori[s] - od);
+// One 256-thread workgroup per 32-edge tile (grid-stride; the tile count toff[nq] is read on the device and
+// tdst maps a tile to its destination): each wave makes 8 of the tile's edges, the rows meet in LDS and
+// leave as the two MFMA operand images (layouts: k_tile_transpose), written as contiguous 16-byte pieces.
+__global__ __launch_bounds__(256) void k_relpe_tiles(const int* __restrict__ esrc, const int* __restrict__ eoff,
+                                                    const int* __restrict__ toff, const int* __restrict__ tdst, int nq,
+                                                    const float* __restrict__ src_pos, const float* __restrict__ src_ori,
+                                                    const float* __restrict__ dst_pos, const float* __restrict__ dst_ori,
+                                                    const float* __restrict__ div32, _Float16* __restrict__ rtA,
+                                                    _Float16* __restrict__ rtT, float eps) {
+  __shared__ __attribute__((aligned(16))) _Float16 buf[32][264];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ntiles = toff[nq];
+  // The 128 features are 64 (sin, cos) pairs: input dist | rel_ori | angle | angle again, 16 frequencies each
+  // (div32[2i] == div32[2i+1], fourier_embedding.py:68-69).  Lane l makes pair l = features 2l, 2l+1 with ONE
+  // sincosf (one argument reduction; a per-feature sinf/cosf select would run both branches in every lane).
+  const int inp = lane >> 4;
+  const float dv = div32[2 * (lane & 15)];
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int d = tdst[tile];
+    const int e0 = eoff[d] + (tile - toff[d]) * 32;
+    const int n = min(32, eoff[d + 1] - e0);
+    const float px = dst_pos[2 * d], py = dst_pos[2 * d + 1], od = dst_ori[d];
     const float cx = cosf(od), cy = sinf(od);
-    // torch's .sum(dim=-1) accumulates from +0, so a dot of (-0, -0) is +0 there: keep the explicit
-    // 0.f + ... (IEEE forbids folding it) or self-loop edges would see atan2(+-0, -0) = +-pi.
-    const float dot = (0.f + cx * dx) + cy * dy;
-    const float ang = atan2f(cx * dy - cy * dx, dot);
-    const int slot = lane & 31;
-    float f0 = fourier_feat(lane < 32 ? dist : rel_ori, slot, div32);
-    float f1 = fourier_feat(ang, slot, div32);
-    if (add) {
-      f0 += add[(size_t)e * 128 + lane];
-      f1 += add[(size_t)e * 128 + 64 + lane];
+    __syncthreads();   // the previous tile's image writes are done with buf
+#pragma unroll 2
+    for (int i = 0; i < 8; ++i) {
+      const int r = wave * 8 + i;
+      float y0 = 0.f, y1 = 0.f;
+      if (r < n) {
+        const int s = esrc[e0 + r];
+        const float dx = src_pos[2 * s] - px, dy = src_pos[2 * s + 1] - py;
+        const float dist = sqrtf(dx * dx + dy * dy);
+        const float rel_ori = wrap_angle(src_ori[s] - od);
+        // torch's .sum(dim=-1) accumulates from +0, so a dot of (-0, -0) is +0 there: keep the explicit
+        // 0.f + ... (IEEE forbids folding it) or self-loop edges would see atan2(+-0, -0) = +-pi.
+        const float dot = (0.f + cx * dx) + cy * dy;
+        const float ang = atan2f(cx * dy - cy * dx, dot);
+        const float xin = inp == 0 ? dist : (inp == 1 ? rel_ori : ang);
+        const float v = (xin * PS_TWO_PI_F) / dv;
+        float f0, f1;
+        sincosf(v, &f0, &f1);
+        const float mean = wave_sum(f0 + f1) * (1.f / 128.f);
+        const float d0 = f0 - mean, d1 = f1 - mean;
+        const float var = wave_sum(d0 * d0 + d1 * d1) * (1.f / 128.f);
+        const float rstd = 1.f / sqrtf(var + eps);
+        y0 = d0 * rstd;
+        y1 = d1 * rstd;
+      }
+      typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+      *reinterpret_cast<half2v*>(&buf[r][2 * lane]) = half2v{f16_hi(y0), f16_hi(y1)};
+      *reinterpret_cast<half2v*>(&buf[r][128 + 2 * lane]) = half2v{f16_lo(y0), f16_lo(y1)};
     }
-    const float mean = wave_sum(f0 + f1) * (1.f / 128.f);
-    const float d0 = f0 - mean, d1 = f1 - mean;
-    const float var = wave_sum(d0 * d0 + d1 * d1) * (1.f / 128.f);
-    const float rstd = 1.f / sqrtf(var + eps);
-    const float y0 = d0 * rstd, y1 = d1 * rstd;
-    // the row as split fp16 (hi[128] | lo[128]): what the score MFMAs of k_attn_chain read
-    _Float16* h = rthl + (size_t)e * 256;
-    h[lane] = f16_hi(y0);
-    h[64 + lane] = f16_hi(y1);
-    h[128 + lane] = f16_lo(y0);
-    h[192 + lane] = f16_lo(y1);
+    __syncthreads();
+    for (int P = tid; P < 1024; P += 256) {
+      const int m = P & 15, kq = (P >> 4) & 3, ks = (P >> 6) & 3, part_ = (P >> 8) & 1, sub = P >> 9;
+      *reinterpret_cast<half8*>(rtA + (size_t)tile * 8192 + (size_t)P * 8) =
+          *reinterpret_cast<const half8*>(&buf[sub * 16 + m][part_ * 128 + ks * 32 + kq * 8]);
+    }
+    const int part = tid >> 7, c = tid & 127;
+    _Float16* o = rtT + (size_t)tile * 8192 + part * 4096 + c * 32;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      half8 v;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = buf[8 * g + j][part * 128 + c];
+      *reinterpret_cast<half8*>(o + 8 * g) = v;
+    }
   }
 }
 
