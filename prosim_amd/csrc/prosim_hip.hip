@@ -228,6 +228,16 @@ void build_attn(Builder& b, const std::string& p, AttnW& w) {
   b.slot(&w.Wkr_g, b.put(wkrg));
   b.slot(&w.kb, b.put(kb));
   b.slot(&w.Wvr_gt, b.put(wvrgt));
+  {   // folded variants for geometric rel-PE rows (features 96..127 == 64..95)
+    std::vector<float> wkrg3 = wkrg, wvrgt3 = wvrgt;
+    for (int hd = 0; hd < D; ++hd)
+      for (int i = 0; i < 32; ++i) {
+        wkrg3[(size_t)hd * D + 64 + i] += wkrg3[(size_t)hd * D + 96 + i];
+        wvrgt3[(size_t)(64 + i) * D + hd] += wvrgt3[(size_t)(96 + i) * D + hd];
+      }
+    b.slot(&w.Wkr_g3, b.put(wkrg3));
+    b.slot(&w.Wvr_gt3, b.put(wvrgt3));
+  }
   b.slot(&w.vb, b.put(vb));
   b.slot(&w.Wkv_t, b.put(wkv));
   b.slot(&w.bkv, b.put(bkv));
@@ -450,10 +460,11 @@ extern "C" int ps_create(const ps_config* cfg, int32_t n_tensors, const char* co
     return fail(PS_E_HIP, "stream/event creation failed");
   }
   // the chain kernel may use up to ~140 KiB of dynamic LDS
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_chain<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_chain<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_chain<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_chain<4, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#define PS_ATTR(TT, NWW, KRR) \
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_chain<TT, NWW, KRR>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+  PS_ATTR(1, 4, 3); PS_ATTR(2, 4, 3); PS_ATTR(4, 4, 3); PS_ATTR(4, 8, 3);
+  PS_ATTR(1, 4, 4); PS_ATTR(2, 4, 4); PS_ATTR(4, 4, 4); PS_ATTR(4, 8, 4);
+#undef PS_ATTR
   *out = e;
   return PS_OK;
 }
@@ -668,6 +679,7 @@ extern "C" int ps_set_scene(ps_engine* e, int32_t B, int32_t M, int32_t P, int32
     s.esrc = es.esrc.p;
     s.toff = es.toff.p;
     s.rtT = es.rtT.p;
+    s.kr = (&es == &e->e_cnd) ? 4 : 3;
     e->h_steps.push_back(s);
   };
   e->step_a2a = (int)e->h_steps.size();
@@ -806,7 +818,9 @@ extern "C" int ps_set_future_obs(ps_engine* e, const float* fut_input) {
 namespace {
 
 int launch_chain(ps_engine* e, float* x, int Nd, int step0, int nsteps, int maxdeg, bool timed = false,
-                 const ChainStep* steps_override = nullptr, int force_T = 0) {
+                 const ChainStep* steps_override = nullptr, int force_T = 0, int kr_override = 0) {
+  // rel-PE width of the launch's steps: condition steps (and the test hook's arbitrary rows) use all 128 columns
+  const int steps_host_kr = kr_override ? kr_override : (steps_override ? 3 : e->h_steps[step0].kr);
   const ChainStep* steps = steps_override ? steps_override : e->d_steps.p + step0;
   hipStream_t st = e->stream;
   // rows per workgroup (T).  More rows per workgroup share each weight load; the T >= 2 kernels are built for
@@ -830,15 +844,23 @@ int launch_chain(ps_engine* e, float* x, int Nd, int step0, int nsteps, int maxd
     prof = d_prof;
   }
   if (timed && e->time_chain) (void)hipEventRecord(e->ev0, st);
-  const size_t lds84 = attn_lds_floats<4, 8>(maxdeg) * sizeof(float);
-  if (T == 84)
-    hipLaunchKernelGGL((k_attn_chain<4, 8>), dim3((Nd + 3) / 4), dim3(512), lds84, st, x, Nd, steps, nsteps, maxdeg, eps, flags, prof);
-  else if (T == 4)
-    hipLaunchKernelGGL((k_attn_chain<4, 4>), dim3((Nd + 3) / 4), dim3(WG), attn_lds_floats<4>(maxdeg) * sizeof(float), st, x, Nd, steps, nsteps, maxdeg, eps, flags, prof);
-  else if (T == 2)
-    hipLaunchKernelGGL((k_attn_chain<2, 4>), dim3((Nd + 1) / 2), dim3(WG), attn_lds_floats<2>(maxdeg) * sizeof(float), st, x, Nd, steps, nsteps, maxdeg, eps, flags, prof);
-  else
-    hipLaunchKernelGGL((k_attn_chain<1, 4>), dim3(Nd), dim3(WG), attn_lds_floats<1>(maxdeg) * sizeof(float), st, x, Nd, steps, nsteps, maxdeg, eps, flags, prof);
+  const size_t lds84 = attn_lds_floats<4, 8>(maxdeg) * sizeof(float), lds4 = attn_lds_floats<4>(maxdeg) * sizeof(float),
+               lds2 = attn_lds_floats<2>(maxdeg) * sizeof(float), lds1 = attn_lds_floats<1>(maxdeg) * sizeof(float);
+  const int kr = steps_host_kr;   // every step of a launch has the same rel-PE width
+#define PS_LAUNCH(TT, NWW, KRR, GRID, LDS) \
+  hipLaunchKernelGGL((k_attn_chain<TT, NWW, KRR>), dim3(GRID), dim3(64 * NWW), LDS, st, x, Nd, steps, nsteps, maxdeg, eps, flags, prof)
+  if (kr == 3) {
+    if (T == 84) PS_LAUNCH(4, 8, 3, (Nd + 3) / 4, lds84);
+    else if (T == 4) PS_LAUNCH(4, 4, 3, (Nd + 3) / 4, lds4);
+    else if (T == 2) PS_LAUNCH(2, 4, 3, (Nd + 1) / 2, lds2);
+    else PS_LAUNCH(1, 4, 3, Nd, lds1);
+  } else {
+    if (T == 84) PS_LAUNCH(4, 8, 4, (Nd + 3) / 4, lds84);
+    else if (T == 4) PS_LAUNCH(4, 4, 4, (Nd + 3) / 4, lds4);
+    else if (T == 2) PS_LAUNCH(2, 4, 4, (Nd + 1) / 2, lds2);
+    else PS_LAUNCH(1, 4, 4, Nd, lds1);
+  }
+#undef PS_LAUNCH
   if (timed && e->time_chain) {
     (void)hipEventRecord(e->ev1, st);
     (void)hipEventSynchronize(e->ev1);
@@ -849,9 +871,9 @@ int launch_chain(ps_engine* e, float* x, int Nd, int step0, int nsteps, int maxd
       (void)hipMemcpy(h, prof, sizeof(h), hipMemcpyDeviceToHost);
       const int Tr = T == 84 ? 4 : T, nwg = (Nd + Tr - 1) / Tr;
       double tot = 0;
-      for (int i = 0; i < 14; ++i) tot += (double)h[i];
+      for (int i = 0; i < 16; ++i) tot += (double)h[i];
       fprintf(stderr, "[chain prof] T=%d wgs=%d %.1f us; mean cycles per workgroup per phase (share):", T, nwg, ms * 1e3);
-      for (int i = 0; i < 14; ++i) fprintf(stderr, " %d:%.0f(%.1f%%)", i, (double)h[i] / nwg, 100.0 * h[i] / tot);
+      for (int i = 0; i < 16; ++i) fprintf(stderr, " %d:%.0f(%.1f%%)", i, (double)h[i] / nwg, 100.0 * h[i] / tot);
       fprintf(stderr, " total %.0f\n", tot / nwg);
     }
     e->chain_ms_sum += ms;
@@ -1321,8 +1343,9 @@ extern "C" int ps_test_attn(ps_engine* e, int32_t layer_index, int32_t Ns, int32
   ChainStep st;
   st.w = e->all_layers[layer_index];
   st.kv = dkv.p; st.eoff = doff.p; st.esrc = dsrc.p; st.toff = dtoff.p; st.rtT = drtT.p; st.rtA = drtA.p; st.khl = dkh.p;
+  st.kr = 4;   // the hook is handed arbitrary rows: all 128 columns count
   if (upload(dstep, &st, 1, e->stream)) return fail(PS_E_HIP, "test upload failed");
-  if (launch_chain(e, dxd.p, Nd, 0, 1, maxdeg, false, dstep.p, T)) return PS_E_HIP;
+  if (launch_chain(e, dxd.p, Nd, 0, 1, maxdeg, false, dstep.p, T, 4)) return PS_E_HIP;
   HIPCHK(hipStreamSynchronize(e->stream));
   HIPCHK(hipMemcpy(out, dxd.p, sizeof(float) * (size_t)Nd * D, hipMemcpyDeviceToHost));
   dxs.release(); dxd.release(); drt.release(); dkv.release(); doff.release(); dsrc.release(); dstep.release(); drth.release(); dkh.release();
@@ -1356,7 +1379,8 @@ extern "C" int64_t ps_test_get_edges(ps_engine* e, int32_t which, int32_t* esrc,
         const size_t tile = (size_t)to[d] + i / 32;
         const int sub = (i % 32) / 16, m = i % 16;
         for (int c = 0; c < 128; ++c) {
-          const int ks = c / 32, kq = (c % 32) / 8, j = c % 8;
+          const int cc = c < 96 ? c : c - 32;   // columns 96..127 repeat 64..95 and are not stored
+          const int ks = cc / 32, kq = (cc % 32) / 8, j = cc % 8;
           const size_t hi_ = tile * 8192 + (size_t)((sub * 2 + 0) * 4 + ks) * 512 + (kq * 16 + m) * 8 + j;
           const size_t lo_ = tile * 8192 + (size_t)((sub * 2 + 1) * 4 + ks) * 512 + (kq * 16 + m) * 8 + j;
           rt[(size_t)(eo[d] + i) * 128 + c] = (float)img[hi_] + (float)img[lo_];
@@ -1479,10 +1503,10 @@ extern "C" int ps_policy_forward(ps_engine* e, int32_t n_scenes, int32_t Na, con
   std::vector<ChainStep> hs;
   for (int i = 0; i < L; ++i) {
     ChainStep s1;
-    s1.w = e->a2p[i]; s1.kv = d_kva.p + (size_t)i * Na * 256 - (size_t)Nm * 256; s1.eoff = ea.eoff.p; s1.esrc = ea.esrc.p; s1.toff = ea.toff.p; s1.rtT = ea.rtT.p; s1.rtA = ea.rtA.p; s1.khl = d_kha.p + (size_t)i * Na * 256 - (size_t)Nm * 256;
+    s1.w = e->a2p[i]; s1.kv = d_kva.p + (size_t)i * Na * 256 - (size_t)Nm * 256; s1.eoff = ea.eoff.p; s1.esrc = ea.esrc.p; s1.toff = ea.toff.p; s1.rtT = ea.rtT.p; s1.rtA = ea.rtA.p; s1.kr = 3; s1.khl = d_kha.p + (size_t)i * Na * 256 - (size_t)Nm * 256;
     hs.push_back(s1);
     ChainStep s2;
-    s2.w = e->m2p[i]; s2.kv = d_kvm.p + (size_t)i * Nm * 256; s2.eoff = em.eoff.p; s2.esrc = em.esrc.p; s2.toff = em.toff.p; s2.rtT = em.rtT.p; s2.rtA = em.rtA.p; s2.khl = d_khm.p + (size_t)i * Nm * 256;
+    s2.w = e->m2p[i]; s2.kv = d_kvm.p + (size_t)i * Nm * 256; s2.eoff = em.eoff.p; s2.esrc = em.esrc.p; s2.toff = em.toff.p; s2.rtT = em.rtT.p; s2.rtA = em.rtA.p; s2.kr = 3; s2.khl = d_khm.p + (size_t)i * Nm * 256;
     hs.push_back(s2);
   }
   int rc = 0;

@@ -25,6 +25,11 @@ struct AttnW {
   const float* Wkr_g;                               // [hd=128][c=128]: to_k_r.weight * gamma_r[c]
   const float* kb;                                  // [128]: to_k_r.weight @ beta_r
   const float* Wvr_gt;                              // [c=128][hd=128]: (to_v_r.weight * gamma_r)^T
+  // The geometric rel-PE row is fourier([dist, rel_ori, angle, angle]) (act_decoder.py:217 and twins): features
+  // 96..127 repeat 64..95.  "Folded" variants add those weight columns / rows onto 64..95, so the kernels read
+  // and multiply only 96 of the 128 rel-PE columns (ChainStep::kr == 3).
+  const float* Wkr_g3;                              // Wkr_g with columns 96..127 added onto 64..95
+  const float* Wvr_gt3;                             // Wvr_gt with rows 96..127 added onto 64..95
   const float* vb;                                  // [128]: to_v_r.weight @ beta_r + to_v_r.bias
   const float *Wga_t, *Wout_t, *bout;
   const float *ln_post_w, *ln_post_b, *ln_ffpre_w, *ln_ffpre_b;
@@ -49,6 +54,8 @@ struct ChainStep {
   const _Float16* rtA;    // [tiles][8192]: score pass A operand (edge-major fragments, 1 KB contiguous per load)
   const _Float16* rtT;    // [tiles][8192]: aggregation pass B operand (edge-minor)
   const _Float16* khl;    // [Ns][256]: the k rows of kv as split fp16 (hi | lo)
+  int kr;                 // rel-PE column blocks of 32 that are distinct: 3 for geometric edge sets (columns 96..127
+                          // repeat 64..95 and are neither stored nor read), 4 for condition rows
 };
 
 // Edge lists are walked in chunks of CH edges per destination with an online (running max / sum)
@@ -154,7 +161,9 @@ __device__ __forceinline__ void fold_kgroups(float (&acc)[T][4]) {
 // 2 + 2.  Measured on the 1024-row policy launch it is SLOWER (733 vs 645 us): the node phase is bound by the
 // per-stage load->fma->fold->barrier latency chain, not by L1 bytes, and 8-wave barriers cost more.  Kept as
 // the experiment variant PS_CHAIN_T=84 (parity-tested), not selected by launch_chain.
-template <int T, int NW = 4>
+// KR: distinct rel-PE column blocks of 32 (3 for geometric edge sets, 4 for condition rows / the test hook); a
+// launch only ever chains steps of one kind, so it is a compile-time parameter (ChainStep::kr must agree).
+template <int T, int NW = 4, int KR = 3>
 __global__ __launch_bounds__(64 * NW, ((T >= 2 && NW == 4) ? 2 : 1)) void k_attn_chain(float* __restrict__ x, int Nd, const ChainStep* __restrict__ steps,
                                                      int nsteps, int maxdeg, float eps, int flags,
                                                      unsigned long long* __restrict__ prof) {
@@ -287,7 +296,7 @@ __global__ __launch_bounds__(64 * NW, ((T >= 2 && NW == 4) ? 2 : 1)) void k_attn
       zero_acc<T>(acc);
       // q~ chunk: NW = 4: wave -> heads 2*wave + k2, all 16 rows of the head; NW = 8: wave -> head `wave`,
       // k2 -> its 8-row half.  lane & 31 -> 4 columns.
-      const float* wkr = w.Wkr_g + (size_t)(NW == 4 ? (2 * wave + k2) * 16 : wave * 16 + 8 * k2) * 128 + 4 * c32;
+      const float* wkr = (KR == 3 ? w.Wkr_g3 : w.Wkr_g) + (size_t)(NW == 4 ? (2 * wave + k2) * 16 : wave * 16 + 8 * k2) * 128 + 4 * c32;
       PS_STAGE(wA, w.Wgx_t + woff, 128, wB, wkr, 128, xn + kgl * RK, 128);   // Wgx
       fold_kgroups<T, LQ>(acc);
       if (kgl == 0) {
@@ -306,7 +315,7 @@ __global__ __launch_bounds__(64 * NW, ((T >= 2 && NW == 4) ? 2 : 1)) void k_attn
       const int hr = NW == 4 ? h * 16 : h * 16 + 8 * k2;   // first of this lane's RK rows of Wkr_g / elements of q_h
       float acc[T][4];
       zero_acc<T>(acc);
-      if (!PF) wload(wB, w.Wkr_g + (size_t)hr * 128 + 4 * c32, 128);
+      if (!PF) wload(wB, (KR == 3 ? w.Wkr_g3 : w.Wkr_g) + (size_t)hr * 128 + 4 * c32, 128);
       wfma<T, RK>(wB, qb + hr, 128, acc);                                               // Wkr_g
       if (NW == 8) fold_kgroups<T, 32>(acc);
       if (NW == 4 || k2 == 0) {
@@ -330,8 +339,8 @@ __global__ __launch_bounds__(64 * NW, ((T >= 2 && NW == 4) ? 2 : 1)) void k_attn
     // Every row read is a fully coalesced 512-byte line per wave (r~ rows, k rows, v rows).
     {
       float* sc = un + (size_t)t * CH * 8;
-      const int hl = lane >> 3, jl = lane & 7;
       const int t_beg = (r < Nd) ? ldgi(st.toff + r) : 0;
+      constexpr bool k4 = KR != 3;   // the fourth rel-PE column block exists (condition rows)
       // B operands of the score MFMAs, built once per destination and layer: lane -> column n = lane & 15
       // (head n & 7, hi half for n < 8 / lo half for n >= 8), k-block lane >> 4 (8 consecutive columns)
       half8 bq[4], bk[4];
@@ -358,7 +367,9 @@ __global__ __launch_bounds__(64 * NW, ((T >= 2 && NW == 4) ? 2 : 1)) void k_attn
       }
       const float cqm = cq[t * 8 + (lane & 7)];
       __syncthreads();   // q~ (in `big`) is in registers now: the k staging area [f1, big) may overwrite it
-      float av0 = 0.f, av1 = 0.f, m_run[8], l_run[8];
+      float4 av = make_float4(0.f, 0.f, 0.f, 0.f);   // a_v partial: columns 4*(lane & 31)..+3, edges of parity lane >> 5
+      const int hv = (lane & 31) >> 2;               // ... which belong to head hv
+      float m_run[8], l_run[8];
       floatx4 ar[8];   // a_r as MFMA accumulators: [column block][row 4*(lane>>4)+r = (p hi | p lo) x head]
 #pragma unroll
       for (int h = 0; h < 8; ++h) { ar[h] = floatx4{0.f, 0.f, 0.f, 0.f}; m_run[h] = -INFINITY; l_run[h] = 0.f; }
@@ -396,11 +407,13 @@ __global__ __launch_bounds__(64 * NW, ((T >= 2 && NW == 4) ? 2 : 1)) void k_attn
             const _Float16* ra = (flags & 32) ? st.rtA + (size_t)((t_beg + (blk >> 1)) & 7) * 8192 + (blk & 1) * 4096 + lane * 8
                                               : st.rtA + (size_t)(t_beg + (blk >> 1)) * 8192 + (blk & 1) * 4096 + lane * 8;
             const int e = (eb + rq < cn) ? eb + rq : cn - 1;
-            const _Float16* kp = st.khl + (size_t)el[e] * 256 + 8 * pq;
+            const _Float16* kp = st.khl + (size_t)((flags & 64) ? (e & 15) : el[e]) * 256 + 8 * pq;   // 64: ablation, cached rows
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-              nrh[ks] = ldgh8(ra + 512 * ks);
-              nrl[ks] = ldgh8(ra + 2048 + 512 * ks);
+              if (ks < 3 || k4) {
+                nrh[ks] = ldgh8(ra + 512 * ks);
+                nrl[ks] = ldgh8(ra + 2048 + 512 * ks);
+              }
               nkh[ks] = ldgh8(kp + 32 * ks);
               nkl[ks] = ldgh8(kp + 128 + 32 * ks);
             }
@@ -414,21 +427,26 @@ __global__ __launch_bounds__(64 * NW, ((T >= 2 && NW == 4) ? 2 : 1)) void k_attn
             half8 arh[4], arl[4], akh[4], akl[4];
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) { arh[ks] = nrh[ks]; arl[ks] = nrl[ks]; }
+            if (flags & 128) {   // ablation: no LDS staging (wrong fragments, timing only)
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) stw[4 * ks] = nkh[ks];
+              for (int ks = 0; ks < 4; ++ks) { akh[ks] = nkh[ks]; akl[ks] = nkl[ks]; }
+            } else {
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) akh[ks] = str[4 * ks];
+              for (int ks = 0; ks < 4; ++ks) stw[4 * ks] = nkh[ks];
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) stw[4 * ks] = nkl[ks];
+              for (int ks = 0; ks < 4; ++ks) akh[ks] = str[4 * ks];
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) akl[ks] = str[4 * ks];
+              for (int ks = 0; ks < 4; ++ks) stw[4 * ks] = nkl[ks];
+#pragma unroll
+              for (int ks = 0; ks < 4; ++ks) akl[ks] = str[4 * ks];
+            }
             if (PFE && eb + 16 * W < cn) gather1(eb + 16 * W);   // the next tile's rows fly under this tile's MFMAs
             floatx4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-              acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(arh[ks], bq[ks], acc, 0, 0, 0);
+              if (ks < 3 || k4) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(arh[ks], bq[ks], acc, 0, 0, 0);
               acc2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(akh[ks], bk[ks], acc2, 0, 0, 0);
-              acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(arl[ks], bq[ks], acc, 0, 0, 0);
+              if (ks < 3 || k4) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(arl[ks], bq[ks], acc, 0, 0, 0);
               acc2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(akl[ks], bk[ks], acc2, 0, 0, 0);
             }
             acc += acc2;
@@ -486,9 +504,8 @@ __global__ __launch_bounds__(64 * NW, ((T >= 2 && NW == 4) ? 2 : 1)) void k_attn
         {
           float sh = scl[0];
 #pragma unroll
-          for (int h = 1; h < 8; ++h) sh = (hl == h) ? scl[h] : sh;
-          av0 *= sh;
-          av1 *= sh;
+          for (int h = 1; h < 8; ++h) sh = (hv == h) ? scl[h] : sh;
+          av.x *= sh; av.y *= sh; av.z *= sh; av.w *= sh;
         }
         __syncthreads();
         PS_MARK(5);
@@ -506,8 +523,10 @@ __global__ __launch_bounds__(64 * NW, ((T >= 2 && NW == 4) ? 2 : 1)) void k_attn
             half8 bh[8], bl[8];
 #pragma unroll
             for (int cb = 0; cb < 8; ++cb) {
-              bh[cb] = ldgh8(tp + cb * 512);
-              bl[cb] = ldgh8(tp + 4096 + cb * 512);
+              if (cb < 6 || k4) {
+                bh[cb] = ldgh8(tp + cb * 512);
+                bl[cb] = ldgh8(tp + 4096 + cb * 512);
+              }
             }
             half8 ap;
 #pragma unroll
@@ -518,41 +537,49 @@ __global__ __launch_bounds__(64 * NW, ((T >= 2 && NW == 4) ? 2 : 1)) void k_attn
             }
 #pragma unroll
             for (int cb = 0; cb < 8; ++cb) {
-              ar[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ap, bh[cb], ar[cb], 0, 0, 0);
-              ar[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ap, bl[cb], ar[cb], 0, 0, 0);
+              if (cb < 6 || k4) {
+                ar[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ap, bh[cb], ar[cb], 0, 0, 0);
+                ar[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ap, bl[cb], ar[cb], 0, 0, 0);
+              }
             }
           }
         }
         PS_MARK(6);
-        // pass 2b: a_v[hd] += sum_e p_e,h v_src[hd]: v rows are gathered by SOURCE (no edge-minor image), 8 edges in flight
-        const float* vbase = st.kv + 128 + 2 * lane;
-        float2 vvn[8];
+        // pass 2b: a_v[hd] += sum_e p_e,h v_src[hd]: v rows are gathered by SOURCE (no edge-minor image).  Lane ->
+        // (edge parity lane >> 5, columns 4*(lane & 31)..+3): a load instruction reads two whole rows as 16-byte
+        // pieces, 8 instructions = 16 edges in flight per batch (each batch is one exposed round trip).
+        const float* vbase = st.kv + 128 + 4 * (lane & 31);
+        const int eh = lane >> 5;
+        float4 vvn[8];
         auto gather2 = [&](int eb) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
-            const int ee = (eb + j < cn) ? eb + j : cn - 1;
-            vvn[j] = ldg2(vbase + (size_t)el[ee] * 256);
+            const int ee = (eb + 2 * j + eh < cn) ? eb + 2 * j + eh : cn - 1;
+            vvn[j] = ldg4(vbase + (size_t)el[ee] * 256);
           }
         };
-        if (PFE && wi * 8 < cn) gather2(wi * 8);
-        for (int eb = wi * 8; eb < cn && !(flags & 8); eb += 8 * W) {
+        if (PFE && wi * 16 < cn) gather2(wi * 16);
+        for (int eb = wi * 16; eb < cn && !(flags & 8); eb += 16 * W) {
           if (!PFE) gather2(eb);
-          float2 vv[8];
+          float4 vv[8];
 #pragma unroll
           for (int j = 0; j < 8; ++j) vv[j] = vvn[j];
-          if (PFE && eb + 8 * W < cn) gather2(eb + 8 * W);
+          if (PFE && eb + 16 * W < cn) gather2(eb + 16 * W);
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
-            const float ph = (eb + j < cn) ? sc[(size_t)(eb + j) * 8 + hl] : 0.f;
-            av0 = fmaf(ph, vv[j].x, av0);
-            av1 = fmaf(ph, vv[j].y, av1);
+            const int ee = eb + 2 * j + eh;
+            const float ph = (ee < cn) ? sc[(size_t)ee * 8 + hv] : 0.f;
+            av.x = fmaf(ph, vv[j].x, av.x);
+            av.y = fmaf(ph, vv[j].y, av.y);
+            av.z = fmaf(ph, vv[j].z, av.z);
+            av.w = fmaf(ph, vv[j].w, av.w);
           }
         }
         PS_MARK(7);
         if (c0 + CH < dmax) __syncthreads();   // the next chunk's pass 1 overwrites the score tile
       }
       // the to_v_r fold's weights leave now and land while the partials are published
-      if (PF) wload(wA, w.Wvr_gt + woff, 128);
+      if (PF) wload(wA, (KR == 3 ? w.Wvr_gt3 : w.Wvr_gt) + woff, 128);
       // rows h (p hi) and h + 8 (p lo) sit 32 lanes apart: one half-wave swap folds two column blocks at a time
 #pragma unroll
       for (int cb = 0; cb < 8; cb += 2) {
@@ -562,7 +589,10 @@ __global__ __launch_bounds__(64 * NW, ((T >= 2 && NW == 4) ? 2 : 1)) void k_attn
           big[(size_t)(wave * 8 + 4 * ((lane >> 4) & 1) + r4) * QP + (cb + (lane >> 5)) * 16 + (lane & 15)] = v;
         }
       }
-      *reinterpret_cast<float2*>(avp + wave * 128 + 2 * lane) = make_float2(av0, av1);
+      {   // even-edge and odd-edge halves meet; lanes 0-31 publish the wave's a_v partial
+        av.x += __shfl_xor(av.x, 32); av.y += __shfl_xor(av.y, 32); av.z += __shfl_xor(av.z, 32); av.w += __shfl_xor(av.w, 32);
+        if (lane < 32) *reinterpret_cast<float4*>(avp + wave * 128 + 4 * lane) = av;
+      }
       if (lane < 8) {
         float v = l_run[0];
 #pragma unroll
@@ -595,7 +625,7 @@ __global__ __launch_bounds__(64 * NW, ((T >= 2 && NW == 4) ? 2 : 1)) void k_attn
     {
       float acc[T][4];
       zero_acc<T>(acc);
-      PS_STAGE(wA, w.Wvr_gt + woff, 128, wB, w.Wga_t + woff, 128, big + (size_t)(ncol >> 4) * QP + kgl * RK, W * 8 * QP);   // Wvr
+      PS_STAGE(wA, (KR == 3 ? w.Wvr_gt3 : w.Wvr_gt) + woff, 128, wB, w.Wga_t + woff, 128, big + (size_t)(ncol >> 4) * QP + kgl * RK, W * 8 * QP);   // Wvr
       fold_kgroups<T, LQ>(acc);
       if (kgl == 0) {
         const int h = ncol >> 4;

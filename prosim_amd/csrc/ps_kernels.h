@@ -429,19 +429,24 @@ __global__ __launch_bounds__(256) void k_relpe_tiles(const int* __restrict__ esr
       *reinterpret_cast<half2v*>(&buf[r][128 + 2 * lane]) = half2v{f16_lo(y0), f16_lo(y1)};
     }
     __syncthreads();
+    // columns 96..127 repeat 64..95 (the angle enters the embedding twice): neither image stores them, the
+    // consumers fold the matching weights instead (AttnW::Wkr_g3 / Wvr_gt3)
     for (int P = tid; P < 1024; P += 256) {
       const int m = P & 15, kq = (P >> 4) & 3, ks = (P >> 6) & 3, part_ = (P >> 8) & 1, sub = P >> 9;
-      *reinterpret_cast<half8*>(rtA + (size_t)tile * 8192 + (size_t)P * 8) =
-          *reinterpret_cast<const half8*>(&buf[sub * 16 + m][part_ * 128 + ks * 32 + kq * 8]);
+      if (ks < 3)
+        *reinterpret_cast<half8*>(rtA + (size_t)tile * 8192 + (size_t)P * 8) =
+            *reinterpret_cast<const half8*>(&buf[sub * 16 + m][part_ * 128 + ks * 32 + kq * 8]);
     }
     const int part = tid >> 7, c = tid & 127;
     _Float16* o = rtT + (size_t)tile * 8192 + part * 4096 + c * 32;
+    if (c < 96) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      half8 v;
+      for (int g = 0; g < 4; ++g) {
+        half8 v;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = buf[8 * g + j][part * 128 + c];
-      *reinterpret_cast<half8*>(o + 8 * g) = v;
+        for (int j = 0; j < 8; ++j) v[j] = buf[8 * g + j][part * 128 + c];
+        *reinterpret_cast<half8*>(o + 8 * g) = v;
+      }
     }
   }
 }
