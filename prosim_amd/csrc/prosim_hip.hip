@@ -160,6 +160,27 @@ struct Builder {
     if (!s) return;
     slot(p, put(std::vector<float>(s, s + numel)));
   }
+  // torch Linear weight [out = 128][in] -> split-fp16 MFMA B fragments over input columns [in0, in0+in_n), K padded
+  // to a multiple of 32: [n-tile 8][k-block][hi|lo][lane 64][8], lane = (n & 15) + 16*kq holds k = 32*ks + 8*kq ..+8
+  void fragments(const _Float16** p, const std::string& name, int out, int in, int in0, int in_n) {
+    const float* s = get(name, (int64_t)out * in);
+    if (!s) return;
+    const int k32 = (in_n + 31) / 32, nt_n = out / 16;
+    std::vector<float> packed(((size_t)nt_n * k32 * 2 * 512 + 1) / 2);
+    _Float16* h = reinterpret_cast<_Float16*>(packed.data());
+    for (int nt = 0; nt < nt_n; ++nt)
+      for (int ks = 0; ks < k32; ++ks)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int j = 0; j < 8; ++j) {
+            const int n = nt * 16 + (lane & 15), k = ks * 32 + (lane >> 4) * 8 + j;
+            const float v = k < in_n ? s[(size_t)n * in + in0 + k] : 0.f;
+            const _Float16 hi = (_Float16)v;
+            const size_t o = ((size_t)(nt * k32 + ks) * 2) * 512 + (size_t)lane * 8 + j;
+            h[o] = hi;
+            h[o + 512] = (_Float16)(v - (float)hi);
+          }
+    slot(reinterpret_cast<const float**>(p), put(packed));
+  }
   void transposed(const float** p, const std::string& name, int out, int in, int in0 = 0, int in_n = -1) {
     // torch Linear weight [out][in] -> K-major [in_n][out] over input columns [in0, in0+in_n)
     const float* s = get(name, (int64_t)out * in);
@@ -293,6 +314,7 @@ void build_pointnet(Builder& b, const std::string& p, int in_dim, int n_pre, int
     const int K = l == 0 ? in_dim : D;
     const std::string q = p + ".pre_mlps.mlp." + std::to_string(sq[l].first);
     b.transposed(&w.pre_Wt[l], q + ".weight", D, K);
+    b.fragments(&w.pre_F[l], q + ".weight", D, K, 0, K);
     b.plain(&w.pre_b[l], q + ".bias", D);
     if (sq[l].second >= 0) {
       const std::string n = p + ".pre_mlps.mlp." + std::to_string(sq[l].second);
@@ -305,6 +327,8 @@ void build_pointnet(Builder& b, const std::string& p, int in_dim, int n_pre, int
     const int K = l == 0 ? 2 * D : D;
     const std::string q = p + ".mlps.mlp." + std::to_string(sq[l].first);
     b.transposed(&w.mid_Wt[l], q + ".weight", D, K);
+    b.fragments(&w.mid_F[l], q + ".weight", D, K, 0, D);   // layer 0: the point-feature half ...
+    if (l == 0) b.fragments(&w.mid_P, q + ".weight", D, K, D, D);   // ... and the pooled half
     b.plain(&w.mid_b[l], q + ".bias", D);
     if (sq[l].second >= 0) {
       const std::string n = p + ".mlps.mlp." + std::to_string(sq[l].second);
@@ -312,6 +336,8 @@ void build_pointnet(Builder& b, const std::string& p, int in_dim, int n_pre, int
       b.plain(&w.mid_lnb[l], n + ".bias", D);
     }
   }
+  b.fragments(&w.out_F0, p + ".out_mlps.mlp.0.weight", D, D, 0, D);
+  b.fragments(&w.out_F1, p + ".out_mlps.mlp.2.weight", D, D, 0, D);
   b.transposed(&w.out_W0t, p + ".out_mlps.mlp.0.weight", D, D);
   b.plain(&w.out_b0, p + ".out_mlps.mlp.0.bias", D);
   b.transposed(&w.out_W1t, p + ".out_mlps.mlp.2.weight", D, D);
@@ -460,6 +486,7 @@ extern "C" int ps_create(const ps_config* cfg, int32_t n_tensors, const char* co
     return fail(PS_E_HIP, "stream/event creation failed");
   }
   // the chain kernel may use up to ~140 KiB of dynamic LDS
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pointnet_mfma), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PN_LDS_BYTES);
 #define PS_ATTR(TT, NWW, KRR) \
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_chain<TT, NWW, KRR>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
   PS_ATTR(1, 4, 3); PS_ATTR(2, 4, 3); PS_ATTR(4, 4, 3); PS_ATTR(4, 8, 3);
@@ -897,13 +924,9 @@ void launch_kv(ps_engine* e, const float* x, int Ns, int layer0, int nlayers, fl
 void launch_pointnet(ps_engine* e, const PointNetW& w, const float* pts, const uint8_t* mask, const int* rows, int n_rows,
                      int P, int feat_mask_dim, float* out) {
   if (n_rows <= 0) return;
-  const float eps = e->cfg.ln_eps;
-  if (P <= 12)
-    hipLaunchKernelGGL(k_pointnet<12>, dim3(n_rows), dim3(128), 0, e->stream, w, pts, mask, rows, n_rows, P, feat_mask_dim, out, eps);
-  else if (P <= 20)
-    hipLaunchKernelGGL(k_pointnet<20>, dim3(n_rows), dim3(128), 0, e->stream, w, pts, mask, rows, n_rows, P, feat_mask_dim, out, eps);
-  else
-    hipLaunchKernelGGL(k_pointnet<32>, dim3(n_rows), dim3(128), 0, e->stream, w, pts, mask, rows, n_rows, P, feat_mask_dim, out, eps);
+  const int G = std::min(PN_G, PN_ROWS / P);   // polylines per workgroup (ps_set_scene bounds P <= 32)
+  hipLaunchKernelGGL(k_pointnet_mfma, dim3((n_rows + G - 1) / G), dim3(256), PN_LDS_BYTES, e->stream, w, pts, mask, rows, n_rows, P,
+                     feat_mask_dim, out, e->cfg.ln_eps);
 }
 
 // rel-PE of an edge set as the two MFMA operand images (device-side tile count, grid-stride over tiles)

@@ -147,20 +147,21 @@ __device__ __forceinline__ void fold_kgroups(float (&acc)[T][4]) {
   }
 }
 
-// stage helper: with PF the chunk in CUR was requested a stage ago and NXT is requested now; without PF
-// CUR is requested here and used straight away (one register set live)
+// stage helper.  Weight chunks do not depend on activations, so every chunk is requested before the stage that
+// multiplies it.  EARLY (T == 1, full register file): the next chunk is requested BEFORE this chunk's FMAs, two
+// register sets live.  Otherwise (two workgroups per CU, <= 256 registers): it is requested right AFTER this
+// chunk's FMAs, into registers that just died -- one set live, and the request still flies under the fold, the
+// LDS write and the barrier that close the stage.  CURP/CURN are kept for readability only.
 #define PS_STAGE(CUR, CURP, CURN, NXT, NXTP, NXTN, X, XS) \
   do {                                                    \
     if (PF) wload(NXT, NXTP, NXTN);                       \
-    else wload(CUR, CURP, CURN);                          \
     wfma<T, RK>(CUR, X, XS, acc);                         \
+    if (!PF) {                                            \
+      __builtin_amdgcn_sched_barrier(0);                  \
+      wload(NXT, NXTP, NXTN);                             \
+    }                                                     \
   } while (0)
 
-// NW waves per workgroup.  NW = 8 (T = 4) is ONE 512-thread workgroup per CU instead of two 256-thread ones:
-// the same 8 waves and registers, and a layer's weights cross the CU's L1 once for 4 rows instead of twice for
-// 2 + 2.  Measured on the 1024-row policy launch it is SLOWER (733 vs 645 us): the node phase is bound by the
-// per-stage load->fma->fold->barrier latency chain, not by L1 bytes, and 8-wave barriers cost more.  Kept as
-// the experiment variant PS_CHAIN_T=84 (parity-tested), not selected by launch_chain.
 // KR: distinct rel-PE column blocks of 32 (3 for geometric edge sets, 4 for condition rows / the test hook); a
 // launch only ever chains steps of one kind, so it is a compile-time parameter (ChainStep::kr must agree).
 template <int T, int NW = 4, int KR = 3>
@@ -274,6 +275,7 @@ __global__ __launch_bounds__(64 * NW, ((T >= 2 && NW == 4) ? 2 : 1)) void k_attn
     {
       float acc[T][4];
       zero_acc<T>(acc);
+      if (!PF) wload(wA, w.Wq_t + woff, 128);   // (late mode keeps no weights in registers across the layer boundary)
       PS_STAGE(wA, w.Wq_t + woff, 128, wB, w.Ws_t + woff, 128, xn + kgl * RK, 128);    // Wq
       fold_kgroups<T, LQ>(acc);
       if (kgl == 0) {
@@ -315,7 +317,6 @@ __global__ __launch_bounds__(64 * NW, ((T >= 2 && NW == 4) ? 2 : 1)) void k_attn
       const int hr = NW == 4 ? h * 16 : h * 16 + 8 * k2;   // first of this lane's RK rows of Wkr_g / elements of q_h
       float acc[T][4];
       zero_acc<T>(acc);
-      if (!PF) wload(wB, (KR == 3 ? w.Wkr_g3 : w.Wkr_g) + (size_t)hr * 128 + 4 * c32, 128);
       wfma<T, RK>(wB, qb + hr, 128, acc);                                               // Wkr_g
       if (NW == 8) fold_kgroups<T, 32>(acc);
       if (NW == 4 || k2 == 0) {
@@ -579,7 +580,7 @@ __global__ __launch_bounds__(64 * NW, ((T >= 2 && NW == 4) ? 2 : 1)) void k_attn
         if (c0 + CH < dmax) __syncthreads();   // the next chunk's pass 1 overwrites the score tile
       }
       // the to_v_r fold's weights leave now and land while the partials are published
-      if (PF) wload(wA, (KR == 3 ? w.Wvr_gt3 : w.Wvr_gt) + woff, 128);
+      wload(wA, (KR == 3 ? w.Wvr_gt3 : w.Wvr_gt) + woff, 128);
       // rows h (p hi) and h + 8 (p lo) sit 32 lanes apart: one half-wave swap folds two column blocks at a time
 #pragma unroll
       for (int cb = 0; cb < 8; cb += 2) {
@@ -723,7 +724,6 @@ __global__ __launch_bounds__(64 * NW, ((T >= 2 && NW == 4) ? 2 : 1)) void k_attn
       PS_STAGE(wB, w2, 128, wA, w2 + (size_t)RK * 128, 128, fk, 512);
       PS_STAGE(wA, w2 + (size_t)RK * 128, 128, wB, w2 + (size_t)2 * RK * 128, 128, fk + RK, 512);
       PS_STAGE(wB, w2 + (size_t)2 * RK * 128, 128, wA, w2 + (size_t)3 * RK * 128, 128, fk + 2 * RK, 512);
-      if (!PF) wload(wA, w2 + (size_t)3 * RK * 128, 128);
       wfma<T, RK>(wA, fk + 3 * RK, 512, acc);
       // the next layer's first chunk leaves now; it lands during the fold and the two norms
       if (PF && s + 1 < nsteps) wload(wA, steps[s + 1].w.Wq_t + woff, 128);

@@ -21,6 +21,11 @@ struct PointNetW {
   const float* mid_lnw[4];
   const float* mid_lnb[4];
   const float *out_W0t, *out_b0, *out_W1t, *out_b1;  // out_mlps: Linear, ReLU, Linear (no norm)
+  // the per-point Linear weights once more as split-fp16 MFMA B fragments: [n-tile 8][k-block K/32][hi|lo][lane 64][8]
+  // (lane = column n + 16*kq holds k = 32*ks + 8*kq ..+8; K padded to 32 with zeros; mid layer 0: rows 0..127 only)
+  const _Float16* pre_F[4];
+  const _Float16* mid_F[4];
+  const _Float16 *mid_P, *out_F0, *out_F1;   // mlps[0] rows 128..255 (pooled half), out_mlps Linear 0 / 1
 };
 
 template <int PTS>
@@ -136,6 +141,226 @@ __global__ __launch_bounds__(128) void k_pointnet(PointNetW w, const float* __re
   a = w.out_b1[col];
   for (int k = 0; k < 128; ++k) a = fmaf(hb[k], w.out_W1t[(size_t)k * 128 + col], a);
   out[(size_t)blockIdx.x * 128 + col] = a;
+}
+
+// ---- the same encoder on the matrix cores.  A workgroup (4 waves) takes G = 64 / P polylines = up to 64
+// point rows.  Every per-point Linear is a [64 x K] x [K x 128] GEMM: the rows live in LDS as split-fp16 planes
+// (A operand, hi | lo), the weights stream from L2 as pre-split B fragments (1 KB contiguous per wave load),
+// and hi*hi + hi*lo + lo*hi accumulate in fp32 (v_mfma_f32_16x16x32_f16; the dropped lo*lo term is ~2^-22).
+// Wave w owns output columns 16*w..+15 and 16*(w+4)..+15 for all four 16-row tiles.  Bias / LayerNorm / ReLU
+// and the two max-pools run on the fp32 result in LDS; the pooled half of mlps[0] and out_mlps are per-polyline
+// GEMVs (VALU).  Replaces one 128-thread workgroup per polyline that re-streamed all weights for 20 rows.
+constexpr int PN_ROWS = 64, PN_AS = 136, PN_CS = 132, PN_G = 8;
+constexpr size_t PN_LDS_BYTES = (size_t)2 * PN_ROWS * PN_AS * 2 + (size_t)PN_ROWS * PN_CS * 4 + (size_t)2 * PN_G * 128 * 4 + PN_ROWS * 4;
+
+// C[16*MT x 128] = A[16*MT x 32*k32] * W: wave w makes the 16-column tiles w and w + 4 (all 16 B-fragment loads
+// of both tiles are in flight before the first MFMA).  Rows >= row_lim are not stored.
+template <int MT>
+__device__ __forceinline__ void pn_gemm(const _Float16* __restrict__ Ah, const _Float16* __restrict__ Al, int k32,
+                                        const _Float16* __restrict__ F, float* __restrict__ C, int cs, int row_lim, int wave,
+                                        int lane) {
+  const int mi = lane & 15, kq = lane >> 4;
+  half8 bh[2][4], bl[2][4];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const _Float16* f = F + (size_t)(wave + 4 * t) * k32 * 1024 + lane * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      if (ks < k32) {
+        bh[t][ks] = ldgh8(f + ks * 1024);
+        bl[t][ks] = ldgh8(f + ks * 1024 + 512);
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int nt = wave + 4 * t;
+    floatx4 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      if (ks < k32) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const half8 ah = *reinterpret_cast<const half8*>(Ah + (mt * 16 + mi) * PN_AS + ks * 32 + kq * 8);
+          const half8 al = *reinterpret_cast<const half8*>(Al + (mt * 16 + mi) * PN_AS + ks * 32 + kq * 8);
+          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[t][ks], acc[mt], 0, 0, 0);
+          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[t][ks], acc[mt], 0, 0, 0);
+          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[t][ks], acc[mt], 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = mt * 16 + 4 * kq + r;
+        if (row < row_lim) C[row * cs + nt * 16 + mi] = acc[mt][r];
+      }
+  }
+}
+
+// bias (per column, or per polyline and column) + LayerNorm + ReLU (or ReLU alone) on the fp32 rows, which
+// also become the next GEMM's A planes.  All 64 rows at once: thread -> (row tid >> 2, 32-column quarter
+// tid & 3); the LayerNorm sums meet inside the lane quad (two DPP steps, no wave-wide reduction chain).
+__device__ __forceinline__ void pn_epilogue(float* __restrict__ C, _Float16* __restrict__ Ah, _Float16* __restrict__ Al,
+                                            const float* __restrict__ bias, const float* __restrict__ pbias, int P,
+                                            const float* __restrict__ lnw, const float* __restrict__ lnb, float eps) {
+  const int r = threadIdx.x >> 2, c0 = (threadIdx.x & 3) * 32;
+  const float* bb = pbias ? pbias + (r / P < PN_G ? r / P : 0) * 128 : bias;
+  float a[32];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float4 v = *reinterpret_cast<const float4*>(C + r * PN_CS + c0 + 4 * i);
+    a[4 * i] = v.x + bb[c0 + 4 * i];
+    a[4 * i + 1] = v.y + bb[c0 + 4 * i + 1];
+    a[4 * i + 2] = v.z + bb[c0 + 4 * i + 2];
+    a[4 * i + 3] = v.w + bb[c0 + 4 * i + 3];
+  }
+  if (lnw) {
+    float sm = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) sm += a[i];
+    sm += dpp_xor1(sm);
+    sm += dpp_xor2(sm);
+    const float mean = sm * (1.f / 128.f);
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      a[i] -= mean;
+      sq = fmaf(a[i], a[i], sq);
+    }
+    sq += dpp_xor1(sq);
+    sq += dpp_xor2(sq);
+    const float rstd = 1.f / sqrtf(sq * (1.f / 128.f) + eps);
+#pragma unroll
+    for (int i = 0; i < 32; ++i) a[i] = fmaf(a[i] * rstd, lnw[c0 + i], lnb[c0 + i]);
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float4 v = make_float4(fmaxf(a[4 * i], 0.f), fmaxf(a[4 * i + 1], 0.f), fmaxf(a[4 * i + 2], 0.f), fmaxf(a[4 * i + 3], 0.f));
+    *reinterpret_cast<float4*>(C + r * PN_CS + c0 + 4 * i) = v;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    half8 h, l;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float v = fmaxf(a[8 * i + j], 0.f);
+      h[j] = f16_hi(v);
+      l[j] = f16_lo(v);
+    }
+    *reinterpret_cast<half8*>(Ah + r * PN_AS + c0 + 8 * i) = h;
+    *reinterpret_cast<half8*>(Al + r * PN_AS + c0 + 8 * i) = l;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_pointnet_mfma(PointNetW w, const float* __restrict__ pts, const uint8_t* __restrict__ pmask,
+                                                      const int* __restrict__ rows, int n_rows, int P, int feat_mask_dim,
+                                                      float* __restrict__ out, float eps) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char pn_smem[];
+  _Float16* Ah = reinterpret_cast<_Float16*>(pn_smem);
+  _Float16* Al = Ah + PN_ROWS * PN_AS;
+  float* C = reinterpret_cast<float*>(Al + PN_ROWS * PN_AS);
+  float* pooled = C + PN_ROWS * PN_CS;    // [PN_G][128]
+  float* pb = pooled + PN_G * 128;        // [PN_G][128]
+  int* valid = reinterpret_cast<int*>(pb + PN_G * 128);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int G = min(PN_G, PN_ROWS / P);
+  const int g0 = blockIdx.x * G;
+  const int Cin = w.in_dim;
+  if (tid < PN_ROWS) {
+    const int g = tid / P, p = tid - g * P;
+    int v = 0;
+    if (g < G && g0 + g < n_rows) {
+      const int row = rows ? rows[g0 + g] : g0 + g;
+      if (feat_mask_dim == 0) v = pmask[(size_t)row * P + p];
+      else {
+        v = 1;
+        for (int f = 0; f < feat_mask_dim; ++f) v &= pmask[((size_t)row * P + p) * feat_mask_dim + f];
+      }
+    }
+    valid[tid] = v;
+  }
+  __syncthreads();
+  for (int i = tid; i < PN_ROWS * 32; i += 256) {   // input rows, K padded to 32, masked points zero-filled
+    const int r = i >> 5, k = i & 31;
+    const int g = r / P, p = r - g * P;
+    float xv = 0.f;
+    if (k < Cin && valid[r]) {
+      const int row = rows ? rows[g0 + g] : g0 + g;
+      xv = pts[((size_t)row * P + p) * Cin + k];
+    }
+    Ah[r * PN_AS + k] = f16_hi(xv);
+    Al[r * PN_AS + k] = f16_lo(xv);
+  }
+  __syncthreads();
+  // ---- pre_mlps
+  for (int l = 0; l < w.n_pre; ++l) {
+    pn_gemm<4>(Ah, Al, l == 0 ? 1 : 4, w.pre_F[l], C, PN_CS, PN_ROWS, wave, lane);
+    __syncthreads();
+    pn_epilogue(C, Ah, Al, w.pre_b[l], nullptr, P, w.pre_lnw[l], w.pre_lnb[l], eps);
+    __syncthreads();
+  }
+  // per-polyline rows (pooled features, then out_mlps' hidden row) as A planes of a 16-row GEMM; they live in
+  // C's memory, which is dead between a max-pool and the next full GEMM
+  _Float16* Ph = reinterpret_cast<_Float16*>(C);
+  _Float16* Pl = Ph + 16 * PN_AS;
+  auto pool_to_planes = [&]() {   // max over the polyline's points of the zero-filled feature buffer (:47, :53)
+    float m[8];   // 16 x 128 values over 256 threads
+    int cnt = 0;
+#pragma unroll
+    for (int i = tid; i < 16 * 128; i += 256, ++cnt) {
+      const int g = i >> 7, col = i & 127;
+      float mm = 0.f;
+      if (g < G)
+        for (int p = 0; p < P; ++p) {
+          const float v = valid[g * P + p] ? C[(g * P + p) * PN_CS + col] : 0.f;
+          mm = p == 0 ? v : fmaxf(mm, v);
+        }
+      m[cnt] = mm;
+    }
+    __syncthreads();   // every thread has read its C values: the planes may overwrite them
+    cnt = 0;
+#pragma unroll
+    for (int i = tid; i < 16 * 128; i += 256, ++cnt) {
+      const int g = i >> 7, col = i & 127;
+      Ph[g * PN_AS + col] = f16_hi(m[cnt]);
+      Pl[g * PN_AS + col] = f16_lo(m[cnt]);
+    }
+    __syncthreads();
+  };
+  pool_to_planes();
+  // ---- mlps: layer 0 consumes cat(point feature, pooled): the pooled half is a per-polyline bias  (:48-50)
+  for (int l = 0; l < w.n_mid; ++l) {
+    if (l == 0) {
+      pn_gemm<1>(Ph, Pl, 4, w.mid_P, pb, 128, PN_G, wave, lane);   // pb[g] = pooled[g] W[128:256]  (+ bias below)
+      __syncthreads();
+      for (int i = tid; i < PN_G * 128; i += 256) pb[i] += w.mid_b[0][i & 127];
+    }
+    pn_gemm<4>(Ah, Al, 4, w.mid_F[l], C, PN_CS, PN_ROWS, wave, lane);
+    __syncthreads();
+    pn_epilogue(C, Ah, Al, w.mid_b[l], l == 0 ? pb : nullptr, P, w.mid_lnw[l], w.mid_lnb[l], eps);
+    __syncthreads();
+  }
+  // max-pool (:53), then out_mlps (:57): Linear, ReLU, Linear on the pooled rows
+  pool_to_planes();
+  pn_gemm<1>(Ph, Pl, 4, w.out_F0, pb, 128, PN_G, wave, lane);
+  __syncthreads();
+  for (int i = tid; i < 16 * 128; i += 256) {
+    const int g = i >> 7, col = i & 127;
+    const float a = g < PN_G ? fmaxf(pb[g * 128 + col] + w.out_b0[col], 0.f) : 0.f;
+    Ph[g * PN_AS + col] = f16_hi(a);
+    Pl[g * PN_AS + col] = f16_lo(a);
+  }
+  __syncthreads();
+  pn_gemm<1>(Ph, Pl, 4, w.out_F1, pb, 128, PN_G, wave, lane);
+  __syncthreads();
+  for (int i = tid; i < G * 128; i += 256) {
+    const int g = i >> 7, col = i & 127;
+    if (g0 + g < n_rows) out[(size_t)(g0 + g) * 128 + col] = pb[i] + w.out_b1[col];
+  }
 }
 
 // ------------------------------------------------------------------------------------------
