@@ -164,7 +164,9 @@ struct Builder {
   // to a multiple of 32: [n-tile 8][k-block][hi|lo][lane 64][8], lane = (n & 15) + 16*kq holds k = 32*ks + 8*kq ..+8
   void fragments(const _Float16** p, const std::string& name, int out, int in, int in0, int in_n) {
     const float* s = get(name, (int64_t)out * in);
-    if (!s) return;
+    if (s) fragments_raw(p, s, out, in, in0, in_n);
+  }
+  void fragments_raw(const _Float16** p, const float* s, int out, int in, int in0, int in_n) {
     const int k32 = (in_n + 31) / 32, nt_n = out / 16;
     std::vector<float> packed(((size_t)nt_n * k32 * 2 * 512 + 1) / 2);
     _Float16* h = reinterpret_cast<_Float16*>(packed.data());
@@ -261,6 +263,12 @@ void build_attn(Builder& b, const std::string& p, AttnW& w) {
   }
   b.slot(&w.vb, b.put(vb));
   b.slot(&w.Wkv_t, b.put(wkv));
+  {   // [to_k ; to_v] as one [256][128] Linear -> B fragments
+    std::vector<float> kvw((size_t)2 * D * D);
+    std::copy(wk, wk + (size_t)D * D, kvw.begin());
+    std::copy(wv, wv + (size_t)D * D, kvw.begin() + (size_t)D * D);
+    b.fragments_raw(&w.Wkv_F, kvw.data(), 2 * D, D, 0, D);
+  }
   b.slot(&w.bkv, b.put(bkv));
   // packed small vectors (ps_attn.h SP_* offsets)
   {
@@ -402,6 +410,8 @@ extern "C" int ps_create(const ps_config* cfg, int32_t n_tensors, const char* co
     // K-major copies of the motion head (reference MLP [128,128,64,out]: seq 0 Lin,1 LN,3 Lin,4 LN,6 Lin)
     const int OUT = cfg->target_steps * cfg->state_dim;
     const std::string mh = pa + ".motion_head.mlp.";
+    b.fragments(&e->head.m0F, mh + "0.weight", D, D, 0, D);
+    b.fragments(&e->head.m1F, mh + "3.weight", D / 2, D, 0, D);
     b.transposed(&e->head.m0t, mh + "0.weight", D, D);
     b.plain(&e->head.m0b, mh + "0.bias", D);
     b.plain(&e->head.m0lnw, mh + "1.weight", D);
@@ -418,11 +428,15 @@ extern "C" int ps_create(const ps_config* cfg, int32_t n_tensors, const char* co
         for (int n = 0; n < OUT && n < 64; ++n) t[(size_t)k * 64 + n] = w2[(size_t)n * 64 + k];
       for (int n = 0; n < OUT && n < 64; ++n) bb[n] = b2[n];
       b.slot(&e->head.m2t, b.put(t));
+      std::vector<float> w2p((size_t)64 * 64, 0.f);   // torch layout [out 64 (zero rows past OUT)][in 64]
+      for (int n = 0; n < OUT && n < 64; ++n) std::copy(w2 + (size_t)n * 64, w2 + (size_t)(n + 1) * 64, w2p.begin() + (size_t)n * 64);
+      b.fragments_raw(&e->head.m2F, w2p.data(), 64, 64, 0, 64);
       b.slot(&e->head.m2b, b.put(bb));
     }
   }
   for (int i = 0; i < 3; ++i) {
     const std::string q = pa + ".CG_decode.CGs." + std::to_string(i) + ".MLP.";
+    b.fragments(&e->head.cgF[i], q + "0.weight", D, D, 0, D);
     b.transposed(&e->head.cgWt[i], q + "0.weight", D, D);
     b.plain(&e->head.cgb[i], q + "0.bias", D);
     b.plain(&e->head.cglnw[i], q + "1.weight", D);
@@ -486,6 +500,7 @@ extern "C" int ps_create(const ps_config* cfg, int32_t n_tensors, const char* co
     return fail(PS_E_HIP, "stream/event creation failed");
   }
   // the chain kernel may use up to ~140 KiB of dynamic LDS
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_kv_proj), hipFuncAttributeMaxDynamicSharedMemorySize, (int)KV_LDS_BYTES);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pointnet_mfma), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PN_LDS_BYTES);
 #define PS_ATTR(TT, NWW, KRR) \
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_chain<TT, NWW, KRR>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
@@ -911,14 +926,8 @@ int launch_chain(ps_engine* e, float* x, int Nd, int step0, int nsteps, int maxd
 
 void launch_kv(ps_engine* e, const float* x, int Ns, int layer0, int nlayers, float* kv, _Float16* khl, size_t layer_stride) {
   if (Ns <= 0 || nlayers <= 0) return;
-  const int T = Ns >= 1024 ? 4 : (Ns >= 512 ? 2 : 1);
-  const AttnW* L = e->d_layers + layer0;
-  if (T == 4)
-    hipLaunchKernelGGL(k_kv_proj<4>, dim3((Ns + 3) / 4, nlayers), dim3(WG), 0, e->stream, x, Ns, L, kv, khl, layer_stride, e->cfg.ln_eps);
-  else if (T == 2)
-    hipLaunchKernelGGL(k_kv_proj<2>, dim3((Ns + 1) / 2, nlayers), dim3(WG), 0, e->stream, x, Ns, L, kv, khl, layer_stride, e->cfg.ln_eps);
-  else
-    hipLaunchKernelGGL(k_kv_proj<1>, dim3(Ns, nlayers), dim3(WG), 0, e->stream, x, Ns, L, kv, khl, layer_stride, e->cfg.ln_eps);
+  hipLaunchKernelGGL(k_kv_proj, dim3((Ns + PN_ROWS - 1) / PN_ROWS, nlayers), dim3(WG), KV_LDS_BYTES, e->stream, x, Ns,
+                     (const AttnW*)(e->d_layers + layer0), kv, khl, layer_stride, e->cfg.ln_eps);
 }
 
 void launch_pointnet(ps_engine* e, const PointNetW& w, const float* pts, const uint8_t* mask, const int* rows, int n_rows,
@@ -1094,7 +1103,7 @@ extern "C" int ps_policy_step(ps_engine* e, int32_t t_idx) {
   const int md = std::max(e->e_a2p.maxdeg, e->e_m2p.maxdeg);
   if (launch_chain(e, e->d_fused.p, A, e->step_pol, 2 * c.pol_layers, md, true)) return PS_E_HIP;
   // _compute_traj + step_agent_traj
-  hipLaunchKernelGGL(k_policy_head, dim3((A + HG - 1) / HG), dim3(128), 0, st, e->head, (const float*)e->d_fused.p,
+  hipLaunchKernelGGL(k_policy_head_mfma, dim3((A + 15) / 16), dim3(256), 0, st, e->head, (const float*)e->d_fused.p,
                      (const int*)e->d_agent_type.p, A, c.motion_k, c.target_steps, c.state_dim, e->d_motion.p + (size_t)t_idx * A * c.target_steps * c.state_dim,
                      e->d_traj.p, e->d_vel.p, e->stride_steps, last, c.replan_freq, c.ln_eps);
   HIPCHK(hipGetLastError());
@@ -1541,7 +1550,7 @@ extern "C" int ps_policy_forward(ps_engine* e, int32_t n_scenes, int32_t Na, con
     std::vector<float> unit((size_t)A * 16 * 4, 0.f);
     for (size_t i = 0; i < (size_t)A * 16; ++i) unit[i * 4 + 3] = 1.f;
     (void)hipMemcpyAsync(d_traj.p, unit.data(), sizeof(float) * unit.size(), hipMemcpyHostToDevice, st);
-    hipLaunchKernelGGL(k_policy_head, dim3((A + HG - 1) / HG), dim3(128), 0, st, e->head, (const float*)d_x.p, (const int*)d_ptype.p, A,
+    hipLaunchKernelGGL(k_policy_head_mfma, dim3((A + 15) / 16), dim3(256), 0, st, e->head, (const float*)d_x.p, (const int*)d_ptype.p, A,
                        c.motion_k, c.target_steps, c.state_dim, d_motion.p, d_traj.p, d_vel.p, 16, 1, 0, c.ln_eps);
     if (hipStreamSynchronize(st) != hipSuccess) rc = fail(PS_E_HIP, "ps_policy_forward: kernel failure");
   }

@@ -35,6 +35,7 @@ struct AttnW {
   const float *ln_post_w, *ln_post_b, *ln_ffpre_w, *ln_ffpre_b;
   const float *W1_t, *b1, *W2_t, *b2, *ln_ffpost_w, *ln_ffpost_b;
   const float *Wkv_t, *bkv;                         // [128][256] K-major (k | v), [256]
+  const _Float16* Wkv_F;                            // the same as split-fp16 MFMA B fragments [n-tile 16][k-block 4][hi|lo][64][8]
   const float* sp;                                  // packed small vectors, SP_* offsets below (2432 floats)
 };
 // offsets (floats) inside AttnW::sp -- one coalesced load per layer stages them in LDS, so no
@@ -757,35 +758,77 @@ __global__ __launch_bounds__(64 * NW, ((T >= 2 && NW == 4) ? 2 : 1)) void k_attn
 }
 
 // k | v projection of source tokens for L layers: kv[l][n][0:128] = Wk LN_src(x_n),
-// kv[l][n][128:256] = Wv LN_src(x_n) + bv   (attention_layer.py:61,65,115-116).  grid (ceil(Ns/T), L).
-template <int T>
+// kv[l][n][128:256] = Wv LN_src(x_n) + bv   (attention_layer.py:61,65,115-116).  grid (ceil(Ns/64), L).
+// 64 rows per workgroup: LayerNorm with a lane quad per row, then two 64 x 128 x 128 GEMMs on the matrix cores
+// (k half, v half; pn_gemm, split-fp16 operands), each written out as whole 512-byte rows; the k half also
+// leaves as split fp16 (hi | lo) for the score MFMAs of k_attn_chain.
+constexpr size_t KV_LDS_BYTES = (size_t)2 * PN_ROWS * PN_AS * 2 + (size_t)PN_ROWS * PN_CS * 4;
 __global__ __launch_bounds__(WG) void k_kv_proj(const float* __restrict__ x, int Ns, const AttnW* __restrict__ layers,
                                                 float* __restrict__ kv, _Float16* __restrict__ khl, size_t layer_stride, float eps) {
-  __shared__ __attribute__((aligned(16))) float xs[T * 128];
-  __shared__ __attribute__((aligned(16))) float xn[T * 128];
-  __shared__ __attribute__((aligned(16))) float part[4 * T * 256];
-  __shared__ __attribute__((aligned(16))) float ob[T * 256];
+  extern __shared__ __attribute__((aligned(16))) unsigned char kv_smem[];
+  _Float16* Ah = reinterpret_cast<_Float16*>(kv_smem);
+  _Float16* Al = Ah + PN_ROWS * PN_AS;
+  float* C = reinterpret_cast<float*>(Al + PN_ROWS * PN_AS);
   const AttnW& w = layers[blockIdx.y];
-  const int row0 = blockIdx.x * T, tid = threadIdx.x;
-  for (int i = tid; i < T * 128; i += WG) {
-    const int r = row0 + (i >> 7);
-    xs[i] = (r < Ns) ? x[(size_t)r * 128 + (i & 127)] : 0.f;
+  const int row0 = blockIdx.x * PN_ROWS, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  {   // LN_src: thread -> (row tid >> 2, 32-column quarter tid & 3)
+    const int r = tid >> 2, c0 = (tid & 3) * 32;
+    float a[32];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row0 + r < Ns) v = ldg4(x + (size_t)(row0 + r) * 128 + c0 + 4 * i);
+      a[4 * i] = v.x; a[4 * i + 1] = v.y; a[4 * i + 2] = v.z; a[4 * i + 3] = v.w;
+    }
+    float sm = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) sm += a[i];
+    sm += dpp_xor1(sm);
+    sm += dpp_xor2(sm);
+    const float mean = sm * (1.f / 128.f);
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      a[i] -= mean;
+      sq = fmaf(a[i], a[i], sq);
+    }
+    sq += dpp_xor1(sq);
+    sq += dpp_xor2(sq);
+    const float rstd = 1.f / sqrtf(sq * (1.f / 128.f) + eps);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      half8 hh, ll;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float v = fmaf(a[8 * i + j] * rstd, w.ln_src_w[c0 + 8 * i + j], w.ln_src_b[c0 + 8 * i + j]);
+        hh[j] = f16_hi(v);
+        ll[j] = f16_lo(v);
+      }
+      *reinterpret_cast<half8*>(Ah + r * PN_AS + c0 + 8 * i) = hh;
+      *reinterpret_cast<half8*>(Al + r * PN_AS + c0 + 8 * i) = ll;
+    }
   }
   __syncthreads();
-  ln_rows<T>(xs, 128, xn, 128, w.ln_src_w, w.ln_src_b, eps, false);
-  __syncthreads();
-  gemv_rows<T, false>(xn, 128, 128, w.Wkv_t, 256, w.bkv, part, ob, 256, false);
   float* out = kv + blockIdx.y * layer_stride;
   _Float16* outh = khl + blockIdx.y * layer_stride;
-  for (int i = tid; i < T * 256; i += WG) {
-    const int r = row0 + (i >> 8), c = i & 255;
-    if (r < Ns) {
-      out[(size_t)r * 256 + c] = ob[i];
-      if (c < 128) {   // k half of the row also as split fp16 (hi | lo) for the score MFMAs
-        outh[(size_t)r * 256 + c] = f16_hi(ob[i]);
-        outh[(size_t)r * 256 + 128 + c] = f16_lo(ob[i]);
+  for (int half = 0; half < 2; ++half) {
+    pn_gemm<4>(Ah, Al, 4, w.Wkv_F + (size_t)half * 8 * 4 * 1024, C, PN_CS, PN_ROWS, wave, lane);
+    __syncthreads();
+    for (int i = tid; i < PN_ROWS * 32; i += WG) {   // 64 rows x 32 float4
+      const int r = i >> 5, c = (i & 31) * 4;
+      if (row0 + r >= Ns) continue;
+      float4 v = *reinterpret_cast<const float4*>(C + r * PN_CS + c);
+      if (half == 1) {
+        v.x += w.bkv[128 + c]; v.y += w.bkv[128 + c + 1]; v.z += w.bkv[128 + c + 2]; v.w += w.bkv[128 + c + 3];
+      }
+      *reinterpret_cast<float4*>(out + (size_t)(row0 + r) * 256 + half * 128 + c) = v;
+      if (half == 0) {
+        typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+        *reinterpret_cast<half4v*>(outh + (size_t)(row0 + r) * 256 + c) = half4v{f16_hi(v.x), f16_hi(v.y), f16_hi(v.z), f16_hi(v.w)};
+        *reinterpret_cast<half4v*>(outh + (size_t)(row0 + r) * 256 + 128 + c) = half4v{f16_lo(v.x), f16_lo(v.y), f16_lo(v.z), f16_lo(v.w)};
       }
     }
+    __syncthreads();
   }
 }
 

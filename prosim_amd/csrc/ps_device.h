@@ -124,53 +124,6 @@ __device__ __forceinline__ void ln_rows(const float* x, int xs, float* y, int ys
   for (int t = wave; t < T; t += 4) ln_row_wave(x + t * xs, y + t * ys, w, b, eps, lane, relu);
 }
 
-// Row-block GEMV: out[t][n] = act(sum_k x[t][k] * Wt[k][n] + bias[n]) for T rows held in LDS.
-// Wt is K-major ([K][N], i.e. the transpose of a torch Linear weight) so a wave reads 1 KiB of
-// contiguous weights per instruction (float4 per lane).  Thread (col4, kg): 4 consecutive
-// columns x a K-slab; the KG partial sums meet in LDS `part` ([KG][T][N]).  N in {128,256,512}.
-// HEADX: x is a per-head image [T][8][QP] and column n reads head n/16 (the to_v_r fold).
-template <int T, bool HEADX>
-__device__ __forceinline__ void gemv_rows(const float* x, int xs, int K, const float* __restrict__ Wt, int N,
-                                          const float* __restrict__ bias, float* part, float* out, int os,
-                                          bool relu) {
-  const int tid = threadIdx.x;
-  const int ncol4 = N >> 2;
-  const int KG = WG / ncol4;
-  const int col4 = tid % ncol4, kg = tid / ncol4;
-  const int klen = K / KG;
-  const int k0 = kg * klen;
-  float acc[T][4];
-#pragma unroll
-  for (int t = 0; t < T; ++t) acc[t][0] = acc[t][1] = acc[t][2] = acc[t][3] = 0.f;
-  const float* wp = Wt + (size_t)k0 * N + 4 * col4;
-  const float* xp = x + k0 + (HEADX ? (col4 >> 2) * QP : 0);
-#pragma unroll 8
-  for (int k = 0; k < klen; ++k) {
-    const float4 w = *reinterpret_cast<const float4*>(wp + (size_t)k * N);
-#pragma unroll
-    for (int t = 0; t < T; ++t) {
-      const float xv = xp[t * xs + k];
-      acc[t][0] = fmaf(xv, w.x, acc[t][0]);
-      acc[t][1] = fmaf(xv, w.y, acc[t][1]);
-      acc[t][2] = fmaf(xv, w.z, acc[t][2]);
-      acc[t][3] = fmaf(xv, w.w, acc[t][3]);
-    }
-  }
-#pragma unroll
-  for (int t = 0; t < T; ++t)
-    *reinterpret_cast<float4*>(part + ((size_t)(kg * T + t)) * N + 4 * col4) =
-        make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
-  __syncthreads();
-  for (int idx = tid; idx < T * N; idx += WG) {
-    const int t = idx / N, n = idx - t * N;
-    float s = bias ? bias[n] : 0.f;
-    for (int g = 0; g < KG; ++g) s += part[((size_t)(g * T + t)) * N + n];
-    if (relu) s = fmaxf(s, 0.f);
-    out[t * os + n] = s;
-  }
-  __syncthreads();
-}
-
 // Small-N GEMV (N not a multiple of 128): one thread per output, torch layout W[N][K].
 template <int T>
 __device__ __forceinline__ void gemv_small(const float* x, int xs, int K, const float* __restrict__ W, int N,
@@ -184,6 +137,61 @@ __device__ __forceinline__ void gemv_small(const float* x, int xs, int K, const 
     out[t * os + n] = s;
   }
   __syncthreads();
+}
+
+// ---- 64-row GEMM on the matrix cores, shared by the PointNet encoder and the k|v projection.
+// Rows live in LDS as split-fp16 planes Ah | Al (row stride PN_AS halfs: 16 B-aligned, staggered over the
+// banks); weights stream from L2 as pre-split B fragments [n-tile][k-block K/32][hi|lo][lane 64][8] (lane =
+// column n + 16*kq holds k = 32*ks + 8*kq ..+8), so a wave load is 1 KB contiguous; hi*hi + hi*lo + lo*hi
+// accumulate in fp32 (the dropped lo*lo term is ~2^-22).  The fp32 result goes to LDS (row stride cs floats).
+constexpr int PN_ROWS = 64, PN_AS = 136, PN_CS = 132;
+// C[16*MT x 128] = A[16*MT x 32*k32] * W: wave w makes the 16-column tiles w and w + 4 (all 16 B-fragment loads
+// of both tiles are in flight before the first MFMA).  Rows >= row_lim are not stored; ntiles < 8 for N < 128.
+template <int MT>
+__device__ __forceinline__ void pn_gemm(const _Float16* __restrict__ Ah, const _Float16* __restrict__ Al, int k32,
+                                        const _Float16* __restrict__ F, float* __restrict__ C, int cs, int row_lim, int wave,
+                                        int lane, int ntiles = 8) {
+  const int mi = lane & 15, kq = lane >> 4;
+  half8 bh[2][4], bl[2][4];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const _Float16* f = F + (size_t)(wave + 4 * t) * k32 * 1024 + lane * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      if (ks < k32 && wave + 4 * t < ntiles) {
+        bh[t][ks] = ldgh8(f + ks * 1024);
+        bl[t][ks] = ldgh8(f + ks * 1024 + 512);
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int nt = wave + 4 * t;
+    if (nt >= ntiles) break;
+    floatx4 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      if (ks < k32) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const half8 ah = *reinterpret_cast<const half8*>(Ah + (mt * 16 + mi) * PN_AS + ks * 32 + kq * 8);
+          const half8 al = *reinterpret_cast<const half8*>(Al + (mt * 16 + mi) * PN_AS + ks * 32 + kq * 8);
+          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[t][ks], acc[mt], 0, 0, 0);
+          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[t][ks], acc[mt], 0, 0, 0);
+          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[t][ks], acc[mt], 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = mt * 16 + 4 * kq + r;
+        if (row < row_lim) C[row * cs + nt * 16 + mi] = acc[mt][r];
+      }
+  }
 }
 
 }  // namespace ps

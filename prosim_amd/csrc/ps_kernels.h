@@ -7,9 +7,8 @@ namespace ps {
 
 // ------------------------------------------------------------------------------------------
 // K1  PointNetPolylineEncoder.forward (prosim/models/scene_encoder/pointnet_encoder.py:24-62)
-// One 128-thread workgroup per VALID polyline; thread = output column; the polyline's points
-// live in registers (acc[PTS]) / LDS.  Masked points contribute 0 to both max-pools
-// (:40-44, :49-53), exactly as the reference's zero-filled scatter buffers do.
+// Masked points contribute 0 to both max-pools (:40-44, :49-53), exactly as the reference's zero-filled
+// scatter buffers do.
 struct PointNetW {
   int in_dim, n_pre, n_mid;             // n_pre = NUM_PRE_LAYERS, n_mid = NUM_MLP_LAYERS - NUM_PRE_LAYERS
   const float* pre_Wt[4];               // [K][128] K-major; K = in_dim for layer 0, else 128
@@ -28,178 +27,16 @@ struct PointNetW {
   const _Float16 *mid_P, *out_F0, *out_F1;   // mlps[0] rows 128..255 (pooled half), out_mlps Linear 0 / 1
 };
 
-template <int PTS>
-__global__ __launch_bounds__(128) void k_pointnet(PointNetW w, const float* __restrict__ pts, const uint8_t* __restrict__ pmask,
-                                                  const int* __restrict__ rows, int n_rows, int P, int feat_mask_dim,
-                                                  float* __restrict__ out, float eps) {
-  // pts [n_total][P][in_dim]; pmask either per point [n_total][P] (feat_mask_dim == 0) or per
-  // feature [n_total][P][feat_mask_dim] (a point is valid iff all features are; obs_encoder.py:84).
-  __shared__ __attribute__((aligned(16))) float xin[PTS * 24];
-  __shared__ __attribute__((aligned(16))) float hb[PTS * 128];
-  __shared__ __attribute__((aligned(16))) float pooled[128];
-  __shared__ int valid[PTS];
-  const int col = threadIdx.x, lane = col & 63, wave = col >> 6;
-  const int row = rows ? rows[blockIdx.x] : blockIdx.x;
-  const int C = w.in_dim;
-  for (int p = col; p < PTS; p += 128) {
-    int v = 0;
-    if (p < P) {
-      if (feat_mask_dim == 0) v = pmask[(size_t)row * P + p];
-      else {
-        v = 1;
-        for (int f = 0; f < feat_mask_dim; ++f) v &= pmask[((size_t)row * P + p) * feat_mask_dim + f];
-      }
-    }
-    valid[p] = v;
-  }
-  __syncthreads();
-  for (int i = col; i < P * C; i += 128) {
-    const int p = i / C;
-    xin[i] = valid[p] ? pts[(size_t)row * P * C + i] : 0.f;
-  }
-  __syncthreads();
-  float acc[PTS];
-  // ---- pre_mlps
-  for (int l = 0; l < w.n_pre; ++l) {
-    const int K = (l == 0) ? C : 128;
-    const float* in = (l == 0) ? xin : hb;
-    const float bias = w.pre_b[l][col];
-#pragma unroll
-    for (int p = 0; p < PTS; ++p) acc[p] = bias;
-    for (int k = 0; k < K; ++k) {
-      const float wv = w.pre_Wt[l][(size_t)k * 128 + col];
-#pragma unroll
-      for (int p = 0; p < PTS; ++p) acc[p] = fmaf(in[p * K + k], wv, acc[p]);
-    }
-    __syncthreads();  // everyone done reading hb
-    const bool has_ln = w.pre_lnw[l] != nullptr;
-#pragma unroll
-    for (int p = 0; p < PTS; ++p) hb[p * 128 + col] = has_ln ? acc[p] : fmaxf(acc[p], 0.f);
-    __syncthreads();
-    if (has_ln) {
-      for (int p = wave; p < P; p += 2) ln_row_wave(hb + p * 128, hb + p * 128, w.pre_lnw[l], w.pre_lnb[l], eps, lane, true);
-      __syncthreads();
-    }
-  }
-  // pooled = max over points of the zero-filled feature buffer (:47)
-  {
-    float m = 0.f;
-    bool any = false;
-    for (int p = 0; p < P; ++p) {
-      const float v = valid[p] ? hb[p * 128 + col] : 0.f;
-      m = any ? fmaxf(m, v) : v;
-      any = true;
-    }
-    pooled[col] = m;
-  }
-  __syncthreads();
-  // ---- mlps: layer 0 consumes cat(point feature, pooled)  (:48-50)
-  for (int l = 0; l < w.n_mid; ++l) {
-    float base = w.mid_b[l][col];
-    const float* Wt = w.mid_Wt[l];
-    if (l == 0) {
-      for (int k = 0; k < 128; ++k) base = fmaf(pooled[k], Wt[(size_t)(128 + k) * 128 + col], base);
-    }
-#pragma unroll
-    for (int p = 0; p < PTS; ++p) acc[p] = (l == 0) ? 0.f : base;
-    for (int k = 0; k < 128; ++k) {
-      const float wv = Wt[(size_t)k * 128 + col];
-#pragma unroll
-      for (int p = 0; p < PTS; ++p) acc[p] = fmaf(hb[p * 128 + k], wv, acc[p]);
-    }
-    if (l == 0) {
-#pragma unroll
-      for (int p = 0; p < PTS; ++p) acc[p] += base;
-    }
-    __syncthreads();
-    const bool has_ln = w.mid_lnw[l] != nullptr;
-#pragma unroll
-    for (int p = 0; p < PTS; ++p) hb[p * 128 + col] = has_ln ? acc[p] : fmaxf(acc[p], 0.f);
-    __syncthreads();
-    if (has_ln) {
-      for (int p = wave; p < P; p += 2) ln_row_wave(hb + p * 128, hb + p * 128, w.mid_lnw[l], w.mid_lnb[l], eps, lane, true);
-      __syncthreads();
-    }
-  }
-  // max-pool (:53), then out_mlps (:57)
-  {
-    float m = 0.f;
-    bool any = false;
-    for (int p = 0; p < P; ++p) {
-      const float v = valid[p] ? hb[p * 128 + col] : 0.f;
-      m = any ? fmaxf(m, v) : v;
-      any = true;
-    }
-    __syncthreads();
-    pooled[col] = m;
-  }
-  __syncthreads();
-  float a = w.out_b0[col];
-  for (int k = 0; k < 128; ++k) a = fmaf(pooled[k], w.out_W0t[(size_t)k * 128 + col], a);
-  hb[col] = fmaxf(a, 0.f);
-  __syncthreads();
-  a = w.out_b1[col];
-  for (int k = 0; k < 128; ++k) a = fmaf(hb[k], w.out_W1t[(size_t)k * 128 + col], a);
-  out[(size_t)blockIdx.x * 128 + col] = a;
-}
-
-// ---- the same encoder on the matrix cores.  A workgroup (4 waves) takes G = 64 / P polylines = up to 64
+// The encoder on the matrix cores.  A workgroup (4 waves) takes G = 64 / P polylines = up to 64
 // point rows.  Every per-point Linear is a [64 x K] x [K x 128] GEMM: the rows live in LDS as split-fp16 planes
 // (A operand, hi | lo), the weights stream from L2 as pre-split B fragments (1 KB contiguous per wave load),
 // and hi*hi + hi*lo + lo*hi accumulate in fp32 (v_mfma_f32_16x16x32_f16; the dropped lo*lo term is ~2^-22).
 // Wave w owns output columns 16*w..+15 and 16*(w+4)..+15 for all four 16-row tiles.  Bias / LayerNorm / ReLU
 // and the two max-pools run on the fp32 result in LDS; the pooled half of mlps[0] and out_mlps are per-polyline
-// GEMVs (VALU).  Replaces one 128-thread workgroup per polyline that re-streamed all weights for 20 rows.
-constexpr int PN_ROWS = 64, PN_AS = 136, PN_CS = 132, PN_G = 8;
+// 16-row GEMMs of the same kind.  (The first version -- one 128-thread workgroup per polyline, VALU, all weights
+// re-streamed for 20 rows -- took 800 us for 8192 map polylines; this one takes 275 us.)
+constexpr int PN_G = 8;   // (PN_ROWS / PN_AS / PN_CS: ps_device.h, shared with the k|v projection)
 constexpr size_t PN_LDS_BYTES = (size_t)2 * PN_ROWS * PN_AS * 2 + (size_t)PN_ROWS * PN_CS * 4 + (size_t)2 * PN_G * 128 * 4 + PN_ROWS * 4;
-
-// C[16*MT x 128] = A[16*MT x 32*k32] * W: wave w makes the 16-column tiles w and w + 4 (all 16 B-fragment loads
-// of both tiles are in flight before the first MFMA).  Rows >= row_lim are not stored.
-template <int MT>
-__device__ __forceinline__ void pn_gemm(const _Float16* __restrict__ Ah, const _Float16* __restrict__ Al, int k32,
-                                        const _Float16* __restrict__ F, float* __restrict__ C, int cs, int row_lim, int wave,
-                                        int lane) {
-  const int mi = lane & 15, kq = lane >> 4;
-  half8 bh[2][4], bl[2][4];
-#pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    const _Float16* f = F + (size_t)(wave + 4 * t) * k32 * 1024 + lane * 8;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      if (ks < k32) {
-        bh[t][ks] = ldgh8(f + ks * 1024);
-        bl[t][ks] = ldgh8(f + ks * 1024 + 512);
-      }
-    }
-  }
-#pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    const int nt = wave + 4 * t;
-    floatx4 acc[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) acc[mt] = floatx4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      if (ks < k32) {
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          const half8 ah = *reinterpret_cast<const half8*>(Ah + (mt * 16 + mi) * PN_AS + ks * 32 + kq * 8);
-          const half8 al = *reinterpret_cast<const half8*>(Al + (mt * 16 + mi) * PN_AS + ks * 32 + kq * 8);
-          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[t][ks], acc[mt], 0, 0, 0);
-          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[t][ks], acc[mt], 0, 0, 0);
-          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[t][ks], acc[mt], 0, 0, 0);
-        }
-      }
-    }
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = mt * 16 + 4 * kq + r;
-        if (row < row_lim) C[row * cs + nt * 16 + mi] = acc[mt][r];
-      }
-  }
-}
 
 // bias (per column, or per polyline and column) + LayerNorm + ReLU (or ReLU alone) on the fp32 rows, which
 // also become the next GEMM's A planes.  All 64 rows at once: thread -> (row tid >> 2, 32-column quarter
@@ -859,9 +696,7 @@ __global__ void k_init_state(const float* __restrict__ obs_input, const int* __r
 
 // ------------------------------------------------------------------------------------------
 // K9-K11  ActDecoder._compute_traj, anchor mode (act_decoder.py:78-140; CG_stacked mlp.py:207-241)
-// fused with step_agent_traj (traj_sam.py:276-349, TOP_K = 1 -> mode 0).  HG agents per 128-thread
-// workgroup, thread = output column, K-major weights (coalesced 512-byte rows shared by the HG rows).
-constexpr int HG = 4;
+// fused with step_agent_traj (traj_sam.py:276-349, TOP_K = 1 -> mode 0).
 struct HeadW {
   const float* anchors;                                   // [K*types][128]
   const float *cgWt[3], *cgb[3], *cglnw[3], *cglnb[3];    // CG_decode.CGs[i].MLP: Linear K-major [128][128] + LN
@@ -869,120 +704,146 @@ struct HeadW {
   const float *m1t, *m1b, *m1lnw, *m1lnb;                 //              128 -> 64  (LN, ReLU), K-major [128][64]
   const float *m2t, *m2b;                                 //              64 -> out, K-major [64][64] (zero-padded)
   Mlp3W motion;                                           // (torch layout, kept for reference/tests)
+  // the six Linears as split-fp16 MFMA B fragments (layout: pn_gemm); m2's output columns are zero-padded to 64
+  const _Float16 *cgF[3], *m0F, *m1F, *m2F;
 };
 
-// out[g][col] = bias[col] + sum_k in[g][k] * Wt[k][col]   (col = threadIdx.x < N)
-template <int G>
-__device__ __forceinline__ void head_dense(const float* in, int in_stride, int K, const float* __restrict__ Wt, int N,
-                                           const float* __restrict__ bias, float (&acc)[G]) {
-  const int col = threadIdx.x;
-  const float b = (col < N) ? ldg1(bias + col) : 0.f;
+// relu(LayerNorm(C[r][0:N] + bias)) for 16 rows, a lane quad per row: thread t < 64 -> row t >> 2, columns
+// (t & 3) * N/4 ..+N/4 returned in a[]
+template <int N>
+__device__ __forceinline__ void head_ln16(const float* __restrict__ C, const float* __restrict__ bias, const float* __restrict__ lw,
+                                          const float* __restrict__ lb, float eps, float (&a)[N / 4]) {
+  const int r = threadIdx.x >> 2, c0 = (threadIdx.x & 3) * (N / 4);
 #pragma unroll
-  for (int g = 0; g < G; ++g) acc[g] = b;
-  if (col < N) {
-#pragma unroll 8
-    for (int k = 0; k < K; ++k) {
-      const float wv = ldg1(Wt + (size_t)k * N + col);
+  for (int i = 0; i < N / 4; ++i) a[i] = C[r * PN_CS + c0 + i] + bias[c0 + i];
+  float sm = 0.f;
 #pragma unroll
-      for (int g = 0; g < G; ++g) acc[g] = fmaf(in[g * in_stride + k], wv, acc[g]);
-    }
+  for (int i = 0; i < N / 4; ++i) sm += a[i];
+  sm += dpp_xor1(sm);
+  sm += dpp_xor2(sm);
+  const float mean = sm * (1.f / (float)N);
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < N / 4; ++i) {
+    a[i] -= mean;
+    sq = fmaf(a[i], a[i], sq);
   }
+  sq += dpp_xor1(sq);
+  sq += dpp_xor2(sq);
+  const float rstd = 1.f / sqrtf(sq * (1.f / (float)N) + eps);
+#pragma unroll
+  for (int i = 0; i < N / 4; ++i) a[i] = fmaxf(fmaf(a[i] * rstd, lw[c0 + i], lb[c0 + i]), 0.f);
 }
 
-__global__ __launch_bounds__(128) void k_policy_head(HeadW w, const float* __restrict__ fused, const int* __restrict__ agent_type,
-                                                    int n_agents, int motion_k, int steps, int sdim, float* __restrict__ motion_pred,
-                                                    float* __restrict__ traj, float* __restrict__ vel, int stride_steps, int last,
-                                                    int replan, float eps) {
-  __shared__ float ctx[HG][128], inp[HG][128], a[HG][128], b[HG][128];
+// On the matrix cores: 16 agents per 256-thread workgroup, every Linear a 16-row split-fp16
+// GEMM (pn_gemm<1>) against pre-split weight fragments; the LayerNorms take a lane quad per row (64 threads).
+__global__ __launch_bounds__(256) void k_policy_head_mfma(HeadW w, const float* __restrict__ fused, const int* __restrict__ agent_type,
+                                                         int n_agents, int motion_k, int steps, int sdim,
+                                                         float* __restrict__ motion_pred, float* __restrict__ traj,
+                                                         float* __restrict__ vel, int stride_steps, int last, int replan, float eps) {
+  __shared__ __attribute__((aligned(16))) _Float16 Ah[16 * PN_AS], Al[16 * PN_AS];
+  __shared__ __attribute__((aligned(16))) float C[16 * PN_CS], ctx[16 * PN_CS], inp[16 * PN_CS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int ag0 = blockIdx.x * HG;
-  for (int g = 0; g < HG; ++g) {
+  const int ag0 = blockIdx.x * 16;
+  for (int i = tid; i < 16 * 128; i += 256) {
+    const int g = i >> 7, c = i & 127;
     const int ag = ag0 + g < n_agents ? ag0 + g : n_agents - 1;
-    ctx[g][tid] = fused[(size_t)ag * 128 + tid];
-    a[g][tid] = w.anchors[(size_t)((agent_type[ag] - 1) * motion_k) * 128 + tid];   // K = 1: anchor row of the type
+    ctx[g * PN_CS + c] = fused[(size_t)ag * 128 + c];
+    const float av = w.anchors[(size_t)((agent_type[ag] - 1) * motion_k) * 128 + c];   // K = 1: anchor row of the type
+    Ah[g * PN_AS + c] = f16_hi(av);
+    Al[g * PN_AS + c] = f16_lo(av);
   }
   __syncthreads();
-  float acc[HG];
   // CG_stacked(3) with K = 1: max over the mode dim is the identity
   for (int i = 0; i < 3; ++i) {
-    head_dense<HG>(i == 0 ? &a[0][0] : &inp[0][0], 128, 128, w.cgWt[i], 128, w.cgb[i], acc);
-#pragma unroll
-    for (int g = 0; g < HG; ++g) b[g][tid] = acc[g];
+    pn_gemm<1>(Ah, Al, 4, w.cgF[i], C, PN_CS, 16, wave, lane);
     __syncthreads();
-    for (int g = wave; g < HG; g += 2) ln_row_wave(b[g], b[g], w.cglnw[i], w.cglnb[i], eps, lane, true);
-    __syncthreads();
+    if (tid < 64) {
+      float a[32];
+      const int r = tid >> 2, c0 = (tid & 3) * 32;
+      head_ln16<128>(C, w.cgb[i], w.cglnw[i], w.cglnb[i], eps, a);
 #pragma unroll
-    for (int g = 0; g < HG; ++g) {
-      const float y = b[g][tid] * ctx[g][tid];
-      if (i == 0) {
-        inp[g][tid] = y;
-        ctx[g][tid] = y;
-      } else {
-        inp[g][tid] = (inp[g][tid] * (float)i + y) / (float)(i + 1);
-        ctx[g][tid] = (ctx[g][tid] * (float)i + y) / (float)(i + 1);
+      for (int j = 0; j < 32; ++j) {
+        const float y = a[j] * ctx[r * PN_CS + c0 + j];
+        float ni, nc;
+        if (i == 0) {
+          ni = y;
+          nc = y;
+        } else {
+          ni = (inp[r * PN_CS + c0 + j] * (float)i + y) / (float)(i + 1);
+          nc = (ctx[r * PN_CS + c0 + j] * (float)i + y) / (float)(i + 1);
+        }
+        inp[r * PN_CS + c0 + j] = ni;
+        ctx[r * PN_CS + c0 + j] = nc;
+        Ah[r * PN_AS + c0 + j] = f16_hi(ni);
+        Al[r * PN_AS + c0 + j] = f16_lo(ni);
       }
     }
     __syncthreads();
   }
   // motion_head: 128 -> 128 (LN, ReLU) -> 64 (LN, ReLU) -> steps*sdim
-  head_dense<HG>(&inp[0][0], 128, 128, w.m0t, 128, w.m0b, acc);
-#pragma unroll
-  for (int g = 0; g < HG; ++g) a[g][tid] = acc[g];
+  pn_gemm<1>(Ah, Al, 4, w.m0F, C, PN_CS, 16, wave, lane);
   __syncthreads();
-  for (int g = wave; g < HG; g += 2) ln_row_wave(a[g], a[g], w.m0lnw, w.m0lnb, eps, lane, true);
-  __syncthreads();
-  head_dense<HG>(&a[0][0], 128, 128, w.m1t, 64, w.m1b, acc);
   if (tid < 64) {
+    float a[32];
+    const int r = tid >> 2, c0 = (tid & 3) * 32;
+    head_ln16<128>(C, w.m0b, w.m0lnw, w.m0lnb, eps, a);
 #pragma unroll
-    for (int g = 0; g < HG; ++g) b[g][tid] = acc[g];
+    for (int j = 0; j < 32; ++j) {
+      Ah[r * PN_AS + c0 + j] = f16_hi(a[j]);
+      Al[r * PN_AS + c0 + j] = f16_lo(a[j]);
+    }
   }
   __syncthreads();
-  for (int g = wave; g < HG; g += 2) {   // LayerNorm over 64 features by one wave
-    const float v = b[g][lane];
-    const float mean = wave_sum(v) * (1.f / 64.f);
-    const float d = v - mean;
-    const float var = wave_sum(d * d) * (1.f / 64.f);
-    b[g][lane] = fmaxf(fmaf(d * (1.f / sqrtf(var + eps)), w.m1lnw[lane], w.m1lnb[lane]), 0.f);
-  }
+  pn_gemm<1>(Ah, Al, 4, w.m1F, C, PN_CS, 16, wave, lane, 4);
   __syncthreads();
-  head_dense<HG>(&b[0][0], 128, 64, w.m2t, 64, w.m2b, acc);
   if (tid < 64) {
+    float a[16];
+    const int r = tid >> 2, c0 = (tid & 3) * 16;
+    head_ln16<64>(C, w.m1b, w.m1lnw, w.m1lnb, eps, a);
 #pragma unroll
-    for (int g = 0; g < HG; ++g) a[g][tid] = acc[g];
+    for (int j = 0; j < 16; ++j) {
+      Ah[r * PN_AS + c0 + j] = f16_hi(a[j]);
+      Al[r * PN_AS + c0 + j] = f16_lo(a[j]);
+    }
   }
   __syncthreads();
-  // cumsum over steps of (dx, dy, dtheta); wrap theta (act_decoder.py:117-121); one thread per agent
-  if (tid < HG && ag0 + tid < n_agents) {
-    const int ag = ag0 + tid;
-    const float* o = a[tid];
+  pn_gemm<1>(Ah, Al, 2, w.m2F, C, PN_CS, 16, wave, lane, 4);
+  __syncthreads();
+  // cumsum over steps of (dx, dy, dtheta); wrap theta (act_decoder.py:117-121).  One thread per (agent, step):
+  // it re-adds the prefix in step order, so the sums round exactly like the sequential scan.
+  for (int i = tid; i < 16 * steps; i += 256) {
+    const int g = i / steps, s = i - g * steps, ag = ag0 + g;
+    if (ag >= n_agents) continue;
+    const float* o = C + g * PN_CS;
     float cx = 0.f, cy = 0.f, ch = 0.f;
-    float* mp = motion_pred + (size_t)ag * motion_k * steps * sdim;
-    const float* cur = traj + ((size_t)ag * stride_steps + last - 1) * 4;
-    const float c0 = cur[0], c1 = cur[1];
-    const float lth = atan2f(cur[2], cur[3]);
-    const float cl = cosf(lth), sl = sinf(lth);
-    for (int s = 0; s < steps; ++s) {
-      cx += o[s * sdim];
-      cy += o[s * sdim + 1];
-      ch += o[s * sdim + 2];
-      const float hh = wrap_angle(ch);
-      mp[s * sdim] = cx;
-      mp[s * sdim + 1] = cy;
-      mp[s * sdim + 2] = hh;
-      for (int f = 3; f < sdim; ++f) mp[s * sdim + f] = o[s * sdim + f];
-      if (s < replan) {
-        // step_agent_traj (traj_sam.py:322-347): rotate into the agent-init frame, append
-        float* t = traj + ((size_t)ag * stride_steps + last + s) * 4;
-        float* v = vel + ((size_t)ag * stride_steps + last + s) * 2;
-        t[0] = (cx * cl - cy * sl) + c0;
-        t[1] = (cy * cl + cx * sl) + c1;
-        const float pth = wrap_angle(lth + hh);
-        t[2] = sinf(pth);
-        t[3] = cosf(pth);
-        const float vx = o[s * sdim + 3], vy = o[s * sdim + 4];
-        v[0] = vx * cl - vy * sl;
-        v[1] = vy * cl + vx * sl;
-      }
+    for (int j = 0; j <= s; ++j) {
+      cx += o[j * sdim] + w.m2b[j * sdim];
+      cy += o[j * sdim + 1] + w.m2b[j * sdim + 1];
+      ch += o[j * sdim + 2] + w.m2b[j * sdim + 2];
+    }
+    const float hh = wrap_angle(ch);
+    float* mp = motion_pred + (size_t)ag * motion_k * steps * sdim + s * sdim;
+    mp[0] = cx;
+    mp[1] = cy;
+    mp[2] = hh;
+    for (int f = 3; f < sdim; ++f) mp[f] = o[s * sdim + f] + w.m2b[s * sdim + f];
+    if (s < replan) {
+      // step_agent_traj (traj_sam.py:322-347): rotate into the agent-init frame, append
+      const float* cur = traj + ((size_t)ag * stride_steps + last - 1) * 4;
+      const float c0 = cur[0], c1 = cur[1];
+      const float lth = atan2f(cur[2], cur[3]);
+      const float cl = cosf(lth), sl = sinf(lth);
+      float* t = traj + ((size_t)ag * stride_steps + last + s) * 4;
+      float* v = vel + ((size_t)ag * stride_steps + last + s) * 2;
+      t[0] = (cx * cl - cy * sl) + c0;
+      t[1] = (cy * cl + cx * sl) + c1;
+      const float pth = wrap_angle(lth + hh);
+      t[2] = sinf(pth);
+      t[3] = cosf(pth);
+      const float vx = o[s * sdim + 3] + w.m2b[s * sdim + 3], vy = o[s * sdim + 4] + w.m2b[s * sdim + 4];
+      v[0] = vx * cl - vy * sl;
+      v[1] = vy * cl + vx * sl;
     }
   }
 }
