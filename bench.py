@@ -202,8 +202,14 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "k_attn_chain (policy: 12 fused attention layers per launch)",
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                          "traffic_note": "HBM bytes per launch, FETCH_SIZE+WRITE_SIZE lower bound (profiles/r01_pmc_policy_chain.json)",
+                         "note": "achieved = ALGORITHMIC FLOPs of the reference formulation (SURVEY.md section 8(d)) / launch time; the "
+                                 "kernel factors the per-edge to_k_r / to_v_r GEMVs out (DESIGN.md section 4) and executes 7.7x fewer, so "
+                                 "frac can exceed 1 and is not hardware utilisation: see executed_frac.  The launch is latency-bound "
+                                 "(DESIGN.md section 4), neither MFMA- nor HBM-bound; HBM side: traffic / avg_launch_ms.",
                          "algorithmic_flops_per_launch": fl_alg, "executed_flops_per_launch": fl_exe,
-                         "executed_tflops": fl_exe / (ms_chain * 1e-3) / 1e12, "avg_launch_ms": ms_chain,
+                         "executed_tflops": fl_exe / (ms_chain * 1e-3) / 1e12, "executed_frac": fl_exe / (ms_chain * 1e-3) / 1e12 / peak,
+                         "hbm_gbps": (traffic / (ms_chain * 1e-3) / 1e9) if traffic else None, "hbm_peak_gbps": 8000.0,
+                         "avg_launch_ms": ms_chain,
                          "edges_per_launch": {"a2p": float(ec[4]), "m2p": float(ec[5])}},
             "stage_ms": {"rollout_events": ms_roll, "encode_scene": stages[0], "generate_policy": stages[1], "replan_loop": stages[2]},
             "single_scene": {"ms_per_rollout": ms_single, "agent_steps_per_s": A1 * spec.max_steps / (ms_single * 1e-3),
