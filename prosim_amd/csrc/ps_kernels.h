@@ -451,44 +451,74 @@ __global__ __launch_bounds__(256) void k_relpe_tiles(const int* __restrict__ esr
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ntiles = toff[nq];
   // The 128 features are 64 (sin, cos) pairs: input dist | rel_ori | angle | angle again, 16 frequencies each
-  // (div32[2i] == div32[2i+1], fourier_embedding.py:68-69).  Lane l makes pair l = features 2l, 2l+1 with ONE
-  // sincosf (one argument reduction; a per-feature sinf/cosf select would run both branches in every lane).
-  const int inp = lane >> 4;
-  const float dv = div32[2 * (lane & 15)];
+  // (div32[2i] == div32[2i+1], fourier_embedding.py:68-69); a pair is ONE sincosf (one argument reduction; a
+  // per-feature sinf/cosf select would run both branches in every lane).
+  const int sub = lane & 7;
+  float dvv[8];   // this lane's 8 frequencies: pairs 8*(sub & 1) ..+7 of its input block
+#pragma unroll
+  for (int j = 0; j < 8; ++j) dvv[j] = div32[2 * ((sub & 1) * 8 + j)];
+  __shared__ float geo[32][4];   // (dist, rel_ori, angle) of the tile's edges
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int d = tdst[tile];
     const int e0 = eoff[d] + (tile - toff[d]) * 32;
     const int n = min(32, eoff[d + 1] - e0);
-    const float px = dst_pos[2 * d], py = dst_pos[2 * d + 1], od = dst_ori[d];
-    const float cx = cosf(od), cy = sinf(od);
-    __syncthreads();   // the previous tile's image writes are done with buf
-#pragma unroll 2
-    for (int i = 0; i < 8; ++i) {
-      const int r = wave * 8 + i;
-      float y0 = 0.f, y1 = 0.f;
+    __syncthreads();   // the previous tile's image writes are done with buf / geo
+    // the 4 scalars of every edge of the tile at once (one lane per edge: ONE dependent gather chain per tile,
+    // not one per edge), act_decoder.py:203-217
+    if (tid < n) {
+      const float px = dst_pos[2 * d], py = dst_pos[2 * d + 1], od = dst_ori[d];
+      const float cx = cosf(od), cy = sinf(od);
+      const int s = esrc[e0 + tid];
+      const float dx = src_pos[2 * s] - px, dy = src_pos[2 * s + 1] - py;
+      geo[tid][0] = sqrtf(dx * dx + dy * dy);
+      geo[tid][1] = wrap_angle(src_ori[s] - od);
+      // torch's .sum(dim=-1) accumulates from +0, so a dot of (-0, -0) is +0 there: keep the explicit
+      // 0.f + ... (IEEE forbids folding it) or self-loop edges would see atan2(+-0, -0) = +-pi.
+      const float dot = (0.f + cx * dx) + cy * dy;
+      geo[tid][2] = atan2f(cx * dy - cy * dx, dot);
+    }
+    __syncthreads();
+    // features: lane -> (edge lane >> 3 of the wave's 8, pair group lane & 7 = 8 consecutive (sin, cos) pairs = 16
+    // features); the 8 edges of a wave advance together and the LayerNorm sums meet inside 8 lanes
+    {
+      const int r = wave * 8 + (lane >> 3);
+      float f[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) f[j] = 0.f;
       if (r < n) {
-        const int s = esrc[e0 + r];
-        const float dx = src_pos[2 * s] - px, dy = src_pos[2 * s + 1] - py;
-        const float dist = sqrtf(dx * dx + dy * dy);
-        const float rel_ori = wrap_angle(src_ori[s] - od);
-        // torch's .sum(dim=-1) accumulates from +0, so a dot of (-0, -0) is +0 there: keep the explicit
-        // 0.f + ... (IEEE forbids folding it) or self-loop edges would see atan2(+-0, -0) = +-pi.
-        const float dot = (0.f + cx * dx) + cy * dy;
-        const float ang = atan2f(cx * dy - cy * dx, dot);
-        const float xin = inp == 0 ? dist : (inp == 1 ? rel_ori : ang);
-        const float v = (xin * PS_TWO_PI_F) / dv;
-        float f0, f1;
-        sincosf(v, &f0, &f1);
-        const float mean = wave_sum(f0 + f1) * (1.f / 128.f);
-        const float d0 = f0 - mean, d1 = f1 - mean;
-        const float var = wave_sum(d0 * d0 + d1 * d1) * (1.f / 128.f);
-        const float rstd = 1.f / sqrtf(var + eps);
-        y0 = d0 * rstd;
-        y1 = d1 * rstd;
+        const float xin = geo[r][sub < 4 ? (sub >> 1) : 2];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sincosf((xin * PS_TWO_PI_F) / dvv[j], &f[2 * j], &f[2 * j + 1]);
       }
-      typedef _Float16 half2v __attribute__((ext_vector_type(2)));
-      *reinterpret_cast<half2v*>(&buf[r][2 * lane]) = half2v{f16_hi(y0), f16_hi(y1)};
-      *reinterpret_cast<half2v*>(&buf[r][128 + 2 * lane]) = half2v{f16_lo(y0), f16_lo(y1)};
+      float sm = 0.f;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) sm += f[j];
+      sm += dpp_xor1(sm);
+      sm += dpp_xor2(sm);
+      sm += __shfl_xor(sm, 4);
+      const float mean = sm * (1.f / 128.f);
+      float sq = 0.f;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        f[j] -= mean;
+        sq = fmaf(f[j], f[j], sq);
+      }
+      sq += dpp_xor1(sq);
+      sq += dpp_xor2(sq);
+      sq += __shfl_xor(sq, 4);
+      const float rstd = (r < n) ? 1.f / sqrtf(sq * (1.f / 128.f) + eps) : 0.f;
+      half8 h0, h1, l0, l1;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float y0 = f[j] * rstd, y1 = f[8 + j] * rstd;
+        h0[j] = f16_hi(y0); l0[j] = f16_lo(y0);
+        h1[j] = f16_hi(y1); l1[j] = f16_lo(y1);
+      }
+      _Float16* br = &buf[r][0];
+      *reinterpret_cast<half8*>(br + 16 * sub) = h0;
+      *reinterpret_cast<half8*>(br + 16 * sub + 8) = h1;
+      *reinterpret_cast<half8*>(br + 128 + 16 * sub) = l0;
+      *reinterpret_cast<half8*>(br + 128 + 16 * sub + 8) = l1;
     }
     __syncthreads();
     // columns 96..127 repeat 64..95 (the angle enters the embedding twice): neither image stores them, the
