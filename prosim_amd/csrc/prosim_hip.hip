@@ -860,7 +860,8 @@ extern "C" int ps_set_future_obs(ps_engine* e, const float* fut_input) {
 namespace {
 
 int launch_chain(ps_engine* e, float* x, int Nd, int step0, int nsteps, int maxdeg, bool timed = false,
-                 const ChainStep* steps_override = nullptr, int force_T = 0, int kr_override = 0) {
+                 const ChainStep* steps_override = nullptr, int force_T = 0, int kr_override = 0, const float* x_in = nullptr) {
+  if (!x_in) x_in = x;   // in place unless the caller has the input rows elsewhere (saves a copy launch)
   // rel-PE width of the launch's steps: condition steps (and the test hook's arbitrary rows) use all 128 columns
   const int steps_host_kr = kr_override ? kr_override : (steps_override ? 3 : e->h_steps[step0].kr);
   const ChainStep* steps = steps_override ? steps_override : e->d_steps.p + step0;
@@ -890,7 +891,7 @@ int launch_chain(ps_engine* e, float* x, int Nd, int step0, int nsteps, int maxd
                lds2 = attn_lds_floats<2>(maxdeg) * sizeof(float), lds1 = attn_lds_floats<1>(maxdeg) * sizeof(float);
   const int kr = steps_host_kr;   // every step of a launch has the same rel-PE width
 #define PS_LAUNCH(TT, NWW, KRR, GRID, LDS) \
-  hipLaunchKernelGGL((k_attn_chain<TT, NWW, KRR>), dim3(GRID), dim3(64 * NWW), LDS, st, x, Nd, steps, nsteps, maxdeg, eps, flags, prof)
+  hipLaunchKernelGGL((k_attn_chain<TT, NWW, KRR>), dim3(GRID), dim3(64 * NWW), LDS, st, x, x_in, Nd, steps, nsteps, maxdeg, eps, flags, prof)
   if (kr == 3) {
     if (T == 84) PS_LAUNCH(4, 8, 3, (Nd + 3) / 4, lds84);
     else if (T == 4) PS_LAUNCH(4, 4, 3, (Nd + 3) / 4, lds4);
@@ -1084,13 +1085,13 @@ extern "C" int ps_policy_step(ps_engine* e, int32_t t_idx) {
   // step_env (traj_sam.py:205-274)
   hipLaunchKernelGGL(k_step_env, dim3(A), dim3(64), 0, st, (const float*)e->d_traj.p, (const float*)e->d_vel.p, e->stride_steps, last,
                      c.hist_steps, c.dt, (const float*)e->d_init_pos.p, (const float*)e->d_init_head.p, stat, c.obs_dim, e->d_obs_in.p,
-                     e->d_cur_pos.p, e->d_cur_ori.p, t_idx > 0 ? 1 : 0);
+                     e->d_cur_pos.p, e->d_cur_ori.p, t_idx > 0 ? 1 : 0, t_idx > 0 ? e->d_tok_pos.p + 2 * (size_t)Mv : (float*)nullptr,
+                     t_idx > 0 ? e->d_tok_ori.p + Mv : (float*)nullptr);
   float* atok = e->d_tok.p + (size_t)Mv * D;
   if (t_idx > 0) {
     // update_scene_emb / _replace_old_obs (attn_fusion.py:205-250): re-encode agents, swap tokens + poses
+    // (k_step_env already moved the agents' token poses)
     launch_pointnet(e, e->pn_obs, e->d_obs_in.p, (const uint8_t*)nullptr, (const int*)nullptr, A, c.hist_steps, -1, atok);
-    HIPCHK(hipMemcpyAsync(e->d_tok_pos.p + 2 * (size_t)Mv, e->d_cur_pos.p, sizeof(float) * 2 * A, hipMemcpyDeviceToDevice, st));
-    HIPCHK(hipMemcpyAsync(e->d_tok_ori.p + Mv, e->d_cur_ori.p, sizeof(float) * A, hipMemcpyDeviceToDevice, st));
   }
   // policy.forward (policy/base.py:19 -> temporal_ar.py:75 -> act_decoder.py:239-283)
   launch_kv(e, atok, A, e->L_a2p, c.pol_layers, e->d_kv_a2p.p, e->d_kh_a2p.p, (size_t)A * 256);
@@ -1099,9 +1100,9 @@ extern "C" int ps_policy_step(ps_engine* e, int32_t t_idx) {
                 e->d_tok_ori.p, e->d_cur_ori.p);
   launch_radius(e, e->e_m2p, e->d_r_map.p, nullptr, e->d_cur_pos.p, pscene, A, c.pol_map_radius, c.pol_max_neigh, -1,
                 e->d_tok_ori.p, e->d_cur_ori.p);
-  HIPCHK(hipMemcpyAsync(e->d_fused.p, e->d_emd.p, sizeof(float) * (size_t)A * D, hipMemcpyDeviceToDevice, st));
   const int md = std::max(e->e_a2p.maxdeg, e->e_m2p.maxdeg);
-  if (launch_chain(e, e->d_fused.p, A, e->step_pol, 2 * c.pol_layers, md, true)) return PS_E_HIP;
+  // the policy tokens enter every replan unchanged (d_emd); the fused features leave to d_fused
+  if (launch_chain(e, e->d_fused.p, A, e->step_pol, 2 * c.pol_layers, md, true, nullptr, 0, 0, e->d_emd.p)) return PS_E_HIP;
   // _compute_traj + step_agent_traj
   hipLaunchKernelGGL(k_policy_head_mfma, dim3((A + 15) / 16), dim3(256), 0, st, e->head, (const float*)e->d_fused.p,
                      (const int*)e->d_agent_type.p, A, c.motion_k, c.target_steps, c.state_dim, e->d_motion.p + (size_t)t_idx * A * c.target_steps * c.state_dim,

@@ -166,8 +166,8 @@ __device__ __forceinline__ void fold_kgroups(float (&acc)[T][4]) {
 // KR: distinct rel-PE column blocks of 32 (3 for geometric edge sets, 4 for condition rows / the test hook); a
 // launch only ever chains steps of one kind, so it is a compile-time parameter (ChainStep::kr must agree).
 template <int T, int NW = 4, int KR = 3>
-__global__ __launch_bounds__(64 * NW, ((T >= 2 && NW == 4) ? 2 : 1)) void k_attn_chain(float* __restrict__ x, int Nd, const ChainStep* __restrict__ steps,
-                                                     int nsteps, int maxdeg, float eps, int flags,
+__global__ __launch_bounds__(64 * NW, ((T >= 2 && NW == 4) ? 2 : 1)) void k_attn_chain(float* __restrict__ x, const float* __restrict__ x_in, int Nd,
+                                                     const ChainStep* __restrict__ steps, int nsteps, int maxdeg, float eps, int flags,
                                                      unsigned long long* __restrict__ prof) {
   // phase clocks for tools/gpu_phase.py (prof == nullptr in every product launch): thread 0 of each
   // workgroup charges the core-clock cycles since the previous mark to phase i
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(64 * NW, ((T >= 2 && NW == 4) ? 2 : 1)) void k_attn
   // load the T residual rows (rows past Nd are zero-filled and never stored)
   for (int i = tid_o; i < T * 128; i += NT) {
     const int t = i >> 7, r = row0 + t;
-    xs[i] = (r < Nd) ? ldg1(x + (size_t)r * 128 + (i & 127)) : 0.f;
+    xs[i] = (r < Nd) ? ldg1(x_in + (size_t)r * 128 + (i & 127)) : 0.f;   // rows come from x_in, leave to x
   }
   sp_store(spb);
   __syncthreads();

@@ -670,16 +670,23 @@ __global__ __launch_bounds__(64) void k_step_env(const float* __restrict__ traj,
                                                  int last, int hist, float dt, const float* __restrict__ init_pos,
                                                  const float* __restrict__ init_head, const float* __restrict__ static_in,
                                                  int obs_dim, float* __restrict__ obs_in, float* __restrict__ cur_pos,
-                                                 float* __restrict__ cur_ori, int write_obs) {
+                                                 float* __restrict__ cur_ori, int write_obs, float* __restrict__ tok_pos,
+                                                 float* __restrict__ tok_ori) {
   const int a = blockIdx.x, tid = threadIdx.x;
   const float* tr = traj + (size_t)a * stride_steps * 4;
   const float* vl = vel + (size_t)a * stride_steps * 2;
   const float lx = tr[(last - 1) * 4], ly = tr[(last - 1) * 4 + 1];
   const float th_last = atan2f(tr[(last - 1) * 4 + 2], tr[(last - 1) * 4 + 3]);
   if (tid == 0) {
-    cur_pos[2 * a] = init_pos[2 * a] + lx;
-    cur_pos[2 * a + 1] = init_pos[2 * a + 1] + ly;
-    cur_ori[a] = wrap_angle(th_last + init_head[a]);
+    const float cpx = init_pos[2 * a] + lx, cpy = init_pos[2 * a + 1] + ly, cor = wrap_angle(th_last + init_head[a]);
+    cur_pos[2 * a] = cpx;
+    cur_pos[2 * a + 1] = cpy;
+    cur_ori[a] = cor;
+    if (tok_pos) {   // update_scene_emb (attn_fusion.py:205-250): the agents' scene tokens move with them
+      tok_pos[2 * a] = cpx;
+      tok_pos[2 * a + 1] = cpy;
+      tok_ori[a] = cor;
+    }
   }
   if (!write_obs) return;
   __shared__ float rvx[16], rvy[16];
