@@ -869,7 +869,8 @@ int launch_chain(ps_engine* e, float* x, int Nd, int step0, int nsteps, int maxd
   // rows per workgroup (T).  More rows per workgroup share each weight load; the T >= 2 kernels are built for
   // two workgroups per CU (<= 256 registers, <= 78 KB LDS) so a co-resident workgroup hides latency: take the
   // largest T that still leaves >= 2 workgroups per CU.  Measured on the 1024-agent policy launch: T=2 (512
-  // WGs) 645 us, T=4 (256 WGs) 770 us, 4 rows on one 8-wave workgroup per CU (code 84) 733 us.
+  // WGs) 541 us, T=4 (256 WGs) 770 us, 4 rows on one 8-wave workgroup per CU (code 84) 733 us; the one-workgroup-
+  // per-CU builds with register prefetch (BIG) at T=2 / T=4: 1005 / 879 us (they spill even with 512 registers).
   int T = Nd >= 2048 ? 4 : (Nd >= 512 ? 2 : 1);
   static const int env_T = getenv("PS_CHAIN_T") ? atoi(getenv("PS_CHAIN_T")) : 0;   // experiments only
   if (env_T && Nd >= 512) T = env_T;

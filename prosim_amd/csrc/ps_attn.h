@@ -165,8 +165,11 @@ __device__ __forceinline__ void fold_kgroups(float (&acc)[T][4]) {
 
 // KR: distinct rel-PE column blocks of 32 (3 for geometric edge sets, 4 for condition rows / the test hook); a
 // launch only ever chains steps of one kind, so it is a compile-time parameter (ChainStep::kr must agree).
-template <int T, int NW = 4, int KR = 3>
-__global__ __launch_bounds__(64 * NW, ((T >= 2 && NW == 4) ? 2 : 1)) void k_attn_chain(float* __restrict__ x, const float* __restrict__ x_in, int Nd,
+// BIG: compiled for ONE workgroup per CU with the whole register file (512 per lane): weight chunks and edge
+// rows are software-prefetched into second register sets.  !BIG (T >= 2 default): two workgroups per CU, <= 256
+// registers, the co-resident workgroup hides latency instead.
+template <int T, int NW = 4, int KR = 3, bool BIG = (T == 1)>
+__global__ __launch_bounds__(64 * NW, ((!BIG && NW == 4) ? 2 : 1)) void k_attn_chain(float* __restrict__ x, const float* __restrict__ x_in, int Nd,
                                                      const ChainStep* __restrict__ steps, int nsteps, int maxdeg, float eps, int flags,
                                                      unsigned long long* __restrict__ prof) {
   // phase clocks for tools/gpu_phase.py (prof == nullptr in every product launch): thread 0 of each
@@ -195,8 +198,8 @@ __global__ __launch_bounds__(64 * NW, ((T >= 2 && NW == 4) ? 2 : 1)) void k_attn
   // T == 1: one workgroup per CU with the full register file -> software prefetch (weights one chunk ahead,
   // edge rows one tile ahead).  T >= 2: compiled for 2 workgroups per CU (__launch_bounds__(256, 2), <= 256
   // registers): the co-resident workgroup hides the latency instead and nothing is double-buffered.
-  constexpr bool PF = (T == 1);                // weight chunks one stage ahead (second register set; spills at T >= 2)
-  constexpr bool PFE = (T == 1);               // edge rows one tile ahead
+  constexpr bool PF = BIG;                     // weight chunks one stage ahead (second register set)
+  constexpr bool PFE = BIG;                    // edge rows one tile ahead
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* xs = smem;                 // [T][128] residual stream
   float* xn = xs + 128 * T;         // [T][128] normed / scratch row
