@@ -940,29 +940,59 @@ void launch_pointnet(ps_engine* e, const PointNetW& w, const float* pts, const u
                      feat_mask_dim, out, e->cfg.ln_eps);
 }
 
-// rel-PE of an edge set as the two MFMA operand images (device-side tile count, grid-stride over tiles)
+// rel-PE of one or two edge sets as the MFMA operand images (device-side tile counts, grid-stride over tiles)
+struct PeArgs {
+  EdgeSet* es;
+  const float *src_ori, *dst_pos, *dst_ori;
+};
+void launch_relpe(ps_engine* e, const PeArgs* a, int nsets) {
+  PeSets ps{};
+  size_t grid = 1;
+  for (int i = 0; i < nsets; ++i) {
+    EdgeSet& es = *a[i].es;
+    ps.s[i] = PeSet{es.esrc.p, es.eoff.p, es.toff.p, es.tdst.p, es.nq, a[i].src_ori, a[i].dst_pos, a[i].dst_ori, es.rtA.p, es.rtT.p};
+    grid = std::max(grid, std::min<size_t>(4096, es.cap_edges / 32 + (size_t)es.nq + 1));
+  }
+  hipLaunchKernelGGL(k_relpe_tiles, dim3((unsigned)grid, nsets), dim3(256), 0, e->stream, ps, (const float*)e->d_tok_pos.p, e->div32, e->cfg.ln_eps);
+}
 void launch_relpe(ps_engine* e, EdgeSet& es, const float* src_ori, const float* dst_pos, const float* dst_ori) {
-  const int grid = (int)std::min<size_t>(4096, es.cap_edges / 32 + (size_t)es.nq + 1);
-  hipLaunchKernelGGL(k_relpe_tiles, dim3(grid), dim3(256), 0, e->stream, (const int*)es.esrc.p, (const int*)es.eoff.p,
-                     (const int*)es.toff.p, (const int*)es.tdst.p, es.nq, (const float*)e->d_tok_pos.p, src_ori, dst_pos, dst_ori, e->div32, es.rtA.p,
-                     es.rtT.p, e->cfg.ln_eps);
+  PeArgs a{&es, src_ori, dst_pos, dst_ori};
+  launch_relpe(e, &a, 1);
 }
 
-// radius search + CSR + rel-PE for one edge set
-void launch_radius(ps_engine* e, EdgeSet& es, const int* r1, const int* r2, const float* qpos, const int* qscene, int nq, float r,
-                   int cap, int self_base, const float* src_ori, const float* dst_ori) {
-  CandSet cs{e->d_tok_pos.p, r1, r2};
-  const float r2f = r * r;
+// radius search + CSR + rel-PE for one or two edge sets over the same queries (count -> scan -> fill -> rel-PE: one
+// launch each for all sets)
+struct RadArgs {
+  EdgeSet* es;
+  const int *r1, *r2;
+  float r;
+  int cap, self_base;
+};
+void launch_radius(ps_engine* e, const RadArgs* a, int nsets, const float* qpos, const int* qscene, int nq, const float* src_ori,
+                   const float* dst_ori) {
+  RadSets rs{};
+  for (int i = 0; i < nsets; ++i) {
+    EdgeSet& es = *a[i].es;
+    rs.s[i] = RadSet{CandSet{e->d_tok_pos.p, a[i].r1, a[i].r2}, a[i].r * a[i].r, a[i].cap, a[i].self_base, es.cnt.p,
+                     es.eoff.p, es.toff.p, es.tdst.p, es.esrc.p, es.edst.p};
+  }
   const int wpb = 4, grid = (nq + wpb - 1) / wpb;
   hipStream_t st = e->stream;
-  hipLaunchKernelGGL(k_radius<0>, dim3(grid), dim3(64 * wpb), 0, st, cs, qpos, qscene, nq, r2f, cap, self_base, es.cnt.p,
-                     (const int*)nullptr, (int*)nullptr, (int*)nullptr, (const int*)nullptr, (int*)nullptr);
-  if (self_base >= 0)
-    hipLaunchKernelGGL(k_radius_selfrank, dim3(grid), dim3(64 * wpb), 0, st, cs, qpos, qscene, nq, r2f, cap, self_base, es.cnt.p);
-  hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, st, (const int*)es.cnt.p, nq, es.eoff.p, es.toff.p);
-  hipLaunchKernelGGL(k_radius<1>, dim3(grid), dim3(64 * wpb), 0, st, cs, qpos, qscene, nq, r2f, cap, self_base, (int*)nullptr,
-                     (const int*)es.eoff.p, es.esrc.p, es.edst.p, (const int*)es.toff.p, es.tdst.p);
-  launch_relpe(e, es, src_ori, qpos, dst_ori);
+  hipLaunchKernelGGL(k_radius<0>, dim3(grid, nsets), dim3(64 * wpb), 0, st, rs, qpos, qscene, nq);
+  for (int i = 0; i < nsets; ++i)
+    if (a[i].self_base >= 0)
+      hipLaunchKernelGGL(k_radius_selfrank, dim3(grid), dim3(64 * wpb), 0, st, rs.s[i].cs, qpos, qscene, nq, rs.s[i].r2, a[i].cap,
+                         a[i].self_base, a[i].es->cnt.p);
+  hipLaunchKernelGGL(k_exclusive_scan, dim3(nsets), dim3(1024), 0, st, rs, nq);
+  hipLaunchKernelGGL(k_radius<1>, dim3(grid, nsets), dim3(64 * wpb), 0, st, rs, qpos, qscene, nq);
+  PeArgs pe[2];
+  for (int i = 0; i < nsets; ++i) pe[i] = PeArgs{a[i].es, src_ori, qpos, dst_ori};
+  launch_relpe(e, pe, nsets);
+}
+void launch_radius(ps_engine* e, EdgeSet& es, const int* r1, const int* r2, const float* qpos, const int* qscene, int nq, float r,
+                   int cap, int self_base, const float* src_ori, const float* dst_ori) {
+  RadArgs a{&es, r1, r2, r, cap, self_base};
+  launch_radius(e, &a, 1, qpos, qscene, nq, src_ori, dst_ori);
 }
 
 }  // namespace
@@ -988,8 +1018,9 @@ extern "C" int ps_encode_scene(ps_engine* e) {
     hipLaunchKernelGGL(k_knn, dim3((Mv + A + 3) / 4), dim3(256), 0, st, csn, (const float*)e->d_tok_pos.p,
                        (const int*)e->d_tok_scene.p, Mv + A, c.scene_knn, (const int*)e->e_s2s.eoff.p, e->e_s2s.esrc.p, e->e_s2s.edst.p);
     // a2a edges index agents globally (Mv + i) for positions; kv rows are agent-local -> fixed up below
-    launch_relpe(e, e->e_a2a, e->d_tok_ori.p, e->d_tok_pos.p + 2 * (size_t)Mv, e->d_tok_ori.p + Mv);
-    launch_relpe(e, e->e_s2s, e->d_tok_ori.p, e->d_tok_pos.p, e->d_tok_ori.p);
+    const PeArgs pe[2] = {{&e->e_a2a, e->d_tok_ori.p, e->d_tok_pos.p + 2 * (size_t)Mv, e->d_tok_ori.p + Mv},
+                          {&e->e_s2s, e->d_tok_ori.p, e->d_tok_pos.p, e->d_tok_ori.p}};
+    launch_relpe(e, pe, 2);
   }
   // 6 x (a2a on the agent rows in place, s2s on all rows)  (attn_fusion.py:117-119).  kv is indexed by
   // GLOBAL token row for both (the a2a projection fills rows Mv.. of the shared kv buffer).
@@ -1097,10 +1128,11 @@ extern "C" int ps_policy_step(ps_engine* e, int32_t t_idx) {
   // policy.forward (policy/base.py:19 -> temporal_ar.py:75 -> act_decoder.py:239-283)
   launch_kv(e, atok, A, e->L_a2p, c.pol_layers, e->d_kv_a2p.p, e->d_kh_a2p.p, (size_t)A * 256);
   const int* pscene = e->d_tok_scene.p + Mv;
-  launch_radius(e, e->e_a2p, e->d_r_agent.p, nullptr, e->d_cur_pos.p, pscene, A, c.pol_agent_radius, c.pol_max_neigh, -1,
-                e->d_tok_ori.p, e->d_cur_ori.p);
-  launch_radius(e, e->e_m2p, e->d_r_map.p, nullptr, e->d_cur_pos.p, pscene, A, c.pol_map_radius, c.pol_max_neigh, -1,
-                e->d_tok_ori.p, e->d_cur_ori.p);
+  {
+    const RadArgs ra[2] = {{&e->e_a2p, e->d_r_agent.p, nullptr, c.pol_agent_radius, c.pol_max_neigh, -1},
+                           {&e->e_m2p, e->d_r_map.p, nullptr, c.pol_map_radius, c.pol_max_neigh, -1}};
+    launch_radius(e, ra, 2, e->d_cur_pos.p, pscene, A, e->d_tok_ori.p, e->d_cur_ori.p);
+  }
   const int md = std::max(e->e_a2p.maxdeg, e->e_m2p.maxdeg);
   // the policy tokens enter every replan unchanged (d_emd); the fused features leave to d_fused
   if (launch_chain(e, e->d_fused.p, A, e->step_pol, 2 * c.pol_layers, md, true, nullptr, 0, 0, e->d_emd.p)) return PS_E_HIP;

@@ -220,10 +220,30 @@ __device__ __forceinline__ float dist2(float ax, float ay, float bx, float by) {
 // One wave per query.  mode 0: count only -> cnt[q];  mode 1: fill esrc/edst at eoff[q].
 // self_base >= 0: candidates and queries are the same set (radius_graph, loop=False): query q
 // is token self_base + q, the scan keeps cap+1 matches and then drops the self match.
+// Up to two edge sets over the SAME queries go out in one launch (blockIdx.y = set): the policy's a2p and m2p
+// sets are built from the same agent poses every replan, and each tiny launch costs ~5 us.
+struct RadSet {
+  CandSet cs;
+  float r2;
+  int cap, self_base;
+  int* cnt;
+  int *eoff, *toff, *tdst, *esrc, *edst;
+};
+struct RadSets {
+  RadSet s[2];
+};
 template <int MODE>
-__global__ void k_radius(CandSet cs, const float* __restrict__ qpos, const int* __restrict__ qscene, int nq, float r2,
-                         int cap, int self_base, int* __restrict__ cnt, const int* __restrict__ eoff,
-                         int* __restrict__ esrc, int* __restrict__ edst, const int* __restrict__ toff, int* __restrict__ tdst) {
+__global__ void k_radius(RadSets sets, const float* __restrict__ qpos, const int* __restrict__ qscene, int nq) {
+  const RadSet& S = sets.s[blockIdx.y];
+  const CandSet cs = S.cs;
+  const float r2 = S.r2;
+  const int cap = S.cap, self_base = S.self_base;
+  int* __restrict__ cnt = S.cnt;
+  const int* __restrict__ eoff = S.eoff;
+  const int* __restrict__ toff = S.toff;
+  int* __restrict__ tdst = S.tdst;
+  int* __restrict__ esrc = S.esrc;
+  int* __restrict__ edst = S.edst;
   const int q = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (q >= nq) return;
@@ -285,9 +305,12 @@ __global__ void k_radius_selfrank(CandSet cs, const float* __restrict__ qpos, co
   if (lane == 0 && before < cap + 1) cnt[q] -= 1;
 }
 
-// exclusive scan of cnt[0..n) -> off[0..n] and of ceil(cnt/32) -> toff[0..n] (32-edge tiles of the
-// transposed rel-PE image), single workgroup (n is a few thousand at most).
-__global__ void k_exclusive_scan(const int* __restrict__ cnt, int n, int* __restrict__ off, int* __restrict__ toff) {
+// exclusive scan of cnt[0..n) -> off[0..n] and of ceil(cnt/32) -> toff[0..n] (32-edge tiles of the rel-PE
+// operand images), one workgroup per edge set (n is a few thousand at most).  Declared after RadSets.
+__global__ void k_exclusive_scan(RadSets sets, int n) {
+  const int* __restrict__ cnt = sets.s[blockIdx.x].cnt;
+  int* __restrict__ off = sets.s[blockIdx.x].eoff;
+  int* __restrict__ toff = sets.s[blockIdx.x].toff;
   __shared__ int wsum[16], wsum2[16];
   __shared__ int carry, carry2;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
@@ -441,12 +464,28 @@ __device__ __forceinline__ float fourier_feat(float x, int slot, const float* __
 // One 256-thread workgroup per 32-edge tile (grid-stride; the tile count toff[nq] is read on the device and
 // tdst maps a tile to its destination): each wave makes 8 of the tile's edges, the rows meet in LDS and
 // leave as the two MFMA operand images (layouts: k_tile_transpose), written as contiguous 16-byte pieces.
-__global__ __launch_bounds__(256) void k_relpe_tiles(const int* __restrict__ esrc, const int* __restrict__ eoff,
-                                                    const int* __restrict__ toff, const int* __restrict__ tdst, int nq,
-                                                    const float* __restrict__ src_pos, const float* __restrict__ src_ori,
-                                                    const float* __restrict__ dst_pos, const float* __restrict__ dst_ori,
-                                                    const float* __restrict__ div32, _Float16* __restrict__ rtA,
-                                                    _Float16* __restrict__ rtT, float eps) {
+struct PeSet {
+  const int *esrc, *eoff, *toff, *tdst;
+  int nq;
+  const float *src_ori, *dst_pos, *dst_ori;
+  _Float16 *rtA, *rtT;
+};
+struct PeSets {
+  PeSet s[2];
+};
+__global__ __launch_bounds__(256) void k_relpe_tiles(PeSets sets, const float* __restrict__ src_pos,
+                                                    const float* __restrict__ div32, float eps) {
+  const PeSet& S = sets.s[blockIdx.y];
+  const int* __restrict__ esrc = S.esrc;
+  const int* __restrict__ eoff = S.eoff;
+  const int* __restrict__ toff = S.toff;
+  const int* __restrict__ tdst = S.tdst;
+  const int nq = S.nq;
+  const float* __restrict__ src_ori = S.src_ori;
+  const float* __restrict__ dst_pos = S.dst_pos;
+  const float* __restrict__ dst_ori = S.dst_ori;
+  _Float16* __restrict__ rtA = S.rtA;
+  _Float16* __restrict__ rtT = S.rtT;
   __shared__ __attribute__((aligned(16))) _Float16 buf[32][264];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ntiles = toff[nq];
