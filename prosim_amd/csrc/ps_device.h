@@ -147,23 +147,28 @@ __device__ __forceinline__ void gemv_small(const float* x, int xs, int K, const 
 constexpr int PN_ROWS = 64, PN_AS = 136, PN_CS = 132;
 // C[16*MT x 128] = A[16*MT x 32*k32] * W: wave w makes the 16-column tiles w and w + 4 (all 16 B-fragment loads
 // of both tiles are in flight before the first MFMA).  Rows >= row_lim are not stored; ntiles < 8 for N < 128.
-template <int MT>
-__device__ __forceinline__ void pn_gemm(const _Float16* __restrict__ Ah, const _Float16* __restrict__ Al, int k32,
-                                        const _Float16* __restrict__ F, float* __restrict__ C, int cs, int row_lim, int wave,
-                                        int lane, int ntiles = 8) {
-  const int mi = lane & 15, kq = lane >> 4;
+// The weight fragments of one GEMM for this wave (tiles w and w + 4): requested as a block so that a caller can
+// start the NEXT GEMM's loads before the barrier / epilogue that separates it from the current one.
+struct PnFrags {
   half8 bh[2][4], bl[2][4];
+};
+__device__ __forceinline__ void pn_load(PnFrags& f, const _Float16* __restrict__ F, int k32, int wave, int lane, int ntiles = 8) {
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
-    const _Float16* f = F + (size_t)(wave + 4 * t) * k32 * 1024 + lane * 8;
+    const _Float16* p = F + (size_t)(wave + 4 * t) * k32 * 1024 + lane * 8;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       if (ks < k32 && wave + 4 * t < ntiles) {
-        bh[t][ks] = ldgh8(f + ks * 1024);
-        bl[t][ks] = ldgh8(f + ks * 1024 + 512);
+        f.bh[t][ks] = ldgh8(p + ks * 1024);
+        f.bl[t][ks] = ldgh8(p + ks * 1024 + 512);
       }
     }
   }
+}
+template <int MT>
+__device__ __forceinline__ void pn_mma(const PnFrags& f, const _Float16* __restrict__ Ah, const _Float16* __restrict__ Al, int k32,
+                                       float* __restrict__ C, int cs, int row_lim, int wave, int lane, int ntiles = 8) {
+  const int mi = lane & 15, kq = lane >> 4;
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     const int nt = wave + 4 * t;
@@ -178,9 +183,9 @@ __device__ __forceinline__ void pn_gemm(const _Float16* __restrict__ Ah, const _
         for (int mt = 0; mt < MT; ++mt) {
           const half8 ah = *reinterpret_cast<const half8*>(Ah + (mt * 16 + mi) * PN_AS + ks * 32 + kq * 8);
           const half8 al = *reinterpret_cast<const half8*>(Al + (mt * 16 + mi) * PN_AS + ks * 32 + kq * 8);
-          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[t][ks], acc[mt], 0, 0, 0);
-          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[t][ks], acc[mt], 0, 0, 0);
-          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[t][ks], acc[mt], 0, 0, 0);
+          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, f.bh[t][ks], acc[mt], 0, 0, 0);
+          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, f.bl[t][ks], acc[mt], 0, 0, 0);
+          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, f.bh[t][ks], acc[mt], 0, 0, 0);
         }
       }
     }
@@ -192,6 +197,14 @@ __device__ __forceinline__ void pn_gemm(const _Float16* __restrict__ Ah, const _
         if (row < row_lim) C[row * cs + nt * 16 + mi] = acc[mt][r];
       }
   }
+}
+template <int MT>
+__device__ __forceinline__ void pn_gemm(const _Float16* __restrict__ Ah, const _Float16* __restrict__ Al, int k32,
+                                        const _Float16* __restrict__ F, float* __restrict__ C, int cs, int row_lim, int wave,
+                                        int lane, int ntiles = 8) {
+  PnFrags f;
+  pn_load(f, F, k32, wave, lane, ntiles);
+  pn_mma<MT>(f, Ah, Al, k32, C, cs, row_lim, wave, lane, ntiles);
 }
 
 }  // namespace ps

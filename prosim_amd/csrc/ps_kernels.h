@@ -821,6 +821,8 @@ __global__ __launch_bounds__(256) void k_policy_head_mfma(HeadW w, const float* 
   __shared__ __attribute__((aligned(16))) float C[16 * PN_CS], ctx[16 * PN_CS], inp[16 * PN_CS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ag0 = blockIdx.x * 16;
+  PnFrags fr;   // the next GEMM's weight fragments always leave before the barrier / epilogue in front of it
+  pn_load(fr, w.cgF[0], 4, wave, lane);
   for (int i = tid; i < 16 * 128; i += 256) {
     const int g = i >> 7, c = i & 127;
     const int ag = ag0 + g < n_agents ? ag0 + g : n_agents - 1;
@@ -832,7 +834,8 @@ __global__ __launch_bounds__(256) void k_policy_head_mfma(HeadW w, const float* 
   __syncthreads();
   // CG_stacked(3) with K = 1: max over the mode dim is the identity
   for (int i = 0; i < 3; ++i) {
-    pn_gemm<1>(Ah, Al, 4, w.cgF[i], C, PN_CS, 16, wave, lane);
+    pn_mma<1>(fr, Ah, Al, 4, C, PN_CS, 16, wave, lane);
+    pn_load(fr, i < 2 ? w.cgF[i + 1] : w.m0F, 4, wave, lane);
     __syncthreads();
     if (tid < 64) {
       float a[32];
@@ -858,7 +861,8 @@ __global__ __launch_bounds__(256) void k_policy_head_mfma(HeadW w, const float* 
     __syncthreads();
   }
   // motion_head: 128 -> 128 (LN, ReLU) -> 64 (LN, ReLU) -> steps*sdim
-  pn_gemm<1>(Ah, Al, 4, w.m0F, C, PN_CS, 16, wave, lane);
+  pn_mma<1>(fr, Ah, Al, 4, C, PN_CS, 16, wave, lane);
+  pn_load(fr, w.m1F, 4, wave, lane, 4);
   __syncthreads();
   if (tid < 64) {
     float a[32];
@@ -871,7 +875,8 @@ __global__ __launch_bounds__(256) void k_policy_head_mfma(HeadW w, const float* 
     }
   }
   __syncthreads();
-  pn_gemm<1>(Ah, Al, 4, w.m1F, C, PN_CS, 16, wave, lane, 4);
+  pn_mma<1>(fr, Ah, Al, 4, C, PN_CS, 16, wave, lane, 4);
+  pn_load(fr, w.m2F, 2, wave, lane, 4);
   __syncthreads();
   if (tid < 64) {
     float a[16];
@@ -884,7 +889,7 @@ __global__ __launch_bounds__(256) void k_policy_head_mfma(HeadW w, const float* 
     }
   }
   __syncthreads();
-  pn_gemm<1>(Ah, Al, 2, w.m2F, C, PN_CS, 16, wave, lane, 4);
+  pn_mma<1>(fr, Ah, Al, 2, C, PN_CS, 16, wave, lane, 4);
   __syncthreads();
   // cumsum over steps of (dx, dy, dtheta); wrap theta (act_decoder.py:117-121).  One thread per (agent, step):
   // it re-adds the prefix in step order, so the sums round exactly like the sequential scan.
