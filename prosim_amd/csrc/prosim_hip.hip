@@ -81,6 +81,7 @@ struct ps_engine {
   PointNetW pn_map{}, pn_obs{};
   Mlp3W mlp_prompt{}, mlp_pred{};
   HeadW head{};
+  DevBuf<float> io_q, io_qt, io_cq, io_ar, io_av, io_l, io_s, io_g;   // split path: per-destination vectors (EdgeIO)
   CondW cond{};
   const float* div32 = nullptr;
   // ---- scene
@@ -121,6 +122,7 @@ struct ps_engine {
 
 namespace {
 void drop_graph(ps_engine* e);
+int io_for(ps_engine* e, int Nd, EdgeIO& io);
 }
 // ------------------------------------------------------------------------------------------ weights
 namespace {
@@ -263,6 +265,67 @@ void build_attn(Builder& b, const std::string& p, AttnW& w) {
   }
   b.slot(&w.vb, b.put(vb));
   b.slot(&w.Wkv_t, b.put(wkv));
+  {   // split path (k_node): node Linears as B fragments
+    const float* wq = b.get(p + ".to_q.weight", (int64_t)D * D);
+    const float* ws = b.get(p + ".to_s.weight", (int64_t)D * D);
+    const float* wg = b.get(p + ".to_g.weight", (int64_t)D * 2 * D);
+    if (wq && ws && wg) {
+      std::vector<float> qsg((size_t)3 * D * D);
+      std::copy(wq, wq + (size_t)D * D, qsg.begin());
+      std::copy(ws, ws + (size_t)D * D, qsg.begin() + (size_t)D * D);
+      for (int n = 0; n < D; ++n) std::copy(wg + (size_t)n * 2 * D + D, wg + (size_t)n * 2 * D + 2 * D, qsg.begin() + (size_t)(2 * D + n) * D);
+      b.fragments_raw(&w.Fqsg, qsg.data(), 3 * D, D, 0, D);
+    }
+    b.fragments(&w.Fga, p + ".to_g.weight", D, 2 * D, 0, D);
+    b.fragments(&w.Fout, p + ".to_out.weight", D, D, 0, D);
+    b.fragments(&w.F1, p + ".ff_mlp.0.weight", FF, D, 0, D);
+    b.fragments(&w.F2, p + ".ff_mlp.3.weight", D, FF, 0, FF);
+    // q~: per head h one k-block = the 32 q columns (heads 2*(h/2), 2*(h/2)+1) with the other head's rows zero;
+    // B[k][n] = Wkr_g[16h + d][c], k = 16*(h & 1) + d, n-tile nt -> c = 16 nt + n
+    auto kr_frag = [&](const _Float16** dst, const std::vector<float>& wk_, int ntq) {
+      std::vector<float> packed(((size_t)8 * ntq * 1024 + 1) / 2);
+      _Float16* hh = reinterpret_cast<_Float16*>(packed.data());
+      for (int h = 0; h < 8; ++h)
+        for (int nt = 0; nt < ntq; ++nt)
+          for (int lane = 0; lane < 64; ++lane)
+            for (int j = 0; j < 8; ++j) {
+              const int c = nt * 16 + (lane & 15), kl = (lane >> 4) * 8 + j;
+              const float v = (kl >> 4) == (h & 1) ? wk_[(size_t)(h * 16 + (kl & 15)) * D + c] : 0.f;
+              const _Float16 hi = (_Float16)v;
+              const size_t o = (size_t)(h * ntq + nt) * 1024 + (size_t)lane * 8 + j;
+              hh[o] = hi;
+              hh[o + 512] = (_Float16)(v - (float)hi);
+            }
+      b.slot(reinterpret_cast<const float**>(dst), b.put(packed));
+    };
+    // to_v_r fold: per head h the n-tile of columns 16h..16h+15 of Wvr_gt [c][hd]; B[k = c][n = d]
+    auto vr_frag = [&](const _Float16** dst, const std::vector<float>& wv_, int kr) {
+      std::vector<float> packed(((size_t)8 * kr * 1024 + 1) / 2);
+      _Float16* hh = reinterpret_cast<_Float16*>(packed.data());
+      for (int h = 0; h < 8; ++h)
+        for (int ks = 0; ks < kr; ++ks)
+          for (int lane = 0; lane < 64; ++lane)
+            for (int j = 0; j < 8; ++j) {
+              const int c = ks * 32 + (lane >> 4) * 8 + j, d = lane & 15;
+              const float v = wv_[(size_t)c * D + h * 16 + d];
+              const _Float16 hi = (_Float16)v;
+              const size_t o = (size_t)(h * kr + ks) * 1024 + (size_t)lane * 8 + j;
+              hh[o] = hi;
+              hh[o + 512] = (_Float16)(v - (float)hi);
+            }
+      b.slot(reinterpret_cast<const float**>(dst), b.put(packed));
+    };
+    std::vector<float> wkrg3 = wkrg, wvrgt3 = wvrgt;
+    for (int hd = 0; hd < D; ++hd)
+      for (int i = 0; i < 32; ++i) {
+        wkrg3[(size_t)hd * D + 64 + i] += wkrg3[(size_t)hd * D + 96 + i];
+        wvrgt3[(size_t)(64 + i) * D + hd] += wvrgt3[(size_t)(96 + i) * D + hd];
+      }
+    kr_frag(&w.Fkr, wkrg, 8);
+    kr_frag(&w.Fkr3, wkrg3, 6);
+    vr_frag(&w.Fvr, wvrgt, 4);
+    vr_frag(&w.Fvr3, wvrgt3, 3);
+  }
   {   // [to_k ; to_v] as one [256][128] Linear -> B fragments
     std::vector<float> kvw((size_t)2 * D * D);
     std::copy(wk, wk + (size_t)D * D, kvw.begin());
@@ -502,6 +565,8 @@ extern "C" int ps_create(const ps_config* cfg, int32_t n_tensors, const char* co
   // the chain kernel may use up to ~140 KiB of dynamic LDS
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_kv_proj), hipFuncAttributeMaxDynamicSharedMemorySize, (int)KV_LDS_BYTES);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pointnet_mfma), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PN_LDS_BYTES);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_node<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ND_LDS_BYTES);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_node<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ND_LDS_BYTES);
 #define PS_ATTR(TT, NWW, KRR) \
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_chain<TT, NWW, KRR>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
   PS_ATTR(1, 4, 3); PS_ATTR(2, 4, 3); PS_ATTR(4, 4, 3); PS_ATTR(4, 8, 3);
@@ -530,6 +595,8 @@ extern "C" void ps_destroy(ps_engine* e) {
     s->cnt.release(); s->eoff.release(); s->esrc.release(); s->edst.release(); s->toff.release(); s->tdst.release(); s->rtA.release(); s->rtT.release();
   }
   e->d_steps.release(); e->d_ent_off.release(); e->d_ent_type.release(); e->d_ent_val.release();
+  e->io_q.release(); e->io_qt.release(); e->io_cq.release(); e->io_ar.release(); e->io_av.release(); e->io_l.release();
+  e->io_s.release(); e->io_g.release();
   drop_graph(e);
   if (e->arena_d) (void)hipFree(e->arena_d);
   if (e->d_layers) (void)hipFree(e->d_layers);
@@ -681,6 +748,10 @@ extern "C" int ps_set_scene(ps_engine* e, int32_t B, int32_t M, int32_t P, int32
       edge_alloc(e->e_a2p, A, (size_t)A * d_a2p, d_a2p) || edge_alloc(e->e_m2p, A, (size_t)A * d_m2p, d_m2p) ||
       edge_alloc(e->e_cnd, A, (size_t)A, 1))
     return fail(PS_E_HIP, "edge allocation failed");
+  {   // split-path exchange buffers for the largest destination set (allocated here, never inside a captured rollout)
+    EdgeIO io_;
+    if (io_for(e, Mv + A, io_)) return fail(PS_E_HIP, "split-path buffers");
+  }
   // closed-form CSR offsets of the knn graphs (every query gets min(k, scene size) neighbours)
   {
     std::vector<int> off(A + 1, 0), tof(A + 1, 0), tds;
@@ -859,6 +930,39 @@ extern "C" int ps_set_future_obs(ps_engine* e, const float* fut_input) {
 // ------------------------------------------------------------------------------------------ launches
 namespace {
 
+// split-path exchange buffers, grown on demand (never inside a captured rollout: ps_set_scene sizes them first)
+int io_for(ps_engine* e, int Nd, EdgeIO& io) {
+  const size_t n = (size_t)std::max(Nd, 1);
+  if (e->io_q.ensure(n * 128) || e->io_qt.ensure(n * 1024) || e->io_cq.ensure(n * 8) || e->io_ar.ensure(n * 1024) ||
+      e->io_av.ensure(n * 128) || e->io_l.ensure(n * 8) || e->io_s.ensure(n * 128) || e->io_g.ensure(n * 128))
+    return -1;
+  io.q = e->io_q.p; io.qt = e->io_qt.p; io.cq = e->io_cq.p; io.ar = e->io_ar.p; io.av = e->io_av.p; io.l = e->io_l.p;
+  io.s = e->io_s.p; io.g = e->io_g.p;
+  return 0;
+}
+
+// One attention layer as three launches: k_node PRE (+ the rows' own k | v when kv_out is given: self-attention),
+// k_edge_small (degree <= ES_MAXDEG), k_node POST.  `stp` is a device pointer to the layer's ChainStep.
+int launch_split_layer(ps_engine* e, float* x, int Nd, const ChainStep* stp, int kr, int maxdeg, float* kv_out, _Float16* khl_out) {
+  EdgeIO io{};
+  if (io_for(e, Nd, io)) return fail(PS_E_HIP, "split-path buffers");
+  hipStream_t st = e->stream;
+  const dim3 gn((Nd + ND_ROWS - 1) / ND_ROWS), ge((Nd + 3) / 4);
+  const float eps = e->cfg.ln_eps;
+  const ChainStep* none = nullptr;
+  if (kr == 3) {
+    hipLaunchKernelGGL(k_node<3>, gn, dim3(256), ND_LDS_BYTES, st, x, Nd, none, stp, io, eps, kv_out, khl_out);
+    if (maxdeg <= 32) hipLaunchKernelGGL((k_edge_small<3, 2>), ge, dim3(256), es_lds_bytes<2>(), st, Nd, stp, io);
+    else hipLaunchKernelGGL((k_edge_small<3, 8>), ge, dim3(256), es_lds_bytes<8>(), st, Nd, stp, io);
+    hipLaunchKernelGGL(k_node<3>, gn, dim3(256), ND_LDS_BYTES, st, x, Nd, stp, none, io, eps, (float*)nullptr, (_Float16*)nullptr);
+  } else {
+    hipLaunchKernelGGL(k_node<4>, gn, dim3(256), ND_LDS_BYTES, st, x, Nd, none, stp, io, eps, kv_out, khl_out);
+    hipLaunchKernelGGL((k_edge_small<4, 8>), ge, dim3(256), es_lds_bytes<8>(), st, Nd, stp, io);
+    hipLaunchKernelGGL(k_node<4>, gn, dim3(256), ND_LDS_BYTES, st, x, Nd, stp, none, io, eps, (float*)nullptr, (_Float16*)nullptr);
+  }
+  return hipGetLastError() == hipSuccess ? 0 : fail(PS_E_HIP, "split layer launch failed");
+}
+
 int launch_chain(ps_engine* e, float* x, int Nd, int step0, int nsteps, int maxdeg, bool timed = false,
                  const ChainStep* steps_override = nullptr, int force_T = 0, int kr_override = 0, const float* x_in = nullptr) {
   if (!x_in) x_in = x;   // in place unless the caller has the input rows elsewhere (saves a copy launch)
@@ -1024,11 +1128,20 @@ extern "C" int ps_encode_scene(ps_engine* e) {
   }
   // 6 x (a2a on the agent rows in place, s2s on all rows)  (attn_fusion.py:117-119).  kv is indexed by
   // GLOBAL token row for both (the a2a projection fills rows Mv.. of the shared kv buffer).
+  static const bool no_split = getenv("PS_NO_SPLIT") != nullptr;   // experiments only
+  const bool split_s2s = !no_split && Mv + A >= 2048 && e->e_s2s.maxdeg <= ES_MAXDEG;
   for (int i = 0; i < c.scene_layers; ++i) {
     launch_kv(e, tok + (size_t)Mv * D, A, e->L_a2a + i, 1, e->d_kv.p + (size_t)Mv * 256, e->d_kh.p + (size_t)Mv * 256, 0);
     if (launch_chain(e, tok + (size_t)Mv * D, A, e->step_a2a + i, 1, e->e_a2a.maxdeg)) return PS_E_HIP;
-    launch_kv(e, tok, Mv + A, e->L_s2s + i, 1, e->d_kv.p, e->d_kh.p, 0);
-    if (launch_chain(e, tok, Mv + A, e->step_s2s + i, 1, e->e_s2s.maxdeg)) return PS_E_HIP;
+    if (split_s2s) {
+      // split layer: node work as 16-row MFMA GEMMs (k_node; its PRE half also makes the rows'
+      // k | v, they are this self-attention layer's sources), the 32-neighbour edge phase one wave per token
+      const ChainStep* stp = e->d_steps.p + e->step_s2s + i;
+      if (launch_split_layer(e, tok, Mv + A, stp, 3, e->e_s2s.maxdeg, e->d_kv.p, e->d_kh.p)) return PS_E_HIP;
+    } else {
+      launch_kv(e, tok, Mv + A, e->L_s2s + i, 1, e->d_kv.p, e->d_kh.p, 0);
+      if (launch_chain(e, tok, Mv + A, e->step_s2s + i, 1, e->e_s2s.maxdeg)) return PS_E_HIP;
+    }
   }
   HIPCHK(hipGetLastError());
   e->encoded = true;
@@ -1411,7 +1524,9 @@ extern "C" int ps_test_attn(ps_engine* e, int32_t layer_index, int32_t Ns, int32
   st.kv = dkv.p; st.eoff = doff.p; st.esrc = dsrc.p; st.toff = dtoff.p; st.rtT = drtT.p; st.rtA = drtA.p; st.khl = dkh.p;
   st.kr = 4;   // the hook is handed arbitrary rows: all 128 columns count
   if (upload(dstep, &st, 1, e->stream)) return fail(PS_E_HIP, "test upload failed");
-  if (launch_chain(e, dxd.p, Nd, 0, 1, maxdeg, false, dstep.p, T, 4)) return PS_E_HIP;
+  if (T == 16 && maxdeg <= ES_MAXDEG) {   // the split layer (k_node + k_edge_small + k_node)
+    if (launch_split_layer(e, dxd.p, Nd, dstep.p, 4, maxdeg, nullptr, nullptr)) return PS_E_HIP;
+  } else if (launch_chain(e, dxd.p, Nd, 0, 1, maxdeg, false, dstep.p, T == 16 ? 0 : T, 4)) return PS_E_HIP;
   HIPCHK(hipStreamSynchronize(e->stream));
   HIPCHK(hipMemcpy(out, dxd.p, sizeof(float) * (size_t)Nd * D, hipMemcpyDeviceToHost));
   dxs.release(); dxd.release(); drt.release(); dkv.release(); doff.release(); dsrc.release(); dstep.release(); drth.release(); dkh.release();

@@ -36,6 +36,11 @@ struct AttnW {
   const float *W1_t, *b1, *W2_t, *b2, *ln_ffpost_w, *ln_ffpost_b;
   const float *Wkv_t, *bkv;                         // [128][256] K-major (k | v), [256]
   const _Float16* Wkv_F;                            // the same as split-fp16 MFMA B fragments [n-tile 16][k-block 4][hi|lo][64][8]
+  // split path (k_node): the node Linears as split-fp16 B fragments [n-tile][k-block][hi|lo][lane 64][8]
+  const _Float16* Fqsg;                             // [to_q ; to_s ; to_g's x half]: 24 n-tiles x 4 k-blocks
+  const _Float16 *Fkr, *Fkr3;                       // q~: [head 8][n-tile 8 | 6][1 k-block = the 32 q columns holding the head, other head zero]
+  const _Float16 *Fvr, *Fvr3;                       // to_v_r fold: [head 8 = n-tile][k-block 4 | 3]
+  const _Float16 *Fga, *Fout, *F1, *F2;             // gate (agg half), to_out, FFN up (32 n-tiles), FFN down (16 k-blocks)
   const float* sp;                                  // packed small vectors, SP_* offsets below (2432 floats)
 };
 // offsets (floats) inside AttnW::sp -- one coalesced load per layer stages them in LDS, so no
@@ -43,6 +48,19 @@ struct AttnW {
 enum : int { SP_LN_DST_W = 0, SP_LN_DST_B = 128, SP_BQ = 256, SP_BS = 384, SP_BG = 512, SP_KB = 640, SP_VB = 768,
              SP_BOUT = 896, SP_LN_POST_W = 1024, SP_LN_POST_B = 1152, SP_LN_FFPRE_W = 1280, SP_LN_FFPRE_B = 1408,
              SP_B1 = 1536, SP_B2 = 2048, SP_LN_FFPOST_W = 2176, SP_LN_FFPOST_B = 2304, SP_SIZE = 2432 };
+
+// Per-destination vectors exchanged between the split kernels of a layer (k_node <-> k_edge_small):
+// the node kernel leaves q, q~, <q, kb> for the edge kernel, which leaves the softmax-weighted sums.
+struct EdgeIO {
+  float* q;    // [Nd][128]      to_q(LN_dst(x)) + bias
+  float* qt;   // [Nd][8][128]   q~[h] = Wkr_g,h^T q_h  (columns >= 32*KR unused)
+  float* cq;   // [Nd][8]        <q_h, kb_h>
+  float* ar;   // [Nd][8][128]   sum_e p_e,h r~_e
+  float* av;   // [Nd][128]      sum_e p_e,h v_src
+  float* l;    // [Nd][8]        sum_e p_e,h (softmax denominators, running-max scaled like ar / av)
+  float* s;    // [Nd][128]      to_s(LN_dst(x)) + bias      (node kernel only)
+  float* g;    // [Nd][128]      to_g's x_dst half + bias     (node kernel only)
+};
 
 struct ChainStep {
   AttnW w;
@@ -832,6 +850,571 @@ __global__ __launch_bounds__(WG) void k_kv_proj(const float* __restrict__ x, int
       }
     }
     __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Split path, node side.  k_node carries 16 destination rows per workgroup through everything of a layer that is
+// not per-edge, as split-fp16 MFMA GEMMs against pre-split weight fragments (pn_gemm's operand scheme):
+//   POST(layer l):  to_v_r fold, agg, gate, u, to_out, LN_post + residual, LN_ffpre, FFN, LN_ffpost + residual
+//   PRE(layer l+1): LN_dst, q | s | g projections, q~[h] = Wkr_g,h^T q_h, <q_h, kb_h>
+// Between two k_node launches the edge kernel (k_edge_small) turns (q, q~, cq) into (ar, av, l).
+// Weights cross the CU once per 16 rows (the fused chain: once per 1-4), the K reductions happen inside the MFMA
+// (no shuffle folds), and with ~100 registers the fragment loads are software-pipelined one group ahead.
+constexpr int ND_ROWS = 16, ND_AS = 136, ND_AS5 = 520, ND_CS = 516, ND_XS = 132;
+constexpr size_t ND_LDS_BYTES = (size_t)2 * ND_ROWS * ND_AS * 2 + (size_t)2 * ND_ROWS * ND_AS5 * 2 + (size_t)ND_ROWS * ND_CS * 4 +
+                                (size_t)2 * ND_ROWS * ND_XS * 4 + (size_t)SP_SIZE * 4;
+
+// C[16 x 16*ntiles] = A[16 x 32*K32] * W.  A: LDS planes (row stride `as` halfs); F: [n-tile][k-block K32][hi|lo][64][8].
+// Wave w makes tiles w, w+4, ...; its work is a list of (tile, 4-k-block) groups of <= 8 fragment loads + <= 12 MFMAs.
+// Weights do not depend on activations, so a ring of ND_DEPTH groups stays in flight ACROSS the epilogues and
+// barriers between GEMMs: frag_prefetch() requests the first groups of the next GEMM as soon as the ring is free,
+// gemm16() consumes group g and requests group g + ND_DEPTH.  (One group ahead hid ~10 % of a 1-2 us round trip:
+// a group's MFMAs take 0.1 us.  k_node runs one workgroup per CU, so the ~160 registers of the ring are free.)
+constexpr int ND_DEPTH = 4;
+struct FragRing {
+  half8 h[ND_DEPTH][4], l[ND_DEPTH][4];
+};
+template <int K32>
+__device__ __forceinline__ void frag_issue(FragRing& R, int slot, const _Float16* __restrict__ F, int g, int wave, int lane) {
+  constexpr int KB = K32 < 4 ? K32 : 4, KG = (K32 + KB - 1) / KB;
+  const _Float16* f = F + ((size_t)(wave + 4 * (g / KG)) * K32 + (g % KG) * KB) * 1024 + lane * 8;
+#pragma unroll
+  for (int j = 0; j < KB; ++j) {
+    R.h[slot][j] = ldgh8(f + j * 1024);
+    R.l[slot][j] = ldgh8(f + j * 1024 + 512);
+  }
+}
+template <int K32>
+__device__ __forceinline__ void frag_prefetch(FragRing& R, const _Float16* __restrict__ F, int ntiles, int wave, int lane) {
+  constexpr int KB = K32 < 4 ? K32 : 4, KG = (K32 + KB - 1) / KB;
+  const int G = ((ntiles - wave + 3) / 4) * KG;
+#pragma unroll
+  for (int d = 0; d < ND_DEPTH; ++d)
+    if (d < G) frag_issue<K32>(R, d, F, d, wave, lane);
+}
+template <int K32>
+__device__ __forceinline__ void gemm16(FragRing& R, const _Float16* __restrict__ Ah, const _Float16* __restrict__ Al, int as,
+                                       const _Float16* __restrict__ F, int ntiles, float* __restrict__ C, int cs, int wave, int lane) {
+  constexpr int KB = K32 < 4 ? K32 : 4, KG = (K32 + KB - 1) / KB;
+  const int mi = lane & 15, kq = lane >> 4;
+  const int G = ((ntiles - wave + 3) / 4) * KG;
+  floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int g0 = 0; g0 < G; g0 += ND_DEPTH) {
+#pragma unroll
+    for (int d = 0; d < ND_DEPTH; ++d) {
+      const int g = g0 + d;
+      if (g < G) {
+        half8 ch[KB], cl[KB];
+#pragma unroll
+        for (int j = 0; j < KB; ++j) { ch[j] = R.h[d][j]; cl[j] = R.l[d][j]; }
+        if (g + ND_DEPTH < G) frag_issue<K32>(R, d, F, g + ND_DEPTH, wave, lane);
+        const int kg = g % KG;
+        if (kg == 0) acc = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < KB; ++j) {
+          const half8 ah = *reinterpret_cast<const half8*>(Ah + mi * as + (kg * KB + j) * 32 + kq * 8);
+          const half8 al = *reinterpret_cast<const half8*>(Al + mi * as + (kg * KB + j) * 32 + kq * 8);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, ch[j], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, cl[j], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, ch[j], acc, 0, 0, 0);
+        }
+        if (kg == KG - 1) {
+          const int nt = wave + 4 * (g / KG);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) C[(4 * kq + r) * cs + nt * 16 + mi] = acc[r];
+        }
+      }
+    }
+  }
+}
+
+// sum over the 16 lanes that share an epilogue row (lanes tid & 15 vary)
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_xor1(v);
+  v += dpp_xor2(v);
+  v += __shfl_xor(v, 4);
+  v += __shfl_xor(v, 8);
+  return v;
+}
+// y = LayerNorm(a[0..8)) over a 128-wide row held by 16 lanes x 8 columns (columns c0..c0+7)
+__device__ __forceinline__ void row16_ln(float (&a)[8], const float* __restrict__ w, const float* __restrict__ b, int c0, float eps) {
+  float sm = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) sm += a[i];
+  const float mean = row16_sum(sm) * (1.f / 128.f);
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    a[i] -= mean;
+    sq = fmaf(a[i], a[i], sq);
+  }
+  const float rstd = 1.f / sqrtf(row16_sum(sq) * (1.f / 128.f) + eps);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) a[i] = fmaf(a[i] * rstd, w[c0 + i], b[c0 + i]);
+}
+__device__ __forceinline__ void planes_store8(_Float16* __restrict__ Ph, _Float16* __restrict__ Pl, const float (&a)[8]) {
+  half8 h, l;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    h[i] = f16_hi(a[i]);
+    l[i] = f16_lo(a[i]);
+  }
+  *reinterpret_cast<half8*>(Ph) = h;
+  *reinterpret_cast<half8*>(Pl) = l;
+}
+
+// kv_out / khl_out (optional, PRE of a SELF-attention layer, where LN_src == LN_dst): the rows are also the
+// layer's sources, so their k | v projection (k_kv_proj's job) is one more GEMM on the normed rows already in LDS.
+template <int KR>
+__global__ __launch_bounds__(256) void k_node(float* __restrict__ x, int Nd, const ChainStep* __restrict__ post,
+                                              const ChainStep* __restrict__ pre, EdgeIO io, float eps,
+                                              float* __restrict__ kv_out, _Float16* __restrict__ khl_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char nd_smem[];
+  _Float16* P0h = reinterpret_cast<_Float16*>(nd_smem);
+  _Float16* P0l = P0h + ND_ROWS * ND_AS;
+  _Float16* P1h = P0l + ND_ROWS * ND_AS;
+  _Float16* P1l = P1h + ND_ROWS * ND_AS5;
+  float* C = reinterpret_cast<float*>(P1l + ND_ROWS * ND_AS5);
+  float* X = C + ND_ROWS * ND_CS;        // [16][132] residual stream
+  float* AG = X + ND_ROWS * ND_XS;       // [16][132] agg (POST) / q (PRE)
+  float* sp = AG + ND_ROWS * ND_XS;      // [SP_SIZE] the layer's small vectors
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int mi = lane & 15, kq = lane >> 4;
+  const int row0 = blockIdx.x * ND_ROWS;
+  const int er = tid >> 4, ec = (tid & 15) * 8;   // epilogue mapping: row, 8 columns
+  const int grow = row0 + er;
+  const bool live = grow < Nd;
+  auto stage_sp = [&](const float* __restrict__ src) {
+    for (int i = tid; i < SP_SIZE / 4; i += 256) *reinterpret_cast<float4*>(sp + 4 * i) = ldg4(src + 4 * i);
+  };
+  {
+    float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+    if (live) { v0 = ldg4(x + (size_t)grow * 128 + ec); v1 = ldg4(x + (size_t)grow * 128 + ec + 4); }
+    *reinterpret_cast<float4*>(X + er * ND_XS + ec) = v0;
+    *reinterpret_cast<float4*>(X + er * ND_XS + ec + 4) = v1;
+  }
+  FragRing R;
+  if (post) {
+    const AttnW& w = post->w;
+    stage_sp(w.sp);
+    frag_prefetch<4>(R, w.Fga, 8, wave, lane);
+    // this thread's slice of the edge kernel's / previous node kernel's rows: requested now, used after the fold
+    float4 in_av0 = make_float4(0.f, 0.f, 0.f, 0.f), in_av1 = in_av0, in_g0 = in_av0, in_g1 = in_av0, in_s0 = in_av0, in_s1 = in_av0;
+    float in_l = 0.f;
+    if (live) {
+      in_l = ldg1(io.l + (size_t)grow * 8 + (ec >> 4));
+      in_av0 = ldg4(io.av + (size_t)grow * 128 + ec); in_av1 = ldg4(io.av + (size_t)grow * 128 + ec + 4);
+      in_g0 = ldg4(io.g + (size_t)grow * 128 + ec); in_g1 = ldg4(io.g + (size_t)grow * 128 + ec + 4);
+      in_s0 = ldg4(io.s + (size_t)grow * 128 + ec); in_s1 = ldg4(io.s + (size_t)grow * 128 + ec + 4);
+    }
+    // ---- to_v_r fold: C[row][16h + d] = sum_c a_r[row][h][c] * Wvr_g[c][16h + d]; wave -> heads 2w, 2w+1; the A
+    //      fragments come straight from the edge kernel's fp32 rows
+    {
+      const _Float16* Fv = KR == 3 ? w.Fvr3 : w.Fvr;
+      float4 a0[2][KR], a1[2][KR];
+      half8 bh[2][KR], bl[2][KR];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {   // every load of both heads is in flight before the first MFMA
+        const int h = 2 * wave + t;
+#pragma unroll
+        for (int ks = 0; ks < KR; ++ks) {
+          a0[t][ks] = make_float4(0.f, 0.f, 0.f, 0.f);
+          a1[t][ks] = a0[t][ks];
+          if (row0 + mi < Nd) {
+            const float* ap = io.ar + (size_t)(row0 + mi) * 1024 + h * 128 + ks * 32 + kq * 8;
+            a0[t][ks] = ldg4(ap);
+            a1[t][ks] = ldg4(ap + 4);
+          }
+          const _Float16* f = Fv + ((size_t)(h * KR + ks) * 2) * 512 + lane * 8;
+          bh[t][ks] = ldgh8(f);
+          bl[t][ks] = ldgh8(f + 512);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int h = 2 * wave + t;
+        floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KR; ++ks) {
+          const float av_[8] = {a0[t][ks].x, a0[t][ks].y, a0[t][ks].z, a0[t][ks].w, a1[t][ks].x, a1[t][ks].y, a1[t][ks].z, a1[t][ks].w};
+          half8 ah, al;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { ah[j] = f16_hi(av_[j]); al[j] = f16_lo(av_[j]); }
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[t][ks], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[t][ks], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[t][ks], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) C[(4 * kq + r) * ND_CS + h * 16 + mi] = acc[r];
+      }
+    }
+    __syncthreads();
+    // ---- agg = (a_v + fold + l * vb) / (l + 1e-16)   (:89, :100)
+    float agg[8];
+    {
+      const float l = in_l;
+      const float inv = 1.f / (l + 1e-16f);
+      const float avv[8] = {in_av0.x, in_av0.y, in_av0.z, in_av0.w, in_av1.x, in_av1.y, in_av1.z, in_av1.w};
+#pragma unroll
+      for (int i = 0; i < 8; ++i) agg[i] = (avv[i] + C[er * ND_CS + ec + i] + l * sp[SP_VB + ec + i]) * inv;
+      planes_store8(P0h + er * ND_AS + ec, P0l + er * ND_AS + ec, agg);
+    }
+    __syncthreads();
+    // ---- gated update (:106-107): g = sigmoid(Wg [agg | x_dst] + bg); u = agg + g * (to_s(x_dst) - agg)
+    gemm16<4>(R, P0h, P0l, ND_AS, w.Fga, 8, C, ND_CS, wave, lane);
+    frag_prefetch<4>(R, w.Fout, 8, wave, lane);
+    __syncthreads();
+    {
+      const float gv[8] = {in_g0.x, in_g0.y, in_g0.z, in_g0.w, in_g1.x, in_g1.y, in_g1.z, in_g1.w};
+      const float sv[8] = {in_s0.x, in_s0.y, in_s0.z, in_s0.w, in_s1.x, in_s1.y, in_s1.z, in_s1.w};
+      float u[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float g = 1.f / (1.f + expf(-(C[er * ND_CS + ec + i] + gv[i])));
+        u[i] = agg[i] + g * (sv[i] - agg[i]);
+      }
+      __syncthreads();   // every thread has read its gate columns of C and P0 is no longer an operand
+      planes_store8(P0h + er * ND_AS + ec, P0l + er * ND_AS + ec, u);
+    }
+    __syncthreads();
+    // ---- x = x + LN_post(to_out(u))  (:76), then LN_ffpre(x)  (:77)
+    gemm16<4>(R, P0h, P0l, ND_AS, w.Fout, 8, C, ND_CS, wave, lane);
+    frag_prefetch<4>(R, w.F1, 32, wave, lane);
+    __syncthreads();
+    {
+      float o[8], xv[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o[i] = C[er * ND_CS + ec + i] + sp[SP_BOUT + ec + i];
+      row16_ln(o, sp + SP_LN_POST_W, sp + SP_LN_POST_B, ec, eps);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        xv[i] = X[er * ND_XS + ec + i] + o[i];
+        X[er * ND_XS + ec + i] = xv[i];
+      }
+      row16_ln(xv, sp + SP_LN_FFPRE_W, sp + SP_LN_FFPRE_B, ec, eps);
+      __syncthreads();
+      planes_store8(P0h + er * ND_AS + ec, P0l + er * ND_AS + ec, xv);
+    }
+    __syncthreads();
+    // ---- FFN: relu(W1 . + b1), W2 . + b2, x = x + LN_ffpost(.)
+    gemm16<4>(R, P0h, P0l, ND_AS, w.F1, 32, C, ND_CS, wave, lane);
+    frag_prefetch<16>(R, w.F2, 8, wave, lane);
+    __syncthreads();
+    {
+      const int c32 = (tid & 15) * 32;
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        float f[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f[i] = fmaxf(C[er * ND_CS + c32 + 8 * q4 + i] + sp[SP_B1 + c32 + 8 * q4 + i], 0.f);
+        planes_store8(P1h + er * ND_AS5 + c32 + 8 * q4, P1l + er * ND_AS5 + c32 + 8 * q4, f);
+      }
+    }
+    __syncthreads();
+    gemm16<16>(R, P1h, P1l, ND_AS5, w.F2, 8, C, ND_CS, wave, lane);
+    if (pre && !kv_out) frag_prefetch<4>(R, pre->w.Fqsg, 24, wave, lane);
+    __syncthreads();
+    {
+      float y[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) y[i] = C[er * ND_CS + ec + i] + sp[SP_B2 + ec + i];
+      row16_ln(y, sp + SP_LN_FFPOST_W, sp + SP_LN_FFPOST_B, ec, eps);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        y[i] += X[er * ND_XS + ec + i];
+        X[er * ND_XS + ec + i] = y[i];
+      }
+      if (live) {
+        *reinterpret_cast<float4*>(x + (size_t)grow * 128 + ec) = make_float4(y[0], y[1], y[2], y[3]);
+        *reinterpret_cast<float4*>(x + (size_t)grow * 128 + ec + 4) = make_float4(y[4], y[5], y[6], y[7]);
+      }
+    }
+    __syncthreads();
+  }
+  if (pre) {
+    const AttnW& w = pre->w;
+    stage_sp(w.sp);
+    if (!post && !kv_out) frag_prefetch<4>(R, w.Fqsg, 24, wave, lane);
+    if (kv_out) frag_prefetch<4>(R, w.Wkv_F, 16, wave, lane);   // (a POST in the same launch left the ring empty)
+    __syncthreads();
+    // ---- xn = LN_dst(x); q | s | g = [Wq ; Ws ; Wg_x] xn + bias  (:61-69, :106-107, :114)
+    {
+      float xn[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) xn[i] = X[er * ND_XS + ec + i];
+      row16_ln(xn, sp + SP_LN_DST_W, sp + SP_LN_DST_B, ec, eps);
+      planes_store8(P0h + er * ND_AS + ec, P0l + er * ND_AS + ec, xn);
+    }
+    __syncthreads();
+    if (kv_out) {   // k | v of these rows as sources (attention_layer.py:61,65,115-116)
+      gemm16<4>(R, P0h, P0l, ND_AS, w.Wkv_F, 16, C, ND_CS, wave, lane);
+      frag_prefetch<4>(R, w.Fqsg, 24, wave, lane);
+      __syncthreads();
+      if (live) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          float v[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) v[i] = C[er * ND_CS + half * 128 + ec + i] + (half ? w.bkv[128 + ec + i] : 0.f);
+          float* o = kv_out + (size_t)grow * 256 + half * 128 + ec;
+          *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+          *reinterpret_cast<float4*>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+          if (half == 0) {
+            half8 hh, ll;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { hh[i] = f16_hi(v[i]); ll[i] = f16_lo(v[i]); }
+            *reinterpret_cast<half8*>(khl_out + (size_t)grow * 256 + ec) = hh;
+            *reinterpret_cast<half8*>(khl_out + (size_t)grow * 256 + 128 + ec) = ll;
+          }
+        }
+      }
+      __syncthreads();
+    }
+    gemm16<4>(R, P0h, P0l, ND_AS, w.Fqsg, 24, C, ND_CS, wave, lane);
+    frag_prefetch<1>(R, KR == 3 ? w.Fkr3 : w.Fkr, 8 * 2 * KR, wave, lane);
+    __syncthreads();
+    {
+      float q[8], sv[8], gv[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        q[i] = C[er * ND_CS + ec + i] + sp[SP_BQ + ec + i];
+        sv[i] = C[er * ND_CS + 128 + ec + i] + sp[SP_BS + ec + i];
+        gv[i] = C[er * ND_CS + 256 + ec + i] + sp[SP_BG + ec + i];
+        AG[er * ND_XS + ec + i] = q[i];
+      }
+      planes_store8(P0h + er * ND_AS + ec, P0l + er * ND_AS + ec, q);
+      if (live) {
+        *reinterpret_cast<float4*>(io.q + (size_t)grow * 128 + ec) = make_float4(q[0], q[1], q[2], q[3]);
+        *reinterpret_cast<float4*>(io.q + (size_t)grow * 128 + ec + 4) = make_float4(q[4], q[5], q[6], q[7]);
+        *reinterpret_cast<float4*>(io.s + (size_t)grow * 128 + ec) = make_float4(sv[0], sv[1], sv[2], sv[3]);
+        *reinterpret_cast<float4*>(io.s + (size_t)grow * 128 + ec + 4) = make_float4(sv[4], sv[5], sv[6], sv[7]);
+        *reinterpret_cast<float4*>(io.g + (size_t)grow * 128 + ec) = make_float4(gv[0], gv[1], gv[2], gv[3]);
+        *reinterpret_cast<float4*>(io.g + (size_t)grow * 128 + ec + 4) = make_float4(gv[4], gv[5], gv[6], gv[7]);
+      }
+    }
+    __syncthreads();
+    // ---- q~[row][h][c] = sum_d q[row][16h + d] * Wkr_g[16h + d][c]: (head, 16-column tile) pairs over the waves;
+    //      A = the 32-column block of q that holds the head (the fragment zeroes the other head's 16 rows)
+    {
+      constexpr int NTQ = 2 * KR;
+      const _Float16* Fk = KR == 3 ? w.Fkr3 : w.Fkr;
+      const int G = (8 * NTQ - wave + 3) / 4;   // one k-block per tile: group g = tile wave + 4 g
+      for (int g0 = 0; g0 < G; g0 += ND_DEPTH) {
+#pragma unroll
+        for (int d = 0; d < ND_DEPTH; ++d) {
+          const int g = g0 + d;
+          if (g < G) {
+            const half8 bh = R.h[d][0], bl = R.l[d][0];
+            if (g + ND_DEPTH < G) frag_issue<1>(R, d, Fk, g + ND_DEPTH, wave, lane);
+            const int t = wave + 4 * g, h = t / NTQ, nt = t - h * NTQ;
+            const half8 ah = *reinterpret_cast<const half8*>(P0h + mi * ND_AS + (h >> 1) * 32 + kq * 8);
+            const half8 al = *reinterpret_cast<const half8*>(P0l + mi * ND_AS + (h >> 1) * 32 + kq * 8);
+            floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (row0 + 4 * kq + r < Nd) io.qt[(size_t)(row0 + 4 * kq + r) * 1024 + h * 128 + nt * 16 + mi] = acc[r];
+          }
+        }
+      }
+      if (tid < 128) {   // cq[row][h] = <q_h, kb_h>
+        const int r = tid >> 3, h = tid & 7;
+        float a = 0.f;
+        for (int d = 0; d < DH; ++d) a = fmaf(AG[r * ND_XS + h * DH + d], sp[SP_KB + h * DH + d], a);
+        if (row0 + r < Nd) io.cq[(size_t)(row0 + r) * 8 + h] = a;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Split path, edge side, for SMALL neighbourhoods (kNN graphs: degree <= 128 = 4 tiles; the scene encoder's s2s
+// layers have exactly 32).  One WAVE per destination, four destinations per workgroup, no cross-wave barrier: all
+// scores of the destination sit in registers (<= 8 blocks of 16 edges), the softmax is a few cross-lane steps, the
+// probabilities go through 4 KB of wave-private LDS to become MFMA A fragments, and the sums leave to global memory
+// for k_node.  Same operand scheme as k_attn_chain's edge phase (rtA / rtT images, quad-contiguous k gather).
+// MAXB: score blocks of 16 edges a destination can have (2 for the 32-neighbour s2s graphs -> 4 waves per SIMD).
+constexpr int ES_MAXDEG = 128;
+template <int MAXB>
+constexpr size_t es_lds_bytes() { return (size_t)4 * (MAXB * 16 * 8 * 4 + 16 * 17 * 16); }
+
+template <int KR, int MAXB>
+__global__ __launch_bounds__(256, (MAXB <= 2 ? 4 : 2)) void k_edge_small(int Nd, const ChainStep* __restrict__ step, EdgeIO io) {
+  constexpr int ES_DEG = MAXB * 16;
+  extern __shared__ __attribute__((aligned(16))) unsigned char es_smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* P = reinterpret_cast<float*>(es_smem) + wave * (ES_DEG * 8);                       // [deg][8] probabilities
+  half8* stg = reinterpret_cast<half8*>(es_smem + 4 * ES_DEG * 8 * 4) + wave * (16 * 17);   // k staging, row stride 17
+  const ChainStep& st = *step;
+  const int r = blockIdx.x * 4 + wave;
+  if (r >= Nd) return;   // (no barriers in this kernel)
+  const int mi = lane & 15, kq = lane >> 4;
+  const int e_beg = ldgi(st.eoff + r);
+  const int deg = min(ldgi(st.eoff + r + 1) - e_beg, ES_DEG);
+  const int t_beg = ldgi(st.toff + r);
+  // B operands of the score MFMAs (as in k_attn_chain): lane -> column n = lane & 15 (head n & 7, hi | lo half), k-block kq
+  half8 bq[KR], bk[4];
+  float cqm;
+  {
+    const int hB = mi & 7;
+    const bool lo = mi >= 8;
+    const float* qtp = io.qt + (size_t)r * 1024 + hB * 128 + 8 * kq;
+    const float* qp = io.q + (size_t)r * 128 + 8 * kq;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      if (ks < KR) {
+        const float4 v0 = ldg4(qtp + 32 * ks), v1 = ldg4(qtp + 32 * ks + 4);
+        const float qv_[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bq[ks < KR ? ks : 0][j] = lo ? f16_lo(qv_[j]) : f16_hi(qv_[j]);
+      }
+      const bool mine = (2 * ks + (kq >> 1)) == hB;   // the 8 columns 32 ks + 8 kq lie inside head 2 ks + (kq >> 1)
+      const float4 w0 = ldg4(qp + 32 * ks), w1 = ldg4(qp + 32 * ks + 4);
+      const float kv_[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float kk = mine ? kv_[j] : 0.f;
+        bk[ks][j] = lo ? f16_lo(kk) : f16_hi(kk);
+      }
+    }
+    cqm = ldg1(io.cq + (size_t)r * 8 + hB);
+  }
+  // ---- scores: block b = edges 16 b ..+15; lane (mi < 8, kq) ends with the scores of head mi, edges 16 b + 4 kq + r4
+  const int nb = (deg + 15) >> 4;
+  float sreg[MAXB][4];
+  const int rq = lane >> 2, pq = lane & 3;
+#pragma unroll
+  for (int b = 0; b < MAXB; ++b) {
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) sreg[b][r4] = -INFINITY;
+    if (b < nb) {
+      const _Float16* ra = st.rtA + (size_t)(t_beg + (b >> 1)) * 8192 + (b & 1) * 4096 + lane * 8;
+      const int e = min(16 * b + rq, deg - 1);
+      const _Float16* kp = st.khl + (size_t)ldgi(st.esrc + e_beg + e) * 256 + 8 * pq;
+      half8 arh[KR], arl[KR], nkh[4], nkl[4], akh[4], akl[4];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        if (ks < KR) {
+          arh[ks < KR ? ks : 0] = ldgh8(ra + 512 * ks);
+          arl[ks < KR ? ks : 0] = ldgh8(ra + 2048 + 512 * ks);
+        }
+        nkh[ks] = ldgh8(kp + 32 * ks);
+        nkl[ks] = ldgh8(kp + 128 + 32 * ks);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      half8* stw = stg + rq * 17 + pq;
+      const half8* str = stg + mi * 17 + kq;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) stw[4 * ks] = nkh[ks];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) akh[ks] = str[4 * ks];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) stw[4 * ks] = nkl[ks];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) akl[ks] = str[4 * ks];
+      floatx4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        if (ks < KR) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(arh[ks < KR ? ks : 0], bq[ks < KR ? ks : 0], acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(akh[ks], bk[ks], acc2, 0, 0, 0);
+        if (ks < KR) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(arl[ks < KR ? ks : 0], bq[ks < KR ? ks : 0], acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(akl[ks], bk[ks], acc2, 0, 0, 0);
+      }
+      acc += acc2;
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const float v = acc[r4] + dpp_xor8(acc[r4]);   // columns h and h + 8 (q hi | q lo)
+        if (16 * b + 4 * kq + r4 < deg) sreg[b][r4] = (v + cqm) * 0.25f;
+      }
+    }
+  }
+  // ---- softmax per head (torch_geometric.utils.softmax: max-shift, exp, / (sum + 1e-16)): the head's scores live in the
+  //      four lanes mi = h (+ the duplicates mi = h + 8), kq = 0..3
+  float m = -INFINITY;
+#pragma unroll
+  for (int b = 0; b < MAXB; ++b)
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) m = fmaxf(m, sreg[b][r4]);
+  m = fmaxf(m, __shfl_xor(m, 16));
+  m = fmaxf(m, __shfl_xor(m, 32));
+  float lsum = 0.f;
+#pragma unroll
+  for (int b = 0; b < MAXB; ++b) {
+    if (b < nb) {
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const int e = 16 * b + 4 * kq + r4;
+        const float p = (e < deg) ? expf(sreg[b][r4] - m) : 0.f;
+        lsum += p;
+        if (mi < 8 && e < deg) P[e * 8 + mi] = p;
+      }
+    }
+  }
+  lsum += __shfl_xor(lsum, 16);
+  lsum += __shfl_xor(lsum, 32);
+  if (lane < 8) io.l[(size_t)r * 8 + lane] = lsum;
+  // ---- aggregation: a_r on the matrix cores per 32-edge tile (A = p hi | lo x head, B = rtT), a_v on the VALU
+  floatx4 ar[2 * KR];
+#pragma unroll
+  for (int cb = 0; cb < 2 * KR; ++cb) ar[cb] = floatx4{0.f, 0.f, 0.f, 0.f};
+  const int ntile = (deg + 31) >> 5;
+  const bool loA = mi >= 8;
+  for (int t = 0; t < ntile; ++t) {
+    const _Float16* tp = st.rtT + (size_t)(t_beg + t) * 8192 + mi * 32 + kq * 8;
+    half8 bh[2 * KR], bl[2 * KR];
+#pragma unroll
+    for (int cb = 0; cb < 2 * KR; ++cb) {
+      bh[cb] = ldgh8(tp + cb * 512);
+      bl[cb] = ldgh8(tp + 4096 + cb * 512);
+    }
+    half8 ap;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int ee = 32 * t + 8 * kq + j;
+      const float pv = (ee < deg) ? P[ee * 8 + (mi & 7)] : 0.f;
+      ap[j] = loA ? f16_lo(pv) : f16_hi(pv);
+    }
+#pragma unroll
+    for (int cb = 0; cb < 2 * KR; ++cb) {
+      ar[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ap, bh[cb], ar[cb], 0, 0, 0);
+      ar[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ap, bl[cb], ar[cb], 0, 0, 0);
+    }
+  }
+  float4 av = make_float4(0.f, 0.f, 0.f, 0.f);
+  {
+    const float* vbase = st.kv + 128 + 4 * (lane & 31);
+    const int eh = lane >> 5, hv = (lane & 31) >> 2;
+    for (int eb = 0; eb < deg; eb += 16) {
+      float4 vv[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int ee = min(eb + 2 * j + eh, deg - 1);
+        vv[j] = ldg4(vbase + (size_t)ldgi(st.esrc + e_beg + ee) * 256);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int ee = eb + 2 * j + eh;
+        const float ph = (ee < deg) ? P[ee * 8 + hv] : 0.f;
+        av.x = fmaf(ph, vv[j].x, av.x);
+        av.y = fmaf(ph, vv[j].y, av.y);
+        av.z = fmaf(ph, vv[j].z, av.z);
+        av.w = fmaf(ph, vv[j].w, av.w);
+      }
+    }
+    av.x += __shfl_xor(av.x, 32); av.y += __shfl_xor(av.y, 32); av.z += __shfl_xor(av.z, 32); av.w += __shfl_xor(av.w, 32);
+    if (lane < 32) *reinterpret_cast<float4*>(io.av + (size_t)r * 128 + 4 * lane) = av;
+  }
+  // rows h (p hi) and h + 8 (p lo) sit 32 lanes apart: one half-wave swap folds two column blocks at a time
+#pragma unroll
+  for (int cb = 0; cb < 2 * KR; cb += 2) {
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+      const float v = swap_add32(ar[cb][r4], ar[cb + 1][r4]);   // lanes < 32: block cb, lanes >= 32: block cb + 1
+      io.ar[(size_t)r * 1024 + (4 * ((lane >> 4) & 1) + r4) * 128 + (cb + (lane >> 5)) * 16 + (lane & 15)] = v;
+    }
   }
 }
 
