@@ -194,7 +194,8 @@ def main():
             "metric": "agent-steps/sec closed-loop rollout", "value": value, "unit": "agent-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32",  # fp32 throughout; the score GEMMs run as split-fp16 MFMA with fp32 accumulate (fp32-class) "data": "synthetic",
+            # fp32 throughout; the matrix-core GEMMs take split-fp16 operands with fp32 accumulation (fp32-class)
+            "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{S} x BASELINE configs[{args.config}] scenes per GPU ({synth.BASELINE_CONFIGS[args.config]['name']}; "
                                    f"S=8 is configs[3]'s per-GPU share), 80-step closed-loop rollout (8 replans), seeded random-init weights",
                        "agents_per_scene": int(scene['prompt_mask'][0].sum()), "polylines_per_scene": int(scene['map_mask'].shape[1]),
