@@ -1,0 +1,166 @@
+"""Agent tracks -> the rollout path's input batch, without trajdata.
+
+The reference builds ``init_obs / init_map / prompt`` from trajdata ``SceneBatch`` objects
+(``prosim/dataset/format_utils.py``); trajdata is a third-party fork that is absent from the tree,
+so this module restates the arithmetic of those formatters on plain arrays:
+
+* ``tracks_from_table``     -- the demo cache's per-scene Arrow table (``agent_data_dt0.10.feather``:
+                               agent_id, scene_ts, x, y, vx, vy, ax, ay, heading, length, width) -> NaN-padded
+                               ``[agent][t]`` arrays;
+* ``scene_from_tracks``     -- ``get_center_obs`` (format_utils.py:357-447): the 11-step history of every agent
+                               in ITS OWN frame at the current step (offset by the pose at t0, rotated by
+                               -heading), NaN + mask for missing steps, extent / type / time one-hots, and the
+                               status prompt ``AgentStatusGenerator.prompt_for_scene_batch``
+                               (prompt_utils.py:111-150): [v_local(2), extent(2), type one-hot(3)];
+* ``polylines_to_map``      -- ``local_map_to_sym_coord`` + ``get_center_vec_init_map`` (format_utils.py:184-263):
+                               per-polyline frame = midpoint / tangent of (first start, last valid end), segments in
+                               that frame, type one-hot, unit direction;
+* ``lanes_from_tracks``     -- NOT in the reference: the demo maps are trajdata VectorMap protobufs whose schema
+                               lives in the missing fork, so the plumbing config draws its lane polylines along
+                               the paths the agents drove.
+
+``transform_to_frame_offset_rot`` (trajdata, absent) is restated from its name and call site: positions are
+offset and rotated into the frame, velocities / accelerations are rotated, headings are made relative --
+parity unpinned, like the rest of the trajdata boundary.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional, Sequence
+
+import numpy as np
+
+from .spec import ModelSpec
+
+TRACK_COLS = ("x", "y", "vx", "vy", "ax", "ay", "heading", "length", "width")
+
+
+def tracks_from_table(cols: Dict[str, np.ndarray], n_steps: Optional[int] = None) -> Dict[str, np.ndarray]:
+    """Columns of the per-scene agent table -> ``{'agent_ids': [N], name: [N, T] float64 (NaN = absent)}``.
+    Agents are ordered by id (string order, as the cache stores them)."""
+    ids = np.asarray(cols["agent_id"]).astype(str)
+    ts = np.asarray(cols["scene_ts"]).astype(np.int64)
+    uniq = sorted(set(ids.tolist()))
+    index = {a: i for i, a in enumerate(uniq)}
+    T = int(n_steps if n_steps is not None else ts.max() + 1)
+    rows = np.array([index[a] for a in ids])
+    keep = ts < T
+    out = {"agent_ids": np.array(uniq)}
+    for c in TRACK_COLS:
+        arr = np.full((len(uniq), T), np.nan, np.float64)
+        arr[rows[keep], ts[keep]] = np.asarray(cols[c], np.float64)[keep]
+        out[c] = arr
+    return out
+
+
+def _rotate(x, y, ang):
+    c, s = np.cos(ang), np.sin(ang)
+    return x * c - y * s, x * s + y * c
+
+
+def scene_from_tracks(spec: ModelSpec, tracks: Dict[str, np.ndarray], t0: int,
+                      map_polylines: Optional[Sequence[np.ndarray]] = None, agent_types: Optional[np.ndarray] = None,
+                      max_agents: Optional[int] = None, points: int = 19,
+                      agents: Optional[Sequence[int]] = None) -> Dict[str, np.ndarray]:
+    """One scene (batch 1) at current step ``t0``.  Agents whose state at ``t0`` is not finite are dropped
+    (get_center_obs skips non-target agents with a NaN origin, :383-388).  ``agents``: row indices of the track
+    table to consider (default: all), ``max_agents``: keep the first so many of those that are present."""
+    H = spec.hist_steps
+    if t0 < 0 or t0 >= tracks["x"].shape[1]:
+        raise ValueError("t0 outside the track table")
+    valid0 = np.isfinite(tracks["x"][:, t0]) & np.isfinite(tracks["y"][:, t0]) & np.isfinite(tracks["heading"][:, t0])
+    sel = np.nonzero(valid0)[0] if agents is None else np.array([i for i in agents if valid0[i]], np.int64)
+    if max_agents is not None:
+        sel = sel[:max_agents]
+    N = len(sel)
+    if N == 0:
+        raise ValueError("no agent is present at t0")
+    f32 = np.float32
+    lo = t0 - H + 1
+    win = np.arange(lo, t0 + 1)
+    inside = win >= 0
+
+    def window(name):
+        w = np.full((N, H), np.nan)
+        w[:, inside] = tracks[name][sel][:, win[inside]]
+        return w
+
+    x, y, h = window("x"), window("y"), window("heading")
+    vx, vy, ax, ay = window("vx"), window("vy"), window("ax"), window("ay")
+    x0, y0, h0 = x[:, -1:], y[:, -1:], h[:, -1:]
+    rx, ry = _rotate(x - x0, y - y0, -h0)
+    rvx, rvy = _rotate(vx, vy, -h0)
+    rax, ray = _rotate(ax, ay, -h0)
+    rh = h - h0
+    obs = np.full((1, N, H, spec.obs_dim), np.nan, np.float64)
+    obs[0, :, :, 0], obs[0, :, :, 1] = rx, ry
+    obs[0, :, :, 2], obs[0, :, :, 3] = np.sin(rh), np.cos(rh)
+    obs[0, :, :, 4], obs[0, :, :, 5] = rvx, rvy
+    obs[0, :, :, 6], obs[0, :, :, 7] = rax, ray
+    # extent: the largest finite (length, width) the agent ever reports (get_all_agent_data :318-322)
+    ext = np.stack([np.nanmax(np.where(np.isfinite(tracks[c][sel]), tracks[c][sel], -1.0), axis=1) for c in ("length", "width")], -1)
+    obs[0, :, :, 8:10] = ext[:, None, :]
+    types = np.ones(N, np.int64) if agent_types is None else np.asarray(agent_types, np.int64)[sel]
+    for tid in (1, 2, 3):
+        obs[0, :, :, 10 + tid - 1] = (types == tid)[:, None]
+    obs[0, :, :, 13:13 + H] = np.eye(H)
+    mask = np.isfinite(obs)
+    prompt = np.zeros((1, N, spec.prompt_dim), f32)
+    prompt[0, :, 0], prompt[0, :, 1] = np.nan_to_num(rvx[:, -1]), np.nan_to_num(rvy[:, -1])
+    prompt[0, :, 2:4] = ext
+    for tid in (1, 2, 3):
+        prompt[0, :, 4 + tid - 1] = types == tid
+    scene = dict(obs_input=obs.astype(f32), obs_mask=mask, obs_pos=np.stack([x0[:, 0], y0[:, 0]], -1)[None].astype(f32),
+                 obs_head=h0[:, 0][None].astype(f32), prompt=prompt, prompt_mask=np.ones((1, N), bool),
+                 agent_type=types[None], agent_ids=tracks["agent_ids"][sel])
+    if map_polylines is None:
+        map_polylines = lanes_from_tracks(tracks, points=points)
+    scene.update(polylines_to_map(spec, map_polylines, points=points))
+    return scene
+
+
+def polylines_to_map(spec: ModelSpec, polylines: Sequence[np.ndarray], points: int = 19, lane_type: int = 1) -> Dict[str, np.ndarray]:
+    """``polylines``: arrays ``[n_i + 1, 2]`` of scene-frame vertices (n_i <= points segments each).
+    Returns map_input [1, M, P, 11], map_mask [1, M, P], map_pos [1, M, 2], map_head [1, M]."""
+    M, P = len(polylines), points
+    f32 = np.float32
+    inp = np.zeros((1, M, P, spec.map_dim), np.float64)
+    msk = np.zeros((1, M, P), bool)
+    pos = np.zeros((1, M, 2), np.float64)
+    head = np.zeros((1, M), np.float64)
+    for m, pl in enumerate(polylines):
+        pl = np.asarray(pl, np.float64)
+        n = min(len(pl) - 1, P)
+        if n < 1:
+            raise ValueError("a polyline needs at least two vertices")
+        start, end = pl[:n], pl[1:n + 1]
+        s0, e1 = start[0], end[-1]                       # local_map_to_sym_coord: first start, last valid end
+        hd = np.arctan2(e1[1] - s0[1], e1[0] - s0[0])
+        ctr = (s0 + e1) / 2
+        for k, pts in ((0, start), (2, end)):
+            lx, ly = _rotate(pts[:, 0] - ctr[0], pts[:, 1] - ctr[1], -hd)
+            inp[0, m, :n, k], inp[0, m, :n, k + 1] = lx, ly
+        inp[0, m, :n, 4] = lane_type
+        inp[0, m, :n, 5] = 0.0                           # traffic-light state: unknown
+        for tid in (1, 2, 3):
+            inp[0, m, :n, 6 + tid - 1] = float(lane_type == tid)
+        d = inp[0, m, :n, 2:4] - inp[0, m, :n, 0:2]
+        inp[0, m, :n, 9:11] = d / np.clip(np.linalg.norm(d, axis=-1, keepdims=True), 1e-6, None)
+        msk[0, m, :n] = True
+        pos[0, m], head[0, m] = ctr, hd
+    return dict(map_input=inp.astype(f32), map_mask=msk, map_pos=pos.astype(f32), map_head=head.astype(f32))
+
+
+def lanes_from_tracks(tracks: Dict[str, np.ndarray], points: int = 19, min_len: float = 5.0, stride: int = 2):
+    """Lane-centre polylines along the paths the agents drove (a stand-in for the VectorMap lanes, see the module
+    docstring): every agent path is cut into polylines of ``points`` segments of ``stride`` steps each."""
+    out = []
+    for i in range(tracks["x"].shape[0]):
+        ok = np.isfinite(tracks["x"][i]) & np.isfinite(tracks["y"][i])
+        p = np.stack([tracks["x"][i][ok], tracks["y"][i][ok]], -1)[::stride]
+        for a in range(0, max(len(p) - 1, 0), points):
+            seg = p[a:a + points + 1]
+            if len(seg) >= 2 and np.linalg.norm(seg[-1] - seg[0]) >= min_len:
+                out.append(seg)
+    if not out:
+        raise ValueError("no agent moved far enough to draw a lane")
+    return out

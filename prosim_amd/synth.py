@@ -122,9 +122,9 @@ def make_scene(spec: ModelSpec, n_agents: int, n_polylines: int, batch: int = 1,
     return scene
 
 
-# The BASELINE.json configs (index -> generator kwargs).  Config 0's demo_dataset scene needs the
-# trajdata fork's VectorMap protobuf schema to load lanes (absent), so the plumbing config uses
-# a 16-agent synthetic scene of the same shape; config 4 (Waymo-val dense scene, unobtainable
+# The BASELINE.json configs (index -> generator kwargs).  Config 0's real demo_dataset scene is built by
+# prosim_amd/formatting.py from the sample agent table (lanes drawn along the driven paths: the VectorMap
+# protobuf schema lives in the absent trajdata fork); this entry is its synthetic twin of the same shape; config 4 (Waymo-val dense scene, unobtainable
 # offline) is a 256-agent scene in a 100 m square.  Both substitutions are stated in DESIGN.md.
 BASELINE_CONFIGS = [
     dict(name="cfg0_16a_128p", n_agents=16, n_polylines=128, batch=1),

@@ -183,7 +183,33 @@ def gen_pure():
     print("ref_pure primitives written:", sorted(out))
 
 
+def gen_demo_tracks(scene: str = "scene_0"):
+    """DATA fixture: the agent table of one demo_dataset scene (the reference's own sample data,
+    demo_dataset/trajdata_cache/waymo_train/<scene>/agent_data_dt0.10.feather), columns only -- the input of
+    prosim_amd/formatting.py.  float32, positions re-centred on the scene's first row to keep them small."""
+    import pyarrow.ipc as ipc
+    path = os.path.join(os.environ.get("PROSIM_REF", "/root/reference"), "demo_dataset", "trajdata_cache", "waymo_train", scene, "agent_data_dt0.10.feather")
+    with open(path, "rb") as f:
+        t = ipc.open_file(f).read_all()
+    cols = {c: t.column(c).to_numpy(zero_copy_only=False) for c in t.column_names}
+    out = {"agent_id": np.asarray(cols["agent_id"]).astype(str), "scene_ts": np.asarray(cols["scene_ts"], np.int64),
+           "origin": np.array([cols["x"][0], cols["y"][0]], np.float64)}
+    for c in ("x", "y", "vx", "vy", "ax", "ay", "heading", "length", "width"):
+        v = np.asarray(cols[c], np.float64)
+        if c == "x":
+            v = v - out["origin"][0]
+        if c == "y":
+            v = v - out["origin"][1]
+        out[c] = v.astype(np.float32)
+    np.savez_compressed(os.path.join(GOLD, f"demo_{scene}_agent_table.npz"), **out)
+    print("demo tracks written:", scene, len(out["scene_ts"]), "rows,", len(set(out["agent_id"].tolist())), "agents")
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
-    gen_pure()
-    gen_full()
+    if len(sys.argv) > 1 and sys.argv[1] == "tracks":
+        gen_demo_tracks()
+    else:
+        gen_pure()
+        gen_full()
+        gen_demo_tracks()

@@ -317,3 +317,36 @@ def test_future_obs_frames_and_conditions_subset(small_engine):
     assert err(o["motion_pred"][A:2 * A].numpy(), o_nofut["motion_pred"][A:2 * A].numpy()) > 1e-3   # the frames matter
     d = np.abs(small_engine.padded("traj") - o["traj"].numpy())[scene["prompt_mask"].astype(bool)].reshape(A, -1).max(1)
     assert (d < 1e-3).mean() >= 0.9
+
+
+def test_demo_dataset_scene_config0():
+    """BASELINE configs[0]: a demo_dataset scene (real Waymo tracks from the reference's sample cache, formatted by
+    prosim_amd/formatting.py; lanes drawn along the driven paths), 16 agents, 20-step unconditional rollout.
+    Ragged real histories (agents that appear mid-window) against the fp64 oracle."""
+    from prosim_amd import formatting as fmt
+    from prosim_amd.engine import Engine
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "demo_scene_0_agent_table.npz"))
+    tracks = fmt.tracks_from_table({k: g[k] for k in g.files if k != "origin"})
+    spec = DEMO_SPEC.replace(max_steps=20)
+    t0 = 10
+    present = np.isfinite(tracks["x"][:, t0])
+    late = present & ~np.isfinite(tracks["x"][:, 0])         # agents that appeared inside the history window first
+    order = list(np.nonzero(late)[0]) + list(np.nonzero(present & ~late)[0])
+    scene = fmt.scene_from_tracks(spec, tracks, t0, agents=order, max_agents=16)
+    scene.pop("agent_ids")
+    assert (~scene["obs_mask"][0, :, 0, :8]).any()          # some histories really are incomplete
+    w = weights.init_weights(spec, 0)
+    with torch.no_grad():
+        o64 = orc.rollout(w, spec, scene, dtype=torch.float64, collect=True)
+    eng = Engine(spec, w)
+    eng.set_scene(scene)
+    eng.encode_scene()
+    assert err(eng.get("scene_tokens"), o64["trace"]["scene_tokens"].numpy()) < TOL
+    eng.rollout()
+    A = eng.num_agents
+    assert A == 16
+    mp = eng.get("motion_pred")
+    assert err(mp[0], o64["motion_pred"][:A].numpy()) < TOL
+    d = np.abs(eng.padded("traj") - o64["traj"].numpy())[0].reshape(A, -1).max(1)
+    assert (d < TOL).mean() >= 0.9 and d.max() < 5e-3, d
+    eng.close()
