@@ -567,6 +567,9 @@ extern "C" int ps_create(const ps_config* cfg, int32_t n_tensors, const char* co
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pointnet_mfma), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PN_LDS_BYTES);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_node<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ND_LDS_BYTES);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_node<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ND_LDS_BYTES);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_chain<1, 4, 3, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_chain<2, 4, 3, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_chain<4, 4, 3, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 #define PS_ATTR(TT, NWW, KRR) \
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_chain<TT, NWW, KRR>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
   PS_ATTR(1, 4, 3); PS_ATTR(2, 4, 3); PS_ATTR(4, 4, 3); PS_ATTR(4, 8, 3);
@@ -997,7 +1000,11 @@ int launch_chain(ps_engine* e, float* x, int Nd, int step0, int nsteps, int maxd
   const int kr = steps_host_kr;   // every step of a launch has the same rel-PE width
 #define PS_LAUNCH(TT, NWW, KRR, GRID, LDS) \
   hipLaunchKernelGGL((k_attn_chain<TT, NWW, KRR>), dim3(GRID), dim3(64 * NWW), LDS, st, x, x_in, Nd, steps, nsteps, maxdeg, eps, flags, prof)
-  if (kr == 3) {
+  if (timed && kr == 3 && (T == 1 || T == 2 || T == 4)) {   // the policy launch under its own symbol
+    if (T == 4) hipLaunchKernelGGL((k_attn_chain<4, 4, 3, false, true>), dim3((Nd + 3) / 4), dim3(WG), lds4, st, x, x_in, Nd, steps, nsteps, maxdeg, eps, flags, prof);
+    else if (T == 2) hipLaunchKernelGGL((k_attn_chain<2, 4, 3, false, true>), dim3((Nd + 1) / 2), dim3(WG), lds2, st, x, x_in, Nd, steps, nsteps, maxdeg, eps, flags, prof);
+    else hipLaunchKernelGGL((k_attn_chain<1, 4, 3, true, true>), dim3(Nd), dim3(WG), lds1, st, x, x_in, Nd, steps, nsteps, maxdeg, eps, flags, prof);
+  } else if (kr == 3) {
     if (T == 84) PS_LAUNCH(4, 8, 3, (Nd + 3) / 4, lds84);
     else if (T == 4) PS_LAUNCH(4, 4, 3, (Nd + 3) / 4, lds4);
     else if (T == 2) PS_LAUNCH(2, 4, 3, (Nd + 1) / 2, lds2);

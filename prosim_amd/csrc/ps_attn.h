@@ -186,7 +186,9 @@ __device__ __forceinline__ void fold_kgroups(float (&acc)[T][4]) {
 // BIG: compiled for ONE workgroup per CU with the whole register file (512 per lane): weight chunks and edge
 // rows are software-prefetched into second register sets.  !BIG (T >= 2 default): two workgroups per CU, <= 256
 // registers, the co-resident workgroup hides latency instead.
-template <int T, int NW = 4, int KR = 3, bool BIG = (T == 1)>
+// POLICY: no effect on the code -- the per-replan policy launch (12 layers) gets its own symbol, so a kernel trace
+// lists the dominant launch apart from the 1-2-layer launches of the same build (profiles/, bench.py's roofline).
+template <int T, int NW = 4, int KR = 3, bool BIG = (T == 1), bool POLICY = false>
 __global__ __launch_bounds__(64 * NW, ((!BIG && NW == 4) ? 2 : 1)) void k_attn_chain(float* __restrict__ x, const float* __restrict__ x_in, int Nd,
                                                      const ChainStep* __restrict__ steps, int nsteps, int maxdeg, float eps, int flags,
                                                      unsigned long long* __restrict__ prof) {
