@@ -159,13 +159,17 @@ int ps_test_fourier(ps_engine* e, int32_t n, const float* x4, float* out128);
 int ps_test_wrap(ps_engine* e, int32_t n, const float* x, float* out);
 /* One AttentionLayer (models/layers/attention_layer.py:56-121) on caller-supplied tokens and a
  * CSR-by-destination edge list; rt = relative-PE rows already LayerNorm-normalised (no affine).
- * layer_index counts over [a2a | s2s | p2p | s2p | a2p | m2p | cond] layers; T in {0 (auto),1,2,4}. */
+ * layer_index counts over [a2a | s2s | p2p | s2p | a2p | m2p | cond] layers.  T selects the kernel build:
+ * 0 auto, 1 / 2 / 4 destination rows per 256-thread workgroup of the fused chain, 84 = 4 rows on 8 waves,
+ * 16 = the split layer (k_node + k_edge_small + k_node; falls back to the fused chain above degree 128). */
 int ps_test_attn(ps_engine* e, int32_t layer_index, int32_t Ns, int32_t Nd, int32_t E, const float* x_src,
                  const float* x_dst, const float* rt, const int32_t* eoff, const int32_t* esrc, int32_t T, float* out);
-/* Read back an edge set built by the last stage: which = 0 a2a, 1 s2s, 2 p2p, 3 s2p, 4 a2p, 5 m2p. */
+/* Read back an edge set built by the last stage: which = 0 a2a, 1 s2s, 2 p2p, 3 s2p, 4 a2p, 5 m2p.
+ * Returns the edge count; rt (optional) receives the normalised rel-PE rows [E][128] rebuilt from the
+ * split-fp16 operand image (columns 96..127 repeat 64..95). */
+int64_t ps_test_get_edges(ps_engine* e, int32_t which, int32_t* esrc, int32_t* edst, float* rt, int64_t capacity);
 /* Micro-benchmark: nwg workgroups stream the same mbytes buffer (depth x 16 float4 in flight per thread). */
 int ps_test_stream(ps_engine* e, int32_t mbytes, int32_t nwg, int32_t depth, int32_t iters, float* ms_out);
-int64_t ps_test_get_edges(ps_engine* e, int32_t which, int32_t* esrc, int32_t* edst, float* rt, int64_t capacity);
 
 #ifdef __cplusplus
 }
