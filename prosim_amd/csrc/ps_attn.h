@@ -422,10 +422,14 @@ __global__ __launch_bounds__(64 * NW, ((!BIG && NW == 4) ? 2 : 1)) void k_attn_c
           // k rows are gathered by source.  Loaded straight into the A-fragment shape (lane = edge + 16*kq) the
           // 4 lanes of a quad would read 4 different rows and the load issues at a quarter of the rate; so the
           // gather uses lane = 4*row + piece (each quad reads 64 contiguous bytes) and the 16 x 256 B half rows
-          // turn into fragments through a wave-private LDS staging area (row stride 272 B).
+          // turn into fragments through a wave-private LDS staging area (4 KB, swizzled: below).
           const int rq = lane >> 2, pq = lane & 3;
-          half8* stw = reinterpret_cast<half8*>(f1 + wave * 1088) + rq * 17 + pq;
-          const half8* str = reinterpret_cast<const half8*>(f1 + wave * 1088) + mi * 17 + kq;
+          // staging layout: 16-byte unit (row, 4 ks + piece) sits at row*16 + ((4 ks + piece) ^ ((row & 3) << 2) ^ (row >> 2)):
+          // the quad-major writes (16 lanes = 4 rows x 4 pieces) and the fragment reads (16 lanes = 16 rows, one piece)
+          // both touch 16 distinct bank groups (a plain padded row stride serves only one of the two)
+          half8* stw = reinterpret_cast<half8*>(f1 + wave * 1024) + rq * 16 + (pq ^ (rq >> 2));
+          const half8* str = reinterpret_cast<const half8*>(f1 + wave * 1024) + mi * 16 + (kq ^ (mi >> 2));
+          const int swa = rq & 3, sra = mi & 3;
           half8 nrh[4], nrl[4], nkh[4], nkl[4];
           auto gather1 = [&](int eb) {
             const int blk = (c0 + eb) >> 4;
@@ -457,13 +461,13 @@ __global__ __launch_bounds__(64 * NW, ((!BIG && NW == 4) ? 2 : 1)) void k_attn_c
               for (int ks = 0; ks < 4; ++ks) { akh[ks] = nkh[ks]; akl[ks] = nkl[ks]; }
             } else {
 #pragma unroll
-              for (int ks = 0; ks < 4; ++ks) stw[4 * ks] = nkh[ks];
+              for (int ks = 0; ks < 4; ++ks) stw[4 * (ks ^ swa)] = nkh[ks];
 #pragma unroll
-              for (int ks = 0; ks < 4; ++ks) akh[ks] = str[4 * ks];
+              for (int ks = 0; ks < 4; ++ks) akh[ks] = str[4 * (ks ^ sra)];
 #pragma unroll
-              for (int ks = 0; ks < 4; ++ks) stw[4 * ks] = nkl[ks];
+              for (int ks = 0; ks < 4; ++ks) stw[4 * (ks ^ swa)] = nkl[ks];
 #pragma unroll
-              for (int ks = 0; ks < 4; ++ks) akl[ks] = str[4 * ks];
+              for (int ks = 0; ks < 4; ++ks) akl[ks] = str[4 * (ks ^ sra)];
             }
             if (PFE && eb + 16 * W < cn) gather1(eb + 16 * W);   // the next tile's rows fly under this tile's MFMAs
             floatx4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
@@ -1241,7 +1245,7 @@ __global__ __launch_bounds__(256) void k_node(float* __restrict__ x, int Nd, con
 // MAXB: score blocks of 16 edges a destination can have (2 for the 32-neighbour s2s graphs -> 4 waves per SIMD).
 constexpr int ES_MAXDEG = 128;
 template <int MAXB>
-constexpr size_t es_lds_bytes() { return (size_t)4 * (MAXB * 16 * 8 * 4 + 16 * 17 * 16); }
+constexpr size_t es_lds_bytes() { return (size_t)4 * (MAXB * 16 * 8 * 4 + 16 * 16 * 16); }
 
 template <int KR, int MAXB>
 __global__ __launch_bounds__(256, (MAXB <= 2 ? 4 : 2)) void k_edge_small(int Nd, const ChainStep* __restrict__ step, EdgeIO io) {
@@ -1249,7 +1253,7 @@ __global__ __launch_bounds__(256, (MAXB <= 2 ? 4 : 2)) void k_edge_small(int Nd,
   extern __shared__ __attribute__((aligned(16))) unsigned char es_smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float* P = reinterpret_cast<float*>(es_smem) + wave * (ES_DEG * 8);                       // [deg][8] probabilities
-  half8* stg = reinterpret_cast<half8*>(es_smem + 4 * ES_DEG * 8 * 4) + wave * (16 * 17);   // k staging, row stride 17
+  half8* stg = reinterpret_cast<half8*>(es_smem + 4 * ES_DEG * 8 * 4) + wave * (16 * 16);   // k staging (swizzled, as in k_attn_chain)
   const ChainStep& st = *step;
   const int r = blockIdx.x * 4 + wave;
   if (r >= Nd) return;   // (no barriers in this kernel)
@@ -1307,16 +1311,17 @@ __global__ __launch_bounds__(256, (MAXB <= 2 ? 4 : 2)) void k_edge_small(int Nd,
         nkl[ks] = ldgh8(kp + 128 + 32 * ks);
       }
       __builtin_amdgcn_sched_barrier(0);
-      half8* stw = stg + rq * 17 + pq;
-      const half8* str = stg + mi * 17 + kq;
+      half8* stw = stg + rq * 16 + (pq ^ (rq >> 2));
+      const half8* str = stg + mi * 16 + (kq ^ (mi >> 2));
+      const int swa = rq & 3, sra = mi & 3;
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) stw[4 * ks] = nkh[ks];
+      for (int ks = 0; ks < 4; ++ks) stw[4 * (ks ^ swa)] = nkh[ks];
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) akh[ks] = str[4 * ks];
+      for (int ks = 0; ks < 4; ++ks) akh[ks] = str[4 * (ks ^ sra)];
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) stw[4 * ks] = nkl[ks];
+      for (int ks = 0; ks < 4; ++ks) stw[4 * (ks ^ swa)] = nkl[ks];
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) akl[ks] = str[4 * ks];
+      for (int ks = 0; ks < 4; ++ks) akl[ks] = str[4 * (ks ^ sra)];
       floatx4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
