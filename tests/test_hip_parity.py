@@ -350,3 +350,22 @@ def test_demo_dataset_scene_config0():
     d = np.abs(eng.padded("traj") - o64["traj"].numpy())[0].reshape(A, -1).max(1)
     assert (d < TOL).mean() >= 0.9 and d.max() < 5e-3, d
     eng.close()
+
+
+def test_split_s2s_layers_on_a_ragged_batch(demo_engine):
+    """>= 2048 scene tokens switch the s2s layers to the split launches (k_node + k_edge_small): a ragged 2-scene
+    batch (token counts that are no multiple of the 16-row tiles, polylines with few valid points, incomplete
+    histories) against the fp64 oracle's scene tokens and generator output."""
+    spec = DEMO_SPEC
+    scene = synth.make_scene(spec, 160, 1100, batch=2, seed=21, goal=True, ragged=True)
+    w = weights.init_weights(spec, 0)
+    with torch.no_grad():
+        o64 = orc.rollout(w, spec, scene, dtype=torch.float64, collect=True)
+    eng = demo_engine
+    eng.set_scene(scene)
+    assert eng.num_agents + eng.num_map_tokens >= 2048
+    eng.encode_scene()
+    assert err(eng.get("scene_tokens"), o64["trace"]["scene_tokens"].numpy()) < TOL
+    eng.generate_policy()
+    pm = torch.from_numpy(scene["prompt_mask"].astype(bool))
+    assert err(eng.get("policy_emd"), o64["policy_emd"][pm].numpy()) < 2 * TOL
