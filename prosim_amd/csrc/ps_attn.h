@@ -90,26 +90,6 @@ __host__ __device__ constexpr size_t attn_lds_floats(int /*maxdeg*/) {
          2 * SP_SIZE + (size_t)chunk_edges<T>() * T;
 }
 
-// 8 partial sums (one per head) held by each of 8 consecutive lanes -> lane cc ends with the
-// total of head cc (transpose-reduce, 7 shuffles instead of 24).
-__device__ __forceinline__ float reduce8_to_lane(const float (&a)[8], int cc) {
-  float b[4], c[2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const float lo = a[i], hi = a[i + 4];
-    const float send = (cc & 4) ? lo : hi, keep = (cc & 4) ? hi : lo;
-    b[i] = keep + __shfl_xor(send, 4);
-  }
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const float lo = b[i], hi = b[i + 2];
-    const float send = (cc & 2) ? lo : hi, keep = (cc & 2) ? hi : lo;
-    c[i] = keep + __shfl_xor(send, 2);
-  }
-  const float send = (cc & 1) ? c[0] : c[1], keep = (cc & 1) ? c[1] : c[0];
-  return keep + __shfl_xor(send, 1);
-}
-
 // ---- weight streaming.  With one destination row per workgroup a layer is GEMV work: 960 KB of
 // fp32 weights stream through each CU per layer and nothing is reused, so the kernel is bound by
 // how many bytes it keeps in flight and by the length of its dependency chain.
@@ -192,7 +172,10 @@ template <int T, int NW = 4, int KR = 3, bool BIG = (T == 1), bool POLICY = fals
 __global__ __launch_bounds__(64 * NW, ((!BIG && NW == 4) ? 2 : 1)) void k_attn_chain(float* __restrict__ x, const float* __restrict__ x_in, int Nd,
                                                      const ChainStep* __restrict__ steps, int nsteps, int maxdeg, float eps, int flags,
                                                      unsigned long long* __restrict__ prof) {
-  // phase clocks for tools/gpu_phase.py (prof == nullptr in every product launch): thread 0 of each
+  // flags: ablation switches of tools/gpu_ablate.py / gpu_profile.sh (0 in every product launch; results are wrong
+  // when set): 1 no edges, 8 skip the aggregation pass, 16 skip the score pass, 32 read the rel-PE images from a
+  // cache-resident region, 128 no k staging.
+  // phase clocks (PS_CHAIN_PROF=1; prof == nullptr in every product launch): thread 0 of each
   // workgroup charges the core-clock cycles since the previous mark to phase i
   long long tprev = prof ? clock64() : 0;
 #define PS_MARK(i)                                                        \
@@ -211,10 +194,6 @@ __global__ __launch_bounds__(64 * NW, ((!BIG && NW == 4) ? 2 : 1)) void k_attn_c
   constexpr int L5 = 128 / NW;
   static_assert(KG * RK == 128 && (64 / L5) * 4 * RK == 128, "GEMV tiling");
   constexpr int CH = chunk_edges<T>();
-  if ((flags >> 8) && blockIdx.x >= gridDim.x / 2) {   // experiment: de-phase the two workgroups of a CU
-    const long long t0 = clock64(), dl = (long long)(flags >> 8) << 10;
-    while (clock64() - t0 < dl) __builtin_amdgcn_s_sleep(32);
-  }
   // T == 1: one workgroup per CU with the full register file -> software prefetch (weights one chunk ahead,
   // edge rows one tile ahead).  T >= 2: compiled for 2 workgroups per CU (__launch_bounds__(256, 2), <= 256
   // registers): the co-resident workgroup hides the latency instead and nothing is double-buffered.
@@ -436,7 +415,7 @@ __global__ __launch_bounds__(64 * NW, ((!BIG && NW == 4) ? 2 : 1)) void k_attn_c
             const _Float16* ra = (flags & 32) ? st.rtA + (size_t)((t_beg + (blk >> 1)) & 7) * 8192 + (blk & 1) * 4096 + lane * 8
                                               : st.rtA + (size_t)(t_beg + (blk >> 1)) * 8192 + (blk & 1) * 4096 + lane * 8;
             const int e = (eb + rq < cn) ? eb + rq : cn - 1;
-            const _Float16* kp = st.khl + (size_t)((flags & 64) ? (e & 15) : el[e]) * 256 + 8 * pq;   // 64: ablation, cached rows
+            const _Float16* kp = st.khl + (size_t)el[e] * 256 + 8 * pq;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
               if (ks < 3 || k4) {

@@ -56,17 +56,12 @@ __device__ __forceinline__ half8 ldgh8(const _Float16* p) { return *(g_chalf8*)p
 __device__ __forceinline__ _Float16 f16_hi(float x) { return (_Float16)x; }
 __device__ __forceinline__ _Float16 f16_lo(float x) { return (_Float16)(x - (float)(_Float16)x); }
 
-// ---- cross-lane exchange without the LDS pipe (gfx950): v_permlane32/16_swap exchange half-waves /
-// odd-even rows between TWO registers, DPP covers xor 8 / 2 / 1 inside a row of 16.
+// ---- cross-lane exchange without the LDS pipe (gfx950): v_permlane32_swap exchanges half-waves between TWO
+// registers, DPP covers xor 8 / 2 / 1 inside a row of 16.
 // swap_add32(lo, hi): lanes 0-31 get lo[l] + lo[l+32], lanes 32-63 get hi[l-32] + hi[l] -- one
 // step of a transposing reduction (the lane's bit 5 selects which of the two values it keeps).
 __device__ __forceinline__ float swap_add32(float lo, float hi) {
   const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo), __float_as_uint(hi), false, false);
-  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-// swap_add16(lo, hi): even rows get lo[own] + lo[row^1], odd rows get hi[row^1] + hi[own] (lane bit 4).
-__device__ __forceinline__ float swap_add16(float lo, float hi) {
-  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(lo), __float_as_uint(hi), false, false);
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 __device__ __forceinline__ float dpp_xor8(float v) {   // row_ror:8
@@ -78,10 +73,6 @@ __device__ __forceinline__ float dpp_xor2(float v) {   // quad_perm [2,3,0,1]
 __device__ __forceinline__ float dpp_xor1(float v) {   // quad_perm [1,0,3,2]
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true));
 }
-// one transposing-reduction step inside a row: the lane keeps the value selected by `bit` and adds
-// the partner's copy of the same value
-#define PS_TSTEP(lo, hi, bitset, xchg) (((bitset) ? (hi) : (lo)) + xchg((bitset) ? (lo) : (hi)))
-
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -114,14 +105,6 @@ __device__ __forceinline__ void ln_row_wave(const float* __restrict__ x, float* 
   }
   y[lane] = y0;
   y[lane + 64] = y1;
-}
-
-// LayerNorm of T rows held in LDS (row stride `xs`/`ys`) by the 4 waves of a 256-thread WG.
-template <int T>
-__device__ __forceinline__ void ln_rows(const float* x, int xs, float* y, int ys, const float* __restrict__ w,
-                                        const float* __restrict__ b, float eps, bool relu) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  for (int t = wave; t < T; t += 4) ln_row_wave(x + t * xs, y + t * ys, w, b, eps, lane, relu);
 }
 
 // Small-N GEMV (N not a multiple of 128): one thread per output, torch layout W[N][K].
