@@ -462,14 +462,17 @@ def rel_traj_coord_to_last_step(traj: T) -> T:
 def rollout(w: Dict[str, np.ndarray], spec: ModelSpec, scene_in: Dict, dtype=torch.float32,
             collect: bool = False) -> Dict:
     """``ProSim.forward(batch, 'val')`` (traj_sam.py:59-175, 205-349, 562-633) for a batch of
-    scenes whose policy agents are exactly the observed agents, in the same slot order
-    (what the synthetic BASELINE configs and M-replica rollouts use).
+    scenes whose policy agents sit in the slots of their observations (prompt_mask[b, n] implies that slot n is
+    observed); observed agents without a prompt are log-replay agents.
 
     scene_in (numpy or torch, batch-major, padded):
       map_input [B,M,P,11], map_mask [B,M,P], map_pos [B,M,2], map_head [B,M]
       obs_input [B,N,11,24] (NaN where masked), obs_mask [B,N,11,24], obs_pos [B,N,2], obs_head [B,N]
       prompt [B,N,7], prompt_mask [B,N], agent_type [B,N] (1..3)
-      optional fut_obs_input [R-1,B,N,11,24], fut_obs_mask [R-1,...] (defaults: the init tensors)
+      optional fut_obs_input [R-1,B,N,11,24], fut_obs_mask [R-1,...] (defaults: the init tensors) and
+      fut_obs_pos [R-1,B,N,2], fut_obs_head [R-1,B,N] (defaults: the init poses): the log of every agent at the
+      later replans (batch.extras['fut_obs'][t], traj_sam.py:221-270); policy agents' rows are overwritten by the
+      simulation, observed agents that are not policy agents (prompt_mask False) replay the log
       optional cond = {'goal': {...}, 'v_action_tag': {...}}
     """
     Wt = W(w, dtype)
@@ -517,6 +520,7 @@ def rollout(w: Dict[str, np.ndarray], spec: ModelSpec, scene_in: Dict, dtype=tor
     p_type = agent_type[prompt_mask]
     fut_in = scene_in.get("fut_obs_input")
     fut_mk = scene_in.get("fut_obs_mask")
+    fut_pos, fut_head = scene_in.get("fut_obs_pos"), scene_in.get("fut_obs_head")
     motion_preds, fused, step_edges = [], [], []
     last = H
     for ti in range(R):
@@ -536,8 +540,10 @@ def rollout(w: Dict[str, np.ndarray], spec: ModelSpec, scene_in: Dict, dtype=tor
             f_in[prompt_mask, :, :4] = rel_tr[prompt_mask][:, -H:]
             f_in[prompt_mask, :, 4:8] = rva[prompt_mask]
             f_mk[prompt_mask] = True
-            f_pos = torch.where(prompt_mask[..., None], a_pos, obs_pos)
-            f_head = torch.where(prompt_mask, a_head[..., 0], obs_head)
+            l_pos = tt(fut_pos[ti - 1]) if fut_pos is not None else obs_pos
+            l_head = tt(fut_head[ti - 1]) if fut_head is not None else obs_head
+            f_pos = torch.where(prompt_mask[..., None], a_pos, l_pos)
+            f_head = torch.where(prompt_mask, a_head[..., 0], l_head)
             new_emb, new_mask = encode_obs(Wt, spec, f_in, f_mk)
             scene = replace_obs(scene, new_emb, new_mask, f_pos, f_head)
             if collect:

@@ -24,10 +24,14 @@ from .spec import ModelSpec
 
 def make_scene(spec: ModelSpec, n_agents: int, n_polylines: int, batch: int = 1, seed: int = 0,
                square: float = 200.0, points: int = 19, goal: bool = False, tags: bool = False,
-               ragged: bool = False, clustered: bool = False) -> Dict[str, np.ndarray]:
+               ragged: bool = False, clustered: bool = False, replay: float = 0.0) -> Dict[str, np.ndarray]:
     """One batch of ``batch`` scenes.  ``ragged``: later scenes in the batch get fewer agents /
     polylines / points, and some history steps are masked (NaN), to exercise the mask paths.
-    ``clustered``: agents are placed along polylines (realistic density) instead of uniformly."""
+    ``clustered``: agents are placed along polylines (realistic density) instead of uniformly.
+    ``replay`` > 0: that fraction of the observed agents is NOT policy-controlled (prompt_mask False, history valid):
+    they replay a log -- ``fut_obs_input / fut_obs_mask / fut_obs_pos / fut_obs_head`` [R-1, B, N, ...] carry their
+    observation and pose at every later replan (straight-line motion here; a few drop out of the log), as the
+    reference's ``batch.extras['fut_obs'][t]`` does (traj_sam.py:221-270)."""
     rng = np.random.RandomState(1234 + seed)
     B, N, M, P, H = batch, n_agents, n_polylines, points, spec.hist_steps
     f32 = np.float32
@@ -98,6 +102,35 @@ def make_scene(spec: ModelSpec, n_agents: int, n_polylines: int, batch: int = 1,
     scene = dict(map_input=map_input, map_mask=map_mask, map_pos=map_pos, map_head=map_head,
                  obs_input=obs_input, obs_mask=obs_mask, obs_pos=obs_pos, obs_head=obs_head,
                  prompt=prompt, prompt_mask=prompt_mask, agent_type=agent_type)
+    if replay > 0:
+        observed = prompt_mask.copy()
+        logged = observed & (rng.rand(B, N) < replay)
+        logged[:, 0] = False                                   # at least one policy agent per scene
+        prompt_mask = observed & ~logged
+        scene["prompt_mask"] = prompt_mask
+        scene["prompt"] = np.where(prompt_mask[..., None], prompt, 0.0).astype(f32)
+        R = spec.n_replans
+        speed = rng.uniform(0.0, 8.0, (B, N)).astype(f32)
+        fi = np.repeat(obs_input[None], R - 1, 0).copy()
+        fm = np.repeat(obs_mask[None], R - 1, 0).copy()
+        fp = np.zeros((R - 1, B, N, 2), f32)
+        fh = np.zeros((R - 1, B, N), f32)
+        for r in range(1, R):
+            tsec = r * spec.replan_freq * spec.dt
+            fp[r - 1] = obs_pos + (speed * tsec)[..., None] * np.stack([np.cos(obs_head), np.sin(obs_head)], -1)
+            fh[r - 1] = obs_head + 0.02 * r
+            # ego-relative history of a straight constant-speed drive, in the frame of the pose at that replan
+            steps = (np.arange(H) - (H - 1)) * spec.dt
+            fi[r - 1, ..., 0] = speed[..., None] * steps
+            fi[r - 1, ..., 1] = 0.0
+            fi[r - 1, ..., 2], fi[r - 1, ..., 3] = 0.0, 1.0
+            fi[r - 1, ..., 4], fi[r - 1, ..., 5] = speed[..., None], 0.0
+            fi[r - 1, ..., 6:8] = 0.0
+            gone = logged & (rng.rand(B, N) < 0.15)            # dropped from the log at this replan: all points masked
+            fm[r - 1][gone] = False
+            fm[r - 1][~observed] = False
+        fi = np.where(fm, fi, np.nan).astype(f32)
+        scene.update(fut_obs_input=fi, fut_obs_mask=fm, fut_obs_pos=fp, fut_obs_head=fh)
     cond = {}
     if goal:
         g = np.zeros((B, N, 3), f32)

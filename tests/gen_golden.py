@@ -52,6 +52,8 @@ FULL_CASES = {
     "small_plain_b1": ("small", dict(n_agents=16, n_polylines=128, batch=1, seed=1), 1),
     "small_goal_64a": ("small", dict(n_agents=64, n_polylines=512, batch=1, seed=2, goal=True), 0),
     "demo_16a_128p": ("demo", dict(n_agents=16, n_polylines=128, batch=1, seed=3, goal=True), 0),
+    # policy agents are a SUBSET of the observed agents: the others replay a log (fut_obs frames)
+    "small_replay_b2": ("small", dict(n_agents=16, n_polylines=128, batch=2, seed=5, goal=True, ragged=True, replay=0.4), 0),
 }
 SPECS = {"small": SMALL_SPEC, "demo": DEMO_SPEC}
 
@@ -75,7 +77,7 @@ def run_reference(spec, w, scene):
     traj = np.zeros((B, N, R, 4), np.float32)
     vel = np.zeros((B, N, R, 2), np.float32)
     for b in range(B):
-        for n in range(int(scene["prompt_mask"][b].sum())):
+        for n in np.nonzero(scene["prompt_mask"][b])[0]:          # policy agents keep their observation slot's id
             r = out["rollout_trajs"][f"{b}-a{n}"]
             traj[b, n] = r["traj"].numpy()
             vel[b, n] = r["vel"].numpy()
@@ -207,7 +209,10 @@ def gen_demo_tracks(scene: str = "scene_0"):
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
-    if len(sys.argv) > 1 and sys.argv[1] == "tracks":
+    if len(sys.argv) > 2 and sys.argv[1] == "only":
+        FULL_CASES = {k: v for k, v in FULL_CASES.items() if k in sys.argv[2:]}
+        gen_full()
+    elif len(sys.argv) > 1 and sys.argv[1] == "tracks":
         gen_demo_tracks()
     else:
         gen_pure()
