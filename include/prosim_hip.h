@@ -94,6 +94,16 @@ int ps_set_conditions(ps_engine* e, int32_t C_goal, const float* goal_input, con
  * type, time one-hot) are used -- columns 0..7 are overwritten by step_env
  * (traj_sam.py:266-270).  Default: the init_obs columns. */
 int ps_set_future_obs(ps_engine* e, const float* fut_input);
+/* The full log of the later replans -- batch.extras['fut_obs'][t] (traj_sam.py:221-270): observation
+ * [R-1][B][N][hist][obs_dim], its mask, position [R-1][B][N][2] and heading [R-1][B][N].  Observed agents WITHOUT a
+ * prompt (prompt_mask false on an observed slot of ps_set_scene) are log-replay agents: at replan t their scene token
+ * is re-encoded from this log and sits at the logged pose; a row whose history is fully masked is no token at that
+ * replan.  Policy agents' rows are overwritten by the simulation (only the static features 8.. are read). */
+int ps_set_future_log(ps_engine* e, const float* fut_input, const uint8_t* fut_mask, const float* fut_pos,
+                      const float* fut_head);
+/* Agent rows (= observed agents, the order of every per-agent result of ps_get) that are policy agents. */
+int32_t ps_num_policy_agents(ps_engine* e);
+int ps_policy_flags(ps_engine* e, int32_t* flags, int64_t capacity);
 
 /* scene_encoder(batch_obs, batch_map) -> token store on device (traj_sam.py:73-77;
  * scene_encoder/base.py:31-46, attn_fusion.py:78-134). */

@@ -106,6 +106,14 @@ struct ps_engine {
   DevBuf<int> d_ent_off, d_ent_type;
   DevBuf<float> d_ent_val;
   bool have_fut = false;
+  // log-replay agents: observed agents that are not policy agents (prompt_mask false on an observed slot).  Every
+  // observed agent is a ROW of the per-agent buffers; is_policy marks the rows the simulation drives.
+  int n_policy = 0;
+  bool all_policy = true, have_log = false;
+  std::vector<int> is_policy_h;
+  DevBuf<int> d_is_policy, d_tok_live;
+  DevBuf<uint8_t> d_obs_in_mask, d_fut_mask, d_obs_mask_rows;   // (d_obs_mask_rows: the initial mask, one row per agent)
+  DevBuf<float> d_fut_pos, d_fut_head;
   int stride_steps = 0;
   // timing of the dominant kernel
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -585,6 +593,9 @@ extern "C" void ps_destroy(ps_engine* e) {
   (void)hipDeviceSynchronize();
   // DevBuf members are plain structs without destructors: release explicitly
   e->d_map_input.release(); e->d_obs_input.release(); e->d_prompt.release(); e->d_fut.release();
+  e->d_is_policy.release(); e->d_tok_live.release(); e->d_obs_in_mask.release(); e->d_fut_mask.release();
+  e->d_obs_mask_rows.release();
+  e->d_fut_pos.release(); e->d_fut_head.release();
   e->d_map_mask.release(); e->d_obs_mask.release();
   e->d_map_rows.release(); e->d_agent_rows.release(); e->d_tok_scene.release(); e->d_agent_type.release();
   e->d_r_map.release(); e->d_r_agent.release(); e->d_r_zero.release();
@@ -645,6 +656,7 @@ extern "C" int ps_set_scene(ps_engine* e, int32_t B, int32_t M, int32_t P, int32
   const int Hs = c.hist_steps, Od = c.obs_dim;
   e->B = B; e->M = M; e->P = P; e->N = N;
   e->map_rows.clear(); e->agent_rows.clear(); e->agent_scene.clear(); e->map_scene.clear();
+  e->is_policy_h.clear();
   e->moff.assign(B + 1, 0); e->aoff.assign(B + 1, 0);
   e->maxA_scene = e->maxM_scene = 0;
   for (int b = 0; b < B; ++b) {
@@ -662,10 +674,12 @@ extern "C" int ps_set_scene(ps_engine* e, int32_t B, int32_t M, int32_t P, int32
         for (int f = 0; f < Od; ++f) all &= mk[f] != 0;
         any |= all;
       }
-      if (any != (prompt_mask[(size_t)b * N + n] != 0))
-        return fail(PS_E_ARG, "policy agents must be exactly the observed agents (scene " + std::to_string(b) + ", slot " +
-                                  std::to_string(n) + ")");
+      const bool pol = prompt_mask[(size_t)b * N + n] != 0;
+      if (pol && !any)
+        return fail(PS_E_ARG, "a policy agent must be observed: its prompt sits in the slot of its history (scene " +
+                                  std::to_string(b) + ", slot " + std::to_string(n) + ")");
       if (any) {
+        e->is_policy_h.push_back(pol ? 1 : 0);
         const int ty = agent_type[(size_t)b * N + n];
         if (ty < 1 || ty > c.num_agent_types) return fail(PS_E_ARG, "agent_type outside 1..num_agent_types");
         e->agent_rows.push_back(b * N + n);
@@ -681,6 +695,11 @@ extern "C" int ps_set_scene(ps_engine* e, int32_t B, int32_t M, int32_t P, int32
   const int Mv = e->Mv = (int)e->map_rows.size();
   const int A = e->A = (int)e->agent_rows.size();
   if (A == 0) return fail(PS_E_ARG, "no valid agents");
+  e->n_policy = 0;
+  for (int v : e->is_policy_h) e->n_policy += v;
+  if (e->n_policy == 0) return fail(PS_E_ARG, "no policy agent (prompt_mask is empty)");
+  e->all_policy = e->n_policy == A;
+  e->have_log = false;
   hipStream_t st = e->stream;
   // raw inputs
   if (upload(e->d_map_input, map_input, (size_t)B * M * P * c.map_dim, st) || upload(e->d_map_mask, map_mask, (size_t)B * M * P, st) ||
@@ -726,6 +745,14 @@ extern "C" int ps_set_scene(ps_engine* e, int32_t B, int32_t M, int32_t P, int32
     if (upload(e->d_static_in, stat.data(), stat.size(), st)) return fail(PS_E_HIP, "static obs upload failed");
   }
   e->have_fut = false;
+  {
+    const size_t arow = (size_t)c.hist_steps * c.obs_dim;
+    std::vector<uint8_t> mrows((size_t)A * arow);
+    for (int i = 0; i < A; ++i) std::memcpy(&mrows[(size_t)i * arow], obs_mask + (size_t)e->agent_rows[i] * arow, arow);
+    if (upload(e->d_is_policy, e->is_policy_h.data(), (size_t)A, st) || e->d_tok_live.ensure((size_t)A) ||
+        e->d_obs_in_mask.ensure((size_t)A * arow) || upload(e->d_obs_mask_rows, mrows.data(), mrows.size(), st))
+      return fail(PS_E_HIP, "policy-flag upload failed");
+  }
   const int R = (c.max_steps + c.replan_freq - 1) / c.replan_freq;
   e->stride_steps = Hs + R * c.replan_freq;
   const int L6 = std::max({c.scene_layers, c.dec_layers, c.pol_layers, c.cond_layers, 1});
@@ -930,6 +957,46 @@ extern "C" int ps_set_future_obs(ps_engine* e, const float* fut_input) {
   return PS_OK;
 }
 
+extern "C" int ps_set_future_log(ps_engine* e, const float* fut_input, const uint8_t* fut_mask, const float* fut_pos,
+                                 const float* fut_head) {
+  if (!e || !e->have_scene) return fail(PS_E_STATE, "ps_set_future_log before ps_set_scene");
+  int rc = ps_set_future_obs(e, fut_input);
+  if (rc) return rc;
+  const ps_config& c = e->cfg;
+  const int R = (c.max_steps + c.replan_freq - 1) / c.replan_freq;
+  e->have_log = false;
+  if (!fut_input || R < 2) return PS_OK;
+  if (!fut_mask || !fut_pos || !fut_head) return fail(PS_E_ARG, "ps_set_future_log needs mask, position and heading frames");
+  const int A = e->A;
+  const size_t arow = (size_t)c.hist_steps * c.obs_dim, frame = (size_t)e->B * e->N;
+  std::vector<uint8_t> mk((size_t)(R - 1) * A * arow);
+  std::vector<float> ps((size_t)(R - 1) * A * 2), hd((size_t)(R - 1) * A);
+  for (int r = 0; r < R - 1; ++r)
+    for (int i = 0; i < A; ++i) {
+      const size_t slot = (size_t)r * frame + e->agent_rows[i];
+      std::memcpy(&mk[((size_t)r * A + i) * arow], fut_mask + slot * arow, arow);
+      ps[((size_t)r * A + i) * 2] = fut_pos[slot * 2];
+      ps[((size_t)r * A + i) * 2 + 1] = fut_pos[slot * 2 + 1];
+      hd[(size_t)r * A + i] = fut_head[slot];
+    }
+  if (upload(e->d_fut_mask, mk.data(), mk.size(), e->stream) || upload(e->d_fut_pos, ps.data(), ps.size(), e->stream) ||
+      upload(e->d_fut_head, hd.data(), hd.size(), e->stream))
+    return fail(PS_E_HIP, "future log upload failed");
+  HIPCHK(hipStreamSynchronize(e->stream));
+  e->have_log = true;
+  drop_graph(e);
+  return PS_OK;
+}
+
+extern "C" int32_t ps_num_policy_agents(ps_engine* e) { return e ? e->n_policy : 0; }
+// flags[i] = 1 if agent row i (the order of every per-agent result) is a policy agent, 0 if it replays the log
+extern "C" int ps_policy_flags(ps_engine* e, int32_t* flags, int64_t capacity) {
+  if (!e || !flags) return fail(PS_E_ARG, "null argument");
+  if (capacity < e->A) return fail(PS_E_ARG, "destination too small");
+  for (int i = 0; i < e->A; ++i) flags[i] = e->is_policy_h[i];
+  return PS_OK;
+}
+
 // ------------------------------------------------------------------------------------------ launches
 namespace {
 
@@ -1078,6 +1145,8 @@ struct RadArgs {
   const int *r1, *r2;
   float r;
   int cap, self_base;
+  const int* cand_ok = nullptr;   // optional candidate filter (RadSet::cand_ok)
+  int cand_base = 0;
 };
 void launch_radius(ps_engine* e, const RadArgs* a, int nsets, const float* qpos, const int* qscene, int nq, const float* src_ori,
                    const float* dst_ori) {
@@ -1085,7 +1154,7 @@ void launch_radius(ps_engine* e, const RadArgs* a, int nsets, const float* qpos,
   for (int i = 0; i < nsets; ++i) {
     EdgeSet& es = *a[i].es;
     rs.s[i] = RadSet{CandSet{e->d_tok_pos.p, a[i].r1, a[i].r2}, a[i].r * a[i].r, a[i].cap, a[i].self_base, es.cnt.p,
-                     es.eoff.p, es.toff.p, es.tdst.p, es.esrc.p, es.edst.p};
+                     es.eoff.p, es.toff.p, es.tdst.p, es.esrc.p, es.edst.p, a[i].cand_ok, a[i].cand_base};
   }
   const int wpb = 4, grid = (nq + wpb - 1) / wpb;
   hipStream_t st = e->stream;
@@ -1093,7 +1162,7 @@ void launch_radius(ps_engine* e, const RadArgs* a, int nsets, const float* qpos,
   for (int i = 0; i < nsets; ++i)
     if (a[i].self_base >= 0)
       hipLaunchKernelGGL(k_radius_selfrank, dim3(grid), dim3(64 * wpb), 0, st, rs.s[i].cs, qpos, qscene, nq, rs.s[i].r2, a[i].cap,
-                         a[i].self_base, a[i].es->cnt.p);
+                         a[i].self_base, a[i].es->cnt.p, a[i].cand_ok, a[i].cand_base);
   hipLaunchKernelGGL(k_exclusive_scan, dim3(nsets), dim3(1024), 0, st, rs, nq);
   hipLaunchKernelGGL(k_radius<1>, dim3(grid, nsets), dim3(64 * wpb), 0, st, rs, qpos, qscene, nq);
   PeArgs pe[2];
@@ -1101,8 +1170,9 @@ void launch_radius(ps_engine* e, const RadArgs* a, int nsets, const float* qpos,
   launch_relpe(e, pe, nsets);
 }
 void launch_radius(ps_engine* e, EdgeSet& es, const int* r1, const int* r2, const float* qpos, const int* qscene, int nq, float r,
-                   int cap, int self_base, const float* src_ori, const float* dst_ori) {
-  RadArgs a{&es, r1, r2, r, cap, self_base};
+                   int cap, int self_base, const float* src_ori, const float* dst_ori, const int* cand_ok = nullptr,
+                   int cand_base = 0) {
+  RadArgs a{&es, r1, r2, r, cap, self_base, cand_ok, cand_base};
   launch_radius(e, &a, 1, qpos, qscene, nq, src_ori, dst_ori);
 }
 
@@ -1173,7 +1243,9 @@ extern "C" int ps_generate_policy(ps_engine* e) {
   // positions taken from the prompt poses -> stage them as the agent token geometry
   HIPCHK(hipMemcpyAsync(e->d_tok_pos.p + 2 * (size_t)Mv, ppos, sizeof(float) * 2 * A, hipMemcpyDeviceToDevice, st));
   HIPCHK(hipMemcpyAsync(e->d_tok_ori.p + Mv, pori, sizeof(float) * A, hipMemcpyDeviceToDevice, st));
-  launch_radius(e, e->e_p2p, e->d_r_agent.p, nullptr, ppos, pscene, A, c.dec_prompt_radius, c.dec_max_neigh, Mv, e->d_tok_ori.p, pori);
+  // (with log-replay agents in the scene only the policy agents are prompts: candidate filter)
+  launch_radius(e, e->e_p2p, e->d_r_agent.p, nullptr, ppos, pscene, A, c.dec_prompt_radius, c.dec_max_neigh, Mv, e->d_tok_ori.p, pori,
+                e->all_policy ? nullptr : (const int*)e->d_is_policy.p, Mv);
   // restore observed agent poses for the scene tokens, then s2p: radius over all scene tokens (:94)
   HIPCHK(hipMemcpyAsync(e->d_tok_pos.p + 2 * (size_t)Mv, e->d_init_pos.p, sizeof(float) * 2 * A, hipMemcpyDeviceToDevice, st));
   HIPCHK(hipMemcpyAsync(e->d_tok_ori.p + Mv, e->d_init_head.p, sizeof(float) * A, hipMemcpyDeviceToDevice, st));
@@ -1234,22 +1306,40 @@ extern "C" int ps_policy_step(ps_engine* e, int32_t t_idx) {
   hipStream_t st = e->stream;
   const int last = c.hist_steps + t_idx * c.replan_freq;
   const float* stat = (e->have_fut && t_idx > 0) ? e->d_fut.p + (size_t)(t_idx - 1) * A * c.hist_steps * c.obs_dim : e->d_static_in.p;
+  StepLog lg{};
+  if (!e->all_policy) {   // log-replay agents: this replan's logged observation / validity / pose
+    const size_t arow = (size_t)c.hist_steps * c.obs_dim;
+    const bool fr = t_idx > 0 && e->have_fut, frl = t_idx > 0 && e->have_log;
+    lg.is_policy = e->d_is_policy.p;
+    lg.frame_in = fr ? e->d_fut.p + (size_t)(t_idx - 1) * A * arow : nullptr;
+    lg.frame_mask = frl ? e->d_fut_mask.p + (size_t)(t_idx - 1) * A * arow : nullptr;
+    lg.frame_pos = frl ? e->d_fut_pos.p + (size_t)(t_idx - 1) * A * 2 : nullptr;
+    lg.frame_head = frl ? e->d_fut_head.p + (size_t)(t_idx - 1) * A : nullptr;
+    lg.init_mask = e->d_obs_mask_rows.p;
+    lg.obs_mask = e->d_obs_in_mask.p;
+    lg.live = e->d_tok_live.p;
+  }
   // step_env (traj_sam.py:205-274)
   hipLaunchKernelGGL(k_step_env, dim3(A), dim3(64), 0, st, (const float*)e->d_traj.p, (const float*)e->d_vel.p, e->stride_steps, last,
                      c.hist_steps, c.dt, (const float*)e->d_init_pos.p, (const float*)e->d_init_head.p, stat, c.obs_dim, e->d_obs_in.p,
                      e->d_cur_pos.p, e->d_cur_ori.p, t_idx > 0 ? 1 : 0, t_idx > 0 ? e->d_tok_pos.p + 2 * (size_t)Mv : (float*)nullptr,
-                     t_idx > 0 ? e->d_tok_ori.p + Mv : (float*)nullptr);
+                     t_idx > 0 ? e->d_tok_ori.p + Mv : (float*)nullptr, lg);
   float* atok = e->d_tok.p + (size_t)Mv * D;
   if (t_idx > 0) {
     // update_scene_emb / _replace_old_obs (attn_fusion.py:205-250): re-encode agents, swap tokens + poses
     // (k_step_env already moved the agents' token poses)
-    launch_pointnet(e, e->pn_obs, e->d_obs_in.p, (const uint8_t*)nullptr, (const int*)nullptr, A, c.hist_steps, -1, atok);
+    if (e->all_policy)
+      launch_pointnet(e, e->pn_obs, e->d_obs_in.p, (const uint8_t*)nullptr, (const int*)nullptr, A, c.hist_steps, -1, atok);
+    else   // logged observations carry their own validity
+      launch_pointnet(e, e->pn_obs, e->d_obs_in.p, (const uint8_t*)e->d_obs_in_mask.p, (const int*)nullptr, A, c.hist_steps, c.obs_dim, atok);
   }
   // policy.forward (policy/base.py:19 -> temporal_ar.py:75 -> act_decoder.py:239-283)
   launch_kv(e, atok, A, e->L_a2p, c.pol_layers, e->d_kv_a2p.p, e->d_kh_a2p.p, (size_t)A * 256);
   const int* pscene = e->d_tok_scene.p + Mv;
   {
-    const RadArgs ra[2] = {{&e->e_a2p, e->d_r_agent.p, nullptr, c.pol_agent_radius, c.pol_max_neigh, -1},
+    // (a log-replay agent that dropped out of the log at this replan is no scene token: candidate filter)
+    const RadArgs ra[2] = {{&e->e_a2p, e->d_r_agent.p, nullptr, c.pol_agent_radius, c.pol_max_neigh, -1,
+                            e->all_policy ? nullptr : (const int*)e->d_tok_live.p, Mv},
                            {&e->e_m2p, e->d_r_map.p, nullptr, c.pol_map_radius, c.pol_max_neigh, -1}};
     launch_radius(e, ra, 2, e->d_cur_pos.p, pscene, A, e->d_tok_ori.p, e->d_cur_ori.p);
   }
@@ -1344,7 +1434,7 @@ extern "C" int ps_rollout_metric(ps_engine* e, const float* gt_dev, float* out_d
   const ps_config& c = e->cfg;
   const int R = (c.max_steps + c.replan_freq - 1) / c.replan_freq;
   hipLaunchKernelGGL(k_rollout_metric, dim3((e->A + 127) / 128), dim3(128), 0, e->stream, (const float*)e->d_traj.p, e->stride_steps,
-                     c.hist_steps, R * c.replan_freq, gt_dev, e->A, out_dev);
+                     c.hist_steps, R * c.replan_freq, gt_dev, e->A, out_dev, e->all_policy ? (const int*)nullptr : (const int*)e->d_is_policy.p);
   HIPCHK(hipGetLastError());
   return PS_OK;
 }

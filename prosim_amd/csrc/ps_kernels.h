@@ -228,6 +228,10 @@ struct RadSet {
   int cap, self_base;
   int* cnt;
   int *eoff, *toff, *tdst, *esrc, *edst;
+  // optional candidate filter: candidate token i takes part iff cand_ok[i - cand_base] != 0 (tokens below cand_base
+  // always do).  p2p: only POLICY agents are prompts; a2p: log-replay agents that dropped out of the log are no tokens.
+  const int* cand_ok;
+  int cand_base;
 };
 struct RadSets {
   RadSet s[2];
@@ -238,6 +242,8 @@ __global__ void k_radius(RadSets sets, const float* __restrict__ qpos, const int
   const CandSet cs = S.cs;
   const float r2 = S.r2;
   const int cap = S.cap, self_base = S.self_base;
+  const int* __restrict__ cand_ok = S.cand_ok;
+  const int cand_base = S.cand_base;
   int* __restrict__ cnt = S.cnt;
   const int* __restrict__ eoff = S.eoff;
   const int* __restrict__ toff = S.toff;
@@ -254,7 +260,8 @@ __global__ void k_radius(RadSets sets, const float* __restrict__ qpos, const int
   const float qx = qpos[2 * q], qy = qpos[2 * q + 1];
   const int b = qscene[q];
   const int capx = cap + (self_base >= 0 ? 1 : 0);
-  const int self = self_base >= 0 ? self_base + q : -1;
+  // (a query that is filtered out as a candidate has no self match to drop)
+  const int self = (self_base >= 0 && (!cand_ok || cand_ok[self_base + q - cand_base])) ? self_base + q : -1;
   int run = 0;
   const int base_out = (MODE == 1) ? eoff[q] : 0;
   for (int rg = 0; rg < 2 && run < capx; ++rg) {
@@ -264,7 +271,7 @@ __global__ void k_radius(RadSets sets, const float* __restrict__ qpos, const int
     for (int i0 = beg; i0 < end && run < capx; i0 += 64) {
       const int i = i0 + lane;
       bool ok = false;
-      if (i < end) ok = dist2(cs.pos[2 * i], cs.pos[2 * i + 1], qx, qy) < r2;
+      if (i < end) ok = dist2(cs.pos[2 * i], cs.pos[2 * i + 1], qx, qy) < r2 && (!cand_ok || i < cand_base || cand_ok[i - cand_base]);
       const unsigned long long m = __ballot(ok);
       const int rank = run + __popcll(m & ((1ull << lane) - 1ull));
       if (MODE == 1 && ok && rank < capx && i != self) {
@@ -283,10 +290,12 @@ __global__ void k_radius(RadSets sets, const float* __restrict__ qpos, const int
 // self handling for the count: the self match is always inside r (d2 = 0) -- it occupies a rank
 // slot iff its rank < cap+1.  Done in a second tiny pass to keep k_radius simple.
 __global__ void k_radius_selfrank(CandSet cs, const float* __restrict__ qpos, const int* __restrict__ qscene, int nq,
-                                  float r2, int cap, int self_base, int* __restrict__ cnt) {
+                                  float r2, int cap, int self_base, int* __restrict__ cnt, const int* __restrict__ cand_ok,
+                                  int cand_base) {
   const int q = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (q >= nq) return;
+  if (cand_ok && !cand_ok[self_base + q - cand_base]) return;   // not a candidate itself: nothing to drop
   const float qx = qpos[2 * q], qy = qpos[2 * q + 1];
   const int b = qscene[q];
   const int self = self_base + q;
@@ -298,7 +307,7 @@ __global__ void k_radius_selfrank(CandSet cs, const float* __restrict__ qpos, co
     for (int i0 = beg; i0 < end; i0 += 64) {
       const int i = i0 + lane;
       bool ok = false;
-      if (i < end) ok = dist2(cs.pos[2 * i], cs.pos[2 * i + 1], qx, qy) < r2;
+      if (i < end) ok = dist2(cs.pos[2 * i], cs.pos[2 * i + 1], qx, qy) < r2 && (!cand_ok || i < cand_base || cand_ok[i - cand_base]);
       before += __popcll(__ballot(ok));
     }
   }
@@ -705,13 +714,66 @@ __global__ void k_split_rows(const float* __restrict__ in, int n, _Float16* __re
 // K12  step_env (traj_sam.py:205-274 + models/utils/geometry.py:24-58 + _get_rel_vel_acc :552):
 // the last hist+2 states -> ego-relative history features written into obs_in[:, :hist, :8];
 // also the agents' current pose (a_pos, :211-215).  One 64-thread WG per agent.
+struct StepLog {                 // all null when every observed agent is a policy agent
+  const int* is_policy;          // [A]
+  const float* frame_in;         // [A][hist][obs_dim] logged observation of this replan (null at replan 0)
+  const uint8_t* frame_mask;     // [A][hist][obs_dim]
+  const float* frame_pos;        // [A][2] logged pose (null: the initial pose)
+  const float* frame_head;       // [A]
+  const uint8_t* init_mask;      // [A][hist][obs_dim] mask of the initial observation
+  uint8_t* obs_mask;             // [A][hist][obs_dim] OUT: validity of obs_in for the agent encoder
+  int* live;                     // [A] OUT: the agent is a scene token at this replan
+};
 __global__ __launch_bounds__(64) void k_step_env(const float* __restrict__ traj, const float* __restrict__ vel, int stride_steps,
                                                  int last, int hist, float dt, const float* __restrict__ init_pos,
                                                  const float* __restrict__ init_head, const float* __restrict__ static_in,
                                                  int obs_dim, float* __restrict__ obs_in, float* __restrict__ cur_pos,
                                                  float* __restrict__ cur_ori, int write_obs, float* __restrict__ tok_pos,
-                                                 float* __restrict__ tok_ori) {
+                                                 float* __restrict__ tok_ori, StepLog lg) {
   const int a = blockIdx.x, tid = threadIdx.x;
+  if (lg.is_policy && !lg.is_policy[a]) {
+    // log-replay agent (observed, not policy-controlled): observation, validity and pose of this replan come from
+    // the log (batch.extras['fut_obs'][t], traj_sam.py:221-270), nothing from the simulated trajectories
+    const int n = hist * obs_dim;
+    int any_valid = 0;
+    for (int i = tid; i < n; i += 64) {
+      const size_t o = (size_t)a * n + i;
+      const bool ok = lg.frame_mask ? lg.frame_mask[o] != 0 : lg.init_mask[o] != 0;
+      if (write_obs) {
+        const float v = lg.frame_in ? lg.frame_in[o] : static_in[o];
+        obs_in[o] = ok ? v : 0.f;
+      }
+      lg.obs_mask[o] = ok ? 1 : 0;
+    }
+    // a token exists iff some history step is fully valid (obs_encoder.py:84, mask.any)
+    for (int s = tid; s < hist; s += 64) {
+      bool all = true;
+      for (int f = 0; f < obs_dim; ++f) {
+        const size_t o = ((size_t)a * hist + s) * obs_dim + f;
+        all &= lg.frame_mask ? lg.frame_mask[o] != 0 : lg.init_mask[o] != 0;
+      }
+      any_valid |= all ? 1 : 0;
+    }
+    any_valid = __any(any_valid);
+    if (tid == 0) {
+      const float px = lg.frame_pos ? lg.frame_pos[2 * a] : init_pos[2 * a], py = lg.frame_pos ? lg.frame_pos[2 * a + 1] : init_pos[2 * a + 1];
+      const float hd = lg.frame_head ? lg.frame_head[a] : init_head[a];
+      cur_pos[2 * a] = px;
+      cur_pos[2 * a + 1] = py;
+      cur_ori[a] = hd;
+      if (tok_pos) {
+        tok_pos[2 * a] = px;
+        tok_pos[2 * a + 1] = py;
+        tok_ori[a] = hd;
+      }
+      lg.live[a] = any_valid;
+    }
+    return;
+  }
+  if (lg.obs_mask) {   // policy agent in a scene that also has log-replay agents: its simulated history is all valid
+    for (int i = tid; i < hist * obs_dim; i += 64) lg.obs_mask[(size_t)a * hist * obs_dim + i] = 1;
+    if (tid == 0) lg.live[a] = 1;
+  }
   const float* tr = traj + (size_t)a * stride_steps * 4;
   const float* vl = vel + (size_t)a * stride_steps * 2;
   const float lx = tr[(last - 1) * 4], ly = tr[(last - 1) * 4 + 1];
@@ -935,9 +997,14 @@ __global__ __launch_bounds__(256) void k_policy_head_mfma(HeadW w, const float* 
 // tensor that is then all-gathered over RCCL).
 __global__ void k_rollout_metric(const float* __restrict__ traj, int stride_steps, int hist, int steps,
                                  const float* __restrict__ gt /*[A][steps][2] or null*/, int n_agents,
-                                 float* __restrict__ out) {
+                                 float* __restrict__ out, const int* __restrict__ is_policy) {
   const int a = blockIdx.x * blockDim.x + threadIdx.x;
   if (a >= n_agents) return;
+  if (is_policy && !is_policy[a]) {   // log-replay agents are not simulated
+    out[2 * a] = 0.f;
+    out[2 * a + 1] = 0.f;
+    return;
+  }
   float sum = 0.f, last = 0.f;
   for (int s = 0; s < steps; ++s) {
     const float* t = traj + ((size_t)a * stride_steps + hist + s) * 4;

@@ -63,6 +63,10 @@ def load_library():
                                       fp, fp, fp, i32p, i32p, fp, fp]
     lib.ps_set_conditions.argtypes = [vp, C.c_int32, fp, u8p, i32p, C.c_int32, fp, u8p, i32p]
     lib.ps_set_future_obs.argtypes = [vp, fp]
+    lib.ps_set_future_log.argtypes = [vp, fp, u8p, fp, fp]
+    lib.ps_num_policy_agents.argtypes = [vp]
+    lib.ps_num_policy_agents.restype = C.c_int32
+    lib.ps_policy_flags.argtypes = [vp, i32p, C.c_int64]
     for name in ("ps_encode_scene", "ps_generate_policy", "ps_reset_rollout", "ps_rollout", "ps_sync"):
         getattr(lib, name).argtypes = [vp]
     lib.ps_policy_step.argtypes = [vp, C.c_int32]
@@ -85,7 +89,7 @@ def load_library():
     return lib
 
 
-EXPORTS = ["ps_create", "ps_destroy", "ps_last_error", "ps_set_scene", "ps_set_prompt", "ps_policy_forward", "ps_set_conditions", "ps_set_future_obs",
+EXPORTS = ["ps_create", "ps_destroy", "ps_last_error", "ps_set_scene", "ps_set_prompt", "ps_policy_forward", "ps_set_conditions", "ps_set_future_obs", "ps_set_future_log", "ps_num_policy_agents", "ps_policy_flags",
            "ps_encode_scene", "ps_generate_policy", "ps_reset_rollout", "ps_policy_step", "ps_rollout", "ps_sync",
            "ps_set_state", "ps_get", "ps_rollout_metric", "ps_num_agents", "ps_num_map_tokens", "ps_time_rollout", "ps_time_policy_kernel",
            "ps_test_pointnet", "ps_test_fourier", "ps_test_wrap", "ps_test_attn", "ps_test_get_edges", "ps_test_stream"]
@@ -176,7 +180,11 @@ class Engine:
                                           _f(obs_input), _u8(obs_mask), _f(keep[11]), _f(keep[12]), _f(prompt), _u8(pm),
                                           _i32(at), _f(ppos), _f(phead)))
         self._shape = (B, N)
-        self._slots = np.nonzero(pm.reshape(-1))[0]
+        # agent rows = observed agents (a history step with every feature valid), in slot order; policy agents are the
+        # rows whose slot carries a prompt, the others replay the log (ps_set_future_log)
+        seen = obs_mask.astype(bool).all(-1).any(-1).reshape(-1)
+        self._slots = np.nonzero(seen)[0]
+        self.policy_rows = pm.reshape(-1).astype(bool)[self._slots]
         cond = s.get("cond") or {}
         g, t = cond.get("goal"), cond.get("v_action_tag")
         args = []
@@ -192,7 +200,13 @@ class Engine:
         self._check(self.lib.ps_set_conditions(self.h, *args))
         if s.get("fut_obs_input") is not None:
             fo = np.ascontiguousarray(s["fut_obs_input"], dtype=np.float32)
-            self._check(self.lib.ps_set_future_obs(self.h, _f(fo)))
+            if s.get("fut_obs_mask") is not None and s.get("fut_obs_pos") is not None and s.get("fut_obs_head") is not None:
+                fm = np.ascontiguousarray(s["fut_obs_mask"]).astype(np.uint8)
+                fp_ = np.ascontiguousarray(s["fut_obs_pos"], dtype=np.float32)
+                fh = np.ascontiguousarray(s["fut_obs_head"], dtype=np.float32)
+                self._check(self.lib.ps_set_future_log(self.h, _f(fo), _u8(fm), _f(fp_), _f(fh)))
+            else:
+                self._check(self.lib.ps_set_future_obs(self.h, _f(fo)))
 
     def set_prompt(self, prompt, prompt_pos, prompt_head, agent_type):
         a = [np.ascontiguousarray(prompt, np.float32), np.ascontiguousarray(prompt_pos, np.float32),
@@ -242,7 +256,12 @@ class Engine:
 
     @property
     def num_agents(self) -> int:
+        """Agent rows = observed agents (policy agents and log-replay agents)."""
         return self.lib.ps_num_agents(self.h)
+
+    @property
+    def num_policy_agents(self) -> int:
+        return self.lib.ps_num_policy_agents(self.h)
 
     @property
     def num_map_tokens(self) -> int:
@@ -263,6 +282,8 @@ class Engine:
     def padded(self, name: str) -> np.ndarray:
         """Per-agent result scattered back to the padded [B, N, ...] slot layout of the inputs."""
         a = self.get(name)
+        if name in ("traj", "vel", "policy_emd", "reconst_pred", "fused"):
+            a = np.where(self.policy_rows.reshape((-1,) + (1,) * (a.ndim - 1)), a, 0.0).astype(np.float32)   # log-replay rows
         B, N = self._shape
         out = np.zeros((B * N,) + a.shape[1:], np.float32)
         out[self._slots] = a

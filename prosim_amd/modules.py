@@ -73,27 +73,81 @@ class _Shared:
         self.scene: Optional[Dict[str, np.ndarray]] = None
 
 
+def prompt_to_slots(pr, ids_o, B, N, obs_pos, obs_head):
+    """Dense prompt tensors (rows = policy agents, with ``agent_ids``) -> observation-slot layout ``[B, N, ...]``.
+    Returns (slots, prompt, prompt_mask, agent_type, position, heading); ``slots[b][j]`` = slot of prompt row j."""
+    ids_p = _g(pr, "agent_ids")
+    p_prompt, p_mask = _np(_g(pr, "prompt")), _np(_g(pr, "prompt_mask"), bool)
+    p_type, p_pos = _np(_g(pr, "agent_type"), np.int64), _np(_g(pr, "position"))
+    p_head = _np(_g(pr, "heading"))
+    p_head = p_head.reshape(p_head.shape[0], p_head.shape[1])
+    slots = []
+    for b in range(B):
+        n_pol = int(p_mask[b].sum())
+        if not p_mask[b, :n_pol].all():
+            raise ValueError("prompt rows must be dense (valid rows first), as the reference's collate builds them")
+        if ids_o is None or ids_p is None:
+            if n_pol > N:
+                raise ValueError("more policy agents than observation slots")
+            row = list(range(n_pol))                       # no ids: prompt j belongs to observation slot j
+        else:
+            where = {a: n for n, a in enumerate(ids_o[b])}
+            missing = [a for a in list(ids_p[b])[:n_pol] if a not in where]
+            if missing:
+                raise ValueError(f"policy agents {missing} of scene {b} are not among the observed agents")
+            row = [where[a] for a in list(ids_p[b])[:n_pol]]
+        slots.append(row)
+    prompt = np.zeros((B, N, p_prompt.shape[-1]), np.float32)
+    prompt_mask = np.zeros((B, N), bool)
+    agent_type = np.ones((B, N), np.int64)
+    prompt_pos, prompt_head = np.array(obs_pos, np.float32), np.array(obs_head, np.float32).reshape(B, N)
+    for b in range(B):
+        for j, n in enumerate(slots[b]):
+            prompt[b, n], prompt_mask[b, n], agent_type[b, n] = p_prompt[b, j], True, p_type[b, j]
+            prompt_pos[b, n], prompt_head[b, n] = p_pos[b, j], p_head[b, j]
+    return slots, prompt, prompt_mask, agent_type, prompt_pos, prompt_head
+
+
+def cond_to_slots(c, slots, Np):
+    """A condition's ``prompt_idx`` (rows of the dense prompt tensor) -> observation slots; conditions that point
+    at a padding row are masked off."""
+    idx = _np(_g(c, "prompt_idx"), np.int64)
+    cm = _np(_g(c, "mask"), bool).copy()
+    sl = np.zeros_like(idx)
+    for b in range(idx.shape[0]):
+        lut = np.array(list(slots[b]) + [0] * (Np - len(slots[b])), np.int64)
+        sl[b] = lut[np.clip(idx[b], 0, Np - 1)]
+        cm[b] &= idx[b, :, 0] < len(slots[b])
+    return dict(input=_np(_g(c, "input")), mask=cm, prompt_idx=sl)
+
+
 def scene_from_extras(extras, spec: ModelSpec, task: str = "motion_pred") -> Dict[str, np.ndarray]:
-    """``batch.extras`` (dataset/format_utils.py:798-815) -> the engine's input dict.  Raises if the
-    policy agents are not exactly the observed agents slot for slot (the layout the BASELINE configs
-    and the M-replica rollout use); log-replay agents are a 'next' row."""
+    """``batch.extras`` (dataset/format_utils.py:798-815) -> the engine's input dict.
+
+    The reference matches policy agents (``prompt[task].agent_ids``) to observations (``init_obs.agent_ids``) by
+    id (traj_sam.py:246-250); the engine wants a policy agent's prompt in the SLOT of its observation, so the dense
+    prompt tensors are scattered into observation slots here.  Observed agents without a prompt are log-replay
+    agents: ``fut_obs[t]`` (observation, mask, pose of all agents at the later replans) drives their scene tokens.
+    ``scene['_policy_slots'][b]`` lists, in PROMPT order, the slot of every policy agent (the order of the outputs).
+    Raises if a policy agent is not observed or if the agent set changes between ``init_obs`` and ``fut_obs``."""
     obs, mp, pr = extras["init_obs"], extras["init_map"], extras["prompt"][task]
-    ids_o, ids_p = _g(obs, "agent_ids"), _g(pr, "agent_ids")
-    if ids_o is not None and ids_p is not None and [list(a) for a in ids_o] != [list(a) for a in ids_p]:
-        raise NotImplementedError("policy agents must be the observed agents in the same order")
-    head = _np(_g(pr, "heading"))
+    obs_input = _np(_g(obs, "input"))
+    B, N = obs_input.shape[:2]
+    ids_o = _g(obs, "agent_ids")
+    Np = _np(_g(pr, "prompt_mask")).shape[1]
+    slots, prompt, prompt_mask, agent_type, prompt_pos, prompt_head = prompt_to_slots(
+        pr, ids_o, B, N, _np(_g(obs, "position")), _np(_g(obs, "heading")))
     scene = dict(map_input=_np(_g(mp, "input")), map_mask=_np(_g(mp, "mask"), bool), map_pos=_np(_g(mp, "position")),
-                 map_head=_np(_g(mp, "heading")), obs_input=_np(_g(obs, "input")), obs_mask=_np(_g(obs, "mask"), bool),
-                 obs_pos=_np(_g(obs, "position")), obs_head=_np(_g(obs, "heading")), prompt=_np(_g(pr, "prompt")),
-                 prompt_mask=_np(_g(pr, "prompt_mask"), bool), agent_type=_np(_g(pr, "agent_type"), np.int64),
-                 prompt_pos=_np(_g(pr, "position")), prompt_head=head.reshape(head.shape[0], head.shape[1]))
+                 map_head=_np(_g(mp, "heading")), obs_input=obs_input, obs_mask=_np(_g(obs, "mask"), bool),
+                 obs_pos=_np(_g(obs, "position")), obs_head=_np(_g(obs, "heading")), prompt=prompt,
+                 prompt_mask=prompt_mask, agent_type=agent_type, prompt_pos=prompt_pos, prompt_head=prompt_head,
+                 _policy_slots=slots)
     cond = extras.get("condition") if hasattr(extras, "get") else None
     if cond:
         out = {}
         for k in ("goal", "v_action_tag"):
             if k in cond.keys() and _g(cond[k], "input").shape[1] > 0:
-                out[k] = dict(input=_np(_g(cond[k], "input")), mask=_np(_g(cond[k], "mask"), bool),
-                              prompt_idx=_np(_g(cond[k], "prompt_idx"), np.int64))
+                out[k] = cond_to_slots(cond[k], slots, Np)
         unsupported = [k for k in cond.keys() if k not in ("goal", "v_action_tag") and _g(cond[k], "input").shape[1] > 0]
         if unsupported:
             raise NotImplementedError(f"condition types {unsupported} are outside this round's scope (unary goal / v_action_tag only)")
@@ -102,7 +156,16 @@ def scene_from_extras(extras, spec: ModelSpec, task: str = "motion_pred") -> Dic
     fut = extras.get("fut_obs") if hasattr(extras, "get") else None
     if fut:
         ts = sorted(int(t) for t in fut.keys())
+        for t in ts:
+            ids_t = _g(fut[t], "agent_ids")
+            if ids_o is not None and ids_t is not None and [list(a) for a in ids_t] != [list(a) for a in ids_o]:
+                raise NotImplementedError("fut_obs frames must list the agents of init_obs in the same order "
+                                          "(agents entering or leaving the scene mid-rollout: mask their rows instead)")
         scene["fut_obs_input"] = np.stack([_np(_g(fut[t], "input")) for t in ts])
+        scene["fut_obs_mask"] = np.stack([_np(_g(fut[t], "mask"), bool) for t in ts])
+        scene["fut_obs_pos"] = np.stack([_np(_g(fut[t], "position")) for t in ts])
+        fh = np.stack([_np(_g(fut[t], "heading")) for t in ts])
+        scene["fut_obs_head"] = fh.reshape(fh.shape[0], B, N)
     return scene
 
 
@@ -141,6 +204,7 @@ class HipSceneEncoder:
                      obs_mask=obs_mask, obs_pos=_np(_g(batch_obs, "position")), obs_head=_np(_g(batch_obs, "heading")),
                      # the prompt side arrives with decoder(); placeholders keep the engine's batch consistent
                      prompt=np.zeros((B, N, spec.prompt_dim), np.float32), prompt_mask=valid, agent_type=np.ones((B, N), np.int64))
+        scene["_obs_ids"] = _g(batch_obs, "agent_ids")
         self.s.scene = scene
         self.s.engine.set_scene(scene)
         self.s.engine.encode_scene()
@@ -165,12 +229,15 @@ class HipDecoder:
         if not scene_emb.get("_hip_resident"):
             raise ValueError("scene_emb must come from HipSceneEncoder (tokens are device-resident)")
         sc, eng = self.s.scene, self.s.engine
-        pm = _np(_g(prompt_enc, "prompt_mask"), bool)
+        B, N = sc["prompt_mask"].shape
+        slots, prompt, pm, a_type, p_pos, p_head = prompt_to_slots(prompt_enc, sc.get("_obs_ids"), B, N, sc["obs_pos"], sc["obs_head"])
         if not np.array_equal(pm, sc["prompt_mask"]):
-            raise NotImplementedError("prompt agents must be the observed agents")
-        head = _np(_g(prompt_enc, "heading"))
-        eng.set_prompt(_np(_g(prompt_enc, "prompt")), _np(_g(prompt_enc, "position")), head.reshape(pm.shape),
-                       _np(_g(prompt_enc, "agent_type"), np.int32))
+            # the staged call encoded every observed agent as a policy agent; a policy SUBSET needs the log frames
+            # of the others, which only ProSimHip.forward(batch) receives (extras['fut_obs'])
+            raise NotImplementedError("staged decoder(): prompt agents must be the observed agents; "
+                                      "use the model's forward(batch) for scenes with log-replay agents")
+        eng.set_prompt(prompt, p_pos, p_head, a_type.astype(np.int32))
+        Np = _np(_g(prompt_enc, "prompt_mask")).shape[1]
         if condition:
             g, t = condition.get("goal"), condition.get("v_action_tag")
             from .engine import _f, _u8, _i32
@@ -179,13 +246,18 @@ class HipDecoder:
                 if c is None or np.asarray(c["input"]).shape[1] == 0:
                     args += [0, None, None, None]
                 else:
-                    ci, cm = _np(c["input"]), _np(c["mask"], bool).astype(np.uint8)
-                    cp = np.ascontiguousarray(_np(c["prompt_idx"], np.int64)[..., 0], dtype=np.int32)
+                    c = cond_to_slots(c, slots, Np)
+                    ci, cm = c["input"], c["mask"].astype(np.uint8)
+                    cp = np.ascontiguousarray(c["prompt_idx"][..., 0], dtype=np.int32)
                     keep += [ci, cm, cp]
                     args += [ci.shape[1], _f(ci), _u8(cm), _i32(cp)]
             eng._check(eng.lib.ps_set_conditions(eng.h, *args))
         eng.generate_policy()
-        return dict(emd=torch.from_numpy(eng.padded("policy_emd")), agent_type=torch.from_numpy(_np(_g(prompt_enc, "agent_type"), np.int64)))
+        emd_slots = eng.padded("policy_emd")                       # [B, N, D] by observation slot
+        emd = np.zeros((B, Np, emd_slots.shape[-1]), np.float32)   # the reference returns prompt order (sym_coord.py:60-75)
+        for b in range(B):
+            emd[b, :len(slots[b])] = emd_slots[b, slots[b]]
+        return dict(emd=torch.from_numpy(emd), agent_type=torch.from_numpy(_np(_g(prompt_enc, "agent_type"), np.int64)))
 
 
 @registry.register_policy(name="rel_pe_temporal")
@@ -253,30 +325,24 @@ class ProSimHip:
         eng.set_scene(scene)
         eng.rollout()
         B, N = scene["prompt_mask"].shape
-        pm = scene["prompt_mask"].astype(bool)
+        pslots = scene["_policy_slots"]                          # per scene: observation slot of every policy agent, prompt order
         ids = _g(extras["prompt"]["motion_pred"], "agent_ids")
         if ids is None:
-            ids = [[str(n) for n in range(int(pm[b].sum()))] for b in range(B)]
+            ids = [[str(j) for j in range(len(pslots[b]))] for b in range(B)]
         traj, vel = eng.padded("traj"), eng.padded("vel")
-        mp = torch.from_numpy(eng.get("motion_pred"))             # [R, A, K, S, D]
+        mp_rows = eng.get("motion_pred")                           # [R, rows = observed agents, K, S, D]
+        rec_rows = eng.get("reconst_pred")
+        slot_of_row = eng._slots                                   # flat slot b * N + n of every agent row
+        row_of_slot = {int(sl): i for i, sl in enumerate(slot_of_row)}
+        order = [row_of_slot[b * N + n] for b in range(B) for n in pslots[b]]   # policy agents, scene-major, prompt order
+        mp = torch.from_numpy(mp_rows[:, order])
         R, A = mp.shape[0], mp.shape[1]
-        slots = [(b, n) for b in range(B) for n in range(N) if pm[b, n]]
-        local = {}
-        for b in range(B):
-            local[b] = 0
-        names = []
-        for t in spec.all_t_indices:
-            cnt = {b: 0 for b in range(B)}
-            for (b, n) in slots:
-                names.append(f"{b}-{ids[b][cnt[b]]}-{t}")
-                cnt[b] += 1
+        names = [f"{b}-{ids[b][j]}-{t}" for t in spec.all_t_indices for b in range(B) for j in range(len(pslots[b]))]
         out = {"motion_pred": mp.reshape(R * A, *mp.shape[2:]), "motion_prob": torch.ones(R * A, mp.shape[2]),
-               "pair_names": names, "reconst_pred": torch.from_numpy(eng.get("reconst_pred")).repeat(R, 1), "rollout_trajs": {}}
-        cnt = {b: 0 for b in range(B)}
-        for (b, n) in slots:
-            key = f"{b}-{ids[b][cnt[b]]}"
-            cnt[b] += 1
-            out["rollout_trajs"][key] = dict(traj=torch.from_numpy(traj[b, n]), vel=torch.from_numpy(vel[b, n]),
-                                             init_pos=torch.from_numpy(scene["obs_pos"][b, n]),
-                                             init_heading=torch.from_numpy(scene["obs_head"][b, n:n + 1]))
+               "pair_names": names, "reconst_pred": torch.from_numpy(rec_rows[order]).repeat(R, 1), "rollout_trajs": {}}
+        for b in range(B):
+            for j, n in enumerate(pslots[b]):
+                out["rollout_trajs"][f"{b}-{ids[b][j]}"] = dict(
+                    traj=torch.from_numpy(traj[b, n]), vel=torch.from_numpy(vel[b, n]),
+                    init_pos=torch.from_numpy(scene["obs_pos"][b, n]), init_heading=torch.from_numpy(scene["obs_head"][b, n:n + 1]))
         return {"motion_pred": out}

@@ -155,10 +155,12 @@ def test_rollout_vs_reference_fixture(name):
     eng = Engine(spec, w)
     eng.set_scene(scene)
     eng.rollout()
-    A = eng.num_agents
-    mp = eng.get("motion_pred").reshape(-1, *g["motion_pred"].shape[1:])
+    pol = eng.policy_rows                                    # the reference returns policy agents only
+    A = int(pol.sum())
+    assert A == eng.num_policy_agents and (A < eng.num_agents) == ("replay" in kw)
+    mp = eng.get("motion_pred")[:, pol].reshape(-1, *g["motion_pred"].shape[1:])
     assert err(mp[:A], g["motion_pred"][:A]) < TOL          # replan 0: open loop
-    assert err(eng.get("reconst_pred"), g["reconst_pred"]) < 1e-5
+    assert err(eng.get("reconst_pred")[pol], g["reconst_pred"]) < 1e-5
     floor = dict(zip(("traj", "vel", "motion_pred"), g["fp32_floor"]))
     assert err(eng.padded("traj"), g["traj"]) < 3 * floor["traj"] + TOL
     assert err(eng.padded("vel"), g["vel"]) < 3 * floor["vel"] + TOL
@@ -283,9 +285,13 @@ def test_errors_are_loud(small_engine):
     spec = SMALL_SPEC
     scene = synth.make_scene(spec, 4, 8, batch=1, seed=0)
     bad = dict(scene)
-    bad["prompt_mask"] = scene["prompt_mask"].copy()
-    bad["prompt_mask"][0, 0] = False      # policy agents != observed agents
-    with pytest.raises(RuntimeError, match="policy agents"):
+    bad["obs_mask"] = scene["obs_mask"].copy()
+    bad["obs_mask"][0, 0] = False         # a policy agent (prompt present) that is not observed
+    with pytest.raises(RuntimeError, match="policy agent must be observed"):
+        small_engine.set_scene(bad)
+    bad = dict(scene)
+    bad["prompt_mask"] = np.zeros_like(scene["prompt_mask"])   # observed agents only: nothing to simulate
+    with pytest.raises(RuntimeError, match="no policy agent"):
         small_engine.set_scene(bad)
     bad = dict(scene)
     bad["agent_type"] = scene["agent_type"] * 0
@@ -369,3 +375,34 @@ def test_split_s2s_layers_on_a_ragged_batch(demo_engine):
     eng.generate_policy()
     pm = torch.from_numpy(scene["prompt_mask"].astype(bool))
     assert err(eng.get("policy_emd"), o64["policy_emd"][pm].numpy()) < 2 * TOL
+
+
+def test_log_replay_agents_vs_oracle(demo_engine):
+    """Policy agents as a subset of the observed agents at demo-model size: a third of the observed agents replay a
+    log (their token is re-encoded from the logged observation at the logged pose every replan, some drop out of the
+    log), goal + action-tag prompts on the policy agents.  Per-agent closed-loop bar against the fp64 oracle."""
+    spec = DEMO_SPEC
+    scene = synth.make_scene(spec, 64, 384, batch=2, seed=31, goal=True, tags=True, ragged=True, replay=0.35)
+    w = weights.init_weights(spec, 0)
+    with torch.no_grad():
+        o64 = orc.rollout(w, spec, scene, dtype=torch.float64, collect=True)
+    eng = demo_engine
+    eng.set_scene(scene)
+    pol = eng.policy_rows
+    A = int(pol.sum())
+    assert 0 < A < eng.num_agents
+    eng.encode_scene()
+    assert err(eng.get("scene_tokens"), o64["trace"]["scene_tokens"].numpy()) < TOL
+    eng.generate_policy()
+    pm = torch.from_numpy(scene["prompt_mask"].astype(bool))
+    assert err(eng.get("policy_emd")[pol], o64["policy_emd"][pm].numpy()) < 2 * TOL
+    eng.rollout()
+    mp = eng.get("motion_pred")[:, pol]
+    assert err(mp[0], o64["motion_pred"][:A].numpy()) < TOL
+    # closed loop: relative to what fp32 itself loses on this (ragged, dense) scene -- the oracle's own fp32 run
+    with torch.no_grad():
+        o32 = orc.rollout(w, spec, scene)
+    floor = float(np.abs(o32["traj"].numpy() - o64["traj"].numpy()).max())
+    d = np.abs(eng.padded("traj") - o64["traj"].numpy())[scene["prompt_mask"].astype(bool)].reshape(A, -1).max(1)
+    assert d.max() < 3 * floor + TOL and (d < TOL).mean() >= 0.8, (floor, d)
+    assert np.abs(eng.padded("traj")[~scene["prompt_mask"].astype(bool)]).max() == 0      # log-replay slots stay empty

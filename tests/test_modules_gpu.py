@@ -63,6 +63,38 @@ def test_forward_output_contract_vs_fixture(model):
         model(batch, "train")
 
 
+def test_forward_with_log_replay_agents_vs_fixture(model):
+    """Policy agents are a subset of the observed agents (matched by id, traj_sam.py:246-250); the others replay
+    ``fut_obs``.  Outputs come back for the policy agents only, in prompt order, with the reference's values."""
+    name = "small_replay_b2"
+    sname, kw, wseed = FULL_CASES[name]
+    spec = SPECS[sname]
+    g = np.load(os.path.join(GOLD, f"ref_standins_{name}.npz"))
+    scene = synth.make_scene(spec, **kw)
+    batch = make_batch(scene, spec)
+    out = model(batch, "val")["motion_pred"]
+    pm = scene["prompt_mask"].astype(bool)
+    A = int(pm.sum())
+    assert A < int(scene["obs_mask"].all(-1).any(-1).sum())                      # the case really has replay agents
+    assert model.engine.num_policy_agents == A
+    assert out["motion_pred"].shape == (spec.n_replans * A, 1, 10, 5) and g["motion_pred"].shape[0] == spec.n_replans * A
+    assert err(out["motion_pred"][:A].numpy(), g["motion_pred"][:A]) < 1e-4
+    assert err(out["reconst_pred"][:A].numpy(), g["reconst_pred"]) < 1e-4
+    floor = g["fp32_floor"][0]
+    names = set()
+    for b in range(2):
+        for n in np.nonzero(pm[b])[0]:
+            r = out["rollout_trajs"][f"{b}-a{n}"]
+            names.add(f"{b}-a{n}")
+            assert err(r["traj"].numpy(), g["traj"][b, n]) < 3 * floor + 1e-4
+    assert set(out["rollout_trajs"]) == names                                     # and nothing for the replay agents
+    # a policy agent that is not observed is an error, not a silent drop
+    bad = make_batch(scene, spec)
+    bad.extras["prompt"]["motion_pred"]["agent_ids"][0][0] = "ghost"
+    with pytest.raises(ValueError, match="not among the observed"):
+        model(bad, "val")
+
+
 def test_staged_components_and_stateless_policy(model):
     """scene_encoder(...) -> decoder(...) -> policy(...) with the reference's argument layouts."""
     spec = SMALL_SPEC
@@ -77,9 +109,11 @@ def test_staged_components_and_stateless_policy(model):
     assert err(se["scene_tokens"].numpy(), o["trace"]["scene_tokens"].numpy()) < 1e-4
     assert torch.equal(se["scene_type"], (torch.arange(se["scene_type"].numel()) >= se["_n_map_tokens"]).long())
     pe = model.decoder(se, batch["prompt"]["motion_pred"])
-    assert err(pe["emd"].numpy(), o["policy_emd"].numpy()) < 1e-4 and pe["emd"].shape == (2, 12, 128)
-    # policy.forward on reference-style padded tokens (traj_sam.py:356-400 layout), replan 0
     pm = torch.from_numpy(scene["prompt_mask"].astype(bool))
+    dm = batch["prompt"]["motion_pred"]["prompt_mask"]                            # dense prompt rows (collate layout)
+    assert pe["emd"].shape == (2, dm.shape[1], 128)
+    assert err(pe["emd"][dm].numpy(), o["policy_emd"][pm].numpy()) < 1e-4
+    # policy.forward on reference-style padded tokens (traj_sam.py:356-400 layout), replan 0
     B, N = pm.shape
     Mv = se["_n_map_tokens"]
     def padded(tok, pos, ori, bidx, S):
@@ -94,7 +128,7 @@ def test_staged_components_and_stateless_policy(model):
     bo = padded(tok[Mv:], se["scene_pos"][Mv:], se["scene_ori"][Mv:], se["scene_batch_idx"][Mv:], N)
     bm = padded(tok[:Mv], se["scene_pos"][:Mv], se["scene_ori"][:Mv], se["scene_batch_idx"][:Mv], scene["map_mask"].shape[1])
     bidx = orc._flat_batch_idx(pm)
-    pol_emd = dict(emd=pe["emd"][pm], agent_type=torch.from_numpy(scene["agent_type"])[pm], batch_idx=bidx)
+    pol_emd = dict(emd=pe["emd"][dm], agent_type=torch.from_numpy(scene["agent_type"])[pm], batch_idx=bidx)
     pos = dict(position=torch.from_numpy(scene["obs_pos"])[pm], heading=orc.wrap_angle(torch.from_numpy(scene["obs_head"])[pm])[:, None])
     names = [f"{int(b)}-x{i}-0" for i, b in enumerate(bidx)]
     out = model.policy(pol_emd, bo, bm, pos, names, None)
