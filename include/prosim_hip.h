@@ -42,6 +42,7 @@ typedef struct ps_config {
   int32_t pol_layers, pol_max_neigh;
   float pol_agent_radius, pol_map_radius;
   int32_t cond_layers;
+  int32_t drag_pre_layers, drag_mlp_layers;    /* CONDITION_ENCODER.DRAG_POINTS (default.py:531-533); mlp_layers 0 = no drag-point encoder */
   int32_t hist_steps, obs_dim, map_dim;        /* 11, 24, 11 */
   int32_t map_pre_layers, map_mlp_layers, obs_pre_layers, obs_mlp_layers;
   int32_t target_steps, state_dim, motion_k, num_agent_types, prompt_dim;
@@ -67,8 +68,9 @@ const char* ps_last_error(void);
  *   obs_pos [B,N,2], obs_head [B,N]
  *   prompt [B,N,prompt_dim], prompt_mask [B,N], agent_type [B,N] (1..num_agent_types),
  *   prompt_pos [B,N,2], prompt_head [B,N]
- * Policy agents must be exactly the observed agents, slot for slot (prompt_mask == any valid
- * history step); otherwise PS_E_ARG. */
+ * Observed agents = slots with a valid history step; policy agents = prompt_mask slots, a non-empty subset of
+ * the observed ones (traj_sam.py:246-250 matches them by id); a policy agent that is not observed, or a scene
+ * batch without any policy agent, is PS_E_ARG.  Observed agents without a prompt replay ps_set_future_log. */
 int ps_set_scene(ps_engine* e, int32_t B, int32_t M, int32_t P, int32_t N,
                  const float* map_input, const uint8_t* map_mask, const float* map_pos, const float* map_head,
                  const float* obs_input, const uint8_t* obs_mask, const float* obs_pos, const float* obs_head,
@@ -88,6 +90,15 @@ int ps_set_prompt(ps_engine* e, const float* prompt, const float* prompt_pos, co
 int ps_set_conditions(ps_engine* e, int32_t C_goal, const float* goal_input, const uint8_t* goal_mask,
                       const int32_t* goal_pidx, int32_t C_tag, const float* tag_input,
                       const uint8_t* tag_mask, const int32_t* tag_pidx);
+
+/* Optional drag-point conditions, the third type of the demo config's PROMPT.CONDITION.TYPES
+ * (dataset/condition_utils.py:401-447): drag_input [B,C,T,2] points in the prompt agent's start frame, a point
+ * with a NaN coordinate is absent; drag_mask [B,C]; drag_pidx [B,C] prompt slot.  T <= 32.  Independent of
+ * ps_set_conditions (either order); C = 0 or NULL clears.  Replaces DragPointEncoder.forward
+ * (models/condition_transformer/condition_encoders.py:164-191) and its share of the pooled condition edge
+ * (condition_attns.py:114-188).  PS_E_ARG if the engine was created with drag_mlp_layers = 0. */
+int ps_set_drag_points(ps_engine* e, int32_t C_drag, int32_t T, const float* drag_input, const uint8_t* drag_mask,
+                       const int32_t* drag_pidx);
 
 /* Optional per-replan observation frames fut_obs[t] for replans 1..R-1
  * (dataset/format_utils.py:667-687): input [R-1,B,N,hist,obs_dim]; only columns 8.. (extent,

@@ -332,8 +332,8 @@ def decoder_fusion(Wt: W, spec: ModelSpec, scene: Dict, prompt_emd: T, prompt_ma
 def condition_transform(Wt: W, spec: ModelSpec, cond: Optional[Dict], emd: T, prompt_mask: T,
                         prompt_pos: T, prompt_head: T) -> T:
     """ConditionTransformer.forward at 'policy_decoder' (condition_transformer/base.py:38-60)
-    with GoalConditionEncoder (condition_encoders.py:21-51), V_ActionTagEncoder (:76-141) and
-    GNNConditionAttn (condition_attns.py:114-228), restricted to UNARY conditions (each
+    with GoalConditionEncoder (condition_encoders.py:21-51), V_ActionTagEncoder (:76-141), DragPointEncoder
+    (:152-191) and GNNConditionAttn (condition_attns.py:114-228), restricted to UNARY conditions (each
     condition attaches to one prompt agent -> self-loop edges), mean pooling over the
     condition entries present on an edge.  ``cond`` = {'goal': {'input' [B,C,3], 'mask' [B,C],
     'prompt_idx' [B,C,1]}, 'v_action_tag': {...}}; None / {} -> identity."""
@@ -357,6 +357,14 @@ def condition_transform(Wt: W, spec: ModelSpec, cond: Optional[Dict], emd: T, pr
             e = Wt[f"{ct}.condition_encoders.v_action_tag.tag_encoder.{tag}"][None, None, :] + \
                 fourier_fix(ci["input"][..., 1:3], D // 2)
             entries.append((e, ci["mask"] & sel, ci["prompt_idx"][..., 0]))
+    if "drag_point" in cond and cond["drag_point"]["input"].shape[1] > 0:
+        # DragPointEncoder.forward (condition_encoders.py:164-191): PointNet over the points that are not NaN
+        ci = cond["drag_point"]
+        pts = ci["input"].to(emd.dtype)
+        pmask = ~(pts.isnan().any(-1))
+        e = pointnet(Wt, f"{ct}.condition_encoders.drag_point.pointnet_encoder", 2, D, spec.drag_pre_layers,
+                     spec.drag_mlp_layers, torch.nan_to_num(pts), pmask)
+        entries.append((e, ci["mask"], ci["prompt_idx"][..., 0]))
     if not entries:
         return emd
     # _construct_cond_edge_matrix + _pool_edges('mean') for self-loop edges only

@@ -238,7 +238,7 @@ def install():
     _INSTALLED = True
 
 
-def get_config(cond_types=("goal", "v_action_tag"), overrides=None):
+def get_config(cond_types=("goal", "v_action_tag", "drag_point"), overrides=None):
     """The demo config (prosim_demo/cfg/no_text.yaml over config/default.py)."""
     install()
     default = importlib.import_module("prosim.config.default")

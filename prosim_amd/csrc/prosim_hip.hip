@@ -78,7 +78,7 @@ struct ps_engine {
   std::vector<AttnW> all_layers;
   AttnW* d_layers = nullptr;  // all layers, device copy (order: a2a s2s p2p s2p a2p m2p cnd)
   int L_a2a = 0, L_s2s = 0, L_p2p = 0, L_s2p = 0, L_a2p = 0, L_m2p = 0, L_cnd = 0;
-  PointNetW pn_map{}, pn_obs{};
+  PointNetW pn_map{}, pn_obs{}, pn_drag{};   // pn_drag: DragPointEncoder (condition_encoders.py:152), optional
   Mlp3W mlp_prompt{}, mlp_pred{};
   HeadW head{};
   DevBuf<float> io_q, io_qt, io_cq, io_ar, io_av, io_l, io_s, io_g;   // split path: per-destination vectors (EdgeIO)
@@ -105,6 +105,13 @@ struct ps_engine {
   int n_cond_edges = 0;
   DevBuf<int> d_ent_off, d_ent_type;
   DevBuf<float> d_ent_val;
+  // host copy of the condition entries (goal / tag from ps_set_conditions, drag from ps_set_drag_points); the device
+  // CSR is rebuilt from both whenever either call changes them
+  struct CondEnt { int agent, type, id; float v[3]; };
+  std::vector<CondEnt> ents_gt, ents_drag;
+  int n_drag = 0, drag_T = 0;
+  DevBuf<float> d_drag_in, d_drag_emd;      // [n_drag][T][2] (NaN -> 0), [n_drag][128]
+  DevBuf<uint8_t> d_drag_mask;              // [n_drag][T]
   bool have_fut = false;
   // log-replay agents: observed agents that are not policy agents (prompt_mask false on an observed slot).  Every
   // observed agent is a ROW of the per-agent buffers; is_policy marks the rows the simulation drives.
@@ -472,6 +479,9 @@ extern "C" int ps_create(const ps_config* cfg, int32_t n_tensors, const char* co
   layers("condition_transformers.policy_decoder.condition_attn.attn_layers", cfg->cond_layers, e->cnd);
   build_pointnet(b, "scene_encoder.map_encoder", cfg->map_dim, cfg->map_pre_layers, cfg->map_mlp_layers, e->pn_map);
   build_pointnet(b, "scene_encoder.obs_encoder", cfg->obs_dim, cfg->obs_pre_layers, cfg->obs_mlp_layers, e->pn_obs);
+  if (cfg->drag_mlp_layers > 0)
+    build_pointnet(b, "condition_transformers.policy_decoder.condition_encoders.drag_point.pointnet_encoder", 2,
+                   cfg->drag_pre_layers, cfg->drag_mlp_layers, e->pn_drag);
   build_mlp3(b, "prompt_encoder.motion_pred.state_encoder", {cfg->prompt_dim, D, D}, false, e->mlp_prompt);
   const std::string pa = "policy.act_decoder";
   build_mlp3(b, pa + ".pred_mlp", {D, D, D / 2, 2}, false, e->mlp_pred);
@@ -609,6 +619,7 @@ extern "C" void ps_destroy(ps_engine* e) {
     s->cnt.release(); s->eoff.release(); s->esrc.release(); s->edst.release(); s->toff.release(); s->tdst.release(); s->rtA.release(); s->rtT.release();
   }
   e->d_steps.release(); e->d_ent_off.release(); e->d_ent_type.release(); e->d_ent_val.release();
+  e->d_drag_in.release(); e->d_drag_emd.release(); e->d_drag_mask.release();
   e->io_q.release(); e->io_qt.release(); e->io_cq.release(); e->io_ar.release(); e->io_av.release(); e->io_l.release();
   e->io_s.release(); e->io_g.release();
   drop_graph(e);
@@ -846,6 +857,9 @@ extern "C" int ps_set_scene(ps_engine* e, int32_t B, int32_t M, int32_t P, int32
   // no conditions until ps_set_conditions
   e->have_cond = false;
   e->n_cond_edges = 0;
+  e->ents_gt.clear();
+  e->ents_drag.clear();
+  e->n_drag = 0;
   HIPCHK(hipStreamSynchronize(st));
   e->have_scene = true;
   e->encoded = e->generated = e->reset = false;
@@ -880,43 +894,22 @@ extern "C" int ps_set_prompt(ps_engine* e, const float* prompt, const float* pro
   return PS_OK;
 }
 
-extern "C" int ps_set_conditions(ps_engine* e, int32_t C_goal, const float* goal_input, const uint8_t* goal_mask,
-                                 const int32_t* goal_pidx, int32_t C_tag, const float* tag_input, const uint8_t* tag_mask,
-                                 const int32_t* tag_pidx) {
-  if (!e || !e->have_scene) return fail(PS_E_STATE, "ps_set_conditions before ps_set_scene");
-  HIPCHK(hipSetDevice(e->cfg.device));
-  const int A = e->A, N = e->N;
-  std::vector<std::vector<std::pair<std::pair<int, int>, const float*>>> per(A);
-  // slot -> compact agent index
-  std::vector<int> slot2a((size_t)e->B * N, -1);
-  for (int i = 0; i < A; ++i) slot2a[e->agent_rows[i]] = i;
-  for (int b = 0; b < e->B; ++b) {
-    for (int c = 0; c < C_goal && goal_input; ++c) {
-      const size_t i = (size_t)b * C_goal + c;
-      if (!goal_mask[i]) continue;
-      const int n = goal_pidx[i];
-      if (n < 0 || n >= N || slot2a[(size_t)b * N + n] < 0) return fail(PS_E_ARG, "goal condition on an invalid prompt slot");
-      per[slot2a[(size_t)b * N + n]].push_back({{0, 0}, goal_input + 3 * i});
-    }
-    for (int c = 0; c < C_tag && tag_input; ++c) {
-      const size_t i = (size_t)b * C_tag + c;
-      if (!tag_mask[i]) continue;
-      const int tag = (int)tag_input[3 * i];
-      if (tag < 0 || tag > 10) continue;  // not a V_Action tag value: no entry (condition_encoders.py:94)
-      const int n = tag_pidx[i];
-      if (n < 0 || n >= N || slot2a[(size_t)b * N + n] < 0) return fail(PS_E_ARG, "tag condition on an invalid prompt slot");
-      per[slot2a[(size_t)b * N + n]].push_back({{1, tag}, tag_input + 3 * i});
-    }
-  }
+// Device CSR of the condition entries: per conditioned agent (one self-loop edge each) the list of its entries
+// (type, id, 3 floats) in the reference's pooling order goal, tags, drag points (PROMPT.CONDITION.TYPES).
+static int rebuild_conditions(ps_engine* e) {
+  const int A = e->A;
+  std::vector<std::vector<const ps_engine::CondEnt*>> per(A);
+  for (const auto& en : e->ents_gt) per[en.agent].push_back(&en);
+  for (const auto& en : e->ents_drag) per[en.agent].push_back(&en);
   std::vector<int> eoff(A + 1, 0), esrc, ent_off(1, 0), ent_type;
   std::vector<float> ent_val;
   for (int a = 0; a < A; ++a) {
     if (!per[a].empty()) {
       esrc.push_back(a);
-      for (auto& en : per[a]) {
-        ent_type.push_back(en.first.first);
-        ent_type.push_back(en.first.second);
-        ent_val.insert(ent_val.end(), en.second, en.second + 3);
+      for (const auto* en : per[a]) {
+        ent_type.push_back(en->type);
+        ent_type.push_back(en->id);
+        ent_val.insert(ent_val.end(), en->v, en->v + 3);
       }
       ent_off.push_back((int)ent_type.size() / 2);
     }
@@ -936,6 +929,83 @@ extern "C" int ps_set_conditions(ps_engine* e, int32_t C_goal, const float* goal
   e->generated = false;
   drop_graph(e);
   return PS_OK;
+}
+
+extern "C" int ps_set_conditions(ps_engine* e, int32_t C_goal, const float* goal_input, const uint8_t* goal_mask,
+                                 const int32_t* goal_pidx, int32_t C_tag, const float* tag_input, const uint8_t* tag_mask,
+                                 const int32_t* tag_pidx) {
+  if (!e || !e->have_scene) return fail(PS_E_STATE, "ps_set_conditions before ps_set_scene");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  const int A = e->A, N = e->N;
+  std::vector<ps_engine::CondEnt> ents;
+  // slot -> compact agent index
+  std::vector<int> slot2a((size_t)e->B * N, -1);
+  for (int i = 0; i < A; ++i) slot2a[e->agent_rows[i]] = i;
+  for (int b = 0; b < e->B; ++b) {
+    for (int c = 0; c < C_goal && goal_input; ++c) {
+      const size_t i = (size_t)b * C_goal + c;
+      if (!goal_mask[i]) continue;
+      const int n = goal_pidx[i];
+      if (n < 0 || n >= N || slot2a[(size_t)b * N + n] < 0) return fail(PS_E_ARG, "goal condition on an invalid prompt slot");
+      ents.push_back({slot2a[(size_t)b * N + n], 0, 0, {goal_input[3 * i], goal_input[3 * i + 1], goal_input[3 * i + 2]}});
+    }
+    for (int c = 0; c < C_tag && tag_input; ++c) {
+      const size_t i = (size_t)b * C_tag + c;
+      if (!tag_mask[i]) continue;
+      const int tag = (int)tag_input[3 * i];
+      if (tag < 0 || tag > 10) continue;  // not a V_Action tag value: no entry (condition_encoders.py:94)
+      const int n = tag_pidx[i];
+      if (n < 0 || n >= N || slot2a[(size_t)b * N + n] < 0) return fail(PS_E_ARG, "tag condition on an invalid prompt slot");
+      ents.push_back({slot2a[(size_t)b * N + n], 1, tag, {tag_input[3 * i], tag_input[3 * i + 1], tag_input[3 * i + 2]}});
+    }
+  }
+  e->ents_gt.swap(ents);
+  return rebuild_conditions(e);
+}
+
+extern "C" int ps_set_drag_points(ps_engine* e, int32_t C_drag, int32_t T, const float* drag_input, const uint8_t* drag_mask,
+                                  const int32_t* drag_pidx) {
+  if (!e || !e->have_scene) return fail(PS_E_STATE, "ps_set_drag_points before ps_set_scene");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  if (C_drag <= 0 || !drag_input) {   // clear
+    e->ents_drag.clear();
+    e->n_drag = 0;
+    return rebuild_conditions(e);
+  }
+  if (e->cfg.drag_mlp_layers <= 0) return fail(PS_E_ARG, "this engine was created without the drag-point encoder (drag_mlp_layers = 0)");
+  if (T < 1 || T > 32) return fail(PS_E_ARG, "drag-point conditions carry 1..32 points");
+  if (!drag_mask || !drag_pidx) return fail(PS_E_ARG, "drag_mask / drag_pidx missing");
+  const int A = e->A, N = e->N;
+  std::vector<int> slot2a((size_t)e->B * N, -1);
+  for (int i = 0; i < A; ++i) slot2a[e->agent_rows[i]] = i;
+  std::vector<ps_engine::CondEnt> ents;
+  std::vector<float> pts;
+  std::vector<uint8_t> pm;
+  for (int b = 0; b < e->B; ++b)
+    for (int c = 0; c < C_drag; ++c) {
+      const size_t i = (size_t)b * C_drag + c;
+      if (!drag_mask[i]) continue;
+      const int n = drag_pidx[i];
+      if (n < 0 || n >= N || slot2a[(size_t)b * N + n] < 0) return fail(PS_E_ARG, "drag-point condition on an invalid prompt slot");
+      const int row = (int)ents.size();
+      ents.push_back({slot2a[(size_t)b * N + n], 2, row, {0.f, 0.f, 0.f}});
+      for (int t = 0; t < T; ++t) {   // a point is valid iff neither coordinate is NaN (condition_encoders.py:180)
+        const float x = drag_input[(i * T + t) * 2], y = drag_input[(i * T + t) * 2 + 1];
+        const bool ok = !(std::isnan(x) || std::isnan(y));
+        pm.push_back(ok ? 1 : 0);
+        pts.push_back(ok ? x : 0.f);
+        pts.push_back(ok ? y : 0.f);
+      }
+    }
+  e->n_drag = (int)ents.size();
+  e->drag_T = T;
+  if (e->n_drag > 0) {
+    if (upload(e->d_drag_in, pts.data(), pts.size(), e->stream) || upload(e->d_drag_mask, pm.data(), pm.size(), e->stream) ||
+        e->d_drag_emd.ensure((size_t)e->n_drag * D))
+      return fail(PS_E_HIP, "drag-point upload failed");
+  }
+  e->ents_drag.swap(ents);
+  return rebuild_conditions(e);
 }
 
 extern "C" int ps_set_future_obs(ps_engine* e, const float* fut_input) {
@@ -1262,8 +1332,11 @@ extern "C" int ps_generate_policy(ps_engine* e) {
   HIPCHK(hipMemcpyAsync(e->d_emd.p, e->d_xp.p, sizeof(float) * (size_t)A * D, hipMemcpyDeviceToDevice, st));
   // condition transformer at 'policy_decoder' (traj_sam.py:129-137)
   if (e->have_cond && c.cond_layers > 0) {
+    if (e->n_drag > 0)
+      launch_pointnet(e, e->pn_drag, e->d_drag_in.p, e->d_drag_mask.p, nullptr, e->n_drag, e->drag_T, 0, e->d_drag_emd.p);
     hipLaunchKernelGGL(k_cond_edges, dim3(e->n_cond_edges), dim3(128), 0, st, e->cond, (const int*)e->d_ent_off.p,
-                       (const int*)e->d_ent_type.p, (const float*)e->d_ent_val.p, e->n_cond_edges, e->e_cnd.rtA.p, e->e_cnd.rtT.p, c.ln_eps);
+                       (const int*)e->d_ent_type.p, (const float*)e->d_ent_val.p, (const float*)e->d_drag_emd.p, e->n_cond_edges,
+                       e->e_cnd.rtA.p, e->e_cnd.rtT.p, c.ln_eps);
     HIPCHK(hipMemcpyAsync(e->d_xc.p, e->d_emd.p, sizeof(float) * (size_t)A * D, hipMemcpyDeviceToDevice, st));
     for (int i = 0; i < c.cond_layers; ++i) {
       launch_kv(e, e->d_xc.p, A, e->L_cnd + i, 1, e->d_kv.p, e->d_kh.p, 0);

@@ -196,7 +196,11 @@ __global__ __launch_bounds__(256) void k_pointnet_mfma(PointNetW w, const float*
   __syncthreads();
   for (int i = tid; i < G * 128; i += 256) {
     const int g = i >> 7, col = i & 127;
-    if (g0 + g < n_rows) out[(size_t)(g0 + g) * 128 + col] = pb[i] + w.out_b1[col];
+    if (g0 + g < n_rows) {
+      bool any = false;   // a polyline without a valid point keeps a zero feature (pointnet_encoder.py:56-60)
+      for (int p = 0; p < P; ++p) any |= valid[g * P + p] != 0;
+      out[(size_t)(g0 + g) * 128 + col] = any ? pb[i] + w.out_b1[col] : 0.f;
+    }
   }
 }
 
@@ -643,14 +647,15 @@ __global__ __launch_bounds__(128) void k_mlp_rows(Mlp3W m, const float* __restri
 // Condition encoders + mean pooling over the condition entries attached to one agent
 // (condition_encoders.py:21-51, :76-141; condition_attns.py:114-188 for self-loop edges), then
 // r = pooled + relPE(self-loop) and the affine-free LayerNorm.  One WG (128 threads) per
-// conditioned agent; entries are a host-built CSR: type (0 goal, 1 tag), tag id, 3 floats.
+// conditioned agent; entries are a host-built CSR: type (0 goal, 1 tag, 2 drag points), tag id | row of the
+// drag-point embeddings (DragPointEncoder :152-191 = k_pointnet_mfma over the [x, y] points), 3 floats.
 struct CondW {
   Mlp3W goal;                 // MLP 2 -> 128 (ReLU) -> 128, no norm
   const float* tag_emb;       // [11][128] indexed by V_Action_MotionTag value
   const float *div32, *div64, *div128;
 };
 __global__ __launch_bounds__(128) void k_cond_edges(CondW w, const int* __restrict__ ent_off, const int* __restrict__ ent_type,
-                                                   const float* __restrict__ ent_val, int n_nodes,
+                                                   const float* __restrict__ ent_val, const float* __restrict__ drag_emd, int n_nodes,
                                                    _Float16* __restrict__ rtA, _Float16* __restrict__ rtT, float eps) {
   __shared__ float a[128], b[128], accum[128];
   const int node = blockIdx.x, tid = threadIdx.x;
@@ -666,6 +671,8 @@ __global__ __launch_bounds__(128) void k_cond_edges(CondW w, const int* __restri
       // + FourierEmbeddingFix(128)(t): one channel, 128 slots
       const float v = (v2 * PS_TWO_PI_F) / w.div128[tid];
       accum[tid] += a[tid] + ((tid & 1) ? cosf(v) : sinf(v));
+    } else if (ent_type[2 * e] == 2) {
+      accum[tid] += drag_emd[(size_t)ent_type[2 * e + 1] * 128 + tid];
     } else {
       // tag parameter + FourierEmbeddingFix(64)([t0, t1]): two channels x 64 slots
       const int slot = tid & 63;

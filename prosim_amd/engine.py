@@ -27,6 +27,7 @@ class PsConfig(C.Structure):
         ("pol_layers", C.c_int32), ("pol_max_neigh", C.c_int32),
         ("pol_agent_radius", C.c_float), ("pol_map_radius", C.c_float),
         ("cond_layers", C.c_int32),
+        ("drag_pre_layers", C.c_int32), ("drag_mlp_layers", C.c_int32),
         ("hist_steps", C.c_int32), ("obs_dim", C.c_int32), ("map_dim", C.c_int32),
         ("map_pre_layers", C.c_int32), ("map_mlp_layers", C.c_int32),
         ("obs_pre_layers", C.c_int32), ("obs_mlp_layers", C.c_int32),
@@ -62,6 +63,7 @@ def load_library():
     lib.ps_policy_forward.argtypes = [vp, C.c_int32, C.c_int32, fp, fp, fp, i32p, C.c_int32, fp, fp, fp, i32p, C.c_int32,
                                       fp, fp, fp, i32p, i32p, fp, fp]
     lib.ps_set_conditions.argtypes = [vp, C.c_int32, fp, u8p, i32p, C.c_int32, fp, u8p, i32p]
+    lib.ps_set_drag_points.argtypes = [vp, C.c_int32, C.c_int32, fp, u8p, i32p]
     lib.ps_set_future_obs.argtypes = [vp, fp]
     lib.ps_set_future_log.argtypes = [vp, fp, u8p, fp, fp]
     lib.ps_num_policy_agents.argtypes = [vp]
@@ -89,7 +91,7 @@ def load_library():
     return lib
 
 
-EXPORTS = ["ps_create", "ps_destroy", "ps_last_error", "ps_set_scene", "ps_set_prompt", "ps_policy_forward", "ps_set_conditions", "ps_set_future_obs", "ps_set_future_log", "ps_num_policy_agents", "ps_policy_flags",
+EXPORTS = ["ps_create", "ps_destroy", "ps_last_error", "ps_set_scene", "ps_set_prompt", "ps_policy_forward", "ps_set_conditions", "ps_set_drag_points", "ps_set_future_obs", "ps_set_future_log", "ps_num_policy_agents", "ps_policy_flags",
            "ps_encode_scene", "ps_generate_policy", "ps_reset_rollout", "ps_policy_step", "ps_rollout", "ps_sync",
            "ps_set_state", "ps_get", "ps_rollout_metric", "ps_num_agents", "ps_num_map_tokens", "ps_time_rollout", "ps_time_policy_kernel",
            "ps_test_pointnet", "ps_test_fourier", "ps_test_wrap", "ps_test_attn", "ps_test_get_edges", "ps_test_stream"]
@@ -128,6 +130,7 @@ class Engine:
                        dec_max_neigh=spec.dec_max_neigh, dec_prompt_radius=spec.dec_prompt_radius,
                        dec_scene_radius=spec.dec_scene_radius, pol_layers=spec.pol_layers, pol_max_neigh=spec.pol_max_neigh,
                        pol_agent_radius=spec.pol_agent_radius, pol_map_radius=spec.pol_map_radius, cond_layers=spec.cond_layers,
+                       drag_pre_layers=spec.drag_pre_layers, drag_mlp_layers=spec.drag_mlp_layers,
                        hist_steps=spec.hist_steps, obs_dim=spec.obs_dim, map_dim=spec.map_dim,
                        map_pre_layers=spec.map_pre_layers, map_mlp_layers=spec.map_mlp_layers,
                        obs_pre_layers=spec.obs_pre_layers, obs_mlp_layers=spec.obs_mlp_layers,
@@ -198,6 +201,10 @@ class Engine:
                 keep += [ci, cm, cp]
                 args += [ci.shape[1], _f(ci), _u8(cm), _i32(cp)]
         self._check(self.lib.ps_set_conditions(self.h, *args))
+        self.set_drag_points(cond.get("drag_point"))
+        unknown = [k for k in cond if k not in ("goal", "v_action_tag", "drag_point")]
+        if unknown:
+            raise NotImplementedError(f"condition types {unknown}: only goal, v_action_tag and drag_point are built")
         if s.get("fut_obs_input") is not None:
             fo = np.ascontiguousarray(s["fut_obs_input"], dtype=np.float32)
             if s.get("fut_obs_mask") is not None and s.get("fut_obs_pos") is not None and s.get("fut_obs_head") is not None:
@@ -207,6 +214,16 @@ class Engine:
                 self._check(self.lib.ps_set_future_log(self.h, _f(fo), _u8(fm), _f(fp_), _f(fh)))
             else:
                 self._check(self.lib.ps_set_future_obs(self.h, _f(fo)))
+
+    def set_drag_points(self, c):
+        """``c`` = {'input' [B,C,T,2] (NaN = absent point), 'mask' [B,C], 'prompt_idx' [B,C,1]} or None (clears)."""
+        if c is None or np.asarray(c["input"]).shape[1] == 0:
+            self._check(self.lib.ps_set_drag_points(self.h, 0, 0, None, None, None))
+            return
+        ci = np.ascontiguousarray(c["input"], dtype=np.float32)
+        cm = np.ascontiguousarray(c["mask"]).astype(np.uint8)
+        cp = np.ascontiguousarray(np.asarray(c["prompt_idx"])[..., 0], dtype=np.int32)
+        self._check(self.lib.ps_set_drag_points(self.h, ci.shape[1], ci.shape[2], _f(ci), _u8(cm), _i32(cp)))
 
     def set_prompt(self, prompt, prompt_pos, prompt_head, agent_type):
         a = [np.ascontiguousarray(prompt, np.float32), np.ascontiguousarray(prompt_pos, np.float32),

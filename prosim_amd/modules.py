@@ -108,6 +108,9 @@ def prompt_to_slots(pr, ids_o, B, N, obs_pos, obs_head):
     return slots, prompt, prompt_mask, agent_type, prompt_pos, prompt_head
 
 
+COND_TYPES = ("goal", "v_action_tag", "drag_point")   # PROMPT.CONDITION.TYPES of prosim_demo/cfg/no_text.yaml:65
+
+
 def cond_to_slots(c, slots, Np):
     """A condition's ``prompt_idx`` (rows of the dense prompt tensor) -> observation slots; conditions that point
     at a padding row are masked off."""
@@ -145,12 +148,13 @@ def scene_from_extras(extras, spec: ModelSpec, task: str = "motion_pred") -> Dic
     cond = extras.get("condition") if hasattr(extras, "get") else None
     if cond:
         out = {}
-        for k in ("goal", "v_action_tag"):
+        for k in COND_TYPES:
             if k in cond.keys() and _g(cond[k], "input").shape[1] > 0:
                 out[k] = cond_to_slots(cond[k], slots, Np)
-        unsupported = [k for k in cond.keys() if k not in ("goal", "v_action_tag") and _g(cond[k], "input").shape[1] > 0]
+        unsupported = [k for k in cond.keys() if k not in COND_TYPES and _g(cond[k], "input").shape[1] > 0]
         if unsupported:
-            raise NotImplementedError(f"condition types {unsupported} are outside this round's scope (unary goal / v_action_tag only)")
+            raise NotImplementedError(f"condition types {unsupported} are not built (the demo config's unary types "
+                                      f"{COND_TYPES} are; v2v_tag and the text types are out of scope)")
         if out:
             scene["cond"] = out
     fut = extras.get("fut_obs") if hasattr(extras, "get") else None
@@ -252,6 +256,8 @@ class HipDecoder:
                     keep += [ci, cm, cp]
                     args += [ci.shape[1], _f(ci), _u8(cm), _i32(cp)]
             eng._check(eng.lib.ps_set_conditions(eng.h, *args))
+            d = condition.get("drag_point")
+            eng.set_drag_points(cond_to_slots(d, slots, Np) if d is not None and np.asarray(d["input"]).shape[1] > 0 else None)
         eng.generate_policy()
         emd_slots = eng.padded("policy_emd")                       # [B, N, D] by observation slot
         emd = np.zeros((B, Np, emd_slots.shape[-1]), np.float32)   # the reference returns prompt order (sym_coord.py:60-75)

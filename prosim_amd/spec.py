@@ -48,6 +48,9 @@ class ModelSpec:
     pol_max_neigh: int = 768
     # MODEL.CONDITION_TRANSFORMER (no_text.yaml:281-288, default.py:521-524)
     cond_layers: int = 3
+    # CONDITION_ENCODER.DRAG_POINTS PointNet (default.py:531-533): [x, y] points -> hidden
+    drag_pre_layers: int = 1
+    drag_mlp_layers: int = 3
     # DATASET.FORMAT.HISTORY (no_text.yaml:195-200): 8 elems + 2 extent + 3 type + 11 time one-hot
     hist_steps: int = 11
     obs_dim: int = 24

@@ -11,6 +11,7 @@ Layouts follow the reference's batch formatters (dataset/format_utils.py:221-263
   obs_pos    [B, N, 2], obs_head [B, N]          agent pose at the last history step, scene frame
   prompt     [B, N, 7]  v_local(2), extent(2), type one-hot(3);  prompt_mask [B, N];  agent_type [B, N] in 1..3
   cond       {'goal': {input [B,C,3]=(gx,gy,t), mask [B,C], prompt_idx [B,C,1]},
+              'drag_point': {input [B,C,T,2] (NaN = no point), mask, prompt_idx},
               'v_action_tag': {input [B,C,3]=(tag_id,t0,t1), mask, prompt_idx}}
 """
 from __future__ import annotations
@@ -24,7 +25,7 @@ from .spec import ModelSpec
 
 def make_scene(spec: ModelSpec, n_agents: int, n_polylines: int, batch: int = 1, seed: int = 0,
                square: float = 200.0, points: int = 19, goal: bool = False, tags: bool = False,
-               ragged: bool = False, clustered: bool = False, replay: float = 0.0) -> Dict[str, np.ndarray]:
+               ragged: bool = False, clustered: bool = False, replay: float = 0.0, drag: bool = False) -> Dict[str, np.ndarray]:
     """One batch of ``batch`` scenes.  ``ragged``: later scenes in the batch get fewer agents /
     polylines / points, and some history steps are masked (NaN), to exercise the mask paths.
     ``clustered``: agents are placed along polylines (realistic density) instead of uniformly.
@@ -150,6 +151,23 @@ def make_scene(spec: ModelSpec, n_agents: int, n_polylines: int, batch: int = 1,
             tm &= rng.rand(B, N) < 0.6
         cond["v_action_tag"] = dict(input=tg, mask=tm,
                                     prompt_idx=np.tile(np.arange(N)[None, :, None], (B, 1, 1)).astype(np.int64))
+    if drag:
+        # drag points (condition_utils.py:401-447): every 5th step of a path in the agent's start frame, a
+        # consecutive subset of the points kept, the others NaN; a condition without any point is masked off
+        Td = (spec.max_steps + 4) // 5
+        t_ = np.arange(Td, dtype=f32)[None, None, :]
+        v = rng.uniform(2.0, 12.0, (B, N, 1)).astype(f32)
+        curv = rng.uniform(-0.02, 0.02, (B, N, 1)).astype(f32)
+        dp = np.stack([v * 0.5 * t_, curv * (v * 0.5 * t_) ** 2], -1) + rng.normal(0, 0.1, (B, N, Td, 2)).astype(f32)
+        lo = rng.randint(0, Td - 5, (B, N, 1))
+        hi = lo + rng.randint(5, Td, (B, N, 1))
+        keep = (np.arange(Td)[None, None, :] >= lo) & (np.arange(Td)[None, None, :] < hi)
+        dm = prompt_mask.copy()
+        if ragged:
+            dm &= rng.rand(B, N) < 0.5
+        keep &= dm[..., None]
+        dp = np.where(keep[..., None], dp, np.nan).astype(f32)
+        cond["drag_point"] = dict(input=dp, mask=dm, prompt_idx=np.tile(np.arange(N)[None, :, None], (B, 1, 1)).astype(np.int64))
     if cond:
         scene["cond"] = cond
     return scene

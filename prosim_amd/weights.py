@@ -134,16 +134,26 @@ def param_shapes(spec: ModelSpec) -> "OrderedDict[str, Tuple[int, ...]]":
         out[f"{ct}.condition_encoders.v_action_tag.tag_encoder.{tag}"] = (d,)
     for i in range(spec.cond_layers):
         _attn_shapes(out, f"{ct}.condition_attn.attn_layers.{i}", d, hd, False)
+    # DragPointEncoder (condition_encoders.py:152-191): a PointNet over the [x, y] drag points
+    if spec.drag_mlp_layers > 0:   # 0: a checkpoint trained without 'drag_point' in PROMPT.CONDITION.TYPES
+        _pointnet_shapes(out, f"{ct}.{DRAG_ENCODER}", 2, d, spec.drag_pre_layers, spec.drag_mlp_layers)
     return out
 
 
+DRAG_ENCODER = "condition_encoders.drag_point.pointnet_encoder"
+
+
 def init_weights(spec: ModelSpec, seed: int = 0) -> Dict[str, np.ndarray]:
-    """Seeded initialiser (torch CPU generator; identical on every box with this image)."""
-    g = torch.Generator(device="cpu")
-    g.manual_seed(1_000_003 * (seed + 1))
+    """Seeded initialiser (torch CPU generator; identical on every box with this image).  The drag-point encoder
+    draws from its own generator, after everything else, so the other tensors keep the values older fixtures saw."""
+    g_main = torch.Generator(device="cpu")
+    g_main.manual_seed(1_000_003 * (seed + 1))
+    g_drag = torch.Generator(device="cpu")
+    g_drag.manual_seed(7_000_003 * (seed + 1) + 11)
     shapes = param_shapes(spec)
     w: Dict[str, np.ndarray] = {}
-    for name in sorted(shapes):
+    for name in sorted(shapes, key=lambda n: (DRAG_ENCODER in n, n)):
+        g = g_drag if DRAG_ENCODER in name else g_main
         shp = shapes[name]
         is_ln = len(shp) == 1 and name.endswith(".weight") and (
             "norm" in name or ".MLP.1." in name or _is_mlp_ln(name, shapes))

@@ -54,6 +54,8 @@ FULL_CASES = {
     "demo_16a_128p": ("demo", dict(n_agents=16, n_polylines=128, batch=1, seed=3, goal=True), 0),
     # policy agents are a SUBSET of the observed agents: the others replay a log (fut_obs frames)
     "small_replay_b2": ("small", dict(n_agents=16, n_polylines=128, batch=2, seed=5, goal=True, ragged=True, replay=0.4), 0),
+    # all three condition types of the demo config (PROMPT.CONDITION.TYPES): goal, v_action_tag, drag_point
+    "small_drag_b2": ("small", dict(n_agents=16, n_polylines=128, batch=2, seed=6, goal=True, tags=True, drag=True, ragged=True), 0),
 }
 SPECS = {"small": SMALL_SPEC, "demo": DEMO_SPEC}
 
@@ -68,7 +70,7 @@ def run_reference(spec, w, scene):
     model = rh.build_model(cfg)
     missing, unexpected = model.load_state_dict(weights.to_reference_state_dict(spec, w), strict=False)
     assert not unexpected, unexpected
-    assert all("drag_point" in m for m in missing), [m for m in missing if "drag_point" not in m]
+    assert not missing, missing
     batch = rh.make_batch(scene, spec)
     with torch.no_grad():
         out = model(batch, "val")["motion_pred"]

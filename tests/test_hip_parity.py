@@ -325,6 +325,57 @@ def test_future_obs_frames_and_conditions_subset(small_engine):
     assert (d < 1e-3).mean() >= 0.9
 
 
+def test_drag_point_conditions_vs_oracle(small_engine):
+    """DragPointEncoder (condition_encoders.py:152-191): a PointNet over the non-NaN [x, y] points of each drag, pooled
+    with the goal / tag entries of the same agent (condition_attns.py:114-188).  Checked on the generator output
+    (policy_emd, fp64 oracle) with drag points alone, with all three types, and after clearing them."""
+    spec = SMALL_SPEC
+    w = weights.init_weights(spec, 0)
+    full = synth.make_scene(spec, 24, 64, batch=2, seed=33, goal=True, tags=True, drag=True, ragged=True)
+    pm = full["prompt_mask"].astype(bool)
+    assert np.isnan(full["cond"]["drag_point"]["input"]).any()             # absent points are NaN, as the dataset makes them
+
+    def emd_of(scene):
+        small_engine.set_scene(scene)
+        small_engine.encode_scene()
+        small_engine.generate_policy()
+        with torch.no_grad():
+            o = orc.rollout(w, spec, scene, dtype=torch.float64, collect=True)
+        return small_engine.padded("policy_emd")[pm], o["policy_emd"].numpy()[pm]
+
+    only_drag = dict(full, cond={"drag_point": full["cond"]["drag_point"]})
+    none = {k: v for k, v in full.items() if k != "cond"}
+    got_d, want_d = emd_of(only_drag)
+    assert err(got_d, want_d) < TOL
+    got_f, want_f = emd_of(full)
+    assert err(got_f, want_f) < TOL
+    got_n, want_n = emd_of(none)                                            # set_scene without conditions clears them
+    assert err(got_n, want_n) < TOL
+    assert err(want_d, want_n) > 1e-2 and err(want_f, want_d) > 1e-2        # and every type moves the result
+    # a drag whose points are all NaN is still an (all-zero) entry of its agent when its mask is set (:180-182)
+    hole = dict(only_drag, cond={"drag_point": {k: v.copy() for k, v in full["cond"]["drag_point"].items()}})
+    b0, c0 = np.argwhere(hole["cond"]["drag_point"]["mask"])[0]
+    hole["cond"]["drag_point"]["input"][b0, c0] = np.nan
+    got_h, want_h = emd_of(hole)
+    assert err(got_h, want_h) < TOL
+    # more than 32 points per drag is outside the PointNet kernel's tile
+    long = dict(only_drag, cond={"drag_point": dict(full["cond"]["drag_point"], input=np.zeros((2, 24, 40, 2), np.float32))})
+    with pytest.raises(RuntimeError, match="1..32 points"):
+        small_engine.set_scene(long)
+    # an engine built for a checkpoint without the drag-point encoder refuses drag conditions
+    from prosim_amd.engine import Engine
+    spec0 = spec.replace(drag_mlp_layers=0)
+    w0 = weights.init_weights(spec0, 0)
+    assert not any("drag_point" in k for k in w0) and all(np.array_equal(w0[k], w[k]) for k in w0)
+    eng0 = Engine(spec0, w0)
+    try:
+        with pytest.raises(RuntimeError, match="without the drag-point encoder"):
+            eng0.set_scene(only_drag)
+        eng0.set_scene(dict(full, cond={k: v for k, v in full["cond"].items() if k != "drag_point"}))
+    finally:
+        eng0.close()
+
+
 def test_demo_dataset_scene_config0():
     """BASELINE configs[0]: a demo_dataset scene (real Waymo tracks from the reference's sample cache, formatted by
     prosim_amd/formatting.py; lanes drawn along the driven paths), 16 agents, 20-step unconditional rollout.

@@ -38,10 +38,11 @@ def test_registry_names_match_reference():
     assert r.get_policy("nope") is None
 
 
-def test_forward_output_contract_vs_fixture(model):
+@pytest.mark.parametrize("name", ["small_ragged_b2", "small_drag_b2"])
+def test_forward_output_contract_vs_fixture(model, name):
     """ProSim.forward(batch,'val') drop-in: same keys/shapes as traj_sam.py:562-595 and the values of
-    the reference fixture (reference Python + stand-ins)."""
-    name = "small_ragged_b2"
+    the reference fixture (reference Python + stand-ins); small_drag_b2 carries all three condition types of the
+    demo config (goal, v_action_tag, drag_point) through ``batch.extras['condition']``."""
     sname, kw, wseed = FULL_CASES[name]
     spec = SPECS[sname]
     g = np.load(os.path.join(GOLD, f"ref_standins_{name}.npz"))

@@ -26,7 +26,8 @@ def Wt():
 
 def test_weight_init_is_stable(pure):
     assert digest(weights.init_weights(DEMO_SPEC, 0)) == str(pure["weight_digest"])
-    assert weights.n_params(DEMO_SPEC) == 11316148  # reference 11 399 220 minus the unused drag-point PointNet
+    assert weights.n_params(DEMO_SPEC) == 11399220  # every learnable tensor of the reference's demo model
+    assert weights.n_params(DEMO_SPEC.replace(drag_mlp_layers=0)) == 11316148   # without the drag-point PointNet
 
 
 @pytest.mark.parametrize("tag,in_dim,pre,n,prefix", [("map", 11, 3, 5, "scene_encoder.map_encoder"),
