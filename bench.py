@@ -115,7 +115,7 @@ def main():
     if world > 1:
         dist.barrier()
     from prosim_amd.engine import Engine
-    from prosim_amd.distributed import shard_scenes, gather_scene_metrics, reduce_metrics
+    from prosim_amd.distributed import shard_scenes, reduce_metrics
 
     spec = DEMO_SPEC
     w = weights.init_weights(spec, 0)
@@ -131,16 +131,37 @@ def main():
     eng.set_scene(scene)
     A = eng.num_agents
     N = scene["prompt_mask"].shape[1]
-    metric_local = torch.zeros(A, 2, device="cuda")
+    from prosim_amd.distributed import SceneMetricGather
+    # The metric gather of rollout k is enqueued behind rollout k on the GPU (event on the engine's stream ->
+    # torch's stream) and the host goes straight on to launch rollout k+1: no host-side wait inside the loop, the
+    # few-KB RCCL all-gather overlaps the next rollout.  Two metric buffers alternate; the engine's stream waits for
+    # the gather that last read a buffer before the metric kernel overwrites it.
+    metric_bufs = [torch.zeros(A, 2, device="cuda") for _ in range(2)]
+    eng_stream = torch.cuda.ExternalStream(eng.stream_handle, device=torch.device("cuda", dev_index))
+    done = [torch.cuda.Event() for _ in range(2)]       # rollout + metric of buffer i finished (engine stream)
+    read = [None, None]                                  # gather of buffer i finished (torch stream)
+    gather = SceneMetricGather(my_scenes, n_scenes, N, 2, "cuda" if backend == "nccl" else "cpu") if world > 1 else None
+    state = {"k": 0, "last": None}
 
     def step():
+        i = state["k"] & 1
+        state["k"] += 1
+        if read[i] is not None:
+            eng_stream.wait_event(read[i])
         eng.rollout()
-        eng.rollout_metric(metric_local.data_ptr())
-        if world > 1:
-            eng.sync()  # engine stream -> host; the gather runs on torch's stream
-            m = metric_local.view(S, N, 2)
-            return gather_scene_metrics(m if backend == "nccl" else m.cpu(), my_scenes, n_scenes, N)
-        return metric_local.view(S, N, 2)
+        eng.rollout_metric(metric_bufs[i].data_ptr())
+        done[i].record(eng_stream)
+        if world == 1:
+            state["last"] = metric_bufs[i].view(S, N, 2)
+            return
+        if backend == "nccl":
+            torch.cuda.current_stream().wait_event(done[i])
+            state["last"] = gather(metric_bufs[i].view(S, N, 2))
+            read[i] = torch.cuda.Event()
+            read[i].record()
+        else:   # CPU test hook: the copy to the host is the wait
+            done[i].synchronize()
+            state["last"] = gather(metric_bufs[i].view(S, N, 2).cpu())
 
     for _ in range(args.warmup):
         step()
@@ -166,7 +187,10 @@ def main():
         total_agents = A
     ms_per_step = 1e3 * dt / args.steps
     value = total_agents * spec.max_steps / (dt / args.steps)
-    metrics = reduce_metrics(step())
+    step()
+    eng.sync()
+    torch.cuda.synchronize()
+    metrics = reduce_metrics(state["last"])
 
     if rank == 0:
         # dominant kernel: the fused policy attention chain (one launch per replan), timed with HIP

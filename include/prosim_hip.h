@@ -131,6 +131,9 @@ int ps_policy_step(ps_engine* e, int32_t t_idx);
  * the engine's stream (replayed from a hipGraph after the first call for a given scene shape). */
 int ps_rollout(ps_engine* e);
 int ps_sync(ps_engine* e);
+/* The engine's hipStream_t (every entry point enqueues on it), so a host can order its own streams against the
+ * engine with events instead of ps_sync -- bench.py overlaps the RCCL metric gather of rollout k with rollout k+1. */
+void* ps_stream(ps_engine* e);
 
 /* Stateless policy.forward -- the drop-in for Policy_RelPE_Temporal.forward(policy_emd, batch_obs,
  * batch_map, batch_pos, pair_names, latent_state) (policy/base.py:19; act_decoder.py:239-283, :78-140) on

@@ -1487,6 +1487,8 @@ extern "C" int ps_sync(ps_engine* e) {
   return PS_OK;
 }
 
+extern "C" void* ps_stream(ps_engine* e) { return e ? (void*)e->stream : nullptr; }
+
 extern "C" int ps_set_state(ps_engine* e, int32_t steps, const float* traj, const float* vel) {
   if (!e || !e->have_scene) return fail(PS_E_STATE, "ps_set_state before ps_set_scene");
   if (steps < e->cfg.hist_steps || steps > e->stride_steps) return fail(PS_E_ARG, "steps out of range");

@@ -22,30 +22,53 @@ def shard_scenes(n_scenes: int, rank: int, world: int) -> List[int]:
     return [i for i in range(n_scenes) if i % world == rank]
 
 
+class SceneMetricGather:
+    """The all-gather of per-scene metric rows, with every buffer and index tensor built ONCE: a call enqueues two
+    collectives and an index_copy on the current stream and never reads device data on the host, so the caller can
+    keep launching rollouts while the gather of the previous one is in flight.  Uneven shards are padded to the
+    largest shard (padding rows carry scene id -1 and land in a scratch row)."""
+
+    def __init__(self, scene_ids: Sequence[int], n_scenes: int, max_agents: int, n_metrics: int, device,
+                 dtype=torch.float32):
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.n_scenes, self.n_local = n_scenes, len(scene_ids)
+        per = (n_scenes + self.world - 1) // self.world
+        if self.n_local > per:
+            raise ValueError("shard larger than ceil(n_scenes / world)")
+        self.buf = torch.full((per, max_agents, n_metrics), float("nan"), dtype=dtype, device=device)
+        ids = torch.full((per,), -1, dtype=torch.int64)
+        ids[:self.n_local] = torch.as_tensor(list(scene_ids), dtype=torch.int64)
+        if self.world == 1:
+            all_ids = ids
+        else:
+            ids = ids.to(device)
+            all_ids = torch.empty((self.world * per,), dtype=torch.int64, device=device)
+            dist.all_gather_into_tensor(all_ids, ids)
+            all_ids = all_ids.cpu()
+        if ((all_ids < -1) | (all_ids >= n_scenes)).any():
+            raise ValueError("scene id outside [0, n_scenes)")
+        # scene ids never change between calls: gather them once, keep the scatter index on the device
+        self.index = torch.where(all_ids >= 0, all_ids, torch.full_like(all_ids, n_scenes)).to(device)
+        self.all_buf = torch.empty((self.world * per, max_agents, n_metrics), dtype=dtype, device=device)
+
+    def __call__(self, local: torch.Tensor) -> torch.Tensor:
+        """``local`` [n_local, max_agents, M] -> [n_scenes, max_agents, M] on every rank, in scene order."""
+        if self.n_local:
+            self.buf[:self.n_local].copy_(local, non_blocking=True)
+        if self.world == 1:
+            self.all_buf.copy_(self.buf)
+        else:
+            dist.all_gather_into_tensor(self.all_buf, self.buf)
+        out = torch.full((self.n_scenes + 1,) + tuple(self.all_buf.shape[1:]), float("nan"), dtype=self.all_buf.dtype,
+                         device=self.all_buf.device)
+        out.index_copy_(0, self.index, self.all_buf)
+        return out[:self.n_scenes]
+
+
 def gather_scene_metrics(local: torch.Tensor, scene_ids: Sequence[int], n_scenes: int, max_agents: int) -> torch.Tensor:
-    """All-gather per-scene metric rows.  ``local`` [n_local, max_agents, M] (NaN-padded rows for missing
-    agents) for the scenes in ``scene_ids``; returns [n_scenes, max_agents, M] on every rank, in scene order.
-    Uneven shards are padded to the largest shard so one all_gather_into_tensor suffices."""
-    world = dist.get_world_size() if dist.is_initialized() else 1
-    M = local.shape[-1]
-    per = (n_scenes + world - 1) // world
-    buf = torch.full((per, max_agents, M), float("nan"), dtype=local.dtype, device=local.device)
-    ids = torch.full((per,), -1, dtype=torch.int64, device=local.device)
-    n = len(scene_ids)
-    if n:
-        buf[:n] = local
-        ids[:n] = torch.as_tensor(list(scene_ids), dtype=torch.int64, device=local.device)
-    if world == 1:
-        all_buf, all_ids = buf, ids
-    else:
-        all_buf = torch.empty((world * per, max_agents, M), dtype=local.dtype, device=local.device)
-        all_ids = torch.empty((world * per,), dtype=torch.int64, device=local.device)
-        dist.all_gather_into_tensor(all_buf, buf)
-        dist.all_gather_into_tensor(all_ids, ids)
-    out = torch.full((n_scenes, max_agents, M), float("nan"), dtype=local.dtype, device=local.device)
-    keep = all_ids >= 0
-    out[all_ids[keep]] = all_buf[keep]
-    return out
+    """One-shot form of :class:`SceneMetricGather`.  ``local`` [n_local, max_agents, M] (NaN-padded rows for missing
+    agents) for the scenes in ``scene_ids``; returns [n_scenes, max_agents, M] on every rank, in scene order."""
+    return SceneMetricGather(scene_ids, n_scenes, max_agents, local.shape[-1], local.device, local.dtype)(local)
 
 
 def reduce_metrics(gathered: torch.Tensor) -> Dict[str, float]:
