@@ -131,6 +131,12 @@ int ps_policy_step(ps_engine* e, int32_t t_idx);
  * the engine's stream (replayed from a hipGraph after the first call for a given scene shape). */
 int ps_rollout(ps_engine* e);
 int ps_sync(ps_engine* e);
+/* scene_encoder.update_scene_emb(scene_embs, batch_obs_new, old_ids) (attn_fusion.py:238-252; OBS_UPDATE FUSION 'replace',
+ * ATTN_UPDATE False as in no_text.yaml:213-215): re-encode the agents from a new observation (same layout as
+ * ps_set_scene's obs_*), replace their tokens and poses, reuse the map tokens.  The observed agents must be those of
+ * ps_set_scene.  ps_policy_step does this on the device from the simulated state; this entry point serves callers
+ * that drive the encoder by hand.  Read the tokens back with ps_get("scene_tokens"). */
+int ps_update_obs(ps_engine* e, const float* obs_input, const uint8_t* obs_mask, const float* obs_pos, const float* obs_head);
 /* The engine's hipStream_t (every entry point enqueues on it), so a host can order its own streams against the
  * engine with events instead of ps_sync -- bench.py overlaps the RCCL metric gather of rollout k with rollout k+1. */
 void* ps_stream(ps_engine* e);

@@ -1487,6 +1487,52 @@ extern "C" int ps_sync(ps_engine* e) {
   return PS_OK;
 }
 
+// scene_encoder.update_scene_emb (attn_fusion.py:238-252 with OBS_UPDATE {FUSION: replace, ATTN_UPDATE: False}): re-encode
+// the agents from a new observation, replace their tokens and poses, keep the map tokens.
+extern "C" int ps_update_obs(ps_engine* e, const float* obs_input, const uint8_t* obs_mask, const float* obs_pos,
+                             const float* obs_head) {
+  if (!e || !e->have_scene || !e->encoded) return fail(PS_E_STATE, "ps_update_obs before ps_encode_scene");
+  if (!obs_input || !obs_mask || !obs_pos || !obs_head) return fail(PS_E_ARG, "ps_update_obs: null argument");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  const ps_config& c = e->cfg;
+  const int A = e->A, Mv = e->Mv;
+  const size_t arow = (size_t)c.hist_steps * c.obs_dim;
+  std::vector<float> in((size_t)A * arow), pos((size_t)A * 2), ori(A);
+  std::vector<uint8_t> mk((size_t)A * arow);
+  for (int i = 0; i < A; ++i) {
+    const size_t r = e->agent_rows[i];
+    bool any = false;
+    for (int h = 0; h < c.hist_steps && !any; ++h) {
+      bool all = true;
+      for (int f = 0; f < c.obs_dim; ++f) all &= obs_mask[r * arow + (size_t)h * c.obs_dim + f] != 0;
+      any = all;
+    }
+    if (!any) return fail(PS_E_ARG, "ps_update_obs: the observed agents must be those of ps_set_scene (an agent lost every history step)");
+    for (size_t k = 0; k < arow; ++k) {
+      mk[i * arow + k] = obs_mask[r * arow + k];
+      const float v = obs_input[r * arow + k];
+      in[i * arow + k] = std::isnan(v) ? 0.f : v;
+    }
+    pos[2 * i] = obs_pos[2 * r];
+    pos[2 * i + 1] = obs_pos[2 * r + 1];
+    ori[i] = obs_head[r];
+  }
+  DevBuf<float> d_in, d_pos, d_ori;
+  DevBuf<uint8_t> d_mk;
+  hipStream_t st = e->stream;
+  if (upload(d_in, in.data(), in.size(), st) || upload(d_mk, mk.data(), mk.size(), st) || upload(d_pos, pos.data(), pos.size(), st) ||
+      upload(d_ori, ori.data(), ori.size(), st))
+    return fail(PS_E_HIP, "ps_update_obs upload failed");
+  launch_pointnet(e, e->pn_obs, d_in.p, d_mk.p, nullptr, A, c.hist_steps, c.obs_dim, e->d_tok.p + (size_t)Mv * D);
+  HIPCHK(hipMemcpyAsync(e->d_tok_pos.p + 2 * (size_t)Mv, d_pos.p, sizeof(float) * 2 * A, hipMemcpyDeviceToDevice, st));
+  HIPCHK(hipMemcpyAsync(e->d_tok_ori.p + Mv, d_ori.p, sizeof(float) * A, hipMemcpyDeviceToDevice, st));
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(st));
+  d_in.release(); d_mk.release(); d_pos.release(); d_ori.release();
+  e->generated = false;   // a policy generated from the old tokens is stale
+  return PS_OK;
+}
+
 extern "C" void* ps_stream(ps_engine* e) { return e ? (void*)e->stream : nullptr; }
 
 extern "C" int ps_set_state(ps_engine* e, int32_t steps, const float* traj, const float* vel) {

@@ -68,6 +68,7 @@ def load_library():
     lib.ps_set_future_log.argtypes = [vp, fp, u8p, fp, fp]
     lib.ps_num_policy_agents.argtypes = [vp]
     lib.ps_num_policy_agents.restype = C.c_int32
+    lib.ps_update_obs.argtypes = [vp, fp, u8p, fp, fp]
     lib.ps_stream.argtypes = [vp]
     lib.ps_stream.restype = C.c_void_p
     lib.ps_policy_flags.argtypes = [vp, i32p, C.c_int64]
@@ -94,7 +95,7 @@ def load_library():
 
 
 EXPORTS = ["ps_create", "ps_destroy", "ps_last_error", "ps_set_scene", "ps_set_prompt", "ps_policy_forward", "ps_set_conditions", "ps_set_drag_points", "ps_set_future_obs", "ps_set_future_log", "ps_num_policy_agents", "ps_policy_flags",
-           "ps_encode_scene", "ps_generate_policy", "ps_reset_rollout", "ps_policy_step", "ps_rollout", "ps_sync", "ps_stream",
+           "ps_encode_scene", "ps_generate_policy", "ps_reset_rollout", "ps_policy_step", "ps_rollout", "ps_sync", "ps_stream", "ps_update_obs",
            "ps_set_state", "ps_get", "ps_rollout_metric", "ps_num_agents", "ps_num_map_tokens", "ps_time_rollout", "ps_time_policy_kernel",
            "ps_test_pointnet", "ps_test_fourier", "ps_test_wrap", "ps_test_attn", "ps_test_get_edges", "ps_test_stream"]
 
@@ -190,23 +191,7 @@ class Engine:
         seen = obs_mask.astype(bool).all(-1).any(-1).reshape(-1)
         self._slots = np.nonzero(seen)[0]
         self.policy_rows = pm.reshape(-1).astype(bool)[self._slots]
-        cond = s.get("cond") or {}
-        g, t = cond.get("goal"), cond.get("v_action_tag")
-        args = []
-        for c in (g, t):
-            if c is None or c["input"].shape[1] == 0:
-                args += [0, None, None, None]
-            else:
-                ci = np.ascontiguousarray(c["input"], dtype=np.float32)
-                cm = np.ascontiguousarray(c["mask"]).astype(np.uint8)
-                cp = np.ascontiguousarray(np.asarray(c["prompt_idx"])[..., 0], dtype=np.int32)
-                keep += [ci, cm, cp]
-                args += [ci.shape[1], _f(ci), _u8(cm), _i32(cp)]
-        self._check(self.lib.ps_set_conditions(self.h, *args))
-        self.set_drag_points(cond.get("drag_point"))
-        unknown = [k for k in cond if k not in ("goal", "v_action_tag", "drag_point")]
-        if unknown:
-            raise NotImplementedError(f"condition types {unknown}: only goal, v_action_tag and drag_point are built")
+        self.set_conditions(s.get("cond"))
         if s.get("fut_obs_input") is not None:
             fo = np.ascontiguousarray(s["fut_obs_input"], dtype=np.float32)
             if s.get("fut_obs_mask") is not None and s.get("fut_obs_pos") is not None and s.get("fut_obs_head") is not None:
@@ -216,6 +201,26 @@ class Engine:
                 self._check(self.lib.ps_set_future_log(self.h, _f(fo), _u8(fm), _f(fp_), _f(fh)))
             else:
                 self._check(self.lib.ps_set_future_obs(self.h, _f(fo)))
+
+    def set_conditions(self, cond):
+        """``cond`` = {'goal' | 'v_action_tag' | 'drag_point': {'input', 'mask', 'prompt_idx' [B,C,1] = prompt SLOT}} or
+        None; replaces every condition of the uploaded batch (batch.extras['condition'] after the id -> slot mapping)."""
+        cond = cond or {}
+        unknown = [k for k in cond if k not in ("goal", "v_action_tag", "drag_point")]
+        if unknown:
+            raise NotImplementedError(f"condition types {unknown}: only goal, v_action_tag and drag_point are built")
+        args, keep = [], []
+        for c in (cond.get("goal"), cond.get("v_action_tag")):
+            if c is None or np.asarray(c["input"]).shape[1] == 0:
+                args += [0, None, None, None]
+            else:
+                ci = np.ascontiguousarray(c["input"], dtype=np.float32)
+                cm = np.ascontiguousarray(c["mask"]).astype(np.uint8)
+                cp = np.ascontiguousarray(np.asarray(c["prompt_idx"])[..., 0], dtype=np.int32)
+                keep += [ci, cm, cp]
+                args += [ci.shape[1], _f(ci), _u8(cm), _i32(cp)]
+        self._check(self.lib.ps_set_conditions(self.h, *args))
+        self.set_drag_points(cond.get("drag_point"))
 
     def set_drag_points(self, c):
         """``c`` = {'input' [B,C,T,2] (NaN = absent point), 'mask' [B,C], 'prompt_idx' [B,C,1]} or None (clears)."""
@@ -258,6 +263,14 @@ class Engine:
 
     def reset_rollout(self):
         self._check(self.lib.ps_reset_rollout(self.h))
+
+    def update_obs(self, obs_input, obs_mask, obs_pos, obs_head):
+        """Re-encode the agents from a new observation ([B,N,hist,obs_dim], mask, [B,N,2], [B,N]); map tokens are kept."""
+        a = [np.ascontiguousarray(obs_input, np.float32), np.ascontiguousarray(obs_mask).astype(np.uint8),
+             np.ascontiguousarray(obs_pos, np.float32), np.ascontiguousarray(obs_head, np.float32).reshape(self._shape)]
+        if a[0].shape[:2] != self._shape or a[1].shape != a[0].shape:
+            raise ValueError("update_obs: the observation must keep the [B, N] layout of set_scene")
+        self._check(self.lib.ps_update_obs(self.h, _f(a[0]), _u8(a[1]), _f(a[2]), _f(a[3])))
 
     def policy_step(self, t_idx: int):
         self._check(self.lib.ps_policy_step(self.h, t_idx))

@@ -144,7 +144,7 @@ def scene_from_extras(extras, spec: ModelSpec, task: str = "motion_pred") -> Dic
                  map_head=_np(_g(mp, "heading")), obs_input=obs_input, obs_mask=_np(_g(obs, "mask"), bool),
                  obs_pos=_np(_g(obs, "position")), obs_head=_np(_g(obs, "heading")), prompt=prompt,
                  prompt_mask=prompt_mask, agent_type=agent_type, prompt_pos=prompt_pos, prompt_head=prompt_head,
-                 _policy_slots=slots)
+                 _policy_slots=slots, _obs_ids=ids_o)
     cond = extras.get("condition") if hasattr(extras, "get") else None
     if cond:
         out = {}
@@ -183,7 +183,7 @@ class HipSceneEncoder:
     def _result(self, scene) -> Dict[str, Any]:
         eng = self.s.engine
         mm = torch.from_numpy(scene["map_mask"].astype(bool)).any(-1)
-        om = torch.from_numpy(scene["prompt_mask"].astype(bool))
+        om = torch.from_numpy(scene["obs_mask"].astype(bool).all(-1).any(-1))    # observed agents = agent tokens
         B = mm.shape[0]
         flat = lambda m: torch.arange(B).unsqueeze(1).repeat(1, m.shape[1]).view(-1)[m.view(-1)]
         mb, ob = flat(mm), flat(om)
@@ -215,8 +215,20 @@ class HipSceneEncoder:
         return self._result(scene)
 
     def update_scene_emb(self, scene_embs, batch_obs, old_obs_agent_ids):
-        raise NotImplementedError("per-replan observation refresh runs inside ps_policy_step / ProSimHip.forward "
-                                  "(step_env + obs PointNet + token swap happen on the device)")
+        """``update_scene_emb`` (attn_fusion.py:238-252) for the demo config's OBS_UPDATE (FUSION 'replace', ATTN_UPDATE
+        False): agents re-encoded from ``batch_obs``, map tokens reused.  Inside a rollout the engine does this on
+        the device (ps_policy_step); this call serves code that drives the encoder itself."""
+        if not scene_embs.get("_hip_resident") or self.s.scene is None:
+            raise ValueError("scene_embs must come from HipSceneEncoder (tokens are device-resident)")
+        new_ids = _g(batch_obs, "agent_ids")
+        if new_ids is not None and old_obs_agent_ids is not None and [list(a) for a in new_ids] != [list(a) for a in old_obs_agent_ids]:
+            raise NotImplementedError("update_scene_emb: agents entering or leaving the scene between replans are not built")
+        scene = dict(self.s.scene)
+        scene.update(obs_input=_np(_g(batch_obs, "input")), obs_mask=_np(_g(batch_obs, "mask"), bool),
+                     obs_pos=_np(_g(batch_obs, "position")), obs_head=_np(_g(batch_obs, "heading")).reshape(scene["obs_head"].shape))
+        self.s.engine.update_obs(scene["obs_input"], scene["obs_mask"], scene["obs_pos"], scene["obs_head"])
+        self.s.scene = scene
+        return self._result(scene)
 
 
 @registry.register_decoder(name="attn_fusion_relpe")
@@ -243,21 +255,11 @@ class HipDecoder:
         eng.set_prompt(prompt, p_pos, p_head, a_type.astype(np.int32))
         Np = _np(_g(prompt_enc, "prompt_mask")).shape[1]
         if condition:
-            g, t = condition.get("goal"), condition.get("v_action_tag")
-            from .engine import _f, _u8, _i32
-            args, keep = [], []
-            for c in (g, t):
-                if c is None or np.asarray(c["input"]).shape[1] == 0:
-                    args += [0, None, None, None]
-                else:
-                    c = cond_to_slots(c, slots, Np)
-                    ci, cm = c["input"], c["mask"].astype(np.uint8)
-                    cp = np.ascontiguousarray(c["prompt_idx"][..., 0], dtype=np.int32)
-                    keep += [ci, cm, cp]
-                    args += [ci.shape[1], _f(ci), _u8(cm), _i32(cp)]
-            eng._check(eng.lib.ps_set_conditions(eng.h, *args))
-            d = condition.get("drag_point")
-            eng.set_drag_points(cond_to_slots(d, slots, Np) if d is not None and np.asarray(d["input"]).shape[1] > 0 else None)
+            unsupported = [k for k in condition.keys() if k not in COND_TYPES and np.asarray(condition[k]["input"]).shape[1] > 0]
+            if unsupported:
+                raise NotImplementedError(f"condition types {unsupported} are not built")
+            eng.set_conditions({k: cond_to_slots(condition[k], slots, Np) for k in COND_TYPES
+                                if k in condition.keys() and np.asarray(condition[k]["input"]).shape[1] > 0})
         eng.generate_policy()
         emd_slots = eng.padded("policy_emd")                       # [B, N, D] by observation slot
         emd = np.zeros((B, Np, emd_slots.shape[-1]), np.float32)   # the reference returns prompt order (sym_coord.py:60-75)
@@ -323,13 +325,101 @@ class ProSimHip:
         return self.forward(batch, mode)
 
     def forward(self, batch, mode="val") -> Dict[str, Any]:
+        """The whole closed loop as ONE device graph (ps_rollout).  The staged methods below give the same values
+        call by call, in the reference's order (traj_sam.py:59-71)."""
         if mode == "train":
             raise NotImplementedError("training is out of scope (DESIGN.md)")
         extras = batch.extras if hasattr(batch, "extras") else batch
+        scene = scene_from_extras(extras, self.spec)
+        self._shared.scene = scene
+        self.engine.set_scene(scene)
+        self.engine.rollout()
+        return self._process_rollout(extras, scene)
+
+    # ---- the reference's stages (traj_sam.py:73-203), device-resident between calls -------------------------------
+    def encode_scene(self, batch) -> Dict[str, Any]:
+        """``ProSim.encode_scene`` (:73-77).  Takes the whole batch, so policy agents may be a subset of the
+        observed agents here (the prompt and ``fut_obs`` are at hand), unlike the bare scene_encoder call."""
+        extras = batch.extras if hasattr(batch, "extras") else batch
+        scene = scene_from_extras(extras, self.spec)
+        self._shared.scene = scene
+        self.engine.set_scene(scene)
+        self.engine.encode_scene()
+        return self.scene_encoder._result(scene)
+
+    def encode_prompt(self, batch, prompt_dict={}) -> Dict[str, Any]:
+        """``ProSim.encode_prompt`` (:79-103).  The prompt MLP runs inside ps_generate_policy; the prompt data pass
+        through (a ``prompt_dict`` override replaces the prompt rows that encode_scene uploaded)."""
+        extras = batch.extras if hasattr(batch, "extras") else batch
+        encs = {}
+        for task in (prompt_dict.keys() if prompt_dict else self.tasks):
+            encs[task] = prompt_dict[task] if task in prompt_dict else extras["prompt"][task]
+        return encs
+
+    def generate_policy(self, batch, scene_embs, prompt_encs) -> Dict[str, Any]:
+        """``ProSim.generate_policy`` (:118-142): decoder + condition transformer -> ``{task: {'emd','agent_type'}}``."""
+        extras = batch.extras if hasattr(batch, "extras") else batch
+        cond = extras.get("condition") if hasattr(extras, "get") else None
+        sc = self._shared.scene
+        if sc is None or not scene_embs.get("_hip_resident"):
+            raise ValueError("scene_embs must come from this model's encode_scene (tokens are device-resident)")
+        out = {}
+        for task, pe in prompt_encs.items():
+            B, N = sc["prompt_mask"].shape
+            slots, prompt, pm, a_type, p_pos, p_head = prompt_to_slots(pe, sc.get("_obs_ids"), B, N, sc["obs_pos"], sc["obs_head"])
+            if not np.array_equal(pm, sc["prompt_mask"]):
+                raise ValueError("generate_policy: the prompt agents differ from the ones encode_scene saw")
+            self.engine.set_prompt(prompt, p_pos, p_head, a_type.astype(np.int32))
+            Np = _np(_g(pe, "prompt_mask")).shape[1]
+            if cond:
+                unsupported = [k for k in cond.keys() if k not in COND_TYPES and _g(cond[k], "input").shape[1] > 0]
+                if unsupported:
+                    raise NotImplementedError(f"condition types {unsupported} are not built")
+                sc["cond"] = {k: cond_to_slots(cond[k], slots, Np) for k in COND_TYPES
+                              if k in cond.keys() and _g(cond[k], "input").shape[1] > 0}
+                self.engine.set_conditions(sc["cond"])
+            self.engine.generate_policy()
+            emd_slots = self.engine.padded("policy_emd")
+            emd = np.zeros((B, Np, emd_slots.shape[-1]), np.float32)
+            for b in range(B):
+                emd[b, :len(slots[b])] = emd_slots[b, slots[b]]
+            out[task] = dict(emd=torch.from_numpy(emd), agent_type=torch.from_numpy(_np(_g(pe, "agent_type"), np.int64)),
+                             _hip_resident=True)
+        return out
+
+    def init_agent_trajs(self, policy_agent_ids, batch) -> Dict[str, Any]:
+        """``ProSim.init_agent_trajs`` (:597-633): the trajectory state lives on the device (ps_reset_rollout)."""
+        self.engine.reset_rollout()
+        return {task: dict(_hip_resident=True, last_step=0) for task in self.tasks}
+
+    def rollout_batch(self, batch, scene_embs, policy_emds, policy_agent_ids, agent_trajs, all_t_indices, mode="val"):
+        """``ProSim.rollout_batch`` (:144-176): per replan step_env -> decode_output -> step_agent_traj = one
+        ``ps_policy_step``; then ``_process_rollout`` (:562-595)."""
+        if mode == "train":
+            raise NotImplementedError("training is out of scope (DESIGN.md)")
+        want = list(self.spec.all_t_indices)
+        if [int(t) for t in all_t_indices] != want:
+            raise ValueError(f"all_t_indices must be {want} (ROLLOUT.POLICY.REPLAN_FREQ / MAX_STEPS of the spec)")
+        if not all(v.get("_hip_resident") for v in (scene_embs, *policy_emds.values(), *agent_trajs.values())):
+            raise ValueError("rollout_batch needs the device-resident results of encode_scene / generate_policy / init_agent_trajs")
+        for i in range(len(want)):
+            self.engine.policy_step(i)
+        extras = batch.extras if hasattr(batch, "extras") else batch
+        return self._process_rollout(extras, self._shared.scene)
+
+    def decode_batch(self, scene_embs, prompt_encs, batch, mode="val"):
+        """``ProSim.decode_batch`` (:105-116)."""
+        extras = batch.extras if hasattr(batch, "extras") else batch
+        policy_emds = self.generate_policy(batch, scene_embs, prompt_encs)
+        policy_agent_ids = {task: _g(extras["prompt"][task], "agent_ids") for task in self.tasks}
+        all_t = sorted(int(t) for t in np.asarray(_np(extras["all_t_indices"], np.int64)).tolist()) if "all_t_indices" in extras \
+            else list(self.spec.all_t_indices)
+        agent_trajs = self.init_agent_trajs(policy_agent_ids, batch)
+        return self.rollout_batch(batch, scene_embs, policy_emds, policy_agent_ids, agent_trajs, all_t, mode)
+
+    def _process_rollout(self, extras, scene) -> Dict[str, Any]:
+        """``ProSim._process_rollout`` (:562-595): outputs of the policy agents, in prompt order."""
         spec, eng = self.spec, self.engine
-        scene = scene_from_extras(extras, spec)
-        eng.set_scene(scene)
-        eng.rollout()
         B, N = scene["prompt_mask"].shape
         pslots = scene["_policy_slots"]                          # per scene: observation slot of every policy agent, prompt order
         ids = _g(extras["prompt"]["motion_pred"], "agent_ids")

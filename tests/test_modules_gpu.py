@@ -96,6 +96,37 @@ def test_forward_with_log_replay_agents_vs_fixture(model):
         model(bad, "val")
 
 
+@pytest.mark.parametrize("name", ["small_replay_b2", "small_drag_b2"])
+def test_staged_model_methods_equal_forward(model, name):
+    """encode_scene -> encode_prompt -> generate_policy -> init_agent_trajs -> rollout_batch, the reference's own
+    call sequence (traj_sam.py:59-116, :144-176), gives the values of the one-graph forward() bit for bit --
+    including a batch whose policy agents are a subset of the observed agents."""
+    sname, kw, wseed = FULL_CASES[name]
+    spec = SPECS[sname]
+    scene = synth.make_scene(spec, **kw)
+    batch = make_batch(scene, spec)
+    whole = model(batch, "val")["motion_pred"]
+    scene_embs = model.encode_scene(batch)
+    assert scene_embs["scene_tokens"].shape[0] == scene_embs["scene_type"].numel()
+    n_obs = int(scene["obs_mask"].all(-1).any(-1).sum())
+    assert int((scene_embs["scene_type"] == 1).sum()) == n_obs                 # every observed agent is a token
+    prompt_encs = model.encode_prompt(batch)
+    policy_emds = model.generate_policy(batch, scene_embs, prompt_encs)
+    dm = batch.extras["prompt"]["motion_pred"]["prompt_mask"]
+    assert policy_emds["motion_pred"]["emd"].shape[:2] == dm.shape
+    ids = {"motion_pred": batch.extras["prompt"]["motion_pred"]["agent_ids"]}
+    trajs = model.init_agent_trajs(ids, batch)
+    out = model.rollout_batch(batch, scene_embs, policy_emds, ids, trajs, spec.all_t_indices, "val")["motion_pred"]
+    assert out["pair_names"] == whole["pair_names"]
+    assert torch.equal(out["motion_pred"], whole["motion_pred"]) and torch.equal(out["reconst_pred"], whole["reconst_pred"])
+    for k, r in whole["rollout_trajs"].items():
+        assert torch.equal(out["rollout_trajs"][k]["traj"], r["traj"]) and torch.equal(out["rollout_trajs"][k]["vel"], r["vel"])
+    again = model.decode_batch(model.encode_scene(batch), model.encode_prompt(batch), batch, "val")["motion_pred"]
+    assert torch.equal(again["motion_pred"], whole["motion_pred"])
+    with pytest.raises(ValueError, match="all_t_indices"):
+        model.rollout_batch(batch, scene_embs, policy_emds, ids, model.init_agent_trajs(ids, batch), [0, 10], "val")
+
+
 def test_staged_components_and_stateless_policy(model):
     """scene_encoder(...) -> decoder(...) -> policy(...) with the reference's argument layouts."""
     spec = SMALL_SPEC
@@ -139,3 +170,19 @@ def test_staged_components_and_stateless_policy(model):
     assert torch.equal(out["motion_prob"], torch.ones(A, 1))
     with pytest.raises(AssertionError):
         model.policy(pol_emd, bo, bm, pos, names[:-1], None)
+    # update_scene_emb (attn_fusion.py:238-252, FUSION 'replace'): agents re-encoded from a new observation, map tokens kept
+    rng = np.random.RandomState(3)
+    new_obs = dict(batch["init_obs"])
+    new_obs["input"] = batch["init_obs"]["input"] + torch.from_numpy(rng.uniform(-0.3, 0.3, tuple(batch["init_obs"]["input"].shape)).astype(np.float32))
+    new_obs["position"] = batch["init_obs"]["position"] + 1.5
+    new_obs["heading"] = batch["init_obs"]["heading"] + 0.2
+    se2 = model.scene_encoder.update_scene_emb(se, new_obs, batch["init_obs"]["agent_ids"])
+    Wt = orc.W(w)
+    emb, valid = orc.encode_obs(Wt, spec, torch.nan_to_num(new_obs["input"]), new_obs["mask"])
+    assert torch.equal(se2["scene_tokens"][:Mv], se["scene_tokens"][:Mv])                 # map tokens reused
+    assert err(se2["scene_tokens"][Mv:].numpy(), emb[valid].numpy()) < 1e-4
+    assert err(se2["scene_pos"][Mv:].numpy(), new_obs["position"][valid].numpy()) == 0
+    assert err(se2["scene_tokens"][Mv:].numpy(), se["scene_tokens"][Mv:].numpy()) > 1e-2   # and they did change
+    moved = dict(new_obs, agent_ids=[list(reversed(a)) for a in batch["init_obs"]["agent_ids"]])
+    with pytest.raises(NotImplementedError):
+        model.scene_encoder.update_scene_emb(se2, moved, batch["init_obs"]["agent_ids"])
