@@ -43,6 +43,8 @@ typedef struct ps_config {
   float pol_agent_radius, pol_map_radius;
   int32_t cond_layers;
   int32_t drag_pre_layers, drag_mlp_layers;    /* CONDITION_ENCODER.DRAG_POINTS (default.py:531-533); mlp_layers 0 = no drag-point encoder */
+  int32_t obs_fusion_mlp, obs_attn_update;     /* MODEL.OBS_UPDATE: FUSION == 'mlp', ATTN_UPDATE (default.py:499-501; both 0 in the demo) */
+  float enc_agent_radius, enc_scene_radius;    /* SCENE_ENCODER.ATTN.AGENT_RADIUS / SCENE_RADIUS, used by ATTN_UPDATE only */
   int32_t hist_steps, obs_dim, map_dim;        /* 11, 24, 11 */
   int32_t map_pre_layers, map_mlp_layers, obs_pre_layers, obs_mlp_layers;
   int32_t target_steps, state_dim, motion_k, num_agent_types, prompt_dim;

@@ -297,6 +297,39 @@ def replace_obs(scene: Dict, obs_emb: T, obs_mask: T, obs_pos: T, obs_head: T) -
     return out
 
 
+def fuse_obs_mlp(Wt: W, spec: ModelSpec, scene: Dict, new_emb: T, new_mask: T) -> T:
+    """_autoregressive_obs_fusion (attn_fusion.py:175-203) for an unchanged agent list: every agent's new token is
+    obs_update_mlp(cat(previous token, re-encoded observation)); an agent that had no token at the previous replan
+    contributes zeros (:193-195).  Returns new_emb [B, N, D] with the fused rows."""
+    B, N, D = new_emb.shape
+    old = torch.zeros(B, N, D, dtype=new_emb.dtype)
+    old[scene["obs_mask"]] = scene["scene_tokens"][scene["scene_type"] == 1]
+    fused = mlp(Wt, "scene_encoder.obs_update_mlp", [2 * D, D, D], torch.cat([old, new_emb], dim=-1), True, False)
+    return fused
+
+
+def update_scene_attn(Wt: W, spec: ModelSpec, scene: Dict) -> Dict:
+    """_update_scene_emb_attn (attn_fusion.py:136-173): after the observation update the agents re-attend to each
+    other (radius_graph, no self loops) and to the map (radius), through the scene encoder's own layers."""
+    mt, ot = scene["scene_type"] == 0, scene["scene_type"] == 1
+    m_pos, m_ori, o_pos, o_ori = scene["scene_pos"][mt], scene["scene_ori"][mt], scene["scene_pos"][ot], scene["scene_ori"][ot]
+    m_b, o_b = scene["scene_batch_idx"][mt], scene["scene_batch_idx"][ot]
+    a_dst, a_src = radius_edges(o_pos, o_b, o_pos, o_b, spec.enc_agent_radius, spec.scene_knn, drop_self=True)
+    m_dst, m_src = radius_edges(m_pos, m_b, o_pos, o_b, spec.enc_scene_radius, spec.scene_knn)
+    a_pe = rel_pe(spec, a_src, a_dst, o_ori, o_pos, o_ori, o_pos)
+    m_pe = rel_pe(spec, m_src, m_dst, o_ori, o_pos, m_ori, m_pos)
+    x_a, x_m = scene["scene_tokens"][ot], scene["scene_tokens"][mt]
+    for i in range(spec.scene_layers):
+        x_a = attention_layer(Wt, f"scene_encoder.a2a_attn_layers.{i}", spec, x_a, x_a, a_pe, a_src, a_dst, False)
+        # a non-bipartite layer called with (x_src, x_dst): one LayerNorm serves both sides (attention_layer.py:48-49)
+        x_a = attention_layer(Wt, f"scene_encoder.s2s_attn_layers.{i}", spec, x_m, x_a, m_pe, m_src, m_dst, False)
+    out = dict(scene)
+    tok = scene["scene_tokens"].clone()
+    tok[ot] = x_a
+    out["scene_tokens"] = tok
+    return out
+
+
 # --------------------------------------------------------------------------- generator (decoder + conditions)
 
 def prompt_encode(Wt: W, spec: ModelSpec, prompt: T) -> T:
@@ -553,7 +586,11 @@ def rollout(w: Dict[str, np.ndarray], spec: ModelSpec, scene_in: Dict, dtype=tor
             f_pos = torch.where(prompt_mask[..., None], a_pos, l_pos)
             f_head = torch.where(prompt_mask, a_head[..., 0], l_head)
             new_emb, new_mask = encode_obs(Wt, spec, f_in, f_mk)
+            if spec.obs_fusion == "mlp":
+                new_emb = fuse_obs_mlp(Wt, spec, scene, new_emb, new_mask)
             scene = replace_obs(scene, new_emb, new_mask, f_pos, f_head)
+            if spec.obs_attn_update:
+                scene = update_scene_attn(Wt, spec, scene)
             if collect:
                 trace[f"obs_in_{ti}"] = f_in
         # decode_output -> policy (traj_sam.py:178-202, 441-525)

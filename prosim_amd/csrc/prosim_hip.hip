@@ -83,6 +83,11 @@ struct ps_engine {
   HeadW head{};
   DevBuf<float> io_q, io_qt, io_cq, io_ar, io_av, io_l, io_s, io_g;   // split path: per-destination vectors (EdgeIO)
   CondW cond{};
+  Mlp3W mlp_obs_fuse{};                     // scene_encoder.obs_update_mlp (OBS_UPDATE.FUSION 'mlp')
+  EdgeSet e_ua, e_um;                       // OBS_UPDATE.ATTN_UPDATE: agents <- agents (no self loops), agents <- map
+  DevBuf<float> d_obs_new, d_kv_um;         // re-encoded observation rows; k|v of the map tokens for the s2s layers
+  DevBuf<_Float16> d_kh_um;
+  int step_upd = 0;
   const float* div32 = nullptr;
   // ---- scene
   bool have_scene = false, encoded = false, generated = false, reset = false;
@@ -483,6 +488,7 @@ extern "C" int ps_create(const ps_config* cfg, int32_t n_tensors, const char* co
     build_pointnet(b, "condition_transformers.policy_decoder.condition_encoders.drag_point.pointnet_encoder", 2,
                    cfg->drag_pre_layers, cfg->drag_mlp_layers, e->pn_drag);
   build_mlp3(b, "prompt_encoder.motion_pred.state_encoder", {cfg->prompt_dim, D, D}, false, e->mlp_prompt);
+  if (cfg->obs_fusion_mlp) build_mlp3(b, "scene_encoder.obs_update_mlp", {2 * D, D, D}, false, e->mlp_obs_fuse);
   const std::string pa = "policy.act_decoder";
   build_mlp3(b, pa + ".pred_mlp", {D, D, D / 2, 2}, false, e->mlp_pred);
   build_mlp3(b, pa + ".motion_head", {D, D, D / 2, cfg->target_steps * cfg->state_dim}, false, e->head.motion);
@@ -620,6 +626,7 @@ extern "C" void ps_destroy(ps_engine* e) {
   }
   e->d_steps.release(); e->d_ent_off.release(); e->d_ent_type.release(); e->d_ent_val.release();
   e->d_drag_in.release(); e->d_drag_emd.release(); e->d_drag_mask.release();
+  e->d_obs_new.release(); e->d_kv_um.release(); e->d_kh_um.release();
   e->io_q.release(); e->io_qt.release(); e->io_cq.release(); e->io_ar.release(); e->io_av.release(); e->io_l.release();
   e->io_s.release(); e->io_g.release();
   drop_graph(e);
@@ -784,6 +791,13 @@ extern "C" int ps_set_scene(ps_engine* e, int32_t B, int32_t M, int32_t P, int32
   // index is not among the first cap+1 keeps all cap+1 of them
   int d_p2p = mn(c.dec_max_neigh + 1, std::max(1, e->maxA_scene - 1)), d_s2p = mn(c.dec_max_neigh, tokS);
   int d_a2p = mn(c.pol_max_neigh, e->maxA_scene), d_m2p = mn(c.pol_max_neigh, std::max(1, e->maxM_scene));
+  if (c.obs_fusion_mlp && e->d_obs_new.ensure((size_t)A * D)) return fail(PS_E_HIP, "device allocation failed");
+  if (c.obs_attn_update) {
+    const int d_ua = mn(c.scene_knn + 1, std::max(1, e->maxA_scene - 1)), d_um = mn(c.scene_knn, std::max(1, e->maxM_scene));
+    if (edge_alloc(e->e_ua, A, (size_t)A * d_ua, d_ua) || edge_alloc(e->e_um, A, (size_t)A * d_um, d_um) ||
+        e->d_kv_um.ensure((size_t)c.scene_layers * std::max(Mv, 1) * 256) || e->d_kh_um.ensure((size_t)c.scene_layers * std::max(Mv, 1) * 256))
+      return fail(PS_E_HIP, "edge allocation failed");
+  }
   if (edge_alloc(e->e_a2a, A, (size_t)A * d_a2a, d_a2a) || edge_alloc(e->e_s2s, Mv + A, (size_t)(Mv + A) * d_s2s, d_s2s) ||
       edge_alloc(e->e_p2p, A, (size_t)A * d_p2p, d_p2p) || edge_alloc(e->e_s2p, A, (size_t)A * d_s2p, d_s2p) ||
       edge_alloc(e->e_a2p, A, (size_t)A * d_a2p, d_a2p) || edge_alloc(e->e_m2p, A, (size_t)A * d_m2p, d_m2p) ||
@@ -853,6 +867,12 @@ extern "C" int ps_set_scene(ps_engine* e, int32_t B, int32_t M, int32_t P, int32
     push(e->a2p[i], e->d_kv_a2p.p + (size_t)i * A * 256 - (size_t)Mv * 256, e->d_kh_a2p.p + (size_t)i * A * 256 - (size_t)Mv * 256, e->e_a2p);
     push(e->m2p[i], e->d_kv_m2p.p + (size_t)i * Mv * 256, e->d_kh_m2p.p + (size_t)i * Mv * 256, e->e_m2p);
   }
+  e->step_upd = (int)e->h_steps.size();
+  if (c.obs_attn_update)
+    for (int i = 0; i < c.scene_layers; ++i) {   // _update_scene_emb_attn: a2a over the agents, then the s2s layer with (map -> agents) edges
+      push(e->a2a[i], e->d_kv.p, e->d_kh.p, e->e_ua);
+      push(e->s2s[i], e->d_kv_um.p + (size_t)i * Mv * 256, e->d_kh_um.p + (size_t)i * Mv * 256, e->e_um);
+    }
   if (upload(e->d_steps, e->h_steps.data(), e->h_steps.size(), st)) return fail(PS_E_HIP, "step table upload failed");
   // no conditions until ps_set_conditions
   e->have_cond = false;
@@ -1349,6 +1369,8 @@ extern "C" int ps_generate_policy(ps_engine* e) {
                      e->d_reconst.p, 2, c.ln_eps);
   // k|v of the map tokens for all m2p layers: map tokens never change during the rollout
   launch_kv(e, e->d_tok.p, Mv, e->L_m2p, c.pol_layers, e->d_kv_m2p.p, e->d_kh_m2p.p, (size_t)Mv * 256);
+  if (c.obs_attn_update)   // ... and for the s2s layers that the per-replan observation update re-runs (map -> agents)
+    launch_kv(e, e->d_tok.p, Mv, e->L_s2s, c.scene_layers, e->d_kv_um.p, e->d_kh_um.p, (size_t)Mv * 256);
   HIPCHK(hipGetLastError());
   e->generated = true;
   return PS_OK;
@@ -1401,10 +1423,30 @@ extern "C" int ps_policy_step(ps_engine* e, int32_t t_idx) {
   if (t_idx > 0) {
     // update_scene_emb / _replace_old_obs (attn_fusion.py:205-250): re-encode agents, swap tokens + poses
     // (k_step_env already moved the agents' token poses)
+    float* enc_out = c.obs_fusion_mlp ? e->d_obs_new.p : atok;
     if (e->all_policy)
-      launch_pointnet(e, e->pn_obs, e->d_obs_in.p, (const uint8_t*)nullptr, (const int*)nullptr, A, c.hist_steps, -1, atok);
+      launch_pointnet(e, e->pn_obs, e->d_obs_in.p, (const uint8_t*)nullptr, (const int*)nullptr, A, c.hist_steps, -1, enc_out);
     else   // logged observations carry their own validity
-      launch_pointnet(e, e->pn_obs, e->d_obs_in.p, (const uint8_t*)e->d_obs_in_mask.p, (const int*)nullptr, A, c.hist_steps, c.obs_dim, atok);
+      launch_pointnet(e, e->pn_obs, e->d_obs_in.p, (const uint8_t*)e->d_obs_in_mask.p, (const int*)nullptr, A, c.hist_steps, c.obs_dim, enc_out);
+    const int* live = e->all_policy ? nullptr : (const int*)e->d_tok_live.p;
+    if (c.obs_fusion_mlp)   // FUSION 'mlp' (attn_fusion.py:175-203): token = obs_update_mlp(cat(previous token, new observation))
+      hipLaunchKernelGGL(k_obs_fuse, dim3(A), dim3(128), 0, st, e->mlp_obs_fuse, atok, (const float*)e->d_obs_new.p, live, c.ln_eps);
+    if (c.obs_attn_update) {
+      // ATTN_UPDATE (attn_fusion.py:136-173): the agents re-attend to each other (radius_graph, no self loops) and to
+      // the map (radius) through the scene encoder's own a2a / s2s layers, at their new poses
+      const float* qpos = e->d_tok_pos.p + 2 * (size_t)Mv;
+      const float* qori = e->d_tok_ori.p + Mv;
+      const RadArgs ru[2] = {{&e->e_ua, e->d_r_agent.p, nullptr, c.enc_agent_radius, c.scene_knn, Mv, live, Mv},
+                             {&e->e_um, e->d_r_map.p, nullptr, c.enc_scene_radius, c.scene_knn, -1}};
+      launch_radius(e, ru, 2, qpos, e->d_tok_scene.p + Mv, A, e->d_tok_ori.p, qori);
+      const int mdu = std::max(e->e_ua.maxdeg, e->e_um.maxdeg);
+      for (int i = 0; i < c.scene_layers; ++i) {
+        launch_kv(e, atok, A, e->L_a2a + i, 1, e->d_kv.p + (size_t)Mv * 256, e->d_kh.p + (size_t)Mv * 256, 0);
+        if (launch_chain(e, atok, A, e->step_upd + 2 * i, 2, mdu)) return PS_E_HIP;
+      }
+      if (live && c.obs_fusion_mlp)   // agents outside the log are no tokens: their rows stay zero for the next fusion
+        hipLaunchKernelGGL(k_zero_dead_rows, dim3((A * D + 255) / 256), dim3(256), 0, st, atok, live, A);
+    }
   }
   // policy.forward (policy/base.py:19 -> temporal_ar.py:75 -> act_decoder.py:239-283)
   launch_kv(e, atok, A, e->L_a2p, c.pol_layers, e->d_kv_a2p.p, e->d_kh_a2p.p, (size_t)A * 256);

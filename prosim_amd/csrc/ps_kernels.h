@@ -644,6 +644,29 @@ __global__ __launch_bounds__(128) void k_mlp_rows(Mlp3W m, const float* __restri
   for (int i = threadIdx.x; i < m.dims[m.n]; i += blockDim.x) out[(size_t)blockIdx.x * out_stride + i] = a[i];
 }
 
+// _autoregressive_obs_fusion (attn_fusion.py:175-203, MODEL.OBS_UPDATE.FUSION 'mlp'): the agent token of this replan =
+// obs_update_mlp(cat(token of the previous replan, re-encoded observation)).  An agent that is no scene token at
+// this replan (a log-replay agent outside the log: live == 0) keeps a ZERO row, which is also what the reference
+// feeds as "previous token" when the agent comes back (:193-195).  One WG (128 threads) per agent.
+__global__ __launch_bounds__(128) void k_obs_fuse(Mlp3W m, float* __restrict__ tok, const float* __restrict__ new_emb,
+                                                 const int* __restrict__ live, float eps) {
+  __shared__ float a[256], b[256];
+  const int row = blockIdx.x, tid = threadIdx.x;
+  if (live && !live[row]) {
+    tok[(size_t)row * 128 + tid] = 0.f;
+    return;
+  }
+  a[tid] = tok[(size_t)row * 128 + tid];
+  a[128 + tid] = new_emb[(size_t)row * 128 + tid];
+  __syncthreads();
+  mlp3_rows1(m, a, b, eps);
+  tok[(size_t)row * 128 + tid] = a[tid];
+}
+__global__ void k_zero_dead_rows(float* __restrict__ tok, const int* __restrict__ live, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n * 128 && !live[i >> 7]) tok[i] = 0.f;
+}
+
 // Condition encoders + mean pooling over the condition entries attached to one agent
 // (condition_encoders.py:21-51, :76-141; condition_attns.py:114-188 for self-loop edges), then
 // r = pooled + relPE(self-loop) and the affine-free LayerNorm.  One WG (128 threads) per

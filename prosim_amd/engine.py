@@ -28,6 +28,8 @@ class PsConfig(C.Structure):
         ("pol_agent_radius", C.c_float), ("pol_map_radius", C.c_float),
         ("cond_layers", C.c_int32),
         ("drag_pre_layers", C.c_int32), ("drag_mlp_layers", C.c_int32),
+        ("obs_fusion_mlp", C.c_int32), ("obs_attn_update", C.c_int32),
+        ("enc_agent_radius", C.c_float), ("enc_scene_radius", C.c_float),
         ("hist_steps", C.c_int32), ("obs_dim", C.c_int32), ("map_dim", C.c_int32),
         ("map_pre_layers", C.c_int32), ("map_mlp_layers", C.c_int32),
         ("obs_pre_layers", C.c_int32), ("obs_mlp_layers", C.c_int32),
@@ -128,12 +130,16 @@ class Engine:
     def __init__(self, spec: ModelSpec, weights: Dict[str, np.ndarray], device: int = 0):
         self.lib = load_library()
         self.spec = spec
+        if spec.obs_fusion not in ("replace", "mlp"):
+            raise ValueError(f"MODEL.OBS_UPDATE.FUSION must be 'replace' or 'mlp', got {spec.obs_fusion!r}")
         cfg = PsConfig(hidden=spec.hidden, heads=spec.heads, head_dim=spec.head_dim, scene_layers=spec.scene_layers,
                        scene_knn=spec.scene_knn, agent_knn=spec.agent_knn, dec_layers=spec.dec_layers,
                        dec_max_neigh=spec.dec_max_neigh, dec_prompt_radius=spec.dec_prompt_radius,
                        dec_scene_radius=spec.dec_scene_radius, pol_layers=spec.pol_layers, pol_max_neigh=spec.pol_max_neigh,
                        pol_agent_radius=spec.pol_agent_radius, pol_map_radius=spec.pol_map_radius, cond_layers=spec.cond_layers,
                        drag_pre_layers=spec.drag_pre_layers, drag_mlp_layers=spec.drag_mlp_layers,
+                       obs_fusion_mlp=int(spec.obs_fusion == "mlp"), obs_attn_update=int(bool(spec.obs_attn_update)),
+                       enc_agent_radius=spec.enc_agent_radius, enc_scene_radius=spec.enc_scene_radius,
                        hist_steps=spec.hist_steps, obs_dim=spec.obs_dim, map_dim=spec.map_dim,
                        map_pre_layers=spec.map_pre_layers, map_mlp_layers=spec.map_mlp_layers,
                        obs_pre_layers=spec.obs_pre_layers, obs_mlp_layers=spec.obs_mlp_layers,

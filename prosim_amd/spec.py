@@ -36,6 +36,14 @@ class ModelSpec:
     # MODEL.SCENE_ENCODER.ATTN (no_text.yaml:226-232)
     scene_layers: int = 6
     scene_knn: int = 32                # MAX_NUM_NEIGH; agents use min(4*k, 100) (attn_fusion.py:107)
+    # MODEL.OBS_UPDATE (default.py:499-501; no_text.yaml:213-215 keeps the defaults): how update_scene_emb folds the
+    # re-encoded observation into the agent tokens at replans 1.. ('replace' | 'mlp'), and whether the agents then
+    # re-attend to each other and to the map (radii: SCENE_ENCODER.ATTN.AGENT_RADIUS / SCENE_RADIUS, default.py:479-480;
+    # neighbour cap = scene_knn)
+    obs_fusion: str = "replace"
+    obs_attn_update: bool = False
+    enc_agent_radius: float = 100.0
+    enc_scene_radius: float = 50.0
     # MODEL.DECODER.ATTN (no_text.yaml:243-251)
     dec_layers: int = 6
     dec_prompt_radius: float = 300.0

@@ -109,6 +109,8 @@ def param_shapes(spec: ModelSpec) -> "OrderedDict[str, Tuple[int, ...]]":
     for i in range(spec.scene_layers):
         _attn_shapes(out, f"scene_encoder.a2a_attn_layers.{i}", d, hd, False)
         _attn_shapes(out, f"scene_encoder.s2s_attn_layers.{i}", d, hd, False)
+    if spec.obs_fusion == "mlp":    # attn_fusion.py:18-19
+        _mlp_shapes(out, OBS_UPDATE_MLP, [2 * d, d, d], True, False)
     # prompt_encoder/base.py:23-34
     _mlp_shapes(out, "prompt_encoder.motion_pred.state_encoder", [spec.prompt_dim, d, d], True, False)
     for i in range(spec.dec_layers):
@@ -141,19 +143,25 @@ def param_shapes(spec: ModelSpec) -> "OrderedDict[str, Tuple[int, ...]]":
 
 
 DRAG_ENCODER = "condition_encoders.drag_point.pointnet_encoder"
+OBS_UPDATE_MLP = "scene_encoder.obs_update_mlp"
+_LATE = (DRAG_ENCODER, OBS_UPDATE_MLP)   # tensor groups added after the first fixtures: each draws from its own generator
 
 
 def init_weights(spec: ModelSpec, seed: int = 0) -> Dict[str, np.ndarray]:
-    """Seeded initialiser (torch CPU generator; identical on every box with this image).  The drag-point encoder
-    draws from its own generator, after everything else, so the other tensors keep the values older fixtures saw."""
+    """Seeded initialiser (torch CPU generator; identical on every box with this image).  The drag-point encoder and
+    the observation-update MLP draw from their own generators, so the other tensors keep the values older fixtures
+    saw and are the same for every variant of a spec."""
     g_main = torch.Generator(device="cpu")
     g_main.manual_seed(1_000_003 * (seed + 1))
-    g_drag = torch.Generator(device="cpu")
-    g_drag.manual_seed(7_000_003 * (seed + 1) + 11)
+    g_late = []
+    for i in range(len(_LATE)):
+        g_late.append(torch.Generator(device="cpu"))
+        g_late[i].manual_seed(7_000_003 * (seed + 1) + 11 + 1000 * i)
+    late = lambda n: next((i for i, key in enumerate(_LATE) if key in n), -1)
     shapes = param_shapes(spec)
     w: Dict[str, np.ndarray] = {}
-    for name in sorted(shapes, key=lambda n: (DRAG_ENCODER in n, n)):
-        g = g_drag if DRAG_ENCODER in name else g_main
+    for name in sorted(shapes, key=lambda n: (late(n), n)):
+        g = g_late[late(name)] if late(name) >= 0 else g_main
         shp = shapes[name]
         is_ln = len(shp) == 1 and name.endswith(".weight") and (
             "norm" in name or ".MLP.1." in name or _is_mlp_ln(name, shapes))

@@ -56,13 +56,21 @@ FULL_CASES = {
     "small_replay_b2": ("small", dict(n_agents=16, n_polylines=128, batch=2, seed=5, goal=True, ragged=True, replay=0.4), 0),
     # all three condition types of the demo config (PROMPT.CONDITION.TYPES): goal, v_action_tag, drag_point
     "small_drag_b2": ("small", dict(n_agents=16, n_polylines=128, batch=2, seed=6, goal=True, tags=True, drag=True, ragged=True), 0),
+    # MODEL.OBS_UPDATE variants (attn_fusion.py:136-203): observation tokens fused by obs_update_mlp instead of
+    # replaced; agents re-attend to each other and to the map after every update.  With log-replay agents that
+    # drop out of the log (their previous token counts as zeros when they come back).
+    "small_fuse_mlp_b2": ("small_mlp", dict(n_agents=16, n_polylines=128, batch=2, seed=7, goal=True, ragged=True, replay=0.4), 0),
+    "small_attn_update_b2": ("small_mlp_attn", dict(n_agents=16, n_polylines=128, batch=2, seed=8, ragged=True, replay=0.3), 0),
 }
-SPECS = {"small": SMALL_SPEC, "demo": DEMO_SPEC}
+SPECS = {"small": SMALL_SPEC, "demo": DEMO_SPEC, "small_mlp": SMALL_SPEC.replace(obs_fusion="mlp"),
+         "small_mlp_attn": SMALL_SPEC.replace(obs_fusion="mlp", obs_attn_update=True)}
 
 
 def ref_overrides(spec: ModelSpec):
     return ["MODEL.SCENE_ENCODER.ATTN.NUM_LAYER", spec.scene_layers, "MODEL.DECODER.ATTN.NUM_LAYER", spec.dec_layers,
-            "MODEL.POLICY.ACT_DECODER.ATTN.NUM_LAYER", spec.pol_layers, "MODEL.CONDITION_TRANSFORMER.NLAYER", spec.cond_layers]
+            "MODEL.POLICY.ACT_DECODER.ATTN.NUM_LAYER", spec.pol_layers, "MODEL.CONDITION_TRANSFORMER.NLAYER", spec.cond_layers,
+            "MODEL.OBS_UPDATE.FUSION", spec.obs_fusion, "MODEL.OBS_UPDATE.ATTN_UPDATE", spec.obs_attn_update,
+            "MODEL.SCENE_ENCODER.ATTN.AGENT_RADIUS", spec.enc_agent_radius, "MODEL.SCENE_ENCODER.ATTN.SCENE_RADIUS", spec.enc_scene_radius]
 
 
 def run_reference(spec, w, scene):

@@ -457,3 +457,38 @@ def test_log_replay_agents_vs_oracle(demo_engine):
     d = np.abs(eng.padded("traj") - o64["traj"].numpy())[scene["prompt_mask"].astype(bool)].reshape(A, -1).max(1)
     assert d.max() < 3 * floor + TOL and (d < TOL).mean() >= 0.8, (floor, d)
     assert np.abs(eng.padded("traj")[~scene["prompt_mask"].astype(bool)]).max() == 0      # log-replay slots stay empty
+
+
+@pytest.mark.parametrize("fusion,attn", [("mlp", False), ("replace", True), ("mlp", True)])
+def test_obs_update_variants_vs_oracle(fusion, attn):
+    """MODEL.OBS_UPDATE (attn_fusion.py:136-203, default.py:499-501), every agent policy-controlled: FUSION 'mlp' folds
+    the re-encoded observation into the previous token, ATTN_UPDATE re-runs the encoder's a2a / s2s(map -> agent)
+    layers at the new poses.  Replan 1 is the first step that sees the update: open-loop bar there, closed-loop bar
+    relative to the fp32 floor on the trajectories."""
+    from prosim_amd.engine import Engine
+    spec = SMALL_SPEC.replace(obs_fusion=fusion, obs_attn_update=attn)
+    w = weights.init_weights(spec, 0)
+    base = weights.init_weights(SMALL_SPEC, 0)
+    assert all(np.array_equal(w[k], base[k]) for k in base)                   # the variants only ADD tensors
+    scene = synth.make_scene(spec, 24, 96, batch=2, seed=41, goal=True, ragged=True, clustered=True)
+    with torch.no_grad():
+        o64 = orc.rollout(w, spec, scene, dtype=torch.float64)
+        o32 = orc.rollout(w, spec, scene)
+        plain = orc.rollout(w, SMALL_SPEC, scene, dtype=torch.float64)
+    eng = Engine(spec, w)
+    try:
+        eng.set_scene(scene)
+        eng.rollout()
+        A = eng.num_agents
+        mp = eng.get("motion_pred")
+        assert err(mp[0], o64["motion_pred"][:A].numpy()) < TOL
+        assert err(mp[1], o64["motion_pred"][A:2 * A].numpy()) < 2 * TOL
+        assert err(o64["motion_pred"][A:2 * A].numpy(), plain["motion_pred"][A:2 * A].numpy()) > 1e-2   # the variant matters
+        floor = float(np.abs(o32["traj"].numpy() - o64["traj"].numpy()).max())
+        pm = scene["prompt_mask"].astype(bool)
+        d = np.abs(eng.padded("traj") - o64["traj"].numpy())[pm].reshape(A, -1).max(1)
+        assert d.max() < 3 * floor + TOL, (floor, d.max())
+    finally:
+        eng.close()
+    with pytest.raises(ValueError, match="FUSION"):
+        Engine(SMALL_SPEC.replace(obs_fusion="sum"), base)
