@@ -1535,6 +1535,8 @@ extern "C" int ps_update_obs(ps_engine* e, const float* obs_input, const uint8_t
                              const float* obs_head) {
   if (!e || !e->have_scene || !e->encoded) return fail(PS_E_STATE, "ps_update_obs before ps_encode_scene");
   if (!obs_input || !obs_mask || !obs_pos || !obs_head) return fail(PS_E_ARG, "ps_update_obs: null argument");
+  if (e->cfg.obs_fusion_mlp || e->cfg.obs_attn_update)
+    return fail(PS_E_ARG, "ps_update_obs implements OBS_UPDATE {FUSION: replace, ATTN_UPDATE: False}; the variants run inside ps_policy_step");
   HIPCHK(hipSetDevice(e->cfg.device));
   const ps_config& c = e->cfg;
   const int A = e->A, Mv = e->Mv;
