@@ -1123,8 +1123,14 @@ int launch_split_layer(ps_engine* e, float* x, int Nd, const ChainStep* stp, int
   return hipGetLastError() == hipSuccess ? 0 : fail(PS_E_HIP, "split layer launch failed");
 }
 
+// which launches use the XCD-aware mapping (PS_XCD overrides for experiments: bit0 policy, bit1 a2a, bit2 generator)
+static bool xcd_on(int bit, bool dflt) {
+  static const int env = getenv("PS_XCD") ? atoi(getenv("PS_XCD")) : -1;
+  return env < 0 ? dflt : ((env >> bit) & 1) != 0;
+}
 int launch_chain(ps_engine* e, float* x, int Nd, int step0, int nsteps, int maxdeg, bool timed = false,
-                 const ChainStep* steps_override = nullptr, int force_T = 0, int kr_override = 0, const float* x_in = nullptr) {
+                 const ChainStep* steps_override = nullptr, int force_T = 0, int kr_override = 0, const float* x_in = nullptr,
+                 bool xcd = false) {
   if (!x_in) x_in = x;   // in place unless the caller has the input rows elsewhere (saves a copy launch)
   // rel-PE width of the launch's steps: condition steps (and the test hook's arbitrary rows) use all 128 columns
   const int steps_host_kr = kr_override ? kr_override : (steps_override ? 3 : e->h_steps[step0].kr);
@@ -1141,7 +1147,8 @@ int launch_chain(ps_engine* e, float* x, int Nd, int step0, int nsteps, int maxd
   if (force_T) T = force_T;
   if (attn_lds_floats<1>(maxdeg) * sizeof(float) > 150 * 1024) return fail(PS_E_ARG, "degree bound too large for LDS");
   const float eps = e->cfg.ln_eps;
-  static const int flags = getenv("PS_CHAIN_FLAGS") ? atoi(getenv("PS_CHAIN_FLAGS")) : 0;  // ablation only
+  static const int env_flags = getenv("PS_CHAIN_FLAGS") ? atoi(getenv("PS_CHAIN_FLAGS")) : 0;  // ablation only
+  const int flags = env_flags | (xcd ? 1024 : 0);   // 1024: XCD-aware block -> row mapping (ps_device.h xcd_block)
   // phase clocks (tools/gpu_phase.py): PS_CHAIN_PROF=1 makes the timed policy launches accumulate cycles per phase
   static const bool want_prof = getenv("PS_CHAIN_PROF") != nullptr;
   static unsigned long long* d_prof = nullptr;
@@ -1299,7 +1306,7 @@ extern "C" int ps_encode_scene(ps_engine* e) {
   const bool split_s2s = !no_split && Mv + A >= 2048 && e->e_s2s.maxdeg <= ES_MAXDEG;
   for (int i = 0; i < c.scene_layers; ++i) {
     launch_kv(e, tok + (size_t)Mv * D, A, e->L_a2a + i, 1, e->d_kv.p + (size_t)Mv * 256, e->d_kh.p + (size_t)Mv * 256, 0);
-    if (launch_chain(e, tok + (size_t)Mv * D, A, e->step_a2a + i, 1, e->e_a2a.maxdeg)) return PS_E_HIP;
+    if (launch_chain(e, tok + (size_t)Mv * D, A, e->step_a2a + i, 1, e->e_a2a.maxdeg, false, nullptr, 0, 0, nullptr, xcd_on(1, false))) return PS_E_HIP;
     if (split_s2s) {
       // split layer: node work as 16-row MFMA GEMMs (k_node; its PRE half also makes the rows'
       // k | v, they are this self-attention layer's sources), the 32-neighbour edge phase one wave per token
@@ -1347,7 +1354,7 @@ extern "C" int ps_generate_policy(ps_engine* e) {
   for (int i = 0; i < c.dec_layers; ++i) {
     // p2p edges carry GLOBAL agent rows (Mv + j): project into rows Mv.. of the shared kv buffer
     launch_kv(e, e->d_xp.p, A, e->L_p2p + i, 1, e->d_kv.p + (size_t)Mv * 256, e->d_kh.p + (size_t)Mv * 256, 0);
-    if (launch_chain(e, e->d_xp.p, A, e->step_dec + 2 * i, 2, md)) return PS_E_HIP;
+    if (launch_chain(e, e->d_xp.p, A, e->step_dec + 2 * i, 2, md, false, nullptr, 0, 0, nullptr, xcd_on(2, false))) return PS_E_HIP;
   }
   HIPCHK(hipMemcpyAsync(e->d_emd.p, e->d_xp.p, sizeof(float) * (size_t)A * D, hipMemcpyDeviceToDevice, st));
   // condition transformer at 'policy_decoder' (traj_sam.py:129-137)
@@ -1460,7 +1467,7 @@ extern "C" int ps_policy_step(ps_engine* e, int32_t t_idx) {
   }
   const int md = std::max(e->e_a2p.maxdeg, e->e_m2p.maxdeg);
   // the policy tokens enter every replan unchanged (d_emd); the fused features leave to d_fused
-  if (launch_chain(e, e->d_fused.p, A, e->step_pol, 2 * c.pol_layers, md, true, nullptr, 0, 0, e->d_emd.p)) return PS_E_HIP;
+  if (launch_chain(e, e->d_fused.p, A, e->step_pol, 2 * c.pol_layers, md, true, nullptr, 0, 0, e->d_emd.p, xcd_on(0, true))) return PS_E_HIP;
   // _compute_traj + step_agent_traj
   hipLaunchKernelGGL(k_policy_head_mfma, dim3((A + 15) / 16), dim3(256), 0, st, e->head, (const float*)e->d_fused.p,
                      (const int*)e->d_agent_type.p, A, c.motion_k, c.target_steps, c.state_dim, e->d_motion.p + (size_t)t_idx * A * c.target_steps * c.state_dim,

@@ -166,15 +166,19 @@ __device__ __forceinline__ void fold_kgroups(float (&acc)[T][4]) {
 // BIG: compiled for ONE workgroup per CU with the whole register file (512 per lane): weight chunks and edge
 // rows are software-prefetched into second register sets.  !BIG (T >= 2 default): two workgroups per CU, <= 256
 // registers, the co-resident workgroup hides latency instead.
-// POLICY: no effect on the code -- the per-replan policy launch (12 layers) gets its own symbol, so a kernel trace
-// lists the dominant launch apart from the 1-2-layer launches of the same build (profiles/, bench.py's roofline).
+// POLICY: the per-replan policy launch (12 layers) gets its own symbol, so a kernel trace lists the dominant launch
+// apart from the 1-2-layer launches of the same build (profiles/, bench.py's roofline) -- and the XCD-aware block ->
+// row mapping (xcd_block): the rows of one scene share an XCD, whose L2 then holds that scene's a2p / m2p k|v rows
+// (measured at 8 scenes x 128 agents: 546 -> 525 us).  The generator's launches are left on the plain mapping: with
+// 512-neighbour s2p rows the same mapping costs 6 % (every workgroup of an XCD gathers the same rows at once).
 template <int T, int NW = 4, int KR = 3, bool BIG = (T == 1), bool POLICY = false>
 __global__ __launch_bounds__(64 * NW, ((!BIG && NW == 4) ? 2 : 1)) void k_attn_chain(float* __restrict__ x, const float* __restrict__ x_in, int Nd,
                                                      const ChainStep* __restrict__ steps, int nsteps, int maxdeg, float eps, int flags,
                                                      unsigned long long* __restrict__ prof) {
   // flags: ablation switches of tools/gpu_ablate.py / gpu_profile.sh (0 in every product launch; results are wrong
   // when set): 1 no edges, 8 skip the aggregation pass, 16 skip the score pass, 32 read the rel-PE images from a
-  // cache-resident region, 128 no k staging.
+  // cache-resident region, 128 no k staging; 512 plain blockIdx -> row mapping in the policy launch
+  // instead of the XCD-aware one (results stay correct).
   // phase clocks (PS_CHAIN_PROF=1; prof == nullptr in every product launch): thread 0 of each
   // workgroup charges the core-clock cycles since the previous mark to phase i
   long long tprev = prof ? clock64() : 0;
@@ -219,7 +223,7 @@ __global__ __launch_bounds__(64 * NW, ((!BIG && NW == 4) ? 2 : 1)) void k_attn_c
   const int c8_o = lane_o % LQ, kgl_o = lane_o / LQ;
   const int ncol_o = wave_o * CW + 4 * c8_o;
   const size_t woff_o = (size_t)(kgl_o * RK) * 128 + ncol_o;
-  const int row0 = blockIdx.x * T;
+  const int row0 = xcd_block(blockIdx.x, gridDim.x, !(flags & 1024) || (flags & 512)) * T;
   // two register sets, one chunk in flight behind the one being multiplied.  (Three sets / two
   // chunks in flight measured no faster -- a CU's 4 waves already pull ~100 GB/s, the per-CU
   // L2->register ceiling measured by ps_test_stream -- and spill at T = 4.)

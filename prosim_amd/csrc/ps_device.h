@@ -107,6 +107,17 @@ __device__ __forceinline__ void ln_row_wave(const float* __restrict__ x, float* 
   y[lane + 64] = y1;
 }
 
+// Workgroup b runs on XCD b % 8 (observed placement, used for speed only: MI355X_MICROARCH.md "Workgroup dispatch").
+// Destination rows are ordered by scene, and the rows of one scene gather the k|v rows of the SAME source tokens, so
+// consecutive LOGICAL blocks should share an XCD (one scene's k|v = 1.5-3 MB per layer sits in that XCD's 4 MB L2
+// instead of every L2 seeing every scene).  Physical block b -> logical block: XCD x takes the x-th contiguous
+// eighth of the grid; a tail of G % 8 blocks keeps its index.
+__device__ __forceinline__ int xcd_block(int b, int G, int off) {
+  const int per = G >> 3;
+  if (off || b >= (per << 3)) return b;
+  return (b & 7) * per + (b >> 3);
+}
+
 // Small-N GEMV (N not a multiple of 128): one thread per output, torch layout W[N][K].
 template <int T>
 __device__ __forceinline__ void gemv_small(const float* x, int xs, int K, const float* __restrict__ W, int N,
