@@ -1141,9 +1141,14 @@ int launch_chain(ps_engine* e, float* x, int Nd, int step0, int nsteps, int maxd
   // largest T that still leaves >= 2 workgroups per CU.  Measured on the 1024-agent policy launch: T=2 (512
   // WGs) 541 us, T=4 (256 WGs) 770 us, 4 rows on one 8-wave workgroup per CU (code 84) 733 us; the one-workgroup-
   // per-CU builds with register prefetch (BIG) at T=2 / T=4: 1005 / 879 us (they spill even with 512 registers).
-  int T = Nd >= 2048 ? 4 : (Nd >= 512 ? 2 : 1);
+  // Below 512 rows (a single 128-agent scene: fewer workgroups than CUs) a row gets a workgroup of EIGHT waves
+  // (code 18: two waves per SIMD, 256 registers each, late weight prefetch) instead of four waves with the whole
+  // register file and early prefetch (code 1): 292 -> 280 us per 128-agent policy launch.
+  int T = Nd >= 2048 ? 4 : (Nd >= 512 ? 2 : 18);
   static const int env_T = getenv("PS_CHAIN_T") ? atoi(getenv("PS_CHAIN_T")) : 0;   // experiments only
   if (env_T && Nd >= 512) T = env_T;
+  static const int env_T1 = getenv("PS_CHAIN_T1") ? atoi(getenv("PS_CHAIN_T1")) : 0;   // experiments only
+  if (env_T1 && Nd < 512) T = env_T1;
   if (force_T) T = force_T;
   if (attn_lds_floats<1>(maxdeg) * sizeof(float) > 150 * 1024) return fail(PS_E_ARG, "degree bound too large for LDS");
   const float eps = e->cfg.ln_eps;
@@ -1159,22 +1164,26 @@ int launch_chain(ps_engine* e, float* x, int Nd, int step0, int nsteps, int maxd
     prof = d_prof;
   }
   if (timed && e->time_chain) (void)hipEventRecord(e->ev0, st);
+  const size_t lds18 = attn_lds_floats<1, 8>(maxdeg) * sizeof(float);
   const size_t lds84 = attn_lds_floats<4, 8>(maxdeg) * sizeof(float), lds4 = attn_lds_floats<4>(maxdeg) * sizeof(float),
                lds2 = attn_lds_floats<2>(maxdeg) * sizeof(float), lds1 = attn_lds_floats<1>(maxdeg) * sizeof(float);
   const int kr = steps_host_kr;   // every step of a launch has the same rel-PE width
 #define PS_LAUNCH(TT, NWW, KRR, GRID, LDS) \
   hipLaunchKernelGGL((k_attn_chain<TT, NWW, KRR>), dim3(GRID), dim3(64 * NWW), LDS, st, x, x_in, Nd, steps, nsteps, maxdeg, eps, flags, prof)
-  if (timed && kr == 3 && (T == 1 || T == 2 || T == 4)) {   // the policy launch under its own symbol
+  if (timed && kr == 3 && (T == 1 || T == 2 || T == 4 || T == 18)) {   // the policy launch under its own symbol
     if (T == 4) hipLaunchKernelGGL((k_attn_chain<4, 4, 3, false, true>), dim3((Nd + 3) / 4), dim3(WG), lds4, st, x, x_in, Nd, steps, nsteps, maxdeg, eps, flags, prof);
     else if (T == 2) hipLaunchKernelGGL((k_attn_chain<2, 4, 3, false, true>), dim3((Nd + 1) / 2), dim3(WG), lds2, st, x, x_in, Nd, steps, nsteps, maxdeg, eps, flags, prof);
+    else if (T == 18) hipLaunchKernelGGL((k_attn_chain<1, 8, 3, false, true>), dim3(Nd), dim3(512), lds18, st, x, x_in, Nd, steps, nsteps, maxdeg, eps, flags, prof);
     else hipLaunchKernelGGL((k_attn_chain<1, 4, 3, true, true>), dim3(Nd), dim3(WG), lds1, st, x, x_in, Nd, steps, nsteps, maxdeg, eps, flags, prof);
   } else if (kr == 3) {
-    if (T == 84) PS_LAUNCH(4, 8, 3, (Nd + 3) / 4, lds84);
+    if (T == 18) hipLaunchKernelGGL((k_attn_chain<1, 8, 3, false>), dim3(Nd), dim3(512), lds18, st, x, x_in, Nd, steps, nsteps, maxdeg, eps, flags, prof);
+    else if (T == 84) PS_LAUNCH(4, 8, 3, (Nd + 3) / 4, lds84);
     else if (T == 4) PS_LAUNCH(4, 4, 3, (Nd + 3) / 4, lds4);
     else if (T == 2) PS_LAUNCH(2, 4, 3, (Nd + 1) / 2, lds2);
     else PS_LAUNCH(1, 4, 3, Nd, lds1);
   } else {
-    if (T == 84) PS_LAUNCH(4, 8, 4, (Nd + 3) / 4, lds84);
+    if (T == 18) hipLaunchKernelGGL((k_attn_chain<1, 8, 4, false>), dim3(Nd), dim3(512), lds18, st, x, x_in, Nd, steps, nsteps, maxdeg, eps, flags, prof);
+    else if (T == 84) PS_LAUNCH(4, 8, 4, (Nd + 3) / 4, lds84);
     else if (T == 4) PS_LAUNCH(4, 4, 4, (Nd + 3) / 4, lds4);
     else if (T == 2) PS_LAUNCH(2, 4, 4, (Nd + 1) / 2, lds2);
     else PS_LAUNCH(1, 4, 4, Nd, lds1);
