@@ -103,8 +103,14 @@ def main():
     backend = os.environ.get("PS_BENCH_BACKEND", "nccl")
     dev_index = 0 if os.environ.get("PS_BENCH_SAME_DEVICE") else local_rank
     torch.cuda.set_device(dev_index)
-    if world > 1:
+    # test hook: PS_BENCH_FORCE_DIST=1 takes the N > 1 code path (process group, event-ordered RCCL gather) with ONE
+    # rank, so the collective path can be exercised with the real nccl backend on a 1-GPU box
+    multi = world > 1 or bool(os.environ.get("PS_BENCH_FORCE_DIST"))
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
         else:
@@ -112,7 +118,7 @@ def main():
     import __graft_entry__ as ge
     if rank == 0:
         ge.build()
-    if world > 1:
+    if multi:
         dist.barrier()
     from prosim_amd.engine import Engine
     from prosim_amd.distributed import shard_scenes, reduce_metrics
@@ -140,7 +146,7 @@ def main():
     eng_stream = torch.cuda.ExternalStream(eng.stream_handle, device=torch.device("cuda", dev_index))
     done = [torch.cuda.Event() for _ in range(2)]       # rollout + metric of buffer i finished (engine stream)
     read = [None, None]                                  # gather of buffer i finished (torch stream)
-    gather = SceneMetricGather(my_scenes, n_scenes, N, 2, "cuda" if backend == "nccl" else "cpu") if world > 1 else None
+    gather = SceneMetricGather(my_scenes, n_scenes, N, 2, "cuda" if backend == "nccl" else "cpu") if multi else None
     state = {"k": 0, "last": None}
 
     def step():
@@ -151,7 +157,7 @@ def main():
         eng.rollout()
         eng.rollout_metric(metric_bufs[i].data_ptr())
         done[i].record(eng_stream)
-        if world == 1:
+        if not multi:
             state["last"] = metric_bufs[i].view(S, N, 2)
             return
         if backend == "nccl":
@@ -165,17 +171,17 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         red_dev = "cuda" if backend == "nccl" else "cpu"
         tmax = torch.tensor([dt], device=red_dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -247,7 +253,7 @@ def main():
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
     eng.close()
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 
