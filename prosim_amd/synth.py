@@ -78,8 +78,8 @@ def make_scene(spec: ModelSpec, n_agents: int, n_polylines: int, batch: int = 1,
     prompt_mask = np.ones((B, N), bool)
     if ragged:
         for b in range(B):
-            n_b = max(2, N - 3 * b - (1 if b == 0 else 0))
-            m_b = max(4, M - 5 * b - 2)
+            n_b = min(N, max(2, N - 3 * b - (1 if b == 0 else 0)))
+            m_b = min(M, max(4, M - 5 * b - 2))
             prompt_mask[b, n_b:] = False
             obs_mask[b, n_b:] = False
             map_mask[b, m_b:] = False
