@@ -492,3 +492,25 @@ def test_obs_update_variants_vs_oracle(fusion, attn):
         eng.close()
     with pytest.raises(ValueError, match="FUSION"):
         Engine(SMALL_SPEC.replace(obs_fusion="sum"), base)
+
+
+def test_maximum_scene_size(small_engine):
+    """The engine's per-scene limits at once: 2560 tokens (512 agents + 2048 polylines, the kNN kernel's candidate
+    registers), 32 points per polyline (the PointNet tile).  One more token is refused loudly."""
+    spec = SMALL_SPEC
+    w = weights.init_weights(spec, 0)
+    scene = synth.make_scene(spec, 512, 2048, batch=1, seed=77, goal=True, points=32, square=400.0)
+    with torch.no_grad():
+        o64 = orc.rollout(w, spec, scene, dtype=torch.float64)
+    small_engine.set_scene(scene)
+    small_engine.rollout()
+    A = small_engine.num_agents
+    assert A == 512 and small_engine.num_map_tokens == 2048
+    assert err(small_engine.get("motion_pred")[0], o64["motion_pred"][:A].numpy()) < TOL
+    pm = scene["prompt_mask"].astype(bool)
+    d = np.abs(small_engine.padded("traj") - o64["traj"].numpy())[pm].reshape(A, -1).max(1)
+    assert (d < TOL).mean() >= 0.97 and np.median(d) < 2e-5, (d.max(), (d < TOL).mean())   # isolated +-pi flips aside (DESIGN.md section 2)
+    with pytest.raises(RuntimeError, match="2560 tokens"):
+        small_engine.set_scene(synth.make_scene(spec, 513, 2048, batch=1, seed=1))
+    with pytest.raises(RuntimeError, match="P <= 32"):
+        small_engine.set_scene(synth.make_scene(spec, 4, 8, batch=1, seed=1, points=33))
