@@ -218,7 +218,7 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_policy_chain.json")
         if os.path.exists(pmc) and S == 8 and args.config == 2:
             with open(pmc) as f:
-                traffic = json.load(f)["hbm_bytes_per_launch_lower"]
+                traffic = json.load(f)["hbm_bytes_per_launch"]
         achieved = fl_alg / (ms_chain * 1e-3) / 1e12
         out = {
             "metric": "agent-steps/sec closed-loop rollout", "value": value, "unit": "agent-steps/s",
@@ -232,11 +232,12 @@ def main():
                        "scenes_per_gpu": S, "parallelism": f"scene-sharded x{world}, RCCL all-gather of per-agent ADE/FDE"},
             "roofline": {"bound": "mfma", "kernel": "k_attn_chain (policy: 12 fused attention layers per launch)",
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
-                         "traffic_note": "HBM bytes per launch, FETCH_SIZE+WRITE_SIZE lower bound (profiles/r01_pmc_policy_chain.json)",
+                         "traffic_note": "bytes leaving the L2s per launch = 2 x FETCH_SIZE (gfx950 halves 16 B/lane reads: profiles/r01_g_pmc_calibration.txt) + WRITE_SIZE, "
+                                         "separate rocprofv3 --pmc passes (profiles/r01_pmc_policy_chain.json); Infinity-Cache hits are counted",
                          "note": "achieved = ALGORITHMIC FLOPs of the reference formulation (SURVEY.md section 8(d)) / launch time; the "
                                  "kernel factors the per-edge to_k_r / to_v_r GEMVs out (DESIGN.md section 4) and executes 7.7x fewer, so "
                                  "frac can exceed 1 and is not hardware utilisation: see executed_frac.  The launch is latency-bound "
-                                 "(DESIGN.md section 4), neither MFMA- nor HBM-bound; HBM side: traffic / avg_launch_ms.",
+                                 "(DESIGN.md section 4), neither MFMA- nor HBM-bound; memory side: traffic / avg_launch_ms = hbm_gbps.",
                          "algorithmic_flops_per_launch": fl_alg, "executed_flops_per_launch": fl_exe,
                          "executed_tflops": fl_exe / (ms_chain * 1e-3) / 1e12, "executed_frac": fl_exe / (ms_chain * 1e-3) / 1e12 / peak,
                          "hbm_gbps": (traffic / (ms_chain * 1e-3) / 1e9) if traffic else None, "hbm_peak_gbps": 8000.0,
