@@ -132,7 +132,8 @@ def scene_from_extras(extras, spec: ModelSpec, task: str = "motion_pred") -> Dic
     prompt tensors are scattered into observation slots here.  Observed agents without a prompt are log-replay
     agents: ``fut_obs[t]`` (observation, mask, pose of all agents at the later replans) drives their scene tokens.
     ``scene['_policy_slots'][b]`` lists, in PROMPT order, the slot of every policy agent (the order of the outputs).
-    Raises if a policy agent is not observed or if the agent set changes between ``init_obs`` and ``fut_obs``."""
+    ``fut_obs`` frames are matched to the slots by id; an agent that leaves gets a masked frame.  Raises if a policy
+    agent is not observed or if an agent enters after the initial step."""
     obs, mp, pr = extras["init_obs"], extras["init_map"], extras["prompt"][task]
     obs_input = _np(_g(obs, "input"))
     B, N = obs_input.shape[:2]
@@ -159,17 +160,40 @@ def scene_from_extras(extras, spec: ModelSpec, task: str = "motion_pred") -> Dic
             scene["cond"] = out
     fut = extras.get("fut_obs") if hasattr(extras, "get") else None
     if fut:
+        # Every frame lists its own agents (get_center_obs drops a non-target agent whose state at that step is NaN,
+        # format_utils.py:383-388), so frames are matched to the init_obs slots BY ID: an agent that has left the
+        # scene gets a fully masked frame (no scene token at that replan).  An agent that only ENTERS later has no
+        # slot: refused, not dropped silently -- it would be a neighbour of the policy agents in the reference.
         ts = sorted(int(t) for t in fut.keys())
-        for t in ts:
-            ids_t = _g(fut[t], "agent_ids")
-            if ids_o is not None and ids_t is not None and [list(a) for a in ids_t] != [list(a) for a in ids_o]:
-                raise NotImplementedError("fut_obs frames must list the agents of init_obs in the same order "
-                                          "(agents entering or leaving the scene mid-rollout: mask their rows instead)")
-        scene["fut_obs_input"] = np.stack([_np(_g(fut[t], "input")) for t in ts])
-        scene["fut_obs_mask"] = np.stack([_np(_g(fut[t], "mask"), bool) for t in ts])
-        scene["fut_obs_pos"] = np.stack([_np(_g(fut[t], "position")) for t in ts])
-        fh = np.stack([_np(_g(fut[t], "heading")) for t in ts])
-        scene["fut_obs_head"] = fh.reshape(fh.shape[0], B, N)
+        H, F = obs_input.shape[2], obs_input.shape[3]
+        f_in = np.full((len(ts), B, N, H, F), np.nan, np.float32)
+        f_mk = np.zeros((len(ts), B, N, H, F), bool)
+        f_pos = np.repeat(_np(_g(obs, "position"))[None], len(ts), 0).copy()
+        f_head = np.repeat(_np(_g(obs, "heading")).reshape(1, B, N), len(ts), 0).copy()
+        for k, t in enumerate(ts):
+            fr = fut[t]
+            ids_t = _g(fr, "agent_ids")
+            fi, fm = _np(_g(fr, "input")), _np(_g(fr, "mask"), bool)
+            fp_, fh = _np(_g(fr, "position")), _np(_g(fr, "heading"))
+            fh = fh.reshape(fh.shape[0], -1)
+            if ids_o is None or ids_t is None:
+                if fi.shape[:2] != (B, N):
+                    raise ValueError("fut_obs frames without agent_ids must keep the [B, N] layout of init_obs")
+                f_in[k], f_mk[k], f_pos[k], f_head[k] = fi, fm, fp_, fh
+                continue
+            for b_ in range(B):
+                where = {a: n for n, a in enumerate(ids_o[b_])}
+                new = [a for a in ids_t[b_] if a not in where]
+                if new:
+                    raise NotImplementedError(f"agents {new} enter scene {b_} at step {t}: only agents observed at the "
+                                              f"initial step have a token slot")
+                for j, a in enumerate(ids_t[b_]):
+                    n = where[a]
+                    f_in[k, b_, n], f_mk[k, b_, n], f_pos[k, b_, n], f_head[k, b_, n] = fi[b_, j], fm[b_, j], fp_[b_, j], fh[b_, j]
+                gone = [ids_o[b_][n] for n in slots[b_] if ids_o[b_][n] not in set(ids_t[b_])]
+                if gone:   # target agents are listed in every frame (format_utils.py:381-385); their static columns come from it
+                    raise ValueError(f"policy agents {gone} of scene {b_} are missing from fut_obs[{t}]")
+        scene["fut_obs_input"], scene["fut_obs_mask"], scene["fut_obs_pos"], scene["fut_obs_head"] = f_in, f_mk, f_pos, f_head
     return scene
 
 

@@ -127,6 +127,58 @@ def test_staged_model_methods_equal_forward(model, name):
         model.rollout_batch(batch, scene_embs, policy_emds, ids, model.init_agent_trajs(ids, batch), [0, 10], "val")
 
 
+def test_fut_obs_frames_are_matched_by_agent_id(model):
+    """Every fut_obs frame lists its own agents (get_center_obs drops agents that have left, format_utils.py:383-388):
+    a frame that omits a log-replay agent and lists the others in another order must equal the same frame with
+    that agent masked in place; an agent that enters later, or a policy agent missing from a frame, is an error."""
+    name = "small_replay_b2"
+    sname, kw, wseed = FULL_CASES[name]
+    spec = SPECS[sname]
+    scene = synth.make_scene(spec, **kw)
+    pm = scene["prompt_mask"].astype(bool)
+    seen = scene["obs_mask"].all(-1).any(-1)
+    b0 = 0
+    replay = [n for n in range(pm.shape[1]) if seen[b0, n] and not pm[b0, n]]
+    assert len(replay) >= 2
+    leaver = replay[0]
+    masked = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in scene.items()}
+    masked["fut_obs_mask"][2:, b0, leaver] = False                      # gone from the log from the 3rd later replan on
+    masked["fut_obs_input"][2:, b0, leaver] = np.nan
+    want = model(make_batch(masked, spec), "val")["motion_pred"]
+    batch = make_batch(scene, spec)
+    for k, t in enumerate(sorted(batch.extras["fut_obs"].keys())):
+        if k < 2:
+            continue
+        fr = batch.extras["fut_obs"][t]
+        n_b = len(fr["agent_ids"][b0])
+        order = [n for n in reversed(range(n_b)) if n != leaver]        # drop the leaver, reverse the others
+        for key in ("input", "mask", "position", "heading"):
+            rows = fr[key][b0, order].clone()
+            fr[key][b0] = 0 if key != "mask" else False
+            fr[key][b0, :len(order)] = rows
+        fr["agent_ids"] = [list(a) for a in fr["agent_ids"]]
+        fr["agent_ids"][b0] = [fr["agent_ids"][b0][n] for n in order]
+    got = model(batch, "val")["motion_pred"]
+    assert got["pair_names"] == want["pair_names"] and torch.equal(got["motion_pred"], want["motion_pred"])
+    t_last = sorted(batch.extras["fut_obs"].keys())[-1]
+    enter = make_batch(scene, spec)
+    enter.extras["fut_obs"][t_last]["agent_ids"] = [list(a) for a in enter.extras["fut_obs"][t_last]["agent_ids"]]
+    enter.extras["fut_obs"][t_last]["agent_ids"][b0][leaver] = "newcomer"
+    with pytest.raises(NotImplementedError, match="enter"):
+        model(enter, "val")
+    lost = make_batch(scene, spec)
+    pol = int(np.nonzero(pm[b0])[0][0])
+    fr = lost.extras["fut_obs"][t_last]
+    fr["agent_ids"] = [list(a) for a in fr["agent_ids"]]
+    fr["agent_ids"][b0] = [a for n, a in enumerate(fr["agent_ids"][b0]) if n != pol]
+    for key in ("input", "mask", "position", "heading"):
+        keep = [n for n in range(len(fr["agent_ids"][b0]) + 1) if n != pol]
+        rows = fr[key][b0, keep].clone()
+        fr[key][b0, :len(keep)] = rows
+    with pytest.raises(ValueError, match="missing from fut_obs"):
+        model(lost, "val")
+
+
 def test_staged_components_and_stateless_policy(model):
     """scene_encoder(...) -> decoder(...) -> policy(...) with the reference's argument layouts."""
     spec = SMALL_SPEC
