@@ -79,6 +79,12 @@ int ps_set_scene(ps_engine* e, int32_t B, int32_t M, int32_t P, int32_t N,
                  const float* prompt, const uint8_t* prompt_mask, const int32_t* agent_type,
                  const float* prompt_pos, const float* prompt_head);
 
+/* Agents that ENTER the scene after the initial step (get_center_obs lists an agent only while its state is finite,
+ * format_utils.py:383-388): call this BEFORE ps_set_scene with rows [B,N] != 0 for every slot that needs a token row
+ * although its initial history has no valid step.  Such a row is no scene token (not a neighbour of anything) until a
+ * ps_set_future_log frame carries a valid step for it.  Consumed by the next ps_set_scene; NULL clears. */
+int ps_declare_agent_rows(ps_engine* e, int32_t B, int32_t N, const uint8_t* rows);
+
 /* Replace only the prompt side of the uploaded batch (prompt [B,N,prompt_dim], prompt_pos [B,N,2],
  * prompt_head [B,N], agent_type [B,N]); prompt_mask must be unchanged.  Lets the decoder be called
  * after the scene encoder with its own prompt_enc argument (decoder/sym_coord.py:112). */

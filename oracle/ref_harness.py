@@ -289,10 +289,15 @@ def make_batch(scene_in, spec):
     t = lambda a, dt=torch.float32: torch.from_numpy(np.ascontiguousarray(a)).to(dt).clone()
     pm = scene_in["prompt_mask"].astype(bool)
     B, N = pm.shape
-    seen = scene_in["obs_mask"].all(-1).any(-1)                       # [B, N] observed slots
-    assert (seen | ~pm).all(), "a policy agent must be observed"
+    seen0 = scene_in["obs_mask"].all(-1).any(-1)                      # [B, N] observed at the initial step
+    assert (seen0 | ~pm).all(), "a policy agent must be observed"
+    seen = seen0.copy()                                                # ... or in any later frame (agents that enter)
+    if "fut_obs_mask" in scene_in:
+        seen |= scene_in["fut_obs_mask"].all(-1).any(-1).any(0)
     n_obs = [int(seen[b].sum()) for b in range(B)]
     assert all(seen[b, :n_obs[b]].all() for b in range(B)), "observed agents must fill the leading slots"
+    # every frame lists every agent that is ever observed; a frame's mask says whether the agent is in the scene at
+    # that step (a listed agent without a valid point is no token: same as not listing it, obs_encoder.py:84-87)
     obs_ids = [[f"a{n}" for n in range(n_obs[b])] for b in range(B)]
     pol = [np.nonzero(pm[b])[0] for b in range(B)]
     Np = max(len(p_) for p_ in pol)

@@ -123,7 +123,10 @@ struct ps_engine {
   int n_policy = 0;
   bool all_policy = true, have_log = false;
   std::vector<int> is_policy_h;
-  DevBuf<int> d_is_policy, d_tok_live;
+  DevBuf<int> d_is_policy, d_tok_live, d_live0;   // d_live0: agent row is in the scene at the initial step
+  std::vector<uint8_t> declared_rows;             // ps_declare_agent_rows: consumed by the next ps_set_scene
+  std::vector<int> live0_h;
+  bool have_dead0 = false;
   DevBuf<uint8_t> d_obs_in_mask, d_fut_mask, d_obs_mask_rows;   // (d_obs_mask_rows: the initial mask, one row per agent)
   DevBuf<float> d_fut_pos, d_fut_head;
   int stride_steps = 0;
@@ -609,7 +612,7 @@ extern "C" void ps_destroy(ps_engine* e) {
   (void)hipDeviceSynchronize();
   // DevBuf members are plain structs without destructors: release explicitly
   e->d_map_input.release(); e->d_obs_input.release(); e->d_prompt.release(); e->d_fut.release();
-  e->d_is_policy.release(); e->d_tok_live.release(); e->d_obs_in_mask.release(); e->d_fut_mask.release();
+  e->d_is_policy.release(); e->d_tok_live.release(); e->d_live0.release(); e->d_obs_in_mask.release(); e->d_fut_mask.release();
   e->d_obs_mask_rows.release();
   e->d_fut_pos.release(); e->d_fut_head.release();
   e->d_map_mask.release(); e->d_obs_mask.release();
@@ -675,6 +678,12 @@ extern "C" int ps_set_scene(ps_engine* e, int32_t B, int32_t M, int32_t P, int32
   e->B = B; e->M = M; e->P = P; e->N = N;
   e->map_rows.clear(); e->agent_rows.clear(); e->agent_scene.clear(); e->map_scene.clear();
   e->is_policy_h.clear();
+  e->live0_h.clear();
+  const bool declared = e->declared_rows.size() == (size_t)B * N;
+  if (!e->declared_rows.empty() && !declared) {
+    e->declared_rows.clear();
+    return fail(PS_E_ARG, "ps_declare_agent_rows was called with another [B, N] than this ps_set_scene");
+  }
   e->moff.assign(B + 1, 0); e->aoff.assign(B + 1, 0);
   e->maxA_scene = e->maxM_scene = 0;
   for (int b = 0; b < B; ++b) {
@@ -696,7 +705,8 @@ extern "C" int ps_set_scene(ps_engine* e, int32_t B, int32_t M, int32_t P, int32
       if (pol && !any)
         return fail(PS_E_ARG, "a policy agent must be observed: its prompt sits in the slot of its history (scene " +
                                   std::to_string(b) + ", slot " + std::to_string(n) + ")");
-      if (any) {
+      if (any || (declared && e->declared_rows[(size_t)b * N + n])) {   // a declared row without history enters later
+        e->live0_h.push_back(any ? 1 : 0);
         e->is_policy_h.push_back(pol ? 1 : 0);
         const int ty = agent_type[(size_t)b * N + n];
         if (ty < 1 || ty > c.num_agent_types) return fail(PS_E_ARG, "agent_type outside 1..num_agent_types");
@@ -712,7 +722,10 @@ extern "C" int ps_set_scene(ps_engine* e, int32_t B, int32_t M, int32_t P, int32
     return fail(PS_E_ARG, "more than 2560 tokens in one scene (knn candidate registers)");
   const int Mv = e->Mv = (int)e->map_rows.size();
   const int A = e->A = (int)e->agent_rows.size();
+  e->declared_rows.clear();
   if (A == 0) return fail(PS_E_ARG, "no valid agents");
+  e->have_dead0 = false;
+  for (int v : e->live0_h) e->have_dead0 |= v == 0;
   e->n_policy = 0;
   for (int v : e->is_policy_h) e->n_policy += v;
   if (e->n_policy == 0) return fail(PS_E_ARG, "no policy agent (prompt_mask is empty)");
@@ -768,6 +781,7 @@ extern "C" int ps_set_scene(ps_engine* e, int32_t B, int32_t M, int32_t P, int32
     std::vector<uint8_t> mrows((size_t)A * arow);
     for (int i = 0; i < A; ++i) std::memcpy(&mrows[(size_t)i * arow], obs_mask + (size_t)e->agent_rows[i] * arow, arow);
     if (upload(e->d_is_policy, e->is_policy_h.data(), (size_t)A, st) || e->d_tok_live.ensure((size_t)A) ||
+        upload(e->d_live0, e->live0_h.data(), (size_t)A, st) ||
         e->d_obs_in_mask.ensure((size_t)A * arow) || upload(e->d_obs_mask_rows, mrows.data(), mrows.size(), st))
       return fail(PS_E_HIP, "policy-flag upload failed");
   }
@@ -809,10 +823,12 @@ extern "C" int ps_set_scene(ps_engine* e, int32_t B, int32_t M, int32_t P, int32
   }
   // closed-form CSR offsets of the knn graphs (every query gets min(k, scene size) neighbours)
   {
+    std::vector<int> nlive(B, 0);   // agents in the scene at the initial step (the kNN candidates)
+    for (int i = 0; i < A; ++i) nlive[e->agent_scene[i]] += e->live0_h[i];
     std::vector<int> off(A + 1, 0), tof(A + 1, 0), tds;
     for (int i = 0; i < A; ++i) {
       const int b = e->agent_scene[i];
-      const int dg = mn(c.agent_knn, e->aoff[b + 1] - e->aoff[b]);
+      const int dg = mn(c.agent_knn, nlive[b]);
       off[i + 1] = off[i] + dg;
       tof[i + 1] = tof[i] + (dg + 31) / 32;
       tds.insert(tds.end(), (dg + 31) / 32, i);
@@ -824,7 +840,7 @@ extern "C" int ps_set_scene(ps_engine* e, int32_t B, int32_t M, int32_t P, int32
     std::vector<int> off2(Mv + A + 1, 0), tof2(Mv + A + 1, 0), tds2;
     for (int i = 0; i < Mv + A; ++i) {
       const int b = scene[i];
-      const int ns = (e->aoff[b + 1] - e->aoff[b]) + (e->moff[b + 1] - e->moff[b]);
+      const int ns = nlive[b] + (e->moff[b + 1] - e->moff[b]);
       const int dg = mn(c.scene_knn, ns);
       off2[i + 1] = off2[i] + dg;
       tof2[i + 1] = tof2[i] + (dg + 31) / 32;
@@ -885,6 +901,13 @@ extern "C" int ps_set_scene(ps_engine* e, int32_t B, int32_t M, int32_t P, int32
   e->encoded = e->generated = e->reset = false;
   drop_graph(e);
   // keep host copies the later stages need
+  return PS_OK;
+}
+
+extern "C" int ps_declare_agent_rows(ps_engine* e, int32_t B, int32_t N, const uint8_t* rows) {
+  if (!e) return fail(PS_E_ARG, "null engine");
+  e->declared_rows.clear();
+  if (rows && B > 0 && N > 0) e->declared_rows.assign(rows, rows + (size_t)B * N);
   return PS_OK;
 }
 
@@ -1296,14 +1319,18 @@ extern "C" int ps_encode_scene(ps_engine* e) {
   HIPCHK(hipMemcpyAsync(e->d_tok_ori.p + Mv, e->d_init_head.p, sizeof(float) * A, hipMemcpyDeviceToDevice, st));
   launch_pointnet(e, e->pn_map, e->d_map_input.p, e->d_map_mask.p, e->d_map_rows.p, Mv, e->P, 0, tok);
   launch_pointnet(e, e->pn_obs, e->d_obs_input.p, e->d_obs_mask.p, e->d_agent_rows.p, A, c.hist_steps, c.obs_dim, tok + (size_t)Mv * D);
-  // knn graphs (attn_fusion.py:107-109) + rel-PE (:111-112)
+  // knn graphs (attn_fusion.py:107-109) + rel-PE (:111-112).  Agent rows that only enter the scene with a later fut_obs
+  // frame are no tokens yet: not a candidate of any query (their own rows are computed and ignored).
+  const int* live0 = e->have_dead0 ? (const int*)e->d_live0.p : nullptr;
   {
     CandSet ca{e->d_tok_pos.p, e->d_r_agent.p, nullptr};
     hipLaunchKernelGGL(k_knn, dim3((A + 3) / 4), dim3(256), 0, st, ca, (const float*)(e->d_tok_pos.p + 2 * (size_t)Mv),
-                       (const int*)(e->d_tok_scene.p + Mv), A, c.agent_knn, (const int*)e->e_a2a.eoff.p, e->e_a2a.esrc.p, e->e_a2a.edst.p);
+                       (const int*)(e->d_tok_scene.p + Mv), A, c.agent_knn, (const int*)e->e_a2a.eoff.p, e->e_a2a.esrc.p, e->e_a2a.edst.p,
+                       live0, Mv);
     CandSet csn{e->d_tok_pos.p, e->d_r_map.p, e->d_r_agent.p};
     hipLaunchKernelGGL(k_knn, dim3((Mv + A + 3) / 4), dim3(256), 0, st, csn, (const float*)e->d_tok_pos.p,
-                       (const int*)e->d_tok_scene.p, Mv + A, c.scene_knn, (const int*)e->e_s2s.eoff.p, e->e_s2s.esrc.p, e->e_s2s.edst.p);
+                       (const int*)e->d_tok_scene.p, Mv + A, c.scene_knn, (const int*)e->e_s2s.eoff.p, e->e_s2s.esrc.p, e->e_s2s.edst.p,
+                       live0, Mv);
     // a2a edges index agents globally (Mv + i) for positions; kv rows are agent-local -> fixed up below
     const PeArgs pe[2] = {{&e->e_a2a, e->d_tok_ori.p, e->d_tok_pos.p + 2 * (size_t)Mv, e->d_tok_ori.p + Mv},
                           {&e->e_s2s, e->d_tok_ori.p, e->d_tok_pos.p, e->d_tok_ori.p}};
@@ -1326,6 +1353,8 @@ extern "C" int ps_encode_scene(ps_engine* e) {
       if (launch_chain(e, tok, Mv + A, e->step_s2s + i, 1, e->e_s2s.maxdeg)) return PS_E_HIP;
     }
   }
+  if (live0)   // rows outside the scene keep a zero token (what FUSION 'mlp' takes as the previous token when they enter)
+    hipLaunchKernelGGL(k_zero_dead_rows, dim3((A * D + 255) / 256), dim3(256), 0, st, tok + (size_t)Mv * D, live0, A);
   HIPCHK(hipGetLastError());
   e->encoded = true;
   e->generated = false;
@@ -1356,7 +1385,7 @@ extern "C" int ps_generate_policy(ps_engine* e) {
   HIPCHK(hipMemcpyAsync(e->d_tok_pos.p + 2 * (size_t)Mv, e->d_init_pos.p, sizeof(float) * 2 * A, hipMemcpyDeviceToDevice, st));
   HIPCHK(hipMemcpyAsync(e->d_tok_ori.p + Mv, e->d_init_head.p, sizeof(float) * A, hipMemcpyDeviceToDevice, st));
   launch_radius(e, e->e_s2p, e->d_r_map.p, e->d_r_agent.p, ppos, pscene, A, c.dec_scene_radius, c.dec_max_neigh, -1,
-                e->d_tok_ori.p, pori);
+                e->d_tok_ori.p, pori, e->have_dead0 ? (const int*)e->d_live0.p : nullptr, Mv);
   // k|v of the (fixed) scene tokens for all s2p layers in one launch
   launch_kv(e, e->d_tok.p, Mv + A, e->L_s2p, c.dec_layers, e->d_kv_s2p.p, e->d_kh_s2p.p, (size_t)(Mv + A) * 256);
   const int md = std::max(e->e_p2p.maxdeg, e->e_s2p.maxdeg);

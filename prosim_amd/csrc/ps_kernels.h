@@ -409,8 +409,11 @@ __global__ __launch_bounds__(256) void k_tile_transpose(const int* __restrict__ 
 // ties at v_k are kept in index order until k are out -- i.e. the k smallest by (d2, index).
 // Edges of a destination come out in candidate-index order.  eoff is closed-form (host).
 constexpr int KNN_SLOTS = 40;   // up to 64*40 = 2560 candidates per scene (2048 polylines + 256 agents fits)
+// cand_ok (optional): candidate token i takes part iff i < cand_base or cand_ok[i - cand_base] != 0 -- agent rows that
+// are not in the scene at the initial step (they enter with a later fut_obs frame) are no tokens yet.
 __global__ void k_knn(CandSet cs, const float* __restrict__ qpos, const int* __restrict__ qscene, int nq, int k,
-                      const int* __restrict__ eoff, int* __restrict__ esrc, int* __restrict__ edst) {
+                      const int* __restrict__ eoff, int* __restrict__ esrc, int* __restrict__ edst,
+                      const int* __restrict__ cand_ok, int cand_base) {
   const int q = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (q >= nq) return;
@@ -426,11 +429,18 @@ __global__ void k_knn(CandSet cs, const float* __restrict__ qpos, const int* __r
     unsigned kk = 0xffffffffu;     // padding sorts last (real keys are finite floats < 0x7f800000)
     if (j < n) {
       const int i = j < n1 ? b1 + j : b2 + (j - n1);
-      kk = __float_as_uint(dist2(cs.pos[2 * i], cs.pos[2 * i + 1], qx, qy));
+      if (!cand_ok || i < cand_base || cand_ok[i - cand_base])
+        kk = __float_as_uint(dist2(cs.pos[2 * i], cs.pos[2 * i + 1], qx, qy));
     }
     key[s] = kk;
   }
-  const int kk_ = k < n ? k : n;
+  int n_ok = n;
+  if (cand_ok) {
+    n_ok = 0;
+#pragma unroll
+    for (int s = 0; s < KNN_SLOTS; ++s) n_ok += __popcll(__ballot(key[s] != 0xffffffffu));
+  }
+  const int kk_ = k < n_ok ? k : n_ok;
   // v_k = largest x with count(key < x) < k
   unsigned vk = 0;
   for (int bit = 31; bit >= 0; --bit) {
@@ -448,7 +458,7 @@ __global__ void k_knn(CandSet cs, const float* __restrict__ qpos, const int* __r
 #pragma unroll
   for (int s = 0; s < KNN_SLOTS; ++s) {
     const int j = s * 64 + lane;
-    const bool lt = key[s] < vk, eq = key[s] == vk && j < n;
+    const bool lt = key[s] < vk, eq = key[s] == vk && j < n && key[s] != 0xffffffffu;
     const unsigned long long meq = __ballot(eq);
     const int eq_rank = __popcll(meq & ((1ull << lane) - 1ull));
     const bool take = lt || (eq && eq_rank < ties_left);

@@ -71,6 +71,7 @@ def load_library():
     lib.ps_num_policy_agents.argtypes = [vp]
     lib.ps_num_policy_agents.restype = C.c_int32
     lib.ps_update_obs.argtypes = [vp, fp, u8p, fp, fp]
+    lib.ps_declare_agent_rows.argtypes = [vp, C.c_int32, C.c_int32, u8p]
     lib.ps_stream.argtypes = [vp]
     lib.ps_stream.restype = C.c_void_p
     lib.ps_policy_flags.argtypes = [vp, i32p, C.c_int64]
@@ -97,7 +98,7 @@ def load_library():
 
 
 EXPORTS = ["ps_create", "ps_destroy", "ps_last_error", "ps_set_scene", "ps_set_prompt", "ps_policy_forward", "ps_set_conditions", "ps_set_drag_points", "ps_set_future_obs", "ps_set_future_log", "ps_num_policy_agents", "ps_policy_flags",
-           "ps_encode_scene", "ps_generate_policy", "ps_reset_rollout", "ps_policy_step", "ps_rollout", "ps_sync", "ps_stream", "ps_update_obs",
+           "ps_encode_scene", "ps_generate_policy", "ps_reset_rollout", "ps_policy_step", "ps_rollout", "ps_sync", "ps_stream", "ps_update_obs", "ps_declare_agent_rows",
            "ps_set_state", "ps_get", "ps_rollout_metric", "ps_num_agents", "ps_num_map_tokens", "ps_time_rollout", "ps_time_policy_kernel",
            "ps_test_pointnet", "ps_test_fourier", "ps_test_wrap", "ps_test_attn", "ps_test_get_edges", "ps_test_stream"]
 
@@ -188,15 +189,26 @@ class Engine:
         phead = f32("prompt_head") if "prompt_head" in s else f32("obs_head")
         keep = [map_input, obs_input, prompt, map_mask, obs_mask, pm, at, ppos, phead, f32("map_pos"), f32("map_head"),
                 f32("obs_pos"), f32("obs_head")]
+        # agent rows = agents observed at the initial step (a history step with every feature valid) plus agents that
+        # only ENTER with a later fut_obs frame (declared to the engine: token rows that are not in the scene yet)
+        seen0 = obs_mask.astype(bool).all(-1).any(-1)
+        seen = seen0.copy()
+        if s.get("fut_obs_mask") is not None:
+            seen |= np.asarray(s["fut_obs_mask"]).astype(bool).all(-1).any(-1).any(0)
+        if (seen & ~seen0).any():
+            rows = np.ascontiguousarray(seen).astype(np.uint8)
+            self._check(self.lib.ps_declare_agent_rows(self.h, B, N, _u8(rows)))
+        else:
+            self._check(self.lib.ps_declare_agent_rows(self.h, 0, 0, None))
         self._check(self.lib.ps_set_scene(self.h, B, M, P, N, _f(map_input), _u8(map_mask), _f(keep[9]), _f(keep[10]),
                                           _f(obs_input), _u8(obs_mask), _f(keep[11]), _f(keep[12]), _f(prompt), _u8(pm),
                                           _i32(at), _f(ppos), _f(phead)))
         self._shape = (B, N)
-        # agent rows = observed agents (a history step with every feature valid), in slot order; policy agents are the
-        # rows whose slot carries a prompt, the others replay the log (ps_set_future_log)
-        seen = obs_mask.astype(bool).all(-1).any(-1).reshape(-1)
-        self._slots = np.nonzero(seen)[0]
+        # rows in slot order; policy agents are the rows whose slot carries a prompt, the others replay the log
+        # (ps_set_future_log); live0_rows: the row is a scene token at the initial step
+        self._slots = np.nonzero(seen.reshape(-1))[0]
         self.policy_rows = pm.reshape(-1).astype(bool)[self._slots]
+        self.live0_rows = seen0.reshape(-1)[self._slots]
         self.set_conditions(s.get("cond"))
         if s.get("fut_obs_input") is not None:
             fo = np.ascontiguousarray(s["fut_obs_input"], dtype=np.float32)

@@ -132,8 +132,8 @@ def scene_from_extras(extras, spec: ModelSpec, task: str = "motion_pred") -> Dic
     prompt tensors are scattered into observation slots here.  Observed agents without a prompt are log-replay
     agents: ``fut_obs[t]`` (observation, mask, pose of all agents at the later replans) drives their scene tokens.
     ``scene['_policy_slots'][b]`` lists, in PROMPT order, the slot of every policy agent (the order of the outputs).
-    ``fut_obs`` frames are matched to the slots by id; an agent that leaves gets a masked frame.  Raises if a policy
-    agent is not observed or if an agent enters after the initial step."""
+    ``fut_obs`` frames are matched to the slots by id; an agent that leaves gets a masked frame, an agent that enters
+    later gets a new slot.  Raises if a policy agent is not observed, or is missing from a frame."""
     obs, mp, pr = extras["init_obs"], extras["init_map"], extras["prompt"][task]
     obs_input = _np(_g(obs, "input"))
     B, N = obs_input.shape[:2]
@@ -161,36 +161,53 @@ def scene_from_extras(extras, spec: ModelSpec, task: str = "motion_pred") -> Dic
     fut = extras.get("fut_obs") if hasattr(extras, "get") else None
     if fut:
         # Every frame lists its own agents (get_center_obs drops a non-target agent whose state at that step is NaN,
-        # format_utils.py:383-388), so frames are matched to the init_obs slots BY ID: an agent that has left the
-        # scene gets a fully masked frame (no scene token at that replan).  An agent that only ENTERS later has no
-        # slot: refused, not dropped silently -- it would be a neighbour of the policy agents in the reference.
+        # format_utils.py:383-388), so frames are matched to the observation slots BY ID.  An agent that has left the
+        # scene gets a fully masked frame (no scene token at that replan); an agent that only ENTERS with a later
+        # frame gets a new slot behind the init_obs ones, without history at the initial step (the engine keeps a
+        # token row for it that joins the scene with its first valid frame).
         ts = sorted(int(t) for t in fut.keys())
         H, F = obs_input.shape[2], obs_input.shape[3]
+        ids_all = None
+        if ids_o is not None and all(_g(fut[t], "agent_ids") is not None for t in ts):
+            ids_all = [list(ids_o[b_]) for b_ in range(B)]
+            for t in ts:
+                for b_ in range(B):
+                    known = set(ids_all[b_])
+                    ids_all[b_] += [a for a in _g(fut[t], "agent_ids")[b_] if a not in known]
+            N2 = max(N, max(len(x) for x in ids_all))
+            if N2 > N:                                           # slots for the agents that enter later
+                def grow(a, fill):
+                    out = np.full((B, N2) + a.shape[2:], fill, a.dtype)
+                    out[:, :N] = a
+                    return out
+                scene.update(obs_input=grow(scene["obs_input"], np.nan), obs_mask=grow(scene["obs_mask"], False),
+                             obs_pos=grow(scene["obs_pos"], 0.0), obs_head=grow(scene["obs_head"].reshape(B, N), 0.0),
+                             prompt=grow(scene["prompt"], 0.0), prompt_mask=grow(scene["prompt_mask"], False),
+                             agent_type=grow(scene["agent_type"], 1), prompt_pos=grow(scene["prompt_pos"], 0.0),
+                             prompt_head=grow(scene["prompt_head"], 0.0))
+                N = N2
+            scene["_obs_ids"] = ids_all
         f_in = np.full((len(ts), B, N, H, F), np.nan, np.float32)
         f_mk = np.zeros((len(ts), B, N, H, F), bool)
-        f_pos = np.repeat(_np(_g(obs, "position"))[None], len(ts), 0).copy()
-        f_head = np.repeat(_np(_g(obs, "heading")).reshape(1, B, N), len(ts), 0).copy()
+        f_pos = np.repeat(scene["obs_pos"][None], len(ts), 0).copy()
+        f_head = np.repeat(scene["obs_head"].reshape(1, B, N), len(ts), 0).copy()
         for k, t in enumerate(ts):
             fr = fut[t]
             ids_t = _g(fr, "agent_ids")
             fi, fm = _np(_g(fr, "input")), _np(_g(fr, "mask"), bool)
             fp_, fh = _np(_g(fr, "position")), _np(_g(fr, "heading"))
             fh = fh.reshape(fh.shape[0], -1)
-            if ids_o is None or ids_t is None:
+            if ids_all is None:
                 if fi.shape[:2] != (B, N):
                     raise ValueError("fut_obs frames without agent_ids must keep the [B, N] layout of init_obs")
                 f_in[k], f_mk[k], f_pos[k], f_head[k] = fi, fm, fp_, fh
                 continue
             for b_ in range(B):
-                where = {a: n for n, a in enumerate(ids_o[b_])}
-                new = [a for a in ids_t[b_] if a not in where]
-                if new:
-                    raise NotImplementedError(f"agents {new} enter scene {b_} at step {t}: only agents observed at the "
-                                              f"initial step have a token slot")
+                where = {a: n for n, a in enumerate(ids_all[b_])}
                 for j, a in enumerate(ids_t[b_]):
                     n = where[a]
                     f_in[k, b_, n], f_mk[k, b_, n], f_pos[k, b_, n], f_head[k, b_, n] = fi[b_, j], fm[b_, j], fp_[b_, j], fh[b_, j]
-                gone = [ids_o[b_][n] for n in slots[b_] if ids_o[b_][n] not in set(ids_t[b_])]
+                gone = [ids_all[b_][n] for n in slots[b_] if ids_all[b_][n] not in set(ids_t[b_])]
                 if gone:   # target agents are listed in every frame (format_utils.py:381-385); their static columns come from it
                     raise ValueError(f"policy agents {gone} of scene {b_} are missing from fut_obs[{t}]")
         scene["fut_obs_input"], scene["fut_obs_mask"], scene["fut_obs_pos"], scene["fut_obs_head"] = f_in, f_mk, f_pos, f_head
@@ -216,8 +233,16 @@ class HipSceneEncoder:
                     scene_type=torch.cat([torch.zeros_like(mb), torch.ones_like(ob)]),
                     scene_pos=torch.cat([torch.from_numpy(scene["map_pos"])[mm], torch.from_numpy(scene["obs_pos"])[om]]),
                     scene_ori=torch.cat([torch.from_numpy(scene["map_head"])[mm], torch.from_numpy(scene["obs_head"])[om]])[:, None],
-                    scene_tokens=torch.from_numpy(eng.get("scene_tokens")), max_map_num=mm.shape[1], max_agent_num=om.shape[1],
+                    scene_tokens=torch.from_numpy(self._tokens()), max_map_num=mm.shape[1], max_agent_num=om.shape[1],
                     _hip_resident=True, _n_map_tokens=Mv)
+
+    def _tokens(self) -> np.ndarray:
+        """[map tokens ; tokens of the agents that are in the scene at the initial step] (rows of agents that only
+        enter later are engine-internal)."""
+        eng = self.s.engine
+        tok = eng.get("scene_tokens")
+        Mv = eng.num_map_tokens
+        return np.concatenate([tok[:Mv], tok[Mv:][eng.live0_rows]])
 
     def __call__(self, batch_obs, batch_map):
         return self.forward(batch_obs, batch_map)

@@ -25,14 +25,18 @@ from .spec import ModelSpec
 
 def make_scene(spec: ModelSpec, n_agents: int, n_polylines: int, batch: int = 1, seed: int = 0,
                square: float = 200.0, points: int = 19, goal: bool = False, tags: bool = False,
-               ragged: bool = False, clustered: bool = False, replay: float = 0.0, drag: bool = False) -> Dict[str, np.ndarray]:
+               ragged: bool = False, clustered: bool = False, replay: float = 0.0, drag: bool = False,
+               enter: float = 0.0) -> Dict[str, np.ndarray]:
     """One batch of ``batch`` scenes.  ``ragged``: later scenes in the batch get fewer agents /
     polylines / points, and some history steps are masked (NaN), to exercise the mask paths.
     ``clustered``: agents are placed along polylines (realistic density) instead of uniformly.
     ``replay`` > 0: that fraction of the observed agents is NOT policy-controlled (prompt_mask False, history valid):
     they replay a log -- ``fut_obs_input / fut_obs_mask / fut_obs_pos / fut_obs_head`` [R-1, B, N, ...] carry their
     observation and pose at every later replan (straight-line motion here; a few drop out of the log), as the
-    reference's ``batch.extras['fut_obs'][t]`` does (traj_sam.py:221-270)."""
+    reference's ``batch.extras['fut_obs'][t]`` does (traj_sam.py:221-270).
+    ``enter`` > 0 (needs ``replay``): that fraction of the log-replay agents is NOT in the scene at the initial step
+    (no valid history point in ``obs_mask``) and enters at a later replan: masked frames before, valid frames from
+    then on -- get_center_obs lists an agent only while its state is finite (format_utils.py:383-388)."""
     rng = np.random.RandomState(1234 + seed)
     B, N, M, P, H = batch, n_agents, n_polylines, points, spec.hist_steps
     f32 = np.float32
@@ -130,6 +134,15 @@ def make_scene(spec: ModelSpec, n_agents: int, n_polylines: int, batch: int = 1,
             gone = logged & (rng.rand(B, N) < 0.15)            # dropped from the log at this replan: all points masked
             fm[r - 1][gone] = False
             fm[r - 1][~observed] = False
+        if enter > 0:
+            late = logged & (rng.rand(B, N) < enter)
+            first = rng.randint(1, max(2, R - 1), (B, N))              # replan index of the first frame that lists the agent
+            for r in range(1, R):
+                fm[r - 1][late & (first > r)] = False
+            obs_mask = obs_mask.copy()
+            obs_mask[late] = False
+            scene["obs_mask"] = obs_mask
+            scene["obs_input"] = np.where(obs_mask, obs_input, np.nan).astype(f32)
         fi = np.where(fm, fi, np.nan).astype(f32)
         scene.update(fut_obs_input=fi, fut_obs_mask=fm, fut_obs_pos=fp, fut_obs_head=fh)
     cond = {}

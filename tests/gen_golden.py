@@ -60,6 +60,8 @@ FULL_CASES = {
     # replaced; agents re-attend to each other and to the map after every update.  With log-replay agents that
     # drop out of the log (their previous token counts as zeros when they come back).
     "small_fuse_mlp_b2": ("small_mlp", dict(n_agents=16, n_polylines=128, batch=2, seed=7, goal=True, ragged=True, replay=0.4), 0),
+    # log-replay agents that ENTER the scene after the initial step (no history at t0, listed from a later frame on)
+    "small_enter_b2": ("small", dict(n_agents=16, n_polylines=128, batch=2, seed=11, goal=True, ragged=True, replay=0.6, enter=0.6), 0),
     "small_attn_update_b2": ("small_mlp_attn", dict(n_agents=16, n_polylines=128, batch=2, seed=8, ragged=True, replay=0.3), 0),
 }
 SPECS = {"small": SMALL_SPEC, "demo": DEMO_SPEC, "small_mlp": SMALL_SPEC.replace(obs_fusion="mlp"),
