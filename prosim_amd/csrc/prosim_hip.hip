@@ -114,6 +114,9 @@ struct ps_engine {
   // CSR is rebuilt from both whenever either call changes them
   struct CondEnt { int agent, type, id; float v[3]; };
   std::vector<CondEnt> ents_gt, ents_drag;
+  // a condition TYPE that is present in the batch makes the reference run the condition layers over every policy
+  // agent, even when each of its entries is masked off (condition_transformer/base.py:43-49, condition_attns.py:203-204)
+  bool cond_present_gt = false, cond_present_drag = false;
   int n_drag = 0, drag_T = 0;
   DevBuf<float> d_drag_in, d_drag_emd;      // [n_drag][T][2] (NaN -> 0), [n_drag][128]
   DevBuf<uint8_t> d_drag_mask;              // [n_drag][T]
@@ -896,6 +899,7 @@ extern "C" int ps_set_scene(ps_engine* e, int32_t B, int32_t M, int32_t P, int32
   e->ents_gt.clear();
   e->ents_drag.clear();
   e->n_drag = 0;
+  e->cond_present_gt = e->cond_present_drag = false;
   HIPCHK(hipStreamSynchronize(st));
   e->have_scene = true;
   e->encoded = e->generated = e->reset = false;
@@ -959,7 +963,7 @@ static int rebuild_conditions(ps_engine* e) {
     eoff[a + 1] = (int)esrc.size();
   }
   e->n_cond_edges = (int)esrc.size();
-  e->have_cond = e->n_cond_edges > 0;
+  e->have_cond = e->cond_present_gt || e->cond_present_drag;
   e->edge_counts[6] = (float)e->n_cond_edges;
   hipStream_t st = e->stream;
   // at most one self-loop edge per destination: tile offsets coincide with edge offsets
@@ -981,6 +985,14 @@ extern "C" int ps_set_conditions(ps_engine* e, int32_t C_goal, const float* goal
   HIPCHK(hipSetDevice(e->cfg.device));
   const int A = e->A, N = e->N;
   std::vector<ps_engine::CondEnt> ents;
+  // GoalConditionEncoder emits its entry whenever the type has rows (condition_encoders.py:21-51); MotionTagEncoder
+  // emits one per used tag that occurs in the input, whatever the mask says (:106-111)
+  bool present = C_goal > 0 && goal_input;
+  for (size_t i = 0; i < (size_t)e->B * (C_tag > 0 && tag_input ? C_tag : 0); ++i) {
+    const int tag = (int)tag_input[3 * i];
+    present |= tag >= 0 && tag <= 10;
+  }
+  e->cond_present_gt = present;
   // slot -> compact agent index
   std::vector<int> slot2a((size_t)e->B * N, -1);
   for (int i = 0; i < A; ++i) slot2a[e->agent_rows[i]] = i;
@@ -1013,6 +1025,7 @@ extern "C" int ps_set_drag_points(ps_engine* e, int32_t C_drag, int32_t T, const
   if (C_drag <= 0 || !drag_input) {   // clear
     e->ents_drag.clear();
     e->n_drag = 0;
+    e->cond_present_drag = false;
     return rebuild_conditions(e);
   }
   if (e->cfg.drag_mlp_layers <= 0) return fail(PS_E_ARG, "this engine was created without the drag-point encoder (drag_mlp_layers = 0)");
@@ -1042,6 +1055,7 @@ extern "C" int ps_set_drag_points(ps_engine* e, int32_t C_drag, int32_t T, const
     }
   e->n_drag = (int)ents.size();
   e->drag_T = T;
+  e->cond_present_drag = true;   // DragPointEncoder emits its entry whenever the type has rows (:164-191)
   if (e->n_drag > 0) {
     if (upload(e->d_drag_in, pts.data(), pts.size(), e->stream) || upload(e->d_drag_mask, pm.data(), pm.size(), e->stream) ||
         e->d_drag_emd.ensure((size_t)e->n_drag * D))
@@ -1399,6 +1413,7 @@ extern "C" int ps_generate_policy(ps_engine* e) {
   if (e->have_cond && c.cond_layers > 0) {
     if (e->n_drag > 0)
       launch_pointnet(e, e->pn_drag, e->d_drag_in.p, e->d_drag_mask.p, nullptr, e->n_drag, e->drag_T, 0, e->d_drag_emd.p);
+    if (e->n_cond_edges > 0)   // (a present type whose entries are all masked off: the layers still run, without edges)
     hipLaunchKernelGGL(k_cond_edges, dim3(e->n_cond_edges), dim3(128), 0, st, e->cond, (const int*)e->d_ent_off.p,
                        (const int*)e->d_ent_type.p, (const float*)e->d_ent_val.p, (const float*)e->d_drag_emd.p, e->n_cond_edges,
                        e->e_cnd.rtA.p, e->e_cnd.rtT.p, c.ln_eps);

@@ -514,3 +514,36 @@ def test_maximum_scene_size(small_engine):
         small_engine.set_scene(synth.make_scene(spec, 513, 2048, batch=1, seed=1))
     with pytest.raises(RuntimeError, match="P <= 32"):
         small_engine.set_scene(synth.make_scene(spec, 4, 8, batch=1, seed=1, points=33))
+
+
+def test_condition_type_present_but_every_entry_masked(small_engine):
+    """A condition TYPE that is present in the batch makes the reference run the condition layers over every policy
+    agent (without edges they still add their node update to the embedding), even when each entry is masked off:
+    condition_transformer/base.py:43-49, condition_encoders.py:106-111, condition_attns.py:203-228.  Found by the
+    randomised sweep (one agent whose only tag entry was masked)."""
+    spec = SMALL_SPEC
+    w = weights.init_weights(spec, 0)
+    scene = synth.make_scene(spec, 6, 24, batch=2, seed=52, goal=True, tags=True, drag=True)
+    pm = scene["prompt_mask"].astype(bool)
+
+    def emd_of(sc):
+        small_engine.set_scene(sc)
+        small_engine.encode_scene()
+        small_engine.generate_policy()
+        with torch.no_grad():
+            o = orc.rollout(w, spec, sc, dtype=torch.float64)
+        return small_engine.padded("policy_emd")[pm], o["policy_emd"].numpy()[pm]
+
+    none = {k: v for k, v in scene.items() if k != "cond"}
+    got_n, want_n = emd_of(none)
+    for keep in (("goal",), ("v_action_tag",), ("drag_point",), ("goal", "v_action_tag", "drag_point")):
+        cond = {k: dict(scene["cond"][k], mask=np.zeros_like(scene["cond"][k]["mask"])) for k in keep}
+        got, want = emd_of(dict(scene, cond=cond))
+        assert err(got, want) < TOL, keep
+        assert err(want, want_n) > 1e-2, keep            # the layers ran although no entry is valid
+    assert err(got_n, want_n) < TOL
+    # tag rows whose id is no V_Action tag (-1 = invalid) do not make the type present (condition_encoders.py:106-111)
+    tags = dict(scene["cond"]["v_action_tag"], input=scene["cond"]["v_action_tag"]["input"].copy())
+    tags["input"][..., 0] = -1
+    got, want = emd_of(dict(scene, cond={"v_action_tag": tags}))
+    assert err(got, want) < TOL and err(want, want_n) < 1e-9

@@ -26,6 +26,8 @@ for case in range(n_cases):
               replay=float(rng.choice([0.0, 0.0, 0.3, 0.6])), square=float(rng.choice([30.0, 100.0, 200.0])))
     if kw["n_agents"] < 3:
         kw["replay"] = 0.0
+    if kw["replay"] > 0 and rng.rand() < 0.5:
+        kw["enter"] = 0.5                                   # some log-replay agents enter the scene at a later replan
     try:
         scene = synth.make_scene(spec, **kw)
     except Exception as ex:   # a generator corner (e.g. nothing left to replay): not an engine case
