@@ -20,6 +20,12 @@ bad = []
 t0 = time.time()
 for case in range(n_cases):
     spec = variants[rng.randint(len(variants)) if rng.rand() < 0.4 else 0]
+    if rng.rand() < 0.35:   # small neighbour caps / radii: the index-order truncation and the degree-bound paths
+        spec = spec.replace(dec_max_neigh=int(rng.choice([4, 16, 512])), pol_max_neigh=int(rng.choice([3, 12, 768])),
+                            scene_knn=int(rng.choice([2, 8, 32])), dec_prompt_radius=float(rng.choice([20.0, 300.0])),
+                            dec_scene_radius=float(rng.choice([30.0, 300.0])), pol_agent_radius=float(rng.choice([15.0, 100.0])),
+                            pol_map_radius=float(rng.choice([10.0, 50.0])), enc_agent_radius=float(rng.choice([20.0, 100.0])),
+                            enc_scene_radius=float(rng.choice([15.0, 50.0])))
     kw = dict(n_agents=int(rng.choice([1, 2, 3, 7, 16, 33, 64, 100, 150])), n_polylines=int(rng.choice([1, 5, 40, 128, 300, 600])),
               batch=int(rng.choice([1, 2, 3, 5])), seed=int(rng.randint(1 << 20)), goal=bool(rng.rand() < 0.5), tags=bool(rng.rand() < 0.4),
               drag=bool(rng.rand() < 0.4), ragged=bool(rng.rand() < 0.6), clustered=bool(rng.rand() < 0.5),
@@ -33,7 +39,12 @@ for case in range(n_cases):
     except Exception as ex:   # a generator corner (e.g. nothing left to replay): not an engine case
         print(case, "skip (generator):", type(ex).__name__, ex, kw, flush=True)
         continue
-    key = (spec.obs_fusion, spec.obs_attn_update)
+    key = (spec.obs_fusion, spec.obs_attn_update, spec.dec_max_neigh, spec.pol_max_neigh, spec.scene_knn, spec.dec_prompt_radius,
+           spec.dec_scene_radius, spec.pol_agent_radius, spec.pol_map_radius, spec.enc_agent_radius, spec.enc_scene_radius)
+    if len(engines) > 12:   # bounded number of live engines
+        for eng_, _ in engines.values():
+            eng_.close()
+        engines.clear()
     if key not in engines:
         engines[key] = (Engine(spec, weights.init_weights(spec, 0)), weights.init_weights(spec, 0))
     eng, w = engines[key]
