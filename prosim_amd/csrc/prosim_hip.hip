@@ -1175,9 +1175,10 @@ int launch_chain(ps_engine* e, float* x, int Nd, int step0, int nsteps, int maxd
   hipStream_t st = e->stream;
   // rows per workgroup (T).  More rows per workgroup share each weight load; the T >= 2 kernels are built for
   // two workgroups per CU (<= 256 registers, <= 78 KB LDS) so a co-resident workgroup hides latency: take the
-  // largest T that still leaves >= 2 workgroups per CU.  Measured on the 1024-agent policy launch: T=2 (512
-  // WGs) 541 us, T=4 (256 WGs) 770 us, 4 rows on one 8-wave workgroup per CU (code 84) 733 us; the one-workgroup-
-  // per-CU builds with register prefetch (BIG) at T=2 / T=4: 1005 / 879 us (they spill even with 512 registers).
+  // largest T that still leaves >= 2 workgroups per CU.  Measured on the 1024-agent policy launch (end of round 1):
+  // T=2 (512 WGs) 521 us, T=4 (256 WGs) 575 us, 4 rows on one 8-wave workgroup per CU (code 84) 563 us; earlier in
+  // the round the one-workgroup-per-CU builds with register prefetch (BIG) at T=2 / T=4: 1005 / 879 us (they spill
+  // even with 512 registers).
   // Below 512 rows (a single 128-agent scene: fewer workgroups than CUs) a row gets a workgroup of EIGHT waves
   // (code 18: two waves per SIMD, 256 registers each, late weight prefetch) instead of four waves with the whole
   // register file and early prefetch (code 1): 292 -> 280 us per 128-agent policy launch.
