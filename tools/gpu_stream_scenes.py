@@ -23,3 +23,27 @@ for rep in range(2):
     print("per 8-scene batch: set_scene %.2f ms, first rollout %.2f ms, repeated rollout %.2f ms -> stream %.2f M agent-steps/s vs repeated %.2f M"
           % (1e3 * t_set / n, 1e3 * t_first / n, 1e3 * t_second / n, 8 * 128 * 80 / ((t_set + t_first) / n) / 1e6, 8 * 128 * 80 / (t_second / n) / 1e6), flush=True)
 eng.close()
+
+# ---- two engines ping-pong: the host prepares batch k+1 (set_scene on the other engine: its own buffers and stream)
+# while the GPU still runs batch k; results of batch k are read when its engine comes up again
+engs = [Engine(spec, weights.init_weights(spec, 0)) for _ in range(2)]
+for e in engs:
+    e.set_scene(batches[0]); e.rollout(); e.sync()
+for rep in range(2):
+    t0 = time.perf_counter()
+    pending = [None, None]
+    n = 0
+    for k, sc in enumerate(batches * 2):
+        e = engs[k & 1]
+        if pending[k & 1] is not None:
+            e.sync(); _ = e.get("traj"); n += 1          # results of the batch this engine ran two steps ago
+        e.set_scene(sc)
+        e.rollout()
+        pending[k & 1] = k
+    for i in range(2):
+        if pending[i] is not None:
+            engs[i].sync(); _ = engs[i].get("traj"); n += 1
+    dt = time.perf_counter() - t0
+    print("ping-pong (2 engines), results read back: %.2f ms per 8-scene batch -> stream %.2f M agent-steps/s" % (1e3 * dt / n, n * 8 * 128 * 80 / dt / 1e6), flush=True)
+for e in engs:
+    e.close()
