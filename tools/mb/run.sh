@@ -9,3 +9,5 @@ for pat in 0 1 2; do
   done
  done
 done
+# transposed LDS read recipe (next round's single rel-PE image)
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 mb_trread.hip -o mb_trread 2>/dev/null && ./mb_trread
