@@ -587,7 +587,9 @@ extern "C" int ps_create(const ps_config* cfg, int32_t n_tensors, const char* co
     delete e;
     return fail(PS_E_HIP, "layer table upload failed");
   }
-  if (hipStreamCreate(&e->stream) != hipSuccess || hipEventCreate(&e->ev0) != hipSuccess ||
+  // non-blocking: the legacy null stream (synchronous hipMemcpy, another library's default-stream work) does not
+  // serialise against this engine's stream -- two engines on one GPU overlap; every read-back below syncs explicitly
+  if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&e->ev0) != hipSuccess ||
       hipEventCreate(&e->ev1) != hipSuccess) {
     delete e;
     return fail(PS_E_HIP, "stream/event creation failed");
@@ -1678,7 +1680,9 @@ extern "C" int64_t ps_get(ps_engine* e, const char* name, float* dst, int64_t ca
   const std::string n(name);
   auto copy = [&](const float* src, int64_t count) -> int64_t {
     if (count > capacity) return fail(PS_E_ARG, "destination too small for '" + n + "'");
-    if (hipMemcpy(dst, src, sizeof(float) * count, hipMemcpyDeviceToHost) != hipSuccess) return fail(PS_E_HIP, "hipMemcpy D2H");
+    if (hipMemcpyAsync(dst, src, sizeof(float) * count, hipMemcpyDeviceToHost, e->stream) != hipSuccess ||
+        hipStreamSynchronize(e->stream) != hipSuccess)
+      return fail(PS_E_HIP, "hipMemcpy D2H");
     return count;
   };
   if (n == "traj" || n == "vel") {
@@ -1865,6 +1869,7 @@ extern "C" int64_t ps_test_get_edges(ps_engine* e, int32_t which, int32_t* esrc,
   if (which < 0 || which > 5) return fail(PS_E_ARG, "bad edge set");
   EdgeSet& s = *sets[which];
   int E = 0;
+  HIPCHK(hipStreamSynchronize(e->stream));
   if (hipMemcpy(&E, s.eoff.p + s.nq, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return fail(PS_E_HIP, "memcpy");
   if (E > capacity) return fail(PS_E_ARG, "capacity too small");
   if (hipMemcpy(esrc, s.esrc.p, sizeof(int) * E, hipMemcpyDeviceToHost) != hipSuccess ||
