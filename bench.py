@@ -91,6 +91,9 @@ def main():
     ap.add_argument("--scenes-per-gpu", type=int, default=8)
     ap.add_argument("--config", type=int, default=2, help="BASELINE.json config index used as the per-scene workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--inflight", type=int, default=3,
+                    help="rollouts in flight per GPU: consecutive steps alternate between this many engines (own buffers and "
+                         "stream each) that hold the same resident batch, so step k+1 starts while step k drains")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -133,30 +136,37 @@ def main():
     scene = {k: (np.concatenate([p[k] for p in parts]) if not isinstance(parts[0][k], dict) else
                  {ck: {f: np.concatenate([p[k][ck][f] for p in parts]) for f in parts[0][k][ck]} for ck in parts[0][k]})
              for k in parts[0]}
-    eng = Engine(spec, w, device=dev_index)
-    eng.set_scene(scene)
+    # Steps are independent rollouts of the resident batch, so consecutive steps are PIPELINED: `inflight` engines (each
+    # with its own device buffers and non-blocking stream, all holding the same batch) take the steps in turn; the
+    # tail of one rollout (the latency-bound last replans of its slowest workgroups) overlaps the head of the next.
+    # Every step is still a complete rollout of the whole batch inside the timed region.
+    n_fl = max(1, args.inflight)
+    engines = [Engine(spec, w, device=dev_index) for _ in range(n_fl)]
+    for e_ in engines:
+        e_.set_scene(scene)
+    eng = engines[0]
     A = eng.num_agents
     N = scene["prompt_mask"].shape[1]
     from prosim_amd.distributed import SceneMetricGather
-    # The metric gather of rollout k is enqueued behind rollout k on the GPU (event on the engine's stream ->
-    # torch's stream) and the host goes straight on to launch rollout k+1: no host-side wait inside the loop, the
-    # few-KB RCCL all-gather overlaps the next rollout.  Two metric buffers alternate; the engine's stream waits for
-    # the gather that last read a buffer before the metric kernel overwrites it.
-    metric_bufs = [torch.zeros(A, 2, device="cuda") for _ in range(2)]
-    eng_stream = torch.cuda.ExternalStream(eng.stream_handle, device=torch.device("cuda", dev_index))
-    done = [torch.cuda.Event() for _ in range(2)]       # rollout + metric of buffer i finished (engine stream)
-    read = [None, None]                                  # gather of buffer i finished (torch stream)
+    # The metric gather of rollout k is enqueued behind rollout k on the GPU (event on that engine's stream -> torch's
+    # stream) and the host goes straight on to launch rollout k+1: no host-side wait inside the loop, the few-KB RCCL
+    # all-gather overlaps the next rollout.  One metric buffer per engine; an engine's stream waits for the gather that
+    # last read its buffer before the metric kernel overwrites it.
+    metric_bufs = [torch.zeros(A, 2, device="cuda") for _ in range(n_fl)]
+    eng_streams = [torch.cuda.ExternalStream(e_.stream_handle, device=torch.device("cuda", dev_index)) for e_ in engines]
+    done = [torch.cuda.Event() for _ in range(n_fl)]    # rollout + metric of engine i finished (its stream)
+    read = [None] * n_fl                                 # gather of buffer i finished (torch stream)
     gather = SceneMetricGather(my_scenes, n_scenes, N, 2, "cuda" if backend == "nccl" else "cpu") if multi else None
     state = {"k": 0, "last": None}
 
     def step():
-        i = state["k"] & 1
+        i = state["k"] % n_fl
         state["k"] += 1
         if read[i] is not None:
-            eng_stream.wait_event(read[i])
-        eng.rollout()
-        eng.rollout_metric(metric_bufs[i].data_ptr())
-        done[i].record(eng_stream)
+            eng_streams[i].wait_event(read[i])
+        engines[i].rollout()
+        engines[i].rollout_metric(metric_bufs[i].data_ptr())
+        done[i].record(eng_streams[i])
         if not multi:
             state["last"] = metric_bufs[i].view(S, N, 2)
             return
@@ -194,9 +204,12 @@ def main():
     ms_per_step = 1e3 * dt / args.steps
     value = total_agents * spec.max_steps / (dt / args.steps)
     step()
-    eng.sync()
+    for e_ in engines:
+        e_.sync()
     torch.cuda.synchronize()
     metrics = reduce_metrics(state["last"])
+    for e_ in engines[1:]:   # the per-stage / per-kernel timings below run on one engine, alone on the GPU
+        e_.close()
 
     if rank == 0:
         # dominant kernel: the fused policy attention chain (one launch per replan), timed with HIP
@@ -229,7 +242,9 @@ def main():
             "config": {"workload": f"{S} x BASELINE configs[{args.config}] scenes per GPU ({synth.BASELINE_CONFIGS[args.config]['name']}; "
                                    f"S=8 is configs[3]'s per-GPU share), 80-step closed-loop rollout (8 replans), seeded random-init weights",
                        "agents_per_scene": int(scene['prompt_mask'][0].sum()), "polylines_per_scene": int(scene['map_mask'].shape[1]),
-                       "scenes_per_gpu": S, "parallelism": f"scene-sharded x{world}, RCCL all-gather of per-agent ADE/FDE"},
+                       "scenes_per_gpu": S, "rollouts_in_flight": n_fl,
+                       "parallelism": f"scene-sharded x{world}, RCCL all-gather of per-agent ADE/FDE; consecutive steps pipelined over "
+                                      f"{n_fl} engine(s) per GPU"},
             "roofline": {"bound": "mfma", "kernel": "k_attn_chain (policy: 12 fused attention layers per launch)",
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                          "traffic_note": "bytes leaving the L2s per launch = 2 x FETCH_SIZE (gfx950 halves 16 B/lane reads: profiles/r01_g_pmc_calibration.txt) + WRITE_SIZE, "
@@ -242,6 +257,9 @@ def main():
                          "executed_tflops": fl_exe / (ms_chain * 1e-3) / 1e12, "executed_frac": fl_exe / (ms_chain * 1e-3) / 1e12 / peak,
                          "hbm_gbps": (traffic / (ms_chain * 1e-3) / 1e9) if traffic else None, "hbm_peak_gbps": 8000.0,
                          "avg_launch_ms": ms_chain,
+                         "launch_timing": "HIP events on the engine's stream around policy launches that run ALONE on the GPU (after the timed "
+                                          "loop); inside the pipelined loop up to `rollouts_in_flight` rollouts share the CUs and a launch "
+                                          "takes correspondingly longer -- profiles/ holds the kernel trace of `--inflight 1`, whose average agrees",
                          "edges_per_launch": {"a2p": float(ec[4]), "m2p": float(ec[5])}},
             "stage_ms": {"rollout_events": ms_roll, "encode_scene": stages[0], "generate_policy": stages[1], "replan_loop": stages[2]},
             "single_scene": {"ms_per_rollout": ms_single, "agent_steps_per_s": A1 * spec.max_steps / (ms_single * 1e-3),
