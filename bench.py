@@ -222,6 +222,24 @@ def main():
         ms_single, stages1 = eng.time_rollout(2, 10)
         ms_chain1 = eng.time_policy_kernel(2)
         A1 = eng.num_agents
+        # ... and the throughput of that single-scene workload (BASELINE configs[2]) when its rollouts are pipelined:
+        # 128 agents are 128 workgroups on 256 CUs, so rollouts in flight fill the other half of the chip
+        pipe1 = {}
+        for nfl1 in (2, 4):
+            es1 = [Engine(spec, w, device=dev_index) for _ in range(nfl1)]
+            for e_ in es1:
+                e_.set_scene(parts[0])
+                e_.rollout()
+            for e_ in es1:
+                e_.sync()
+            t1 = time.perf_counter()
+            for k_ in range(10 * nfl1):
+                es1[k_ % nfl1].rollout()
+            for e_ in es1:
+                e_.sync()
+            pipe1[str(nfl1)] = A1 * spec.max_steps * 10 * nfl1 / (time.perf_counter() - t1)
+            for e_ in es1:
+                e_.close()
         fl_alg = algorithmic_flops_chain(A, float(ec[4]), float(ec[5]), spec.pol_layers)
         fl_exe = executed_flops_chain(A, float(ec[4]), float(ec[5]), spec.pol_layers)
         peak = 157.3  # TFLOP/s: dense fp32 MFMA peak = fp32 vector peak (MI355X_MICROARCH.md)
@@ -264,6 +282,7 @@ def main():
             "stage_ms": {"rollout_events": ms_roll, "encode_scene": stages[0], "generate_policy": stages[1], "replan_loop": stages[2]},
             "single_scene": {"ms_per_rollout": ms_single, "agent_steps_per_s": A1 * spec.max_steps / (ms_single * 1e-3),
                              "policy_chain_launch_ms": ms_chain1,
+                             "agent_steps_per_s_pipelined": pipe1,   # key = rollouts in flight
                              "stage_ms": {"encode_scene": stages1[0], "generate_policy": stages1[1], "replan_loop": stages1[2]}},
             "rollout_metrics": metrics,
         }
