@@ -1,0 +1,39 @@
+"""prosim_amd.stream.RolloutPipeline: batches pipelined over several engines give the results of one engine, in order."""
+import numpy as np
+import pytest
+
+from prosim_amd import synth, weights
+from prosim_amd.spec import SMALL_SPEC
+
+pytestmark = pytest.mark.gpu
+
+
+def test_pipeline_equals_single_engine_and_keeps_order():
+    from prosim_amd.engine import Engine
+    from prosim_amd.stream import RolloutPipeline
+    spec = SMALL_SPEC
+    w = weights.init_weights(spec, 0)
+    scenes = [synth.make_scene(spec, 6 + 5 * (i % 3), 20 + 17 * i, batch=1 + i % 2, seed=60 + i, goal=bool(i % 2), ragged=bool(i % 3 == 0),
+                               replay=0.4 if i % 4 == 1 else 0.0) for i in range(7)]
+    eng = Engine(spec, w)
+    want = []
+    for sc in scenes:
+        eng.set_scene(sc)
+        eng.rollout()
+        want.append((eng.padded("traj"), eng.get("motion_pred")))
+    eng.close()
+    for depth in (1, 2, 3):
+        with RolloutPipeline(spec, w, depth=depth, outputs=("traj", "motion_pred")) as pipe:
+            got = list(pipe.run(scenes))
+            assert [i for i, _ in got] == list(range(len(scenes)))
+            for (i, out), (traj, mp) in zip(got, want):
+                assert np.array_equal(out["traj"], traj) and np.array_equal(out["motion_pred"], mp), (depth, i)
+            # tickets keep counting across run() calls; an engine that is busy refuses another batch
+            t0 = pipe.submit(scenes[0])
+            for _ in range(depth - 1):
+                pipe.submit(scenes[1])
+            with pytest.raises(RuntimeError, match="collect it"):
+                pipe.submit(scenes[2])
+            assert np.array_equal(pipe.collect(t0)["traj"], want[0][0])
+            with pytest.raises(RuntimeError, match="not in flight"):
+                pipe.collect(t0)
