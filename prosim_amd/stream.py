@@ -4,8 +4,8 @@ A rollout is ~330 dependent launches whose tail is latency-bound, and ``ps_set_s
 work plus its upload.  Engines own their device buffers and a NON-BLOCKING stream each, so while one engine's
 rollout drains on the GPU the host prepares, captures and launches the next batch on another engine and the two
 overlap on the device.  Measured on one MI355X, 8 x 128-agent scenes per batch (tools/gpu_stream_scenes.py,
-bench.py): one engine 8.0 M agent-steps/s over a stream of NEW batches, two engines 9.7 M; 10.7 M for a resident
-batch with three rollouts in flight.
+tools/gpu_pipeline_depth.py, bench.py): over a stream of NEW batches, results read back, depth 1: 7.6 M agent-steps/s,
+2: 9.7 M, 3: 10.2 M, 4: 9.4 M; 10.7 M for a resident batch with three rollouts in flight.
 
 The reference runs its batches strictly one after the other (rollout/callbacks.py); this is the serving-side
 counterpart of its M-replica fan-out (rollout/gpu_utils.py:59-123): independent batches, no data exchanged.
@@ -25,7 +25,7 @@ DEFAULT_OUTPUTS = ("traj", "vel")
 class RolloutPipeline:
     """``depth`` engines on one device; ``run(scenes)`` yields ``(index, outputs)`` in submission order."""
 
-    def __init__(self, spec: ModelSpec, weights: Dict[str, np.ndarray], device: int = 0, depth: int = 2,
+    def __init__(self, spec: ModelSpec, weights: Dict[str, np.ndarray], device: int = 0, depth: int = 3,
                  outputs: Sequence[str] = DEFAULT_OUTPUTS):
         if depth < 1:
             raise ValueError("depth must be >= 1")
