@@ -91,6 +91,8 @@ def main():
     ap.add_argument("--scenes-per-gpu", type=int, default=8)
     ap.add_argument("--config", type=int, default=2, help="BASELINE.json config index used as the per-scene workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--chain-rows", type=int, default=-1, choices=[-1, 0, 2, 4],
+                    help="rows per workgroup of the fused attention launches (ps_set_chain_rows); -1: 4 when rollouts are pipelined, else 0")
     ap.add_argument("--inflight", type=int, default=3,
                     help="rollouts in flight per GPU: consecutive steps alternate between this many engines (own buffers and "
                          "stream each) that hold the same resident batch, so step k+1 starts while step k drains")
@@ -142,7 +144,9 @@ def main():
     # Every step is still a complete rollout of the whole batch inside the timed region.
     n_fl = max(1, args.inflight)
     engines = [Engine(spec, w, device=dev_index) for _ in range(n_fl)]
+    chain_rows = args.chain_rows if args.chain_rows >= 0 else (4 if n_fl > 1 else 0)
     for e_ in engines:
+        e_.set_chain_rows(chain_rows)
         e_.set_scene(scene)
     eng = engines[0]
     A = eng.num_agents
@@ -217,6 +221,11 @@ def main():
         ms_chain = eng.time_policy_kernel(3)
         ec = eng.get("edge_counts")
         ms_roll, stages = eng.time_rollout(1, 5)
+        # one rollout alone on the GPU in the engine's latency mode (2 rows per workgroup, two workgroups per CU)
+        eng.set_chain_rows(0)
+        ms_roll_lat, stages_lat = eng.time_rollout(1, 5)
+        ms_chain_lat = eng.time_policy_kernel(3)
+        eng.set_chain_rows(chain_rows)
         # single-scene latency of the same workload (S = 1), same engine, same run
         eng.set_scene(parts[0])
         ms_single, stages1 = eng.time_rollout(2, 10)
@@ -249,7 +258,8 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_policy_chain.json")
         if os.path.exists(pmc) and S == 8 and args.config == 2:
             with open(pmc) as f:
-                traffic = json.load(f)["hbm_bytes_per_launch"]
+                pj = json.load(f)
+            traffic = pj["hbm_bytes_per_launch"] if chain_rows == 4 else pj["latency_mode_kernel"]["hbm_bytes_per_launch"]
         achieved = fl_alg / (ms_chain * 1e-3) / 1e12
         out = {
             "metric": "agent-steps/sec closed-loop rollout", "value": value, "unit": "agent-steps/s",
@@ -260,10 +270,10 @@ def main():
             "config": {"workload": f"{S} x BASELINE configs[{args.config}] scenes per GPU ({synth.BASELINE_CONFIGS[args.config]['name']}; "
                                    f"S=8 is configs[3]'s per-GPU share), 80-step closed-loop rollout (8 replans), seeded random-init weights",
                        "agents_per_scene": int(scene['prompt_mask'][0].sum()), "polylines_per_scene": int(scene['map_mask'].shape[1]),
-                       "scenes_per_gpu": S, "rollouts_in_flight": n_fl,
+                       "scenes_per_gpu": S, "rollouts_in_flight": n_fl, "chain_rows_per_workgroup": chain_rows,
                        "parallelism": f"scene-sharded x{world}, RCCL all-gather of per-agent ADE/FDE; consecutive steps pipelined over "
                                       f"{n_fl} engine(s) per GPU"},
-            "roofline": {"bound": "mfma", "kernel": "k_attn_chain (policy: 12 fused attention layers per launch)",
+            "roofline": {"bound": "mfma", "kernel": f"k_attn_chain (policy: 12 fused attention layers per launch; {chain_rows or 2} rows per workgroup)",
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                          "traffic_note": "bytes leaving the L2s per launch = 2 x FETCH_SIZE (gfx950 halves 16 B/lane reads: profiles/r01_g_pmc_calibration.txt) + WRITE_SIZE, "
                                          "separate rocprofv3 --pmc passes (profiles/r01_pmc_policy_chain.json); Infinity-Cache hits are counted",
@@ -277,9 +287,13 @@ def main():
                          "avg_launch_ms": ms_chain,
                          "launch_timing": "HIP events on the engine's stream around policy launches that run ALONE on the GPU (after the timed "
                                           "loop); inside the pipelined loop up to `rollouts_in_flight` rollouts share the CUs and a launch "
-                                          "takes correspondingly longer -- profiles/ holds the kernel trace of `--inflight 1`, whose average agrees",
+                                          "takes correspondingly longer -- profiles/ holds the kernel trace of `--inflight 1 --chain-rows 4` (the same "
+                                          "kernel build), whose average agrees",
                          "edges_per_launch": {"a2p": float(ec[4]), "m2p": float(ec[5])}},
             "stage_ms": {"rollout_events": ms_roll, "encode_scene": stages[0], "generate_policy": stages[1], "replan_loop": stages[2]},
+            "latency_mode": {"note": "ps_set_chain_rows(0): one rollout alone on the GPU", "ms_per_rollout": ms_roll_lat,
+                             "encode_scene": stages_lat[0], "generate_policy": stages_lat[1], "replan_loop": stages_lat[2],
+                             "policy_chain_launch_ms": ms_chain_lat},
             "single_scene": {"ms_per_rollout": ms_single, "agent_steps_per_s": A1 * spec.max_steps / (ms_single * 1e-3),
                              "policy_chain_launch_ms": ms_chain1,
                              "agent_steps_per_s_pipelined": pipe1,   # key = rollouts in flight

@@ -145,6 +145,12 @@ int ps_sync(ps_engine* e);
  * ps_set_scene.  ps_policy_step does this on the device from the simulated state; this entry point serves callers
  * that drive the encoder by hand.  Read the tokens back with ps_get("scene_tokens"). */
 int ps_update_obs(ps_engine* e, const float* obs_input, const uint8_t* obs_mask, const float* obs_pos, const float* obs_head);
+/* Destination rows per workgroup of the fused attention launches with >= 512 rows: 0 = the engine's choice for ONE
+ * rollout on the GPU (2 rows, two workgroups per CU: 9.0 ms per 8-scene rollout), 4 = throughput mode for several
+ * engines sharing the GPU (one workgroup per CU and launch, so two rollouts' launches co-reside on every CU and each
+ * streams its weights once per 4 rows: alone 9.6 ms per rollout, with three rollouts in flight 6.7 instead of 7.7 ms
+ * per rollout).  Results do not depend on it beyond fp32 summation order. */
+int ps_set_chain_rows(ps_engine* e, int32_t rows);
 /* The engine's hipStream_t (every entry point enqueues on it), so a host can order its own streams against the
  * engine with events instead of ps_sync -- bench.py overlaps the RCCL metric gather of rollout k with rollout k+1. */
 void* ps_stream(ps_engine* e);

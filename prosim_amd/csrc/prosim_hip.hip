@@ -142,6 +142,7 @@ struct ps_engine {
   // whole-rollout hipGraph (captured on the first ps_rollout after a scene / condition change)
   hipGraph_t graph = nullptr;
   hipGraphExec_t graph_exec = nullptr;
+  int chain_rows = 0;   // ps_set_chain_rows: 0 = latency-optimal choice, 2 | 4 = rows per workgroup for launches of >= 512 rows
   bool graph_ok = false;
   bool use_graph = true;
 };
@@ -1187,6 +1188,9 @@ int launch_chain(ps_engine* e, float* x, int Nd, int step0, int nsteps, int maxd
   int T = Nd >= 2048 ? 4 : (Nd >= 512 ? 2 : 18);
   static const int env_T = getenv("PS_CHAIN_T") ? atoi(getenv("PS_CHAIN_T")) : 0;   // experiments only
   if (env_T && Nd >= 512) T = env_T;
+  if (e->chain_rows && Nd >= 512) T = e->chain_rows;
+  static const int env_TP = getenv("PS_CHAIN_TP") ? atoi(getenv("PS_CHAIN_TP")) : 0;   // experiments only: the policy launch alone
+  if (env_TP && timed && Nd >= 512) T = env_TP;
   static const int env_T1 = getenv("PS_CHAIN_T1") ? atoi(getenv("PS_CHAIN_T1")) : 0;   // experiments only
   if (env_T1 && Nd < 512) T = env_T1;
   if (force_T) T = force_T;
@@ -1637,6 +1641,14 @@ extern "C" int ps_update_obs(ps_engine* e, const float* obs_input, const uint8_t
   HIPCHK(hipStreamSynchronize(st));
   d_in.release(); d_mk.release(); d_pos.release(); d_ori.release();
   e->generated = false;   // a policy generated from the old tokens is stale
+  return PS_OK;
+}
+
+extern "C" int ps_set_chain_rows(ps_engine* e, int32_t rows) {
+  if (!e) return fail(PS_E_ARG, "null engine");
+  if (rows != 0 && rows != 2 && rows != 4) return fail(PS_E_ARG, "ps_set_chain_rows: 0 (auto), 2 or 4");
+  if (rows != e->chain_rows) drop_graph(e);
+  e->chain_rows = rows;
   return PS_OK;
 }
 

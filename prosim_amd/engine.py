@@ -72,6 +72,7 @@ def load_library():
     lib.ps_num_policy_agents.restype = C.c_int32
     lib.ps_update_obs.argtypes = [vp, fp, u8p, fp, fp]
     lib.ps_declare_agent_rows.argtypes = [vp, C.c_int32, C.c_int32, u8p]
+    lib.ps_set_chain_rows.argtypes = [vp, C.c_int32]
     lib.ps_stream.argtypes = [vp]
     lib.ps_stream.restype = C.c_void_p
     lib.ps_policy_flags.argtypes = [vp, i32p, C.c_int64]
@@ -98,7 +99,7 @@ def load_library():
 
 
 EXPORTS = ["ps_create", "ps_destroy", "ps_last_error", "ps_set_scene", "ps_set_prompt", "ps_policy_forward", "ps_set_conditions", "ps_set_drag_points", "ps_set_future_obs", "ps_set_future_log", "ps_num_policy_agents", "ps_policy_flags",
-           "ps_encode_scene", "ps_generate_policy", "ps_reset_rollout", "ps_policy_step", "ps_rollout", "ps_sync", "ps_stream", "ps_update_obs", "ps_declare_agent_rows",
+           "ps_encode_scene", "ps_generate_policy", "ps_reset_rollout", "ps_policy_step", "ps_rollout", "ps_sync", "ps_stream", "ps_set_chain_rows", "ps_update_obs", "ps_declare_agent_rows",
            "ps_set_state", "ps_get", "ps_rollout_metric", "ps_num_agents", "ps_num_map_tokens", "ps_time_rollout", "ps_time_policy_kernel",
            "ps_test_pointnet", "ps_test_fourier", "ps_test_wrap", "ps_test_attn", "ps_test_get_edges", "ps_test_stream"]
 
@@ -298,6 +299,10 @@ class Engine:
 
     def sync(self):
         self._check(self.lib.ps_sync(self.h))
+
+    def set_chain_rows(self, rows: int):
+        """0: latency-optimal (one rollout on the GPU); 4: throughput mode for several engines sharing the GPU."""
+        self._check(self.lib.ps_set_chain_rows(self.h, rows))
 
     @property
     def stream_handle(self) -> int:

@@ -30,6 +30,9 @@ class RolloutPipeline:
         if depth < 1:
             raise ValueError("depth must be >= 1")
         self.engines: List[Engine] = [Engine(spec, weights, device=device) for _ in range(depth)]
+        if depth > 1:   # throughput mode: one workgroup per CU and launch, launches of different rollouts co-reside
+            for e in self.engines:
+                e.set_chain_rows(4)
         self.outputs = tuple(outputs)
         self._pending: List[Optional[int]] = [None] * depth      # ticket each engine is working on
         self._next = 0
