@@ -550,3 +550,34 @@ def test_condition_type_present_but_every_entry_masked(small_engine):
     tags["input"][..., 0] = -1
     got, want = emd_of(dict(scene, cond={"v_action_tag": tags}))
     assert err(got, want) < TOL and err(want, want_n) < 1e-9
+
+
+def test_throughput_mode_rows_per_workgroup(small_engine):
+    """ps_set_chain_rows(4) (throughput mode for pipelined rollouts) changes the tiling of the fused attention launches
+    with >= 512 rows, not the results: same parity against the fp64 oracle, and fp32-summation-order close to the
+    latency-mode rollout of the same scene."""
+    spec = SMALL_SPEC
+    w = weights.init_weights(spec, 0)
+    scene = synth.make_scene(spec, 150, 96, batch=4, seed=71, goal=True, tags=True)
+    with torch.no_grad():
+        o64 = orc.rollout(w, spec, scene, dtype=torch.float64)
+    outs = {}
+    try:
+        for rows in (0, 4, 2):
+            small_engine.set_chain_rows(rows)
+            small_engine.set_scene(scene)
+            small_engine.rollout()
+            A = small_engine.num_agents
+            assert A == 600
+            mp = small_engine.get("motion_pred")
+            assert err(mp[0], o64["motion_pred"][:A].numpy()) < TOL, rows
+            pm = scene["prompt_mask"].astype(bool)
+            d = np.abs(small_engine.padded("traj") - o64["traj"].numpy())[pm].reshape(A, -1).max(1)
+            assert (d < TOL).mean() >= 0.97 and np.median(d) < 3e-5, (rows, d.max())
+            outs[rows] = mp
+        assert np.array_equal(outs[0], outs[2])                       # 0 = the engine's own choice = 2 rows at this size
+        assert err(outs[4][0], outs[0][0]) < 1e-5                     # another tiling, another summation order
+        with pytest.raises(RuntimeError, match="0 .auto., 2 or 4"):
+            small_engine.set_chain_rows(3)
+    finally:
+        small_engine.set_chain_rows(0)
