@@ -9,6 +9,8 @@ from prosim_amd.spec import SMALL_SPEC
 from prosim_amd.engine import Engine
 from oracle import prosim_oracle as orc
 
+# FUZZ_ROWS=4: engines in throughput mode (ps_set_chain_rows(4)) and only batches of >= 512 agent rows, where it matters
+FUZZ_ROWS = int(os.environ.get("FUZZ_ROWS", "0"))
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 torch.set_num_threads(32)
@@ -30,6 +32,8 @@ for case in range(n_cases):
               batch=int(rng.choice([1, 2, 3, 5])), seed=int(rng.randint(1 << 20)), goal=bool(rng.rand() < 0.5), tags=bool(rng.rand() < 0.4),
               drag=bool(rng.rand() < 0.4), ragged=bool(rng.rand() < 0.6), clustered=bool(rng.rand() < 0.5),
               replay=float(rng.choice([0.0, 0.0, 0.3, 0.6])), square=float(rng.choice([30.0, 100.0, 200.0])))
+    if FUZZ_ROWS:
+        kw["n_agents"], kw["batch"] = int(rng.choice([110, 130, 150])), int(rng.choice([5, 6, 8]))
     if kw["n_agents"] < 3:
         kw["replay"] = 0.0
     if kw["replay"] > 0 and rng.rand() < 0.5:
@@ -47,6 +51,7 @@ for case in range(n_cases):
         engines.clear()
     if key not in engines:
         engines[key] = (Engine(spec, weights.init_weights(spec, 0)), weights.init_weights(spec, 0))
+        engines[key][0].set_chain_rows(FUZZ_ROWS)
     eng, w = engines[key]
     with torch.no_grad():
         o64 = orc.rollout(w, spec, scene, dtype=torch.float64)
