@@ -232,9 +232,10 @@ def main():
         ms_chain1 = eng.time_policy_kernel(2)
         A1 = eng.num_agents
         # ... and the throughput of that single-scene workload (BASELINE configs[2]) when its rollouts are pipelined:
-        # 128 agents are 128 workgroups on 256 CUs, so rollouts in flight fill the other half of the chip
+        # 128 agents are 128 workgroups on 256 CUs (two of them fit a CU), so rollouts in flight fill the rest of the chip;
+        # beyond two in flight the host's graph launches (one per ~2 ms rollout) become the limit
         pipe1 = {}
-        for nfl1 in (2, 4):
+        for nfl1 in (2, 6):
             es1 = [Engine(spec, w, device=dev_index) for _ in range(nfl1)]
             for e_ in es1:
                 e_.set_scene(parts[0])

@@ -204,7 +204,7 @@ int ps_test_wrap(ps_engine* e, int32_t n, const float* x, float* out);
 /* One AttentionLayer (models/layers/attention_layer.py:56-121) on caller-supplied tokens and a
  * CSR-by-destination edge list; rt = relative-PE rows already LayerNorm-normalised (no affine).
  * layer_index counts over [a2a | s2s | p2p | s2p | a2p | m2p | cond] layers.  T selects the kernel build:
- * 0 auto, 1 / 2 / 4 destination rows per 256-thread workgroup of the fused chain, 18 = 1 row on 8 waves, 84 = 4 rows on 8 waves,
+ * 0 auto, 1 / 2 / 4 destination rows per 256-thread workgroup of the fused chain, 11 = 1 row on 4 waves built for two workgroups per CU, 18 = 1 row on 8 waves, 84 = 4 rows on 8 waves,
  * 16 = the split layer (k_node + k_edge_small + k_node; falls back to the fused chain above degree 128). */
 int ps_test_attn(ps_engine* e, int32_t layer_index, int32_t Ns, int32_t Nd, int32_t E, const float* x_src,
                  const float* x_dst, const float* rt, const int32_t* eoff, const int32_t* esrc, int32_t T, float* out);

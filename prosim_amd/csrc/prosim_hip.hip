@@ -1182,10 +1182,11 @@ int launch_chain(ps_engine* e, float* x, int Nd, int step0, int nsteps, int maxd
   // T=2 (512 WGs) 521 us, T=4 (256 WGs) 575 us, 4 rows on one 8-wave workgroup per CU (code 84) 563 us; earlier in
   // the round the one-workgroup-per-CU builds with register prefetch (BIG) at T=2 / T=4: 1005 / 879 us (they spill
   // even with 512 registers).
-  // Below 512 rows (a single 128-agent scene: fewer workgroups than CUs) a row gets a workgroup of EIGHT waves
-  // (code 18: two waves per SIMD, 256 registers each, late weight prefetch) instead of four waves with the whole
-  // register file and early prefetch (code 1): 292 -> 280 us per 128-agent policy launch.
-  int T = Nd >= 2048 ? 4 : (Nd >= 512 ? 2 : 18);
+  // Below 512 rows (a single 128-agent scene: fewer workgroups than CUs) a row gets one 4-wave workgroup built for two
+  // workgroups per CU (code 11: 256 registers, late weight prefetch): 274 us per 128-agent policy launch, against 280
+  // for eight waves per row (code 18) and 292 for four waves with the whole register file and early prefetch (code 1)
+  // -- and the workgroups of two pipelined rollouts co-reside on a CU.
+  int T = Nd >= 2048 ? 4 : (Nd >= 512 ? 2 : 11);
   static const int env_T = getenv("PS_CHAIN_T") ? atoi(getenv("PS_CHAIN_T")) : 0;   // experiments only
   if (env_T && Nd >= 512) T = env_T;
   if (e->chain_rows && Nd >= 512) T = e->chain_rows;
@@ -1214,7 +1215,11 @@ int launch_chain(ps_engine* e, float* x, int Nd, int step0, int nsteps, int maxd
   const int kr = steps_host_kr;   // every step of a launch has the same rel-PE width
 #define PS_LAUNCH(TT, NWW, KRR, GRID, LDS) \
   hipLaunchKernelGGL((k_attn_chain<TT, NWW, KRR>), dim3(GRID), dim3(64 * NWW), LDS, st, x, x_in, Nd, steps, nsteps, maxdeg, eps, flags, prof)
-  if (timed && kr == 3 && (T == 1 || T == 2 || T == 4 || T == 18)) {   // the policy launch under its own symbol
+  if (T == 11) {
+    if (kr == 3 && timed) hipLaunchKernelGGL((k_attn_chain<1, 4, 3, false, true>), dim3(Nd), dim3(WG), lds1, st, x, x_in, Nd, steps, nsteps, maxdeg, eps, flags, prof);
+    else if (kr == 3) hipLaunchKernelGGL((k_attn_chain<1, 4, 3, false, false>), dim3(Nd), dim3(WG), lds1, st, x, x_in, Nd, steps, nsteps, maxdeg, eps, flags, prof);
+    else hipLaunchKernelGGL((k_attn_chain<1, 4, 4, false, false>), dim3(Nd), dim3(WG), lds1, st, x, x_in, Nd, steps, nsteps, maxdeg, eps, flags, prof);
+  } else if (timed && kr == 3 && (T == 1 || T == 2 || T == 4 || T == 18)) {   // the policy launch under its own symbol
     if (T == 4) hipLaunchKernelGGL((k_attn_chain<4, 4, 3, false, true>), dim3((Nd + 3) / 4), dim3(WG), lds4, st, x, x_in, Nd, steps, nsteps, maxdeg, eps, flags, prof);
     else if (T == 2) hipLaunchKernelGGL((k_attn_chain<2, 4, 3, false, true>), dim3((Nd + 1) / 2), dim3(WG), lds2, st, x, x_in, Nd, steps, nsteps, maxdeg, eps, flags, prof);
     else if (T == 18) hipLaunchKernelGGL((k_attn_chain<1, 8, 3, false, true>), dim3(Nd), dim3(512), lds18, st, x, x_in, Nd, steps, nsteps, maxdeg, eps, flags, prof);

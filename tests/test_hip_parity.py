@@ -89,7 +89,7 @@ def test_attention_layer_vs_oracle(small_engine, group, prefix, bip, shape):
     eoff = np.cumsum(eoff)
     rt = _rnorm(r) if E else np.zeros((1, 128), np.float32)
     li = small_engine.layer_index(group, int(prefix[-1]))
-    for T in (1, 18, 2, 4, 84, 16):   # rows per workgroup; 18 = 1 row on 8 waves; 84 = 4 rows on 8 waves; 16 = split layer (k_node + k_edge_small) when degree <= 128
+    for T in (1, 11, 18, 2, 4, 84, 16):   # rows per workgroup; 11 = 1 row on 4 waves, two workgroups per CU; 18 = 1 row on 8 waves; 84 = 4 rows on 8 waves; 16 = split layer (k_node + k_edge_small) when degree <= 128
         out = small_engine.test_attn(li, xs.numpy(), xd.numpy(), rt, eoff, src.numpy(), T)
         assert err(out, ref) < 2e-5, (T, err(out, ref))
 
