@@ -850,7 +850,11 @@ __global__ __launch_bounds__(WG) void k_kv_proj(const float* __restrict__ x, int
 // Between two k_node launches the edge kernel (k_edge_small) turns (q, q~, cq) into (ar, av, l).
 // Weights cross the CU once per 16 rows (the fused chain: once per 1-4), the K reductions happen inside the MFMA
 // (no shuffle folds), and with ~100 registers the fragment loads are software-pipelined one group ahead.
-constexpr int ND_ROWS = 16, ND_AS = 136, ND_AS5 = 520, ND_CS = 516, ND_XS = 132;
+// ND_CS: the 128-column GEMM results; ND_CW: the PRE half's wide results (q | s | g = 384 columns, k | v = 256), which
+// live in the FFN planes' memory (dead outside the FFN) -- 75 KB in all, so two workgroups (or one and a 78 KB
+// attention-chain workgroup of another pipelined rollout) share a CU.
+constexpr int ND_ROWS = 16, ND_AS = 136, ND_AS5 = 520, ND_CS = 132, ND_CW = 388, ND_XS = 132;
+static_assert((size_t)ND_ROWS * ND_CW * 4 <= (size_t)2 * ND_ROWS * ND_AS5 * 2, "wide results must fit the FFN planes");
 constexpr size_t ND_LDS_BYTES = (size_t)2 * ND_ROWS * ND_AS * 2 + (size_t)2 * ND_ROWS * ND_AS5 * 2 + (size_t)ND_ROWS * ND_CS * 4 +
                                 (size_t)2 * ND_ROWS * ND_XS * 4 + (size_t)SP_SIZE * 4;
 
@@ -882,9 +886,13 @@ __device__ __forceinline__ void frag_prefetch(FragRing& R, const _Float16* __res
   for (int d = 0; d < ND_DEPTH; ++d)
     if (d < G) frag_issue<K32>(R, d, F, d, wave, lane);
 }
+// ph / pl (optional): instead of C, a finished tile leaves as relu(acc + bias) in split-fp16 planes (row stride ps) -- the
+// FFN-up result goes straight into the A operand of the FFN-down GEMM.
 template <int K32>
 __device__ __forceinline__ void gemm16(FragRing& R, const _Float16* __restrict__ Ah, const _Float16* __restrict__ Al, int as,
-                                       const _Float16* __restrict__ F, int ntiles, float* __restrict__ C, int cs, int wave, int lane) {
+                                       const _Float16* __restrict__ F, int ntiles, float* __restrict__ C, int cs, int wave, int lane,
+                                       _Float16* __restrict__ ph = nullptr, _Float16* __restrict__ pl = nullptr, int ps = 0,
+                                       const float* __restrict__ bias = nullptr) {
   constexpr int KB = K32 < 4 ? K32 : 4, KG = (K32 + KB - 1) / KB;
   const int mi = lane & 15, kq = lane >> 4;
   const int G = ((ntiles - wave + 3) / 4) * KG;
@@ -910,8 +918,18 @@ __device__ __forceinline__ void gemm16(FragRing& R, const _Float16* __restrict__
         }
         if (kg == KG - 1) {
           const int nt = wave + 4 * (g / KG);
+          if (ph) {
+            const float bv = bias[nt * 16 + mi];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) C[(4 * kq + r) * cs + nt * 16 + mi] = acc[r];
+            for (int r = 0; r < 4; ++r) {
+              const float v = fmaxf(acc[r] + bv, 0.f);
+              ph[(4 * kq + r) * ps + nt * 16 + mi] = f16_hi(v);
+              pl[(4 * kq + r) * ps + nt * 16 + mi] = f16_lo(v);
+            }
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) C[(4 * kq + r) * cs + nt * 16 + mi] = acc[r];
+          }
         }
       }
     }
@@ -964,7 +982,8 @@ __global__ __launch_bounds__(256) void k_node(float* __restrict__ x, int Nd, con
   _Float16* P0l = P0h + ND_ROWS * ND_AS;
   _Float16* P1h = P0l + ND_ROWS * ND_AS;
   _Float16* P1l = P1h + ND_ROWS * ND_AS5;
-  float* C = reinterpret_cast<float*>(P1l + ND_ROWS * ND_AS5);
+  float* C = reinterpret_cast<float*>(P1l + ND_ROWS * ND_AS5);   // [16][132] results of the 128-column GEMMs
+  float* Cw = reinterpret_cast<float*>(P1h);                     // [16][388] wide results of the PRE half (FFN planes' memory)
   float* X = C + ND_ROWS * ND_CS;        // [16][132] residual stream
   float* AG = X + ND_ROWS * ND_XS;       // [16][132] agg (POST) / q (PRE)
   float* sp = AG + ND_ROWS * ND_XS;      // [SP_SIZE] the layer's small vectors
@@ -1087,19 +1106,8 @@ __global__ __launch_bounds__(256) void k_node(float* __restrict__ x, int Nd, con
     }
     __syncthreads();
     // ---- FFN: relu(W1 . + b1), W2 . + b2, x = x + LN_ffpost(.)
-    gemm16<4>(R, P0h, P0l, ND_AS, w.F1, 32, C, ND_CS, wave, lane);
+    gemm16<4>(R, P0h, P0l, ND_AS, w.F1, 32, nullptr, 0, wave, lane, P1h, P1l, ND_AS5, sp + SP_B1);
     frag_prefetch<16>(R, w.F2, 8, wave, lane);
-    __syncthreads();
-    {
-      const int c32 = (tid & 15) * 32;
-#pragma unroll
-      for (int q4 = 0; q4 < 4; ++q4) {
-        float f[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) f[i] = fmaxf(C[er * ND_CS + c32 + 8 * q4 + i] + sp[SP_B1 + c32 + 8 * q4 + i], 0.f);
-        planes_store8(P1h + er * ND_AS5 + c32 + 8 * q4, P1l + er * ND_AS5 + c32 + 8 * q4, f);
-      }
-    }
     __syncthreads();
     gemm16<16>(R, P1h, P1l, ND_AS5, w.F2, 8, C, ND_CS, wave, lane);
     if (pre && !kv_out) frag_prefetch<4>(R, pre->w.Fqsg, 24, wave, lane);
@@ -1137,7 +1145,7 @@ __global__ __launch_bounds__(256) void k_node(float* __restrict__ x, int Nd, con
     }
     __syncthreads();
     if (kv_out) {   // k | v of these rows as sources (attention_layer.py:61,65,115-116)
-      gemm16<4>(R, P0h, P0l, ND_AS, w.Wkv_F, 16, C, ND_CS, wave, lane);
+      gemm16<4>(R, P0h, P0l, ND_AS, w.Wkv_F, 16, Cw, ND_CW, wave, lane);
       frag_prefetch<4>(R, w.Fqsg, 24, wave, lane);
       __syncthreads();
       if (live) {
@@ -1145,7 +1153,7 @@ __global__ __launch_bounds__(256) void k_node(float* __restrict__ x, int Nd, con
         for (int half = 0; half < 2; ++half) {
           float v[8];
 #pragma unroll
-          for (int i = 0; i < 8; ++i) v[i] = C[er * ND_CS + half * 128 + ec + i] + (half ? w.bkv[128 + ec + i] : 0.f);
+          for (int i = 0; i < 8; ++i) v[i] = Cw[er * ND_CW + half * 128 + ec + i] + (half ? w.bkv[128 + ec + i] : 0.f);
           float* o = kv_out + (size_t)grow * 256 + half * 128 + ec;
           *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
           *reinterpret_cast<float4*>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
@@ -1160,16 +1168,16 @@ __global__ __launch_bounds__(256) void k_node(float* __restrict__ x, int Nd, con
       }
       __syncthreads();
     }
-    gemm16<4>(R, P0h, P0l, ND_AS, w.Fqsg, 24, C, ND_CS, wave, lane);
+    gemm16<4>(R, P0h, P0l, ND_AS, w.Fqsg, 24, Cw, ND_CW, wave, lane);
     frag_prefetch<1>(R, KR == 3 ? w.Fkr3 : w.Fkr, 8 * 2 * KR, wave, lane);
     __syncthreads();
     {
       float q[8], sv[8], gv[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        q[i] = C[er * ND_CS + ec + i] + sp[SP_BQ + ec + i];
-        sv[i] = C[er * ND_CS + 128 + ec + i] + sp[SP_BS + ec + i];
-        gv[i] = C[er * ND_CS + 256 + ec + i] + sp[SP_BG + ec + i];
+        q[i] = Cw[er * ND_CW + ec + i] + sp[SP_BQ + ec + i];
+        sv[i] = Cw[er * ND_CW + 128 + ec + i] + sp[SP_BS + ec + i];
+        gv[i] = Cw[er * ND_CW + 256 + ec + i] + sp[SP_BG + ec + i];
         AG[er * ND_XS + ec + i] = q[i];
       }
       planes_store8(P0h + er * ND_AS + ec, P0l + er * ND_AS + ec, q);
