@@ -13,6 +13,8 @@ cases = {
  "c25": (SMALL_SPEC, dict(n_agents=100, n_polylines=300, batch=1, seed=809746, goal=False, tags=True, drag=True, ragged=False, clustered=False, replay=0.3, square=30.0)),
  "c50": (SMALL_SPEC.replace(obs_fusion="mlp"), dict(n_agents=150, n_polylines=40, batch=5, seed=377116, goal=False, tags=False, drag=True, ragged=False, clustered=False, replay=0.3, square=100.0)),
 }
+cases["t70"] = (SMALL_SPEC.replace(obs_fusion="mlp"), dict(n_agents=1, n_polylines=300, batch=5, seed=189543, goal=False, tags=False, drag=False, ragged=False, clustered=True, replay=0.0, square=30.0))
+cases["t80"] = (SMALL_SPEC, dict(n_agents=3, n_polylines=128, batch=5, seed=587658, goal=False, tags=False, drag=False, ragged=True, clustered=False, replay=0.0, square=100.0))
 for name in sys.argv[1:] or list(cases):
     spec, kw = cases[name]
     scene = synth.make_scene(spec, **kw)

@@ -69,7 +69,7 @@ for case in range(n_cases):
     # closed loop: within the fp32 floor, or -- the model is DISCONTINUOUS where a neighbour's bearing / relative heading
     # crosses +-pi (the Fourier embedding of a wrapped angle, fourier_embedding.py:56) -- isolated agents knocked off by
     # one such flip while the rest stay on the reference trajectory
-    spike = not (et < 3 * floor + 1e-4) and (per_agent < 1e-3).mean() >= 0.9
+    spike = not (et < 3 * floor + 1e-4) and int((per_agent >= 1e-3).sum()) <= max(1, A // 10)   # (one agent of a 5-agent batch is 20 %)
     ok = e0 < 1e-4 and (et < 3 * floor + 1e-4 or spike)
     worst = max(worst, e0)
     print(case, ("OK*" if spike else "OK ") if ok else "BAD", key, {k: v for k, v in kw.items() if k != "seed"}, "replan0 %.2e traj %.2e floor %.2e" % (e0, et, floor), flush=True)
