@@ -145,12 +145,18 @@ int ps_sync(ps_engine* e);
  * ps_set_scene.  ps_policy_step does this on the device from the simulated state; this entry point serves callers
  * that drive the encoder by hand.  Read the tokens back with ps_get("scene_tokens"). */
 int ps_update_obs(ps_engine* e, const float* obs_input, const uint8_t* obs_mask, const float* obs_pos, const float* obs_head);
-/* Destination rows per workgroup of the fused attention launches with >= 512 rows: 0 = the engine's choice for ONE
- * rollout on the GPU (2 rows, two workgroups per CU: 9.0 ms per 8-scene rollout), 4 = throughput mode for several
- * engines sharing the GPU (one workgroup per CU and launch, so two rollouts' launches co-reside on every CU and each
- * streams its weights once per 4 rows: alone 9.6 ms per rollout, with three rollouts in flight 6.7 instead of 7.7 ms
- * per rollout).  Results do not depend on it beyond fp32 summation order. */
+/* Destination rows per workgroup of the fused attention launches: 0 = the engine's choice for ONE rollout on the GPU
+ * (k_chain16: as many rows as keep >= 256 workgroups in a launch -- 4 at 1024 destinations), 16 = throughput mode for
+ * several engines sharing the GPU (a layer's weights cross a CU once per 16 rows; 64 workgroups per 1024-row launch, so
+ * the launches of three or four rollouts fill the chip side by side).  1, 2, 4, 8, 16 are accepted by k_chain16; the
+ * round-1 kernel (ps_set_chain_impl 1) takes 0, 2, 4.  Results do not depend on it beyond fp32 summation order. */
 int ps_set_chain_rows(ps_engine* e, int32_t rows);
+/* Which fused-chain kernel runs the policy layers (and the other geometric layer chains as they move over):
+ * 0 (default) = k_chain16: node Linears as 16-row MFMA GEMMs, rel-PE rows recomputed per tile from 32 B of geometry per edge;
+ * 1 = k_attn_chain, the round-1 kernel (2-4 rows per workgroup, rel-PE operand images streamed from HBM) -- kept for
+ * A/B measurements and as a second implementation the parity tests compare against.  Resets ps_set_chain_rows to 0 and
+ * invalidates the encoded / generated stages. */
+int ps_set_chain_impl(ps_engine* e, int32_t impl);
 /* The engine's hipStream_t (every entry point enqueues on it), so a host can order its own streams against the
  * engine with events instead of ps_sync -- bench.py overlaps the RCCL metric gather of rollout k with rollout k+1. */
 void* ps_stream(ps_engine* e);
@@ -180,11 +186,25 @@ int ps_set_state(ps_engine* e, int32_t steps, const float* traj, const float* ve
  *   "edge_counts" [8] (a2a, s2s, p2p, s2p, a2p, m2p of the last step, cond, 0) as float.
  * Returns the number of floats written, or a negative error. */
 int64_t ps_get(ps_engine* e, const char* name, float* dst, int64_t capacity);
-/* Per-agent rollout ADE / FDE (metrics/motion_pred.py:31-76, 125-143) computed on device into a
- * caller-owned DEVICE buffer out_dev [A, 2] (e.g. a torch tensor handed to an RCCL all-gather);
- * gt_dev [A, max_steps, 2] is a device pointer to the ground-truth future in the agent-init frame,
- * or NULL for displacement from the origin.  Enqueued on the engine's stream. */
+/* Closed-loop displacement metric on the device: per agent row the mean distance between the rolled-out xy and a
+ * ground-truth future over the steps whose ground truth is finite, and the distance at the LAST such step (the
+ * NaN-masked target / last-valid-index conventions of metrics/motion_pred.py:31-76).  gt_dev [A, max_steps, 2] is a
+ * device pointer to the future in the agent-init frame (NaN = no ground truth), or NULL: then the two numbers are the
+ * mean / final distance from the origin of the agent-init frame (a path length, not an error).  out_dev [A, 2] is a
+ * caller-owned DEVICE buffer (e.g. a torch tensor handed to an RCCL all-gather); rows of log-replay agents and of
+ * agents without a valid step are NaN.  Enqueued on the engine's stream. */
 int ps_rollout_metric(ps_engine* e, const float* gt_dev, float* out_dev);
+/* The reference's validation metric on the device -- PairMotionPred (metrics/motion_pred.py:111-199): per (replan,
+ * agent) pair the ADE / FDE of the arg-max-probability mode and the minima over the K modes (_update_traj_error
+ * :31-76), and the rollout ADE of the chained per-replan predictions against the chained targets (_compute_traj_ade
+ * :125-143 over loss/loss_func.py:215-313 rollout_traj / rollout_temp_traj_preds).  Device pointers:
+ * tgt_dev [R, A, target_steps, 5] local targets per replan (io_pairs_batch['tgt'] in agent-row order, NaN = missing),
+ * pair_mask_dev [R, A] uint8 (io_pairs_batch['mask']), prob_dev [R, A, K] mode probabilities or NULL (mode 0),
+ * out_dev [A, 10] = per agent row (sum ade, sum fde, sum min_ade, sum min_fde, the four counts of finite entries behind
+ * them, rollout ade, 1 if the agent has a valid rollout step); rows of log-replay agents are NaN.  The logged scalars
+ * are sums / counts over the gathered rows and the mean of the valid agents' rollout ade
+ * (prosim_amd.distributed.reduce_pair_metrics).  Enqueued on the engine's stream after the rollout. */
+int ps_pair_metric(ps_engine* e, const float* tgt_dev, const uint8_t* pair_mask_dev, const float* prob_dev, float* out_dev);
 int32_t ps_num_agents(ps_engine* e);
 int32_t ps_num_map_tokens(ps_engine* e);
 

@@ -344,3 +344,59 @@ def make_batch(scene_in, spec):
                        prompt_mask=t(pmask, torch.bool))
     extras["condition"] = cond
     return Extras(extras)
+
+
+# --------------------------------------------------------------------------- the reference's rollout metric
+class _MetricBase(nn.Module):
+    """torchmetrics.Metric stand-in (structural): a module that knows its device."""
+
+    @property
+    def device(self):
+        return torch.device("cpu")
+
+
+class _MeanMetric(_MetricBase):
+    """torchmetrics.MeanMetric as the reference uses it (update(value) with the default weight 1, nan_strategy
+    'warn'): NaN entries of an update are dropped, compute() = sum of the kept values / their count."""
+
+    def __init__(self):
+        super().__init__()
+        self.total = torch.zeros((), dtype=torch.float64)
+        self.count = torch.zeros((), dtype=torch.float64)
+
+    def update(self, value):
+        v = torch.as_tensor(value, dtype=torch.float32).reshape(-1)
+        v = v[~v.isnan()]
+        self.total += v.double().sum()
+        self.count += v.numel()
+
+    def compute(self):
+        return (self.total / self.count).float()
+
+    def reset(self):
+        self.total.zero_()
+        self.count.zero_()
+
+
+def load_pair_metric():
+    """The reference's own PairMotionPred class (metrics/motion_pred.py:111) over its own loss/loss_func.py, with
+    stand-ins for torchmetrics (above) and for prosim.dataset.data_utils.rotate (trajdata-bound, not on this path)."""
+    install()
+    import importlib.util
+
+    def rotate(x, y, angle):
+        return torch.stack([x * torch.cos(angle) - y * torch.sin(angle), x * torch.sin(angle) + y * torch.cos(angle)], dim=-1)
+
+    _mod("torchmetrics", Metric=_MetricBase, MeanMetric=_MeanMetric, Accuracy=_MetricBase)
+    saved = {k: sys.modules.get(k) for k in ("prosim.dataset.data_utils", "prosim.loss.loss_func")}
+    _mod("prosim.dataset.data_utils", rotate=rotate)
+    spec = importlib.util.spec_from_file_location("prosim.loss.loss_func", os.path.join(REF_ROOT, "prosim", "loss", "loss_func.py"))
+    lf = importlib.util.module_from_spec(spec)
+    sys.modules["prosim.loss.loss_func"] = lf
+    spec.loader.exec_module(lf)
+    importlib.import_module("prosim.core.registry")
+    mp = importlib.import_module("prosim.metrics.motion_pred")
+    for k, v in saved.items():   # the rollout harness keeps its own (empty) loss_func stand-in
+        if v is not None and k == "prosim.loss.loss_func":
+            sys.modules[k] = v
+    return mp.PairMotionPred, lf

@@ -15,6 +15,7 @@
 
 #include "ps_attn.h"
 #include "ps_kernels.h"
+#include "ps_chain16.h"
 
 using namespace ps;
 
@@ -34,9 +35,18 @@ static int fail(int code, const std::string& msg) {
 namespace {
 
 template <class T>
-struct DevBuf {
+struct DevBuf {   // owning device allocation: freed by release() or at scope exit; movable, not copyable
   T* p = nullptr;
   size_t n = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  DevBuf(DevBuf&& o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+  DevBuf& operator=(DevBuf&& o) noexcept {
+    if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; }
+    return *this;
+  }
+  ~DevBuf() { release(); }
   int ensure(size_t count) {
     if (count <= n && p) return 0;
     if (p) (void)hipFree(p);
@@ -57,6 +67,7 @@ struct DevBuf {
 struct EdgeSet {  // CSR by destination + normalised rel-PE
   DevBuf<int> cnt, eoff, toff, tdst, esrc, edst;   // toff: offsets in 32-edge tiles (sum of ceil(deg/32)); tdst: tile -> destination
   DevBuf<_Float16> rtA, rtT;                  // rel-PE rows (split fp16) as the two MFMA operand images (32-edge tiles)
+  DevBuf<EdgeGeo> geo;                        // per-edge geometry records: what k_chain16 rebuilds the rel-PE rows from
   size_t cap_edges = 0;
   int nq = 0;
   int maxdeg = 0;
@@ -81,7 +92,7 @@ struct ps_engine {
   PointNetW pn_map{}, pn_obs{}, pn_drag{};   // pn_drag: DragPointEncoder (condition_encoders.py:152), optional
   Mlp3W mlp_prompt{}, mlp_pred{};
   HeadW head{};
-  DevBuf<float> io_q, io_qt, io_cq, io_ar, io_av, io_l, io_s, io_g;   // split path: per-destination vectors (EdgeIO)
+  DevBuf<float> io_q, io_qt, io_cq, io_ar, io_av, io_l, io_s, io_g, io_m;   // split path / k_chain16: per-destination vectors (EdgeIO)
   CondW cond{};
   Mlp3W mlp_obs_fuse{};                     // scene_encoder.obs_update_mlp (OBS_UPDATE.FUSION 'mlp')
   EdgeSet e_ua, e_um;                       // OBS_UPDATE.ATTN_UPDATE: agents <- agents (no self loops), agents <- map
@@ -142,7 +153,8 @@ struct ps_engine {
   // whole-rollout hipGraph (captured on the first ps_rollout after a scene / condition change)
   hipGraph_t graph = nullptr;
   hipGraphExec_t graph_exec = nullptr;
-  int chain_rows = 0;   // ps_set_chain_rows: 0 = latency-optimal choice, 2 | 4 = rows per workgroup for launches of >= 512 rows
+  int chain_rows = 0;   // ps_set_chain_rows: 0 = latency-optimal choice, else rows per workgroup of the fused attention launches
+  int chain_impl = 0;   // ps_set_chain_impl: 0 = k_chain16 (16-row MFMA node phase, recomputed rel-PE) where it applies, 1 = k_attn_chain everywhere
   bool graph_ok = false;
   bool use_graph = true;
 };
@@ -473,6 +485,10 @@ extern "C" int ps_create(const ps_config* cfg, int32_t n_tensors, const char* co
       cfg->target_steps * cfg->state_dim > 64 || cfg->map_pre_layers > 4 || cfg->obs_pre_layers > 4 ||
       cfg->map_mlp_layers - cfg->map_pre_layers > 4 || cfg->obs_mlp_layers - cfg->obs_pre_layers > 4)
     return fail(PS_E_ARG, "unsupported config (hist<=15, obs_dim<=24, map_dim<=24, motion_k==1, steps*state<=64)");
+  if (cfg->replan_freq < 1 || cfg->replan_freq > cfg->target_steps)
+    return fail(PS_E_ARG, "replan_freq must be in 1..target_steps (a replan appends replan_freq of the target_steps predicted states)");
+  if (cfg->pol_max_neigh < 1 || cfg->pol_max_neigh > 2047 || cfg->dec_max_neigh < 1 || cfg->dec_max_neigh > 2047)
+    return fail(PS_E_ARG, "pol_max_neigh / dec_max_neigh must be in 1..2047 (64 rel-PE tiles per destination)");
   if (hipSetDevice(cfg->device) != hipSuccess) return fail(PS_E_HIP, "hipSetDevice failed (no GPU?)");
   ps_engine* e = new ps_engine();
   e->cfg = *cfg;
@@ -550,17 +566,17 @@ extern "C" int ps_create(const ps_config* cfg, int32_t n_tensors, const char* co
   b.plain(&e->cond.div64, "const.fourier_div64", 64);
   b.plain(&e->cond.div128, "const.fourier_div128", 128);
   if (!b.err.empty()) {
-    delete e;
+    ps_destroy(e);   // releases whatever was built so far
     return fail(PS_E_WEIGHT, b.err);
   }
   // upload the arena and rebase every recorded pointer slot
   const size_t nfl = e->arena_h.size();
   if (hipMalloc((void**)&e->arena_d, nfl * sizeof(float)) != hipSuccess) {
-    delete e;
+    ps_destroy(e);   // releases whatever was built so far
     return fail(PS_E_HIP, "hipMalloc(weights) failed");
   }
   if (hipMemcpy(e->arena_d, e->arena_h.data(), nfl * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
-    delete e;
+    ps_destroy(e);   // releases whatever was built so far
     return fail(PS_E_HIP, "hipMemcpy(weights) failed");
   }
   for (const float** p : b.ptrs) {
@@ -585,14 +601,14 @@ extern "C" int ps_create(const ps_config* cfg, int32_t n_tensors, const char* co
   e->all_layers = all;
   if (hipMalloc((void**)&e->d_layers, std::max<size_t>(1, all.size()) * sizeof(AttnW)) != hipSuccess ||
       hipMemcpy(e->d_layers, all.data(), all.size() * sizeof(AttnW), hipMemcpyHostToDevice) != hipSuccess) {
-    delete e;
+    ps_destroy(e);   // releases whatever was built so far
     return fail(PS_E_HIP, "layer table upload failed");
   }
   // non-blocking: the legacy null stream (synchronous hipMemcpy, another library's default-stream work) does not
   // serialise against this engine's stream -- two engines on one GPU overlap; every read-back below syncs explicitly
   if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&e->ev0) != hipSuccess ||
       hipEventCreate(&e->ev1) != hipSuccess) {
-    delete e;
+    ps_destroy(e);   // releases whatever was built so far
     return fail(PS_E_HIP, "stream/event creation failed");
   }
   // the chain kernel may use up to ~140 KiB of dynamic LDS
@@ -603,6 +619,10 @@ extern "C" int ps_create(const ps_config* cfg, int32_t n_tensors, const char* co
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_chain<1, 4, 3, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_chain<2, 4, 3, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_chain<4, 4, 3, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain16<8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c16_lds_bytes<8>());
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain16<8, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c16_lds_bytes<8>());
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain16<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c16_lds_bytes<4>());
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain16<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c16_lds_bytes<4>());
 #define PS_ATTR(TT, NWW, KRR) \
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_chain<TT, NWW, KRR>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
   PS_ATTR(1, 4, 3); PS_ATTR(2, 4, 3); PS_ATTR(4, 4, 3); PS_ATTR(4, 8, 3);
@@ -630,14 +650,14 @@ extern "C" void ps_destroy(ps_engine* e) {
   e->d_static_in.release(); e->d_kv.release(); e->d_kv_s2p.release(); e->d_kv_m2p.release(); e->d_kv_a2p.release();
   e->d_traj.release(); e->d_vel.release(); e->d_motion.release(); e->d_reconst.release();
   e->d_kh.release(); e->d_kh_s2p.release(); e->d_kh_m2p.release(); e->d_kh_a2p.release();
-  for (EdgeSet* s : {&e->e_a2a, &e->e_s2s, &e->e_p2p, &e->e_s2p, &e->e_a2p, &e->e_m2p, &e->e_cnd}) {
-    s->cnt.release(); s->eoff.release(); s->esrc.release(); s->edst.release(); s->toff.release(); s->tdst.release(); s->rtA.release(); s->rtT.release();
+  for (EdgeSet* s : {&e->e_a2a, &e->e_s2s, &e->e_p2p, &e->e_s2p, &e->e_a2p, &e->e_m2p, &e->e_cnd, &e->e_ua, &e->e_um}) {
+    s->cnt.release(); s->eoff.release(); s->esrc.release(); s->edst.release(); s->toff.release(); s->tdst.release(); s->rtA.release(); s->rtT.release(); s->geo.release();
   }
   e->d_steps.release(); e->d_ent_off.release(); e->d_ent_type.release(); e->d_ent_val.release();
   e->d_drag_in.release(); e->d_drag_emd.release(); e->d_drag_mask.release();
   e->d_obs_new.release(); e->d_kv_um.release(); e->d_kh_um.release();
   e->io_q.release(); e->io_qt.release(); e->io_cq.release(); e->io_ar.release(); e->io_av.release(); e->io_l.release();
-  e->io_s.release(); e->io_g.release();
+  e->io_s.release(); e->io_g.release(); e->io_m.release();
   drop_graph(e);
   if (e->arena_d) (void)hipFree(e->arena_d);
   if (e->d_layers) (void)hipFree(e->d_layers);
@@ -664,7 +684,8 @@ int edge_alloc(EdgeSet& s, int nq, size_t cap_edges, int maxdeg) {
   if (s.cnt.ensure(nq + 1) || s.eoff.ensure(nq + 1) || s.toff.ensure(nq + 1) || s.tdst.ensure(cap_edges / 32 + (size_t)nq + 1) ||
       s.esrc.ensure(cap_edges + 1) ||
       s.edst.ensure(cap_edges + 1) ||
-      s.rtA.ensure((cap_edges / 32 + (size_t)nq + 1) * 8192) || s.rtT.ensure((cap_edges / 32 + (size_t)nq + 1) * 8192))
+      s.rtA.ensure((cap_edges / 32 + (size_t)nq + 1) * 8192) || s.rtT.ensure((cap_edges / 32 + (size_t)nq + 1) * 8192) ||
+      s.geo.ensure(cap_edges + 1))
     return -1;
   return 0;
 }
@@ -681,15 +702,23 @@ extern "C" int ps_set_scene(ps_engine* e, int32_t B, int32_t M, int32_t P, int32
   const ps_config& c = e->cfg;
   HIPCHK(hipSetDevice(c.device));
   const int Hs = c.hist_steps, Od = c.obs_dim;
+  // whatever happens below, the previous scene is gone: a caller that catches an error must not be able to replay a
+  // graph (or read results) over buffers this call has already resized
+  e->have_scene = e->encoded = e->generated = e->reset = false;
+  drop_graph(e);
+  struct DeclaredGuard {   // ps_declare_agent_rows is consumed by this call on EVERY exit path
+    std::vector<uint8_t> rows;
+    std::vector<uint8_t>& ref;
+    explicit DeclaredGuard(std::vector<uint8_t>& r) : rows(r), ref(r) { ref.clear(); }
+  } declared_guard(e->declared_rows);
+  const std::vector<uint8_t>& declared_rows = declared_guard.rows;
   e->B = B; e->M = M; e->P = P; e->N = N;
   e->map_rows.clear(); e->agent_rows.clear(); e->agent_scene.clear(); e->map_scene.clear();
   e->is_policy_h.clear();
   e->live0_h.clear();
-  const bool declared = e->declared_rows.size() == (size_t)B * N;
-  if (!e->declared_rows.empty() && !declared) {
-    e->declared_rows.clear();
+  const bool declared = declared_rows.size() == (size_t)B * N;
+  if (!declared_rows.empty() && !declared)
     return fail(PS_E_ARG, "ps_declare_agent_rows was called with another [B, N] than this ps_set_scene");
-  }
   e->moff.assign(B + 1, 0); e->aoff.assign(B + 1, 0);
   e->maxA_scene = e->maxM_scene = 0;
   for (int b = 0; b < B; ++b) {
@@ -711,7 +740,7 @@ extern "C" int ps_set_scene(ps_engine* e, int32_t B, int32_t M, int32_t P, int32
       if (pol && !any)
         return fail(PS_E_ARG, "a policy agent must be observed: its prompt sits in the slot of its history (scene " +
                                   std::to_string(b) + ", slot " + std::to_string(n) + ")");
-      if (any || (declared && e->declared_rows[(size_t)b * N + n])) {   // a declared row without history enters later
+      if (any || (declared && declared_rows[(size_t)b * N + n])) {   // a declared row without history enters later
         e->live0_h.push_back(any ? 1 : 0);
         e->is_policy_h.push_back(pol ? 1 : 0);
         const int ty = agent_type[(size_t)b * N + n];
@@ -728,7 +757,6 @@ extern "C" int ps_set_scene(ps_engine* e, int32_t B, int32_t M, int32_t P, int32
     return fail(PS_E_ARG, "more than 2560 tokens in one scene (knn candidate registers)");
   const int Mv = e->Mv = (int)e->map_rows.size();
   const int A = e->A = (int)e->agent_rows.size();
-  e->declared_rows.clear();
   if (A == 0) return fail(PS_E_ARG, "no valid agents");
   e->have_dead0 = false;
   for (int v : e->live0_h) e->have_dead0 |= v == 0;
@@ -774,9 +802,13 @@ extern "C" int ps_set_scene(ps_engine* e, int32_t B, int32_t M, int32_t P, int32
       upload(e->d_r_map, r_map.data(), r_map.size(), st) || upload(e->d_r_agent, r_agent.data(), r_agent.size(), st) ||
       upload(e->d_r_zero, r_zero.data(), r_zero.size(), st))
     return fail(PS_E_HIP, "geometry upload failed");
+  // staging vectors of the asynchronous uploads below live until the hipStreamSynchronize that ends this call
+  std::vector<float> stat;
+  std::vector<uint8_t> mrows;
+  std::vector<int> off, tof, tds, off2, tof2, tds2;
   // static observation columns (extent, type, time one-hot) default to init_obs
   {
-    std::vector<float> stat((size_t)A * Hs * Od);
+    stat.assign((size_t)A * Hs * Od, 0.f);
     for (int i = 0; i < A; ++i)
       std::memcpy(&stat[(size_t)i * Hs * Od], obs_input + (size_t)e->agent_rows[i] * Hs * Od, sizeof(float) * Hs * Od);
     if (upload(e->d_static_in, stat.data(), stat.size(), st)) return fail(PS_E_HIP, "static obs upload failed");
@@ -784,7 +816,7 @@ extern "C" int ps_set_scene(ps_engine* e, int32_t B, int32_t M, int32_t P, int32
   e->have_fut = false;
   {
     const size_t arow = (size_t)c.hist_steps * c.obs_dim;
-    std::vector<uint8_t> mrows((size_t)A * arow);
+    mrows.assign((size_t)A * arow, 0);
     for (int i = 0; i < A; ++i) std::memcpy(&mrows[(size_t)i * arow], obs_mask + (size_t)e->agent_rows[i] * arow, arow);
     if (upload(e->d_is_policy, e->is_policy_h.data(), (size_t)A, st) || e->d_tok_live.ensure((size_t)A) ||
         upload(e->d_live0, e->live0_h.data(), (size_t)A, st) ||
@@ -825,13 +857,14 @@ extern "C" int ps_set_scene(ps_engine* e, int32_t B, int32_t M, int32_t P, int32
     return fail(PS_E_HIP, "edge allocation failed");
   {   // split-path exchange buffers for the largest destination set (allocated here, never inside a captured rollout)
     EdgeIO io_;
-    if (io_for(e, Mv + A, io_)) return fail(PS_E_HIP, "split-path buffers");
+    if (io_for(e, std::max(Mv + A, 8 * A), io_)) return fail(PS_E_HIP, "split-path buffers");
   }
   // closed-form CSR offsets of the knn graphs (every query gets min(k, scene size) neighbours)
   {
     std::vector<int> nlive(B, 0);   // agents in the scene at the initial step (the kNN candidates)
     for (int i = 0; i < A; ++i) nlive[e->agent_scene[i]] += e->live0_h[i];
-    std::vector<int> off(A + 1, 0), tof(A + 1, 0), tds;
+    off.assign(A + 1, 0);
+    tof.assign(A + 1, 0);
     for (int i = 0; i < A; ++i) {
       const int b = e->agent_scene[i];
       const int dg = mn(c.agent_knn, nlive[b]);
@@ -843,7 +876,8 @@ extern "C" int ps_set_scene(ps_engine* e, int32_t B, int32_t M, int32_t P, int32
         upload(e->e_a2a.tdst, tds.data(), tds.size(), st))
       return fail(PS_E_HIP, "upload failed");
     e->edge_counts[0] = (float)off[A];
-    std::vector<int> off2(Mv + A + 1, 0), tof2(Mv + A + 1, 0), tds2;
+    off2.assign(Mv + A + 1, 0);
+    tof2.assign(Mv + A + 1, 0);
     for (int i = 0; i < Mv + A; ++i) {
       const int b = scene[i];
       const int ns = nlive[b] + (e->moff[b + 1] - e->moff[b]);
@@ -870,6 +904,7 @@ extern "C" int ps_set_scene(ps_engine* e, int32_t B, int32_t M, int32_t P, int32
     s.toff = es.toff.p;
     s.rtT = es.rtT.p;
     s.kr = (&es == &e->e_cnd) ? 4 : 3;
+    s.geo = es.geo.p;
     e->h_steps.push_back(s);
   };
   e->step_a2a = (int)e->h_steps.size();
@@ -1134,10 +1169,10 @@ namespace {
 int io_for(ps_engine* e, int Nd, EdgeIO& io) {
   const size_t n = (size_t)std::max(Nd, 1);
   if (e->io_q.ensure(n * 128) || e->io_qt.ensure(n * 1024) || e->io_cq.ensure(n * 8) || e->io_ar.ensure(n * 1024) ||
-      e->io_av.ensure(n * 128) || e->io_l.ensure(n * 8) || e->io_s.ensure(n * 128) || e->io_g.ensure(n * 128))
+      e->io_av.ensure(n * 128) || e->io_l.ensure(n * 8) || e->io_s.ensure(n * 128) || e->io_g.ensure(n * 128) || e->io_m.ensure(n * 8))
     return -1;
   io.q = e->io_q.p; io.qt = e->io_qt.p; io.cq = e->io_cq.p; io.ar = e->io_ar.p; io.av = e->io_av.p; io.l = e->io_l.p;
-  io.s = e->io_s.p; io.g = e->io_g.p;
+  io.s = e->io_s.p; io.g = e->io_g.p; io.m = e->io_m.p;
   return 0;
 }
 
@@ -1189,7 +1224,8 @@ int launch_chain(ps_engine* e, float* x, int Nd, int step0, int nsteps, int maxd
   int T = Nd >= 2048 ? 4 : (Nd >= 512 ? 2 : 11);
   static const int env_T = getenv("PS_CHAIN_T") ? atoi(getenv("PS_CHAIN_T")) : 0;   // experiments only
   if (env_T && Nd >= 512) T = env_T;
-  if (e->chain_rows && Nd >= 512) T = e->chain_rows;
+  if ((e->chain_rows == 2 || e->chain_rows == 4) && Nd >= 512) T = e->chain_rows;   // (1 / 8 / 16 address k_chain16 only)
+  if (e->chain_rows >= 8 && Nd >= 512) T = 4;   // throughput mode of this kernel
   static const int env_TP = getenv("PS_CHAIN_TP") ? atoi(getenv("PS_CHAIN_TP")) : 0;   // experiments only: the policy launch alone
   if (env_TP && timed && Nd >= 512) T = env_TP;
   static const int env_T1 = getenv("PS_CHAIN_T1") ? atoi(getenv("PS_CHAIN_T1")) : 0;   // experiments only
@@ -1293,8 +1329,76 @@ void launch_relpe(ps_engine* e, EdgeSet& es, const float* src_ori, const float* 
   launch_relpe(e, &a, 1);
 }
 
+// the per-edge geometry records of one or two edge sets (what k_chain16 rebuilds the rel-PE rows from)
+void launch_geo(ps_engine* e, const PeArgs* a, int nsets) {
+  GeoSets gs{};
+  size_t grid = 1;
+  for (int i = 0; i < nsets; ++i) {
+    EdgeSet& es = *a[i].es;
+    gs.s[i] = GeoSet{es.esrc.p, es.edst.p, es.eoff.p, es.nq, a[i].src_ori, a[i].dst_pos, a[i].dst_ori, es.geo.p};
+    grid = std::max(grid, std::min<size_t>(2048, es.cap_edges / 256 + 1));
+  }
+  hipLaunchKernelGGL(k_edge_geo, dim3((unsigned)grid, nsets), dim3(256), 0, e->stream, gs, (const float*)e->d_tok_pos.p, e->div32, e->cfg.ln_eps);
+}
+
+// Fused chain, second generation (ps_chain16.h).  rows per workgroup: the engine's choice keeps >= 256 workgroups in a
+// launch while it can (4 rows at 1024 destinations), ps_set_chain_rows overrides (16 = throughput mode).
+int chain16_rows(ps_engine* e, int Nd) {
+  static const int env_rows = getenv("PS_C16_ROWS") ? atoi(getenv("PS_C16_ROWS")) : 0;   // experiments only
+  int rows = Nd >= 4096 ? 16 : (Nd >= 2048 ? 8 : (Nd >= 512 ? 4 : (Nd >= 256 ? 2 : 1)));
+  if (e->chain_rows == 1 || e->chain_rows == 2 || e->chain_rows == 4 || e->chain_rows == 8 || e->chain_rows == 16) rows = e->chain_rows;
+  if (env_rows) rows = env_rows;
+  return rows;
+}
+int launch_chain16(ps_engine* e, float* x, int Nd, const ChainStep* steps, int nsteps, bool timed, const float* x_in, bool xcd) {
+  if (!x_in) x_in = x;
+  static const int env_nw = getenv("PS_C16_NW") ? atoi(getenv("PS_C16_NW")) : 0;   // experiments only: 4 = two 4-wave workgroups per CU
+  const int nw = env_nw == 4 ? 4 : 8;
+  const int rows = chain16_rows(e, Nd);
+  const int W = rows < nw ? nw / rows : 1;   // waves per row: each leaves its own partial sums (slot = part * Nd + row)
+  EdgeIO io{};
+  if (io_for(e, Nd * W, io)) return fail(PS_E_HIP, "chain scratch buffers");
+  const dim3 grid((Nd + rows - 1) / rows);
+  hipStream_t st = e->stream;
+  if (timed && e->time_chain) (void)hipEventRecord(e->ev0, st);
+  static const bool want_prof = getenv("PS_CHAIN_PROF") != nullptr;   // tools only: in-kernel phase clocks of the timed launches
+  static unsigned long long* d_prof = nullptr;
+  unsigned long long* prof = nullptr;
+  if (want_prof && timed && e->time_chain) {
+    if (!d_prof && hipMalloc(&d_prof, 16 * sizeof(unsigned long long)) != hipSuccess) d_prof = nullptr;
+    if (d_prof) (void)hipMemsetAsync(d_prof, 0, 16 * sizeof(unsigned long long), st);
+    prof = d_prof;
+  }
+#define PS_C16(NWW, POL) \
+  hipLaunchKernelGGL((k_chain16<NWW, POL>), grid, dim3(64 * NWW), c16_lds_bytes<NWW>(), st, x, x_in, Nd, rows, steps, nsteps, io, e->div32, e->cfg.ln_eps, xcd ? 1 : 0, prof)
+  if (nw == 8) {
+    if (timed) PS_C16(8, true); else PS_C16(8, false);
+  } else {
+    if (timed) PS_C16(4, true); else PS_C16(4, false);
+  }
+#undef PS_C16
+  if (timed && e->time_chain) {
+    (void)hipEventRecord(e->ev1, st);
+    (void)hipEventSynchronize(e->ev1);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e->ev0, e->ev1);
+    if (prof) {
+      unsigned long long h[16];
+      (void)hipMemcpy(h, prof, sizeof(h), hipMemcpyDeviceToHost);
+      const int nwg = (Nd + rows - 1) / rows;
+      fprintf(stderr, "[chain16 prof] rows=%d nw=%d wgs=%d %.1f us; mean cycles per workgroup:", rows, nw, nwg, ms * 1e3);
+      static const char* nm[13] = {"PRE", "EDGE", "POST", "-", "rec+kissue", "fourier", "stage+score", "softmax", "a_r", "a_v", "row-epi", "row-pro", "tiles"};
+      for (int i = 0; i < 13; ++i) fprintf(stderr, " %s:%.0f", nm[i], (double)h[i] / nwg);
+      fprintf(stderr, "\n");
+    }
+    e->chain_ms_sum += ms;
+    e->chain_launches++;
+  }
+  return hipGetLastError() == hipSuccess ? 0 : fail(PS_E_HIP, "k_chain16 launch failed");
+}
+
 // radius search + CSR + rel-PE for one or two edge sets over the same queries (count -> scan -> fill -> rel-PE: one
-// launch each for all sets)
+// launch each for all sets).  pe_mode: 1 = the operand images of k_attn_chain, 2 = the geometry records of k_chain16.
 struct RadArgs {
   EdgeSet* es;
   const int *r1, *r2;
@@ -1304,7 +1408,7 @@ struct RadArgs {
   int cand_base = 0;
 };
 void launch_radius(ps_engine* e, const RadArgs* a, int nsets, const float* qpos, const int* qscene, int nq, const float* src_ori,
-                   const float* dst_ori) {
+                   const float* dst_ori, int pe_mode = 1) {
   RadSets rs{};
   for (int i = 0; i < nsets; ++i) {
     EdgeSet& es = *a[i].es;
@@ -1322,13 +1426,14 @@ void launch_radius(ps_engine* e, const RadArgs* a, int nsets, const float* qpos,
   hipLaunchKernelGGL(k_radius<1>, dim3(grid, nsets), dim3(64 * wpb), 0, st, rs, qpos, qscene, nq);
   PeArgs pe[2];
   for (int i = 0; i < nsets; ++i) pe[i] = PeArgs{a[i].es, src_ori, qpos, dst_ori};
-  launch_relpe(e, pe, nsets);
+  if (pe_mode & 1) launch_relpe(e, pe, nsets);
+  if (pe_mode & 2) launch_geo(e, pe, nsets);
 }
 void launch_radius(ps_engine* e, EdgeSet& es, const int* r1, const int* r2, const float* qpos, const int* qscene, int nq, float r,
                    int cap, int self_base, const float* src_ori, const float* dst_ori, const int* cand_ok = nullptr,
-                   int cand_base = 0) {
+                   int cand_base = 0, int pe_mode = 1) {
   RadArgs a{&es, r1, r2, r, cap, self_base, cand_ok, cand_base};
-  launch_radius(e, &a, 1, qpos, qscene, nq, src_ori, dst_ori);
+  launch_radius(e, &a, 1, qpos, qscene, nq, src_ori, dst_ori, pe_mode);
 }
 
 }  // namespace
@@ -1528,11 +1633,13 @@ extern "C" int ps_policy_step(ps_engine* e, int32_t t_idx) {
     const RadArgs ra[2] = {{&e->e_a2p, e->d_r_agent.p, nullptr, c.pol_agent_radius, c.pol_max_neigh, -1,
                             e->all_policy ? nullptr : (const int*)e->d_tok_live.p, Mv},
                            {&e->e_m2p, e->d_r_map.p, nullptr, c.pol_map_radius, c.pol_max_neigh, -1}};
-    launch_radius(e, ra, 2, e->d_cur_pos.p, pscene, A, e->d_tok_ori.p, e->d_cur_ori.p);
+    launch_radius(e, ra, 2, e->d_cur_pos.p, pscene, A, e->d_tok_ori.p, e->d_cur_ori.p, e->chain_impl == 0 ? 2 : 1);
   }
   const int md = std::max(e->e_a2p.maxdeg, e->e_m2p.maxdeg);
   // the policy tokens enter every replan unchanged (d_emd); the fused features leave to d_fused
-  if (launch_chain(e, e->d_fused.p, A, e->step_pol, 2 * c.pol_layers, md, true, nullptr, 0, 0, e->d_emd.p, xcd_on(0, true))) return PS_E_HIP;
+  if (e->chain_impl == 0) {
+    if (launch_chain16(e, e->d_fused.p, A, e->d_steps.p + e->step_pol, 2 * c.pol_layers, true, e->d_emd.p, xcd_on(0, true))) return PS_E_HIP;
+  } else if (launch_chain(e, e->d_fused.p, A, e->step_pol, 2 * c.pol_layers, md, true, nullptr, 0, 0, e->d_emd.p, xcd_on(0, true))) return PS_E_HIP;
   // _compute_traj + step_agent_traj
   hipLaunchKernelGGL(k_policy_head_mfma, dim3((A + 15) / 16), dim3(256), 0, st, e->head, (const float*)e->d_fused.p,
                      (const int*)e->d_agent_type.p, A, c.motion_k, c.target_steps, c.state_dim, e->d_motion.p + (size_t)t_idx * A * c.target_steps * c.state_dim,
@@ -1651,9 +1758,22 @@ extern "C" int ps_update_obs(ps_engine* e, const float* obs_input, const uint8_t
 
 extern "C" int ps_set_chain_rows(ps_engine* e, int32_t rows) {
   if (!e) return fail(PS_E_ARG, "null engine");
-  if (rows != 0 && rows != 2 && rows != 4) return fail(PS_E_ARG, "ps_set_chain_rows: 0 (auto), 2 or 4");
+  if (rows != 0 && rows != 1 && rows != 2 && rows != 4 && rows != 8 && rows != 16) return fail(PS_E_ARG, "ps_set_chain_rows: 0 (auto), 1, 2, 4, 8 or 16");
+  if (e->chain_impl == 1 && rows != 0 && rows != 2 && rows != 4) return fail(PS_E_ARG, "ps_set_chain_rows: k_attn_chain (ps_set_chain_impl 1) takes 0, 2 or 4");
   if (rows != e->chain_rows) drop_graph(e);
   e->chain_rows = rows;
+  return PS_OK;
+}
+
+extern "C" int ps_set_chain_impl(ps_engine* e, int32_t impl) {
+  if (!e) return fail(PS_E_ARG, "null engine");
+  if (impl != 0 && impl != 1) return fail(PS_E_ARG, "ps_set_chain_impl: 0 (k_chain16) or 1 (k_attn_chain)");
+  if (impl != e->chain_impl) {
+    drop_graph(e);
+    e->chain_rows = 0;
+    e->encoded = e->generated = false;   // the edge sets of the finished stages carry the other kernel's rel-PE form
+  }
+  e->chain_impl = impl;
   return PS_OK;
 }
 
@@ -1680,6 +1800,19 @@ extern "C" int ps_rollout_metric(ps_engine* e, const float* gt_dev, float* out_d
   const int R = (c.max_steps + c.replan_freq - 1) / c.replan_freq;
   hipLaunchKernelGGL(k_rollout_metric, dim3((e->A + 127) / 128), dim3(128), 0, e->stream, (const float*)e->d_traj.p, e->stride_steps,
                      c.hist_steps, R * c.replan_freq, gt_dev, e->A, out_dev, e->all_policy ? (const int*)nullptr : (const int*)e->d_is_policy.p);
+  HIPCHK(hipGetLastError());
+  return PS_OK;
+}
+
+extern "C" int ps_pair_metric(ps_engine* e, const float* tgt_dev, const uint8_t* pair_mask_dev, const float* prob_dev, float* out_dev) {
+  if (!e || !e->reset) return fail(PS_E_STATE, "ps_pair_metric before a rollout");
+  if (!tgt_dev || !pair_mask_dev || !out_dev) return fail(PS_E_ARG, "ps_pair_metric: null target / mask / output");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  const ps_config& c = e->cfg;
+  const int R = (c.max_steps + c.replan_freq - 1) / c.replan_freq;
+  hipLaunchKernelGGL(k_pair_metric, dim3((e->A + 127) / 128), dim3(128), 0, e->stream, (const float*)e->d_motion.p, prob_dev, tgt_dev,
+                     pair_mask_dev, R, e->A, c.motion_k, c.target_steps, c.state_dim, c.replan_freq,
+                     e->all_policy ? (const int*)nullptr : (const int*)e->d_is_policy.p, out_dev);
   HIPCHK(hipGetLastError());
   return PS_OK;
 }
@@ -1867,6 +2000,7 @@ extern "C" int ps_test_attn(ps_engine* e, int32_t layer_index, int32_t Ns, int32
   st.w = e->all_layers[layer_index];
   st.kv = dkv.p; st.eoff = doff.p; st.esrc = dsrc.p; st.toff = dtoff.p; st.rtT = drtT.p; st.rtA = drtA.p; st.khl = dkh.p;
   st.kr = 4;   // the hook is handed arbitrary rows: all 128 columns count
+  st.geo = nullptr;
   if (upload(dstep, &st, 1, e->stream)) return fail(PS_E_HIP, "test upload failed");
   if (T == 16 && maxdeg <= ES_MAXDEG) {   // the split layer (k_node + k_edge_small + k_node)
     if (launch_split_layer(e, dxd.p, Nd, dstep.p, 4, maxdeg, nullptr, nullptr)) return PS_E_HIP;
@@ -2011,7 +2145,8 @@ extern "C" int ps_policy_forward(ps_engine* e, int32_t n_scenes, int32_t Na, con
   const int OUT = c.target_steps * c.state_dim;
   std::vector<int> ptype(p_type, p_type + A);
   if (upload(d_pos, pos.data(), pos.size(), st) || upload(d_ori, ori.data(), ori.size(), st) ||
-      upload(d_atok, a_tok, (size_t)std::max(Na, 1) * D, st) || upload(d_mtok, m_tok, (size_t)std::max(Nm, 1) * D, st) ||
+      d_atok.ensure((size_t)std::max(Na, 1) * D) || d_mtok.ensure((size_t)std::max(Nm, 1) * D) ||
+      (Na > 0 && upload(d_atok, a_tok, (size_t)Na * D, st)) || (Nm > 0 && upload(d_mtok, m_tok, (size_t)Nm * D, st)) ||
       upload(d_ppos, p_pos, (size_t)A * 2, st) || upload(d_pori, p_ori, (size_t)A, st) || upload(d_x, p_emd, (size_t)A * D, st) ||
       upload(d_rmap, r_map.data(), r_map.size(), st) || upload(d_ragent, r_agent.data(), r_agent.size(), st) ||
       upload(d_pscene, pscene.data(), pscene.size(), st) || upload(d_ptype, ptype.data(), ptype.size(), st) ||
@@ -2024,20 +2159,22 @@ extern "C" int ps_policy_forward(ps_engine* e, int32_t n_scenes, int32_t Na, con
   std::swap(e->d_tok_pos, d_pos);
   launch_kv(e, d_atok.p, Na, e->L_a2p, L, d_kva.p, d_kha.p, (size_t)Na * 256);
   launch_kv(e, d_mtok.p, Nm, e->L_m2p, L, d_kvm.p, d_khm.p, (size_t)Nm * 256);
-  launch_radius(e, ea, d_ragent.p, nullptr, d_ppos.p, d_pscene.p, A, c.pol_agent_radius, c.pol_max_neigh, -1, d_ori.p, d_pori.p);
-  launch_radius(e, em, d_rmap.p, nullptr, d_ppos.p, d_pscene.p, A, c.pol_map_radius, c.pol_max_neigh, -1, d_ori.p, d_pori.p);
+  const int pe_mode = e->chain_impl == 0 ? 2 : 1;
+  launch_radius(e, ea, d_ragent.p, nullptr, d_ppos.p, d_pscene.p, A, c.pol_agent_radius, c.pol_max_neigh, -1, d_ori.p, d_pori.p, nullptr, 0, pe_mode);
+  launch_radius(e, em, d_rmap.p, nullptr, d_ppos.p, d_pscene.p, A, c.pol_map_radius, c.pol_max_neigh, -1, d_ori.p, d_pori.p, nullptr, 0, pe_mode);
   std::vector<ChainStep> hs;
   for (int i = 0; i < L; ++i) {
     ChainStep s1;
-    s1.w = e->a2p[i]; s1.kv = d_kva.p + (size_t)i * Na * 256 - (size_t)Nm * 256; s1.eoff = ea.eoff.p; s1.esrc = ea.esrc.p; s1.toff = ea.toff.p; s1.rtT = ea.rtT.p; s1.rtA = ea.rtA.p; s1.kr = 3; s1.khl = d_kha.p + (size_t)i * Na * 256 - (size_t)Nm * 256;
+    s1.w = e->a2p[i]; s1.kv = d_kva.p + (size_t)i * Na * 256 - (size_t)Nm * 256; s1.eoff = ea.eoff.p; s1.esrc = ea.esrc.p; s1.toff = ea.toff.p; s1.rtT = ea.rtT.p; s1.rtA = ea.rtA.p; s1.kr = 3; s1.geo = ea.geo.p; s1.khl = d_kha.p + (size_t)i * Na * 256 - (size_t)Nm * 256;
     hs.push_back(s1);
     ChainStep s2;
-    s2.w = e->m2p[i]; s2.kv = d_kvm.p + (size_t)i * Nm * 256; s2.eoff = em.eoff.p; s2.esrc = em.esrc.p; s2.toff = em.toff.p; s2.rtT = em.rtT.p; s2.rtA = em.rtA.p; s2.kr = 3; s2.khl = d_khm.p + (size_t)i * Nm * 256;
+    s2.w = e->m2p[i]; s2.kv = d_kvm.p + (size_t)i * Nm * 256; s2.eoff = em.eoff.p; s2.esrc = em.esrc.p; s2.toff = em.toff.p; s2.rtT = em.rtT.p; s2.rtA = em.rtA.p; s2.kr = 3; s2.geo = em.geo.p; s2.khl = d_khm.p + (size_t)i * Nm * 256;
     hs.push_back(s2);
   }
   int rc = 0;
   if (upload(d_steps, hs.data(), hs.size(), st)) rc = fail(PS_E_HIP, "step upload failed");
-  if (!rc) rc = launch_chain(e, d_x.p, A, 0, 2 * L, std::max(da, dm), false, d_steps.p);
+  if (!rc) rc = e->chain_impl == 0 ? launch_chain16(e, d_x.p, A, d_steps.p, 2 * L, false, nullptr, false)
+                                   : launch_chain(e, d_x.p, A, 0, 2 * L, std::max(da, dm), false, d_steps.p);
   if (!rc) {
     // head with a neutral state (last pose = origin, heading 0): only motion_pred is read back
     (void)hipMemsetAsync(d_traj.p, 0, sizeof(float) * (size_t)A * 16 * 4, st);
@@ -2057,7 +2194,7 @@ extern "C" int ps_policy_forward(ps_engine* e, int32_t n_scenes, int32_t Na, con
   for (DevBuf<float>* b : {&d_pos, &d_ori, &d_atok, &d_mtok, &d_ppos, &d_pori, &d_x, &d_kva, &d_kvm, &d_motion, &d_traj, &d_vel}) b->release();
   for (DevBuf<int>* b : {&d_rmap, &d_ragent, &d_pscene, &d_ptype}) b->release();
   d_kha.release(); d_khm.release();
-  for (EdgeSet* s_ : {&ea, &em}) { s_->cnt.release(); s_->eoff.release(); s_->esrc.release(); s_->edst.release(); s_->toff.release(); s_->tdst.release(); s_->rtA.release(); s_->rtT.release(); }
+  for (EdgeSet* s_ : {&ea, &em}) { s_->cnt.release(); s_->eoff.release(); s_->esrc.release(); s_->edst.release(); s_->toff.release(); s_->tdst.release(); s_->rtA.release(); s_->rtT.release(); s_->geo.release(); }
   d_steps.release();
   return rc;
 }

@@ -60,6 +60,7 @@ struct EdgeIO {
   float* l;    // [Nd][8]        sum_e p_e,h (softmax denominators, running-max scaled like ar / av)
   float* s;    // [Nd][128]      to_s(LN_dst(x)) + bias      (node kernel only)
   float* g;    // [Nd][128]      to_g's x_dst half + bias     (node kernel only)
+  float* m;    // [W][Nd][8]     running maxima of the W partial edge sums of a destination (k_chain16 with W > 1 waves per row)
 };
 
 struct ChainStep {
@@ -75,6 +76,7 @@ struct ChainStep {
   const _Float16* khl;    // [Ns][256]: the k rows of kv as split fp16 (hi | lo)
   int kr;                 // rel-PE column blocks of 32 that are distinct: 3 for geometric edge sets (columns 96..127
                           // repeat 64..95 and are neither stored nor read), 4 for condition rows
+  const void* geo;        // [E] EdgeGeo records (ps_chain16.h): what k_chain16 rebuilds the rel-PE rows from (geometric sets)
 };
 
 // Edge lists are walked in chunks of CH edges per destination with an online (running max / sum)
@@ -865,47 +867,51 @@ constexpr size_t ND_LDS_BYTES = (size_t)2 * ND_ROWS * ND_AS * 2 + (size_t)2 * ND
 // gemm16() consumes group g and requests group g + ND_DEPTH.  (One group ahead hid ~10 % of a 1-2 us round trip:
 // a group's MFMAs take 0.1 us.  k_node runs one workgroup per CU, so the ~160 registers of the ring are free.)
 constexpr int ND_DEPTH = 4;
-struct FragRing {
-  half8 h[ND_DEPTH][4], l[ND_DEPTH][4];
+template <int DEPTH_>
+struct FragRingT {
+  static constexpr int DEPTH = DEPTH_;
+  half8 h[DEPTH_][4], l[DEPTH_][4];
 };
-template <int K32>
-__device__ __forceinline__ void frag_issue(FragRing& R, int slot, const _Float16* __restrict__ F, int g, int wave, int lane) {
+typedef FragRingT<ND_DEPTH> FragRing;
+template <int K32, class RingT, int NWV = 4>
+__device__ __forceinline__ void frag_issue(RingT& R, int slot, const _Float16* __restrict__ F, int g, int wave, int lane) {
   constexpr int KB = K32 < 4 ? K32 : 4, KG = (K32 + KB - 1) / KB;
-  const _Float16* f = F + ((size_t)(wave + 4 * (g / KG)) * K32 + (g % KG) * KB) * 1024 + lane * 8;
+  const _Float16* f = F + ((size_t)(wave + NWV * (g / KG)) * K32 + (g % KG) * KB) * 1024 + lane * 8;
 #pragma unroll
   for (int j = 0; j < KB; ++j) {
     R.h[slot][j] = ldgh8(f + j * 1024);
     R.l[slot][j] = ldgh8(f + j * 1024 + 512);
   }
 }
-template <int K32>
-__device__ __forceinline__ void frag_prefetch(FragRing& R, const _Float16* __restrict__ F, int ntiles, int wave, int lane) {
+template <int K32, class RingT, int NWV = 4>
+__device__ __forceinline__ void frag_prefetch(RingT& R, const _Float16* __restrict__ F, int ntiles, int wave, int lane) {
   constexpr int KB = K32 < 4 ? K32 : 4, KG = (K32 + KB - 1) / KB;
-  const int G = ((ntiles - wave + 3) / 4) * KG;
+  const int G = ((ntiles - wave + NWV - 1) / NWV) * KG;
 #pragma unroll
-  for (int d = 0; d < ND_DEPTH; ++d)
-    if (d < G) frag_issue<K32>(R, d, F, d, wave, lane);
+  for (int d = 0; d < RingT::DEPTH; ++d)
+    if (d < G) frag_issue<K32, RingT, NWV>(R, d, F, d, wave, lane);
 }
 // ph / pl (optional): instead of C, a finished tile leaves as relu(acc + bias) in split-fp16 planes (row stride ps) -- the
 // FFN-up result goes straight into the A operand of the FFN-down GEMM.
-template <int K32>
-__device__ __forceinline__ void gemm16(FragRing& R, const _Float16* __restrict__ Ah, const _Float16* __restrict__ Al, int as,
+template <int K32, class RingT, int NWV = 4>
+__device__ __forceinline__ void gemm16(RingT& R, const _Float16* __restrict__ Ah, const _Float16* __restrict__ Al, int as,
                                        const _Float16* __restrict__ F, int ntiles, float* __restrict__ C, int cs, int wave, int lane,
                                        _Float16* __restrict__ ph = nullptr, _Float16* __restrict__ pl = nullptr, int ps = 0,
                                        const float* __restrict__ bias = nullptr) {
   constexpr int KB = K32 < 4 ? K32 : 4, KG = (K32 + KB - 1) / KB;
   const int mi = lane & 15, kq = lane >> 4;
-  const int G = ((ntiles - wave + 3) / 4) * KG;
+  const int G = ((ntiles - wave + NWV - 1) / NWV) * KG;
   floatx4 acc = {0.f, 0.f, 0.f, 0.f};
-  for (int g0 = 0; g0 < G; g0 += ND_DEPTH) {
+  constexpr int DEPTH = RingT::DEPTH;
+  for (int g0 = 0; g0 < G; g0 += DEPTH) {
 #pragma unroll
-    for (int d = 0; d < ND_DEPTH; ++d) {
+    for (int d = 0; d < DEPTH; ++d) {
       const int g = g0 + d;
       if (g < G) {
         half8 ch[KB], cl[KB];
 #pragma unroll
         for (int j = 0; j < KB; ++j) { ch[j] = R.h[d][j]; cl[j] = R.l[d][j]; }
-        if (g + ND_DEPTH < G) frag_issue<K32>(R, d, F, g + ND_DEPTH, wave, lane);
+        if (g + DEPTH < G) frag_issue<K32, RingT, NWV>(R, d, F, g + DEPTH, wave, lane);
         const int kg = g % KG;
         if (kg == 0) acc = floatx4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -917,7 +923,7 @@ __device__ __forceinline__ void gemm16(FragRing& R, const _Float16* __restrict__
           acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, ch[j], acc, 0, 0, 0);
         }
         if (kg == KG - 1) {
-          const int nt = wave + 4 * (g / KG);
+          const int nt = wave + NWV * (g / KG);
           if (ph) {
             const float bv = bias[nt * 16 + mi];
 #pragma unroll

@@ -1,0 +1,781 @@
+// Fused attention-layer chain, second generation (gfx950): node work on the matrix cores for up to 16 destination
+// rows per workgroup, edge work one wave per destination with the relative-PE rows RECOMPUTED from 32 bytes of
+// geometry per edge instead of streamed from two 384-byte operand images.
+//
+// Reference math: AttentionLayer.forward (prosim/models/layers/attention_layer.py:56-121), rel-PE rows
+// act_decoder.py:203-221 (and twins) through FourierEmbeddingFix (fourier_embedding.py:63-78).
+//
+// Why (round-1 profile of the 1024-agent policy launch): k_attn_chain streams every layer's
+// 960 KB of fp32 weights through each 2-4-row workgroup (21 TB/s of L2 -> CU traffic, half of the launch) and reads
+// 1.05 GB of rel-PE operand images per launch (768 B per edge and layer).  Here
+//   * a workgroup (4 waves) owns R <= 16 rows; every node Linear is a 16-row split-fp16 MFMA GEMM against pre-split
+//     weight fragments (k_node's machinery: the fragment ring stays in flight across epilogues and barriers), so the
+//     weights cross the CU once per 16 rows;
+//   * the edge phase takes one WAVE per destination (rows are handed out through an LDS counter), walks the edge list
+//     in 32-edge tiles with an online softmax (no workgroup barrier inside), and rebuilds each tile's normalised
+//     Fourier rows in registers from (2 pi dist, 2 pi rel_ori, 2 pi angle, rstd, -mean rstd): per (edge, frequency)
+//     one exact division by reciprocal + correction, one Cody-Waite reduction and two degree-7 polynomials.  The rows
+//     feed the score MFMAs straight from registers and the aggregation MFMAs through a wave-private row-major LDS tile
+//     read back with ds_read_b64_tr_b16 (recipe: tools/mb/mb_trread.hip);
+//   * per-destination vectors (q~, s, g, a_r, a_v, l) pass between the phases through the workgroup's own rows of the
+//     EdgeIO scratch (L2-resident; same-CU visibility needs only the workgroup barrier).
+// The 12 policy layers stay one launch per replan; LDS <= 78 KB and <= 256 registers: two workgroups per CU.
+#pragma once
+#include "ps_attn.h"
+
+namespace ps {
+
+// geometry of one edge, made once per edge set (k_edge_geo) and read by every layer of the set
+struct EdgeGeo {
+  float a0, a1, a2;   // 2 pi * (dist, rel_ori, angle): the three distinct FourierEmbeddingFix inputs, already scaled (:66)
+  float rstd, nmr;    // affine-free LayerNorm of the 128-feature row: y = f * rstd + nmr (nmr = -mean * rstd)
+  int src;            // source row (as in esrc)
+  int pad0, pad1;
+};
+static_assert(sizeof(EdgeGeo) == 32, "EdgeGeo is two 16-byte loads");
+
+// x / d for the 16 divisors dim_t[2k] of FourierEmbeddingFix(32), by reciprocal + one correction step: equals the
+// IEEE quotient for every |x| in [2^-24, 65536) and for 0 (checked exhaustively over those inputs: tools/check_fdiv.c;
+// the only mismatches over ALL finite inputs below 65536 sit where the quotient is denormal, |x| < 1e-34 -- a last-bit
+// difference of an argument whose sine is the argument); at and beyond 65536 the caller takes the true division.
+__device__ __forceinline__ float fdiv16(float x, float d, float rd) {
+  const float q0 = x * rd;
+  const float rem = fmaf(-q0, d, x);
+  return fmaf(rem, rd, q0);
+}
+__device__ __forceinline__ bool fdiv16_ok(float x) {
+  const float a = fabsf(x);
+  return a < 65536.f;
+}
+// sin and cos of |a| < 2^13: three-term Cody-Waite reduction by pi/2 (fma: the products are exact), degree-7 kernels on
+// [-pi/4, pi/4]; max abs error 7.4e-8 against the exact values over the arguments the rel-PE rows produce
+// (tools/check_sincos.c) -- torch's own sin/cos are within 1 ulp = 6e-8.
+__device__ __forceinline__ void sincos_cw(float a, float& s, float& c) {
+  const float n = rintf(a * 0.636619747f);
+  float r = fmaf(-n, 1.57079637f, a);
+  r = fmaf(-n, -4.37113883e-8f, r);
+  r = fmaf(-n, -1.71512489e-15f, r);
+  const float z = r * r;
+  const float sp = fmaf(z, fmaf(z, fmaf(z, 2.7183114939898219064e-6f, -1.98393348360966317347e-4f), 8.3333293858894631756e-3f), -0.166666666416265235595f);
+  const float sn = fmaf(r * z, sp, r);
+  const float cp = fmaf(z, fmaf(z, fmaf(z, 2.43904487962774090654e-5f, -1.38867637746099294692e-3f), 4.16666233237390631894e-2f), -0.499999997251031003120f);
+  const float cs = fmaf(z, cp, 1.0f);
+  const int q = (int)n;
+  const float ss = (q & 1) ? cs : sn, cc = (q & 1) ? sn : cs;
+  s = (q & 2) ? -ss : ss;
+  c = ((q + 1) & 2) ? -cc : cc;
+}
+// one (sin, cos) pair of the embedding: argument (x 2 pi) / dim_t exactly as the reference rounds it, then sin / cos
+__device__ __forceinline__ void fourier_pair(float xs, float d, float rd, bool fast, float& s, float& c) {
+  if (fast) {
+    sincos_cw(fdiv16(xs, d, rd), s, c);
+  } else {
+    sincosf(xs / d, &s, &c);
+  }
+}
+
+// ---- per edge set and replan: the geometry records.  One thread per edge: the three scalars (act_decoder.py:203-217),
+// then all 48 distinct (sin, cos) pairs once for the LayerNorm statistics of the 128-feature row (the angle block
+// counts twice: features 96..127 repeat 64..95).
+struct GeoSet {
+  const int *esrc, *edst, *eoff;
+  int nq;
+  const float *src_ori, *dst_pos, *dst_ori;
+  EdgeGeo* geo;
+};
+struct GeoSets {
+  GeoSet s[2];
+};
+__global__ __launch_bounds__(256) void k_edge_geo(GeoSets sets, const float* __restrict__ src_pos, const float* __restrict__ div32,
+                                                 float eps) {
+  const GeoSet& S = sets.s[blockIdx.y];
+  const int E = S.eoff[S.nq];
+  float dv[16], rdv[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    dv[k] = div32[2 * k];
+    rdv[k] = 1.0f / dv[k];
+  }
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < E; e += gridDim.x * blockDim.x) {
+    const int d = S.edst[e], s = S.esrc[e];
+    const float px = S.dst_pos[2 * d], py = S.dst_pos[2 * d + 1], od = S.dst_ori[d];
+    const float cx = cosf(od), cy = sinf(od);
+    const float dx = src_pos[2 * s] - px, dy = src_pos[2 * s + 1] - py;
+    float xin[3];
+    xin[0] = sqrtf(dx * dx + dy * dy);
+    xin[1] = wrap_angle(S.src_ori[s] - od);
+    // torch's .sum(dim=-1) accumulates from +0, so a dot of (-0, -0) is +0 there: keep the explicit 0.f + ...
+    const float dot = (0.f + cx * dx) + cy * dy;
+    xin[2] = atan2f(cx * dy - cy * dx, dot);
+    float xs[3];
+    bool fast = true;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      xs[i] = xin[i] * PS_TWO_PI_F;
+      fast = fast && fdiv16_ok(xs[i]);
+    }
+    // two passes like torch's LayerNorm (mean, then centred squares); the pairs are recomputed instead of stored
+    float sm = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      float part = 0.f;
+      for (int k = 0; k < 16; ++k) {
+        float sv, cv;
+        fourier_pair(xs[i], dv[k], rdv[k], fast, sv, cv);
+        part += sv + cv;
+      }
+      sm += (i == 2) ? 2.f * part : part;
+    }
+    const float mean = sm * (1.f / 128.f);
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      float part = 0.f;
+      for (int k = 0; k < 16; ++k) {
+        float sv, cv;
+        fourier_pair(xs[i], dv[k], rdv[k], fast, sv, cv);
+        sv -= mean;
+        cv -= mean;
+        part = fmaf(sv, sv, part);
+        part = fmaf(cv, cv, part);
+      }
+      sq += (i == 2) ? 2.f * part : part;
+    }
+    const float rstd = 1.f / sqrtf(sq * (1.f / 128.f) + eps);
+    EdgeGeo g;
+    g.a0 = xs[0]; g.a1 = xs[1]; g.a2 = xs[2];
+    g.rstd = rstd;
+    g.nmr = -mean * rstd;
+    g.src = s;
+    g.pad0 = g.pad1 = 0;
+    S.geo[e] = g;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// LDS plan (bytes): k_node's node-phase buffers, then cq and the row counter, then whatever the wave-private areas of
+// the edge phase (k staging 4 KB | probability tile 0.5 KB | feature tile 3.5 KB | source rows of the tile 64 B) need
+// beyond the operand planes and the GEMM result buffer, which they alias (dead while the edge phase runs).
+constexpr int C16_FS = 112;   // feature-tile row stride in halfs: 96 features + 16 pad = 56 dwords, so the 8 rows x 32 B that a
+                              // half-wave's transposed read touches (and the 8 rows of a b128 write group) fall on distinct banks
+constexpr size_t C16_NODE_BYTES = ND_LDS_BYTES;
+constexpr size_t C16_PLANES_BYTES = (size_t)2 * ND_ROWS * ND_AS * 2 + (size_t)2 * ND_ROWS * ND_AS5 * 2 + (size_t)ND_ROWS * ND_CS * 4;   // P0 | P1 | C
+constexpr size_t C16_WAVE_BYTES = 4096 + 512 + (size_t)16 * C16_FS * 2 + 64;
+template <int NWV>
+constexpr size_t c16_lds_bytes() {
+  return (NWV * C16_WAVE_BYTES > C16_PLANES_BYTES ? NWV * C16_WAVE_BYTES - C16_PLANES_BYTES : 0) + C16_NODE_BYTES + 16 * 8 * 4 + 64;
+}
+
+typedef __fp16 fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+
+// this lane's 8 consecutive features (4 pairs) of input block xs, normalised and split: A-fragment order of the
+// score MFMAs (lane = edge + 16 kq holds features 8 kq .. 8 kq + 7 of the 32-feature block)
+__device__ __forceinline__ void feat8(float xs, float rstd, float nmr, const float (&dv)[4], const float (&rdv)[4], half8& hi, half8& lo) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float s, c;
+    sincos_cw(fdiv16(xs, dv[j], rdv[j]), s, c);
+    const float ys = fmaf(s, rstd, nmr), yc = fmaf(c, rstd, nmr);
+    hi[2 * j] = f16_hi(ys);
+    lo[2 * j] = f16_lo(ys);
+    hi[2 * j + 1] = f16_hi(yc);
+    lo[2 * j + 1] = f16_lo(yc);
+  }
+}
+// the same outside fdiv16's checked range (a distance beyond 10 km): true division, libm sincos.  Rolled, and through LDS
+// (hi halfs into the feature tile row, lo halfs into `lrow`): the rare path must not cost the common one registers.
+__device__ __forceinline__ void feat_slow_row(float a0, float a1, float a2, float rstd, float nmr, const float (&dv)[4], int kq,
+                                              _Float16* __restrict__ hrow, _Float16* __restrict__ lrow) {
+#pragma unroll 1
+  for (int i = 0; i < 12; ++i) {
+    const int ks = i >> 2, j = i & 3;
+    const float xs = ks == 0 ? a0 : (ks == 1 ? a1 : a2);
+    const float d = j == 0 ? dv[0] : (j == 1 ? dv[1] : (j == 2 ? dv[2] : dv[3]));
+    float sv, cv;
+    sincosf(xs / d, &sv, &cv);
+    const float ys = fmaf(sv, rstd, nmr), yc = fmaf(cv, rstd, nmr);
+    const int c = 32 * ks + 8 * kq + 2 * j;
+    hrow[c] = f16_hi(ys);
+    hrow[c + 1] = f16_hi(yc);
+    lrow[c] = f16_lo(ys);
+    lrow[c + 1] = f16_lo(yc);
+  }
+}
+
+// The edge phase of one layer for the rows of a workgroup (called once per layer).  Out of line on purpose: inlined into
+// the layer loop its register pressure makes the allocator spill the weight-fragment ring of the node GEMMs; as a
+// function it gets an allocation of its own.  smem = the workgroup's dynamic LDS (wave areas from its start), AG / CQ /
+// ctr = the node phase's q rows, <q, kb> and the row counter.
+template <int NWV>
+__device__ __noinline__ void c16_edge_phase(const ChainStep* __restrict__ stp, EdgeIO io, unsigned char* c16_smem, const float* AG,
+                                            const float* CQ, int* ctr, const float* __restrict__ div32, int row0, int nrows, int W, int Nd,
+                                            unsigned long long* __restrict__ prof) {
+  const ChainStep& st = *stp;
+  long long tprev = (prof && threadIdx.x == 0) ? clock64() : 0;
+#define C16_EMARK(i)                                                  \
+  do {                                                                \
+    if (prof && threadIdx.x == 0) {                                   \
+      const long long now_ = clock64();                               \
+      atomicAdd(prof + (i), (unsigned long long)(now_ - tprev));      \
+      tprev = now_;                                                   \
+    }                                                                 \
+  } while (0)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int mi = lane & 15, kq = lane >> 4;
+    // =========================================================== EDGE: W waves per destination row (or a queue of rows per wave)
+    {
+      // this lane's four frequencies (pairs 4 kq .. 4 kq + 3 of every 32-feature block) and their reciprocals
+      float dv[4], rdv[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        dv[j] = ldg1(div32 + 2 * (4 * kq + j));
+        rdv[j] = 1.0f / dv[j];
+      }
+      unsigned char* wbase = c16_smem + (size_t)wave * C16_WAVE_BYTES;
+      half8* stg = reinterpret_cast<half8*>(wbase);                               // k staging (swizzled, as in k_attn_chain)
+      float* Pt = reinterpret_cast<float*>(wbase + 4096);                         // [16 edges][8 heads] probabilities
+      _Float16* Ft = reinterpret_cast<_Float16*>(wbase + 4096 + 512);             // [16 edges][C16_FS] feature tile (hi, then lo)
+      int* Ss = reinterpret_cast<int*>(wbase + 4096 + 512 + 16 * C16_FS * 2);     // [16] source rows of the tile
+      const EdgeGeo* __restrict__ geo = reinterpret_cast<const EdgeGeo*>(st.geo);
+      const int rq = lane >> 2, pq = lane & 3;
+      half8* stw = stg + rq * 16 + (pq ^ (rq >> 2));
+      const half8* str = stg + mi * 16 + (kq ^ (mi >> 2));
+      const int swa = rq & 3, sra = mi & 3;
+      const bool loA = mi >= 8;
+      const int hv = (lane & 31) >> 2, eh = lane >> 5;
+      for (int it = 0;; ++it) {
+        int lr, part;
+        if (W > 1) {   // static: wave -> (row wave / W, part wave % W)
+          if (it > 0) break;
+          lr = wave / W;
+          part = wave - lr * W;
+        } else {       // dynamic: the next row of the workgroup
+          lr = 0;
+          if (lane == 0) lr = atomicAdd(ctr, 1);
+          lr = __builtin_amdgcn_readfirstlane(lr);
+          part = 0;
+        }
+        if (lr >= nrows) break;
+        const int r = row0 + lr;
+        const int e_beg = ldgi(st.eoff + r);
+        const int deg = ldgi(st.eoff + r + 1) - e_beg;
+        const int tstep = 16 * W;
+        // Tiles of 16 edges (one score block).  Tile t0's geometry and source rows are requested one tile ahead (registers).
+        int t0 = 16 * part;
+        float4 ng;
+        float nn = 0.f;
+        int nsrc = 0;
+        auto prefetch = [&](int tt) {
+          const int n_ = min(16, deg - tt);
+          if (n_ > 0) {
+            const EdgeGeo* gp = geo + e_beg + tt + min(mi, n_ - 1);
+            ng = ldg4(reinterpret_cast<const float*>(gp));
+            nn = ldg1(reinterpret_cast<const float*>(gp) + 4);
+            nsrc = ldgi(reinterpret_cast<const int*>(gp) + 5);   // (lanes 0-15 publish it)
+          }
+        };
+        prefetch(t0);
+        // B operands of the score MFMAs: lane -> column n = mi (head mi & 7, hi | lo half), k-block kq
+        half8 bq[3], bk[4];
+        float cqm;
+        {
+          const int hB = mi & 7;
+          const float* qtp = io.qt + (size_t)r * 1024 + hB * 128 + 8 * kq;
+          const float* qp = AG + lr * ND_XS + 8 * kq;
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) {
+            if (ks < 3) {
+              const float4 v0 = ldg4(qtp + 32 * ks), v1 = ldg4(qtp + 32 * ks + 4);
+              const float qv_[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+              for (int j = 0; j < 8; ++j) bq[ks < 3 ? ks : 0][j] = loA ? f16_lo(qv_[j]) : f16_hi(qv_[j]);
+            }
+            const bool mine = (2 * ks + (kq >> 1)) == hB;   // the 8 columns 32 ks + 8 kq lie inside head 2 ks + (kq >> 1)
+            const float4 w0 = *reinterpret_cast<const float4*>(qp + 32 * ks), w1 = *reinterpret_cast<const float4*>(qp + 32 * ks + 4);
+            const float kv_[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const float kk = mine ? kv_[j] : 0.f;
+              bk[ks][j] = loA ? f16_lo(kk) : f16_hi(kk);
+            }
+          }
+          cqm = CQ[lr * 8 + hB];
+        }
+        C16_EMARK(11);
+        float m_run = -INFINITY, l_run = 0.f;   // of head mi & 7 (the lanes mi and mi + 8, all kq, carry copies)
+        floatx4 ar[6];
+#pragma unroll
+        for (int cb = 0; cb < 6; ++cb) ar[cb] = floatx4{0.f, 0.f, 0.f, 0.f};
+        float4 av = make_float4(0.f, 0.f, 0.f, 0.f);   // a_v partial: columns 4 (lane & 31) ..+3, edges of parity lane >> 5
+        const float* vbase = st.kv + 128 + 4 * (lane & 31);
+#pragma unroll 1
+        for (; t0 < deg; t0 += tstep) {
+          const int n = min(16, deg - t0);
+          // this tile's records (requested a tile ago); the next tile's leave now
+          const float4 g0 = ng;
+          const float nmr = nn;
+          if (lane < 16) Ss[lane] = nsrc;
+          prefetch(t0 + tstep);
+          // the k rows leave before the Fourier rows are computed
+          half8 nkh[4], nkl[4];
+          {
+            const _Float16* kp = st.khl + (size_t)Ss[min(rq, n - 1)] * 256 + 8 * pq;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+              nkh[ks] = ldgh8(kp + 32 * ks);
+              nkl[ks] = ldgh8(kp + 128 + 32 * ks);
+            }
+          }
+          C16_EMARK(4);
+          if (prof && threadIdx.x == 0) atomicAdd(prof + 12, 1ull);
+          float sreg[4];
+          half8 fl[3];
+          {
+            const bool fast = !__any(!(fdiv16_ok(g0.x) && fdiv16_ok(g0.y) && fdiv16_ok(g0.z)));
+            half8 fh[3];
+            if (fast) {
+              feat8(g0.x, g0.w, nmr, dv, rdv, fh[0], fl[0]);
+              feat8(g0.y, g0.w, nmr, dv, rdv, fh[1], fl[1]);
+              feat8(g0.z, g0.w, nmr, dv, rdv, fh[2], fl[2]);
+#pragma unroll
+              for (int ks = 0; ks < 3; ++ks) *reinterpret_cast<half8*>(Ft + mi * C16_FS + 32 * ks + 8 * kq) = fh[ks];
+            } else {   // (the staging area is free until the k rows are staged below)
+              _Float16* lrow = reinterpret_cast<_Float16*>(stg) + mi * C16_FS;
+              feat_slow_row(g0.x, g0.y, g0.z, g0.w, nmr, dv, kq, Ft + mi * C16_FS, lrow);
+#pragma unroll
+              for (int ks = 0; ks < 3; ++ks) {
+                fh[ks] = *reinterpret_cast<const half8*>(Ft + mi * C16_FS + 32 * ks + 8 * kq);
+                fl[ks] = *reinterpret_cast<const half8*>(lrow + 32 * ks + 8 * kq);
+              }
+            }
+            C16_EMARK(5);
+            // k rows: quad-contiguous gather -> fragments through the swizzled staging area; scores on the matrix cores
+            floatx4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+            half8 ak[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) stw[4 * (ks ^ swa)] = nkh[ks];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) ak[ks] = str[4 * (ks ^ sra)];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+              if (ks < 3) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[ks < 3 ? ks : 0], bq[ks < 3 ? ks : 0], acc, 0, 0, 0);
+              acc2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ak[ks], bk[ks], acc2, 0, 0, 0);
+            }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) stw[4 * (ks ^ swa)] = nkl[ks];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) ak[ks] = str[4 * (ks ^ sra)];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+              if (ks < 3) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl[ks < 3 ? ks : 0], bq[ks < 3 ? ks : 0], acc, 0, 0, 0);
+              acc2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ak[ks], bk[ks], acc2, 0, 0, 0);
+            }
+            acc += acc2;
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+              const float v = acc[r4] + dpp_xor8(acc[r4]);   // columns h and h + 8 (q hi | q lo)
+              sreg[r4] = (4 * kq + r4 < n) ? (v + cqm) * 0.25f : -INFINITY;
+            }
+          }
+          C16_EMARK(6);
+          // v rows of the tile leave now (the k registers are dead) and fly under the softmax and the a_r MFMAs:
+          // gathered by source, two rows per load instruction
+          float4 vv[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) vv[j] = ldg4(vbase + (size_t)Ss[min(2 * j + eh, n - 1)] * 256);
+          // ---- online softmax over the tile (torch_geometric.utils.softmax: max-shift, exp, / (sum + 1e-16))
+          float tmax = fmaxf(fmaxf(sreg[0], sreg[1]), fmaxf(sreg[2], sreg[3]));
+          tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
+          tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+          const float m_new = fmaxf(m_run, tmax);   // finite: the tile has at least one edge
+          const float scale = (m_run == -INFINITY) ? 0.f : expf(m_run - m_new);
+          float psum = 0.f;
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4) {
+            const float p = expf(sreg[r4] - m_new);   // exp(-inf) = 0 for the slots past the edge list
+            psum += p;
+            if (mi < 8) Pt[(4 * kq + r4) * 8 + mi] = p;
+          }
+          psum += __shfl_xor(psum, 16);
+          psum += __shfl_xor(psum, 32);
+          l_run = l_run * scale + psum;
+          m_run = m_new;
+          // what is already accumulated shrinks by the head's scale: accumulator row 4 (lane >> 4) + r belongs to head
+          // (4 (lane >> 4) + r) & 7; the a_v columns of this lane to head hv
+          {
+            float scl[8];
+#pragma unroll
+            for (int h = 0; h < 8; ++h) scl[h] = __shfl(scale, h);
+            const bool up = kq & 1;
+            const float s0 = up ? scl[4] : scl[0], s1 = up ? scl[5] : scl[1], s2 = up ? scl[6] : scl[2], s3 = up ? scl[7] : scl[3];
+#pragma unroll
+            for (int cb = 0; cb < 6; ++cb) { ar[cb][0] *= s0; ar[cb][1] *= s1; ar[cb][2] *= s2; ar[cb][3] *= s3; }
+            float sh = scl[0];
+#pragma unroll
+            for (int h = 1; h < 8; ++h) sh = (hv == h) ? scl[h] : sh;
+            av.x *= sh; av.y *= sh; av.z *= sh; av.w *= sh;
+          }
+          C16_EMARK(7);
+          // ---- a_r[h][c] += sum_e p_e,h r~_e[c] on the matrix cores (16x16x16): A = (p hi | p lo) x head from the probability
+          //      tile (lane: 4 consecutive edges), B = the feature tile read back transposed (4 consecutive EDGES of one
+          //      feature per lane: one ds_read_b64_tr_b16), hi pass then lo pass
+          half4v ap;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float pv = Pt[(4 * kq + j) * 8 + (mi & 7)];
+            ap[j] = loA ? f16_lo(pv) : f16_hi(pv);
+          }
+          const _Float16* tp = Ft + (kq * 4 + (mi >> 2)) * C16_FS + (lane & 3) * 4;
+#pragma unroll
+          for (int pass = 0; pass < 2; ++pass) {
+            if (pass == 1) {
+#pragma unroll
+              for (int ks = 0; ks < 3; ++ks) *reinterpret_cast<half8*>(Ft + mi * C16_FS + 32 * ks + 8 * kq) = fl[ks];
+            }
+#pragma unroll
+            for (int cb = 0; cb < 6; ++cb) {
+              const fp16x4 tv = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)(tp + cb * 16));
+              half4v bfr;
+#pragma unroll
+              for (int j = 0; j < 4; ++j) bfr[j] = (_Float16)tv[j];
+              ar[cb] = __builtin_amdgcn_mfma_f32_16x16x16f16(ap, bfr, ar[cb], 0, 0, 0);
+            }
+          }
+          C16_EMARK(8);
+          // ---- a_v[hd] += sum_e p_e,h v_src[hd] on the VALU
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float ph = Pt[(2 * j + eh) * 8 + hv];   // 0 past the edge list
+            av.x = fmaf(ph, vv[j].x, av.x);
+            av.y = fmaf(ph, vv[j].y, av.y);
+            av.z = fmaf(ph, vv[j].z, av.z);
+            av.w = fmaf(ph, vv[j].w, av.w);
+          }
+        }
+        C16_EMARK(9);
+        // ---- the row's (partial) sums leave for the POST half: slot = part * Nd + row
+        const size_t slot = (size_t)part * Nd + r;
+        if (lane < 8) {   // lane h (mi = h, kq = 0) holds head h
+          io.l[slot * 8 + lane] = l_run;
+          if (W > 1) io.m[slot * 8 + lane] = m_run;
+        }
+        av.x += __shfl_xor(av.x, 32); av.y += __shfl_xor(av.y, 32); av.z += __shfl_xor(av.z, 32); av.w += __shfl_xor(av.w, 32);
+        if (lane < 32) *reinterpret_cast<float4*>(io.av + slot * 128 + 4 * lane) = av;
+        // rows h (p hi) and h + 8 (p lo) sit 32 lanes apart: one half-wave swap folds two column blocks at a time
+#pragma unroll
+        for (int cb = 0; cb < 6; cb += 2) {
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4) {
+            const float v = swap_add32(ar[cb][r4], ar[cb + 1][r4]);   // lanes < 32: block cb, lanes >= 32: block cb + 1
+            io.ar[slot * 1024 + (4 * ((lane >> 4) & 1) + r4) * 128 + (cb + (lane >> 5)) * 16 + (lane & 15)] = v;
+          }
+        }
+        C16_EMARK(10);
+      }
+    }
+    }
+
+// NWV: waves per workgroup (8: one workgroup per CU, two waves per SIMD hide each other's latency; 4: two workgroups per CU).
+// POLICY: own symbol for the per-replan policy launch (kernel traces, bench.py) + the XCD-aware block -> row mapping.
+// rows: destination rows per workgroup (<= 16; the MFMA tiles are 16 rows, the rest zero).  With rows < NWV a row's edge
+// list is shared by W = NWV / rows waves (tiles w, w + W, ...): every wave keeps its own running maximum and sums, the
+// POST half merges the W partials.
+template <int NWV, bool POLICY>
+__global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void k_chain16(float* __restrict__ x, const float* __restrict__ x_in, int Nd, int rows,
+                                                    const ChainStep* __restrict__ steps, int nsteps, EdgeIO io,
+                                                    const float* __restrict__ div32, float eps, int xcd,
+                                                    unsigned long long* __restrict__ prof) {
+  // prof (PS_CHAIN_PROF=1; nullptr in every product launch): thread 0 of each workgroup charges the cycles since the
+  // previous mark to slot i: 0 PRE, 1 EDGE, 2 POST; wave 0 of the edge phase: 4 records + k issue, 5 Fourier rows,
+  // 6 staging + score MFMAs, 7 softmax, 8 a_r MFMAs, 9 a_v, 10 row epilogue, 11 row prologue, 12 tiles
+  long long tprev = prof ? clock64() : 0;
+#define C16_MARK(i)                                                   \
+  do {                                                                \
+    if (prof && threadIdx.x == 0) {                                   \
+      const long long now_ = clock64();                               \
+      atomicAdd(prof + (i), (unsigned long long)(now_ - tprev));      \
+      tprev = now_;                                                   \
+    }                                                                 \
+  } while (0)
+  constexpr int NT = 64 * NWV;
+  extern __shared__ __attribute__((aligned(16))) unsigned char c16_smem[];
+  constexpr size_t EXTRA = NWV * C16_WAVE_BYTES > C16_PLANES_BYTES ? NWV * C16_WAVE_BYTES - C16_PLANES_BYTES : 0;
+  // [wave areas beyond the planes (EXTRA)] [P0 | P1 | C] [X | AG | sp | CQ | ctr]: the wave areas run from the start
+  unsigned char* node_base = c16_smem + EXTRA;
+  _Float16* P0h = reinterpret_cast<_Float16*>(node_base);
+  _Float16* P0l = P0h + ND_ROWS * ND_AS;
+  _Float16* P1h = P0l + ND_ROWS * ND_AS;
+  _Float16* P1l = P1h + ND_ROWS * ND_AS5;
+  float* C = reinterpret_cast<float*>(P1l + ND_ROWS * ND_AS5);   // [16][132] results of the 128-column GEMMs
+  float* Cw = reinterpret_cast<float*>(P1h);                     // [16][388] wide results of the PRE half (FFN planes' memory)
+  float* X = C + ND_ROWS * ND_CS;        // [16][132] residual stream
+  float* AG = X + ND_ROWS * ND_XS;       // [16][132] q (PRE -> edge phase)
+  float* sp = AG + ND_ROWS * ND_XS;      // [SP_SIZE] the layer's small vectors
+  float* CQ = sp + SP_SIZE;              // [16][8] <q_h, kb_h>
+  int* ctr = reinterpret_cast<int*>(CQ + 16 * 8);
+
+  const int row0 = xcd_block(blockIdx.x, gridDim.x, !xcd) * rows;
+  const int nrows = min(rows, Nd - row0);          // rows of this workgroup that exist (> 0: the grid is ceil(Nd / rows))
+  const int W = rows < NWV ? NWV / rows : 1;       // waves per row in the edge phase (rows is a power of two)
+  {
+    const int tid0 = threadIdx.x, er0 = (tid0 >> 4) & 15, ec0 = (tid0 & 15) * 8;
+    if (tid0 < 256) {
+      float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+      if (er0 < nrows) { v0 = ldg4(x_in + (size_t)(row0 + er0) * 128 + ec0); v1 = ldg4(x_in + (size_t)(row0 + er0) * 128 + ec0 + 4); }
+      *reinterpret_cast<float4*>(X + er0 * ND_XS + ec0) = v0;
+      *reinterpret_cast<float4*>(X + er0 * ND_XS + ec0 + 4) = v1;
+    }
+  }
+  constexpr int C16_DEPTH = 3;   // fragment groups in flight per wave (k_node, alone on its CU with 512 registers: 4; 4 spills here)
+  typedef FragRingT<C16_DEPTH> Ring;
+
+  // Iteration s: EDGE(s), POST(s), PRE(s + 1); iteration -1 is PRE(0) alone.  The fragment ring is declared between the
+  // edge phase and the node phases, so that it is dead (not merely unused) while the edge phase needs the registers.
+  for (int s = -1; s < nsteps; ++s) {
+    // Lane-derived indices are re-materialised behind an opaque asm every layer: otherwise LICM hoists the loop-invariant
+    // LDS / global addresses of every phase out of the layer loop and they spill (> 100 registers' worth).
+    int tid_v = threadIdx.x;
+    asm volatile("" : "+v"(tid_v));
+    const int tid = tid_v, lane = tid_v & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid_v >> 6);
+    const int mi = lane & 15, kq = lane >> 4;
+    const bool epi = tid < 256;                      // the 16 x 128 epilogues take 256 threads: row er, 8 columns from ec
+    const int er = (tid >> 4) & 15, ec = (tid & 15) * 8;
+    const int grow = row0 + er;
+    const bool live = epi && er < nrows;
+    auto stage_sp = [&](const float* __restrict__ src) {
+      for (int i = tid; i < SP_SIZE / 4; i += NT) *reinterpret_cast<float4*>(sp + 4 * i) = ldg4(src + 4 * i);
+    };
+    C16_MARK(0);
+    if (s >= 0) c16_edge_phase<NWV>(steps + s, io, c16_smem, AG, CQ, ctr, div32, row0, nrows, W, Nd, prof);
+    if (s >= 0) __syncthreads();   // every row's sums are in the scratch; the wave-private areas are dead
+    C16_MARK(1);
+    Ring R;
+    if (s >= 0) {
+      const ChainStep& st = steps[s];
+      const AttnW& w = st.w;
+    // =========================================================== POST: to_v_r fold, gate, to_out, norms, FFN   (:76-77, :100-107)
+    {
+      frag_prefetch<4, Ring, NWV>(R, w.Fga, 8, wave, lane);
+      float4 in_av0 = make_float4(0.f, 0.f, 0.f, 0.f), in_av1 = in_av0, in_g0 = in_av0, in_g1 = in_av0, in_s0 = in_av0, in_s1 = in_av0;
+      float in_l = 0.f;
+      if (live) {
+        in_g0 = ldg4(io.g + (size_t)grow * 128 + ec); in_g1 = ldg4(io.g + (size_t)grow * 128 + ec + 4);
+        in_s0 = ldg4(io.s + (size_t)grow * 128 + ec); in_s1 = ldg4(io.s + (size_t)grow * 128 + ec + 4);
+        if (W == 1) {
+          in_l = ldg1(io.l + (size_t)grow * 8 + (ec >> 4));
+          in_av0 = ldg4(io.av + (size_t)grow * 128 + ec); in_av1 = ldg4(io.av + (size_t)grow * 128 + ec + 4);
+        } else {   // merge the W partial softmax sums of the row (head ec >> 4): common maximum, rescale, add
+          float mm = -INFINITY;
+          for (int p = 0; p < W; ++p) mm = fmaxf(mm, ldg1(io.m + ((size_t)p * Nd + grow) * 8 + (ec >> 4)));
+          for (int p = 0; p < W; ++p) {
+            const size_t slot = (size_t)p * Nd + grow;
+            const float mp = ldg1(io.m + slot * 8 + (ec >> 4));
+            const float sc = (mp == -INFINITY) ? 0.f : expf(mp - mm);
+            in_l = fmaf(ldg1(io.l + slot * 8 + (ec >> 4)), sc, in_l);
+            const float4 a0 = ldg4(io.av + slot * 128 + ec), a1 = ldg4(io.av + slot * 128 + ec + 4);
+            in_av0.x = fmaf(a0.x, sc, in_av0.x); in_av0.y = fmaf(a0.y, sc, in_av0.y); in_av0.z = fmaf(a0.z, sc, in_av0.z); in_av0.w = fmaf(a0.w, sc, in_av0.w);
+            in_av1.x = fmaf(a1.x, sc, in_av1.x); in_av1.y = fmaf(a1.y, sc, in_av1.y); in_av1.z = fmaf(a1.z, sc, in_av1.z); in_av1.w = fmaf(a1.w, sc, in_av1.w);
+          }
+        }
+      }
+      {   // fold: C[row][16h + d] = sum_c a_r[row][h][c] * Wvr_g3[c][16h + d]; one head at a time, 8 / NWV heads per wave
+#pragma unroll 1
+        for (int t = 0; t < 8 / NWV; ++t) {
+          const int h = (8 / NWV) * wave + t;
+          float av_[3][8];
+          half8 bh[3], bl[3];
+#pragma unroll
+          for (int ks = 0; ks < 3; ++ks) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) av_[ks][j] = 0.f;
+            const _Float16* f = w.Fvr3 + ((size_t)(h * 3 + ks) * 2) * 512 + lane * 8;
+            bh[ks] = ldgh8(f);
+            bl[ks] = ldgh8(f + 512);
+          }
+          if (mi < nrows) {
+            float mm = -INFINITY;
+            if (W > 1)
+              for (int p = 0; p < W; ++p) mm = fmaxf(mm, ldg1(io.m + ((size_t)p * Nd + row0 + mi) * 8 + h));
+            for (int p = 0; p < W; ++p) {
+              const size_t slot = (size_t)p * Nd + row0 + mi;
+              float sc = 1.f;
+              if (W > 1) {
+                const float mp = ldg1(io.m + slot * 8 + h);
+                sc = (mp == -INFINITY) ? 0.f : expf(mp - mm);
+              }
+#pragma unroll
+              for (int ks = 0; ks < 3; ++ks) {
+                const float* ap_ = io.ar + slot * 1024 + h * 128 + ks * 32 + kq * 8;
+                const float4 a0 = ldg4(ap_), a1 = ldg4(ap_ + 4);
+                av_[ks][0] = fmaf(a0.x, sc, av_[ks][0]); av_[ks][1] = fmaf(a0.y, sc, av_[ks][1]);
+                av_[ks][2] = fmaf(a0.z, sc, av_[ks][2]); av_[ks][3] = fmaf(a0.w, sc, av_[ks][3]);
+                av_[ks][4] = fmaf(a1.x, sc, av_[ks][4]); av_[ks][5] = fmaf(a1.y, sc, av_[ks][5]);
+                av_[ks][6] = fmaf(a1.z, sc, av_[ks][6]); av_[ks][7] = fmaf(a1.w, sc, av_[ks][7]);
+              }
+            }
+          }
+          floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < 3; ++ks) {
+            half8 ah, al;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { ah[j] = f16_hi(av_[ks][j]); al[j] = f16_lo(av_[ks][j]); }
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[ks], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[ks], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[ks], acc, 0, 0, 0);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) C[(4 * kq + r) * ND_CS + h * 16 + mi] = acc[r];
+        }
+      }
+      __syncthreads();
+      float agg[8];
+      if (epi) {   // agg = (a_v + fold + l * vb) / (l + 1e-16)   (:89, :100)
+        const float l = in_l;
+        const float inv = 1.f / (l + 1e-16f);
+        const float avv[8] = {in_av0.x, in_av0.y, in_av0.z, in_av0.w, in_av1.x, in_av1.y, in_av1.z, in_av1.w};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) agg[i] = (avv[i] + C[er * ND_CS + ec + i] + l * sp[SP_VB + ec + i]) * inv;
+        planes_store8(P0h + er * ND_AS + ec, P0l + er * ND_AS + ec, agg);
+      }
+      __syncthreads();
+      gemm16<4, Ring, NWV>(R, P0h, P0l, ND_AS, w.Fga, 8, C, ND_CS, wave, lane);
+      frag_prefetch<4, Ring, NWV>(R, w.Fout, 8, wave, lane);
+      __syncthreads();
+      {   // gated update (:106-107): g = sigmoid(Wg [agg | x_dst] + bg); u = agg + g * (to_s(x_dst) - agg)
+        const float gv[8] = {in_g0.x, in_g0.y, in_g0.z, in_g0.w, in_g1.x, in_g1.y, in_g1.z, in_g1.w};
+        const float sv[8] = {in_s0.x, in_s0.y, in_s0.z, in_s0.w, in_s1.x, in_s1.y, in_s1.z, in_s1.w};
+        float u[8];
+        if (epi) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const float g = 1.f / (1.f + expf(-(C[er * ND_CS + ec + i] + gv[i])));
+            u[i] = agg[i] + g * (sv[i] - agg[i]);
+          }
+        }
+        __syncthreads();   // every thread has read its gate columns of C and P0 is no longer an operand
+        if (epi) planes_store8(P0h + er * ND_AS + ec, P0l + er * ND_AS + ec, u);
+      }
+      __syncthreads();
+      gemm16<4, Ring, NWV>(R, P0h, P0l, ND_AS, w.Fout, 8, C, ND_CS, wave, lane);
+      frag_prefetch<4, Ring, NWV>(R, w.F1, 32, wave, lane);
+      __syncthreads();
+      {   // x = x + LN_post(to_out(u))  (:76), then LN_ffpre(x)  (:77)
+        float o[8], xv[8];
+        if (epi) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) o[i] = C[er * ND_CS + ec + i] + sp[SP_BOUT + ec + i];
+          row16_ln(o, sp + SP_LN_POST_W, sp + SP_LN_POST_B, ec, eps);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            xv[i] = X[er * ND_XS + ec + i] + o[i];
+            X[er * ND_XS + ec + i] = xv[i];
+          }
+          row16_ln(xv, sp + SP_LN_FFPRE_W, sp + SP_LN_FFPRE_B, ec, eps);
+        }
+        __syncthreads();
+        if (epi) planes_store8(P0h + er * ND_AS + ec, P0l + er * ND_AS + ec, xv);
+      }
+      __syncthreads();
+      gemm16<4, Ring, NWV>(R, P0h, P0l, ND_AS, w.F1, 32, nullptr, 0, wave, lane, P1h, P1l, ND_AS5, sp + SP_B1);
+      frag_prefetch<16, Ring, NWV>(R, w.F2, 8, wave, lane);
+      __syncthreads();
+      gemm16<16, Ring, NWV>(R, P1h, P1l, ND_AS5, w.F2, 8, C, ND_CS, wave, lane);
+      if (s + 1 < nsteps) frag_prefetch<4, Ring, NWV>(R, steps[s + 1].w.Fqsg, 24, wave, lane);   // (the next PRE's first GEMM)
+      __syncthreads();
+      if (epi) {   // x = x + LN_ffpost(FFN)
+        float y[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) y[i] = C[er * ND_CS + ec + i] + sp[SP_B2 + ec + i];
+        row16_ln(y, sp + SP_LN_FFPOST_W, sp + SP_LN_FFPOST_B, ec, eps);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          y[i] += X[er * ND_XS + ec + i];
+          X[er * ND_XS + ec + i] = y[i];
+        }
+        if (live && s + 1 == nsteps) {
+          *reinterpret_cast<float4*>(x + (size_t)grow * 128 + ec) = make_float4(y[0], y[1], y[2], y[3]);
+          *reinterpret_cast<float4*>(x + (size_t)grow * 128 + ec + 4) = make_float4(y[4], y[5], y[6], y[7]);
+        }
+      }
+      __syncthreads();   // X is final for this layer; sp may be restaged
+    }
+    }
+    C16_MARK(2);
+    if (s + 1 < nsteps) {
+      const ChainStep& st = steps[s + 1];
+      const AttnW& w = st.w;
+    // =========================================================== PRE: LN_dst, q | s | g, q~, <q, kb>   (:61-69, :106-107, :114)
+    stage_sp(w.sp);
+    if (s < 0) frag_prefetch<4, Ring, NWV>(R, w.Fqsg, 24, wave, lane);   // (later layers: requested at the end of the previous POST)
+    __syncthreads();
+    if (epi) {
+      float xn[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) xn[i] = X[er * ND_XS + ec + i];
+      row16_ln(xn, sp + SP_LN_DST_W, sp + SP_LN_DST_B, ec, eps);
+      planes_store8(P0h + er * ND_AS + ec, P0l + er * ND_AS + ec, xn);
+    }
+    __syncthreads();
+    gemm16<4, Ring, NWV>(R, P0h, P0l, ND_AS, w.Fqsg, 24, Cw, ND_CW, wave, lane);
+    frag_prefetch<1, Ring, NWV>(R, w.Fkr3, 8 * 6, wave, lane);
+    __syncthreads();
+    if (epi) {
+      float q[8], sv[8], gv[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        q[i] = Cw[er * ND_CW + ec + i] + sp[SP_BQ + ec + i];
+        sv[i] = Cw[er * ND_CW + 128 + ec + i] + sp[SP_BS + ec + i];
+        gv[i] = Cw[er * ND_CW + 256 + ec + i] + sp[SP_BG + ec + i];
+        AG[er * ND_XS + ec + i] = q[i];
+      }
+      planes_store8(P0h + er * ND_AS + ec, P0l + er * ND_AS + ec, q);
+      if (live) {
+        *reinterpret_cast<float4*>(io.s + (size_t)grow * 128 + ec) = make_float4(sv[0], sv[1], sv[2], sv[3]);
+        *reinterpret_cast<float4*>(io.s + (size_t)grow * 128 + ec + 4) = make_float4(sv[4], sv[5], sv[6], sv[7]);
+        *reinterpret_cast<float4*>(io.g + (size_t)grow * 128 + ec) = make_float4(gv[0], gv[1], gv[2], gv[3]);
+        *reinterpret_cast<float4*>(io.g + (size_t)grow * 128 + ec + 4) = make_float4(gv[4], gv[5], gv[6], gv[7]);
+      }
+    }
+    __syncthreads();
+    // q~[row][h][c] = sum_d q[row][16h + d] * Wkr_g3[16h + d][c]: (head, 16-column tile) pairs over the waves
+    {
+      constexpr int NTQ = 6;
+      const int G = (8 * NTQ - wave + NWV - 1) / NWV;   // one k-block per tile: group g = tile wave + NWV g
+      for (int g0 = 0; g0 < G; g0 += C16_DEPTH) {
+#pragma unroll
+        for (int d = 0; d < C16_DEPTH; ++d) {
+          const int g = g0 + d;
+          if (g < G) {
+            const half8 bh = R.h[d][0], bl = R.l[d][0];
+            if (g + C16_DEPTH < G) frag_issue<1, Ring, NWV>(R, d, w.Fkr3, g + C16_DEPTH, wave, lane);
+            const int t = wave + NWV * g, h = t / NTQ, nt = t - h * NTQ;
+            const half8 ah = *reinterpret_cast<const half8*>(P0h + mi * ND_AS + (h >> 1) * 32 + kq * 8);
+            const half8 al = *reinterpret_cast<const half8*>(P0l + mi * ND_AS + (h >> 1) * 32 + kq * 8);
+            floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (4 * kq + r < nrows) io.qt[(size_t)(row0 + 4 * kq + r) * 1024 + h * 128 + nt * 16 + mi] = acc[r];
+          }
+        }
+      }
+      if (tid < 128) {   // cq[row][h] = <q_h, kb_h>
+        const int r = tid >> 3, h = tid & 7;
+        float a = 0.f;
+        for (int d = 0; d < DH; ++d) a = fmaf(AG[r * ND_XS + h * DH + d], sp[SP_KB + h * DH + d], a);
+        CQ[r * 8 + h] = a;
+      }
+      if (tid == 0) *ctr = 0;
+    }
+    __syncthreads();   // q~ rows (global scratch of this workgroup), cq, counter: visible to every wave
+    }
+  }
+}
+
+}  // namespace ps

@@ -1031,30 +1031,146 @@ __global__ __launch_bounds__(256) void k_policy_head_mfma(HeadW w, const float* 
   }
 }
 
-// Rollout metric (metrics/motion_pred.py:31-76, rollout ADE / FDE): per-agent mean and final L2
-// displacement between the rolled-out xy and a ground-truth future (nullptr -> the origin, i.e.
-// distance travelled in the agent-init frame).  out [A][2] may be any device buffer (e.g. a torch
-// tensor that is then all-gathered over RCCL).
+// Closed-loop displacement of the rolled-out xy from a ground-truth future in the agent-init frame (the quantity the
+// Sim-Agents style evaluation of rollout/ works on): per agent the mean over the steps whose ground truth is finite and
+// the displacement at the LAST such step -- the NaN-masked target / last-valid-index conventions of
+// metrics/motion_pred.py:31-76.  gt [A][steps][2] (NaN = no ground truth at that step), or nullptr: the path length
+// from the origin of the agent-init frame.  out [A][2]; NaN for log-replay agents and for agents without a valid step.
 __global__ void k_rollout_metric(const float* __restrict__ traj, int stride_steps, int hist, int steps,
                                  const float* __restrict__ gt /*[A][steps][2] or null*/, int n_agents,
                                  float* __restrict__ out, const int* __restrict__ is_policy) {
   const int a = blockIdx.x * blockDim.x + threadIdx.x;
   if (a >= n_agents) return;
-  if (is_policy && !is_policy[a]) {   // log-replay agents are not simulated
-    out[2 * a] = 0.f;
-    out[2 * a + 1] = 0.f;
+  const float nan = __int_as_float(0x7fc00000);
+  if (is_policy && !is_policy[a]) {   // log-replay agents are not simulated: no metric row
+    out[2 * a] = nan;
+    out[2 * a + 1] = nan;
     return;
   }
-  float sum = 0.f, last = 0.f;
+  float sum = 0.f, last = nan;
+  int cnt = 0;
   for (int s = 0; s < steps; ++s) {
     const float* t = traj + ((size_t)a * stride_steps + hist + s) * 4;
     const float gx = gt ? gt[((size_t)a * steps + s) * 2] : 0.f, gy = gt ? gt[((size_t)a * steps + s) * 2 + 1] : 0.f;
+    if (gx != gx || gy != gy) continue;
     const float dx = t[0] - gx, dy = t[1] - gy;
     last = sqrtf(dx * dx + dy * dy);
     sum += last;
+    ++cnt;
   }
-  out[2 * a] = sum / (float)steps;
+  out[2 * a] = cnt ? sum / (float)cnt : nan;
   out[2 * a + 1] = last;
+}
+
+// The reference's validation metric PairMotionPred (metrics/motion_pred.py:111-199) on the device, one thread per
+// agent row.  Pairs = (replan r, agent a) with pair_mask[r][a]; per pair the K-mode errors of _update_traj_error
+// (:31-76): a step counts unless BOTH target coordinates are NaN, ade_k = sum / count (NaN without a valid step),
+// fde_k = the masked distance at the last valid step (0 without one: index -1 picks the masked last step),
+// ade / fde of the arg-max-probability mode, min over the modes (a NaN mode makes the minimum NaN, as torch.min does).
+// Then the chained per-replan predictions against the chained targets (loss_func.py:215-313 rollout_traj /
+// rollout_temp_traj_preds, PRED_GMM False): every replan's first `rs` steps, rotated by the wrapped cumulative heading
+// of the replans before it, summed up; mean distance over the steps whose target x and y are finite (:125-143).
+// tgt [R][A][S][5] (NaN = missing), pair_mask [R][A], pred [R][A][K][S][sd], prob [R][A][K] or nullptr (mode 0).
+// out [A][10] = (sum ade, sum fde, sum min_ade, sum min_fde, the four counts of finite entries behind those sums -- what
+// torchmetrics.MeanMetric keeps of an update --, rollout ade of the agent, 1 if the agent has a valid rollout step);
+// NaN row for agents that are not policy agents.
+__global__ void k_pair_metric(const float* __restrict__ pred, const float* __restrict__ prob, const float* __restrict__ tgt,
+                              const uint8_t* __restrict__ pair_mask, int R, int A, int K, int S, int sd, int rs,
+                              const int* __restrict__ is_policy, float* __restrict__ out) {
+  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= A) return;
+  const float nan = __int_as_float(0x7fc00000);
+  float* o = out + (size_t)a * 10;
+  if (is_policy && !is_policy[a]) {
+    for (int i = 0; i < 10; ++i) o[i] = nan;
+    return;
+  }
+  float s_ade = 0.f, s_fde = 0.f, s_made = 0.f, s_mfde = 0.f;
+  int n_ade = 0, n_fde = 0, n_made = 0, n_mfde = 0;
+  // chained trajectories: wrapped cumulative heading and running position of target and prediction
+  float th_t = 0.f, th_p = 0.f;          // unwrapped sums of the replans' heading steps so far
+  float ptx = 0.f, pty = 0.f, ppx = 0.f, ppy = 0.f;
+  float r_sum = 0.f;
+  int r_cnt = 0;
+  for (int r = 0; r < R; ++r) {
+    const bool pm = pair_mask[(size_t)r * A + a] != 0;
+    const float* tg = tgt + ((size_t)r * A + a) * S * 5;
+    int kidx = 0;
+    if (pm) {
+      if (prob) {
+        float best = prob[((size_t)r * A + a) * K];
+        for (int k = 1; k < K; ++k) {
+          const float v = prob[((size_t)r * A + a) * K + k];
+          if (v > best) { best = v; kidx = k; }
+        }
+      }
+      int last = -1, cnt = 0;
+      for (int s = 0; s < S; ++s) {
+        const float gx = tg[s * 5], gy = tg[s * 5 + 1];
+        if (!(gx != gx && gy != gy)) { last = s; ++cnt; }
+      }
+      float ade_sel = 0.f, fde_sel = 0.f, ade_min = 0.f, fde_min = 0.f;
+      bool ade_min_nan = false, fde_min_nan = false;
+      for (int k = 0; k < K; ++k) {
+        const float* pp = pred + (((size_t)r * A + a) * K + k) * S * sd;
+        float sum = 0.f, fde = 0.f;
+        for (int s = 0; s < S; ++s) {
+          const float gx = tg[s * 5], gy = tg[s * 5 + 1];
+          if (gx != gx && gy != gy) continue;                     // masked step: distance filled with 0
+          const float dx = gx - pp[s * sd], dy = gy - pp[s * sd + 1];
+          const float d = sqrtf(dx * dx + dy * dy);               // NaN when only one coordinate is missing (as the reference)
+          sum += d;
+          if (s == last) fde = d;
+        }
+        const float ade = sum / (float)cnt;                        // 0 / 0 = NaN without a valid step
+        if (k == kidx) { ade_sel = ade; fde_sel = fde; }
+        if (k == 0) { ade_min = ade; fde_min = fde; }
+        ade_min_nan |= ade != ade;
+        fde_min_nan |= fde != fde;
+        ade_min = fminf(ade_min, ade);
+        fde_min = fminf(fde_min, fde);
+      }
+      if (ade_min_nan) ade_min = nan;
+      if (fde_min_nan) fde_min = nan;
+      // MeanMetric drops the NaN entries of each metric separately
+      if (ade_sel == ade_sel) { s_ade += ade_sel; ++n_ade; }
+      if (fde_sel == fde_sel) { s_fde += fde_sel; ++n_fde; }
+      if (ade_min == ade_min) { s_made += ade_min; ++n_made; }
+      if (fde_min == fde_min) { s_mfde += fde_min; ++n_mfde; }
+    }
+    // ---- chained rollout of this replan (target zero-filled where missing or unpaired, prediction zero where unpaired)
+    const float ct = cosf(wrap_angle(th_t)), st_ = sinf(wrap_angle(th_t));
+    const float cp = cosf(wrap_angle(th_p)), sp_ = sinf(wrap_angle(th_p));
+    const float* pp = pred + (((size_t)r * A + a) * K + kidx) * S * sd;
+    float ltx = 0.f, lty = 0.f, lpx = 0.f, lpy = 0.f;            // previous step inside the replan (diff)
+    for (int s = 0; s < rs; ++s) {
+      float gx = tg[s * 5], gy = tg[s * 5 + 1];
+      const bool vx = pm && gx == gx, vy = pm && gy == gy;
+      gx = vx ? gx : 0.f;
+      gy = vy ? gy : 0.f;
+      const float px = pm ? pp[s * sd] : 0.f, py = pm ? pp[s * sd + 1] : 0.f;
+      const float dtx = gx - ltx, dty = gy - lty, dpx = px - lpx, dpy = py - lpy;
+      ltx = gx; lty = gy; lpx = px; lpy = py;
+      ptx += dtx * ct - dty * st_;
+      pty += dty * ct + dtx * st_;
+      ppx += dpx * cp - dpy * sp_;
+      ppy += dpy * cp + dpx * sp_;
+      if (vx && vy) {
+        const float ex = ptx - ppx, ey = pty - ppy;
+        r_sum += sqrtf(ex * ex + ey * ey);
+        ++r_cnt;
+      }
+    }
+    {
+      const float gh = tg[(rs - 1) * 5 + 2];
+      th_t += (pm && gh == gh) ? gh : 0.f;
+      th_p += pm ? pp[(rs - 1) * sd + 2] : 0.f;
+    }
+  }
+  o[0] = s_ade; o[1] = s_fde; o[2] = s_made; o[3] = s_mfde;
+  o[4] = (float)n_ade; o[5] = (float)n_fde; o[6] = (float)n_made; o[7] = (float)n_mfde;
+  o[8] = r_sum / (float)(r_cnt > 0 ? r_cnt : 1);
+  o[9] = r_cnt > 0 ? 1.f : 0.f;
 }
 
 // policy_emd += x_p after the condition layers (condition_attns.py:226)

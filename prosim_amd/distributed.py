@@ -3,8 +3,8 @@
 Scenes are independent (every graph op of the model is batch-segmented, e.g. act_decoder.py:250,
 attn_fusion.py:107), so the path shards by scene with NO data-path collective: scene i runs on rank
 ``i % world`` (mirrors rollout/callbacks.py:76,247).  The only exchange is the metric reduction
-after a rollout: the per-agent (ADE, FDE) vector each rank computed on its device
-(``ps_rollout_metric``) is all-gathered -- RCCL over xGMI on the GPU box (backend "nccl"), gloo in the
+after a rollout: the per-agent metric rows each rank computed on its device (``ps_pair_metric``: the sums behind the
+reference's PairMotionPred; ``ps_rollout_metric``: closed-loop displacement) are all-gathered -- RCCL over xGMI on the GPU box (backend "nccl"), gloo in the
 CPU tests.  The payload is a few KB, latency-bound; link bandwidth is irrelevant.
 """
 from __future__ import annotations
@@ -69,6 +69,35 @@ def gather_scene_metrics(local: torch.Tensor, scene_ids: Sequence[int], n_scenes
     """One-shot form of :class:`SceneMetricGather`.  ``local`` [n_local, max_agents, M] (NaN-padded rows for missing
     agents) for the scenes in ``scene_ids``; returns [n_scenes, max_agents, M] on every rank, in scene order."""
     return SceneMetricGather(scene_ids, n_scenes, max_agents, local.shape[-1], local.device, local.dtype)(local)
+
+
+def rows_to_slots(rows: torch.Tensor, slots: torch.Tensor, n_scenes: int, max_agents: int) -> torch.Tensor:
+    """Per-agent-row results [A, M] (the engine's compact row order) -> the padded [n_scenes, max_agents, M] slot layout
+    the gather works on; slots without an agent row stay NaN.  ``slots`` = Engine.row_slots as a device int64 tensor."""
+    out = torch.full((n_scenes * max_agents, rows.shape[-1]), float("nan"), dtype=rows.dtype, device=rows.device)
+    out.index_copy_(0, slots, rows)
+    return out.view(n_scenes, max_agents, rows.shape[-1])
+
+
+def reduce_pair_metrics(gathered: torch.Tensor, batches: Sequence[Sequence[int]] = None) -> Dict[str, float]:
+    """The scalars PairMotionPred logs (metrics/motion_pred.py:20-25, :184-199) from gathered ``ps_pair_metric`` rows
+    [n_scenes, max_agents, 10]: ade / fde / min_ade / min_fde = sum of the finite pair values / their count (what
+    MeanMetric keeps); rollout_ade = per update (``batches``: the scene ids of each update, default one update with every
+    scene) the mean over the agents with a valid rollout step, then the mean over the updates."""
+    g = torch.nan_to_num(gathered.double(), nan=0.0)
+    tot = g.sum(dim=(0, 1))
+    out = {k: float(tot[i] / tot[4 + i]) if float(tot[4 + i]) > 0 else float("nan")
+           for i, k in enumerate(("ade", "fde", "min_ade", "min_fde"))}
+    batches = [list(range(gathered.shape[0]))] if batches is None else batches
+    per = []
+    for ids in batches:
+        gb = g[list(ids)]
+        n = gb[..., 9].sum()
+        if float(n) > 0:
+            per.append((gb[..., 8] * gb[..., 9]).sum() / n)
+    out["rollout_ade"] = float(torch.stack(per).mean()) if per else float("nan")
+    out["agents"] = int(g[..., 9].sum())
+    return out
 
 
 def reduce_metrics(gathered: torch.Tensor) -> Dict[str, float]:

@@ -73,6 +73,7 @@ def load_library():
     lib.ps_update_obs.argtypes = [vp, fp, u8p, fp, fp]
     lib.ps_declare_agent_rows.argtypes = [vp, C.c_int32, C.c_int32, u8p]
     lib.ps_set_chain_rows.argtypes = [vp, C.c_int32]
+    lib.ps_set_chain_impl.argtypes = [vp, C.c_int32]
     lib.ps_stream.argtypes = [vp]
     lib.ps_stream.restype = C.c_void_p
     lib.ps_policy_flags.argtypes = [vp, i32p, C.c_int64]
@@ -83,6 +84,7 @@ def load_library():
     lib.ps_get.argtypes = [vp, C.c_char_p, fp, C.c_int64]
     lib.ps_get.restype = C.c_int64
     lib.ps_rollout_metric.argtypes = [vp, vp, vp]
+    lib.ps_pair_metric.argtypes = [vp, vp, vp, vp, vp]
     lib.ps_num_agents.argtypes = [vp]
     lib.ps_num_map_tokens.argtypes = [vp]
     lib.ps_time_rollout.argtypes = [vp, C.c_int32, C.c_int32, fp, fp]
@@ -99,8 +101,8 @@ def load_library():
 
 
 EXPORTS = ["ps_create", "ps_destroy", "ps_last_error", "ps_set_scene", "ps_set_prompt", "ps_policy_forward", "ps_set_conditions", "ps_set_drag_points", "ps_set_future_obs", "ps_set_future_log", "ps_num_policy_agents", "ps_policy_flags",
-           "ps_encode_scene", "ps_generate_policy", "ps_reset_rollout", "ps_policy_step", "ps_rollout", "ps_sync", "ps_stream", "ps_set_chain_rows", "ps_update_obs", "ps_declare_agent_rows",
-           "ps_set_state", "ps_get", "ps_rollout_metric", "ps_num_agents", "ps_num_map_tokens", "ps_time_rollout", "ps_time_policy_kernel",
+           "ps_encode_scene", "ps_generate_policy", "ps_reset_rollout", "ps_policy_step", "ps_rollout", "ps_sync", "ps_stream", "ps_set_chain_rows", "ps_set_chain_impl", "ps_update_obs", "ps_declare_agent_rows",
+           "ps_set_state", "ps_get", "ps_rollout_metric", "ps_pair_metric", "ps_num_agents", "ps_num_map_tokens", "ps_time_rollout", "ps_time_policy_kernel",
            "ps_test_pointnet", "ps_test_fourier", "ps_test_wrap", "ps_test_attn", "ps_test_get_edges", "ps_test_stream"]
 
 
@@ -301,8 +303,12 @@ class Engine:
         self._check(self.lib.ps_sync(self.h))
 
     def set_chain_rows(self, rows: int):
-        """0: latency-optimal (one rollout on the GPU); 4: throughput mode for several engines sharing the GPU."""
+        """0: latency-optimal (one rollout on the GPU); 16: throughput mode for several engines sharing the GPU."""
         self._check(self.lib.ps_set_chain_rows(self.h, rows))
+
+    def set_chain_impl(self, impl: int):
+        """0: k_chain16 (default); 1: k_attn_chain, the round-1 fused chain (A/B measurements, cross-checks)."""
+        self._check(self.lib.ps_set_chain_impl(self.h, impl))
 
     @property
     def stream_handle(self) -> int:
@@ -352,6 +358,17 @@ class Engine:
     def rollout_metric(self, out_dev_ptr: int, gt_dev_ptr: int = 0):
         """Per-agent (ADE, FDE) into a caller-owned device buffer [A, 2] (pass tensor.data_ptr())."""
         self._check(self.lib.ps_rollout_metric(self.h, C.c_void_p(gt_dev_ptr or None), C.c_void_p(out_dev_ptr)))
+
+    def pair_metric(self, out_dev_ptr: int, tgt_dev_ptr: int, pair_mask_dev_ptr: int, prob_dev_ptr: int = 0):
+        """The reference's PairMotionPred sums per agent row into a caller-owned device buffer [A, 10]; tgt
+        [R, A, target_steps, 5] float32 and pair_mask [R, A] uint8 are device pointers in agent-row order."""
+        self._check(self.lib.ps_pair_metric(self.h, C.c_void_p(tgt_dev_ptr), C.c_void_p(pair_mask_dev_ptr),
+                                            C.c_void_p(prob_dev_ptr or None), C.c_void_p(out_dev_ptr)))
+
+    @property
+    def row_slots(self) -> np.ndarray:
+        """Flat slot index b * N + n of every agent row (the order of all per-agent results)."""
+        return self._slots.copy()
 
     def time_rollout(self, warmup: int, iters: int):
         ms = C.c_float()

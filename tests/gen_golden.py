@@ -219,6 +219,72 @@ def gen_demo_tracks(scene: str = "scene_0"):
     print("demo tracks written:", scene, len(out["scene_ts"]), "rows,", len(set(out["agent_id"].tolist())), "agents")
 
 
+def make_pair_metric_inputs(seed: int, B: int = 2, N: int = 6, R: int = 8, K: int = 3, S: int = 10, D: int = 5):
+    """Seeded inputs of the rollout metric: per-(scene, replan, agent) local targets with the gaps a real log has
+    (agents that leave: trailing NaN steps; agents without any future at a replan: mask False or all-NaN; one
+    coordinate missing), K-mode predictions and mode probabilities."""
+    rng = np.random.RandomState(4321 + seed)
+    tgt = np.cumsum(rng.uniform(-0.5, 1.5, (B, R, N, S, D)), axis=3).astype(np.float32)
+    tgt[..., 2] = rng.uniform(-0.3, 0.3, (B, R, N, S))                # per-step heading offsets stay small
+    mask = np.ones((B, R, N), bool)
+    for b in range(B):
+        tgt[b, 3:, 1] = np.nan                                         # agent 1 leaves after replan 2 ...
+        mask[b, 3:, 1] = False
+        tgt[b, 2, 1, 4:] = np.nan                                      # ... and its last logged replan is cut short
+        tgt[b, 5, 2] = np.nan                                          # a NaN target whose mask says valid
+        mask[b, 6, 3] = False                                          # a masked pair whose target is finite
+        tgt[b, 1, 4, 7:, 0] = np.nan                                   # only x missing on the last steps
+    n_agents = [N, N - 2][:B] + [N] * max(0, B - 2)
+    pairs = [(b, t, n) for b in range(B) for t in range(R) for n in range(n_agents[b]) if mask[b, t, n]]
+    bidx, tidx, nidx = (np.array(v, np.int64) for v in zip(*pairs))
+    pair_tgt = tgt[bidx, tidx, nidx]
+    pred = (np.nan_to_num(pair_tgt)[:, None] + rng.normal(0, 0.4, (len(pairs), K, S, D))).astype(np.float32)
+    prob = rng.uniform(0, 1, (len(pairs), K)).astype(np.float32)
+    return dict(tgt=tgt, mask=mask, motion_pred=pred, motion_prob=prob, bidx=bidx, tidx=tidx, nidx=nidx)
+
+
+def gen_pair_metric():
+    """tests/golden/ref_pair_metric.npz: the reference's own PairMotionPred (metrics/motion_pred.py:111-199 over
+    loss/loss_func.py:215-313) on seeded inputs -- the five logged scalars after one and after two updates -- and the
+    oracle (oracle/metric_oracle.py) checked against it on the way.  torchmetrics is absent: MeanMetric is the
+    harness's restatement (ref_harness._MeanMetric)."""
+    from oracle import metric_oracle as mo
+    PairMotionPred, lf = rh.load_pair_metric()
+    cfg = rh.get_config(cond_types=())
+    metric = PairMotionPred(cfg)
+    out = {}
+    scal = []
+    for i, seed in enumerate((0, 1)):
+        d = make_pair_metric_inputs(seed)
+        B, R, N = d["mask"].shape
+        names = [[f"a{n}" for n in range(N)] for _ in range(B)]
+        T_indices = [10 * t for t in range(R)]
+        batch = rh.Extras(dict(io_pairs_batch=dict(tgt=torch.from_numpy(d["tgt"]), mask=torch.from_numpy(d["mask"]),
+                                                   agent_names=names, T_indices=T_indices), condition={}))
+        output = dict(motion_pred=torch.from_numpy(d["motion_pred"]), motion_prob=torch.from_numpy(d["motion_prob"]),
+                      pair_names=[f"{b}-a{n}-{T_indices[t]}" for b, t, n in zip(d["bidx"], d["tidx"], d["nidx"])])
+        metric.update(batch, output)
+        res = {k: float(v) for k, v in metric.compute().items()}
+        scal.append([res[k] for k in ("ade", "fde", "min_ade", "min_fde", "rollout_ade")])
+        # oracle == reference on this batch alone
+        solo = PairMotionPred(cfg)
+        solo.update(batch, output)
+        ref1 = {k: float(v) for k, v in solo.compute().items()}
+        o = mo.pair_motion_pred(torch.from_numpy(d["motion_pred"]), torch.from_numpy(d["motion_prob"]), torch.from_numpy(d["tgt"]),
+                                torch.from_numpy(d["mask"]), d["bidx"], d["tidx"], d["nidx"], cfg.ROLLOUT.POLICY.REPLAN_FREQ)
+        for k in ("ade", "fde", "min_ade", "min_fde", "rollout_ade"):
+            assert abs(float(o[k]) - ref1[k]) < 1e-6, (k, float(o[k]), ref1[k])
+        tr, rr, _, valid, _, _ = lf.rollout_temp_traj_preds(batch, output, cfg, torch.argmax(output["motion_prob"], -1), None)
+        assert torch.equal(tr, o["tgt_rollout"]) and torch.equal(rr, o["pred_rollout"])
+        out[f"single_{i}"] = np.array([ref1[k] for k in ("ade", "fde", "min_ade", "min_fde", "rollout_ade")], np.float64)
+        out[f"tgt_rollout_{i}"] = tr.numpy()
+        out[f"pred_rollout_{i}"] = rr.numpy()
+        out[f"digest_{i}"] = np.array(digest(d))
+    out["after_updates"] = np.array(scal, np.float64)     # [2 updates][ade, fde, min_ade, min_fde, rollout_ade]
+    np.savez_compressed(os.path.join(GOLD, "ref_pair_metric.npz"), **out)
+    print("ref_pair_metric written:", out["after_updates"])
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     if len(sys.argv) > 2 and sys.argv[1] == "only":
@@ -226,7 +292,10 @@ if __name__ == "__main__":
         gen_full()
     elif len(sys.argv) > 1 and sys.argv[1] == "tracks":
         gen_demo_tracks()
+    elif len(sys.argv) > 1 and sys.argv[1] == "metric":
+        gen_pair_metric()
     else:
         gen_pure()
         gen_full()
         gen_demo_tracks()
+        gen_pair_metric()
