@@ -10,7 +10,8 @@ BASELINE.json configs[3]'s per-GPU share (64 scenes sharded 8 per GPU; at --gpus
 every scene is a configs[2] scene (goal-point prompts).  metric = agent-steps/s over all ranks; the
 single-scene (S = 1, latency-bound) figure is measured in the same run and reported alongside.
 Scenes shard by index over ranks (i % world, rollout/callbacks.py:76) with no data-path collective;
-after each rollout the per-agent (ADE, FDE) vector is all-gathered over RCCL (the path's only exchange).
+after each rollout the per-agent sums of the reference's rollout metric (PairMotionPred, computed on the device against
+seeded synthetic targets) are all-gathered over RCCL (the path's only exchange).
 """
 from __future__ import annotations
 
@@ -47,6 +48,17 @@ def executed_flops_chain(A: int, e_a2p: float, e_m2p: float, layers: int) -> flo
     (to_v_r fold); per edge 2*(8*128) score + 2*(8*128) aggregate + 4 D."""
     per = lambda E: D * D * 30 * A + E * (4 * 8 * D + 4 * D)
     return layers * (per(e_a2p) + per(e_m2p))
+
+
+def executed_mfma_flops_chain16(n_wg: int, tiles: float, layers: int) -> float:
+    """FLOPs of the v_mfma_f32_16x16x32_f16 / 16x16x16_f16 instructions one k_chain16 policy launch issues (ps_chain16.h):
+    per workgroup and layer the node GEMMs on 16-row tiles -- q|s|g 24 n-tiles x 4 k-blocks, q~ 48 x 1, to_v_r fold 8 x 3,
+    gate 8 x 4, to_out 8 x 4, FFN up 32 x 4, FFN down 8 x 16, three split-fp16 products each = 1464 MFMAs of 16384 FLOP;
+    per 16-edge tile 14 score MFMAs (16x16x32) + 12 aggregation MFMAs (16x16x16, 8192 FLOP).  `tiles` = sum over the
+    layers' edge sets of ceil(deg / 16) per destination (one a2p + one m2p set per layer pair)."""
+    node = n_wg * 2 * layers * 1464 * 16384.0
+    edge = tiles * layers * (14 * 16384.0 + 12 * 8192.0)
+    return node + edge
 
 
 def cpu_baseline(spec, w, scene, reps: int = 3):
@@ -91,8 +103,8 @@ def main():
     ap.add_argument("--scenes-per-gpu", type=int, default=8)
     ap.add_argument("--config", type=int, default=2, help="BASELINE.json config index used as the per-scene workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--chain-rows", type=int, default=-1, choices=[-1, 0, 1, 2, 4, 8, 16],
-                    help="rows per workgroup of the fused attention launches (ps_set_chain_rows); -1: 16 when rollouts are pipelined, else 0")
+    ap.add_argument("--chain-rows", type=int, default=-1, choices=[-1, 0, 1, 2, 4, 8, 9, 10, 11, 12, 13, 14, 15, 16],
+                    help="rows per workgroup of the fused attention launches (ps_set_chain_rows); -1: 12 when rollouts are pipelined, else 0")
     ap.add_argument("--inflight", type=int, default=3,
                     help="rollouts in flight per GPU: consecutive steps alternate between this many engines (own buffers and "
                          "stream each) that hold the same resident batch, so step k+1 starts while step k drains")
@@ -126,7 +138,7 @@ def main():
     if multi:
         dist.barrier()
     from prosim_amd.engine import Engine
-    from prosim_amd.distributed import shard_scenes, reduce_metrics
+    from prosim_amd.distributed import shard_scenes, reduce_pair_metrics, rows_to_slots
 
     spec = DEMO_SPEC
     w = weights.init_weights(spec, 0)
@@ -144,7 +156,7 @@ def main():
     # Every step is still a complete rollout of the whole batch inside the timed region.
     n_fl = max(1, args.inflight)
     engines = [Engine(spec, w, device=dev_index) for _ in range(n_fl)]
-    chain_rows = args.chain_rows if args.chain_rows >= 0 else (16 if n_fl > 1 else 0)
+    chain_rows = args.chain_rows if args.chain_rows >= 0 else (12 if n_fl > 1 else 0)
     for e_ in engines:
         e_.set_chain_rows(chain_rows)
         e_.set_scene(scene)
@@ -156,12 +168,23 @@ def main():
     # stream) and the host goes straight on to launch rollout k+1: no host-side wait inside the loop, the few-KB RCCL
     # all-gather overlaps the next rollout.  One metric buffer per engine; an engine's stream waits for the gather that
     # last read its buffer before the metric kernel overwrites it.
-    metric_bufs = [torch.zeros(A, 2, device="cuda") for _ in range(n_fl)]
+    NM = 10                                              # floats per agent row of ps_pair_metric
+    metric_bufs = [torch.zeros(A, NM, device="cuda") for _ in range(n_fl)]
     eng_streams = [torch.cuda.ExternalStream(e_.stream_handle, device=torch.device("cuda", dev_index)) for e_ in engines]
     done = [torch.cuda.Event() for _ in range(n_fl)]    # rollout + metric of engine i finished (its stream)
     read = [None] * n_fl                                 # gather of buffer i finished (torch stream)
-    gather = SceneMetricGather(my_scenes, n_scenes, N, 2, "cuda" if backend == "nccl" else "cpu") if multi else None
+    gather = SceneMetricGather(my_scenes, n_scenes, N, NM, "cuda" if backend == "nccl" else "cpu") if multi else None
     state = {"k": 0, "last": None}
+    # seeded synthetic ground truth of the metric (there is no log behind synthetic scenes): per (replan, agent row) local
+    # targets with gaps, scene i of the job = generator seed i, resident on the device like the scenes themselves
+    R_, S_ = spec.n_replans, spec.target_steps
+    slots_np = eng.row_slots
+    tg_parts = [synth.make_pair_metric_inputs(i, B=1, N=N, R=R_, K=1, S=S_) for i in my_scenes]
+    tgt_all = np.concatenate([p["tgt"] for p in tg_parts]).transpose(1, 0, 2, 3, 4).reshape(R_, S * N, S_, 5)
+    msk_all = np.concatenate([p["mask"] for p in tg_parts]).transpose(1, 0, 2).reshape(R_, S * N)
+    t_tgt = torch.from_numpy(np.ascontiguousarray(tgt_all[:, slots_np])).cuda()
+    t_msk = torch.from_numpy(np.ascontiguousarray(msk_all[:, slots_np].astype(np.uint8))).cuda()
+    slots = torch.from_numpy(slots_np).cuda()
 
     def step():
         i = state["k"] % n_fl
@@ -169,19 +192,19 @@ def main():
         if read[i] is not None:
             eng_streams[i].wait_event(read[i])
         engines[i].rollout()
-        engines[i].rollout_metric(metric_bufs[i].data_ptr())
+        engines[i].pair_metric(metric_bufs[i].data_ptr(), t_tgt.data_ptr(), t_msk.data_ptr())
         done[i].record(eng_streams[i])
         if not multi:
-            state["last"] = metric_bufs[i].view(S, N, 2)
+            state["last"] = (i, None)
             return
         if backend == "nccl":
             torch.cuda.current_stream().wait_event(done[i])
-            state["last"] = gather(metric_bufs[i].view(S, N, 2))
+            state["last"] = (i, gather(rows_to_slots(metric_bufs[i], slots, S, N)))
             read[i] = torch.cuda.Event()
             read[i].record()
         else:   # CPU test hook: the copy to the host is the wait
             done[i].synchronize()
-            state["last"] = gather(metric_bufs[i].view(S, N, 2).cpu())
+            state["last"] = (i, gather(rows_to_slots(metric_bufs[i], slots, S, N).cpu()))
 
     for _ in range(args.warmup):
         step()
@@ -206,12 +229,27 @@ def main():
     else:
         total_agents = A
     ms_per_step = 1e3 * dt / args.steps
+    # launch durations of the dominant kernel while the pipeline is full: the same loop again for 2 rounds of the engines with
+    # an event pair around every policy launch (such rollouts are launched eagerly -- events do not survive graph replay
+    # on ROCm 7.2 -- at ~1 ms of host time each against a 6 ms step), read after the last one
+    for e_ in engines:
+        e_.enable_policy_events(True)
+    for _ in range(2 * n_fl):
+        step()
+    ev_ms = np.concatenate([e_.policy_event_times() for e_ in engines])
+    for e_ in engines:
+        e_.enable_policy_events(False)
     value = total_agents * spec.max_steps / (dt / args.steps)
     step()
     for e_ in engines:
         e_.sync()
     torch.cuda.synchronize()
-    metrics = reduce_metrics(state["last"])
+    li, lg = state["last"]
+    if lg is None:
+        lg = rows_to_slots(metric_bufs[li], slots, S, N)
+    # one PairMotionPred update per rank (its scenes are its batch, rollout/callbacks.py:76), MeanMetric over the updates
+    metrics = reduce_pair_metrics(lg, batches=[shard_scenes(n_scenes, r_, world) for r_ in range(world)])
+    metrics["scenes"] = int(n_scenes)
     for e_ in engines[1:]:   # the per-stage / per-kernel timings below run on one engine, alone on the GPU
         e_.close()
 
@@ -226,7 +264,8 @@ def main():
         ms_roll_lat, stages_lat = eng.time_rollout(1, 5)
         ms_chain_lat = eng.time_policy_kernel(3)
         eng.set_chain_rows(chain_rows)
-        # single-scene latency of the same workload (S = 1), same engine, same run
+        # single-scene latency of the same workload (S = 1), same engine, same run, latency mode
+        eng.set_chain_rows(0)
         eng.set_scene(parts[0])
         ms_single, stages1 = eng.time_rollout(2, 10)
         ms_chain1 = eng.time_policy_kernel(2)
@@ -251,17 +290,32 @@ def main():
             for e_ in es1:
                 e_.close()
         fl_alg = algorithmic_flops_chain(A, float(ec[4]), float(ec[5]), spec.pol_layers)
-        fl_exe = executed_flops_chain(A, float(ec[4]), float(ec[5]), spec.pol_layers)
-        peak = 157.3  # TFLOP/s: dense fp32 MFMA peak = fp32 vector peak (MI355X_MICROARCH.md)
-        # HBM traffic of the dominant kernel comes from a separate rocprofv3 --pmc run (counters cannot be
-        # read from inside this process); the committed summary is only valid for the default workload
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_policy_chain.json")
+        # per-destination degrees of the last replan's edge sets -> 16-edge tiles the edge phase walked
+        eng.set_chain_rows(chain_rows)
+        eng.set_scene(scene)
+        eng.rollout()
+        tiles = 0.0
+        for which in (4, 5):
+            _, edst, _ = eng.get_edges(which, cap=1 << 22)
+            tiles += float(np.ceil(np.bincount(edst, minlength=A) / 16.0).sum())
+        c16 = chain_rows >= 8
+        n_wg = (A + chain_rows - 1) // chain_rows if c16 else 0
+        fl_mfma = executed_mfma_flops_chain16(n_wg, tiles, spec.pol_layers) if c16 else None
+        ms_launch = float(ev_ms.mean())
+        peak = 2500.0   # TFLOP/s: dense f16 / bf16 MFMA peak (MI355X_MICROARCH.md) -- the instruction class the kernel issues
+        # HBM-side traffic of the launch comes from separate rocprofv3 --pmc passes (tools/gpu_round_profile.sh; counters
+        # cannot be read from inside this process): offline, valid for the default workload only, stamped with its source
+        traffic, traffic_src = None, None
+        pmc = os.path.join(ROOT, "profiles", "r02_pmc_policy_chain.json")
         if os.path.exists(pmc) and S == 8 and args.config == 2:
             with open(pmc) as f:
                 pj = json.load(f)
-            traffic = pj["hbm_bytes_per_launch"] if chain_rows == 4 else pj["latency_mode_kernel"]["hbm_bytes_per_launch"]
-        achieved = fl_alg / (ms_chain * 1e-3) / 1e12
+            if pj.get("chain_rows") == chain_rows:
+                traffic = pj["hbm_bytes_per_launch"]
+                traffic_src = {"file": "profiles/r02_pmc_policy_chain.json", "git": pj.get("git"), "measured": "offline rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), not in this run"}
+        achieved = fl_alg / (ms_launch * 1e-3) / 1e12
+        kern = (f"k_chain16<8, policy> (12 fused attention layers per launch, {chain_rows} rows per 8-wave workgroup, {n_wg} workgroups)" if c16
+                else f"k_attn_chain (policy: 12 fused attention layers per launch; {chain_rows or 2} rows per workgroup)")
         out = {
             "metric": "agent-steps/sec closed-loop rollout", "value": value, "unit": "agent-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -272,25 +326,34 @@ def main():
                                    f"S=8 is configs[3]'s per-GPU share), 80-step closed-loop rollout (8 replans), seeded random-init weights",
                        "agents_per_scene": int(scene['prompt_mask'][0].sum()), "polylines_per_scene": int(scene['map_mask'].shape[1]),
                        "scenes_per_gpu": S, "rollouts_in_flight": n_fl, "chain_rows_per_workgroup": chain_rows,
-                       "parallelism": f"scene-sharded x{world}, RCCL all-gather of per-agent ADE/FDE; consecutive steps pipelined over "
+                       "parallelism": f"scene-sharded x{world}, RCCL all-gather of the per-agent PairMotionPred sums; consecutive steps pipelined over "
                                       f"{n_fl} engine(s) per GPU"},
-            "roofline": {"bound": "mfma", "kernel": f"k_attn_chain (policy: 12 fused attention layers per launch; {chain_rows or 2} rows per workgroup)",
+            "roofline": {"bound": "mfma", "kernel": kern,
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
-                         "traffic_note": "bytes leaving the L2s per launch = 2 x FETCH_SIZE (gfx950 halves 16 B/lane reads: profiles/r01_g_pmc_calibration.txt) + WRITE_SIZE, "
-                                         "separate rocprofv3 --pmc passes (profiles/r01_pmc_policy_chain.json); Infinity-Cache hits are counted",
-                         "note": "achieved = ALGORITHMIC FLOPs of the reference formulation (SURVEY.md section 8(d)) / launch time; the "
-                                 "kernel factors the per-edge to_k_r / to_v_r GEMVs out (DESIGN.md section 4) and executes 7.7x fewer, so "
-                                 "frac can exceed 1 and is not hardware utilisation: see executed_frac.  The launch is latency-bound "
-                                 "(DESIGN.md section 4), neither MFMA- nor HBM-bound; memory side: traffic / avg_launch_ms = hbm_gbps.",
-                         "algorithmic_flops_per_launch": fl_alg, "executed_flops_per_launch": fl_exe,
-                         "executed_tflops": fl_exe / (ms_chain * 1e-3) / 1e12, "executed_frac": fl_exe / (ms_chain * 1e-3) / 1e12 / peak,
-                         "hbm_gbps": (traffic / (ms_chain * 1e-3) / 1e9) if traffic else None, "hbm_peak_gbps": 8000.0,
-                         "avg_launch_ms": ms_chain,
-                         "launch_timing": "HIP events on the engine's stream around policy launches that run ALONE on the GPU (after the timed "
-                                          "loop); inside the pipelined loop up to `rollouts_in_flight` rollouts share the CUs and a launch "
-                                          "takes correspondingly longer -- profiles/ holds the kernel trace of `--inflight 1 --chain-rows 4` (the same "
-                                          "kernel build), whose average agrees",
-                         "edges_per_launch": {"a2p": float(ec[4]), "m2p": float(ec[5])}},
+                         "traffic_source": traffic_src,
+                         "note": "achieved = ALGORITHMIC FLOPs of the reference formulation per launch (SURVEY.md section 8(d): per-edge to_k_r / "
+                                 "to_v_r GEMVs counted) / avg_launch_ms; peak = dense f16 MFMA, the instruction class the kernel issues "
+                                 "(v_mfma_f32_16x16x32_f16 on split-fp16 operands).  The kernel factors the per-edge GEMVs out and executes "
+                                 "fewer FLOPs: executed_mfma_* is the hardware-side figure (instruction counts of ps_chain16.h x FLOPs per "
+                                 "instruction; the PMC pass SQ_INSTS_VALU_MFMA_MOPS_F16 under profiles/ counts the same instructions).  "
+                                 "A launch occupies `workgroups` of the 256 CUs and `rollouts_in_flight` launches overlap, so the per-launch "
+                                 "rate understates the chip: chip_algorithmic_tflops = all policy launches of the timed region / its wall time.  "
+                                 "What bounds the launch: DESIGN.md section 4 (edge phase: fp32 VALU issue of the recomputed Fourier rows; "
+                                 "node phase: per-CU L1 fill rate of the weight fragments).",
+                         "algorithmic_flops_per_launch": fl_alg,
+                         "executed_mfma_flops_per_launch": fl_mfma,
+                         "executed_mfma_tflops": (fl_mfma / (ms_launch * 1e-3) / 1e12) if fl_mfma else None,
+                         "executed_mfma_frac": (fl_mfma / (ms_launch * 1e-3) / 1e12 / peak) if fl_mfma else None,
+                         "chip_algorithmic_tflops": fl_alg * spec.n_replans / (ms_per_step * 1e-3) / 1e12,
+                         "hbm_gbps": (traffic / (ms_launch * 1e-3) / 1e9) if traffic else None, "hbm_peak_gbps": 8000.0,
+                         "avg_launch_ms": ms_launch,
+                         "launch_timing": f"HIP event pairs around the policy launches on each engine's stream, in the same pipelined loop as the timed "
+                                          f"region (run right after it with {n_fl} rollouts in flight, launched eagerly: events do not survive graph "
+                                          f"replay): the {len(ev_ms)} launches of each engine's last rollout (min {float(ev_ms.min()):.3f} / max "
+                                          f"{float(ev_ms.max()):.3f} ms); alone on the GPU the same launch takes launch_alone_ms",
+                         "launch_alone_ms": ms_chain,
+                         "workgroups": n_wg if c16 else None,
+                         "edges_per_launch": {"a2p": float(ec[4]), "m2p": float(ec[5])}, "tiles16_per_layer_pair": tiles},
             "stage_ms": {"rollout_events": ms_roll, "encode_scene": stages[0], "generate_policy": stages[1], "replan_loop": stages[2]},
             "latency_mode": {"note": "ps_set_chain_rows(0): one rollout alone on the GPU", "ms_per_rollout": ms_roll_lat,
                              "encode_scene": stages_lat[0], "generate_policy": stages_lat[1], "replan_loop": stages_lat[2],

@@ -38,6 +38,7 @@ typedef struct ps_config {
   int32_t hidden, heads, head_dim;             /* must be 128, 8, 16 in this build */
   int32_t scene_layers, scene_knn, agent_knn;  /* SCENE_ENCODER.ATTN; agent_knn = min(4*k, 100) */
   int32_t dec_layers, dec_max_neigh;
+  int32_t goal_pred_k;                         /* MODEL.DECODER.GOAL_PRED: K goal hypotheses per prompt (decoder/base.py:22-58); 0 = disabled; K <= 64 */
   float dec_prompt_radius, dec_scene_radius;
   int32_t pol_layers, pol_max_neigh;
   float pol_agent_radius, pol_map_radius;
@@ -120,6 +121,13 @@ int ps_set_future_obs(ps_engine* e, const float* fut_input);
  * replan.  Policy agents' rows are overwritten by the simulation (only the static features 8.. are read). */
 int ps_set_future_log(ps_engine* e, const float* fut_input, const uint8_t* fut_mask, const float* fut_pos,
                       const float* fut_head);
+/* The motion mode every policy agent follows at every replan, for models with TRAJ.K > 1 and ROLLOUT.POLICY.TOP_K > 1
+ * (traj_sam.py:300-313: torch.topk over motion_prob, then torch.randint among the top k).  motion_prob is all ones on this
+ * path (act_decoder.py:124), so the pick does not depend on the model's output: the caller draws it -- with the
+ * reference's own torch.topk / torch.randint calls to replay its stream exactly -- and hands the table over before the
+ * rollout: choice [R, B, N] int32 in slot layout (entries of non-policy slots are ignored), NULL = mode 0 everywhere
+ * (TOP_K = 1: torch.topk of equal probabilities returns index 0).  The table survives until the next ps_set_scene. */
+int ps_set_mode_choice(ps_engine* e, const int32_t* choice);
 /* Agent rows (= observed agents, the order of every per-agent result of ps_get) that are policy agents. */
 int32_t ps_num_policy_agents(ps_engine* e);
 int ps_policy_flags(ps_engine* e, int32_t* flags, int64_t capacity);
@@ -145,17 +153,20 @@ int ps_sync(ps_engine* e);
  * ps_set_scene.  ps_policy_step does this on the device from the simulated state; this entry point serves callers
  * that drive the encoder by hand.  Read the tokens back with ps_get("scene_tokens"). */
 int ps_update_obs(ps_engine* e, const float* obs_input, const uint8_t* obs_mask, const float* obs_pos, const float* obs_head);
-/* Destination rows per workgroup of the fused attention launches: 0 = the engine's choice for ONE rollout on the GPU
- * (k_chain16: as many rows as keep >= 256 workgroups in a launch -- 4 at 1024 destinations), 16 = throughput mode for
- * several engines sharing the GPU (a layer's weights cross a CU once per 16 rows; 64 workgroups per 1024-row launch, so
- * the launches of three or four rollouts fill the chip side by side).  1, 2, 4, 8, 16 are accepted by k_chain16; the
- * round-1 kernel (ps_set_chain_impl 1) takes 0, 2, 4.  Results do not depend on it beyond fp32 summation order. */
+/* Destination rows per workgroup of the fused attention launches = the engine's operating mode:
+ *   0       latency mode, ONE rollout on the GPU: the round-1 kernel k_attn_chain with 2 rows per workgroup (512 small
+ *           workgroups per 1024-row policy launch, two per CU);
+ *   8..16   throughput mode, several engines share the GPU: the policy layers run on k_chain16 -- node Linears as 16-row
+ *           MFMA GEMMs (a layer's weights cross a CU once per workgroup), rel-PE rows recomputed per 16-edge tile from 32 B of
+ *           geometry per edge -- with that many rows per 8-wave workgroup; 12 rows x 3 rollouts in flight = 258 workgroups,
+ *           one per CU, is what bench.py runs.  The other fused launches take 4 rows per workgroup then.
+ *   1, 2, 4 rows per workgroup of either kernel (k_chain16 shares a row's edge list between 8 / rows waves; k_attn_chain
+ *           takes 2 or 4) -- experiments.
+ * Results do not depend on it beyond fp32 summation order. */
 int ps_set_chain_rows(ps_engine* e, int32_t rows);
-/* Which fused-chain kernel runs the policy layers (and the other geometric layer chains as they move over):
- * 0 (default) = k_chain16: node Linears as 16-row MFMA GEMMs, rel-PE rows recomputed per tile from 32 B of geometry per edge;
- * 1 = k_attn_chain, the round-1 kernel (2-4 rows per workgroup, rel-PE operand images streamed from HBM) -- kept for
- * A/B measurements and as a second implementation the parity tests compare against.  Resets ps_set_chain_rows to 0 and
- * invalidates the encoded / generated stages. */
+/* Which fused-chain kernel runs the policy layers: 0 (default) = by mode as above, 1 = k_attn_chain always, 2 = k_chain16
+ * always.  Both stay in the library: each is the other's cross-check in the parity tests.  Resets ps_set_chain_rows to 0
+ * and invalidates the encoded / generated stages. */
 int ps_set_chain_impl(ps_engine* e, int32_t impl);
 /* The engine's hipStream_t (every entry point enqueues on it), so a host can order its own streams against the
  * engine with events instead of ps_sync -- bench.py overlaps the RCCL metric gather of rollout k with rollout k+1. */
@@ -180,8 +191,9 @@ int ps_set_state(ps_engine* e, int32_t steps, const float* traj, const float* ve
 /* Copy a named result to the host.  Names / shapes (A = number of valid agents, compact,
  * scene-major; Mv = valid polylines):
  *   "traj" [A, max_steps, 4] (x, y, sin, cos in the agent-init frame; traj_sam.py:588)
- *   "vel" [A, max_steps, 2]; "motion_pred" [R, A, K, target_steps, state_dim];
- *   "reconst_pred" [A, 2]; "policy_emd" [A, hidden]; "scene_tokens" [Mv + A, hidden];
+ *   "vel" [A, max_steps, 2]; "motion_pred" [R, A, K, target_steps, state_dim] (K = motion_k modes);
+ *   "reconst_pred" [A, 2]; "policy_emd" [A, hidden];
+ *   "goal_prob" [A, goal_pred_k], "goal_point" [A, goal_pred_k, 2] (decoder goal heads, when enabled); "scene_tokens" [Mv + A, hidden];
  *   "fused" [A, hidden] (last policy step); "obs_in" [A, hist, obs_dim] (last step_env);
  *   "edge_counts" [8] (a2a, s2s, p2p, s2p, a2p, m2p of the last step, cond, 0) as float.
  * Returns the number of floats written, or a negative error. */
@@ -215,6 +227,14 @@ int ps_time_rollout(ps_engine* e, int32_t warmup, int32_t iters, float* ms_rollo
 /* Average duration (ms) of the dominant kernel (the fused policy attention chain) over the
  * launches of the last ps_time_rollout / ps_rollout, measured with HIP events around each launch. */
 int ps_time_policy_kernel(ps_engine* e, int32_t iters, float* ms_kernel);
+
+/* Launch durations of the dominant kernel INSIDE a pipelined run: with events enabled every rollout records an event pair
+ * around each of its policy-chain launches on the engine's stream (such rollouts are launched eagerly instead of
+ * replayed from the graph: ROCm 7.2 cannot time events recorded by graph nodes); ps_policy_event_times syncs the stream
+ * and returns the R durations (ms) of the engine's LAST rollout -- while other engines' rollouts shared the GPU, if the
+ * host kept them in flight.  Returns R or a negative error. */
+int ps_enable_policy_events(ps_engine* e, int32_t on);
+int ps_policy_event_times(ps_engine* e, float* ms, int32_t capacity);
 
 /* Unit-test hooks for single primitives (parity against tests/golden/ref_pure_primitives.npz). */
 int ps_test_pointnet(ps_engine* e, int32_t which /*0 map, 1 obs*/, int32_t n_poly, int32_t P,

@@ -362,6 +362,19 @@ def decoder_fusion(Wt: W, spec: ModelSpec, scene: Dict, prompt_emd: T, prompt_ma
     return emd, dict(p2p=int(pp_src.numel()), s2p=int(sp_src.numel()))
 
 
+def goal_heads(Wt: W, spec: ModelSpec, emd: T, prompt_mask: T) -> Tuple[T, T]:
+    """Decoder._goal_pred (decoder/base.py:22-58): goal_prob [B, N, K] and goal_point [B, N, K, 2] from the decoder's
+    embedding of every prompt (zeros elsewhere); both heads are MLP([D, D/2, .]) with LayerNorm + ReLU between."""
+    B, N, d = emd.shape
+    K = spec.goal_pred_k
+    prob = torch.zeros(B, N, K, dtype=emd.dtype)
+    point = torch.zeros(B, N, K, 2, dtype=emd.dtype)
+    x = emd[prompt_mask]
+    prob[prompt_mask] = mlp(Wt, "decoder.goal_prob_head", [d, d // 2, K], x, True, False)
+    point[prompt_mask] = mlp(Wt, "decoder.goal_point_head", [d, d // 2, 2 * K], x, True, False).view(-1, K, 2)
+    return prob, point
+
+
 def condition_transform(Wt: W, spec: ModelSpec, cond: Optional[Dict], emd: T, prompt_mask: T,
                         prompt_pos: T, prompt_head: T) -> T:
     """ConditionTransformer.forward at 'policy_decoder' (condition_transformer/base.py:38-60)
@@ -515,6 +528,7 @@ def rollout(w: Dict[str, np.ndarray], spec: ModelSpec, scene_in: Dict, dtype=tor
       later replans (batch.extras['fut_obs'][t], traj_sam.py:221-270); policy agents' rows are overwritten by the
       simulation, observed agents that are not policy agents (prompt_mask False) replay the log
       optional cond = {'goal': {...}, 'v_action_tag': {...}}
+      optional mode_choice [R, B, N] int: motion mode followed per replan (models with motion_k > 1)
     """
     Wt = W(w, dtype)
     tt = lambda a, dt=dtype: (a if isinstance(a, torch.Tensor) else torch.from_numpy(np.asarray(a))).to(dt)
@@ -543,6 +557,7 @@ def rollout(w: Dict[str, np.ndarray], spec: ModelSpec, scene_in: Dict, dtype=tor
     emd, e = decoder_fusion(Wt, spec, scene, pemd, prompt_mask, obs_pos, obs_head)
     edges.update(e)
     emd_dec = emd
+    goal = goal_heads(Wt, spec, emd_dec, prompt_mask) if spec.goal_pred_k > 0 else None
     emd = condition_transform(Wt, spec, cond, emd, prompt_mask, obs_pos, obs_head)
     if collect:
         trace.update(map_emb=map_emb, obs_emb=obs_emb, scene_tokens=scene["scene_tokens"], prompt_emd=pemd,
@@ -598,8 +613,13 @@ def rollout(w: Dict[str, np.ndarray], spec: ModelSpec, scene_in: Dict, dtype=tor
         motion_preds.append(out["motion_pred"])
         fused.append(out["fused"])
         step_edges.append(out["edges"])
-        # step_agent_traj (traj_sam.py:276-349), TOP_K = 1 -> mode 0
-        pred = out["motion_pred"][:, 0, :spec.replan_freq]
+        # step_agent_traj (traj_sam.py:276-349): the mode picked among the top-k (scene_in['mode_choice'] [R, B, N], the
+        # reference's torch.topk + torch.randint draw replayed by the caller); TOP_K = 1 -> mode 0
+        if scene_in.get("mode_choice") is not None:
+            pick = tt(scene_in["mode_choice"][ti], torch.long)[prompt_mask]
+            pred = out["motion_pred"][torch.arange(pick.shape[0]), pick, :spec.replan_freq]
+        else:
+            pred = out["motion_pred"][:, 0, :spec.replan_freq]
         cur_last = traj[:, :, last - 1][prompt_mask]
         lth = torch.atan2(cur_last[:, 2], cur_last[:, 3])[:, None]
         pxy = batch_rotate_2d(pred[:, :, :2], lth) + cur_last[:, None, :2]
@@ -616,6 +636,8 @@ def rollout(w: Dict[str, np.ndarray], spec: ModelSpec, scene_in: Dict, dtype=tor
     res = dict(traj=traj[:, :, H:], vel=vel[:, :, H:], init_pos=init_pos, init_heading=init_head,
                motion_pred=torch.cat(motion_preds, dim=0), reconst_pred=out["reconst_pred"],
                policy_emd=emd, edges=edges, step_edges=step_edges)
+    if goal is not None:
+        res.update(goal_prob=goal[0], goal_point=goal[1])
     if collect:
         trace["fused"] = torch.stack(fused)
         res["trace"] = trace

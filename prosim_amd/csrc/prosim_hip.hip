@@ -90,7 +90,7 @@ struct ps_engine {
   AttnW* d_layers = nullptr;  // all layers, device copy (order: a2a s2s p2p s2p a2p m2p cnd)
   int L_a2a = 0, L_s2s = 0, L_p2p = 0, L_s2p = 0, L_a2p = 0, L_m2p = 0, L_cnd = 0;
   PointNetW pn_map{}, pn_obs{}, pn_drag{};   // pn_drag: DragPointEncoder (condition_encoders.py:152), optional
-  Mlp3W mlp_prompt{}, mlp_pred{};
+  Mlp3W mlp_prompt{}, mlp_pred{}, mlp_goal_prob{}, mlp_goal_point{};   // (goal heads: decoder/base.py:18-20, optional)
   HeadW head{};
   DevBuf<float> io_q, io_qt, io_cq, io_ar, io_av, io_l, io_s, io_g, io_m;   // split path / k_chain16: per-destination vectors (EdgeIO)
   CondW cond{};
@@ -110,7 +110,8 @@ struct ps_engine {
   DevBuf<int> d_map_rows, d_agent_rows, d_tok_scene, d_agent_type, d_r_map, d_r_agent, d_r_zero;
   DevBuf<float> d_tok, d_tok_pos, d_tok_ori, d_init_pos, d_init_head, d_cur_pos, d_cur_ori, d_prompt_pos, d_prompt_ori;
   DevBuf<float> d_xp, d_emd, d_xc, d_fused, d_obs_in, d_static_in, d_kv, d_kv_s2p, d_kv_m2p, d_kv_a2p;
-  DevBuf<float> d_traj, d_vel, d_motion, d_reconst;
+  DevBuf<float> d_traj, d_vel, d_motion, d_reconst, d_goal_prob, d_goal_point;
+  DevBuf<int> d_choice;                     // [R][A] motion mode each agent follows at each replan (ps_set_mode_choice; zeros = mode 0)
   DevBuf<_Float16> d_kh, d_kh_s2p, d_kh_m2p, d_kh_a2p;   // split-fp16 k rows beside each kv buffer
   EdgeSet e_a2a, e_s2s, e_p2p, e_s2p, e_a2p, e_m2p, e_cnd;
   DevBuf<ChainStep> d_steps;
@@ -154,9 +155,13 @@ struct ps_engine {
   hipGraph_t graph = nullptr;
   hipGraphExec_t graph_exec = nullptr;
   int chain_rows = 0;   // ps_set_chain_rows: 0 = latency-optimal choice, else rows per workgroup of the fused attention launches
-  int chain_impl = 0;   // ps_set_chain_impl: 0 = k_chain16 (16-row MFMA node phase, recomputed rel-PE) where it applies, 1 = k_attn_chain everywhere
+  int chain_impl = 0;   // ps_set_chain_impl: 0 = by mode (k_chain16 in throughput mode: chain_rows >= 8; k_attn_chain otherwise), 1 = k_attn_chain, 2 = k_chain16
   bool graph_ok = false;
   bool use_graph = true;
+  // ps_enable_policy_events: an event pair around every policy-chain launch of a rollout, recorded on the engine's stream
+  // (the rollout is then launched eagerly), so the launch durations of a PIPELINED run can be read afterwards
+  bool policy_events = false;
+  std::vector<hipEvent_t> pev;
 };
 
 namespace {
@@ -481,10 +486,11 @@ extern "C" int ps_create(const ps_config* cfg, int32_t n_tensors, const char* co
   if (!cfg || !out) return fail(PS_E_ARG, "null argument");
   if (cfg->hidden != D || cfg->heads != H || cfg->head_dim != DH)
     return fail(PS_E_ARG, "this build supports hidden=128, heads=8, head_dim=16 only");
-  if (cfg->hist_steps > 15 || cfg->obs_dim > 24 || cfg->map_dim > 24 || cfg->motion_k != 1 || cfg->state_dim < 5 ||
+  if (cfg->hist_steps > 15 || cfg->obs_dim > 24 || cfg->map_dim > 24 || cfg->motion_k < 1 || cfg->motion_k > 16 || cfg->state_dim < 5 ||
       cfg->target_steps * cfg->state_dim > 64 || cfg->map_pre_layers > 4 || cfg->obs_pre_layers > 4 ||
       cfg->map_mlp_layers - cfg->map_pre_layers > 4 || cfg->obs_mlp_layers - cfg->obs_pre_layers > 4)
-    return fail(PS_E_ARG, "unsupported config (hist<=15, obs_dim<=24, map_dim<=24, motion_k==1, steps*state<=64)");
+    return fail(PS_E_ARG, "unsupported config (hist<=15, obs_dim<=24, map_dim<=24, 1<=motion_k<=16, steps*state<=64)");
+  if (cfg->goal_pred_k < 0 || cfg->goal_pred_k > 64) return fail(PS_E_ARG, "goal_pred_k must be in 0..64");
   if (cfg->replan_freq < 1 || cfg->replan_freq > cfg->target_steps)
     return fail(PS_E_ARG, "replan_freq must be in 1..target_steps (a replan appends replan_freq of the target_steps predicted states)");
   if (cfg->pol_max_neigh < 1 || cfg->pol_max_neigh > 2047 || cfg->dec_max_neigh < 1 || cfg->dec_max_neigh > 2047)
@@ -512,6 +518,10 @@ extern "C" int ps_create(const ps_config* cfg, int32_t n_tensors, const char* co
                    cfg->drag_pre_layers, cfg->drag_mlp_layers, e->pn_drag);
   build_mlp3(b, "prompt_encoder.motion_pred.state_encoder", {cfg->prompt_dim, D, D}, false, e->mlp_prompt);
   if (cfg->obs_fusion_mlp) build_mlp3(b, "scene_encoder.obs_update_mlp", {2 * D, D, D}, false, e->mlp_obs_fuse);
+  if (cfg->goal_pred_k > 0) {
+    build_mlp3(b, "decoder.goal_prob_head", {D, D / 2, cfg->goal_pred_k}, false, e->mlp_goal_prob);
+    build_mlp3(b, "decoder.goal_point_head", {D, D / 2, 2 * cfg->goal_pred_k}, false, e->mlp_goal_point);
+  }
   const std::string pa = "policy.act_decoder";
   build_mlp3(b, pa + ".pred_mlp", {D, D, D / 2, 2}, false, e->mlp_pred);
   build_mlp3(b, pa + ".motion_head", {D, D, D / 2, cfg->target_steps * cfg->state_dim}, false, e->head.motion);
@@ -648,7 +658,7 @@ extern "C" void ps_destroy(ps_engine* e) {
   e->d_cur_pos.release(); e->d_cur_ori.release(); e->d_prompt_pos.release(); e->d_prompt_ori.release();
   e->d_xp.release(); e->d_emd.release(); e->d_xc.release(); e->d_fused.release(); e->d_obs_in.release();
   e->d_static_in.release(); e->d_kv.release(); e->d_kv_s2p.release(); e->d_kv_m2p.release(); e->d_kv_a2p.release();
-  e->d_traj.release(); e->d_vel.release(); e->d_motion.release(); e->d_reconst.release();
+  e->d_traj.release(); e->d_vel.release(); e->d_motion.release(); e->d_reconst.release(); e->d_choice.release();
   e->d_kh.release(); e->d_kh_s2p.release(); e->d_kh_m2p.release(); e->d_kh_a2p.release();
   for (EdgeSet* s : {&e->e_a2a, &e->e_s2s, &e->e_p2p, &e->e_s2p, &e->e_a2p, &e->e_m2p, &e->e_cnd, &e->e_ua, &e->e_um}) {
     s->cnt.release(); s->eoff.release(); s->esrc.release(); s->edst.release(); s->toff.release(); s->tdst.release(); s->rtA.release(); s->rtT.release(); s->geo.release();
@@ -661,6 +671,7 @@ extern "C" void ps_destroy(ps_engine* e) {
   drop_graph(e);
   if (e->arena_d) (void)hipFree(e->arena_d);
   if (e->d_layers) (void)hipFree(e->d_layers);
+  for (auto ev : e->pev) if (ev) (void)hipEventDestroy(ev);
   if (e->ev0) (void)hipEventDestroy(e->ev0);
   if (e->ev1) (void)hipEventDestroy(e->ev1);
   if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -833,8 +844,11 @@ extern "C" int ps_set_scene(ps_engine* e, int32_t B, int32_t M, int32_t P, int32
       e->d_kh.ensure((size_t)(Mv + A) * 256) || e->d_kh_s2p.ensure((size_t)L6 * (Mv + A) * 256) ||
       e->d_kh_m2p.ensure((size_t)L6 * std::max(Mv, 1) * 256) || e->d_kh_a2p.ensure((size_t)L6 * A * 256) ||
       e->d_traj.ensure((size_t)A * e->stride_steps * 4) || e->d_vel.ensure((size_t)A * e->stride_steps * 2) ||
-      e->d_motion.ensure((size_t)R * A * c.target_steps * c.state_dim) || e->d_reconst.ensure((size_t)A * 2))
+      e->d_motion.ensure((size_t)R * A * c.motion_k * c.target_steps * c.state_dim) || e->d_reconst.ensure((size_t)A * 2) ||
+      e->d_choice.ensure((size_t)R * A) || e->d_goal_prob.ensure((size_t)A * std::max(1, c.goal_pred_k)) ||
+      e->d_goal_point.ensure((size_t)A * 2 * std::max(1, c.goal_pred_k)))
     return fail(PS_E_HIP, "device allocation failed");
+  HIPCHK(hipMemsetAsync(e->d_choice.p, 0, sizeof(int) * (size_t)R * A, st));   // mode 0 until ps_set_mode_choice
   // ---- edge sets: capacities from worst-case degrees
   auto mn = [](int a, int b) { return a < b ? a : b; };
   const int tokS = e->maxA_scene + e->maxM_scene;
@@ -1153,6 +1167,25 @@ extern "C" int ps_set_future_log(ps_engine* e, const float* fut_input, const uin
   return PS_OK;
 }
 
+extern "C" int ps_set_mode_choice(ps_engine* e, const int32_t* choice) {
+  if (!e || !e->have_scene) return fail(PS_E_STATE, "ps_set_mode_choice before ps_set_scene");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  const ps_config& c = e->cfg;
+  const int R = (c.max_steps + c.replan_freq - 1) / c.replan_freq, A = e->A;
+  std::vector<int> rows((size_t)R * A, 0);
+  if (choice)
+    for (int r = 0; r < R; ++r)
+      for (int i = 0; i < A; ++i) {
+        const int k = choice[(size_t)r * e->B * e->N + e->agent_rows[i]];
+        if (e->is_policy_h[i] && (k < 0 || k >= c.motion_k)) return fail(PS_E_ARG, "ps_set_mode_choice: mode index outside 0..motion_k-1");
+        rows[(size_t)r * A + i] = e->is_policy_h[i] ? k : 0;
+      }
+  // (the captured graph reads the table through its device pointer: no re-capture)
+  HIPCHK(hipMemcpyAsync(e->d_choice.p, rows.data(), sizeof(int) * rows.size(), hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return PS_OK;
+}
+
 extern "C" int32_t ps_num_policy_agents(ps_engine* e) { return e ? e->n_policy : 0; }
 // flags[i] = 1 if agent row i (the order of every per-agent result) is a policy agent, 0 if it replays the log
 extern "C" int ps_policy_flags(ps_engine* e, int32_t* flags, int64_t capacity) {
@@ -1168,7 +1201,7 @@ namespace {
 // split-path exchange buffers, grown on demand (never inside a captured rollout: ps_set_scene sizes them first)
 int io_for(ps_engine* e, int Nd, EdgeIO& io) {
   const size_t n = (size_t)std::max(Nd, 1);
-  if (e->io_q.ensure(n * 128) || e->io_qt.ensure(n * 1024) || e->io_cq.ensure(n * 8) || e->io_ar.ensure(n * 1024) ||
+  if (e->io_q.ensure(n * 128) || e->io_qt.ensure(n * C16_QS) || e->io_cq.ensure(n * 8) || e->io_ar.ensure(n * C16_QS) ||
       e->io_av.ensure(n * 128) || e->io_l.ensure(n * 8) || e->io_s.ensure(n * 128) || e->io_g.ensure(n * 128) || e->io_m.ensure(n * 8))
     return -1;
   io.q = e->io_q.p; io.qt = e->io_qt.p; io.cq = e->io_cq.p; io.ar = e->io_ar.p; io.av = e->io_av.p; io.l = e->io_l.p;
@@ -1343,10 +1376,13 @@ void launch_geo(ps_engine* e, const PeArgs* a, int nsets) {
 
 // Fused chain, second generation (ps_chain16.h).  rows per workgroup: the engine's choice keeps >= 256 workgroups in a
 // launch while it can (4 rows at 1024 destinations), ps_set_chain_rows overrides (16 = throughput mode).
+// does the policy chain run on k_chain16?  (ps_set_chain_impl; 0 = in throughput mode only: alone on the GPU the
+// round-1 kernel's 512 small workgroups still finish a 1024-row launch sooner, 0.53 against 0.64 ms)
+bool use_c16(const ps_engine* e) { return e->chain_impl == 2 || (e->chain_impl == 0 && e->chain_rows >= 8); }
 int chain16_rows(ps_engine* e, int Nd) {
   static const int env_rows = getenv("PS_C16_ROWS") ? atoi(getenv("PS_C16_ROWS")) : 0;   // experiments only
   int rows = Nd >= 4096 ? 16 : (Nd >= 2048 ? 8 : (Nd >= 512 ? 4 : (Nd >= 256 ? 2 : 1)));
-  if (e->chain_rows == 1 || e->chain_rows == 2 || e->chain_rows == 4 || e->chain_rows == 8 || e->chain_rows == 16) rows = e->chain_rows;
+  if (e->chain_rows >= 1 && e->chain_rows <= 16) rows = e->chain_rows;
   if (env_rows) rows = env_rows;
   return rows;
 }
@@ -1365,8 +1401,8 @@ int launch_chain16(ps_engine* e, float* x, int Nd, const ChainStep* steps, int n
   static unsigned long long* d_prof = nullptr;
   unsigned long long* prof = nullptr;
   if (want_prof && timed && e->time_chain) {
-    if (!d_prof && hipMalloc(&d_prof, 16 * sizeof(unsigned long long)) != hipSuccess) d_prof = nullptr;
-    if (d_prof) (void)hipMemsetAsync(d_prof, 0, 16 * sizeof(unsigned long long), st);
+    if (!d_prof && hipMalloc(&d_prof, 48 * sizeof(unsigned long long)) != hipSuccess) d_prof = nullptr;
+    if (d_prof) (void)hipMemsetAsync(d_prof, 0, 48 * sizeof(unsigned long long), st);
     prof = d_prof;
   }
 #define PS_C16(NWW, POL) \
@@ -1383,10 +1419,15 @@ int launch_chain16(ps_engine* e, float* x, int Nd, const ChainStep* steps, int n
     float ms = 0;
     (void)hipEventElapsedTime(&ms, e->ev0, e->ev1);
     if (prof) {
-      unsigned long long h[16];
+      unsigned long long h[48];
       (void)hipMemcpy(h, prof, sizeof(h), hipMemcpyDeviceToHost);
       const int nwg = (Nd + rows - 1) / rows;
       fprintf(stderr, "[chain16 prof] rows=%d nw=%d wgs=%d %.1f us; mean cycles per workgroup:", rows, nw, nwg, ms * 1e3);
+      fprintf(stderr, " POST stages:");
+      for (int i = 16; i < 32; ++i) fprintf(stderr, " %.0f", (double)h[i] / nwg);
+      fprintf(stderr, " PRE stages:");
+      for (int i = 32; i < 40; ++i) fprintf(stderr, " %.0f", (double)h[i] / nwg);
+      fprintf(stderr, " |");
       static const char* nm[13] = {"PRE", "EDGE", "POST", "-", "rec+kissue", "fourier", "stage+score", "softmax", "a_r", "a_v", "row-epi", "row-pro", "tiles"};
       for (int i = 0; i < 13; ++i) fprintf(stderr, " %s:%.0f", nm[i], (double)h[i] / nwg);
       fprintf(stderr, "\n");
@@ -1526,6 +1567,12 @@ extern "C" int ps_generate_policy(ps_engine* e) {
     if (launch_chain(e, e->d_xp.p, A, e->step_dec + 2 * i, 2, md, false, nullptr, 0, 0, nullptr, xcd_on(2, false))) return PS_E_HIP;
   }
   HIPCHK(hipMemcpyAsync(e->d_emd.p, e->d_xp.p, sizeof(float) * (size_t)A * D, hipMemcpyDeviceToDevice, st));
+  if (c.goal_pred_k > 0) {   // Decoder._goal_pred on the decoder's embedding (decoder/base.py:22-58, sym_coord.py:133-136)
+    hipLaunchKernelGGL(k_mlp_rows, dim3(A), dim3(128), 0, st, e->mlp_goal_prob, (const float*)e->d_xp.p, (const int*)nullptr, D,
+                       e->d_goal_prob.p, c.goal_pred_k, c.ln_eps);
+    hipLaunchKernelGGL(k_mlp_rows, dim3(A), dim3(128), 0, st, e->mlp_goal_point, (const float*)e->d_xp.p, (const int*)nullptr, D,
+                       e->d_goal_point.p, 2 * c.goal_pred_k, c.ln_eps);
+  }
   // condition transformer at 'policy_decoder' (traj_sam.py:129-137)
   if (e->have_cond && c.cond_layers > 0) {
     if (e->n_drag > 0)
@@ -1633,17 +1680,23 @@ extern "C" int ps_policy_step(ps_engine* e, int32_t t_idx) {
     const RadArgs ra[2] = {{&e->e_a2p, e->d_r_agent.p, nullptr, c.pol_agent_radius, c.pol_max_neigh, -1,
                             e->all_policy ? nullptr : (const int*)e->d_tok_live.p, Mv},
                            {&e->e_m2p, e->d_r_map.p, nullptr, c.pol_map_radius, c.pol_max_neigh, -1}};
-    launch_radius(e, ra, 2, e->d_cur_pos.p, pscene, A, e->d_tok_ori.p, e->d_cur_ori.p, e->chain_impl == 0 ? 2 : 1);
+    launch_radius(e, ra, 2, e->d_cur_pos.p, pscene, A, e->d_tok_ori.p, e->d_cur_ori.p, use_c16(e) ? 2 : 1);
   }
   const int md = std::max(e->e_a2p.maxdeg, e->e_m2p.maxdeg);
+  if (e->policy_events && (int)e->pev.size() >= 2 * R) HIPCHK(hipEventRecord(e->pev[2 * t_idx], st));
   // the policy tokens enter every replan unchanged (d_emd); the fused features leave to d_fused
-  if (e->chain_impl == 0) {
+  if (use_c16(e)) {
     if (launch_chain16(e, e->d_fused.p, A, e->d_steps.p + e->step_pol, 2 * c.pol_layers, true, e->d_emd.p, xcd_on(0, true))) return PS_E_HIP;
   } else if (launch_chain(e, e->d_fused.p, A, e->step_pol, 2 * c.pol_layers, md, true, nullptr, 0, 0, e->d_emd.p, xcd_on(0, true))) return PS_E_HIP;
+  if (e->policy_events && (int)e->pev.size() >= 2 * R) HIPCHK(hipEventRecord(e->pev[2 * t_idx + 1], st));
   // _compute_traj + step_agent_traj
-  hipLaunchKernelGGL(k_policy_head_mfma, dim3((A + 15) / 16), dim3(256), 0, st, e->head, (const float*)e->d_fused.p,
-                     (const int*)e->d_agent_type.p, A, c.motion_k, c.target_steps, c.state_dim, e->d_motion.p + (size_t)t_idx * A * c.target_steps * c.state_dim,
-                     e->d_traj.p, e->d_vel.p, e->stride_steps, last, c.replan_freq, c.ln_eps);
+  {
+    const int G = 16 / c.motion_k;   // agents per workgroup: one 16-row tile holds G agents x K modes
+    hipLaunchKernelGGL(k_policy_head_mfma, dim3((A + G - 1) / G), dim3(256), 0, st, e->head, (const float*)e->d_fused.p,
+                       (const int*)e->d_agent_type.p, A, c.motion_k, c.target_steps, c.state_dim,
+                       e->d_motion.p + (size_t)t_idx * A * c.motion_k * c.target_steps * c.state_dim,
+                       e->d_traj.p, e->d_vel.p, e->stride_steps, last, c.replan_freq, c.ln_eps, (const int*)(e->d_choice.p + (size_t)t_idx * A));
+  }
   HIPCHK(hipGetLastError());
   return PS_OK;
 }
@@ -1674,7 +1727,9 @@ void drop_graph(ps_engine* e) {
 extern "C" int ps_rollout(ps_engine* e) {
   if (!e || !e->have_scene) return fail(PS_E_STATE, "ps_rollout before ps_set_scene");
   HIPCHK(hipSetDevice(e->cfg.device));
-  if (!e->use_graph || e->time_chain) return rollout_eager(e);
+  // (event pairs do not survive graph capture on ROCm 7.2 -- hipEventElapsedTime rejects events recorded by graph nodes --
+  // so a rollout with policy events enabled is launched eagerly: ~200 launches, ~1 ms of host time per rollout)
+  if (!e->use_graph || e->time_chain || e->policy_events) return rollout_eager(e);
   if (!e->graph_ok) {
     drop_graph(e);
     HIPCHK(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
@@ -1758,7 +1813,7 @@ extern "C" int ps_update_obs(ps_engine* e, const float* obs_input, const uint8_t
 
 extern "C" int ps_set_chain_rows(ps_engine* e, int32_t rows) {
   if (!e) return fail(PS_E_ARG, "null engine");
-  if (rows != 0 && rows != 1 && rows != 2 && rows != 4 && rows != 8 && rows != 16) return fail(PS_E_ARG, "ps_set_chain_rows: 0 (auto), 1, 2, 4, 8 or 16");
+  if (rows < 0 || rows > 16 || (rows < 8 && rows != 0 && rows != 1 && rows != 2 && rows != 4)) return fail(PS_E_ARG, "ps_set_chain_rows: 0 (auto), 1, 2, 4, or 8..16");
   if (e->chain_impl == 1 && rows != 0 && rows != 2 && rows != 4) return fail(PS_E_ARG, "ps_set_chain_rows: k_attn_chain (ps_set_chain_impl 1) takes 0, 2 or 4");
   if (rows != e->chain_rows) drop_graph(e);
   e->chain_rows = rows;
@@ -1767,7 +1822,7 @@ extern "C" int ps_set_chain_rows(ps_engine* e, int32_t rows) {
 
 extern "C" int ps_set_chain_impl(ps_engine* e, int32_t impl) {
   if (!e) return fail(PS_E_ARG, "null engine");
-  if (impl != 0 && impl != 1) return fail(PS_E_ARG, "ps_set_chain_impl: 0 (k_chain16) or 1 (k_attn_chain)");
+  if (impl < 0 || impl > 2) return fail(PS_E_ARG, "ps_set_chain_impl: 0 (by mode), 1 (k_attn_chain) or 2 (k_chain16)");
   if (impl != e->chain_impl) {
     drop_graph(e);
     e->chain_rows = 0;
@@ -1775,6 +1830,29 @@ extern "C" int ps_set_chain_impl(ps_engine* e, int32_t impl) {
   }
   e->chain_impl = impl;
   return PS_OK;
+}
+
+extern "C" int ps_enable_policy_events(ps_engine* e, int32_t on) {
+  if (!e) return fail(PS_E_ARG, "null engine");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  const int R = (e->cfg.max_steps + e->cfg.replan_freq - 1) / e->cfg.replan_freq;
+  if (on && e->pev.empty()) {
+    e->pev.resize(2 * R, nullptr);
+    for (auto& ev : e->pev) HIPCHK(hipEventCreate(&ev));
+  }
+  if ((on != 0) != e->policy_events) drop_graph(e);
+  e->policy_events = on != 0;
+  return PS_OK;
+}
+extern "C" int ps_policy_event_times(ps_engine* e, float* ms, int32_t capacity) {
+  if (!e || !ms) return fail(PS_E_ARG, "null argument");
+  const int R = (e->cfg.max_steps + e->cfg.replan_freq - 1) / e->cfg.replan_freq;
+  if (!e->policy_events || (int)e->pev.size() < 2 * R) return fail(PS_E_STATE, "ps_policy_event_times: call ps_enable_policy_events first");
+  if (capacity < R) return fail(PS_E_ARG, "destination too small");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  for (int t = 0; t < R; ++t) HIPCHK(hipEventElapsedTime(&ms[t], e->pev[2 * t], e->pev[2 * t + 1]));
+  return R;
 }
 
 extern "C" void* ps_stream(ps_engine* e) { return e ? (void*)e->stream : nullptr; }
@@ -1845,9 +1923,13 @@ extern "C" int64_t ps_get(ps_engine* e, const char* name, float* dst, int64_t ca
       return fail(PS_E_HIP, "hipMemcpy2D D2H");
     return count;
   }
-  if (n == "motion_pred") return copy(e->d_motion.p, (int64_t)R * A * c.target_steps * c.state_dim);
+  if (n == "motion_pred") return copy(e->d_motion.p, (int64_t)R * A * c.motion_k * c.target_steps * c.state_dim);
   if (n == "reconst_pred") return copy(e->d_reconst.p, (int64_t)A * 2);
   if (n == "policy_emd") return copy(e->d_emd.p, (int64_t)A * D);
+  if (n == "goal_prob" || n == "goal_point") {
+    if (c.goal_pred_k <= 0) return fail(PS_E_ARG, "the engine was created without goal heads (goal_pred_k = 0)");
+    return n == "goal_prob" ? copy(e->d_goal_prob.p, (int64_t)A * c.goal_pred_k) : copy(e->d_goal_point.p, (int64_t)A * 2 * c.goal_pred_k);
+  }
   if (n == "scene_tokens") return copy(e->d_tok.p, (int64_t)(Mv + A) * D);
   if (n == "fused") return copy(e->d_fused.p, (int64_t)A * D);
   if (n == "obs_in") return copy(e->d_obs_in.p, (int64_t)A * c.hist_steps * c.obs_dim);
@@ -2142,7 +2224,7 @@ extern "C" int ps_policy_forward(ps_engine* e, int32_t n_scenes, int32_t Na, con
   auto mn = [](int a, int b) { return a < b ? a : b; };
   const int da = mn(c.pol_max_neigh, maxA), dm = mn(c.pol_max_neigh, maxM);
   const int L = c.pol_layers;
-  const int OUT = c.target_steps * c.state_dim;
+  const int OUT = c.motion_k * c.target_steps * c.state_dim;
   std::vector<int> ptype(p_type, p_type + A);
   if (upload(d_pos, pos.data(), pos.size(), st) || upload(d_ori, ori.data(), ori.size(), st) ||
       d_atok.ensure((size_t)std::max(Na, 1) * D) || d_mtok.ensure((size_t)std::max(Nm, 1) * D) ||
@@ -2159,7 +2241,7 @@ extern "C" int ps_policy_forward(ps_engine* e, int32_t n_scenes, int32_t Na, con
   std::swap(e->d_tok_pos, d_pos);
   launch_kv(e, d_atok.p, Na, e->L_a2p, L, d_kva.p, d_kha.p, (size_t)Na * 256);
   launch_kv(e, d_mtok.p, Nm, e->L_m2p, L, d_kvm.p, d_khm.p, (size_t)Nm * 256);
-  const int pe_mode = e->chain_impl == 0 ? 2 : 1;
+  const int pe_mode = use_c16(e) ? 2 : 1;
   launch_radius(e, ea, d_ragent.p, nullptr, d_ppos.p, d_pscene.p, A, c.pol_agent_radius, c.pol_max_neigh, -1, d_ori.p, d_pori.p, nullptr, 0, pe_mode);
   launch_radius(e, em, d_rmap.p, nullptr, d_ppos.p, d_pscene.p, A, c.pol_map_radius, c.pol_max_neigh, -1, d_ori.p, d_pori.p, nullptr, 0, pe_mode);
   std::vector<ChainStep> hs;
@@ -2173,7 +2255,7 @@ extern "C" int ps_policy_forward(ps_engine* e, int32_t n_scenes, int32_t Na, con
   }
   int rc = 0;
   if (upload(d_steps, hs.data(), hs.size(), st)) rc = fail(PS_E_HIP, "step upload failed");
-  if (!rc) rc = e->chain_impl == 0 ? launch_chain16(e, d_x.p, A, d_steps.p, 2 * L, false, nullptr, false)
+  if (!rc) rc = use_c16(e) ? launch_chain16(e, d_x.p, A, d_steps.p, 2 * L, false, nullptr, false)
                                    : launch_chain(e, d_x.p, A, 0, 2 * L, std::max(da, dm), false, d_steps.p);
   if (!rc) {
     // head with a neutral state (last pose = origin, heading 0): only motion_pred is read back
@@ -2181,8 +2263,8 @@ extern "C" int ps_policy_forward(ps_engine* e, int32_t n_scenes, int32_t Na, con
     std::vector<float> unit((size_t)A * 16 * 4, 0.f);
     for (size_t i = 0; i < (size_t)A * 16; ++i) unit[i * 4 + 3] = 1.f;
     (void)hipMemcpyAsync(d_traj.p, unit.data(), sizeof(float) * unit.size(), hipMemcpyHostToDevice, st);
-    hipLaunchKernelGGL(k_policy_head_mfma, dim3((A + 15) / 16), dim3(256), 0, st, e->head, (const float*)d_x.p, (const int*)d_ptype.p, A,
-                       c.motion_k, c.target_steps, c.state_dim, d_motion.p, d_traj.p, d_vel.p, 16, 1, 0, c.ln_eps);
+    hipLaunchKernelGGL(k_policy_head_mfma, dim3((A + 16 / c.motion_k - 1) / (16 / c.motion_k)), dim3(256), 0, st, e->head, (const float*)d_x.p, (const int*)d_ptype.p, A,
+                       c.motion_k, c.target_steps, c.state_dim, d_motion.p, d_traj.p, d_vel.p, 16, 1, 0, c.ln_eps, (const int*)nullptr);
     if (hipStreamSynchronize(st) != hipSuccess) rc = fail(PS_E_HIP, "ps_policy_forward: kernel failure");
   }
   std::swap(e->d_tok_pos, d_pos);

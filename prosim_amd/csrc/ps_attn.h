@@ -901,7 +901,8 @@ __device__ __forceinline__ void gemm16(RingT& R, const _Float16* __restrict__ Ah
   constexpr int KB = K32 < 4 ? K32 : 4, KG = (K32 + KB - 1) / KB;
   const int mi = lane & 15, kq = lane >> 4;
   const int G = ((ntiles - wave + NWV - 1) / NWV) * KG;
-  floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+  // three accumulators (hi*hi, hi*lo, lo*hi): the MFMAs of a k-block do not wait for one another
+  floatx4 acc = {0.f, 0.f, 0.f, 0.f}, acc1 = acc, acc2 = acc;
   constexpr int DEPTH = RingT::DEPTH;
   for (int g0 = 0; g0 < G; g0 += DEPTH) {
 #pragma unroll
@@ -913,15 +914,16 @@ __device__ __forceinline__ void gemm16(RingT& R, const _Float16* __restrict__ Ah
         for (int j = 0; j < KB; ++j) { ch[j] = R.h[d][j]; cl[j] = R.l[d][j]; }
         if (g + DEPTH < G) frag_issue<K32, RingT, NWV>(R, d, F, g + DEPTH, wave, lane);
         const int kg = g % KG;
-        if (kg == 0) acc = floatx4{0.f, 0.f, 0.f, 0.f};
+        if (kg == 0) { acc = floatx4{0.f, 0.f, 0.f, 0.f}; acc1 = acc; acc2 = acc; }
 #pragma unroll
         for (int j = 0; j < KB; ++j) {
           const half8 ah = *reinterpret_cast<const half8*>(Ah + mi * as + (kg * KB + j) * 32 + kq * 8);
           const half8 al = *reinterpret_cast<const half8*>(Al + mi * as + (kg * KB + j) * 32 + kq * 8);
           acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, ch[j], acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, cl[j], acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, ch[j], acc, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, cl[j], acc1, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, ch[j], acc2, 0, 0, 0);
         }
+        if (kg == KG - 1) acc += acc1 + acc2;
         if (kg == KG - 1) {
           const int nt = wave + NWV * (g / KG);
           if (ph) {

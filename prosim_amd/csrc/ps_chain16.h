@@ -156,6 +156,8 @@ __global__ __launch_bounds__(256) void k_edge_geo(GeoSets sets, const float* __r
 // LDS plan (bytes): k_node's node-phase buffers, then cq and the row counter, then whatever the wave-private areas of
 // the edge phase (k staging 4 KB | probability tile 0.5 KB | feature tile 3.5 KB | source rows of the tile 64 B) need
 // beyond the operand planes and the GEMM result buffer, which they alias (dead while the edge phase runs).
+constexpr int C16_QS = 1024 + 32;   // floats between the q~ / a_r scratch rows of consecutive destinations: 4 KB apart every row of a
+                                    // workgroup would queue on one L2 channel
 constexpr int C16_FS = 112;   // feature-tile row stride in halfs: 96 features + 16 pad = 56 dwords, so the 8 rows x 32 B that a
                               // half-wave's transposed read touches (and the 8 rows of a b128 write group) fall on distinct banks
 constexpr size_t C16_NODE_BYTES = ND_LDS_BYTES;
@@ -282,7 +284,7 @@ __device__ __noinline__ void c16_edge_phase(const ChainStep* __restrict__ stp, E
         float cqm;
         {
           const int hB = mi & 7;
-          const float* qtp = io.qt + (size_t)r * 1024 + hB * 128 + 8 * kq;
+          const float* qtp = io.qt + (size_t)r * C16_QS + hB * 128 + 8 * kq;
           const float* qp = AG + lr * ND_XS + 8 * kq;
 #pragma unroll
           for (int ks = 0; ks < 4; ++ks) {
@@ -376,7 +378,7 @@ __device__ __noinline__ void c16_edge_phase(const ChainStep* __restrict__ stp, E
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
               const float v = acc[r4] + dpp_xor8(acc[r4]);   // columns h and h + 8 (q hi | q lo)
-              sreg[r4] = (4 * kq + r4 < n) ? (v + cqm) * 0.25f : -INFINITY;
+              sreg[r4] = (4 * kq + r4 < n) ? (v + cqm) * (0.25f * 1.44269504088896341f) : -INFINITY;   // in units of log2: exp(x) = exp2(x log2 e)
             }
           }
           C16_EMARK(6);
@@ -390,11 +392,11 @@ __device__ __noinline__ void c16_edge_phase(const ChainStep* __restrict__ stp, E
           tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
           tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
           const float m_new = fmaxf(m_run, tmax);   // finite: the tile has at least one edge
-          const float scale = (m_run == -INFINITY) ? 0.f : expf(m_run - m_new);
+          const float scale = (m_run == -INFINITY) ? 0.f : exp2f(m_run - m_new);
           float psum = 0.f;
 #pragma unroll
           for (int r4 = 0; r4 < 4; ++r4) {
-            const float p = expf(sreg[r4] - m_new);   // exp(-inf) = 0 for the slots past the edge list
+            const float p = exp2f(sreg[r4] - m_new);   // 2^-inf = 0 for the slots past the edge list
             psum += p;
             if (mi < 8) Pt[(4 * kq + r4) * 8 + mi] = p;
           }
@@ -469,7 +471,7 @@ __device__ __noinline__ void c16_edge_phase(const ChainStep* __restrict__ stp, E
 #pragma unroll
           for (int r4 = 0; r4 < 4; ++r4) {
             const float v = swap_add32(ar[cb][r4], ar[cb + 1][r4]);   // lanes < 32: block cb, lanes >= 32: block cb + 1
-            io.ar[slot * 1024 + (4 * ((lane >> 4) & 1) + r4) * 128 + (cb + (lane >> 5)) * 16 + (lane & 15)] = v;
+            io.ar[slot * C16_QS + (4 * ((lane >> 4) & 1) + r4) * 128 + (cb + (lane >> 5)) * 16 + (lane & 15)] = v;
           }
         }
         C16_EMARK(10);
@@ -573,7 +575,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void k_chain16(float* _
           for (int p = 0; p < W; ++p) {
             const size_t slot = (size_t)p * Nd + grow;
             const float mp = ldg1(io.m + slot * 8 + (ec >> 4));
-            const float sc = (mp == -INFINITY) ? 0.f : expf(mp - mm);
+            const float sc = (mp == -INFINITY) ? 0.f : exp2f(mp - mm);
             in_l = fmaf(ldg1(io.l + slot * 8 + (ec >> 4)), sc, in_l);
             const float4 a0 = ldg4(io.av + slot * 128 + ec), a1 = ldg4(io.av + slot * 128 + ec + 4);
             in_av0.x = fmaf(a0.x, sc, in_av0.x); in_av0.y = fmaf(a0.y, sc, in_av0.y); in_av0.z = fmaf(a0.z, sc, in_av0.z); in_av0.w = fmaf(a0.w, sc, in_av0.w);
@@ -595,20 +597,26 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void k_chain16(float* _
             bh[ks] = ldgh8(f);
             bl[ks] = ldgh8(f + 512);
           }
-          if (mi < nrows) {
+          if (mi < nrows && W == 1) {   // one wave per row: the row's sums as they are (all six loads in flight at once)
+            const float* ap_ = io.ar + (size_t)(row0 + mi) * C16_QS + h * 128 + kq * 8;
+            float4 a0[3], a1[3];
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks) { a0[ks] = ldg4(ap_ + ks * 32); a1[ks] = ldg4(ap_ + ks * 32 + 4); }
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks) {
+              av_[ks][0] = a0[ks].x; av_[ks][1] = a0[ks].y; av_[ks][2] = a0[ks].z; av_[ks][3] = a0[ks].w;
+              av_[ks][4] = a1[ks].x; av_[ks][5] = a1[ks].y; av_[ks][6] = a1[ks].z; av_[ks][7] = a1[ks].w;
+            }
+          } else if (mi < nrows) {      // W partial sums: common maximum, rescale, add
             float mm = -INFINITY;
-            if (W > 1)
-              for (int p = 0; p < W; ++p) mm = fmaxf(mm, ldg1(io.m + ((size_t)p * Nd + row0 + mi) * 8 + h));
+            for (int p = 0; p < W; ++p) mm = fmaxf(mm, ldg1(io.m + ((size_t)p * Nd + row0 + mi) * 8 + h));
             for (int p = 0; p < W; ++p) {
               const size_t slot = (size_t)p * Nd + row0 + mi;
-              float sc = 1.f;
-              if (W > 1) {
-                const float mp = ldg1(io.m + slot * 8 + h);
-                sc = (mp == -INFINITY) ? 0.f : expf(mp - mm);
-              }
+              const float mp = ldg1(io.m + slot * 8 + h);
+              const float sc = (mp == -INFINITY) ? 0.f : exp2f(mp - mm);
 #pragma unroll
               for (int ks = 0; ks < 3; ++ks) {
-                const float* ap_ = io.ar + slot * 1024 + h * 128 + ks * 32 + kq * 8;
+                const float* ap_ = io.ar + slot * C16_QS + h * 128 + ks * 32 + kq * 8;
                 const float4 a0 = ldg4(ap_), a1 = ldg4(ap_ + 4);
                 av_[ks][0] = fmaf(a0.x, sc, av_[ks][0]); av_[ks][1] = fmaf(a0.y, sc, av_[ks][1]);
                 av_[ks][2] = fmaf(a0.z, sc, av_[ks][2]); av_[ks][3] = fmaf(a0.w, sc, av_[ks][3]);
@@ -632,6 +640,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void k_chain16(float* _
         }
       }
       __syncthreads();
+      C16_MARK(16);
       float agg[8];
       if (epi) {   // agg = (a_v + fold + l * vb) / (l + 1e-16)   (:89, :100)
         const float l = in_l;
@@ -642,9 +651,11 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void k_chain16(float* _
         planes_store8(P0h + er * ND_AS + ec, P0l + er * ND_AS + ec, agg);
       }
       __syncthreads();
+      C16_MARK(17);
       gemm16<4, Ring, NWV>(R, P0h, P0l, ND_AS, w.Fga, 8, C, ND_CS, wave, lane);
       frag_prefetch<4, Ring, NWV>(R, w.Fout, 8, wave, lane);
       __syncthreads();
+      C16_MARK(18);
       {   // gated update (:106-107): g = sigmoid(Wg [agg | x_dst] + bg); u = agg + g * (to_s(x_dst) - agg)
         const float gv[8] = {in_g0.x, in_g0.y, in_g0.z, in_g0.w, in_g1.x, in_g1.y, in_g1.z, in_g1.w};
         const float sv[8] = {in_s0.x, in_s0.y, in_s0.z, in_s0.w, in_s1.x, in_s1.y, in_s1.z, in_s1.w};
@@ -657,12 +668,15 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void k_chain16(float* _
           }
         }
         __syncthreads();   // every thread has read its gate columns of C and P0 is no longer an operand
+      C16_MARK(19);
         if (epi) planes_store8(P0h + er * ND_AS + ec, P0l + er * ND_AS + ec, u);
       }
       __syncthreads();
+      C16_MARK(20);
       gemm16<4, Ring, NWV>(R, P0h, P0l, ND_AS, w.Fout, 8, C, ND_CS, wave, lane);
       frag_prefetch<4, Ring, NWV>(R, w.F1, 32, wave, lane);
       __syncthreads();
+      C16_MARK(21);
       {   // x = x + LN_post(to_out(u))  (:76), then LN_ffpre(x)  (:77)
         float o[8], xv[8];
         if (epi) {
@@ -677,15 +691,19 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void k_chain16(float* _
           row16_ln(xv, sp + SP_LN_FFPRE_W, sp + SP_LN_FFPRE_B, ec, eps);
         }
         __syncthreads();
+      C16_MARK(22);
         if (epi) planes_store8(P0h + er * ND_AS + ec, P0l + er * ND_AS + ec, xv);
       }
       __syncthreads();
+      C16_MARK(23);
       gemm16<4, Ring, NWV>(R, P0h, P0l, ND_AS, w.F1, 32, nullptr, 0, wave, lane, P1h, P1l, ND_AS5, sp + SP_B1);
       frag_prefetch<16, Ring, NWV>(R, w.F2, 8, wave, lane);
       __syncthreads();
+      C16_MARK(24);
       gemm16<16, Ring, NWV>(R, P1h, P1l, ND_AS5, w.F2, 8, C, ND_CS, wave, lane);
       if (s + 1 < nsteps) frag_prefetch<4, Ring, NWV>(R, steps[s + 1].w.Fqsg, 24, wave, lane);   // (the next PRE's first GEMM)
       __syncthreads();
+      C16_MARK(25);
       if (epi) {   // x = x + LN_ffpost(FFN)
         float y[8];
 #pragma unroll
@@ -702,6 +720,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void k_chain16(float* _
         }
       }
       __syncthreads();   // X is final for this layer; sp may be restaged
+      C16_MARK(26);
     }
     }
     C16_MARK(2);
@@ -712,6 +731,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void k_chain16(float* _
     stage_sp(w.sp);
     if (s < 0) frag_prefetch<4, Ring, NWV>(R, w.Fqsg, 24, wave, lane);   // (later layers: requested at the end of the previous POST)
     __syncthreads();
+    C16_MARK(32);
     if (epi) {
       float xn[8];
 #pragma unroll
@@ -720,9 +740,11 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void k_chain16(float* _
       planes_store8(P0h + er * ND_AS + ec, P0l + er * ND_AS + ec, xn);
     }
     __syncthreads();
+    C16_MARK(33);
     gemm16<4, Ring, NWV>(R, P0h, P0l, ND_AS, w.Fqsg, 24, Cw, ND_CW, wave, lane);
     frag_prefetch<1, Ring, NWV>(R, w.Fkr3, 8 * 6, wave, lane);
     __syncthreads();
+    C16_MARK(34);
     if (epi) {
       float q[8], sv[8], gv[8];
 #pragma unroll
@@ -741,6 +763,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void k_chain16(float* _
       }
     }
     __syncthreads();
+    C16_MARK(35);
     // q~[row][h][c] = sum_d q[row][16h + d] * Wkr_g3[16h + d][c]: (head, 16-column tile) pairs over the waves
     {
       constexpr int NTQ = 6;
@@ -761,7 +784,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void k_chain16(float* _
             acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc, 0, 0, 0);
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-              if (4 * kq + r < nrows) io.qt[(size_t)(row0 + 4 * kq + r) * 1024 + h * 128 + nt * 16 + mi] = acc[r];
+              if (4 * kq + r < nrows) io.qt[(size_t)(row0 + 4 * kq + r) * C16_QS + h * 128 + nt * 16 + mi] = acc[r];
           }
         }
       }
@@ -774,6 +797,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void k_chain16(float* _
       if (tid == 0) *ctr = 0;
     }
     __syncthreads();   // q~ rows (global scratch of this workgroup), cq, counter: visible to every wave
+    C16_MARK(36);
     }
   }
 }

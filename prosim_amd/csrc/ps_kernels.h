@@ -913,46 +913,66 @@ __device__ __forceinline__ void head_ln16(const float* __restrict__ C, const flo
   for (int i = 0; i < N / 4; ++i) a[i] = fmaxf(fmaf(a[i] * rstd, lw[c0 + i], lb[c0 + i]), 0.f);
 }
 
-// On the matrix cores: 16 agents per 256-thread workgroup, every Linear a 16-row split-fp16
-// GEMM (pn_gemm<1>) against pre-split weight fragments; the LayerNorms take a lane quad per row (64 threads).
+// On the matrix cores: G = 16 / K agents per 256-thread workgroup (K = motion modes; one row per (agent, mode)), every Linear
+// a 16-row split-fp16 GEMM (pn_gemm<1>) against pre-split weight fragments; the LayerNorms take a lane quad per row
+// (64 threads).  CG_stacked's context of an agent is the maximum over its K mode rows (mlp.py:207-241, all-true mask).
+// step_agent_traj appends the mode choice[agent] of this replan (traj_sam.py:300-313: an index among the top-k modes,
+// drawn on the host -- motion_prob is all ones, so the draw does not depend on the model's output); nullptr = mode 0.
 __global__ __launch_bounds__(256) void k_policy_head_mfma(HeadW w, const float* __restrict__ fused, const int* __restrict__ agent_type,
                                                          int n_agents, int motion_k, int steps, int sdim,
                                                          float* __restrict__ motion_pred, float* __restrict__ traj,
-                                                         float* __restrict__ vel, int stride_steps, int last, int replan, float eps) {
+                                                         float* __restrict__ vel, int stride_steps, int last, int replan, float eps,
+                                                         const int* __restrict__ choice) {
   __shared__ __attribute__((aligned(16))) _Float16 Ah[16 * PN_AS], Al[16 * PN_AS];
-  __shared__ __attribute__((aligned(16))) float C[16 * PN_CS], ctx[16 * PN_CS], inp[16 * PN_CS];
+  __shared__ __attribute__((aligned(16))) float C[16 * PN_CS], ctx[16 * PN_CS], inp[16 * PN_CS], Y[16 * PN_CS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int ag0 = blockIdx.x * 16;
+  const int K = motion_k, G = 16 / K;          // agents per workgroup; rows g * K + k, rows >= G * K idle
+  const int ag0 = blockIdx.x * G;
   PnFrags fr;   // the next GEMM's weight fragments always leave before the barrier / epilogue in front of it
   pn_load(fr, w.cgF[0], 4, wave, lane);
   for (int i = tid; i < 16 * 128; i += 256) {
-    const int g = i >> 7, c = i & 127;
-    const int ag = ag0 + g < n_agents ? ag0 + g : n_agents - 1;
-    ctx[g * PN_CS + c] = fused[(size_t)ag * 128 + c];
-    const float av = w.anchors[(size_t)((agent_type[ag] - 1) * motion_k) * 128 + c];   // K = 1: anchor row of the type
-    Ah[g * PN_AS + c] = f16_hi(av);
-    Al[g * PN_AS + c] = f16_lo(av);
+    const int row = i >> 7, c = i & 127;
+    const int g = row / K, k = row - g * K;
+    const int ag = (g < G && ag0 + g < n_agents) ? ag0 + g : n_agents - 1;
+    ctx[row * PN_CS + c] = fused[(size_t)ag * 128 + c];      // (every mode row carries its agent's context)
+    const float av = w.anchors[(size_t)((agent_type[ag] - 1) * K + (g < G ? k : 0)) * 128 + c];   // anchor of (type, mode)
+    Ah[row * PN_AS + c] = f16_hi(av);
+    Al[row * PN_AS + c] = f16_lo(av);
   }
   __syncthreads();
-  // CG_stacked(3) with K = 1: max over the mode dim is the identity
+  // CG_stacked(3): block i: y = relu(LN(W inp + b)) * context; context' = max over the agent's modes of y
   for (int i = 0; i < 3; ++i) {
     pn_mma<1>(fr, Ah, Al, 4, C, PN_CS, 16, wave, lane);
     pn_load(fr, i < 2 ? w.cgF[i + 1] : w.m0F, 4, wave, lane);
     __syncthreads();
+    float a[32];
+    const int r = tid >> 2, c0 = (tid & 3) * 32;
     if (tid < 64) {
-      float a[32];
-      const int r = tid >> 2, c0 = (tid & 3) * 32;
       head_ln16<128>(C, w.cgb[i], w.cglnw[i], w.cglnb[i], eps, a);
 #pragma unroll
       for (int j = 0; j < 32; ++j) {
-        const float y = a[j] * ctx[r * PN_CS + c0 + j];
+        a[j] *= ctx[r * PN_CS + c0 + j];
+        Y[r * PN_CS + c0 + j] = a[j];
+      }
+    }
+    __syncthreads();
+    if (tid < 64) {
+      const int g = r / K;
+#pragma unroll
+      for (int j = 0; j < 32; ++j) {
+        const float y = a[j];
+        float ymax = y;
+        if (K > 1 && g < G) {
+          ymax = Y[(g * K) * PN_CS + c0 + j];
+          for (int k = 1; k < K; ++k) ymax = fmaxf(ymax, Y[(g * K + k) * PN_CS + c0 + j]);
+        }
         float ni, nc;
         if (i == 0) {
           ni = y;
-          nc = y;
+          nc = ymax;
         } else {
           ni = (inp[r * PN_CS + c0 + j] * (float)i + y) / (float)(i + 1);
-          nc = (ctx[r * PN_CS + c0 + j] * (float)i + y) / (float)(i + 1);
+          nc = (ctx[r * PN_CS + c0 + j] * (float)i + ymax) / (float)(i + 1);
         }
         inp[r * PN_CS + c0 + j] = ni;
         ctx[r * PN_CS + c0 + j] = nc;
@@ -993,12 +1013,13 @@ __global__ __launch_bounds__(256) void k_policy_head_mfma(HeadW w, const float* 
   __syncthreads();
   pn_mma<1>(fr, Ah, Al, 2, C, PN_CS, 16, wave, lane, 4);
   __syncthreads();
-  // cumsum over steps of (dx, dy, dtheta); wrap theta (act_decoder.py:117-121).  One thread per (agent, step):
+  // cumsum over steps of (dx, dy, dtheta); wrap theta (act_decoder.py:117-121).  One thread per (row, step):
   // it re-adds the prefix in step order, so the sums round exactly like the sequential scan.
-  for (int i = tid; i < 16 * steps; i += 256) {
-    const int g = i / steps, s = i - g * steps, ag = ag0 + g;
+  for (int i = tid; i < G * K * steps; i += 256) {
+    const int row = i / steps, s = i - row * steps;
+    const int g = row / K, k = row - g * K, ag = ag0 + g;
     if (ag >= n_agents) continue;
-    const float* o = C + g * PN_CS;
+    const float* o = C + row * PN_CS;
     float cx = 0.f, cy = 0.f, ch = 0.f;
     for (int j = 0; j <= s; ++j) {
       cx += o[j * sdim] + w.m2b[j * sdim];
@@ -1006,12 +1027,13 @@ __global__ __launch_bounds__(256) void k_policy_head_mfma(HeadW w, const float* 
       ch += o[j * sdim + 2] + w.m2b[j * sdim + 2];
     }
     const float hh = wrap_angle(ch);
-    float* mp = motion_pred + (size_t)ag * motion_k * steps * sdim + s * sdim;
+    float* mp = motion_pred + ((size_t)ag * K + k) * steps * sdim + s * sdim;
     mp[0] = cx;
     mp[1] = cy;
     mp[2] = hh;
     for (int f = 3; f < sdim; ++f) mp[f] = o[s * sdim + f] + w.m2b[s * sdim + f];
-    if (s < replan) {
+    const int pick = choice ? choice[ag] : 0;
+    if (s < replan && k == pick) {
       // step_agent_traj (traj_sam.py:322-347): rotate into the agent-init frame, append
       const float* cur = traj + ((size_t)ag * stride_steps + last - 1) * 4;
       const float c0 = cur[0], c1 = cur[1];

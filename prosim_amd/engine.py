@@ -22,7 +22,7 @@ class PsConfig(C.Structure):
     _fields_ = [
         ("hidden", C.c_int32), ("heads", C.c_int32), ("head_dim", C.c_int32),
         ("scene_layers", C.c_int32), ("scene_knn", C.c_int32), ("agent_knn", C.c_int32),
-        ("dec_layers", C.c_int32), ("dec_max_neigh", C.c_int32),
+        ("dec_layers", C.c_int32), ("dec_max_neigh", C.c_int32), ("goal_pred_k", C.c_int32),
         ("dec_prompt_radius", C.c_float), ("dec_scene_radius", C.c_float),
         ("pol_layers", C.c_int32), ("pol_max_neigh", C.c_int32),
         ("pol_agent_radius", C.c_float), ("pol_map_radius", C.c_float),
@@ -68,12 +68,15 @@ def load_library():
     lib.ps_set_drag_points.argtypes = [vp, C.c_int32, C.c_int32, fp, u8p, i32p]
     lib.ps_set_future_obs.argtypes = [vp, fp]
     lib.ps_set_future_log.argtypes = [vp, fp, u8p, fp, fp]
+    lib.ps_set_mode_choice.argtypes = [vp, i32p]
     lib.ps_num_policy_agents.argtypes = [vp]
     lib.ps_num_policy_agents.restype = C.c_int32
     lib.ps_update_obs.argtypes = [vp, fp, u8p, fp, fp]
     lib.ps_declare_agent_rows.argtypes = [vp, C.c_int32, C.c_int32, u8p]
     lib.ps_set_chain_rows.argtypes = [vp, C.c_int32]
     lib.ps_set_chain_impl.argtypes = [vp, C.c_int32]
+    lib.ps_enable_policy_events.argtypes = [vp, C.c_int32]
+    lib.ps_policy_event_times.argtypes = [vp, fp, C.c_int32]
     lib.ps_stream.argtypes = [vp]
     lib.ps_stream.restype = C.c_void_p
     lib.ps_policy_flags.argtypes = [vp, i32p, C.c_int64]
@@ -100,8 +103,8 @@ def load_library():
     return lib
 
 
-EXPORTS = ["ps_create", "ps_destroy", "ps_last_error", "ps_set_scene", "ps_set_prompt", "ps_policy_forward", "ps_set_conditions", "ps_set_drag_points", "ps_set_future_obs", "ps_set_future_log", "ps_num_policy_agents", "ps_policy_flags",
-           "ps_encode_scene", "ps_generate_policy", "ps_reset_rollout", "ps_policy_step", "ps_rollout", "ps_sync", "ps_stream", "ps_set_chain_rows", "ps_set_chain_impl", "ps_update_obs", "ps_declare_agent_rows",
+EXPORTS = ["ps_create", "ps_destroy", "ps_last_error", "ps_set_scene", "ps_set_prompt", "ps_policy_forward", "ps_set_conditions", "ps_set_drag_points", "ps_set_future_obs", "ps_set_future_log", "ps_set_mode_choice", "ps_num_policy_agents", "ps_policy_flags",
+           "ps_encode_scene", "ps_generate_policy", "ps_reset_rollout", "ps_policy_step", "ps_rollout", "ps_sync", "ps_stream", "ps_set_chain_rows", "ps_set_chain_impl", "ps_enable_policy_events", "ps_policy_event_times", "ps_update_obs", "ps_declare_agent_rows",
            "ps_set_state", "ps_get", "ps_rollout_metric", "ps_pair_metric", "ps_num_agents", "ps_num_map_tokens", "ps_time_rollout", "ps_time_policy_kernel",
            "ps_test_pointnet", "ps_test_fourier", "ps_test_wrap", "ps_test_attn", "ps_test_get_edges", "ps_test_stream"]
 
@@ -138,7 +141,7 @@ class Engine:
             raise ValueError(f"MODEL.OBS_UPDATE.FUSION must be 'replace' or 'mlp', got {spec.obs_fusion!r}")
         cfg = PsConfig(hidden=spec.hidden, heads=spec.heads, head_dim=spec.head_dim, scene_layers=spec.scene_layers,
                        scene_knn=spec.scene_knn, agent_knn=spec.agent_knn, dec_layers=spec.dec_layers,
-                       dec_max_neigh=spec.dec_max_neigh, dec_prompt_radius=spec.dec_prompt_radius,
+                       dec_max_neigh=spec.dec_max_neigh, goal_pred_k=spec.goal_pred_k, dec_prompt_radius=spec.dec_prompt_radius,
                        dec_scene_radius=spec.dec_scene_radius, pol_layers=spec.pol_layers, pol_max_neigh=spec.pol_max_neigh,
                        pol_agent_radius=spec.pol_agent_radius, pol_map_radius=spec.pol_map_radius, cond_layers=spec.cond_layers,
                        drag_pre_layers=spec.drag_pre_layers, drag_mlp_layers=spec.drag_mlp_layers,
@@ -213,6 +216,8 @@ class Engine:
         self.policy_rows = pm.reshape(-1).astype(bool)[self._slots]
         self.live0_rows = seen0.reshape(-1)[self._slots]
         self.set_conditions(s.get("cond"))
+        if s.get("mode_choice") is not None:
+            self.set_mode_choice(s["mode_choice"])
         if s.get("fut_obs_input") is not None:
             fo = np.ascontiguousarray(s["fut_obs_input"], dtype=np.float32)
             if s.get("fut_obs_mask") is not None and s.get("fut_obs_pos") is not None and s.get("fut_obs_head") is not None:
@@ -222,6 +227,16 @@ class Engine:
                 self._check(self.lib.ps_set_future_log(self.h, _f(fo), _u8(fm), _f(fp_), _f(fh)))
             else:
                 self._check(self.lib.ps_set_future_obs(self.h, _f(fo)))
+
+    def set_mode_choice(self, choice):
+        """``choice`` [R, B, N] int: the motion mode each policy agent follows at each replan (TOP_K > 1), or None."""
+        if choice is None:
+            self._check(self.lib.ps_set_mode_choice(self.h, None))
+            return
+        c = np.ascontiguousarray(choice, dtype=np.int32)
+        if c.shape != (self.spec.n_replans,) + tuple(self._shape):
+            raise ValueError(f"mode choice must be [R, B, N] = {(self.spec.n_replans,) + tuple(self._shape)}, got {c.shape}")
+        self._check(self.lib.ps_set_mode_choice(self.h, _i32(c)))
 
     def set_conditions(self, cond):
         """``cond`` = {'goal' | 'v_action_tag' | 'drag_point': {'input', 'mask', 'prompt_idx' [B,C,1] = prompt SLOT}} or
@@ -303,11 +318,11 @@ class Engine:
         self._check(self.lib.ps_sync(self.h))
 
     def set_chain_rows(self, rows: int):
-        """0: latency-optimal (one rollout on the GPU); 16: throughput mode for several engines sharing the GPU."""
+        """0: latency mode (one rollout on the GPU); 8..16: throughput mode for several engines sharing the GPU (12 in bench.py)."""
         self._check(self.lib.ps_set_chain_rows(self.h, rows))
 
     def set_chain_impl(self, impl: int):
-        """0: k_chain16 (default); 1: k_attn_chain, the round-1 fused chain (A/B measurements, cross-checks)."""
+        """0: by mode (default); 1: k_attn_chain always; 2: k_chain16 always (A/B measurements, cross-checks)."""
         self._check(self.lib.ps_set_chain_impl(self.h, impl))
 
     @property
@@ -338,7 +353,8 @@ class Engine:
         R, S = sp.n_replans, sp.n_replans * sp.replan_freq
         shapes = {"traj": (A, S, 4), "vel": (A, S, 2), "motion_pred": (R, A, sp.motion_k, sp.target_steps, sp.state_dim),
                   "reconst_pred": (A, 2), "policy_emd": (A, sp.hidden), "scene_tokens": (Mv + A, sp.hidden),
-                  "fused": (A, sp.hidden), "obs_in": (A, sp.hist_steps, sp.obs_dim), "cur_pos": (A, 2), "edge_counts": (8,)}
+                  "fused": (A, sp.hidden), "obs_in": (A, sp.hist_steps, sp.obs_dim), "cur_pos": (A, 2), "edge_counts": (8,),
+                  "goal_prob": (A, max(sp.goal_pred_k, 1)), "goal_point": (A, max(sp.goal_pred_k, 1), 2)}
         out = np.empty(shapes[name], np.float32)
         n = self.lib.ps_get(self.h, name.encode(), _f(out), out.size)
         if n < 0:
@@ -348,7 +364,7 @@ class Engine:
     def padded(self, name: str) -> np.ndarray:
         """Per-agent result scattered back to the padded [B, N, ...] slot layout of the inputs."""
         a = self.get(name)
-        if name in ("traj", "vel", "policy_emd", "reconst_pred", "fused"):
+        if name in ("traj", "vel", "policy_emd", "reconst_pred", "fused", "goal_prob", "goal_point"):
             a = np.where(self.policy_rows.reshape((-1,) + (1,) * (a.ndim - 1)), a, 0.0).astype(np.float32)   # log-replay rows
         B, N = self._shape
         out = np.zeros((B * N,) + a.shape[1:], np.float32)
@@ -369,6 +385,18 @@ class Engine:
     def row_slots(self) -> np.ndarray:
         """Flat slot index b * N + n of every agent row (the order of all per-agent results)."""
         return self._slots.copy()
+
+    def enable_policy_events(self, on: bool = True):
+        """Record an event pair around every policy-chain launch of the following rollouts (see policy_event_times)."""
+        self._check(self.lib.ps_enable_policy_events(self.h, int(bool(on))))
+
+    def policy_event_times(self) -> np.ndarray:
+        """Durations (ms) of the policy-chain launches of this engine's last rollout, as they ran (pipelined or alone)."""
+        out = np.zeros(self.spec.n_replans, np.float32)
+        n = self.lib.ps_policy_event_times(self.h, _f(out), out.size)
+        if n < 0:
+            self._check(int(n))
+        return out[:n]
 
     def time_rollout(self, warmup: int, iters: int):
         ms = C.c_float()

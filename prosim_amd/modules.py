@@ -314,7 +314,23 @@ class HipDecoder:
         emd = np.zeros((B, Np, emd_slots.shape[-1]), np.float32)   # the reference returns prompt order (sym_coord.py:60-75)
         for b in range(B):
             emd[b, :len(slots[b])] = emd_slots[b, slots[b]]
-        return dict(emd=torch.from_numpy(emd), agent_type=torch.from_numpy(_np(_g(prompt_enc, "agent_type"), np.int64)))
+        out = dict(emd=torch.from_numpy(emd), agent_type=torch.from_numpy(_np(_g(prompt_enc, "agent_type"), np.int64)))
+        out.update(_goal_outputs(eng, self.s.spec, slots, B, Np))
+        return out
+
+
+def _goal_outputs(eng, spec, slots, B, Np) -> Dict[str, Any]:
+    """``Decoder._goal_pred`` (decoder/base.py:22-58) when MODEL.DECODER.GOAL_PRED is enabled: goal_prob [B, N, K] and
+    goal_point [B, N, K, 2] in prompt order, zeros past the prompts."""
+    K = spec.goal_pred_k
+    if K <= 0:
+        return {}
+    gp, gq = eng.padded("goal_prob"), eng.padded("goal_point")
+    prob, point = np.zeros((B, Np, K), np.float32), np.zeros((B, Np, K, 2), np.float32)
+    for b in range(B):
+        prob[b, :len(slots[b])] = gp[b, slots[b]]
+        point[b, :len(slots[b])] = gq[b, slots[b]]
+    return dict(goal_prob=torch.from_numpy(prob), goal_point=torch.from_numpy(point))
 
 
 @registry.register_policy(name="rel_pe_temporal")
@@ -367,6 +383,10 @@ class ProSimHip:
     def engine(self) -> Engine:
         return self._shared.engine
 
+    def close(self):
+        """Release the engine (device buffers, stream, graph)."""
+        self._shared.engine.close()
+
     def eval(self):
         return self   # inference only: dropout never runs on this path
 
@@ -382,6 +402,8 @@ class ProSimHip:
         scene = scene_from_extras(extras, self.spec)
         self._shared.scene = scene
         self.engine.set_scene(scene)
+        self._last_mode_choice = self._draw_mode_choice()
+        self.engine.set_mode_choice(self._last_mode_choice)
         self.engine.rollout()
         return self._process_rollout(extras, scene)
 
@@ -434,6 +456,7 @@ class ProSimHip:
                 emd[b, :len(slots[b])] = emd_slots[b, slots[b]]
             out[task] = dict(emd=torch.from_numpy(emd), agent_type=torch.from_numpy(_np(_g(pe, "agent_type"), np.int64)),
                              _hip_resident=True)
+            out[task].update(_goal_outputs(self.engine, self.spec, slots, B, Np))
         return out
 
     def init_agent_trajs(self, policy_agent_ids, batch) -> Dict[str, Any]:
@@ -451,10 +474,36 @@ class ProSimHip:
             raise ValueError(f"all_t_indices must be {want} (ROLLOUT.POLICY.REPLAN_FREQ / MAX_STEPS of the spec)")
         if not all(v.get("_hip_resident") for v in (scene_embs, *policy_emds.values(), *agent_trajs.values())):
             raise ValueError("rollout_batch needs the device-resident results of encode_scene / generate_policy / init_agent_trajs")
+        self._last_mode_choice = self._draw_mode_choice()
+        self.engine.set_mode_choice(self._last_mode_choice)
         for i in range(len(want)):
             self.engine.policy_step(i)
         extras = batch.extras if hasattr(batch, "extras") else batch
         return self._process_rollout(extras, self._shared.scene)
+
+    def _draw_mode_choice(self):
+        """``ProSim.step_agent_traj`` (:300-313) with ROLLOUT.POLICY.TOP_K > 1: per replan torch.topk over the (all-ones)
+        motion_prob of the P pairs and a torch.randint among the top k -- the reference's own two calls, in its order, so
+        a seeded torch generator yields the reference's draws.  motion_prob does not depend on the model, so the whole
+        table is drawn before the rollout and handed to the engine (ps_set_mode_choice).  None for TOP_K = 1."""
+        spec, scene = self.spec, self._shared.scene
+        k = min(spec.rollout_top_k, spec.motion_k)
+        if k <= 1:
+            return None
+        B, N = scene["prompt_mask"].shape
+        pslots = scene["_policy_slots"]
+        P = sum(len(p) for p in pslots)
+        choice = np.zeros((spec.n_replans, B, N), np.int32)
+        for t in range(spec.n_replans):
+            _, top = torch.topk(torch.ones(P, spec.motion_k), k, dim=1)
+            rnd = torch.randint(0, k, (P,))
+            pick = top[torch.arange(P), rnd].numpy()
+            i = 0
+            for b in range(B):
+                for n in pslots[b]:
+                    choice[t, b, n] = pick[i]
+                    i += 1
+        return choice
 
     def decode_batch(self, scene_embs, prompt_encs, batch, mode="val"):
         """``ProSim.decode_batch`` (:105-116)."""

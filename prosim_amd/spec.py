@@ -49,6 +49,9 @@ class ModelSpec:
     dec_prompt_radius: float = 300.0
     dec_scene_radius: float = 300.0
     dec_max_neigh: int = 512
+    # MODEL.DECODER.GOAL_PRED (default.py:610-614; ENABLE False in the demo): K goal hypotheses per prompt from the
+    # decoder's embedding -- goal_prob [B, N, K], goal_point [B, N, K, 2] (decoder/base.py:22-58); 0 = disabled
+    goal_pred_k: int = 0
     # MODEL.POLICY.ACT_DECODER.ATTN (no_text.yaml:270-279)
     pol_layers: int = 6
     pol_agent_radius: float = 100.0
@@ -73,6 +76,7 @@ class ModelSpec:
     target_steps: int = 10
     state_dim: int = 5
     motion_k: int = 1                  # MODEL.POLICY.ACT_DECODER.TRAJ.K
+    rollout_top_k: int = 1             # ROLLOUT.POLICY.TOP_K (default.py:136): modes a rollout step draws from (host-side draw)
     num_agent_types: int = 3           # DATASET.USE_PED_CYCLIST -> anchors K*3 (act_decoder.py:66-68)
     prompt_dim: int = 7                # v_local(2)+extent(2)+type one-hot(3) (prompt_utils.py:111-150)
     # ROLLOUT.POLICY (no_text.yaml:44-48)

@@ -206,3 +206,27 @@ def baseline_scene(spec: ModelSpec, idx: int, seed: int = 0, batch: Optional[int
     if batch is not None:
         kw["batch"] = batch
     return make_scene(spec, seed=seed, **kw)
+
+
+def make_pair_metric_inputs(seed: int, B: int = 2, N: int = 6, R: int = 8, K: int = 3, S: int = 10, D: int = 5):
+    """Seeded inputs of the rollout metric: per-(scene, replan, agent) local targets with the gaps a real log has
+    (agents that leave: trailing NaN steps; agents without any future at a replan: mask False or all-NaN; one
+    coordinate missing), K-mode predictions and mode probabilities."""
+    rng = np.random.RandomState(4321 + seed)
+    tgt = np.cumsum(rng.uniform(-0.5, 1.5, (B, R, N, S, D)), axis=3).astype(np.float32)
+    tgt[..., 2] = rng.uniform(-0.3, 0.3, (B, R, N, S))                # per-step heading offsets stay small
+    mask = np.ones((B, R, N), bool)
+    for b in range(B):
+        tgt[b, 3:, 1] = np.nan                                         # agent 1 leaves after replan 2 ...
+        mask[b, 3:, 1] = False
+        tgt[b, 2, 1, 4:] = np.nan                                      # ... and its last logged replan is cut short
+        tgt[b, 5, 2] = np.nan                                          # a NaN target whose mask says valid
+        mask[b, 6, 3] = False                                          # a masked pair whose target is finite
+        tgt[b, 1, 4, 7:, 0] = np.nan                                   # only x missing on the last steps
+    n_agents = [N, N - 2][:B] + [N] * max(0, B - 2)
+    pairs = [(b, t, n) for b in range(B) for t in range(R) for n in range(n_agents[b]) if mask[b, t, n]]
+    bidx, tidx, nidx = (np.array(v, np.int64) for v in zip(*pairs))
+    pair_tgt = tgt[bidx, tidx, nidx]
+    pred = (np.nan_to_num(pair_tgt)[:, None] + rng.normal(0, 0.4, (len(pairs), K, S, D))).astype(np.float32)
+    prob = rng.uniform(0, 1, (len(pairs), K)).astype(np.float32)
+    return dict(tgt=tgt, mask=mask, motion_pred=pred, motion_prob=prob, bidx=bidx, tidx=tidx, nidx=nidx)

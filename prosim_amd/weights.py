@@ -116,6 +116,9 @@ def param_shapes(spec: ModelSpec) -> "OrderedDict[str, Tuple[int, ...]]":
     for i in range(spec.dec_layers):
         _attn_shapes(out, f"decoder.p2p_attn_layers.{i}", d, hd, False)
         _attn_shapes(out, f"decoder.s2p_attn_layers.{i}", d, hd, True)
+    if spec.goal_pred_k > 0:        # decoder/base.py:18-20
+        _mlp_shapes(out, "decoder.goal_prob_head", [d, d // 2, spec.goal_pred_k], True, False)
+        _mlp_shapes(out, "decoder.goal_point_head", [d, d // 2, spec.goal_pred_k * 2], True, False)
     pa = "policy.act_decoder"
     for i in range(spec.pol_layers):
         _attn_shapes(out, f"{pa}.a2p_attn_layers.{i}", d, hd, True)

@@ -63,16 +63,23 @@ FULL_CASES = {
     # log-replay agents that ENTER the scene after the initial step (no history at t0, listed from a later frame on)
     "small_enter_b2": ("small", dict(n_agents=16, n_polylines=128, batch=2, seed=11, goal=True, ragged=True, replay=0.6, enter=0.6), 0),
     "small_attn_update_b2": ("small_mlp_attn", dict(n_agents=16, n_polylines=128, batch=2, seed=8, ragged=True, replay=0.3), 0),
+    # TRAJ.K = 3 motion modes, ROLLOUT.POLICY.TOP_K = 3: every replan follows a randomly drawn mode (traj_sam.py:300-313);
+    # the fixture keeps the reference's draws (mode_choice) and the torch seed they came from
+    "small_topk3_b2": ("small_k3", dict(n_agents=16, n_polylines=128, batch=2, seed=12, goal=True, ragged=True, replay=0.3), 0),
 }
 SPECS = {"small": SMALL_SPEC, "demo": DEMO_SPEC, "small_mlp": SMALL_SPEC.replace(obs_fusion="mlp"),
-         "small_mlp_attn": SMALL_SPEC.replace(obs_fusion="mlp", obs_attn_update=True)}
+         "small_mlp_attn": SMALL_SPEC.replace(obs_fusion="mlp", obs_attn_update=True),
+         "small_k3": SMALL_SPEC.replace(motion_k=3, rollout_top_k=3)}
+TOPK_SEED = 777   # torch.manual_seed before a forward whose rollout draws modes
 
 
 def ref_overrides(spec: ModelSpec):
     return ["MODEL.SCENE_ENCODER.ATTN.NUM_LAYER", spec.scene_layers, "MODEL.DECODER.ATTN.NUM_LAYER", spec.dec_layers,
             "MODEL.POLICY.ACT_DECODER.ATTN.NUM_LAYER", spec.pol_layers, "MODEL.CONDITION_TRANSFORMER.NLAYER", spec.cond_layers,
             "MODEL.OBS_UPDATE.FUSION", spec.obs_fusion, "MODEL.OBS_UPDATE.ATTN_UPDATE", spec.obs_attn_update,
-            "MODEL.SCENE_ENCODER.ATTN.AGENT_RADIUS", spec.enc_agent_radius, "MODEL.SCENE_ENCODER.ATTN.SCENE_RADIUS", spec.enc_scene_radius]
+            "MODEL.SCENE_ENCODER.ATTN.AGENT_RADIUS", spec.enc_agent_radius, "MODEL.SCENE_ENCODER.ATTN.SCENE_RADIUS", spec.enc_scene_radius,
+            "MODEL.POLICY.ACT_DECODER.TRAJ.K", spec.motion_k, "ROLLOUT.POLICY.TOP_K", spec.rollout_top_k,
+            "MODEL.DECODER.GOAL_PRED.ENABLE", spec.goal_pred_k > 0, "MODEL.DECODER.GOAL_PRED.K", max(spec.goal_pred_k, 1)]
 
 
 def run_reference(spec, w, scene):
@@ -82,8 +89,29 @@ def run_reference(spec, w, scene):
     assert not unexpected, unexpected
     assert not missing, missing
     batch = rh.make_batch(scene, spec)
-    with torch.no_grad():
-        out = model(batch, "val")["motion_pred"]
+    # record the reference's own mode draws (step_agent_traj: torch.topk over the all-ones motion_prob, then torch.randint)
+    draws = []
+    real_topk, real_randint = torch.topk, torch.randint
+
+    def topk_rec(inp, k, *a, **kw):
+        r = real_topk(inp, k, *a, **kw)
+        if inp.dim() == 2 and inp.shape[1] == spec.motion_k and bool((inp == 1).all()):
+            draws.append([r[1].clone(), None])
+        return r
+
+    def randint_rec(*a, **kw):
+        r = real_randint(*a, **kw)
+        if draws and draws[-1][1] is None and r.dim() == 1 and r.shape[0] == draws[-1][0].shape[0]:
+            draws[-1][1] = r.clone()
+        return r
+
+    torch.manual_seed(TOPK_SEED)
+    torch.topk, torch.randint = topk_rec, randint_rec
+    try:
+        with torch.no_grad():
+            out = model(batch, "val")["motion_pred"]
+    finally:
+        torch.topk, torch.randint = real_topk, real_randint
     B, N = scene["prompt_mask"].shape
     R = spec.n_replans * spec.replan_freq
     traj = np.zeros((B, N, R, 4), np.float32)
@@ -93,7 +121,15 @@ def run_reference(spec, w, scene):
             r = out["rollout_trajs"][f"{b}-a{n}"]
             traj[b, n] = r["traj"].numpy()
             vel[b, n] = r["vel"].numpy()
-    return dict(traj=traj, vel=vel, motion_pred=out["motion_pred"].numpy(), reconst_pred=out["reconst_pred"].numpy())
+    res = dict(traj=traj, vel=vel, motion_pred=out["motion_pred"].numpy(), reconst_pred=out["reconst_pred"].numpy())
+    if spec.motion_k > 1:
+        assert len(draws) == spec.n_replans and all(d[1] is not None for d in draws)
+        pm = scene["prompt_mask"].astype(bool)
+        choice = np.zeros((spec.n_replans, B, N), np.int32)
+        for t, (top, rnd) in enumerate(draws):
+            choice[t][pm] = top[torch.arange(top.shape[0]), rnd].numpy()     # pairs come in (scene, policy agent) order
+        res["mode_choice"] = choice
+    return res
 
 
 def gen_full():
@@ -102,6 +138,8 @@ def gen_full():
         w = weights.init_weights(spec, wseed)
         scene = synth.make_scene(spec, **kw)
         ref = run_reference(spec, w, scene)
+        if "mode_choice" in ref:
+            scene = dict(scene, mode_choice=ref["mode_choice"])
         with torch.no_grad():
             o = orc.rollout(w, spec, scene)
             o64 = orc.rollout(w, spec, scene, dtype=torch.float64)
@@ -123,8 +161,47 @@ def gen_full():
                             traj=ref["traj"], vel=ref["vel"], motion_pred=ref["motion_pred"],
                             reconst_pred=ref["reconst_pred"][:A],
                             fp32_floor=np.array([floor["traj"], floor["vel"], floor["motion_pred"]]),
-                            scene_digest=np.array(digest(scene)), weight_digest=np.array(digest(w)),
+                            scene_digest=np.array(digest({k: v for k, v in scene.items() if k != "mode_choice"})), weight_digest=np.array(digest(w)),
+                            **({"mode_choice": ref["mode_choice"], "torch_seed": np.array(TOPK_SEED)} if "mode_choice" in ref else {}),
                             label=np.array("reference Python + builder stand-ins for torch_cluster/torch_geometric"))
+
+
+GOAL_CASE = ("small_goal_heads_b2", SMALL_SPEC.replace(goal_pred_k=4),
+             dict(n_agents=16, n_polylines=128, batch=2, seed=14, goal=True, ragged=True), 0)
+
+
+def gen_goal_heads():
+    """tests/golden/ref_standins_small_goal_heads_b2.npz: the reference's decoder with MODEL.DECODER.GOAL_PRED enabled
+    (decoder/base.py:22-58 over sym_coord.py:112-140) -- goal_prob, goal_point and the decoder embedding they are read
+    from, in the [B, N] slot layout -- and the oracle checked against it."""
+    name, spec, kw, wseed = GOAL_CASE
+    w = weights.init_weights(spec, wseed)
+    scene = synth.make_scene(spec, **kw)
+    cfg = rh.get_config(overrides=ref_overrides(spec))
+    model = rh.build_model(cfg)
+    missing, unexpected = model.load_state_dict(weights.to_reference_state_dict(spec, w), strict=False)
+    assert not unexpected and not missing, (unexpected, missing)
+    batch = rh.make_batch(scene, spec)
+    with torch.no_grad():
+        scene_embs = model.encode_scene(batch)
+        penc = model.encode_prompt(batch)["motion_pred"]
+        dec = model.decoder(scene_embs, penc)
+        o = orc.rollout(w, spec, scene, collect=True)
+    pm = scene["prompt_mask"].astype(bool)
+    B, N = pm.shape
+    out = {}
+    for key, ok in (("goal_prob", o["goal_prob"]), ("goal_point", o["goal_point"]), ("emd", o["trace"]["policy_emd_dec"])):
+        ref = dec[key].numpy()
+        slot = np.zeros((B, N) + ref.shape[2:], np.float32)
+        for b in range(B):
+            idx = np.nonzero(pm[b])[0]
+            slot[b, idx] = ref[b, :len(idx)]
+        e = float(np.abs(slot[pm] - ok.numpy()[pm]).max())
+        print(name, key, "oracle-vs-reference", e)
+        assert e < 2e-5, (key, e)
+        out[key] = slot
+    np.savez_compressed(os.path.join(GOLD, f"ref_standins_{name}.npz"), scene_digest=np.array(digest(scene)),
+                        weight_digest=np.array(digest(w)), **out)
 
 
 def gen_pure():
@@ -219,28 +296,7 @@ def gen_demo_tracks(scene: str = "scene_0"):
     print("demo tracks written:", scene, len(out["scene_ts"]), "rows,", len(set(out["agent_id"].tolist())), "agents")
 
 
-def make_pair_metric_inputs(seed: int, B: int = 2, N: int = 6, R: int = 8, K: int = 3, S: int = 10, D: int = 5):
-    """Seeded inputs of the rollout metric: per-(scene, replan, agent) local targets with the gaps a real log has
-    (agents that leave: trailing NaN steps; agents without any future at a replan: mask False or all-NaN; one
-    coordinate missing), K-mode predictions and mode probabilities."""
-    rng = np.random.RandomState(4321 + seed)
-    tgt = np.cumsum(rng.uniform(-0.5, 1.5, (B, R, N, S, D)), axis=3).astype(np.float32)
-    tgt[..., 2] = rng.uniform(-0.3, 0.3, (B, R, N, S))                # per-step heading offsets stay small
-    mask = np.ones((B, R, N), bool)
-    for b in range(B):
-        tgt[b, 3:, 1] = np.nan                                         # agent 1 leaves after replan 2 ...
-        mask[b, 3:, 1] = False
-        tgt[b, 2, 1, 4:] = np.nan                                      # ... and its last logged replan is cut short
-        tgt[b, 5, 2] = np.nan                                          # a NaN target whose mask says valid
-        mask[b, 6, 3] = False                                          # a masked pair whose target is finite
-        tgt[b, 1, 4, 7:, 0] = np.nan                                   # only x missing on the last steps
-    n_agents = [N, N - 2][:B] + [N] * max(0, B - 2)
-    pairs = [(b, t, n) for b in range(B) for t in range(R) for n in range(n_agents[b]) if mask[b, t, n]]
-    bidx, tidx, nidx = (np.array(v, np.int64) for v in zip(*pairs))
-    pair_tgt = tgt[bidx, tidx, nidx]
-    pred = (np.nan_to_num(pair_tgt)[:, None] + rng.normal(0, 0.4, (len(pairs), K, S, D))).astype(np.float32)
-    prob = rng.uniform(0, 1, (len(pairs), K)).astype(np.float32)
-    return dict(tgt=tgt, mask=mask, motion_pred=pred, motion_prob=prob, bidx=bidx, tidx=tidx, nidx=nidx)
+make_pair_metric_inputs = synth.make_pair_metric_inputs
 
 
 def gen_pair_metric():
@@ -294,8 +350,11 @@ if __name__ == "__main__":
         gen_demo_tracks()
     elif len(sys.argv) > 1 and sys.argv[1] == "metric":
         gen_pair_metric()
+    elif len(sys.argv) > 1 and sys.argv[1] == "goal":
+        gen_goal_heads()
     else:
         gen_pure()
         gen_full()
         gen_demo_tracks()
         gen_pair_metric()
+        gen_goal_heads()

@@ -152,6 +152,8 @@ def test_rollout_vs_reference_fixture(name):
     w = weights.init_weights(spec, wseed)
     scene = synth.make_scene(spec, **kw)
     assert digest(scene) == str(g["scene_digest"]) and digest(w) == str(g["weight_digest"])
+    if "mode_choice" in g.files:      # TOP_K > 1: the reference's own mode draws (ps_set_mode_choice)
+        scene["mode_choice"] = g["mode_choice"]
     eng = Engine(spec, w)
     eng.set_scene(scene)
     eng.rollout()

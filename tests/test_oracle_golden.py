@@ -73,6 +73,8 @@ def test_rollout_ref_standins(name):
     w = weights.init_weights(spec, wseed)
     scene = synth.make_scene(spec, **kw)
     assert digest(scene) == str(g["scene_digest"]) and digest(w) == str(g["weight_digest"])
+    if "mode_choice" in g.files:      # TOP_K > 1: the reference's own mode draws, replayed
+        scene["mode_choice"] = g["mode_choice"]
     with torch.no_grad():
         o = orc.rollout(w, spec, scene)
     A = int(scene["prompt_mask"].sum())
@@ -99,3 +101,34 @@ def test_neighbour_semantics():
     b2 = torch.tensor([0, 0, 1, 1, 1])
     yi, xi = orc.knn_edges(pos, b2, pos, b2, 4)
     assert sorted(xi[yi == 0].tolist()) == [0, 1] and sorted(xi[yi == 3].tolist()) == [2, 3, 4]
+
+
+def test_pair_metric_oracle_vs_reference_fixture():
+    """oracle/metric_oracle.py against tests/golden/ref_pair_metric.npz, which the reference's own PairMotionPred
+    (metrics/motion_pred.py:111-199 over loss/loss_func.py:215-313) produced from the same seeded inputs: the five logged
+    scalars per batch, the accumulated values after two updates, and the chained trajectories bit for bit."""
+    import torch
+    from gen_golden import make_pair_metric_inputs, digest
+    from oracle import metric_oracle as mo
+    g = np.load(os.path.join(GOLD, "ref_pair_metric.npz"))
+    keys = ("ade", "fde", "min_ade", "min_fde", "rollout_ade")
+    sums = {k: [0.0, 0.0] for k in keys}
+    for i, seed in enumerate((0, 1)):
+        d = make_pair_metric_inputs(seed)
+        assert digest(d) == str(g[f"digest_{i}"])
+        o = mo.pair_motion_pred(torch.from_numpy(d["motion_pred"]), torch.from_numpy(d["motion_prob"]), torch.from_numpy(d["tgt"]),
+                                torch.from_numpy(d["mask"]), d["bidx"], d["tidx"], d["nidx"], 10)
+        for j, k in enumerate(keys):
+            assert abs(float(o[k]) - g[f"single_{i}"][j]) < 1e-6 * max(1.0, abs(g[f"single_{i}"][j])), (i, k)
+        assert np.array_equal(o["tgt_rollout"].numpy(), g[f"tgt_rollout_{i}"])
+        assert np.array_equal(o["pred_rollout"].numpy(), g[f"pred_rollout_{i}"])
+        # MeanMetric over updates: pair metrics pool their finite values, rollout_ade averages the per-update scalars
+        for k, vec in (("ade", o["pair_ade"]), ("fde", o["pair_fde"]), ("min_ade", o["pair_min_ade"]), ("min_fde", o["pair_min_fde"])):
+            ok = ~vec.isnan()
+            sums[k][0] += float(vec[ok].double().sum())
+            sums[k][1] += int(ok.sum())
+        sums["rollout_ade"][0] += float(o["rollout_ade"])
+        sums["rollout_ade"][1] += 1
+        for j, k in enumerate(keys):
+            want = g["after_updates"][i][j]
+            assert abs(sums[k][0] / sums[k][1] - want) < 1e-6 * max(1.0, abs(want)), (i, k, sums[k][0] / sums[k][1], want)

@@ -19,8 +19,8 @@ with torch.no_grad():
     o64 = orc.rollout(w, spec, scene, dtype=torch.float64)
 eng = Engine(spec, w)
 res = {}
-for impl in (1, 0):
-    for rows in ((0,) if impl else (0, 1, 2, 4, 8, 16)):
+for impl in (1, 2):
+    for rows in ((0,) if impl == 1 else (0, 1, 2, 4, 8, 12, 16)):
         eng.set_chain_impl(impl); eng.set_chain_rows(rows); eng.set_scene(scene); eng.rollout(); eng.sync()
         A = eng.num_agents
         mp = eng.get("motion_pred")
@@ -37,7 +37,7 @@ scene = {k: (np.concatenate([p[k] for p in parts]) if not isinstance(parts[0][k]
              {ck: {f: np.concatenate([p[k][ck][f] for p in parts]) for f in parts[0][k][ck]} for ck in parts[0][k]}) for k in parts[0]}
 eng = Engine(spec, w)
 ref = None
-for impl, rows in ((1, 0), (0, 0), (0, 2), (0, 4), (0, 8), (0, 16)):
+for impl, rows in ((1, 0), (2, 0), (2, 2), (2, 4), (2, 8), (2, 12), (2, 16)):
     eng.set_chain_impl(impl); eng.set_chain_rows(rows); eng.set_scene(scene); eng.rollout(); eng.sync()
     traj = eng.padded("traj"); mp0 = eng.get("motion_pred")[0]
     if ref is None:
