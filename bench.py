@@ -21,6 +21,11 @@ import os
 import sys
 import time
 
+# The HIP runtime multiplexes its streams onto 4 hardware queues by default; the pipelined steps use one stream per engine
+# plus torch's, and with 4 queues the engines' graph replays serialise behind one another (4 engines in flight: 9.5 M
+# agent-steps/s with 4 queues, 16.7 M with 8).  Must be set before the runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -104,8 +109,8 @@ def main():
     ap.add_argument("--config", type=int, default=2, help="BASELINE.json config index used as the per-scene workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--chain-rows", type=int, default=-1, choices=[-1, 0, 1, 2, 4, 8, 9, 10, 11, 12, 13, 14, 15, 16],
-                    help="rows per workgroup of the fused attention launches (ps_set_chain_rows); -1: 12 when rollouts are pipelined, else 0")
-    ap.add_argument("--inflight", type=int, default=3,
+                    help="rows per workgroup of the fused attention launches (ps_set_chain_rows); -1: 16 when rollouts are pipelined, else 0")
+    ap.add_argument("--inflight", type=int, default=4,
                     help="rollouts in flight per GPU: consecutive steps alternate between this many engines (own buffers and "
                          "stream each) that hold the same resident batch, so step k+1 starts while step k drains")
     args = ap.parse_args()
@@ -156,7 +161,7 @@ def main():
     # Every step is still a complete rollout of the whole batch inside the timed region.
     n_fl = max(1, args.inflight)
     engines = [Engine(spec, w, device=dev_index) for _ in range(n_fl)]
-    chain_rows = args.chain_rows if args.chain_rows >= 0 else (12 if n_fl > 1 else 0)
+    chain_rows = args.chain_rows if args.chain_rows >= 0 else (16 if n_fl > 1 else 0)
     for e_ in engines:
         e_.set_chain_rows(chain_rows)
         e_.set_scene(scene)

@@ -158,8 +158,9 @@ int ps_update_obs(ps_engine* e, const float* obs_input, const uint8_t* obs_mask,
  *           workgroups per 1024-row policy launch, two per CU);
  *   8..16   throughput mode, several engines share the GPU: the policy layers run on k_chain16 -- node Linears as 16-row
  *           MFMA GEMMs (a layer's weights cross a CU once per workgroup), rel-PE rows recomputed per 16-edge tile from 32 B of
- *           geometry per edge -- with that many rows per 8-wave workgroup; 12 rows x 3 rollouts in flight = 258 workgroups,
- *           one per CU, is what bench.py runs.  The other fused launches take 4 rows per workgroup then.
+ *           geometry per edge -- with that many rows per 8-wave workgroup; 16 rows x 4 rollouts in flight = 256 workgroups,
+ *           one per CU, is what bench.py runs (with GPU_MAX_HW_QUEUES=8: the runtime's default 4 hardware queues
+ *           serialise four engines' streams).  The other fused launches take 4 rows per workgroup then.
  *   1, 2, 4 rows per workgroup of either kernel (k_chain16 shares a row's edge list between 8 / rows waves; k_attn_chain
  *           takes 2 or 4) -- experiments.
  * Results do not depend on it beyond fp32 summation order. */

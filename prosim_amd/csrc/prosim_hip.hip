@@ -1506,7 +1506,12 @@ extern "C" int ps_encode_scene(ps_engine* e) {
     // a2a edges index agents globally (Mv + i) for positions; kv rows are agent-local -> fixed up below
     const PeArgs pe[2] = {{&e->e_a2a, e->d_tok_ori.p, e->d_tok_pos.p + 2 * (size_t)Mv, e->d_tok_ori.p + Mv},
                           {&e->e_s2s, e->d_tok_ori.p, e->d_tok_pos.p, e->d_tok_ori.p}};
-    launch_relpe(e, pe, 2);
+    if (use_c16(e)) {   // the a2a layers run on k_chain16 (geometry records), the s2s layers keep the operand images
+      launch_geo(e, &pe[0], 1);
+      launch_relpe(e, &pe[1], 1);
+    } else {
+      launch_relpe(e, pe, 2);
+    }
   }
   // 6 x (a2a on the agent rows in place, s2s on all rows)  (attn_fusion.py:117-119).  kv is indexed by
   // GLOBAL token row for both (the a2a projection fills rows Mv.. of the shared kv buffer).
@@ -1514,7 +1519,9 @@ extern "C" int ps_encode_scene(ps_engine* e) {
   const bool split_s2s = !no_split && Mv + A >= 2048 && e->e_s2s.maxdeg <= ES_MAXDEG;
   for (int i = 0; i < c.scene_layers; ++i) {
     launch_kv(e, tok + (size_t)Mv * D, A, e->L_a2a + i, 1, e->d_kv.p + (size_t)Mv * 256, e->d_kh.p + (size_t)Mv * 256, 0);
-    if (launch_chain(e, tok + (size_t)Mv * D, A, e->step_a2a + i, 1, e->e_a2a.maxdeg, false, nullptr, 0, 0, nullptr, xcd_on(1, false))) return PS_E_HIP;
+    if (use_c16(e)) {
+      if (launch_chain16(e, tok + (size_t)Mv * D, A, e->d_steps.p + e->step_a2a + i, 1, false, nullptr, false)) return PS_E_HIP;
+    } else if (launch_chain(e, tok + (size_t)Mv * D, A, e->step_a2a + i, 1, e->e_a2a.maxdeg, false, nullptr, 0, 0, nullptr, xcd_on(1, false))) return PS_E_HIP;
     if (split_s2s) {
       // split layer: node work as 16-row MFMA GEMMs (k_node; its PRE half also makes the rows'
       // k | v, they are this self-attention layer's sources), the 32-neighbour edge phase one wave per token
@@ -1551,20 +1558,23 @@ extern "C" int ps_generate_policy(ps_engine* e) {
   HIPCHK(hipMemcpyAsync(e->d_tok_pos.p + 2 * (size_t)Mv, ppos, sizeof(float) * 2 * A, hipMemcpyDeviceToDevice, st));
   HIPCHK(hipMemcpyAsync(e->d_tok_ori.p + Mv, pori, sizeof(float) * A, hipMemcpyDeviceToDevice, st));
   // (with log-replay agents in the scene only the policy agents are prompts: candidate filter)
+  const int pe_gen = use_c16(e) ? 2 : 1;   // k_chain16 rebuilds the rel-PE rows from geometry records, k_attn_chain streams operand images
   launch_radius(e, e->e_p2p, e->d_r_agent.p, nullptr, ppos, pscene, A, c.dec_prompt_radius, c.dec_max_neigh, Mv, e->d_tok_ori.p, pori,
-                e->all_policy ? nullptr : (const int*)e->d_is_policy.p, Mv);
+                e->all_policy ? nullptr : (const int*)e->d_is_policy.p, Mv, pe_gen);
   // restore observed agent poses for the scene tokens, then s2p: radius over all scene tokens (:94)
   HIPCHK(hipMemcpyAsync(e->d_tok_pos.p + 2 * (size_t)Mv, e->d_init_pos.p, sizeof(float) * 2 * A, hipMemcpyDeviceToDevice, st));
   HIPCHK(hipMemcpyAsync(e->d_tok_ori.p + Mv, e->d_init_head.p, sizeof(float) * A, hipMemcpyDeviceToDevice, st));
   launch_radius(e, e->e_s2p, e->d_r_map.p, e->d_r_agent.p, ppos, pscene, A, c.dec_scene_radius, c.dec_max_neigh, -1,
-                e->d_tok_ori.p, pori, e->have_dead0 ? (const int*)e->d_live0.p : nullptr, Mv);
+                e->d_tok_ori.p, pori, e->have_dead0 ? (const int*)e->d_live0.p : nullptr, Mv, pe_gen);
   // k|v of the (fixed) scene tokens for all s2p layers in one launch
   launch_kv(e, e->d_tok.p, Mv + A, e->L_s2p, c.dec_layers, e->d_kv_s2p.p, e->d_kh_s2p.p, (size_t)(Mv + A) * 256);
   const int md = std::max(e->e_p2p.maxdeg, e->e_s2p.maxdeg);
   for (int i = 0; i < c.dec_layers; ++i) {
     // p2p edges carry GLOBAL agent rows (Mv + j): project into rows Mv.. of the shared kv buffer
     launch_kv(e, e->d_xp.p, A, e->L_p2p + i, 1, e->d_kv.p + (size_t)Mv * 256, e->d_kh.p + (size_t)Mv * 256, 0);
-    if (launch_chain(e, e->d_xp.p, A, e->step_dec + 2 * i, 2, md, false, nullptr, 0, 0, nullptr, xcd_on(2, false))) return PS_E_HIP;
+    if (use_c16(e)) {
+      if (launch_chain16(e, e->d_xp.p, A, e->d_steps.p + e->step_dec + 2 * i, 2, false, nullptr, false)) return PS_E_HIP;
+    } else if (launch_chain(e, e->d_xp.p, A, e->step_dec + 2 * i, 2, md, false, nullptr, 0, 0, nullptr, xcd_on(2, false))) return PS_E_HIP;
   }
   HIPCHK(hipMemcpyAsync(e->d_emd.p, e->d_xp.p, sizeof(float) * (size_t)A * D, hipMemcpyDeviceToDevice, st));
   if (c.goal_pred_k > 0) {   // Decoder._goal_pred on the decoder's embedding (decoder/base.py:22-58, sym_coord.py:133-136)

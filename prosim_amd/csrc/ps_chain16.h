@@ -47,28 +47,25 @@ __device__ __forceinline__ bool fdiv16_ok(float x) {
   const float a = fabsf(x);
   return a < 65536.f;
 }
-// sin and cos of |a| < 2^13: three-term Cody-Waite reduction by pi/2 (fma: the products are exact), degree-7 kernels on
-// [-pi/4, pi/4]; max abs error 7.4e-8 against the exact values over the arguments the rel-PE rows produce
-// (tools/check_sincos.c) -- torch's own sin/cos are within 1 ulp = 6e-8.
-__device__ __forceinline__ void sincos_cw(float a, float& s, float& c) {
-  const float n = rintf(a * 0.636619747f);
-  float r = fmaf(-n, 1.57079637f, a);
-  r = fmaf(-n, -4.37113883e-8f, r);
-  r = fmaf(-n, -1.71512489e-15f, r);
-  const float z = r * r;
-  const float sp = fmaf(z, fmaf(z, fmaf(z, 2.7183114939898219064e-6f, -1.98393348360966317347e-4f), 8.3333293858894631756e-3f), -0.166666666416265235595f);
-  const float sn = fmaf(r * z, sp, r);
-  const float cp = fmaf(z, fmaf(z, fmaf(z, 2.43904487962774090654e-5f, -1.38867637746099294692e-3f), 4.16666233237390631894e-2f), -0.499999997251031003120f);
-  const float cs = fmaf(z, cp, 1.0f);
-  const int q = (int)n;
-  const float ss = (q & 1) ? cs : sn, cc = (q & 1) ? sn : cs;
-  s = (q & 2) ? -ss : ss;
-  c = ((q + 1) & 2) ? -cc : cc;
+// sin and cos of |a| < 2^16 on the transcendental unit: v_sin_f32 / v_cos_f32 take REVOLUTIONS, so the argument is turned
+// into a / (2 pi) with the product's rounding error recovered by an fma (C1 + C2 = 1 / (2 pi) to fp64 precision) and the
+// integer turns dropped before the two instructions.  Max abs error 2.5e-7 against the exact values over the arguments
+// the rel-PE rows produce (tools/mb/mb_vsin.hip, measured on MI355X; torch's own sin / cos: 6e-8) -- 7 issue slots per
+// pair where the Cody-Waite + degree-7 polynomial version (7.4e-8; tools/check_sincos.c) took 26: the edge phase of
+// this kernel is bound by VALU issue, and the rows are rounded to 22 bits (split fp16) right after.
+__device__ __forceinline__ void sincos_hw(float a, float& s, float& c) {
+  constexpr float C1 = 0.15915494309189535f;
+  constexpr float C2 = (float)(0.15915494309189535 - (double)0.15915494309189535f);
+  const float u = a * C1;
+  const float n = rintf(u);
+  const float f = fmaf(a, C1, -n) + a * C2;
+  s = __builtin_amdgcn_sinf(f);
+  c = __builtin_amdgcn_cosf(f);
 }
 // one (sin, cos) pair of the embedding: argument (x 2 pi) / dim_t exactly as the reference rounds it, then sin / cos
 __device__ __forceinline__ void fourier_pair(float xs, float d, float rd, bool fast, float& s, float& c) {
   if (fast) {
-    sincos_cw(fdiv16(xs, d, rd), s, c);
+    sincos_hw(fdiv16(xs, d, rd), s, c);
   } else {
     sincosf(xs / d, &s, &c);
   }
@@ -154,7 +151,7 @@ __global__ __launch_bounds__(256) void k_edge_geo(GeoSets sets, const float* __r
 
 // ------------------------------------------------------------------------------------------------------------
 // LDS plan (bytes): k_node's node-phase buffers, then cq and the row counter, then whatever the wave-private areas of
-// the edge phase (k staging 4 KB | probability tile 0.5 KB | feature tile 3.5 KB | source rows of the tile 64 B) need
+// the edge phase (k staging 4 KB | probability tile 0.5 KB | feature tile 3.5 KB | source rows of two tiles 128 B) need
 // beyond the operand planes and the GEMM result buffer, which they alias (dead while the edge phase runs).
 constexpr int C16_QS = 1024 + 32;   // floats between the q~ / a_r scratch rows of consecutive destinations: 4 KB apart every row of a
                                     // workgroup would queue on one L2 channel
@@ -162,7 +159,7 @@ constexpr int C16_FS = 112;   // feature-tile row stride in halfs: 96 features +
                               // half-wave's transposed read touches (and the 8 rows of a b128 write group) fall on distinct banks
 constexpr size_t C16_NODE_BYTES = ND_LDS_BYTES;
 constexpr size_t C16_PLANES_BYTES = (size_t)2 * ND_ROWS * ND_AS * 2 + (size_t)2 * ND_ROWS * ND_AS5 * 2 + (size_t)ND_ROWS * ND_CS * 4;   // P0 | P1 | C
-constexpr size_t C16_WAVE_BYTES = 4096 + 512 + (size_t)16 * C16_FS * 2 + 64;
+constexpr size_t C16_WAVE_BYTES = 4096 + 512 + (size_t)16 * C16_FS * 2 + 128;
 template <int NWV>
 constexpr size_t c16_lds_bytes() {
   return (NWV * C16_WAVE_BYTES > C16_PLANES_BYTES ? NWV * C16_WAVE_BYTES - C16_PLANES_BYTES : 0) + C16_NODE_BYTES + 16 * 8 * 4 + 64;
@@ -177,7 +174,7 @@ __device__ __forceinline__ void feat8(float xs, float rstd, float nmr, const flo
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     float s, c;
-    sincos_cw(fdiv16(xs, dv[j], rdv[j]), s, c);
+    sincos_hw(fdiv16(xs, dv[j], rdv[j]), s, c);
     const float ys = fmaf(s, rstd, nmr), yc = fmaf(c, rstd, nmr);
     hi[2 * j] = f16_hi(ys);
     lo[2 * j] = f16_lo(ys);
@@ -239,7 +236,7 @@ __device__ __noinline__ void c16_edge_phase(const ChainStep* __restrict__ stp, E
       half8* stg = reinterpret_cast<half8*>(wbase);                               // k staging (swizzled, as in k_attn_chain)
       float* Pt = reinterpret_cast<float*>(wbase + 4096);                         // [16 edges][8 heads] probabilities
       _Float16* Ft = reinterpret_cast<_Float16*>(wbase + 4096 + 512);             // [16 edges][C16_FS] feature tile (hi, then lo)
-      int* Ss = reinterpret_cast<int*>(wbase + 4096 + 512 + 16 * C16_FS * 2);     // [16] source rows of the tile
+      int* Ss = reinterpret_cast<int*>(wbase + 4096 + 512 + 16 * C16_FS * 2);     // [2][16] source rows of this tile and the next
       const EdgeGeo* __restrict__ geo = reinterpret_cast<const EdgeGeo*>(st.geo);
       const int rq = lane >> 2, pq = lane & 3;
       half8* stw = stg + rq * 16 + (pq ^ (rq >> 2));
@@ -312,24 +309,31 @@ __device__ __noinline__ void c16_edge_phase(const ChainStep* __restrict__ stp, E
         for (int cb = 0; cb < 6; ++cb) ar[cb] = floatx4{0.f, 0.f, 0.f, 0.f};
         float4 av = make_float4(0.f, 0.f, 0.f, 0.f);   // a_v partial: columns 4 (lane & 31) ..+3, edges of parity lane >> 5
         const float* vbase = st.kv + 128 + 4 * (lane & 31);
+        // the k rows of a tile are requested one tile ahead as well, as soon as the previous tile's rows have been staged
+        // (their registers are free then): they fly under that tile's softmax / aggregation and this tile's Fourier rows
+        half8 nkh[4], nkl[4];
+        int sb = 0;   // Ss buffer holding this tile's source rows
+        auto kload = [&](int tt, int buf) {
+          const int n_ = min(16, deg - tt);
+          const _Float16* kp = st.khl + (size_t)Ss[16 * buf + min(rq, n_ - 1)] * 256 + 8 * pq;
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) {
+            nkh[ks] = ldgh8(kp + 32 * ks);
+            nkl[ks] = ldgh8(kp + 128 + 32 * ks);
+          }
+        };
+        if (t0 < deg) {
+          if (lane < 16) Ss[lane] = nsrc;
+          kload(t0, 0);
+        }
 #pragma unroll 1
         for (; t0 < deg; t0 += tstep) {
           const int n = min(16, deg - t0);
           // this tile's records (requested a tile ago); the next tile's leave now
           const float4 g0 = ng;
           const float nmr = nn;
-          if (lane < 16) Ss[lane] = nsrc;
+          const int* Sc = Ss + 16 * sb;
           prefetch(t0 + tstep);
-          // the k rows leave before the Fourier rows are computed
-          half8 nkh[4], nkl[4];
-          {
-            const _Float16* kp = st.khl + (size_t)Ss[min(rq, n - 1)] * 256 + 8 * pq;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-              nkh[ks] = ldgh8(kp + 32 * ks);
-              nkl[ks] = ldgh8(kp + 128 + 32 * ks);
-            }
-          }
           C16_EMARK(4);
           if (prof && threadIdx.x == 0) atomicAdd(prof + 12, 1ull);
           float sreg[4];
@@ -369,6 +373,10 @@ __device__ __noinline__ void c16_edge_phase(const ChainStep* __restrict__ stp, E
             for (int ks = 0; ks < 4; ++ks) stw[4 * (ks ^ swa)] = nkl[ks];
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) ak[ks] = str[4 * (ks ^ sra)];
+            if (t0 + tstep < deg) {   // the next tile's source rows arrived with the prefetch: publish them, request its k rows
+              if (lane < 16) Ss[16 * (sb ^ 1) + lane] = nsrc;
+              kload(t0 + tstep, sb ^ 1);
+            }
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
               if (ks < 3) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl[ks < 3 ? ks : 0], bq[ks < 3 ? ks : 0], acc, 0, 0, 0);
@@ -386,11 +394,10 @@ __device__ __noinline__ void c16_edge_phase(const ChainStep* __restrict__ stp, E
           // gathered by source, two rows per load instruction
           float4 vv[8];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) vv[j] = ldg4(vbase + (size_t)Ss[min(2 * j + eh, n - 1)] * 256);
+          for (int j = 0; j < 8; ++j) vv[j] = ldg4(vbase + (size_t)Sc[min(2 * j + eh, n - 1)] * 256);
           // ---- online softmax over the tile (torch_geometric.utils.softmax: max-shift, exp, / (sum + 1e-16))
           float tmax = fmaxf(fmaxf(sreg[0], sreg[1]), fmaxf(sreg[2], sreg[3]));
-          tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
-          tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+          tmax = kq_max(tmax);
           const float m_new = fmaxf(m_run, tmax);   // finite: the tile has at least one edge
           const float scale = (m_run == -INFINITY) ? 0.f : exp2f(m_run - m_new);
           float psum = 0.f;
@@ -400,13 +407,13 @@ __device__ __noinline__ void c16_edge_phase(const ChainStep* __restrict__ stp, E
             psum += p;
             if (mi < 8) Pt[(4 * kq + r4) * 8 + mi] = p;
           }
-          psum += __shfl_xor(psum, 16);
-          psum += __shfl_xor(psum, 32);
+          psum = kq_sum(psum);
           l_run = l_run * scale + psum;
           m_run = m_new;
           // what is already accumulated shrinks by the head's scale: accumulator row 4 (lane >> 4) + r belongs to head
-          // (4 (lane >> 4) + r) & 7; the a_v columns of this lane to head hv
-          {
+          // (4 (lane >> 4) + r) & 7; the a_v columns of this lane to head hv.  Skipped while no head's maximum moves
+          // (most tiles after a row's first few).
+          if (__any(scale != 1.f)) {
             float scl[8];
 #pragma unroll
             for (int h = 0; h < 8; ++h) scl[h] = __shfl(scale, h);
@@ -455,6 +462,7 @@ __device__ __noinline__ void c16_edge_phase(const ChainStep* __restrict__ stp, E
             av.z = fmaf(ph, vv[j].z, av.z);
             av.w = fmaf(ph, vv[j].w, av.w);
           }
+          sb ^= 1;
         }
         C16_EMARK(9);
         // ---- the row's (partial) sums leave for the POST half: slot = part * Nd + row

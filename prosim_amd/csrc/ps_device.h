@@ -64,6 +64,21 @@ __device__ __forceinline__ float swap_add32(float lo, float hi) {
   const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo), __float_as_uint(hi), false, false);
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
+// all-reduce over the four lanes l, l ^ 16, l ^ 32, l ^ 48 on the VALU (v_permlane16_swap / v_permlane32_swap of gfx950)
+// instead of two ds_bpermute round trips through the LDS crossbar.  permlane16_swap(a, b): rows 1 / 3 of a trade places
+// with rows 0 / 2 of b, so with a = b = v the two results hold (row 0, row 0, row 2, row 2) and (row 1, row 1, row 3, row 3).
+__device__ __forceinline__ float kq_max(float v) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  const float m = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+  const auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+  return fmaxf(__uint_as_float(q[0]), __uint_as_float(q[1]));
+}
+__device__ __forceinline__ float kq_sum(float v) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  const float m = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  const auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+  return __uint_as_float(q[0]) + __uint_as_float(q[1]);
+}
 __device__ __forceinline__ float dpp_xor8(float v) {   // row_ror:8
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, true));
 }

@@ -318,7 +318,7 @@ class Engine:
         self._check(self.lib.ps_sync(self.h))
 
     def set_chain_rows(self, rows: int):
-        """0: latency mode (one rollout on the GPU); 8..16: throughput mode for several engines sharing the GPU (12 in bench.py)."""
+        """0: latency mode (one rollout on the GPU); 8..16: throughput mode for several engines sharing the GPU (16 in bench.py)."""
         self._check(self.lib.ps_set_chain_rows(self.h, rows))
 
     def set_chain_impl(self, impl: int):
