@@ -154,13 +154,14 @@ int ps_sync(ps_engine* e);
  * that drive the encoder by hand.  Read the tokens back with ps_get("scene_tokens"). */
 int ps_update_obs(ps_engine* e, const float* obs_input, const uint8_t* obs_mask, const float* obs_pos, const float* obs_head);
 /* Destination rows per workgroup of the fused attention launches = the engine's operating mode:
- *   0       latency mode, ONE rollout on the GPU: the round-1 kernel k_attn_chain with 2 rows per workgroup (512 small
- *           workgroups per 1024-row policy launch, two per CU);
- *   8..16   throughput mode, several engines share the GPU: the policy layers run on k_chain16 -- node Linears as 16-row
- *           MFMA GEMMs (a layer's weights cross a CU once per workgroup), rel-PE rows recomputed per 16-edge tile from 32 B of
- *           geometry per edge -- with that many rows per 8-wave workgroup; 16 rows x 4 rollouts in flight = 256 workgroups,
- *           one per CU, is what bench.py runs (with GPU_MAX_HW_QUEUES=8: the runtime's default 4 hardware queues
- *           serialise four engines' streams).  The other fused launches take 4 rows per workgroup then.
+ *   0       latency mode, ONE rollout on the GPU: from 1024 destination rows up the fused chains run on k_chain16 with 4 rows
+ *           per 8-wave workgroup (256 workgroups per 1024-row policy launch, two waves per row); smaller launches on
+ *           the round-1 kernel k_attn_chain (one or two rows per 4-wave workgroup);
+ *   8..16   throughput mode, several engines share the GPU: k_chain16 -- node Linears as 16-row MFMA GEMMs (a layer's
+ *           weights cross a CU once per workgroup), rel-PE rows recomputed per 16-edge tile from 32 B of geometry per edge
+ *           -- with that many rows per workgroup; 16 rows x 4 rollouts in flight = 256 workgroups, one per CU, is what
+ *           bench.py runs (with GPU_MAX_HW_QUEUES=8: the runtime's default 4 hardware queues serialise four engines'
+ *           streams).
  *   1, 2, 4 rows per workgroup of either kernel (k_chain16 shares a row's edge list between 8 / rows waves; k_attn_chain
  *           takes 2 or 4) -- experiments.
  * Results do not depend on it beyond fp32 summation order. */

@@ -1201,7 +1201,7 @@ namespace {
 // split-path exchange buffers, grown on demand (never inside a captured rollout: ps_set_scene sizes them first)
 int io_for(ps_engine* e, int Nd, EdgeIO& io) {
   const size_t n = (size_t)std::max(Nd, 1);
-  if (e->io_q.ensure(n * 128) || e->io_qt.ensure(n * C16_QS) || e->io_cq.ensure(n * 8) || e->io_ar.ensure(n * C16_QS) ||
+  if (e->io_q.ensure(n * 128) || e->io_qt.ensure(n * 1024) || e->io_cq.ensure(n * 8) || e->io_ar.ensure(n * 1024) ||
       e->io_av.ensure(n * 128) || e->io_l.ensure(n * 8) || e->io_s.ensure(n * 128) || e->io_g.ensure(n * 128) || e->io_m.ensure(n * 8))
     return -1;
   io.q = e->io_q.p; io.qt = e->io_qt.p; io.cq = e->io_cq.p; io.ar = e->io_ar.p; io.av = e->io_av.p; io.l = e->io_l.p;
@@ -1376,9 +1376,12 @@ void launch_geo(ps_engine* e, const PeArgs* a, int nsets) {
 
 // Fused chain, second generation (ps_chain16.h).  rows per workgroup: the engine's choice keeps >= 256 workgroups in a
 // launch while it can (4 rows at 1024 destinations), ps_set_chain_rows overrides (16 = throughput mode).
-// does the policy chain run on k_chain16?  (ps_set_chain_impl; 0 = in throughput mode only: alone on the GPU the
-// round-1 kernel's 512 small workgroups still finish a 1024-row launch sooner, 0.53 against 0.64 ms)
-bool use_c16(const ps_engine* e) { return e->chain_impl == 2 || (e->chain_impl == 0 && e->chain_rows >= 8); }
+// do the fused chains over Nd destination rows run on k_chain16?  (ps_set_chain_impl; 0 = in throughput mode, and in
+// latency mode from 1024 rows up: 0.47 against 0.53 ms per 1024-row policy launch; below that the round-1 kernel's one
+// small workgroup per row fills the chip better, 0.27 against 0.37 ms at 128 rows)
+bool use_c16(const ps_engine* e, int Nd) {
+  return e->chain_impl == 2 || (e->chain_impl == 0 && (e->chain_rows >= 8 || (e->chain_rows == 0 && Nd >= 1024)));
+}
 int chain16_rows(ps_engine* e, int Nd) {
   static const int env_rows = getenv("PS_C16_ROWS") ? atoi(getenv("PS_C16_ROWS")) : 0;   // experiments only
   int rows = Nd >= 4096 ? 16 : (Nd >= 2048 ? 8 : (Nd >= 512 ? 4 : (Nd >= 256 ? 2 : 1)));
@@ -1506,7 +1509,7 @@ extern "C" int ps_encode_scene(ps_engine* e) {
     // a2a edges index agents globally (Mv + i) for positions; kv rows are agent-local -> fixed up below
     const PeArgs pe[2] = {{&e->e_a2a, e->d_tok_ori.p, e->d_tok_pos.p + 2 * (size_t)Mv, e->d_tok_ori.p + Mv},
                           {&e->e_s2s, e->d_tok_ori.p, e->d_tok_pos.p, e->d_tok_ori.p}};
-    if (use_c16(e)) {   // the a2a layers run on k_chain16 (geometry records), the s2s layers keep the operand images
+    if (use_c16(e, A)) {   // the a2a layers run on k_chain16 (geometry records), the s2s layers keep the operand images
       launch_geo(e, &pe[0], 1);
       launch_relpe(e, &pe[1], 1);
     } else {
@@ -1519,7 +1522,7 @@ extern "C" int ps_encode_scene(ps_engine* e) {
   const bool split_s2s = !no_split && Mv + A >= 2048 && e->e_s2s.maxdeg <= ES_MAXDEG;
   for (int i = 0; i < c.scene_layers; ++i) {
     launch_kv(e, tok + (size_t)Mv * D, A, e->L_a2a + i, 1, e->d_kv.p + (size_t)Mv * 256, e->d_kh.p + (size_t)Mv * 256, 0);
-    if (use_c16(e)) {
+    if (use_c16(e, A)) {
       if (launch_chain16(e, tok + (size_t)Mv * D, A, e->d_steps.p + e->step_a2a + i, 1, false, nullptr, false)) return PS_E_HIP;
     } else if (launch_chain(e, tok + (size_t)Mv * D, A, e->step_a2a + i, 1, e->e_a2a.maxdeg, false, nullptr, 0, 0, nullptr, xcd_on(1, false))) return PS_E_HIP;
     if (split_s2s) {
@@ -1558,7 +1561,7 @@ extern "C" int ps_generate_policy(ps_engine* e) {
   HIPCHK(hipMemcpyAsync(e->d_tok_pos.p + 2 * (size_t)Mv, ppos, sizeof(float) * 2 * A, hipMemcpyDeviceToDevice, st));
   HIPCHK(hipMemcpyAsync(e->d_tok_ori.p + Mv, pori, sizeof(float) * A, hipMemcpyDeviceToDevice, st));
   // (with log-replay agents in the scene only the policy agents are prompts: candidate filter)
-  const int pe_gen = use_c16(e) ? 2 : 1;   // k_chain16 rebuilds the rel-PE rows from geometry records, k_attn_chain streams operand images
+  const int pe_gen = use_c16(e, A) ? 2 : 1;   // k_chain16 rebuilds the rel-PE rows from geometry records, k_attn_chain streams operand images
   launch_radius(e, e->e_p2p, e->d_r_agent.p, nullptr, ppos, pscene, A, c.dec_prompt_radius, c.dec_max_neigh, Mv, e->d_tok_ori.p, pori,
                 e->all_policy ? nullptr : (const int*)e->d_is_policy.p, Mv, pe_gen);
   // restore observed agent poses for the scene tokens, then s2p: radius over all scene tokens (:94)
@@ -1572,7 +1575,7 @@ extern "C" int ps_generate_policy(ps_engine* e) {
   for (int i = 0; i < c.dec_layers; ++i) {
     // p2p edges carry GLOBAL agent rows (Mv + j): project into rows Mv.. of the shared kv buffer
     launch_kv(e, e->d_xp.p, A, e->L_p2p + i, 1, e->d_kv.p + (size_t)Mv * 256, e->d_kh.p + (size_t)Mv * 256, 0);
-    if (use_c16(e)) {
+    if (use_c16(e, A)) {
       if (launch_chain16(e, e->d_xp.p, A, e->d_steps.p + e->step_dec + 2 * i, 2, false, nullptr, false)) return PS_E_HIP;
     } else if (launch_chain(e, e->d_xp.p, A, e->step_dec + 2 * i, 2, md, false, nullptr, 0, 0, nullptr, xcd_on(2, false))) return PS_E_HIP;
   }
@@ -1690,12 +1693,12 @@ extern "C" int ps_policy_step(ps_engine* e, int32_t t_idx) {
     const RadArgs ra[2] = {{&e->e_a2p, e->d_r_agent.p, nullptr, c.pol_agent_radius, c.pol_max_neigh, -1,
                             e->all_policy ? nullptr : (const int*)e->d_tok_live.p, Mv},
                            {&e->e_m2p, e->d_r_map.p, nullptr, c.pol_map_radius, c.pol_max_neigh, -1}};
-    launch_radius(e, ra, 2, e->d_cur_pos.p, pscene, A, e->d_tok_ori.p, e->d_cur_ori.p, use_c16(e) ? 2 : 1);
+    launch_radius(e, ra, 2, e->d_cur_pos.p, pscene, A, e->d_tok_ori.p, e->d_cur_ori.p, use_c16(e, A) ? 2 : 1);
   }
   const int md = std::max(e->e_a2p.maxdeg, e->e_m2p.maxdeg);
   if (e->policy_events && (int)e->pev.size() >= 2 * R) HIPCHK(hipEventRecord(e->pev[2 * t_idx], st));
   // the policy tokens enter every replan unchanged (d_emd); the fused features leave to d_fused
-  if (use_c16(e)) {
+  if (use_c16(e, A)) {
     if (launch_chain16(e, e->d_fused.p, A, e->d_steps.p + e->step_pol, 2 * c.pol_layers, true, e->d_emd.p, xcd_on(0, true))) return PS_E_HIP;
   } else if (launch_chain(e, e->d_fused.p, A, e->step_pol, 2 * c.pol_layers, md, true, nullptr, 0, 0, e->d_emd.p, xcd_on(0, true))) return PS_E_HIP;
   if (e->policy_events && (int)e->pev.size() >= 2 * R) HIPCHK(hipEventRecord(e->pev[2 * t_idx + 1], st));
@@ -2251,7 +2254,7 @@ extern "C" int ps_policy_forward(ps_engine* e, int32_t n_scenes, int32_t Na, con
   std::swap(e->d_tok_pos, d_pos);
   launch_kv(e, d_atok.p, Na, e->L_a2p, L, d_kva.p, d_kha.p, (size_t)Na * 256);
   launch_kv(e, d_mtok.p, Nm, e->L_m2p, L, d_kvm.p, d_khm.p, (size_t)Nm * 256);
-  const int pe_mode = use_c16(e) ? 2 : 1;
+  const int pe_mode = use_c16(e, A) ? 2 : 1;
   launch_radius(e, ea, d_ragent.p, nullptr, d_ppos.p, d_pscene.p, A, c.pol_agent_radius, c.pol_max_neigh, -1, d_ori.p, d_pori.p, nullptr, 0, pe_mode);
   launch_radius(e, em, d_rmap.p, nullptr, d_ppos.p, d_pscene.p, A, c.pol_map_radius, c.pol_max_neigh, -1, d_ori.p, d_pori.p, nullptr, 0, pe_mode);
   std::vector<ChainStep> hs;
@@ -2265,7 +2268,7 @@ extern "C" int ps_policy_forward(ps_engine* e, int32_t n_scenes, int32_t Na, con
   }
   int rc = 0;
   if (upload(d_steps, hs.data(), hs.size(), st)) rc = fail(PS_E_HIP, "step upload failed");
-  if (!rc) rc = use_c16(e) ? launch_chain16(e, d_x.p, A, d_steps.p, 2 * L, false, nullptr, false)
+  if (!rc) rc = use_c16(e, A) ? launch_chain16(e, d_x.p, A, d_steps.p, 2 * L, false, nullptr, false)
                                    : launch_chain(e, d_x.p, A, 0, 2 * L, std::max(da, dm), false, d_steps.p);
   if (!rc) {
     // head with a neutral state (last pose = origin, heading 0): only motion_pred is read back

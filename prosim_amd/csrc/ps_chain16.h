@@ -153,16 +153,20 @@ __global__ __launch_bounds__(256) void k_edge_geo(GeoSets sets, const float* __r
 // LDS plan (bytes): k_node's node-phase buffers, then cq and the row counter, then whatever the wave-private areas of
 // the edge phase (k staging 4 KB | probability tile 0.5 KB | feature tile 3.5 KB | source rows of two tiles 128 B) need
 // beyond the operand planes and the GEMM result buffer, which they alias (dead while the edge phase runs).
-constexpr int C16_QS = 1024 + 32;   // floats between the q~ / a_r scratch rows of consecutive destinations: 4 KB apart every row of a
-                                    // workgroup would queue on one L2 channel
 constexpr int C16_FS = 112;   // feature-tile row stride in halfs: 96 features + 16 pad = 56 dwords, so the 8 rows x 32 B that a
                               // half-wave's transposed read touches (and the 8 rows of a b128 write group) fall on distinct banks
 constexpr size_t C16_NODE_BYTES = ND_LDS_BYTES;
 constexpr size_t C16_PLANES_BYTES = (size_t)2 * ND_ROWS * ND_AS * 2 + (size_t)2 * ND_ROWS * ND_AS5 * 2 + (size_t)ND_ROWS * ND_CS * 4;   // P0 | P1 | C
 constexpr size_t C16_WAVE_BYTES = 4096 + 512 + (size_t)16 * C16_FS * 2 + 128;
+// q~ (PRE -> edge phase) and the edge phase's a_r sums (-> POST) stay in LDS: 16 slots of [8 heads][96 (+4)] floats.  One
+// wave per row: the row's a_r overwrites its q~ (slot = row).  W waves per row (rows <= 4): a_r slots row * W + part (8 at
+// most), q~ of row r in slot 8 + r.  Slot stride 808 floats = 8 mod 64: the 16 rows of a fold A-fragment read spread over
+// the banks two deep.
+constexpr int C16_QH = 100, C16_QSL = 8 * C16_QH + 8;
+constexpr size_t C16_QA_BYTES = (size_t)16 * C16_QSL * 4;
 template <int NWV>
 constexpr size_t c16_lds_bytes() {
-  return (NWV * C16_WAVE_BYTES > C16_PLANES_BYTES ? NWV * C16_WAVE_BYTES - C16_PLANES_BYTES : 0) + C16_NODE_BYTES + 16 * 8 * 4 + 64;
+  return (NWV * C16_WAVE_BYTES > C16_PLANES_BYTES ? NWV * C16_WAVE_BYTES - C16_PLANES_BYTES : 0) + C16_NODE_BYTES + 16 * 8 * 4 + 144 + C16_QA_BYTES;
 }
 
 typedef __fp16 fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
@@ -208,7 +212,7 @@ __device__ __forceinline__ void feat_slow_row(float a0, float a1, float a2, floa
 // ctr = the node phase's q rows, <q, kb> and the row counter.
 template <int NWV>
 __device__ __noinline__ void c16_edge_phase(const ChainStep* __restrict__ stp, EdgeIO io, unsigned char* c16_smem, const float* AG,
-                                            const float* CQ, int* ctr, const float* __restrict__ div32, int row0, int nrows, int W, int Nd,
+                                            const float* CQ, int* ctr, float* QA, const float* __restrict__ div32, int row0, int nrows, int W, int Nd,
                                             unsigned long long* __restrict__ prof) {
   const ChainStep& st = *stp;
   long long tprev = (prof && threadIdx.x == 0) ? clock64() : 0;
@@ -254,6 +258,8 @@ __device__ __noinline__ void c16_edge_phase(const ChainStep* __restrict__ stp, E
           lr = 0;
           if (lane == 0) lr = atomicAdd(ctr, 1);
           lr = __builtin_amdgcn_readfirstlane(lr);
+          if (lr >= nrows) break;
+          lr = ctr[1 + lr];
           part = 0;
         }
         if (lr >= nrows) break;
@@ -281,12 +287,12 @@ __device__ __noinline__ void c16_edge_phase(const ChainStep* __restrict__ stp, E
         float cqm;
         {
           const int hB = mi & 7;
-          const float* qtp = io.qt + (size_t)r * C16_QS + hB * 128 + 8 * kq;
+          const float* qtp = QA + ((W == 1 ? 0 : 8) + lr) * C16_QSL + hB * C16_QH + 8 * kq;
           const float* qp = AG + lr * ND_XS + 8 * kq;
 #pragma unroll
           for (int ks = 0; ks < 4; ++ks) {
             if (ks < 3) {
-              const float4 v0 = ldg4(qtp + 32 * ks), v1 = ldg4(qtp + 32 * ks + 4);
+              const float4 v0 = *reinterpret_cast<const float4*>(qtp + 32 * ks), v1 = *reinterpret_cast<const float4*>(qtp + 32 * ks + 4);
               const float qv_[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
               for (int j = 0; j < 8; ++j) bq[ks < 3 ? ks : 0][j] = loA ? f16_lo(qv_[j]) : f16_hi(qv_[j]);
@@ -479,7 +485,7 @@ __device__ __noinline__ void c16_edge_phase(const ChainStep* __restrict__ stp, E
 #pragma unroll
           for (int r4 = 0; r4 < 4; ++r4) {
             const float v = swap_add32(ar[cb][r4], ar[cb + 1][r4]);   // lanes < 32: block cb, lanes >= 32: block cb + 1
-            io.ar[slot * C16_QS + (4 * ((lane >> 4) & 1) + r4) * 128 + (cb + (lane >> 5)) * 16 + (lane & 15)] = v;
+            QA[(W == 1 ? lr : lr * W + part) * C16_QSL + (4 * ((lane >> 4) & 1) + r4) * C16_QH + (cb + (lane >> 5)) * 16 + (lane & 15)] = v;
           }
         }
         C16_EMARK(10);
@@ -487,20 +493,6 @@ __device__ __noinline__ void c16_edge_phase(const ChainStep* __restrict__ stp, E
     }
     }
 
-// NWV: waves per workgroup (8: one workgroup per CU, two waves per SIMD hide each other's latency; 4: two workgroups per CU).
-// POLICY: own symbol for the per-replan policy launch (kernel traces, bench.py) + the XCD-aware block -> row mapping.
-// rows: destination rows per workgroup (<= 16; the MFMA tiles are 16 rows, the rest zero).  With rows < NWV a row's edge
-// list is shared by W = NWV / rows waves (tiles w, w + W, ...): every wave keeps its own running maximum and sums, the
-// POST half merges the W partials.
-template <int NWV, bool POLICY>
-__global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void k_chain16(float* __restrict__ x, const float* __restrict__ x_in, int Nd, int rows,
-                                                    const ChainStep* __restrict__ steps, int nsteps, EdgeIO io,
-                                                    const float* __restrict__ div32, float eps, int xcd,
-                                                    unsigned long long* __restrict__ prof) {
-  // prof (PS_CHAIN_PROF=1; nullptr in every product launch): thread 0 of each workgroup charges the cycles since the
-  // previous mark to slot i: 0 PRE, 1 EDGE, 2 POST; wave 0 of the edge phase: 4 records + k issue, 5 Fourier rows,
-  // 6 staging + score MFMAs, 7 softmax, 8 a_r MFMAs, 9 a_v, 10 row epilogue, 11 row prologue, 12 tiles
-  long long tprev = prof ? clock64() : 0;
 #define C16_MARK(i)                                                   \
   do {                                                                \
     if (prof && threadIdx.x == 0) {                                   \
@@ -509,10 +501,19 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void k_chain16(float* _
       tprev = now_;                                                   \
     }                                                                 \
   } while (0)
+
+// The node phases between two edge phases: POST of layer `post` (to_v_r fold, gate, to_out, norms, FFN) and PRE of layer
+// `pre` (LN_dst, q | s | g, q~, <q, kb>, the row queue); either may be null.  Out of line like the edge phase, so that the
+// weight-fragment ring gets a register allocation that no other phase's pressure can push into scratch.  x_out: where the
+// residual rows go after the last layer (null otherwise).
+template <int NWV>
+__device__ __noinline__ void c16_node_phase(const ChainStep* __restrict__ post, const ChainStep* __restrict__ pre, EdgeIO io,
+                                            unsigned char* c16_smem, float* __restrict__ x_out, int row0, int nrows, int W, int Nd,
+                                            float eps, unsigned long long* __restrict__ prof) {
+  long long tprev = (prof && threadIdx.x == 0) ? clock64() : 0;
   constexpr int NT = 64 * NWV;
-  extern __shared__ __attribute__((aligned(16))) unsigned char c16_smem[];
   constexpr size_t EXTRA = NWV * C16_WAVE_BYTES > C16_PLANES_BYTES ? NWV * C16_WAVE_BYTES - C16_PLANES_BYTES : 0;
-  // [wave areas beyond the planes (EXTRA)] [P0 | P1 | C] [X | AG | sp | CQ | ctr]: the wave areas run from the start
+  // [wave areas beyond the planes (EXTRA)] [P0 | P1 | C] [X | AG | sp | CQ | ctr | QA]: the wave areas run from the start
   unsigned char* node_base = c16_smem + EXTRA;
   _Float16* P0h = reinterpret_cast<_Float16*>(node_base);
   _Float16* P0l = P0h + ND_ROWS * ND_AS;
@@ -524,47 +525,23 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void k_chain16(float* _
   float* AG = X + ND_ROWS * ND_XS;       // [16][132] q (PRE -> edge phase)
   float* sp = AG + ND_ROWS * ND_XS;      // [SP_SIZE] the layer's small vectors
   float* CQ = sp + SP_SIZE;              // [16][8] <q_h, kb_h>
-  int* ctr = reinterpret_cast<int*>(CQ + 16 * 8);
-
-  const int row0 = xcd_block(blockIdx.x, gridDim.x, !xcd) * rows;
-  const int nrows = min(rows, Nd - row0);          // rows of this workgroup that exist (> 0: the grid is ceil(Nd / rows))
-  const int W = rows < NWV ? NWV / rows : 1;       // waves per row in the edge phase (rows is a power of two)
-  {
-    const int tid0 = threadIdx.x, er0 = (tid0 >> 4) & 15, ec0 = (tid0 & 15) * 8;
-    if (tid0 < 256) {
-      float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
-      if (er0 < nrows) { v0 = ldg4(x_in + (size_t)(row0 + er0) * 128 + ec0); v1 = ldg4(x_in + (size_t)(row0 + er0) * 128 + ec0 + 4); }
-      *reinterpret_cast<float4*>(X + er0 * ND_XS + ec0) = v0;
-      *reinterpret_cast<float4*>(X + er0 * ND_XS + ec0 + 4) = v1;
-    }
-  }
-  constexpr int C16_DEPTH = 3;   // fragment groups in flight per wave (k_node, alone on its CU with 512 registers: 4; 4 spills here)
+  int* ctr = reinterpret_cast<int*>(CQ + 16 * 8);   // [0] row counter, [1..16] the rows in queue order (longest edge list first), [17..32] their edge counts
+  float* QA = reinterpret_cast<float*>(ctr + 36);   // [16 slots][C16_QSL] q~ / a_r
+  constexpr int C16_DEPTH = 3;   // fragment groups in flight per wave (k_node, alone on its CU with 512 registers: 4)
   typedef FragRingT<C16_DEPTH> Ring;
-
-  // Iteration s: EDGE(s), POST(s), PRE(s + 1); iteration -1 is PRE(0) alone.  The fragment ring is declared between the
-  // edge phase and the node phases, so that it is dead (not merely unused) while the edge phase needs the registers.
-  for (int s = -1; s < nsteps; ++s) {
-    // Lane-derived indices are re-materialised behind an opaque asm every layer: otherwise LICM hoists the loop-invariant
-    // LDS / global addresses of every phase out of the layer loop and they spill (> 100 registers' worth).
-    int tid_v = threadIdx.x;
-    asm volatile("" : "+v"(tid_v));
-    const int tid = tid_v, lane = tid_v & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid_v >> 6);
-    const int mi = lane & 15, kq = lane >> 4;
-    const bool epi = tid < 256;                      // the 16 x 128 epilogues take 256 threads: row er, 8 columns from ec
-    const int er = (tid >> 4) & 15, ec = (tid & 15) * 8;
-    const int grow = row0 + er;
-    const bool live = epi && er < nrows;
-    auto stage_sp = [&](const float* __restrict__ src) {
-      for (int i = tid; i < SP_SIZE / 4; i += NT) *reinterpret_cast<float4*>(sp + 4 * i) = ldg4(src + 4 * i);
-    };
-    C16_MARK(0);
-    if (s >= 0) c16_edge_phase<NWV>(steps + s, io, c16_smem, AG, CQ, ctr, div32, row0, nrows, W, Nd, prof);
-    if (s >= 0) __syncthreads();   // every row's sums are in the scratch; the wave-private areas are dead
-    C16_MARK(1);
-    Ring R;
-    if (s >= 0) {
-      const ChainStep& st = steps[s];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int mi = lane & 15, kq = lane >> 4;
+  const bool epi = tid < 256;                      // the 16 x 128 epilogues take 256 threads: row er, 8 columns from ec
+  const int er = (tid >> 4) & 15, ec = (tid & 15) * 8;
+  const int grow = row0 + er;
+  const bool live = epi && er < nrows;
+  auto stage_sp = [&](const float* __restrict__ src) {
+    for (int i = tid; i < SP_SIZE / 4; i += NT) *reinterpret_cast<float4*>(sp + 4 * i) = ldg4(src + 4 * i);
+  };
+  Ring R;
+  if (post) {
+      const ChainStep& st = *post;
       const AttnW& w = st.w;
     // =========================================================== POST: to_v_r fold, gate, to_out, norms, FFN   (:76-77, :100-107)
     {
@@ -606,10 +583,10 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void k_chain16(float* _
             bl[ks] = ldgh8(f + 512);
           }
           if (mi < nrows && W == 1) {   // one wave per row: the row's sums as they are (all six loads in flight at once)
-            const float* ap_ = io.ar + (size_t)(row0 + mi) * C16_QS + h * 128 + kq * 8;
+            const float* ap_ = QA + mi * C16_QSL + h * C16_QH + kq * 8;
             float4 a0[3], a1[3];
 #pragma unroll
-            for (int ks = 0; ks < 3; ++ks) { a0[ks] = ldg4(ap_ + ks * 32); a1[ks] = ldg4(ap_ + ks * 32 + 4); }
+            for (int ks = 0; ks < 3; ++ks) { a0[ks] = *reinterpret_cast<const float4*>(ap_ + ks * 32); a1[ks] = *reinterpret_cast<const float4*>(ap_ + ks * 32 + 4); }
 #pragma unroll
             for (int ks = 0; ks < 3; ++ks) {
               av_[ks][0] = a0[ks].x; av_[ks][1] = a0[ks].y; av_[ks][2] = a0[ks].z; av_[ks][3] = a0[ks].w;
@@ -624,8 +601,8 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void k_chain16(float* _
               const float sc = (mp == -INFINITY) ? 0.f : exp2f(mp - mm);
 #pragma unroll
               for (int ks = 0; ks < 3; ++ks) {
-                const float* ap_ = io.ar + slot * C16_QS + h * 128 + ks * 32 + kq * 8;
-                const float4 a0 = ldg4(ap_), a1 = ldg4(ap_ + 4);
+                const float* ap_ = QA + (mi * W + p) * C16_QSL + h * C16_QH + ks * 32 + kq * 8;
+                const float4 a0 = *reinterpret_cast<const float4*>(ap_), a1 = *reinterpret_cast<const float4*>(ap_ + 4);
                 av_[ks][0] = fmaf(a0.x, sc, av_[ks][0]); av_[ks][1] = fmaf(a0.y, sc, av_[ks][1]);
                 av_[ks][2] = fmaf(a0.z, sc, av_[ks][2]); av_[ks][3] = fmaf(a0.w, sc, av_[ks][3]);
                 av_[ks][4] = fmaf(a1.x, sc, av_[ks][4]); av_[ks][5] = fmaf(a1.y, sc, av_[ks][5]);
@@ -709,7 +686,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void k_chain16(float* _
       __syncthreads();
       C16_MARK(24);
       gemm16<16, Ring, NWV>(R, P1h, P1l, ND_AS5, w.F2, 8, C, ND_CS, wave, lane);
-      if (s + 1 < nsteps) frag_prefetch<4, Ring, NWV>(R, steps[s + 1].w.Fqsg, 24, wave, lane);   // (the next PRE's first GEMM)
+      if (pre) frag_prefetch<4, Ring, NWV>(R, pre->w.Fqsg, 24, wave, lane);   // (the next PRE's first GEMM)
       __syncthreads();
       C16_MARK(25);
       if (epi) {   // x = x + LN_ffpost(FFN)
@@ -722,9 +699,9 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void k_chain16(float* _
           y[i] += X[er * ND_XS + ec + i];
           X[er * ND_XS + ec + i] = y[i];
         }
-        if (live && s + 1 == nsteps) {
-          *reinterpret_cast<float4*>(x + (size_t)grow * 128 + ec) = make_float4(y[0], y[1], y[2], y[3]);
-          *reinterpret_cast<float4*>(x + (size_t)grow * 128 + ec + 4) = make_float4(y[4], y[5], y[6], y[7]);
+        if (live && x_out) {
+          *reinterpret_cast<float4*>(x_out + (size_t)grow * 128 + ec) = make_float4(y[0], y[1], y[2], y[3]);
+          *reinterpret_cast<float4*>(x_out + (size_t)grow * 128 + ec + 4) = make_float4(y[4], y[5], y[6], y[7]);
         }
       }
       __syncthreads();   // X is final for this layer; sp may be restaged
@@ -732,12 +709,13 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void k_chain16(float* _
     }
     }
     C16_MARK(2);
-    if (s + 1 < nsteps) {
-      const ChainStep& st = steps[s + 1];
+  if (pre) {
+      const ChainStep& st = *pre;
       const AttnW& w = st.w;
     // =========================================================== PRE: LN_dst, q | s | g, q~, <q, kb>   (:61-69, :106-107, :114)
     stage_sp(w.sp);
-    if (s < 0) frag_prefetch<4, Ring, NWV>(R, w.Fqsg, 24, wave, lane);   // (later layers: requested at the end of the previous POST)
+    if (tid < 16) ctr[17 + tid] = tid < nrows ? ldgi(st.eoff + row0 + tid + 1) - ldgi(st.eoff + row0 + tid) : -1;   // (for the row queue)
+    if (!post) frag_prefetch<4, Ring, NWV>(R, w.Fqsg, 24, wave, lane);   // (later layers: requested at the end of the previous POST)
     __syncthreads();
     C16_MARK(32);
     if (epi) {
@@ -792,7 +770,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void k_chain16(float* _
             acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc, 0, 0, 0);
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-              if (4 * kq + r < nrows) io.qt[(size_t)(row0 + 4 * kq + r) * C16_QS + h * 128 + nt * 16 + mi] = acc[r];
+              if (4 * kq + r < nrows) QA[((W == 1 ? 0 : 8) + 4 * kq + r) * C16_QSL + h * C16_QH + nt * 16 + mi] = acc[r];
           }
         }
       }
@@ -802,11 +780,77 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void k_chain16(float* _
         for (int d = 0; d < DH; ++d) a = fmaf(AG[r * ND_XS + h * DH + d], sp[SP_KB + h * DH + d], a);
         CQ[r * 8 + h] = a;
       }
-      if (tid == 0) *ctr = 0;
+      if (tid == 0) ctr[0] = 0;
+      if (tid < 16) {   // queue order of the edge phase: rows by falling edge count (read at the top of this PRE), long rows first
+        const int mine = ctr[17 + tid];
+        int rank = 0;
+        for (int j = 0; j < 16; ++j) {
+          const int dj = ctr[17 + j];
+          rank += (dj > mine || (dj == mine && j < tid)) ? 1 : 0;
+        }
+        ctr[1 + rank] = tid;
+      }
     }
-    __syncthreads();   // q~ rows (global scratch of this workgroup), cq, counter: visible to every wave
+    __syncthreads();   // q~ rows, cq, the row queue: visible to every wave
     C16_MARK(36);
     }
+}
+
+// NWV: waves per workgroup (8: one workgroup per CU, two waves per SIMD hide each other's latency; 4: two workgroups per CU).
+// POLICY: own symbol for the per-replan policy launch (kernel traces, bench.py) + the XCD-aware block -> row mapping.
+// rows: destination rows per workgroup (<= 16; the MFMA tiles are 16 rows, the rest zero).  With rows < NWV a row's edge
+// list is shared by W = NWV / rows waves (tiles w, w + W, ...): every wave keeps its own running maximum and sums, the
+// POST half merges the W partials.
+template <int NWV, bool POLICY>
+__global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void k_chain16(float* __restrict__ x, const float* __restrict__ x_in, int Nd, int rows,
+                                                    const ChainStep* __restrict__ steps, int nsteps, EdgeIO io,
+                                                    const float* __restrict__ div32, float eps, int xcd,
+                                                    unsigned long long* __restrict__ prof) {
+  // prof (PS_CHAIN_PROF=1; nullptr in every product launch): thread 0 of each workgroup charges the cycles since the
+  // previous mark to slot i: 0 PRE, 1 EDGE, 2 POST; wave 0 of the edge phase: 4 records + k issue, 5 Fourier rows,
+  // 6 staging + score MFMAs, 7 softmax, 8 a_r MFMAs, 9 a_v, 10 row epilogue, 11 row prologue, 12 tiles
+  long long tprev = prof ? clock64() : 0;
+  extern __shared__ __attribute__((aligned(16))) unsigned char c16_smem[];
+  constexpr size_t EXTRA = NWV * C16_WAVE_BYTES > C16_PLANES_BYTES ? NWV * C16_WAVE_BYTES - C16_PLANES_BYTES : 0;
+  // [wave areas beyond the planes (EXTRA)] [P0 | P1 | C] [X | AG | sp | CQ | ctr | QA]: the wave areas run from the start
+  unsigned char* node_base = c16_smem + EXTRA;
+  _Float16* P0h = reinterpret_cast<_Float16*>(node_base);
+  _Float16* P0l = P0h + ND_ROWS * ND_AS;
+  _Float16* P1h = P0l + ND_ROWS * ND_AS;
+  _Float16* P1l = P1h + ND_ROWS * ND_AS5;
+  float* C = reinterpret_cast<float*>(P1l + ND_ROWS * ND_AS5);   // [16][132] results of the 128-column GEMMs
+  float* Cw = reinterpret_cast<float*>(P1h);                     // [16][388] wide results of the PRE half (FFN planes' memory)
+  float* X = C + ND_ROWS * ND_CS;        // [16][132] residual stream
+  float* AG = X + ND_ROWS * ND_XS;       // [16][132] q (PRE -> edge phase)
+  float* sp = AG + ND_ROWS * ND_XS;      // [SP_SIZE] the layer's small vectors
+  float* CQ = sp + SP_SIZE;              // [16][8] <q_h, kb_h>
+  int* ctr = reinterpret_cast<int*>(CQ + 16 * 8);   // [0] row counter, [1..16] the rows in queue order (longest edge list first), [17..32] their edge counts
+  float* QA = reinterpret_cast<float*>(ctr + 36);   // [16 slots][C16_QSL] q~ / a_r
+
+  const int row0 = xcd_block(blockIdx.x, gridDim.x, !xcd) * rows;
+  const int nrows = min(rows, Nd - row0);          // rows of this workgroup that exist (> 0: the grid is ceil(Nd / rows))
+  const int W = rows < NWV ? NWV / rows : 1;       // waves per row in the edge phase (rows is a power of two)
+  {
+    const int tid0 = threadIdx.x, er0 = (tid0 >> 4) & 15, ec0 = (tid0 & 15) * 8;
+    if (tid0 < 256) {
+      float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+      if (er0 < nrows) { v0 = ldg4(x_in + (size_t)(row0 + er0) * 128 + ec0); v1 = ldg4(x_in + (size_t)(row0 + er0) * 128 + ec0 + 4); }
+      *reinterpret_cast<float4*>(X + er0 * ND_XS + ec0) = v0;
+      *reinterpret_cast<float4*>(X + er0 * ND_XS + ec0 + 4) = v1;
+    }
+  }
+  // PRE(0); then per layer EDGE(s), POST(s) + PRE(s + 1).  Every phase is a function of its own: the phases' register
+  // needs differ (the edge phase's accumulators and operands, the node phases' weight-fragment ring) and inlined into one
+  // body each pushed the other's into scratch.
+  c16_node_phase<NWV>(nullptr, steps, io, c16_smem, nullptr, row0, nrows, W, Nd, eps, prof);
+  C16_MARK(0);
+  for (int s = 0; s < nsteps; ++s) {
+    c16_edge_phase<NWV>(steps + s, io, c16_smem, AG, CQ, ctr, QA, div32, row0, nrows, W, Nd, prof);
+    __syncthreads();   // every row's sums are in place; the wave-private areas are dead
+    C16_MARK(1);
+    const bool last = s + 1 == nsteps;
+    c16_node_phase<NWV>(steps + s, last ? nullptr : steps + s + 1, io, c16_smem, last ? x : nullptr, row0, nrows, W, Nd, eps, prof);
+    C16_MARK(2);
   }
 }
 
