@@ -15,9 +15,9 @@ so this module restates the arithmetic of those formatters on plain arrays:
 * ``polylines_to_map``      -- ``local_map_to_sym_coord`` + ``get_center_vec_init_map`` (format_utils.py:184-263):
                                per-polyline frame = midpoint / tangent of (first start, last valid end), segments in
                                that frame, type one-hot, unit direction;
-* ``lanes_from_tracks``     -- NOT in the reference: the demo maps are trajdata VectorMap protobufs whose schema
-                               lives in the missing fork, so the plumbing config draws its lane polylines along
-                               the paths the agents drove.
+* ``lanes_from_tracks``     -- NOT in the reference: a stand-in that draws lane polylines along the paths the agents
+                               drove, for tables that come without a map.  The demo scenes' real lanes (trajdata VectorMap
+                               protobufs) are decoded by ``prosim_amd/vecmap.py`` and passed in as ``map_fields``.
 
 ``transform_to_frame_offset_rot`` (trajdata, absent) is restated from its name and call site: positions are
 offset and rotated into the frame, velocities / accelerations are rotated, headings are made relative --
@@ -60,10 +60,15 @@ def _rotate(x, y, ang):
 def scene_from_tracks(spec: ModelSpec, tracks: Dict[str, np.ndarray], t0: int,
                       map_polylines: Optional[Sequence[np.ndarray]] = None, agent_types: Optional[np.ndarray] = None,
                       max_agents: Optional[int] = None, points: int = 19,
-                      agents: Optional[Sequence[int]] = None) -> Dict[str, np.ndarray]:
+                      agents: Optional[Sequence[int]] = None, frame: Optional[Sequence[float]] = None,
+                      map_fields: Optional[Dict[str, np.ndarray]] = None) -> Dict[str, np.ndarray]:
     """One scene (batch 1) at current step ``t0``.  Agents whose state at ``t0`` is not finite are dropped
     (get_center_obs skips non-target agents with a NaN origin, :383-388).  ``agents``: row indices of the track
-    table to consider (default: all), ``max_agents``: keep the first so many of those that are present."""
+    table to consider (default: all), ``max_agents``: keep the first so many of those that are present.
+    ``frame`` = (x, y, heading) of the centre agent at ``t0`` (``ego_frame``): agent poses are reported in that frame, as
+    the scene-centric batch of the reference is (its obs positions are relative to the centred agent); default: the
+    table's own frame.  ``map_fields``: the map_* entries made by ``prosim_amd.vecmap`` in the SAME frame (the scene's
+    real lanes); without them (and without ``map_polylines``) lanes are drawn along the driven paths."""
     H = spec.hist_steps
     if t0 < 0 or t0 >= tracks["x"].shape[1]:
         raise ValueError("t0 outside the track table")
@@ -109,13 +114,32 @@ def scene_from_tracks(spec: ModelSpec, tracks: Dict[str, np.ndarray], t0: int,
     prompt[0, :, 2:4] = ext
     for tid in (1, 2, 3):
         prompt[0, :, 4 + tid - 1] = types == tid
-    scene = dict(obs_input=obs.astype(f32), obs_mask=mask, obs_pos=np.stack([x0[:, 0], y0[:, 0]], -1)[None].astype(f32),
-                 obs_head=h0[:, 0][None].astype(f32), prompt=prompt, prompt_mask=np.ones((1, N), bool),
+    px, py, ph = x0[:, 0], y0[:, 0], h0[:, 0]
+    if frame is not None:
+        px, py = _rotate(px - frame[0], py - frame[1], -frame[2])
+        ph = ph - frame[2]
+    scene = dict(obs_input=obs.astype(f32), obs_mask=mask, obs_pos=np.stack([px, py], -1)[None].astype(f32),
+                 obs_head=ph[None].astype(f32), prompt=prompt, prompt_mask=np.ones((1, N), bool),
                  agent_type=types[None], agent_ids=tracks["agent_ids"][sel])
+    if map_fields is not None:
+        scene.update({k: map_fields[k] for k in ("map_input", "map_mask", "map_pos", "map_head")})
+        return scene
     if map_polylines is None:
+        if frame is not None:
+            raise ValueError("lanes drawn along the tracks are in the table's frame: pass frame=None or real lanes")
         map_polylines = lanes_from_tracks(tracks, points=points)
     scene.update(polylines_to_map(spec, map_polylines, points=points))
     return scene
+
+
+def ego_frame(tracks: Dict[str, np.ndarray], t0: int, agent_id: str = "ego") -> np.ndarray:
+    """(x, y, heading) of the centre agent at ``t0`` -- the frame trajdata centres a scene batch on (the reference reads
+    it as centered_agent_from_world_tf, data_utils.py:141-142)."""
+    i = list(tracks["agent_ids"]).index(agent_id)
+    f = np.array([tracks["x"][i, t0], tracks["y"][i, t0], tracks["heading"][i, t0]], np.float64)
+    if not np.isfinite(f).all():
+        raise ValueError("the centre agent is absent at t0")
+    return f
 
 
 def polylines_to_map(spec: ModelSpec, polylines: Sequence[np.ndarray], points: int = 19, lane_type: int = 1) -> Dict[str, np.ndarray]:

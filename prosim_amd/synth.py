@@ -187,8 +187,8 @@ def make_scene(spec: ModelSpec, n_agents: int, n_polylines: int, batch: int = 1,
 
 
 # The BASELINE.json configs (index -> generator kwargs).  Config 0's real demo_dataset scene is built by
-# prosim_amd/formatting.py from the sample agent table (lanes drawn along the driven paths: the VectorMap
-# protobuf schema lives in the absent trajdata fork); this entry is its synthetic twin of the same shape; config 4 (Waymo-val dense scene, unobtainable
+# prosim_amd/formatting.py from the sample agent table and prosim_amd/vecmap.py from the cache's VectorMap protobuf
+# (tests/test_vecmap_cpu.py::demo_scene_real_lanes); this entry is its synthetic twin of the same shape; config 4 (Waymo-val dense scene, unobtainable
 # offline) is a 256-agent scene in a 100 m square.  Both substitutions are stated in DESIGN.md.
 BASELINE_CONFIGS = [
     dict(name="cfg0_16a_128p", n_agents=16, n_polylines=128, batch=1),

@@ -285,7 +285,7 @@ def gen_demo_tracks(scene: str = "scene_0"):
     cols = {c: t.column(c).to_numpy(zero_copy_only=False) for c in t.column_names}
     out = {"agent_id": np.asarray(cols["agent_id"]).astype(str), "scene_ts": np.asarray(cols["scene_ts"], np.int64),
            "origin": np.array([cols["x"][0], cols["y"][0]], np.float64)}
-    for c in ("x", "y", "vx", "vy", "ax", "ay", "heading", "length", "width"):
+    for c in ("x", "y", "z", "vx", "vy", "ax", "ay", "heading", "length", "width"):
         v = np.asarray(cols[c], np.float64)
         if c == "x":
             v = v - out["origin"][0]
@@ -294,6 +294,24 @@ def gen_demo_tracks(scene: str = "scene_0"):
         out[c] = v.astype(np.float32)
     np.savez_compressed(os.path.join(GOLD, f"demo_{scene}_agent_table.npz"), **out)
     print("demo tracks written:", scene, len(out["scene_ts"]), "rows,", len(set(out["agent_id"].tolist())), "agents")
+
+
+def gen_demo_map(scene: str = "scene_1", map_name: str = "waymo_train_1"):
+    """DATA fixtures for the real-lane plumbing config: the scene's vector map as the cache stores it (a protobuf data
+    file of the reference's sample data, copied byte for byte -- prosim_amd/vecmap.py decodes its wire format) and its
+    traffic-light table (lane_id, scene_ts, status; empty for scene_1)."""
+    import shutil
+    import pyarrow.ipc as ipc
+    root = os.path.join(os.environ.get("PROSIM_REF", "/root/reference"), "demo_dataset", "trajdata_cache", "waymo_train")
+    shutil.copyfile(os.path.join(root, "maps", map_name + ".pb"), os.path.join(GOLD, f"demo_{map_name}_map.pb"))
+    os.chmod(os.path.join(GOLD, f"demo_{map_name}_map.pb"), 0o644)
+    with open(os.path.join(root, scene, "tls_data_dt0.10.feather"), "rb") as f:
+        t = ipc.open_file(f).read_all()
+    np.savez_compressed(os.path.join(GOLD, f"demo_{scene}_tls_table.npz"),
+                        lane_id=np.asarray(t.column("lane_id").to_numpy(zero_copy_only=False)).astype(str),
+                        scene_ts=np.asarray(t.column("scene_ts").to_numpy(zero_copy_only=False), np.int64),
+                        status=np.asarray(t.column("status").to_numpy(zero_copy_only=False), np.int64))
+    print("demo map written:", map_name, os.path.getsize(os.path.join(GOLD, f"demo_{map_name}_map.pb")), "bytes; tls rows", t.num_rows)
 
 
 make_pair_metric_inputs = synth.make_pair_metric_inputs
@@ -348,6 +366,9 @@ if __name__ == "__main__":
         gen_full()
     elif len(sys.argv) > 1 and sys.argv[1] == "tracks":
         gen_demo_tracks()
+    elif len(sys.argv) > 1 and sys.argv[1] == "map":
+        gen_demo_tracks("scene_1")
+        gen_demo_map()
     elif len(sys.argv) > 1 and sys.argv[1] == "metric":
         gen_pair_metric()
     elif len(sys.argv) > 1 and sys.argv[1] == "goal":
@@ -356,5 +377,7 @@ if __name__ == "__main__":
         gen_pure()
         gen_full()
         gen_demo_tracks()
+        gen_demo_tracks("scene_1")
+        gen_demo_map()
         gen_pair_metric()
         gen_goal_heads()

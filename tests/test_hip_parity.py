@@ -414,6 +414,33 @@ def test_demo_dataset_scene_config0():
     eng.close()
 
 
+def test_demo_dataset_real_lanes_config0():
+    """BASELINE configs[0] on the scene's REAL lanes: demo scene_1 (agent table + the cache's VectorMap protobuf decoded by
+    prosim_amd/vecmap.py, chunked and framed as data_utils.py:156-255 / format_utils.py:150-263 do), centred on the ego,
+    16 agents, 20-step unconditional rollout, against the fp64 oracle."""
+    from prosim_amd.engine import Engine
+    from test_vecmap_cpu import demo_scene_real_lanes
+    spec = DEMO_SPEC.replace(max_steps=20)
+    scene = demo_scene_real_lanes(spec)
+    assert scene["map_input"].shape[1] > 300
+    w = weights.init_weights(spec, 0)
+    with torch.no_grad():
+        o64 = orc.rollout(w, spec, scene, dtype=torch.float64, collect=True)
+    eng = Engine(spec, w)
+    try:
+        eng.set_scene(scene)
+        eng.encode_scene()
+        assert err(eng.get("scene_tokens"), o64["trace"]["scene_tokens"].numpy()) < TOL
+        eng.rollout()
+        A = eng.num_agents
+        assert A == 16
+        assert err(eng.get("motion_pred")[0], o64["motion_pred"][:A].numpy()) < TOL
+        d = np.abs(eng.padded("traj") - o64["traj"].numpy())[0].reshape(A, -1).max(1)
+        assert (d < TOL).mean() >= 0.9 and d.max() < 5e-3, d
+    finally:
+        eng.close()
+
+
 def test_split_s2s_layers_on_a_ragged_batch(demo_engine):
     """>= 2048 scene tokens switch the s2s layers to the split launches (k_node + k_edge_small): a ragged 2-scene
     batch (token counts that are no multiple of the 16-row tiles, polylines with few valid points, incomplete
