@@ -34,6 +34,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from prosim_amd import synth, weights  # noqa: E402
+from prosim_amd.postprocess import replicate_scene  # noqa: E402
 from prosim_amd.spec import DEMO_SPEC  # noqa: E402
 
 D = 128
@@ -125,7 +126,7 @@ def main():
     backend = os.environ.get("PS_BENCH_BACKEND", "nccl")
     dev_index = 0 if os.environ.get("PS_BENCH_SAME_DEVICE") else local_rank
     torch.cuda.set_device(dev_index)
-    # test hook: PS_BENCH_FORCE_DIST=1 takes the N > 1 code path (process group, event-ordered RCCL gather) with ONE
+    # test hook: PS_BENCH_FORCE_DIST=1 takes the N > 1 code path (process group, RCCL gather at metric-compute time) with ONE
     # rank, so the collective path can be exercised with the real nccl backend on a 1-GPU box
     multi = world > 1 or bool(os.environ.get("PS_BENCH_FORCE_DIST"))
     if multi:
@@ -169,15 +170,15 @@ def main():
     A = eng.num_agents
     N = scene["prompt_mask"].shape[1]
     from prosim_amd.distributed import SceneMetricGather
-    # The metric gather of rollout k is enqueued behind rollout k on the GPU (event on that engine's stream -> torch's
-    # stream) and the host goes straight on to launch rollout k+1: no host-side wait inside the loop, the few-KB RCCL
-    # all-gather overlaps the next rollout.  One metric buffer per engine; an engine's stream waits for the gather that
-    # last read its buffer before the metric kernel overwrites it.
+    # Metrics follow the reference's torchmetrics flow (metrics/motion_pred.py:111-199 under Lightning): every step UPDATES
+    # the metric state on the device (ps_pair_metric: per-agent sums and counts, enqueued behind the rollout on the
+    # engine's stream), and the cross-rank exchange happens ONCE, when the metric is computed -- one RCCL all-gather of
+    # the per-scene rows at the end of the timed region, inside it.  It is enqueued on the stream of the engine that ran
+    # the last step: a cross-stream event wait behind a graph launch costs ~1 ms of pipeline on ROCm 7.2
+    # (tools/gpu_gather_cost.py: 4.11 -> 5.1 ms per step with one such wait per step, 4.11 with none).
     NM = 10                                              # floats per agent row of ps_pair_metric
     metric_bufs = [torch.zeros(A, NM, device="cuda") for _ in range(n_fl)]
     eng_streams = [torch.cuda.ExternalStream(e_.stream_handle, device=torch.device("cuda", dev_index)) for e_ in engines]
-    done = [torch.cuda.Event() for _ in range(n_fl)]    # rollout + metric of engine i finished (its stream)
-    read = [None] * n_fl                                 # gather of buffer i finished (torch stream)
     gather = SceneMetricGather(my_scenes, n_scenes, N, NM, "cuda" if backend == "nccl" else "cpu") if multi else None
     state = {"k": 0, "last": None}
     # seeded synthetic ground truth of the metric (there is no log behind synthetic scenes): per (replan, agent row) local
@@ -194,31 +195,34 @@ def main():
     def step():
         i = state["k"] % n_fl
         state["k"] += 1
-        if read[i] is not None:
-            eng_streams[i].wait_event(read[i])
         engines[i].rollout()
         engines[i].pair_metric(metric_bufs[i].data_ptr(), t_tgt.data_ptr(), t_msk.data_ptr())
-        done[i].record(eng_streams[i])
+        state["last"] = (i, None)
+
+    def compute_metrics():
+        """PairMotionPred.compute(): the per-scene rows of the last update, from every rank, in scene order."""
+        i, _ = state["last"]
         if not multi:
-            state["last"] = (i, None)
-            return
-        if backend == "nccl":
-            torch.cuda.current_stream().wait_event(done[i])
-            state["last"] = (i, gather(rows_to_slots(metric_bufs[i], slots, S, N)))
-            read[i] = torch.cuda.Event()
-            read[i].record()
+            with torch.cuda.stream(eng_streams[i]):
+                lg = rows_to_slots(metric_bufs[i], slots, S, N)
+        elif backend == "nccl":
+            with torch.cuda.stream(eng_streams[i]):
+                lg = gather(rows_to_slots(metric_bufs[i], slots, S, N))
         else:   # CPU test hook: the copy to the host is the wait
-            done[i].synchronize()
-            state["last"] = (i, gather(rows_to_slots(metric_bufs[i], slots, S, N).cpu()))
+            engines[i].sync()
+            lg = gather(rows_to_slots(metric_bufs[i], slots, S, N).cpu())
+        state["last"] = (i, lg)
 
     for _ in range(args.warmup):
         step()
+    compute_metrics()   # (warm: the first collective builds RCCL's communicator)
     if multi:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    compute_metrics()
     if multi:
         dist.barrier()
     torch.cuda.synchronize()
@@ -246,12 +250,11 @@ def main():
         e_.enable_policy_events(False)
     value = total_agents * spec.max_steps / (dt / args.steps)
     step()
+    compute_metrics()
     for e_ in engines:
         e_.sync()
     torch.cuda.synchronize()
     li, lg = state["last"]
-    if lg is None:
-        lg = rows_to_slots(metric_bufs[li], slots, S, N)
     # one PairMotionPred update per rank (its scenes are its batch, rollout/callbacks.py:76), MeanMetric over the updates
     metrics = reduce_pair_metrics(lg, batches=[shard_scenes(n_scenes, r_, world) for r_ in range(world)])
     metrics["scenes"] = int(n_scenes)
@@ -294,6 +297,35 @@ def main():
             pipe1[str(nfl1)] = A1 * spec.max_steps * 10 * nfl1 / (time.perf_counter() - t1)
             for e_ in es1:
                 e_.close()
+        # the Sim-Agents shape: ONE scene x 32 replicas, parallel_rollout_batch (rollout/gpu_utils.py:179-228).
+        # ps_set_replicas computes the scene encoder and the generator once and keeps the map once; the reference's way
+        # (the 32-fold replicated batch through the whole path) runs on the same engine beside it.
+        MREP = 32
+        eng.set_chain_rows(0)
+        eng.set_replicas(MREP)
+        eng.set_scene(parts[0])
+        ms_rep, st_rep = eng.time_rollout(1, 3)
+        A_rep = eng.num_agents
+        world_buf = torch.zeros(A_rep, spec.max_steps, 3, device="cuda")
+        tf = np.array([[0.6, -0.8, 3418.7], [0.8, 0.6, -1650.2], [0, 0, 1]], np.float32)
+        eng.world_trajs(tf, world_buf.data_ptr())
+        eng.sync()
+        t_w = time.perf_counter()
+        for _ in range(20):
+            eng.world_trajs(tf, world_buf.data_ptr())
+        eng.sync()
+        ms_world = 1e3 * (time.perf_counter() - t_w) / 20
+        eng.set_replicas(1)
+        eng.set_scene(replicate_scene(parts[0], MREP))
+        ms_tiled, st_tiled = eng.time_rollout(1, 3)
+        replica = {"workload": f"1 x BASELINE configs[{args.config}] scene x {MREP} replicas (ps_set_replicas: shared encoder + generator, one copy of the map)",
+                   "agent_rows": A_rep, "ms_per_rollout": ms_rep, "agent_steps_per_s": A_rep * spec.max_steps / (ms_rep * 1e-3),
+                   "stage_ms": {"encode_scene": st_rep[0], "generate_policy": st_rep[1], "replan_loop": st_rep[2]},
+                   "replicated_batch": {"note": "the reference's layout: every tensor .repeat(32) on the batch dim, whole path per replica",
+                                        "ms_per_rollout": ms_tiled,
+                                        "stage_ms": {"encode_scene": st_tiled[0], "generate_policy": st_tiled[1], "replan_loop": st_tiled[2]}},
+                   "speedup_vs_replicated_batch": ms_tiled / ms_rep,
+                   "world_frame_kernel_ms": ms_world}
         fl_alg = algorithmic_flops_chain(A, float(ec[4]), float(ec[5]), spec.pol_layers)
         # per-destination degrees of the last replan's edge sets -> 16-edge tiles the edge phase walked
         eng.set_chain_rows(chain_rows)
@@ -367,6 +399,7 @@ def main():
                              "policy_chain_launch_ms": ms_chain1,
                              "agent_steps_per_s_pipelined": pipe1,   # key = rollouts in flight
                              "stage_ms": {"encode_scene": stages1[0], "generate_policy": stages1[1], "replan_loop": stages1[2]}},
+            "replica_fanout": replica,
             "rollout_metrics": metrics,
         }
         if world == 1 and not args.no_cpu_baseline:

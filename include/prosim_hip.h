@@ -126,8 +126,20 @@ int ps_set_future_log(ps_engine* e, const float* fut_input, const uint8_t* fut_m
  * path (act_decoder.py:124), so the pick does not depend on the model's output: the caller draws it -- with the
  * reference's own torch.topk / torch.randint calls to replay its stream exactly -- and hands the table over before the
  * rollout: choice [R, B, N] int32 in slot layout (entries of non-policy slots are ignored), NULL = mode 0 everywhere
- * (TOP_K = 1: torch.topk of equal probabilities returns index 0).  The table survives until the next ps_set_scene. */
+ * (TOP_K = 1: torch.topk of equal probabilities returns index 0).  The table survives until the next ps_set_scene.
+ * With replicas (below) the table is [R, replicas, N]: every replica draws its own modes. */
 int ps_set_mode_choice(ps_engine* e, const int32_t* choice);
+/* M replicas of ONE scene rolled out side by side -- parallel_rollout_batch / replica_batch_for_parallel_rollout
+ * (rollout/gpu_utils.py:59-123, :179-228: scene_embs, policy_emds, prompt_encs, agent_trajs and fut_obs .repeat(M, ...) on
+ * the batch dim, then one rollout_batch over the M-batch).  Call before ps_set_scene (B must be 1 there); it holds until
+ * changed.  The replicas are identical until the first mode draw, so ps_encode_scene and ps_generate_policy compute ONE
+ * replica and fan its agent rows out on the device; the map tokens (and their k | v rows for the policy layers) exist
+ * once and are every replica's candidates.  Afterwards the engine has replicas * (agents of the scene) agent rows,
+ * replica-major: every per-agent result of ps_get / ps_pair_metric / ps_world_trajs has that many rows.  Inputs that are
+ * per scene (ps_set_prompt, ps_set_future_obs / _log, ps_set_conditions, ps_set_drag_points) stay [1, N, ...] and apply to
+ * every replica; ps_set_mode_choice is per replica.  replicas = 1 switches the mode off. */
+int ps_set_replicas(ps_engine* e, int32_t replicas);
+int32_t ps_num_replicas(ps_engine* e);
 /* Agent rows (= observed agents, the order of every per-agent result of ps_get) that are policy agents. */
 int32_t ps_num_policy_agents(ps_engine* e);
 int ps_policy_flags(ps_engine* e, int32_t* flags, int64_t capacity);
@@ -219,6 +231,14 @@ int ps_rollout_metric(ps_engine* e, const float* gt_dev, float* out_dev);
  * are sums / counts over the gathered rows and the mean of the valid agents' rollout ade
  * (prosim_amd.distributed.reduce_pair_metrics).  Enqueued on the engine's stream after the rollout. */
 int ps_pair_metric(ps_engine* e, const float* tgt_dev, const uint8_t* pair_mask_dev, const float* prob_dev, float* out_dev);
+/* obtain_rollout_trajs_in_world (rollout/gpu_utils.py:230-281): the rolled-out steps of every agent row in the world
+ * frame -- rotate the agent-init-frame xy by the initial heading and add the initial position (batch_rotate_2D,
+ * models/utils/geometry.py:19-22), heading = wrap_angle(atan2(sin, cos) + initial heading) (:13-17), then the centre ->
+ * world matrix on points and angles (batch_nd_transform_points_pt / _angles_pt, rollout/utils.py:347-392).
+ * center_to_world: HOST pointer, row-major 3 x 3 (batch.centered_world_from_agent_tf[0]) or NULL (identity);
+ * out_dev: DEVICE pointer [A, max_steps, 3] float32 (x, y, heading), or NULL to keep the result in the engine
+ * (ps_get "world_traj").  fp32 in the reference's order of operations.  Enqueued on the engine's stream. */
+int ps_world_trajs(ps_engine* e, const float* center_to_world, float* out_dev);
 int32_t ps_num_agents(ps_engine* e);
 int32_t ps_num_map_tokens(ps_engine* e);
 

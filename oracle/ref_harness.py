@@ -400,3 +400,31 @@ def load_pair_metric():
         if v is not None and k == "prosim.loss.loss_func":
             sys.modules[k] = v
     return mp.PairMotionPred, lf
+
+
+def load_world_output():
+    """The reference's own ``obtain_rollout_trajs_in_world`` and ``replica_batch_for_parallel_rollout``
+    (rollout/gpu_utils.py:59-123, :230-281) over its own rollout/utils.py transforms and models/utils/geometry.py.
+    Structural stand-ins only: the Waymo packaging helpers, trajdata's array utilities and the dataset classes those
+    files import by name carry no arithmetic on these two functions."""
+    install()
+    saved = {k: sys.modules.get(k) for k in ("prosim.dataset.format_utils", "prosim.dataset.data_utils", "prosim.models.utils.data")}
+    names = ("get_waymo_file_template", "get_waymo_scene_object", "joint_scene_from_states", "plot_waymo_gt_trajectory",
+             "rollout_states_to_joint_scene", "plot_waymo_rollout_trajectory")
+    _mod("prosim.rollout.waymo_utils", **{n: None for n in names})
+    _mod("prosim.dataset.format_utils", BatchDataDict=dict, InputMaskData=type("InputMaskData", (), {"from_dict": staticmethod(lambda d: d)}))
+    _mod("prosim.dataset.data_utils", rotate=None, transform_to_frame_offset_rot=None)
+    _mod("prosim.models.utils.data", get_agent_pos_dict=None, extract_agent_obs_from_center_obs=None)
+    sys.modules["prosim.models.utils.visualization"].vis_rollout_traj_pred = None
+    td = _mod("trajdata")
+    td.data_structures = _mod("trajdata.data_structures")
+    td.data_structures.state = _mod("trajdata.data_structures.state", StateArray=None)
+    td.utils = _mod("trajdata.utils")
+    td.utils.arr_utils = _mod("trajdata.utils.arr_utils", transform_coords_np=None, transform_angles_np=None, transform_matrices=None)
+    for k in ("prosim.rollout.utils", "prosim.rollout.gpu_utils"):
+        sys.modules.pop(k, None)
+    gu = importlib.import_module("prosim.rollout.gpu_utils")
+    for k, v in saved.items():
+        if v is not None:
+            sys.modules[k] = v
+    return gu.obtain_rollout_trajs_in_world, gu.replica_batch_for_parallel_rollout

@@ -103,6 +103,12 @@ struct ps_engine {
   // ---- scene
   bool have_scene = false, encoded = false, generated = false, reset = false;
   int B = 0, M = 0, P = 0, N = 0, Mv = 0, A = 0;
+  // ps_set_replicas: the ONE input scene is rolled out `replicas` times side by side.  A = replicas * Ap agent rows
+  // (replica-major), the Mv map tokens exist once and every replica's candidate range names them; encode_scene and
+  // generate_policy run over the first Ap rows only (the replicas are identical until the first mode draw) and fan
+  // their results out.  Without replicas Ap == A.
+  int replicas = 1, replicas_next = 1, Ap = 0;
+  std::vector<int> agent_slot;   // per agent row: its slot in the caller's per-agent arrays ([B or replicas][N])
   int maxA_scene = 0, maxM_scene = 0;
   std::vector<int> map_rows, agent_rows, agent_scene, map_scene, moff, aoff;  // host copies
   DevBuf<float> d_map_input, d_obs_input, d_prompt, d_fut;
@@ -110,7 +116,7 @@ struct ps_engine {
   DevBuf<int> d_map_rows, d_agent_rows, d_tok_scene, d_agent_type, d_r_map, d_r_agent, d_r_zero;
   DevBuf<float> d_tok, d_tok_pos, d_tok_ori, d_init_pos, d_init_head, d_cur_pos, d_cur_ori, d_prompt_pos, d_prompt_ori;
   DevBuf<float> d_xp, d_emd, d_xc, d_fused, d_obs_in, d_static_in, d_kv, d_kv_s2p, d_kv_m2p, d_kv_a2p;
-  DevBuf<float> d_traj, d_vel, d_motion, d_reconst, d_goal_prob, d_goal_point;
+  DevBuf<float> d_traj, d_vel, d_motion, d_reconst, d_goal_prob, d_goal_point, d_world;
   DevBuf<int> d_choice;                     // [R][A] motion mode each agent follows at each replan (ps_set_mode_choice; zeros = mode 0)
   DevBuf<_Float16> d_kh, d_kh_s2p, d_kh_m2p, d_kh_a2p;   // split-fp16 k rows beside each kv buffer
   EdgeSet e_a2a, e_s2s, e_p2p, e_s2p, e_a2p, e_m2p, e_cnd;
@@ -658,7 +664,7 @@ extern "C" void ps_destroy(ps_engine* e) {
   e->d_cur_pos.release(); e->d_cur_ori.release(); e->d_prompt_pos.release(); e->d_prompt_ori.release();
   e->d_xp.release(); e->d_emd.release(); e->d_xc.release(); e->d_fused.release(); e->d_obs_in.release();
   e->d_static_in.release(); e->d_kv.release(); e->d_kv_s2p.release(); e->d_kv_m2p.release(); e->d_kv_a2p.release();
-  e->d_traj.release(); e->d_vel.release(); e->d_motion.release(); e->d_reconst.release(); e->d_choice.release();
+  e->d_traj.release(); e->d_vel.release(); e->d_motion.release(); e->d_reconst.release(); e->d_choice.release(); e->d_world.release();
   e->d_kh.release(); e->d_kh_s2p.release(); e->d_kh_m2p.release(); e->d_kh_a2p.release();
   for (EdgeSet* s : {&e->e_a2a, &e->e_s2s, &e->e_p2p, &e->e_s2p, &e->e_a2p, &e->e_m2p, &e->e_cnd, &e->e_ua, &e->e_um}) {
     s->cnt.release(); s->eoff.release(); s->esrc.release(); s->edst.release(); s->toff.release(); s->tdst.release(); s->rtA.release(); s->rtT.release(); s->geo.release();
@@ -723,6 +729,9 @@ extern "C" int ps_set_scene(ps_engine* e, int32_t B, int32_t M, int32_t P, int32
     explicit DeclaredGuard(std::vector<uint8_t>& r) : rows(r), ref(r) { ref.clear(); }
   } declared_guard(e->declared_rows);
   const std::vector<uint8_t>& declared_rows = declared_guard.rows;
+  e->replicas = e->replicas_next;
+  if (e->replicas > 1 && B != 1) return fail(PS_E_ARG, "ps_set_replicas: the replicated batch holds ONE scene");
+  const int Bi = e->replicas > 1 ? e->replicas : B;   // scenes the kernels see
   e->B = B; e->M = M; e->P = P; e->N = N;
   e->map_rows.clear(); e->agent_rows.clear(); e->agent_scene.clear(); e->map_scene.clear();
   e->is_policy_h.clear();
@@ -764,10 +773,33 @@ extern "C" int ps_set_scene(ps_engine* e, int32_t B, int32_t M, int32_t P, int32
     e->maxA_scene = std::max(e->maxA_scene, e->aoff[b + 1] - e->aoff[b]);
     e->maxM_scene = std::max(e->maxM_scene, e->moff[b + 1] - e->moff[b]);
   }
+  // begin / end of every scene's map tokens and agent rows
+  std::vector<int> mbeg(Bi), mend(Bi);
+  if (e->replicas > 1) {   // replica r: the same input slots again, its own agent rows, the shared map tokens
+    const int A1 = (int)e->agent_rows.size();
+    for (int r = 1; r < e->replicas; ++r)
+      for (int i = 0; i < A1; ++i) {
+        e->agent_rows.push_back(e->agent_rows[i]);
+        e->agent_scene.push_back(r);
+        e->live0_h.push_back(e->live0_h[i]);
+        e->is_policy_h.push_back(e->is_policy_h[i]);
+      }
+    e->aoff.assign(Bi + 1, 0);
+    for (int r = 0; r <= Bi; ++r) e->aoff[r] = r * A1;
+    for (int r = 0; r < Bi; ++r) { mbeg[r] = 0; mend[r] = (int)e->map_rows.size(); }
+    e->Ap = A1;
+  } else {
+    for (int b = 0; b < B; ++b) { mbeg[b] = e->moff[b]; mend[b] = e->moff[b + 1]; }
+    e->Ap = (int)e->agent_rows.size();
+  }
+  e->agent_slot.resize(e->agent_rows.size());
+  for (size_t i = 0; i < e->agent_rows.size(); ++i)
+    e->agent_slot[i] = e->replicas > 1 ? e->agent_scene[i] * N + e->agent_rows[i] : e->agent_rows[i];
   if (e->maxA_scene + e->maxM_scene > 64 * KNN_SLOTS)
     return fail(PS_E_ARG, "more than 2560 tokens in one scene (knn candidate registers)");
   const int Mv = e->Mv = (int)e->map_rows.size();
   const int A = e->A = (int)e->agent_rows.size();
+  const int Ap = e->Ap;
   if (A == 0) return fail(PS_E_ARG, "no valid agents");
   e->have_dead0 = false;
   for (int v : e->live0_h) e->have_dead0 |= v == 0;
@@ -803,8 +835,11 @@ extern "C" int ps_set_scene(ps_engine* e, int32_t B, int32_t M, int32_t P, int32
     scene[Mv + i] = e->agent_scene[i];
     atype[i] = agent_type[r];
   }
-  std::vector<int> r_map(B + 1), r_agent(B + 1), r_zero(B + 1, 0);
-  for (int b = 0; b <= B; ++b) { r_map[b] = e->moff[b]; r_agent[b] = Mv + e->aoff[b]; }
+  std::vector<int> r_map(2 * Bi), r_agent(2 * Bi), r_zero(2 * Bi, 0);
+  for (int b = 0; b < Bi; ++b) {
+    r_map[2 * b] = mbeg[b]; r_map[2 * b + 1] = mend[b];
+    r_agent[2 * b] = Mv + e->aoff[b]; r_agent[2 * b + 1] = Mv + e->aoff[b + 1];
+  }
   if (upload(e->d_tok_pos, pos.data(), pos.size(), st) || upload(e->d_tok_ori, ori.data(), ori.size(), st) ||
       upload(e->d_init_pos, ipos.data(), ipos.size(), st) || upload(e->d_init_head, ihead.data(), ihead.size(), st) ||
       upload(e->d_prompt_pos, ppos.data(), ppos.size(), st) || upload(e->d_prompt_ori, pori.data(), pori.size(), st) ||
@@ -864,8 +899,9 @@ extern "C" int ps_set_scene(ps_engine* e, int32_t B, int32_t M, int32_t P, int32
         e->d_kv_um.ensure((size_t)c.scene_layers * std::max(Mv, 1) * 256) || e->d_kh_um.ensure((size_t)c.scene_layers * std::max(Mv, 1) * 256))
       return fail(PS_E_HIP, "edge allocation failed");
   }
-  if (edge_alloc(e->e_a2a, A, (size_t)A * d_a2a, d_a2a) || edge_alloc(e->e_s2s, Mv + A, (size_t)(Mv + A) * d_s2s, d_s2s) ||
-      edge_alloc(e->e_p2p, A, (size_t)A * d_p2p, d_p2p) || edge_alloc(e->e_s2p, A, (size_t)A * d_s2p, d_s2p) ||
+  // (the scene encoder's and the generator's sets have Ap destination rows: with replicas they run once)
+  if (edge_alloc(e->e_a2a, Ap, (size_t)Ap * d_a2a, d_a2a) || edge_alloc(e->e_s2s, Mv + Ap, (size_t)(Mv + Ap) * d_s2s, d_s2s) ||
+      edge_alloc(e->e_p2p, Ap, (size_t)Ap * d_p2p, d_p2p) || edge_alloc(e->e_s2p, Ap, (size_t)Ap * d_s2p, d_s2p) ||
       edge_alloc(e->e_a2p, A, (size_t)A * d_a2p, d_a2p) || edge_alloc(e->e_m2p, A, (size_t)A * d_m2p, d_m2p) ||
       edge_alloc(e->e_cnd, A, (size_t)A, 1))
     return fail(PS_E_HIP, "edge allocation failed");
@@ -875,11 +911,11 @@ extern "C" int ps_set_scene(ps_engine* e, int32_t B, int32_t M, int32_t P, int32
   }
   // closed-form CSR offsets of the knn graphs (every query gets min(k, scene size) neighbours)
   {
-    std::vector<int> nlive(B, 0);   // agents in the scene at the initial step (the kNN candidates)
+    std::vector<int> nlive(Bi, 0);   // agents in the scene at the initial step (the kNN candidates)
     for (int i = 0; i < A; ++i) nlive[e->agent_scene[i]] += e->live0_h[i];
-    off.assign(A + 1, 0);
-    tof.assign(A + 1, 0);
-    for (int i = 0; i < A; ++i) {
+    off.assign(Ap + 1, 0);
+    tof.assign(Ap + 1, 0);
+    for (int i = 0; i < Ap; ++i) {
       const int b = e->agent_scene[i];
       const int dg = mn(c.agent_knn, nlive[b]);
       off[i + 1] = off[i] + dg;
@@ -889,12 +925,12 @@ extern "C" int ps_set_scene(ps_engine* e, int32_t B, int32_t M, int32_t P, int32
     if (upload(e->e_a2a.eoff, off.data(), off.size(), st) || upload(e->e_a2a.toff, tof.data(), tof.size(), st) ||
         upload(e->e_a2a.tdst, tds.data(), tds.size(), st))
       return fail(PS_E_HIP, "upload failed");
-    e->edge_counts[0] = (float)off[A];
-    off2.assign(Mv + A + 1, 0);
-    tof2.assign(Mv + A + 1, 0);
-    for (int i = 0; i < Mv + A; ++i) {
+    e->edge_counts[0] = (float)off[Ap];
+    off2.assign(Mv + Ap + 1, 0);
+    tof2.assign(Mv + Ap + 1, 0);
+    for (int i = 0; i < Mv + Ap; ++i) {
       const int b = scene[i];
-      const int ns = nlive[b] + (e->moff[b + 1] - e->moff[b]);
+      const int ns = nlive[b] + (mend[b] - mbeg[b]);
       const int dg = mn(c.scene_knn, ns);
       off2[i + 1] = off2[i] + dg;
       tof2[i + 1] = tof2[i] + (dg + 31) / 32;
@@ -903,7 +939,7 @@ extern "C" int ps_set_scene(ps_engine* e, int32_t B, int32_t M, int32_t P, int32
     if (upload(e->e_s2s.eoff, off2.data(), off2.size(), st) || upload(e->e_s2s.toff, tof2.data(), tof2.size(), st) ||
         upload(e->e_s2s.tdst, tds2.data(), tds2.size(), st))
       return fail(PS_E_HIP, "upload failed");
-    e->edge_counts[1] = (float)off2[Mv + A];
+    e->edge_counts[1] = (float)off2[Mv + Ap];
   }
   // ---- chain step tables (device pointers are stable until the next ps_set_scene)
   e->h_steps.clear();
@@ -928,7 +964,7 @@ extern "C" int ps_set_scene(ps_engine* e, int32_t B, int32_t M, int32_t P, int32
   e->step_dec = (int)e->h_steps.size();
   for (int i = 0; i < c.dec_layers; ++i) {
     push(e->p2p[i], e->d_kv.p, e->d_kh.p, e->e_p2p);
-    push(e->s2p[i], e->d_kv_s2p.p + (size_t)i * (Mv + A) * 256, e->d_kh_s2p.p + (size_t)i * (Mv + A) * 256, e->e_s2p);
+    push(e->s2p[i], e->d_kv_s2p.p + (size_t)i * (Mv + Ap) * 256, e->d_kh_s2p.p + (size_t)i * (Mv + Ap) * 256, e->e_s2p);
   }
   e->step_cnd = (int)e->h_steps.size();
   for (int i = 0; i < c.cond_layers; ++i) push(e->cnd[i], e->d_kv.p, e->d_kh.p, e->e_cnd);
@@ -996,7 +1032,7 @@ extern "C" int ps_set_prompt(ps_engine* e, const float* prompt, const float* pro
 // Device CSR of the condition entries: per conditioned agent (one self-loop edge each) the list of its entries
 // (type, id, 3 floats) in the reference's pooling order goal, tags, drag points (PROMPT.CONDITION.TYPES).
 static int rebuild_conditions(ps_engine* e) {
-  const int A = e->A;
+  const int A = e->Ap;   // (with replicas the condition layers run once, over the first replica's rows)
   std::vector<std::vector<const ps_engine::CondEnt*>> per(A);
   for (const auto& en : e->ents_gt) per[en.agent].push_back(&en);
   for (const auto& en : e->ents_drag) per[en.agent].push_back(&en);
@@ -1047,7 +1083,7 @@ extern "C" int ps_set_conditions(ps_engine* e, int32_t C_goal, const float* goal
   e->cond_present_gt = present;
   // slot -> compact agent index
   std::vector<int> slot2a((size_t)e->B * N, -1);
-  for (int i = 0; i < A; ++i) slot2a[e->agent_rows[i]] = i;
+  for (int i = 0; i < e->Ap; ++i) slot2a[e->agent_rows[i]] = i;
   for (int b = 0; b < e->B; ++b) {
     for (int c = 0; c < C_goal && goal_input; ++c) {
       const size_t i = (size_t)b * C_goal + c;
@@ -1085,7 +1121,7 @@ extern "C" int ps_set_drag_points(ps_engine* e, int32_t C_drag, int32_t T, const
   if (!drag_mask || !drag_pidx) return fail(PS_E_ARG, "drag_mask / drag_pidx missing");
   const int A = e->A, N = e->N;
   std::vector<int> slot2a((size_t)e->B * N, -1);
-  for (int i = 0; i < A; ++i) slot2a[e->agent_rows[i]] = i;
+  for (int i = 0; i < e->Ap; ++i) slot2a[e->agent_rows[i]] = i;
   std::vector<ps_engine::CondEnt> ents;
   std::vector<float> pts;
   std::vector<uint8_t> pm;
@@ -1167,6 +1203,18 @@ extern "C" int ps_set_future_log(ps_engine* e, const float* fut_input, const uin
   return PS_OK;
 }
 
+extern "C" int ps_set_replicas(ps_engine* e, int32_t replicas) {
+  if (!e) return fail(PS_E_ARG, "null engine");
+  if (replicas < 1) return fail(PS_E_ARG, "ps_set_replicas: need replicas >= 1");
+  if (replicas != e->replicas_next) {   // takes effect with the next ps_set_scene; the current scene is gone
+    e->replicas_next = replicas;
+    e->have_scene = e->encoded = e->generated = e->reset = false;
+    drop_graph(e);
+  }
+  return PS_OK;
+}
+extern "C" int32_t ps_num_replicas(ps_engine* e) { return e ? e->replicas : 0; }
+
 extern "C" int ps_set_mode_choice(ps_engine* e, const int32_t* choice) {
   if (!e || !e->have_scene) return fail(PS_E_STATE, "ps_set_mode_choice before ps_set_scene");
   HIPCHK(hipSetDevice(e->cfg.device));
@@ -1176,7 +1224,7 @@ extern "C" int ps_set_mode_choice(ps_engine* e, const int32_t* choice) {
   if (choice)
     for (int r = 0; r < R; ++r)
       for (int i = 0; i < A; ++i) {
-        const int k = choice[(size_t)r * e->B * e->N + e->agent_rows[i]];
+        const int k = choice[(size_t)r * std::max(e->B, e->replicas) * e->N + e->agent_slot[i]];   // [R][B or replicas][N]
         if (e->is_policy_h[i] && (k < 0 || k >= c.motion_k)) return fail(PS_E_ARG, "ps_set_mode_choice: mode index outside 0..motion_k-1");
         rows[(size_t)r * A + i] = e->is_policy_h[i] ? k : 0;
       }
@@ -1487,29 +1535,30 @@ extern "C" int ps_encode_scene(ps_engine* e) {
   HIPCHK(hipSetDevice(e->cfg.device));
   const ps_config& c = e->cfg;
   const int Mv = e->Mv, A = e->A;
+  const int Ap = e->Ap;   // rows the encoder computes (== A without replicas; the replicas' rows are copies, made at the end)
   hipStream_t st = e->stream;
   float* tok = e->d_tok.p;
   // agent token geometry back to the init poses (a previous rollout moved them)
   HIPCHK(hipMemcpyAsync(e->d_tok_pos.p + 2 * (size_t)Mv, e->d_init_pos.p, sizeof(float) * 2 * A, hipMemcpyDeviceToDevice, st));
   HIPCHK(hipMemcpyAsync(e->d_tok_ori.p + Mv, e->d_init_head.p, sizeof(float) * A, hipMemcpyDeviceToDevice, st));
   launch_pointnet(e, e->pn_map, e->d_map_input.p, e->d_map_mask.p, e->d_map_rows.p, Mv, e->P, 0, tok);
-  launch_pointnet(e, e->pn_obs, e->d_obs_input.p, e->d_obs_mask.p, e->d_agent_rows.p, A, c.hist_steps, c.obs_dim, tok + (size_t)Mv * D);
+  launch_pointnet(e, e->pn_obs, e->d_obs_input.p, e->d_obs_mask.p, e->d_agent_rows.p, Ap, c.hist_steps, c.obs_dim, tok + (size_t)Mv * D);
   // knn graphs (attn_fusion.py:107-109) + rel-PE (:111-112).  Agent rows that only enter the scene with a later fut_obs
   // frame are no tokens yet: not a candidate of any query (their own rows are computed and ignored).
   const int* live0 = e->have_dead0 ? (const int*)e->d_live0.p : nullptr;
   {
     CandSet ca{e->d_tok_pos.p, e->d_r_agent.p, nullptr};
-    hipLaunchKernelGGL(k_knn, dim3((A + 3) / 4), dim3(256), 0, st, ca, (const float*)(e->d_tok_pos.p + 2 * (size_t)Mv),
-                       (const int*)(e->d_tok_scene.p + Mv), A, c.agent_knn, (const int*)e->e_a2a.eoff.p, e->e_a2a.esrc.p, e->e_a2a.edst.p,
+    hipLaunchKernelGGL(k_knn, dim3((Ap + 3) / 4), dim3(256), 0, st, ca, (const float*)(e->d_tok_pos.p + 2 * (size_t)Mv),
+                       (const int*)(e->d_tok_scene.p + Mv), Ap, c.agent_knn, (const int*)e->e_a2a.eoff.p, e->e_a2a.esrc.p, e->e_a2a.edst.p,
                        live0, Mv);
     CandSet csn{e->d_tok_pos.p, e->d_r_map.p, e->d_r_agent.p};
-    hipLaunchKernelGGL(k_knn, dim3((Mv + A + 3) / 4), dim3(256), 0, st, csn, (const float*)e->d_tok_pos.p,
-                       (const int*)e->d_tok_scene.p, Mv + A, c.scene_knn, (const int*)e->e_s2s.eoff.p, e->e_s2s.esrc.p, e->e_s2s.edst.p,
+    hipLaunchKernelGGL(k_knn, dim3((Mv + Ap + 3) / 4), dim3(256), 0, st, csn, (const float*)e->d_tok_pos.p,
+                       (const int*)e->d_tok_scene.p, Mv + Ap, c.scene_knn, (const int*)e->e_s2s.eoff.p, e->e_s2s.esrc.p, e->e_s2s.edst.p,
                        live0, Mv);
     // a2a edges index agents globally (Mv + i) for positions; kv rows are agent-local -> fixed up below
     const PeArgs pe[2] = {{&e->e_a2a, e->d_tok_ori.p, e->d_tok_pos.p + 2 * (size_t)Mv, e->d_tok_ori.p + Mv},
                           {&e->e_s2s, e->d_tok_ori.p, e->d_tok_pos.p, e->d_tok_ori.p}};
-    if (use_c16(e, A)) {   // the a2a layers run on k_chain16 (geometry records), the s2s layers keep the operand images
+    if (use_c16(e, Ap)) {   // the a2a layers run on k_chain16 (geometry records), the s2s layers keep the operand images
       launch_geo(e, &pe[0], 1);
       launch_relpe(e, &pe[1], 1);
     } else {
@@ -1519,24 +1568,26 @@ extern "C" int ps_encode_scene(ps_engine* e) {
   // 6 x (a2a on the agent rows in place, s2s on all rows)  (attn_fusion.py:117-119).  kv is indexed by
   // GLOBAL token row for both (the a2a projection fills rows Mv.. of the shared kv buffer).
   static const bool no_split = getenv("PS_NO_SPLIT") != nullptr;   // experiments only
-  const bool split_s2s = !no_split && Mv + A >= 2048 && e->e_s2s.maxdeg <= ES_MAXDEG;
+  const bool split_s2s = !no_split && Mv + Ap >= 2048 && e->e_s2s.maxdeg <= ES_MAXDEG;
   for (int i = 0; i < c.scene_layers; ++i) {
-    launch_kv(e, tok + (size_t)Mv * D, A, e->L_a2a + i, 1, e->d_kv.p + (size_t)Mv * 256, e->d_kh.p + (size_t)Mv * 256, 0);
-    if (use_c16(e, A)) {
-      if (launch_chain16(e, tok + (size_t)Mv * D, A, e->d_steps.p + e->step_a2a + i, 1, false, nullptr, false)) return PS_E_HIP;
-    } else if (launch_chain(e, tok + (size_t)Mv * D, A, e->step_a2a + i, 1, e->e_a2a.maxdeg, false, nullptr, 0, 0, nullptr, xcd_on(1, false))) return PS_E_HIP;
+    launch_kv(e, tok + (size_t)Mv * D, Ap, e->L_a2a + i, 1, e->d_kv.p + (size_t)Mv * 256, e->d_kh.p + (size_t)Mv * 256, 0);
+    if (use_c16(e, Ap)) {
+      if (launch_chain16(e, tok + (size_t)Mv * D, Ap, e->d_steps.p + e->step_a2a + i, 1, false, nullptr, false)) return PS_E_HIP;
+    } else if (launch_chain(e, tok + (size_t)Mv * D, Ap, e->step_a2a + i, 1, e->e_a2a.maxdeg, false, nullptr, 0, 0, nullptr, xcd_on(1, false))) return PS_E_HIP;
     if (split_s2s) {
       // split layer: node work as 16-row MFMA GEMMs (k_node; its PRE half also makes the rows'
       // k | v, they are this self-attention layer's sources), the 32-neighbour edge phase one wave per token
       const ChainStep* stp = e->d_steps.p + e->step_s2s + i;
-      if (launch_split_layer(e, tok, Mv + A, stp, 3, e->e_s2s.maxdeg, e->d_kv.p, e->d_kh.p)) return PS_E_HIP;
+      if (launch_split_layer(e, tok, Mv + Ap, stp, 3, e->e_s2s.maxdeg, e->d_kv.p, e->d_kh.p)) return PS_E_HIP;
     } else {
-      launch_kv(e, tok, Mv + A, e->L_s2s + i, 1, e->d_kv.p, e->d_kh.p, 0);
-      if (launch_chain(e, tok, Mv + A, e->step_s2s + i, 1, e->e_s2s.maxdeg)) return PS_E_HIP;
+      launch_kv(e, tok, Mv + Ap, e->L_s2s + i, 1, e->d_kv.p, e->d_kh.p, 0);
+      if (launch_chain(e, tok, Mv + Ap, e->step_s2s + i, 1, e->e_s2s.maxdeg)) return PS_E_HIP;
     }
   }
   if (live0)   // rows outside the scene keep a zero token (what FUSION 'mlp' takes as the previous token when they enter)
-    hipLaunchKernelGGL(k_zero_dead_rows, dim3((A * D + 255) / 256), dim3(256), 0, st, tok + (size_t)Mv * D, live0, A);
+    hipLaunchKernelGGL(k_zero_dead_rows, dim3((Ap * D + 255) / 256), dim3(256), 0, st, tok + (size_t)Mv * D, live0, Ap);
+  if (e->replicas > 1)   // replica_batch_for_parallel_rollout (rollout/gpu_utils.py:59-123): every replica starts from the same tokens
+    hipLaunchKernelGGL(k_fan_out_rows, dim3(std::min(2048, (A - Ap) * (D / 4) / 256 + 1)), dim3(256), 0, st, tok + (size_t)Mv * D, Ap, A, D);
   HIPCHK(hipGetLastError());
   e->encoded = true;
   e->generated = false;
@@ -1548,9 +1599,10 @@ extern "C" int ps_generate_policy(ps_engine* e) {
   HIPCHK(hipSetDevice(e->cfg.device));
   const ps_config& c = e->cfg;
   const int Mv = e->Mv, A = e->A;
+  const int Ap = e->Ap;   // rows the generator computes (== A without replicas)
   hipStream_t st = e->stream;
   // prompt encoder (prompt_encoder/base.py:36-46)
-  hipLaunchKernelGGL(k_mlp_rows, dim3(A), dim3(128), 0, st, e->mlp_prompt, (const float*)e->d_prompt.p, (const int*)e->d_agent_rows.p,
+  hipLaunchKernelGGL(k_mlp_rows, dim3(Ap), dim3(128), 0, st, e->mlp_prompt, (const float*)e->d_prompt.p, (const int*)e->d_agent_rows.p,
                      c.prompt_dim, e->d_xp.p, D, c.ln_eps);
   // prompt poses (== the observed poses in the reference's batches; kept separate for generality)
   const float* ppos = e->d_prompt_pos.p;
@@ -1561,29 +1613,29 @@ extern "C" int ps_generate_policy(ps_engine* e) {
   HIPCHK(hipMemcpyAsync(e->d_tok_pos.p + 2 * (size_t)Mv, ppos, sizeof(float) * 2 * A, hipMemcpyDeviceToDevice, st));
   HIPCHK(hipMemcpyAsync(e->d_tok_ori.p + Mv, pori, sizeof(float) * A, hipMemcpyDeviceToDevice, st));
   // (with log-replay agents in the scene only the policy agents are prompts: candidate filter)
-  const int pe_gen = use_c16(e, A) ? 2 : 1;   // k_chain16 rebuilds the rel-PE rows from geometry records, k_attn_chain streams operand images
-  launch_radius(e, e->e_p2p, e->d_r_agent.p, nullptr, ppos, pscene, A, c.dec_prompt_radius, c.dec_max_neigh, Mv, e->d_tok_ori.p, pori,
+  const int pe_gen = use_c16(e, Ap) ? 2 : 1;   // k_chain16 rebuilds the rel-PE rows from geometry records, k_attn_chain streams operand images
+  launch_radius(e, e->e_p2p, e->d_r_agent.p, nullptr, ppos, pscene, Ap, c.dec_prompt_radius, c.dec_max_neigh, Mv, e->d_tok_ori.p, pori,
                 e->all_policy ? nullptr : (const int*)e->d_is_policy.p, Mv, pe_gen);
   // restore observed agent poses for the scene tokens, then s2p: radius over all scene tokens (:94)
   HIPCHK(hipMemcpyAsync(e->d_tok_pos.p + 2 * (size_t)Mv, e->d_init_pos.p, sizeof(float) * 2 * A, hipMemcpyDeviceToDevice, st));
   HIPCHK(hipMemcpyAsync(e->d_tok_ori.p + Mv, e->d_init_head.p, sizeof(float) * A, hipMemcpyDeviceToDevice, st));
-  launch_radius(e, e->e_s2p, e->d_r_map.p, e->d_r_agent.p, ppos, pscene, A, c.dec_scene_radius, c.dec_max_neigh, -1,
+  launch_radius(e, e->e_s2p, e->d_r_map.p, e->d_r_agent.p, ppos, pscene, Ap, c.dec_scene_radius, c.dec_max_neigh, -1,
                 e->d_tok_ori.p, pori, e->have_dead0 ? (const int*)e->d_live0.p : nullptr, Mv, pe_gen);
   // k|v of the (fixed) scene tokens for all s2p layers in one launch
-  launch_kv(e, e->d_tok.p, Mv + A, e->L_s2p, c.dec_layers, e->d_kv_s2p.p, e->d_kh_s2p.p, (size_t)(Mv + A) * 256);
+  launch_kv(e, e->d_tok.p, Mv + Ap, e->L_s2p, c.dec_layers, e->d_kv_s2p.p, e->d_kh_s2p.p, (size_t)(Mv + Ap) * 256);
   const int md = std::max(e->e_p2p.maxdeg, e->e_s2p.maxdeg);
   for (int i = 0; i < c.dec_layers; ++i) {
     // p2p edges carry GLOBAL agent rows (Mv + j): project into rows Mv.. of the shared kv buffer
-    launch_kv(e, e->d_xp.p, A, e->L_p2p + i, 1, e->d_kv.p + (size_t)Mv * 256, e->d_kh.p + (size_t)Mv * 256, 0);
-    if (use_c16(e, A)) {
-      if (launch_chain16(e, e->d_xp.p, A, e->d_steps.p + e->step_dec + 2 * i, 2, false, nullptr, false)) return PS_E_HIP;
-    } else if (launch_chain(e, e->d_xp.p, A, e->step_dec + 2 * i, 2, md, false, nullptr, 0, 0, nullptr, xcd_on(2, false))) return PS_E_HIP;
+    launch_kv(e, e->d_xp.p, Ap, e->L_p2p + i, 1, e->d_kv.p + (size_t)Mv * 256, e->d_kh.p + (size_t)Mv * 256, 0);
+    if (use_c16(e, Ap)) {
+      if (launch_chain16(e, e->d_xp.p, Ap, e->d_steps.p + e->step_dec + 2 * i, 2, false, nullptr, false)) return PS_E_HIP;
+    } else if (launch_chain(e, e->d_xp.p, Ap, e->step_dec + 2 * i, 2, md, false, nullptr, 0, 0, nullptr, xcd_on(2, false))) return PS_E_HIP;
   }
-  HIPCHK(hipMemcpyAsync(e->d_emd.p, e->d_xp.p, sizeof(float) * (size_t)A * D, hipMemcpyDeviceToDevice, st));
+  HIPCHK(hipMemcpyAsync(e->d_emd.p, e->d_xp.p, sizeof(float) * (size_t)Ap * D, hipMemcpyDeviceToDevice, st));
   if (c.goal_pred_k > 0) {   // Decoder._goal_pred on the decoder's embedding (decoder/base.py:22-58, sym_coord.py:133-136)
-    hipLaunchKernelGGL(k_mlp_rows, dim3(A), dim3(128), 0, st, e->mlp_goal_prob, (const float*)e->d_xp.p, (const int*)nullptr, D,
+    hipLaunchKernelGGL(k_mlp_rows, dim3(Ap), dim3(128), 0, st, e->mlp_goal_prob, (const float*)e->d_xp.p, (const int*)nullptr, D,
                        e->d_goal_prob.p, c.goal_pred_k, c.ln_eps);
-    hipLaunchKernelGGL(k_mlp_rows, dim3(A), dim3(128), 0, st, e->mlp_goal_point, (const float*)e->d_xp.p, (const int*)nullptr, D,
+    hipLaunchKernelGGL(k_mlp_rows, dim3(Ap), dim3(128), 0, st, e->mlp_goal_point, (const float*)e->d_xp.p, (const int*)nullptr, D,
                        e->d_goal_point.p, 2 * c.goal_pred_k, c.ln_eps);
   }
   // condition transformer at 'policy_decoder' (traj_sam.py:129-137)
@@ -1594,16 +1646,24 @@ extern "C" int ps_generate_policy(ps_engine* e) {
     hipLaunchKernelGGL(k_cond_edges, dim3(e->n_cond_edges), dim3(128), 0, st, e->cond, (const int*)e->d_ent_off.p,
                        (const int*)e->d_ent_type.p, (const float*)e->d_ent_val.p, (const float*)e->d_drag_emd.p, e->n_cond_edges,
                        e->e_cnd.rtA.p, e->e_cnd.rtT.p, c.ln_eps);
-    HIPCHK(hipMemcpyAsync(e->d_xc.p, e->d_emd.p, sizeof(float) * (size_t)A * D, hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipMemcpyAsync(e->d_xc.p, e->d_emd.p, sizeof(float) * (size_t)Ap * D, hipMemcpyDeviceToDevice, st));
     for (int i = 0; i < c.cond_layers; ++i) {
-      launch_kv(e, e->d_xc.p, A, e->L_cnd + i, 1, e->d_kv.p, e->d_kh.p, 0);
-      if (launch_chain(e, e->d_xc.p, A, e->step_cnd + i, 1, 1)) return PS_E_HIP;
+      launch_kv(e, e->d_xc.p, Ap, e->L_cnd + i, 1, e->d_kv.p, e->d_kh.p, 0);
+      if (launch_chain(e, e->d_xc.p, Ap, e->step_cnd + i, 1, 1)) return PS_E_HIP;
     }
-    hipLaunchKernelGGL(k_add_rows, dim3((A * D + 255) / 256), dim3(256), 0, st, e->d_emd.p, (const float*)e->d_xc.p, A * D);
+    hipLaunchKernelGGL(k_add_rows, dim3((Ap * D + 255) / 256), dim3(256), 0, st, e->d_emd.p, (const float*)e->d_xc.p, Ap * D);
   }
   // reconst_pred = pred_mlp(policy_emd) (act_decoder.py:133-135) -- constant over the replans
-  hipLaunchKernelGGL(k_mlp_rows, dim3(A), dim3(128), 0, st, e->mlp_pred, (const float*)e->d_emd.p, (const int*)nullptr, D,
+  hipLaunchKernelGGL(k_mlp_rows, dim3(Ap), dim3(128), 0, st, e->mlp_pred, (const float*)e->d_emd.p, (const int*)nullptr, D,
                      e->d_reconst.p, 2, c.ln_eps);
+  if (e->replicas > 1) {   // the replicas share the prompts' embeddings (gpu_utils.py:73-82): fan the Ap computed rows out
+    auto fan = [&](float* p, int w) {
+      hipLaunchKernelGGL(k_fan_out_rows, dim3(std::min(2048, (A - Ap) * std::max(w / 4, 1) / 256 + 1)), dim3(256), 0, st, p, Ap, A, w);
+    };
+    fan(e->d_emd.p, D);
+    fan(e->d_reconst.p, 2);
+    if (c.goal_pred_k > 0) { fan(e->d_goal_prob.p, c.goal_pred_k); fan(e->d_goal_point.p, 2 * c.goal_pred_k); }
+  }
   // k|v of the map tokens for all m2p layers: map tokens never change during the rollout
   launch_kv(e, e->d_tok.p, Mv, e->L_m2p, c.pol_layers, e->d_kv_m2p.p, e->d_kh_m2p.p, (size_t)Mv * 256);
   if (c.obs_attn_update)   // ... and for the s2s layers that the per-replan observation update re-runs (map -> agents)
@@ -1908,6 +1968,26 @@ extern "C" int ps_pair_metric(ps_engine* e, const float* tgt_dev, const uint8_t*
   return PS_OK;
 }
 
+// obtain_rollout_trajs_in_world (rollout/gpu_utils.py:230-281) on the device: [A][T][3] world-frame (x, y, heading) of the
+// rolled-out steps.  center_to_world: host, row-major 3 x 3 (batch.centered_world_from_agent_tf[0]); NULL = identity.
+// out_dev NULL: the result stays in the engine (ps_get "world_traj").
+extern "C" int ps_world_trajs(ps_engine* e, const float* center_to_world, float* out_dev) {
+  if (!e || !e->have_scene || !e->reset) return fail(PS_E_STATE, "ps_world_trajs before a rollout");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  const ps_config& c = e->cfg;
+  const int R = (c.max_steps + c.replan_freq - 1) / c.replan_freq, T = R * c.replan_freq;
+  WorldTf tf{{1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f}};
+  if (center_to_world) std::memcpy(tf.m, center_to_world, sizeof(tf.m));
+  if (!out_dev) {
+    if (e->d_world.ensure((size_t)e->A * T * 3)) return fail(PS_E_HIP, "device allocation failed");
+    out_dev = e->d_world.p;
+  }
+  hipLaunchKernelGGL(k_world_traj, dim3((e->A * T + 255) / 256), dim3(256), 0, e->stream, (const float*)e->d_traj.p, e->stride_steps,
+                     c.hist_steps, T, e->A, (const float*)e->d_init_pos.p, (const float*)e->d_init_head.p, tf, out_dev);
+  HIPCHK(hipGetLastError());
+  return PS_OK;
+}
+
 extern "C" int32_t ps_num_agents(ps_engine* e) { return e ? e->A : 0; }
 extern "C" int32_t ps_num_map_tokens(ps_engine* e) { return e ? e->Mv : 0; }
 
@@ -1936,6 +2016,10 @@ extern "C" int64_t ps_get(ps_engine* e, const char* name, float* dst, int64_t ca
       return fail(PS_E_HIP, "hipMemcpy2D D2H");
     return count;
   }
+  if (n == "world_traj") {
+    if (!e->d_world.p) return fail(PS_E_STATE, "ps_get 'world_traj' before ps_world_trajs");
+    return copy(e->d_world.p, (int64_t)A * R * c.replan_freq * 3);
+  }
   if (n == "motion_pred") return copy(e->d_motion.p, (int64_t)R * A * c.motion_k * c.target_steps * c.state_dim);
   if (n == "reconst_pred") return copy(e->d_reconst.p, (int64_t)A * 2);
   if (n == "policy_emd") return copy(e->d_emd.p, (int64_t)A * D);
@@ -1950,8 +2034,8 @@ extern "C" int64_t ps_get(ps_engine* e, const char* name, float* dst, int64_t ca
   if (n == "edge_counts") {
     if (capacity < 8) return fail(PS_E_ARG, "destination too small");
     int v[4] = {0, 0, 0, 0};
-    (void)hipMemcpy(&v[0], e->e_p2p.eoff.p + A, sizeof(int), hipMemcpyDeviceToHost);
-    (void)hipMemcpy(&v[1], e->e_s2p.eoff.p + A, sizeof(int), hipMemcpyDeviceToHost);
+    (void)hipMemcpy(&v[0], e->e_p2p.eoff.p + e->Ap, sizeof(int), hipMemcpyDeviceToHost);
+    (void)hipMemcpy(&v[1], e->e_s2p.eoff.p + e->Ap, sizeof(int), hipMemcpyDeviceToHost);
     (void)hipMemcpy(&v[2], e->e_a2p.eoff.p + A, sizeof(int), hipMemcpyDeviceToHost);
     (void)hipMemcpy(&v[3], e->e_m2p.eoff.p + A, sizeof(int), hipMemcpyDeviceToHost);
     dst[0] = e->edge_counts[0]; dst[1] = e->edge_counts[1];

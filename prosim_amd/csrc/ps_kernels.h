@@ -209,11 +209,12 @@ __global__ __launch_bounds__(256) void k_pointnet_mfma(PointNetW w, const float*
 // install_local_env.sh:4) -- semantics of its CUDA kernels restated: per query scan the
 // candidates of the same scene in index order; d2 = dx*dx + dy*dy rounded per op (the file is
 // built with -ffp-contract=off); radius keeps the first `cap` with d2 < r*r; knn keeps the k
-// smallest by (d2, index).  Candidates of scene b = tokens [r1[b], r1[b+1]) then [r2[b], r2[b+1]).
+// smallest by (d2, index).  Candidates of scene b = tokens [r1[2b], r1[2b+1]) then [r2[2b], r2[2b+1]): begin / end pairs,
+// so that the replicas of one scene (ps_set_replicas) can all name the SAME map token range.
 struct CandSet {
   const float* pos;   // [n_tokens][2]
-  const int* r1;      // [B+1] first range per scene (global token indices)
-  const int* r2;      // [B+1] second range per scene or nullptr
+  const int* r1;      // [B][2] first range per scene (global token indices)
+  const int* r2;      // [B][2] second range per scene or nullptr
 };
 
 __device__ __forceinline__ float dist2(float ax, float ay, float bx, float by) {
@@ -271,7 +272,7 @@ __global__ void k_radius(RadSets sets, const float* __restrict__ qpos, const int
   for (int rg = 0; rg < 2 && run < capx; ++rg) {
     const int* rr = rg == 0 ? cs.r1 : cs.r2;
     if (!rr) break;
-    const int beg = rr[b], end = rr[b + 1];
+    const int beg = rr[2 * b], end = rr[2 * b + 1];
     for (int i0 = beg; i0 < end && run < capx; i0 += 64) {
       const int i = i0 + lane;
       bool ok = false;
@@ -307,7 +308,7 @@ __global__ void k_radius_selfrank(CandSet cs, const float* __restrict__ qpos, co
   for (int rg = 0; rg < 2; ++rg) {
     const int* rr = rg == 0 ? cs.r1 : cs.r2;
     if (!rr) break;
-    const int beg = rr[b], end = rr[b + 1] < self ? rr[b + 1] : self;
+    const int beg = rr[2 * b], end = rr[2 * b + 1] < self ? rr[2 * b + 1] : self;
     for (int i0 = beg; i0 < end; i0 += 64) {
       const int i = i0 + lane;
       bool ok = false;
@@ -419,8 +420,8 @@ __global__ void k_knn(CandSet cs, const float* __restrict__ qpos, const int* __r
   if (q >= nq) return;
   const float qx = qpos[2 * q], qy = qpos[2 * q + 1];
   const int b = qscene[q];
-  const int b1 = cs.r1[b], n1 = cs.r1[b + 1] - b1;
-  const int b2 = cs.r2 ? cs.r2[b] : 0, n2 = cs.r2 ? cs.r2[b + 1] - b2 : 0;
+  const int b1 = cs.r1[2 * b], n1 = cs.r1[2 * b + 1] - b1;
+  const int b2 = cs.r2 ? cs.r2[2 * b] : 0, n2 = cs.r2 ? cs.r2[2 * b + 1] - b2 : 0;
   const int n = n1 + n2;
   unsigned key[KNN_SLOTS];
 #pragma unroll
@@ -675,6 +676,46 @@ __global__ __launch_bounds__(128) void k_obs_fuse(Mlp3W m, float* __restrict__ t
 __global__ void k_zero_dead_rows(float* __restrict__ tok, const int* __restrict__ live, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n * 128 && !live[i >> 7]) tok[i] = 0.f;
+}
+
+// M-replica fan-out (replica_batch_for_parallel_rollout, rollout/gpu_utils.py:59-123: every per-agent tensor .repeat(M, ...)):
+// rows [np, n) of a row-major [n][w] buffer become copies of rows [0, np), replica after replica.
+__global__ void k_fan_out_rows(float* __restrict__ p, int np, int n, int w) {
+  const size_t first = (size_t)np * w, total = (size_t)n * w;
+  for (size_t i = first + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
+    p[i] = p[i % first];
+}
+
+// Rollout trajectories in the world frame (obtain_rollout_trajs_in_world, rollout/gpu_utils.py:255-267, over
+// batch_rotate_2D / wrap_angle models/utils/geometry.py:13-22 and batch_nd_transform_points_pt / _angles_pt / angle_wrap
+// rollout/utils.py:272-283, :347-392): the agent-init-frame steps are rotated by the initial heading and moved to the
+// initial position (the scene-centre frame), then taken through the centre -> world matrix.  fp32, in the reference's
+// order of operations.  One thread per (agent row, step); out [A][T][3] = (x, y, heading).
+struct WorldTf { float m[9]; };   // row-major 3 x 3 homogeneous 2-D transform
+__device__ __forceinline__ float floor_mod(float a, float m) {   // torch.remainder / numpy % for m > 0
+  float r = fmodf(a, m);
+  if (r != 0.f && r < 0.f) r += m;
+  return r;
+}
+__global__ void k_world_traj(const float* __restrict__ traj, int stride_steps, int hist, int T, int A,
+                             const float* __restrict__ init_pos, const float* __restrict__ init_head, WorldTf tf,
+                             float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= A * T) return;
+  const int a = i / T, t = i - a * T;
+  const float4 s = *(const float4*)(traj + ((size_t)a * stride_steps + hist + t) * 4);   // x, y, sin, cos
+  const float th = init_head[a];
+  const float c = cosf(th), sn = sinf(th);
+  const float xc = (s.x * c - s.y * sn) + init_pos[2 * a];
+  const float yc = (s.y * c + s.x * sn) + init_pos[2 * a + 1];
+  const float PI = 3.14159265358979323846f, TWO_PI = 6.28318530717958647692f;
+  const float hc = -PI + floor_mod((atan2f(s.z, s.w) + th) + PI, TWO_PI);
+  const float xw = (xc * tf.m[0] + yc * tf.m[1]) + tf.m[2];
+  const float yw = (xc * tf.m[3] + yc * tf.m[4]) + tf.m[5];
+  const float hw = floor_mod((hc + atan2f(tf.m[3], tf.m[0])) + PI, TWO_PI) - PI;
+  out[(size_t)i * 3] = xw;
+  out[(size_t)i * 3 + 1] = yw;
+  out[(size_t)i * 3 + 2] = hw;
 }
 
 // Condition encoders + mean pooling over the condition entries attached to one agent

@@ -69,6 +69,10 @@ def load_library():
     lib.ps_set_future_obs.argtypes = [vp, fp]
     lib.ps_set_future_log.argtypes = [vp, fp, u8p, fp, fp]
     lib.ps_set_mode_choice.argtypes = [vp, i32p]
+    lib.ps_set_replicas.argtypes = [vp, C.c_int32]
+    lib.ps_num_replicas.argtypes = [vp]
+    lib.ps_num_replicas.restype = C.c_int32
+    lib.ps_world_trajs.argtypes = [vp, fp, vp]
     lib.ps_num_policy_agents.argtypes = [vp]
     lib.ps_num_policy_agents.restype = C.c_int32
     lib.ps_update_obs.argtypes = [vp, fp, u8p, fp, fp]
@@ -103,7 +107,7 @@ def load_library():
     return lib
 
 
-EXPORTS = ["ps_create", "ps_destroy", "ps_last_error", "ps_set_scene", "ps_set_prompt", "ps_policy_forward", "ps_set_conditions", "ps_set_drag_points", "ps_set_future_obs", "ps_set_future_log", "ps_set_mode_choice", "ps_num_policy_agents", "ps_policy_flags",
+EXPORTS = ["ps_create", "ps_destroy", "ps_last_error", "ps_set_scene", "ps_set_prompt", "ps_policy_forward", "ps_set_conditions", "ps_set_drag_points", "ps_set_future_obs", "ps_set_future_log", "ps_set_mode_choice", "ps_set_replicas", "ps_num_replicas", "ps_world_trajs", "ps_num_policy_agents", "ps_policy_flags",
            "ps_encode_scene", "ps_generate_policy", "ps_reset_rollout", "ps_policy_step", "ps_rollout", "ps_sync", "ps_stream", "ps_set_chain_rows", "ps_set_chain_impl", "ps_enable_policy_events", "ps_policy_event_times", "ps_update_obs", "ps_declare_agent_rows",
            "ps_set_state", "ps_get", "ps_rollout_metric", "ps_pair_metric", "ps_num_agents", "ps_num_map_tokens", "ps_time_rollout", "ps_time_policy_kernel",
            "ps_test_pointnet", "ps_test_fourier", "ps_test_wrap", "ps_test_attn", "ps_test_get_edges", "ps_test_stream"]
@@ -209,12 +213,15 @@ class Engine:
         self._check(self.lib.ps_set_scene(self.h, B, M, P, N, _f(map_input), _u8(map_mask), _f(keep[9]), _f(keep[10]),
                                           _f(obs_input), _u8(obs_mask), _f(keep[11]), _f(keep[12]), _f(prompt), _u8(pm),
                                           _i32(at), _f(ppos), _f(phead)))
-        self._shape = (B, N)
+        Mrep = self.replicas
+        self._shape = (B, N) if Mrep == 1 else (Mrep, N)
         # rows in slot order; policy agents are the rows whose slot carries a prompt, the others replay the log
         # (ps_set_future_log); live0_rows: the row is a scene token at the initial step
-        self._slots = np.nonzero(seen.reshape(-1))[0]
-        self.policy_rows = pm.reshape(-1).astype(bool)[self._slots]
-        self.live0_rows = seen0.reshape(-1)[self._slots]
+        in_slots = np.nonzero(seen.reshape(-1))[0]
+        self.policy_rows = np.tile(pm.reshape(-1).astype(bool)[in_slots], Mrep)
+        self.live0_rows = np.tile(seen0.reshape(-1)[in_slots], Mrep)
+        # with replicas the rows are replica-major and slot r * N + n is agent n of replica r
+        self._slots = in_slots if Mrep == 1 else (np.arange(Mrep)[:, None] * N + in_slots[None, :]).reshape(-1)
         self.set_conditions(s.get("cond"))
         if s.get("mode_choice") is not None:
             self.set_mode_choice(s["mode_choice"])
@@ -228,8 +235,31 @@ class Engine:
             else:
                 self._check(self.lib.ps_set_future_obs(self.h, _f(fo)))
 
+    @property
+    def replicas(self) -> int:
+        return int(getattr(self, "_replicas", 1))
+
+    def set_replicas(self, m: int):
+        """Roll the next scenes out as ``m`` replicas side by side (parallel_rollout_batch, rollout/gpu_utils.py:179-228):
+        ``set_scene`` then takes a ONE-scene batch; encode / generate run once and fan out on the device; every per-agent
+        result has ``m * agents`` rows (``padded`` returns [m, N, ...]); ``mode_choice`` is [R, m, N]."""
+        self._check(self.lib.ps_set_replicas(self.h, int(m)))
+        self._replicas = int(m)
+        self._shape = self._slots = None
+
+    def world_trajs(self, center_to_world=None, out_dev_ptr: int = 0):
+        """obtain_rollout_trajs_in_world (rollout/gpu_utils.py:230-281) on the device.  ``center_to_world``: 3 x 3 or None
+        (identity).  With ``out_dev_ptr`` (a device buffer [A, max_steps, 3] float32) nothing is returned; without, the
+        result is read back: [A, max_steps, 3] (x, y, heading)."""
+        tf = None if center_to_world is None else np.ascontiguousarray(center_to_world, dtype=np.float32).reshape(9)
+        self._check(self.lib.ps_world_trajs(self.h, None if tf is None else _f(tf), C.c_void_p(out_dev_ptr or None)))
+        if out_dev_ptr:
+            return None
+        return self.get("world_traj")
+
     def set_mode_choice(self, choice):
-        """``choice`` [R, B, N] int: the motion mode each policy agent follows at each replan (TOP_K > 1), or None."""
+        """``choice`` [R, B, N] int ([R, replicas, N] with replicas): the motion mode each policy agent follows at each
+        replan (TOP_K > 1), or None."""
         if choice is None:
             self._check(self.lib.ps_set_mode_choice(self.h, None))
             return
@@ -354,7 +384,7 @@ class Engine:
         shapes = {"traj": (A, S, 4), "vel": (A, S, 2), "motion_pred": (R, A, sp.motion_k, sp.target_steps, sp.state_dim),
                   "reconst_pred": (A, 2), "policy_emd": (A, sp.hidden), "scene_tokens": (Mv + A, sp.hidden),
                   "fused": (A, sp.hidden), "obs_in": (A, sp.hist_steps, sp.obs_dim), "cur_pos": (A, 2), "edge_counts": (8,),
-                  "goal_prob": (A, max(sp.goal_pred_k, 1)), "goal_point": (A, max(sp.goal_pred_k, 1), 2)}
+                  "goal_prob": (A, max(sp.goal_pred_k, 1)), "goal_point": (A, max(sp.goal_pred_k, 1), 2), "world_traj": (A, S, 3)}
         out = np.empty(shapes[name], np.float32)
         n = self.lib.ps_get(self.h, name.encode(), _f(out), out.size)
         if n < 0:

@@ -314,6 +314,53 @@ def gen_demo_map(scene: str = "scene_1", map_name: str = "waymo_train_1"):
     print("demo map written:", map_name, os.path.getsize(os.path.join(GOLD, f"demo_{map_name}_map.pb")), "bytes; tls rows", t.num_rows)
 
 
+def make_world_inputs(seed: int, n_scenes: int = 3, n_agents: int = 7, T: int = 80):
+    """Seeded inputs of the world-frame output step: per (replica, agent) a rolled-out trajectory in the agent-init frame,
+    the init pose in the scene-centre frame, and a centre -> world matrix at Waymo-like coordinates.  A few headings sit
+    next to the +-pi cut on purpose."""
+    g = np.random.default_rng(seed)
+    n = n_scenes * n_agents
+    step = g.normal(0.8, 0.4, (n, T, 1)) * np.stack([np.ones((n, T)), 0.1 * g.normal(size=(n, T))], -1)
+    xy = np.cumsum(step, 1)
+    h = np.cumsum(0.02 * g.normal(size=(n, T)), 1)
+    h[::5] += np.pi - 0.01
+    traj = np.concatenate([xy, np.sin(h)[..., None], np.cos(h)[..., None]], -1).astype(np.float32)
+    init_pos = g.uniform(-150, 150, (n, 2)).astype(np.float32)
+    init_head = g.uniform(-np.pi, np.pi, (n, 1)).astype(np.float32)
+    a = g.uniform(-np.pi, np.pi)
+    tf = np.array([[np.cos(a), -np.sin(a), 3418.7], [np.sin(a), np.cos(a), -1650.2], [0, 0, 1]], np.float32)
+    return dict(traj=traj, init_pos=init_pos, init_head=init_head, tf=tf, batch_ids=np.repeat(np.arange(n_scenes), n_agents),
+                object_ids=np.tile(np.arange(100, 100 + n_agents), n_scenes))
+
+
+def gen_world():
+    """tests/golden/ref_world_trajs.npz: the reference's own obtain_rollout_trajs_in_world (rollout/gpu_utils.py:230-281)
+    on seeded inputs (fp32, as the rollout hands them over), and the oracle (oracle/world_oracle.py) checked on the way."""
+    from oracle import world_oracle as wo
+    fn, _ = rh.load_world_output()
+    out = {}
+    for seed in (0, 1):
+        d = make_world_inputs(seed)
+        names = {}
+        for i, (b, o) in enumerate(zip(d["batch_ids"], d["object_ids"])):
+            names[f"{b}-{o}"] = dict(traj=torch.from_numpy(d["traj"][i]), init_pos=torch.from_numpy(d["init_pos"][i]),
+                                     init_heading=torch.from_numpy(d["init_head"][i]))
+        batch = rh.Extras({})
+        batch.centered_world_from_agent_tf = torch.from_numpy(d["tf"])[None]
+        trajs_M, ids_M = fn(batch, dict(motion_pred=dict(rollout_trajs=names)))
+        ref = np.concatenate(trajs_M, 0)
+        assert [int(x) for ids in ids_M for x in ids] == d["object_ids"].tolist()
+        mine = wo.trajs_in_world(d["traj"], d["init_pos"], d["init_head"], d["tf"]).numpy()
+        dxy = np.abs(mine[..., :2] - ref[..., :2]).max()
+        dh = np.abs(np.angle(np.exp(1j * (mine[..., 2] - ref[..., 2])))).max()
+        assert dxy == 0 and dh == 0, (dxy, dh)                                # same fp32 operations in the same order
+        for k, v in d.items():
+            out[f"s{seed}_{k}"] = v
+        out[f"s{seed}_world"] = ref.astype(np.float32)
+    np.savez_compressed(os.path.join(GOLD, "ref_world_trajs.npz"), **out)
+    print("ref_world_trajs written:", ref.shape)
+
+
 make_pair_metric_inputs = synth.make_pair_metric_inputs
 
 
@@ -369,6 +416,8 @@ if __name__ == "__main__":
     elif len(sys.argv) > 1 and sys.argv[1] == "map":
         gen_demo_tracks("scene_1")
         gen_demo_map()
+    elif len(sys.argv) > 1 and sys.argv[1] == "world":
+        gen_world()
     elif len(sys.argv) > 1 and sys.argv[1] == "metric":
         gen_pair_metric()
     elif len(sys.argv) > 1 and sys.argv[1] == "goal":
@@ -380,4 +429,5 @@ if __name__ == "__main__":
         gen_demo_tracks("scene_1")
         gen_demo_map()
         gen_pair_metric()
+        gen_world()
         gen_goal_heads()

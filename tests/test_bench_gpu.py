@@ -1,5 +1,5 @@
 """bench.py end to end on the GPU box: the driver's command lines, the one JSON line, and the multi-rank code path
-(process group + event-ordered RCCL gather) taken with a single rank (PS_BENCH_FORCE_DIST)."""
+(process group + the RCCL gather at metric-compute time) taken with a single rank (PS_BENCH_FORCE_DIST)."""
 import json
 import os
 import subprocess
@@ -33,4 +33,4 @@ def test_bench_line_single_and_forced_distributed():
     # same scenes, same engine: the gathered metrics equal the local ones, and the gather costs a few per cent at most
     # (warmup 4 = one pass of every in-flight engine, so no first-use cost lands in the 8 timed steps)
     assert dist["rollout_metrics"] == plain["rollout_metrics"] and dist["rollout_metrics"]["scenes"] == 8
-    assert dist["value"] > 0.8 * plain["value"]
+    assert dist["value"] > 0.9 * plain["value"]

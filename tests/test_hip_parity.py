@@ -417,7 +417,10 @@ def test_demo_dataset_scene_config0():
 def test_demo_dataset_real_lanes_config0():
     """BASELINE configs[0] on the scene's REAL lanes: demo scene_1 (agent table + the cache's VectorMap protobuf decoded by
     prosim_amd/vecmap.py, chunked and framed as data_utils.py:156-255 / format_utils.py:150-263 do), centred on the ego,
-    16 agents, 20-step unconditional rollout, against the fp64 oracle."""
+    16 agents, 20-step unconditional rollout.  Trajectories and predictions against the fp64 oracle, all agents within 1e-4.
+    The scene TOKENS are compared with the fp32 oracle: two antiparallel lane chunks of this map have a relative heading of
+    exactly pi, which wrap_angle (geometry.py:13-17) sends to -pi in fp32 (the reference's arithmetic, and the engine's)
+    and to +pi in fp64 -- one edge whose Fourier features flip sign; the test pins that this is the whole difference."""
     from prosim_amd.engine import Engine
     from test_vecmap_cpu import demo_scene_real_lanes
     spec = DEMO_SPEC.replace(max_steps=20)
@@ -426,17 +429,21 @@ def test_demo_dataset_real_lanes_config0():
     w = weights.init_weights(spec, 0)
     with torch.no_grad():
         o64 = orc.rollout(w, spec, scene, dtype=torch.float64, collect=True)
+        o32 = orc.rollout(w, spec, scene, dtype=torch.float32, collect=True)
     eng = Engine(spec, w)
     try:
         eng.set_scene(scene)
         eng.encode_scene()
-        assert err(eng.get("scene_tokens"), o64["trace"]["scene_tokens"].numpy()) < TOL
+        tok = eng.get("scene_tokens")
+        assert err(tok, o32["trace"]["scene_tokens"].numpy()) < TOL
+        cut = np.abs(o32["trace"]["scene_tokens"].double().numpy() - o64["trace"]["scene_tokens"].numpy()).max(1) > TOL
+        assert cut.any() and np.array_equal(np.abs(tok - o64["trace"]["scene_tokens"].numpy()).max(1) > TOL, cut)
         eng.rollout()
         A = eng.num_agents
         assert A == 16
         assert err(eng.get("motion_pred")[0], o64["motion_pred"][:A].numpy()) < TOL
         d = np.abs(eng.padded("traj") - o64["traj"].numpy())[0].reshape(A, -1).max(1)
-        assert (d < TOL).mean() >= 0.9 and d.max() < 5e-3, d
+        assert d.max() < TOL, d
     finally:
         eng.close()
 
@@ -606,7 +613,7 @@ def test_throughput_mode_rows_per_workgroup(small_engine):
             outs[rows] = mp
         assert np.array_equal(outs[0], outs[2])                       # 0 = the engine's own choice = 2 rows at this size
         assert err(outs[4][0], outs[0][0]) < 1e-5                     # another tiling, another summation order
-        with pytest.raises(RuntimeError, match="0 .auto., 2 or 4"):
+        with pytest.raises(RuntimeError, match="0 .auto., 1, 2, 4, or 8..16"):
             small_engine.set_chain_rows(3)
     finally:
         small_engine.set_chain_rows(0)

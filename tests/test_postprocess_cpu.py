@@ -1,7 +1,8 @@
 import numpy as np
+import pytest
 
 from prosim_amd import synth
-from prosim_amd.postprocess import replicate_scene, trajs_to_world
+from prosim_amd.postprocess import replicate_scene
 from prosim_amd.spec import SMALL_SPEC
 
 
@@ -14,18 +15,13 @@ def test_replicate_scene_shapes():
     assert np.array_equal(r["map_pos"][3], s["map_pos"][0])
 
 
-def test_world_frame_transform_round_trip():
-    rng = np.random.RandomState(0)
-    th = rng.uniform(-np.pi, np.pi, (3, 6))
-    traj = np.zeros((3, 6, 4), np.float32)
-    traj[..., 0], traj[..., 1] = rng.randn(3, 6), rng.randn(3, 6)
-    traj[..., 2], traj[..., 3] = np.sin(th), np.cos(th)
-    pos, h0 = rng.randn(3, 2).astype(np.float32) * 10, rng.uniform(-np.pi, np.pi, 3).astype(np.float32)
-    w = trajs_to_world(traj, pos, h0)
-    # inverse transform recovers the local trajectory
-    d = w["xy"] - pos[:, None]
-    c, s = np.cos(-h0)[:, None], np.sin(-h0)[:, None]
-    back = np.stack([d[..., 0] * c - d[..., 1] * s, d[..., 0] * s + d[..., 1] * c], -1)
-    assert np.abs(back - traj[..., :2]).max() < 1e-5
-    assert np.abs(np.angle(np.exp(1j * (w["heading"] - h0[:, None] - th)))).max() < 1e-5
-    assert w["heading"].min() >= -np.pi - 1e-6 and w["heading"].max() < np.pi + 1e-6
+def test_replicate_scene_keys_the_frame_axis_on_the_field_name():
+    """A 2-replan spec has ONE fut_obs frame: [1, 1, N, ...] must still be tiled on axis 1 (the batch), not axis 0."""
+    spec = SMALL_SPEC.replace(max_steps=20)
+    s = synth.make_scene(spec, 5, 7, batch=1, seed=0, replay=0.4)
+    assert s["fut_obs_input"].shape[:2] == (1, 1)
+    r = replicate_scene(s, 3)
+    for k in ("fut_obs_input", "fut_obs_mask", "fut_obs_pos", "fut_obs_head"):
+        assert r[k].shape[:2] == (1, 3), k
+    with pytest.raises(ValueError):
+        replicate_scene(synth.make_scene(spec, 5, 7, batch=2, seed=0), 3)
