@@ -52,6 +52,10 @@ typedef struct ps_config {
   int32_t replan_freq, max_steps;
   float dt, ln_eps;
   int32_t device;                              /* HIP device ordinal */
+  /* *.ATTN.LEARNABLE_PE of the scene encoder / the decoder / the policy (default.py:472, :594, :665; 0 in the demo): the
+   * relative-PE rows of that part's two edge sets come from a learnable FourierEmbedding (layers/fourier_embedding.py:11-54;
+   * weights "<part>.<set>_rel_pe_emb.*") instead of the fixed one.  pe_num_freq = PE_NUM_FREQ, must be 64 (the default). */
+  int32_t enc_learnable_pe, dec_learnable_pe, pol_learnable_pe, pe_num_freq;
 } ps_config;
 
 /* Create an engine and upload weights.  names[i] are reference state_dict keys

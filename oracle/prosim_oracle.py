@@ -189,8 +189,37 @@ def rel_pe_input(src: T, dst: T, ori_dst: T, pos_dst: T, ori_src: T, pos_src: T)
     return torch.stack([torch.norm(rel_pos, dim=-1), rel_ori, ang, ang], dim=-1)
 
 
-def rel_pe(spec: ModelSpec, src, dst, ori_dst, pos_dst, ori_src, pos_src) -> T:
-    return fourier_fix(rel_pe_input(src, dst, ori_dst, pos_dst, ori_src, pos_src), spec.hidden / 4)
+def fourier_learn(Wt: W, prefix: str, x: T, eps: float = 1e-5) -> T:
+    """FourierEmbedding.forward with continuous inputs only (models/layers/fourier_embedding.py:37-54): x [E, 3] ->
+    [E, hidden].  Per input i: [cos(x_i f_ik 2 pi), sin(...), x_i] -> Linear, LayerNorm, ReLU, Linear; summed over the
+    inputs; then LayerNorm, ReLU, Linear."""
+    f = Wt[f"{prefix}.freqs.weight"]
+    v = x.unsqueeze(-1) * f * 2 * math.pi
+    v = torch.cat([v.cos(), v.sin(), x.unsqueeze(-1)], dim=-1)
+    embs = []
+    for i in range(x.shape[-1]):
+        q = f"{prefix}.mlps.{i}"
+        h = v[:, i] @ Wt[f"{q}.0.weight"].T + Wt[f"{q}.0.bias"]
+        h = torch.relu(layer_norm(h, Wt[f"{q}.1.weight"], Wt[f"{q}.1.bias"], eps))
+        embs.append(h @ Wt[f"{q}.3.weight"].T + Wt[f"{q}.3.bias"])
+    y = torch.stack(embs).sum(dim=0)
+    y = torch.relu(layer_norm(y, Wt[f"{prefix}.to_out.0.weight"], Wt[f"{prefix}.to_out.0.bias"], eps))
+    return y @ Wt[f"{prefix}.to_out.2.weight"].T + Wt[f"{prefix}.to_out.2.bias"]
+
+
+def rel_pe(spec: ModelSpec, src, dst, ori_dst, pos_dst, ori_src, pos_src, Wt: W = None, emb: str = None) -> T:
+    """The relative-PE rows of one edge set.  ``emb``: state-dict prefix of the set's learnable FourierEmbedding
+    (LEARNABLE_PE: three inputs, attn_fusion.py:50-51) or None for the fixed one (four inputs: the angle twice)."""
+    x = rel_pe_input(src, dst, ori_dst, pos_dst, ori_src, pos_src)
+    if emb is not None:
+        return fourier_learn(Wt, emb, x[..., :3], spec.ln_eps)
+    return fourier_fix(x, spec.hidden / 4)
+
+
+def _emb(spec: ModelSpec, part: str, name: str):
+    """Prefix of a learnable rel-PE embedding, or None when that part of the model uses the fixed embedding."""
+    on = {"scene_encoder": spec.enc_learnable_pe, "decoder": spec.dec_learnable_pe, "policy.act_decoder": spec.pol_learnable_pe}[part]
+    return f"{part}.{name}_rel_pe_emb" if on else None
 
 
 def attention_layer(Wt: W, p: str, spec: ModelSpec, x_src: T, x_dst: T, r: T, src: T, dst: T,
@@ -268,8 +297,8 @@ def scene_fusion(Wt: W, spec: ModelSpec, map_emb, map_mask, map_pos, map_head,
     # knn_graph(loop=True, flow=source_to_target): edge (x-neighbour j -> query i)
     a_dst, a_src = knn_edges(o_pos, obs_b, o_pos, obs_b, spec.agent_knn)
     s_dst, s_src = knn_edges(s_pos, scene_b, s_pos, scene_b, spec.scene_knn)
-    a_pe = rel_pe(spec, a_src, a_dst, o_ori, o_pos, o_ori, o_pos)
-    s_pe = rel_pe(spec, s_src, s_dst, s_ori, s_pos, s_ori, s_pos)
+    a_pe = rel_pe(spec, a_src, a_dst, o_ori, o_pos, o_ori, o_pos, Wt, _emb(spec, "scene_encoder", "a2a"))
+    s_pe = rel_pe(spec, s_src, s_dst, s_ori, s_pos, s_ori, s_pos, Wt, _emb(spec, "scene_encoder", "s2s"))
     a_mask = scene_type == 1
     for i in range(spec.scene_layers):
         xa = x[a_mask]
@@ -316,6 +345,8 @@ def update_scene_attn(Wt: W, spec: ModelSpec, scene: Dict) -> Dict:
     m_b, o_b = scene["scene_batch_idx"][mt], scene["scene_batch_idx"][ot]
     a_dst, a_src = radius_edges(o_pos, o_b, o_pos, o_b, spec.enc_agent_radius, spec.scene_knn, drop_self=True)
     m_dst, m_src = radius_edges(m_pos, m_b, o_pos, o_b, spec.enc_scene_radius, spec.scene_knn)
+    if spec.enc_learnable_pe:
+        raise NotImplementedError("OBS_UPDATE.ATTN_UPDATE with a learnable scene-encoder PE is not restated")
     a_pe = rel_pe(spec, a_src, a_dst, o_ori, o_pos, o_ori, o_pos)
     m_pe = rel_pe(spec, m_src, m_dst, o_ori, o_pos, m_ori, m_pos)
     x_a, x_m = scene["scene_tokens"][ot], scene["scene_tokens"][mt]
@@ -349,10 +380,10 @@ def decoder_fusion(Wt: W, spec: ModelSpec, scene: Dict, prompt_emd: T, prompt_ma
     pori = prompt_head.reshape(-1, 1)[prompt_mask.view(-1)]
     # radius_graph(loop=False): (x=source j, y=target i)
     pp_dst, pp_src = radius_edges(ppos, pb, ppos, pb, spec.dec_prompt_radius, spec.dec_max_neigh, drop_self=True)
-    pp_pe = rel_pe(spec, pp_src, pp_dst, pori, ppos, pori, ppos)
+    pp_pe = rel_pe(spec, pp_src, pp_dst, pori, ppos, pori, ppos, Wt, _emb(spec, "decoder", "p2p"))
     sp_dst, sp_src = radius_edges(scene["scene_pos"], scene["scene_batch_idx"], ppos, pb,
                                   spec.dec_scene_radius, spec.dec_max_neigh)
-    sp_pe = rel_pe(spec, sp_src, sp_dst, pori, ppos, scene["scene_ori"], scene["scene_pos"])
+    sp_pe = rel_pe(spec, sp_src, sp_dst, pori, ppos, scene["scene_ori"], scene["scene_pos"], Wt, _emb(spec, "decoder", "s2p"))
     xs = scene["scene_tokens"]
     for i in range(spec.dec_layers):
         xp = attention_layer(Wt, f"decoder.p2p_attn_layers.{i}", spec, xp, xp, pp_pe, pp_src, pp_dst, False)
@@ -453,9 +484,9 @@ def policy_forward(Wt: W, spec: ModelSpec, scene: Dict, policy_emd: T, agent_typ
     x_m, m_pos, m_ori, m_b = (scene["scene_tokens"][st == 0], scene["scene_pos"][st == 0],
                               scene["scene_ori"][st == 0], scene["scene_batch_idx"][st == 0])
     ap_dst, ap_src = radius_edges(a_pos, a_b, pos, policy_b, spec.pol_agent_radius, spec.pol_max_neigh)
-    ap_pe = rel_pe(spec, ap_src, ap_dst, head, pos, a_ori, a_pos)
+    ap_pe = rel_pe(spec, ap_src, ap_dst, head, pos, a_ori, a_pos, Wt, _emb(spec, "policy.act_decoder", "a2p"))
     mp_dst, mp_src = radius_edges(m_pos, m_b, pos, policy_b, spec.pol_map_radius, spec.pol_max_neigh)
-    mp_pe = rel_pe(spec, mp_src, mp_dst, head, pos, m_ori, m_pos)
+    mp_pe = rel_pe(spec, mp_src, mp_dst, head, pos, m_ori, m_pos, Wt, _emb(spec, "policy.act_decoder", "m2p"))
     xp = policy_emd
     for i in range(spec.pol_layers):
         xp = attention_layer(Wt, f"{pa}.a2p_attn_layers.{i}", spec, x_a, xp, ap_pe, ap_src, ap_dst, True)

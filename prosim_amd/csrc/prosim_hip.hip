@@ -16,6 +16,7 @@
 #include "ps_attn.h"
 #include "ps_kernels.h"
 #include "ps_chain16.h"
+#include "ps_pe_learn.h"
 
 using namespace ps;
 
@@ -94,6 +95,9 @@ struct ps_engine {
   HeadW head{};
   DevBuf<float> io_q, io_qt, io_cq, io_ar, io_av, io_l, io_s, io_g, io_m;   // split path / k_chain16: per-destination vectors (EdgeIO)
   CondW cond{};
+  // learnable relative-PE embeddings (*.ATTN.LEARNABLE_PE): a2a, s2s | p2p, s2p | a2p, m2p; pe_on[part] = that part has them
+  PeLearnW pe_learn[6]{};
+  bool pe_on[3] = {false, false, false};
   Mlp3W mlp_obs_fuse{};                     // scene_encoder.obs_update_mlp (OBS_UPDATE.FUSION 'mlp')
   EdgeSet e_ua, e_um;                       // OBS_UPDATE.ATTN_UPDATE: agents <- agents (no self loops), agents <- map
   DevBuf<float> d_obs_new, d_kv_um;         // re-encoded observation rows; k|v of the map tokens for the s2s layers
@@ -173,6 +177,13 @@ struct ps_engine {
 namespace {
 void drop_graph(ps_engine* e);
 int io_for(ps_engine* e, int Nd, EdgeIO& io);
+// the learnable rel-PE embedding that makes the rows of edge set `es`, or nullptr (fixed Fourier rows)
+const PeLearnW* pe_of(const ps_engine* e, const EdgeSet* es) {
+  const EdgeSet* sets[6] = {&e->e_a2a, &e->e_s2s, &e->e_p2p, &e->e_s2p, &e->e_a2p, &e->e_m2p};
+  for (int i = 0; i < 6; ++i)
+    if (es == sets[i]) return e->pe_on[i / 2] ? &e->pe_learn[i] : nullptr;
+  return nullptr;
+}
 }
 // ------------------------------------------------------------------------------------------ weights
 namespace {
@@ -465,6 +476,30 @@ void build_pointnet(Builder& b, const std::string& p, int in_dim, int n_pre, int
   b.plain(&w.out_b1, p + ".out_mlps.mlp.2.bias", D);
 }
 
+// FourierEmbedding(input_dim = 3, hidden_dim = 128, num_freq_bands = 64) (layers/fourier_embedding.py:11-35)
+void build_pe_learn(Builder& b, const std::string& p, PeLearnW& w) {
+  std::memset(&w, 0, sizeof(w));
+  b.plain(&w.freqs, p + ".freqs.weight", 3 * 64);
+  std::vector<float> b2(D, 0.f);
+  for (int i = 0; i < 3; ++i) {
+    const std::string q = p + ".mlps." + std::to_string(i);
+    b.fragments(&w.F1[i], q + ".0.weight", D, 129, 0, 128);
+    b.transposed(&w.w1x[i], q + ".0.weight", D, 129, 128, 1);
+    b.plain(&w.b1[i], q + ".0.bias", D);
+    b.plain(&w.ln1w[i], q + ".1.weight", D);
+    b.plain(&w.ln1b[i], q + ".1.bias", D);
+    b.fragments(&w.F2[i], q + ".3.weight", D, D, 0, D);
+    const float* s = b.get(q + ".3.bias", D);
+    if (s)
+      for (int c = 0; c < D; ++c) b2[c] += s[c];
+  }
+  b.slot(&w.b2sum, b.put(b2));
+  b.plain(&w.lnow, p + ".to_out.0.weight", D);
+  b.plain(&w.lnob, p + ".to_out.0.bias", D);
+  b.fragments(&w.Fo, p + ".to_out.2.weight", D, D, 0, D);
+  b.plain(&w.bo, p + ".to_out.2.bias", D);
+}
+
 void build_mlp3(Builder& b, const std::string& p, std::vector<int> dims, bool without_norm, Mlp3W& m) {
   std::memset(&m, 0, sizeof(m));
   m.n = (int)dims.size() - 1;
@@ -501,9 +536,15 @@ extern "C" int ps_create(const ps_config* cfg, int32_t n_tensors, const char* co
     return fail(PS_E_ARG, "replan_freq must be in 1..target_steps (a replan appends replan_freq of the target_steps predicted states)");
   if (cfg->pol_max_neigh < 1 || cfg->pol_max_neigh > 2047 || cfg->dec_max_neigh < 1 || cfg->dec_max_neigh > 2047)
     return fail(PS_E_ARG, "pol_max_neigh / dec_max_neigh must be in 1..2047 (64 rel-PE tiles per destination)");
+  const bool any_lpe = cfg->enc_learnable_pe || cfg->dec_learnable_pe || cfg->pol_learnable_pe;
+  if (any_lpe && cfg->pe_num_freq != 64)
+    return fail(PS_E_ARG, "learnable rel-PE: this build supports PE_NUM_FREQ = 64 (the reference's default) only");
+  if (cfg->enc_learnable_pe && cfg->obs_attn_update)
+    return fail(PS_E_ARG, "OBS_UPDATE.ATTN_UPDATE together with a learnable scene-encoder rel-PE is not supported");
   if (hipSetDevice(cfg->device) != hipSuccess) return fail(PS_E_HIP, "hipSetDevice failed (no GPU?)");
   ps_engine* e = new ps_engine();
   e->cfg = *cfg;
+  e->pe_on[0] = cfg->enc_learnable_pe != 0; e->pe_on[1] = cfg->dec_learnable_pe != 0; e->pe_on[2] = cfg->pol_learnable_pe != 0;
   for (int i = 0; i < n_tensors; ++i) e->src[names[i]] = {data[i], numel[i]};
   Builder b{e};
   auto layers = [&](const std::string& pre, int n, std::vector<AttnW>& v) {
@@ -522,6 +563,12 @@ extern "C" int ps_create(const ps_config* cfg, int32_t n_tensors, const char* co
   if (cfg->drag_mlp_layers > 0)
     build_pointnet(b, "condition_transformers.policy_decoder.condition_encoders.drag_point.pointnet_encoder", 2,
                    cfg->drag_pre_layers, cfg->drag_mlp_layers, e->pn_drag);
+  {
+    static const char* kPe[6] = {"scene_encoder.a2a_rel_pe_emb", "scene_encoder.s2s_rel_pe_emb", "decoder.p2p_rel_pe_emb",
+                                 "decoder.s2p_rel_pe_emb", "policy.act_decoder.a2p_rel_pe_emb", "policy.act_decoder.m2p_rel_pe_emb"};
+    for (int i = 0; i < 6; ++i)
+      if (e->pe_on[i / 2]) build_pe_learn(b, kPe[i], e->pe_learn[i]);
+  }
   build_mlp3(b, "prompt_encoder.motion_pred.state_encoder", {cfg->prompt_dim, D, D}, false, e->mlp_prompt);
   if (cfg->obs_fusion_mlp) build_mlp3(b, "scene_encoder.obs_update_mlp", {2 * D, D, D}, false, e->mlp_obs_fuse);
   if (cfg->goal_pred_k > 0) {
@@ -630,6 +677,7 @@ extern "C" int ps_create(const ps_config* cfg, int32_t n_tensors, const char* co
   // the chain kernel may use up to ~140 KiB of dynamic LDS
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_kv_proj), hipFuncAttributeMaxDynamicSharedMemorySize, (int)KV_LDS_BYTES);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pointnet_mfma), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PN_LDS_BYTES);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pe_learn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PL_LDS_BYTES);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_node<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ND_LDS_BYTES);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_node<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ND_LDS_BYTES);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_chain<1, 4, 3, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -953,7 +1001,7 @@ extern "C" int ps_set_scene(ps_engine* e, int32_t B, int32_t M, int32_t P, int32
     s.esrc = es.esrc.p;
     s.toff = es.toff.p;
     s.rtT = es.rtT.p;
-    s.kr = (&es == &e->e_cnd) ? 4 : 3;
+    s.kr = (&es == &e->e_cnd || pe_of(e, &es)) ? 4 : 3;   // learnable rel-PE rows have no repeated columns to fold
     s.geo = es.geo.p;
     e->h_steps.push_back(s);
   };
@@ -1411,7 +1459,7 @@ void launch_relpe(ps_engine* e, EdgeSet& es, const float* src_ori, const float* 
 }
 
 // the per-edge geometry records of one or two edge sets (what k_chain16 rebuilds the rel-PE rows from)
-void launch_geo(ps_engine* e, const PeArgs* a, int nsets) {
+void launch_geo(ps_engine* e, const PeArgs* a, int nsets, bool raw = false) {
   GeoSets gs{};
   size_t grid = 1;
   for (int i = 0; i < nsets; ++i) {
@@ -1419,7 +1467,15 @@ void launch_geo(ps_engine* e, const PeArgs* a, int nsets) {
     gs.s[i] = GeoSet{es.esrc.p, es.edst.p, es.eoff.p, es.nq, a[i].src_ori, a[i].dst_pos, a[i].dst_ori, es.geo.p};
     grid = std::max(grid, std::min<size_t>(2048, es.cap_edges / 256 + 1));
   }
-  hipLaunchKernelGGL(k_edge_geo, dim3((unsigned)grid, nsets), dim3(256), 0, e->stream, gs, (const float*)e->d_tok_pos.p, e->div32, e->cfg.ln_eps);
+  hipLaunchKernelGGL(k_edge_geo, dim3((unsigned)grid, nsets), dim3(256), 0, e->stream, gs, (const float*)e->d_tok_pos.p, e->div32, e->cfg.ln_eps, raw ? 1 : 0);
+}
+
+// the learnable rel-PE rows of one edge set (after launch_geo made its geometry records): both operand images, KR = 4
+void launch_pe_learn(ps_engine* e, EdgeSet& es, const PeLearnW& w) {
+  const size_t pairs = (es.cap_edges / 32 + (size_t)es.nq + 2) / 2;
+  hipLaunchKernelGGL(k_pe_learn, dim3((unsigned)std::min<size_t>(1024, std::max<size_t>(pairs, 1))), dim3(256), PL_LDS_BYTES, e->stream, w,
+                     (const EdgeGeo*)es.geo.p, (const int*)es.eoff.p, (const int*)es.toff.p, (const int*)es.tdst.p, es.nq, es.rtA.p,
+                     es.rtT.p, e->cfg.ln_eps);
 }
 
 // Fused chain, second generation (ps_chain16.h).  rows per workgroup: the engine's choice keeps >= 256 workgroups in a
@@ -1427,7 +1483,10 @@ void launch_geo(ps_engine* e, const PeArgs* a, int nsets) {
 // do the fused chains over Nd destination rows run on k_chain16?  (ps_set_chain_impl; 0 = in throughput mode, and in
 // latency mode from 1024 rows up: 0.47 against 0.53 ms per 1024-row policy launch; below that the round-1 kernel's one
 // small workgroup per row fills the chip better, 0.27 against 0.37 ms at 128 rows)
-bool use_c16(const ps_engine* e, int Nd) {
+// (part: 0 scene encoder, 1 generator, 2 policy -- a part with a LEARNABLE rel-PE cannot rebuild its rows from geometry
+// records inside the kernel: it reads the operand images the edge-MLP kernel made, on k_attn_chain)
+bool use_c16(const ps_engine* e, int Nd, int part) {
+  if (e->pe_on[part]) return false;
   return e->chain_impl == 2 || (e->chain_impl == 0 && (e->chain_rows >= 8 || (e->chain_rows == 0 && Nd >= 1024)));
 }
 int chain16_rows(ps_engine* e, int Nd) {
@@ -1498,6 +1557,7 @@ struct RadArgs {
   int cap, self_base;
   const int* cand_ok = nullptr;   // optional candidate filter (RadSet::cand_ok)
   int cand_base = 0;
+  const PeLearnW* learn = nullptr;   // the set's learnable rel-PE embedding, or nullptr (fixed Fourier rows per pe_mode)
 };
 void launch_radius(ps_engine* e, const RadArgs* a, int nsets, const float* qpos, const int* qscene, int nq, const float* src_ori,
                    const float* dst_ori, int pe_mode = 1) {
@@ -1517,14 +1577,23 @@ void launch_radius(ps_engine* e, const RadArgs* a, int nsets, const float* qpos,
   hipLaunchKernelGGL(k_exclusive_scan, dim3(nsets), dim3(1024), 0, st, rs, nq);
   hipLaunchKernelGGL(k_radius<1>, dim3(grid, nsets), dim3(64 * wpb), 0, st, rs, qpos, qscene, nq);
   PeArgs pe[2];
-  for (int i = 0; i < nsets; ++i) pe[i] = PeArgs{a[i].es, src_ori, qpos, dst_ori};
+  bool learn = false;
+  for (int i = 0; i < nsets; ++i) {
+    pe[i] = PeArgs{a[i].es, src_ori, qpos, dst_ori};
+    learn |= a[i].learn != nullptr;
+  }
+  if (learn) {   // (the two sets of a launch belong to the same part of the model: both learnable or neither)
+    launch_geo(e, pe, nsets, true);
+    for (int i = 0; i < nsets; ++i) launch_pe_learn(e, *a[i].es, *a[i].learn);
+    return;
+  }
   if (pe_mode & 1) launch_relpe(e, pe, nsets);
   if (pe_mode & 2) launch_geo(e, pe, nsets);
 }
 void launch_radius(ps_engine* e, EdgeSet& es, const int* r1, const int* r2, const float* qpos, const int* qscene, int nq, float r,
                    int cap, int self_base, const float* src_ori, const float* dst_ori, const int* cand_ok = nullptr,
-                   int cand_base = 0, int pe_mode = 1) {
-  RadArgs a{&es, r1, r2, r, cap, self_base, cand_ok, cand_base};
+                   int cand_base = 0, int pe_mode = 1, const PeLearnW* learn = nullptr) {
+  RadArgs a{&es, r1, r2, r, cap, self_base, cand_ok, cand_base, learn};
   launch_radius(e, &a, 1, qpos, qscene, nq, src_ori, dst_ori, pe_mode);
 }
 
@@ -1558,7 +1627,11 @@ extern "C" int ps_encode_scene(ps_engine* e) {
     // a2a edges index agents globally (Mv + i) for positions; kv rows are agent-local -> fixed up below
     const PeArgs pe[2] = {{&e->e_a2a, e->d_tok_ori.p, e->d_tok_pos.p + 2 * (size_t)Mv, e->d_tok_ori.p + Mv},
                           {&e->e_s2s, e->d_tok_ori.p, e->d_tok_pos.p, e->d_tok_ori.p}};
-    if (use_c16(e, Ap)) {   // the a2a layers run on k_chain16 (geometry records), the s2s layers keep the operand images
+    if (e->pe_on[0]) {   // LEARNABLE_PE: geometry records, then the edge MLP writes the (128-column) operand images
+      launch_geo(e, pe, 2, true);
+      launch_pe_learn(e, e->e_a2a, e->pe_learn[0]);
+      launch_pe_learn(e, e->e_s2s, e->pe_learn[1]);
+    } else if (use_c16(e, Ap, 0)) {   // the a2a layers run on k_chain16 (geometry records), the s2s layers keep the operand images
       launch_geo(e, &pe[0], 1);
       launch_relpe(e, &pe[1], 1);
     } else {
@@ -1571,14 +1644,14 @@ extern "C" int ps_encode_scene(ps_engine* e) {
   const bool split_s2s = !no_split && Mv + Ap >= 2048 && e->e_s2s.maxdeg <= ES_MAXDEG;
   for (int i = 0; i < c.scene_layers; ++i) {
     launch_kv(e, tok + (size_t)Mv * D, Ap, e->L_a2a + i, 1, e->d_kv.p + (size_t)Mv * 256, e->d_kh.p + (size_t)Mv * 256, 0);
-    if (use_c16(e, Ap)) {
+    if (use_c16(e, Ap, 0)) {
       if (launch_chain16(e, tok + (size_t)Mv * D, Ap, e->d_steps.p + e->step_a2a + i, 1, false, nullptr, false)) return PS_E_HIP;
     } else if (launch_chain(e, tok + (size_t)Mv * D, Ap, e->step_a2a + i, 1, e->e_a2a.maxdeg, false, nullptr, 0, 0, nullptr, xcd_on(1, false))) return PS_E_HIP;
     if (split_s2s) {
       // split layer: node work as 16-row MFMA GEMMs (k_node; its PRE half also makes the rows'
       // k | v, they are this self-attention layer's sources), the 32-neighbour edge phase one wave per token
       const ChainStep* stp = e->d_steps.p + e->step_s2s + i;
-      if (launch_split_layer(e, tok, Mv + Ap, stp, 3, e->e_s2s.maxdeg, e->d_kv.p, e->d_kh.p)) return PS_E_HIP;
+      if (launch_split_layer(e, tok, Mv + Ap, stp, e->pe_on[0] ? 4 : 3, e->e_s2s.maxdeg, e->d_kv.p, e->d_kh.p)) return PS_E_HIP;
     } else {
       launch_kv(e, tok, Mv + Ap, e->L_s2s + i, 1, e->d_kv.p, e->d_kh.p, 0);
       if (launch_chain(e, tok, Mv + Ap, e->step_s2s + i, 1, e->e_s2s.maxdeg)) return PS_E_HIP;
@@ -1613,21 +1686,21 @@ extern "C" int ps_generate_policy(ps_engine* e) {
   HIPCHK(hipMemcpyAsync(e->d_tok_pos.p + 2 * (size_t)Mv, ppos, sizeof(float) * 2 * A, hipMemcpyDeviceToDevice, st));
   HIPCHK(hipMemcpyAsync(e->d_tok_ori.p + Mv, pori, sizeof(float) * A, hipMemcpyDeviceToDevice, st));
   // (with log-replay agents in the scene only the policy agents are prompts: candidate filter)
-  const int pe_gen = use_c16(e, Ap) ? 2 : 1;   // k_chain16 rebuilds the rel-PE rows from geometry records, k_attn_chain streams operand images
+  const int pe_gen = use_c16(e, Ap, 1) ? 2 : 1;   // k_chain16 rebuilds the rel-PE rows from geometry records, k_attn_chain streams operand images
   launch_radius(e, e->e_p2p, e->d_r_agent.p, nullptr, ppos, pscene, Ap, c.dec_prompt_radius, c.dec_max_neigh, Mv, e->d_tok_ori.p, pori,
-                e->all_policy ? nullptr : (const int*)e->d_is_policy.p, Mv, pe_gen);
+                e->all_policy ? nullptr : (const int*)e->d_is_policy.p, Mv, pe_gen, pe_of(e, &e->e_p2p));
   // restore observed agent poses for the scene tokens, then s2p: radius over all scene tokens (:94)
   HIPCHK(hipMemcpyAsync(e->d_tok_pos.p + 2 * (size_t)Mv, e->d_init_pos.p, sizeof(float) * 2 * A, hipMemcpyDeviceToDevice, st));
   HIPCHK(hipMemcpyAsync(e->d_tok_ori.p + Mv, e->d_init_head.p, sizeof(float) * A, hipMemcpyDeviceToDevice, st));
   launch_radius(e, e->e_s2p, e->d_r_map.p, e->d_r_agent.p, ppos, pscene, Ap, c.dec_scene_radius, c.dec_max_neigh, -1,
-                e->d_tok_ori.p, pori, e->have_dead0 ? (const int*)e->d_live0.p : nullptr, Mv, pe_gen);
+                e->d_tok_ori.p, pori, e->have_dead0 ? (const int*)e->d_live0.p : nullptr, Mv, pe_gen, pe_of(e, &e->e_s2p));
   // k|v of the (fixed) scene tokens for all s2p layers in one launch
   launch_kv(e, e->d_tok.p, Mv + Ap, e->L_s2p, c.dec_layers, e->d_kv_s2p.p, e->d_kh_s2p.p, (size_t)(Mv + Ap) * 256);
   const int md = std::max(e->e_p2p.maxdeg, e->e_s2p.maxdeg);
   for (int i = 0; i < c.dec_layers; ++i) {
     // p2p edges carry GLOBAL agent rows (Mv + j): project into rows Mv.. of the shared kv buffer
     launch_kv(e, e->d_xp.p, Ap, e->L_p2p + i, 1, e->d_kv.p + (size_t)Mv * 256, e->d_kh.p + (size_t)Mv * 256, 0);
-    if (use_c16(e, Ap)) {
+    if (use_c16(e, Ap, 1)) {
       if (launch_chain16(e, e->d_xp.p, Ap, e->d_steps.p + e->step_dec + 2 * i, 2, false, nullptr, false)) return PS_E_HIP;
     } else if (launch_chain(e, e->d_xp.p, Ap, e->step_dec + 2 * i, 2, md, false, nullptr, 0, 0, nullptr, xcd_on(2, false))) return PS_E_HIP;
   }
@@ -1751,14 +1824,14 @@ extern "C" int ps_policy_step(ps_engine* e, int32_t t_idx) {
   {
     // (a log-replay agent that dropped out of the log at this replan is no scene token: candidate filter)
     const RadArgs ra[2] = {{&e->e_a2p, e->d_r_agent.p, nullptr, c.pol_agent_radius, c.pol_max_neigh, -1,
-                            e->all_policy ? nullptr : (const int*)e->d_tok_live.p, Mv},
-                           {&e->e_m2p, e->d_r_map.p, nullptr, c.pol_map_radius, c.pol_max_neigh, -1}};
-    launch_radius(e, ra, 2, e->d_cur_pos.p, pscene, A, e->d_tok_ori.p, e->d_cur_ori.p, use_c16(e, A) ? 2 : 1);
+                            e->all_policy ? nullptr : (const int*)e->d_tok_live.p, Mv, pe_of(e, &e->e_a2p)},
+                           {&e->e_m2p, e->d_r_map.p, nullptr, c.pol_map_radius, c.pol_max_neigh, -1, nullptr, 0, pe_of(e, &e->e_m2p)}};
+    launch_radius(e, ra, 2, e->d_cur_pos.p, pscene, A, e->d_tok_ori.p, e->d_cur_ori.p, use_c16(e, A, 2) ? 2 : 1);
   }
   const int md = std::max(e->e_a2p.maxdeg, e->e_m2p.maxdeg);
   if (e->policy_events && (int)e->pev.size() >= 2 * R) HIPCHK(hipEventRecord(e->pev[2 * t_idx], st));
   // the policy tokens enter every replan unchanged (d_emd); the fused features leave to d_fused
-  if (use_c16(e, A)) {
+  if (use_c16(e, A, 2)) {
     if (launch_chain16(e, e->d_fused.p, A, e->d_steps.p + e->step_pol, 2 * c.pol_layers, true, e->d_emd.p, xcd_on(0, true))) return PS_E_HIP;
   } else if (launch_chain(e, e->d_fused.p, A, e->step_pol, 2 * c.pol_layers, md, true, nullptr, 0, 0, e->d_emd.p, xcd_on(0, true))) return PS_E_HIP;
   if (e->policy_events && (int)e->pev.size() >= 2 * R) HIPCHK(hipEventRecord(e->pev[2 * t_idx + 1], st));
@@ -2308,6 +2381,15 @@ extern "C" int ps_policy_forward(ps_engine* e, int32_t n_scenes, int32_t Na, con
     r_agent[b + 1] += r_agent[b];
   }
   for (int b = 0; b <= n_scenes; ++b) r_agent[b] += Nm;
+  {   // the search kernels take begin / end pairs per scene
+    std::vector<int> pm(2 * n_scenes), pa(2 * n_scenes);
+    for (int b = 0; b < n_scenes; ++b) {
+      pm[2 * b] = r_map[b]; pm[2 * b + 1] = r_map[b + 1];
+      pa[2 * b] = r_agent[b]; pa[2 * b + 1] = r_agent[b + 1];
+    }
+    r_map.swap(pm);
+    r_agent.swap(pa);
+  }
   for (int i = 0; i < A; ++i) {
     if (p_type[i] < 1 || p_type[i] > c.num_agent_types) return fail(PS_E_ARG, "agent_type outside 1..num_agent_types");
     if (p_scene[i] < 0 || p_scene[i] >= n_scenes) return fail(PS_E_ARG, "policy batch_idx out of range");
@@ -2338,22 +2420,24 @@ extern "C" int ps_policy_forward(ps_engine* e, int32_t n_scenes, int32_t Na, con
   std::swap(e->d_tok_pos, d_pos);
   launch_kv(e, d_atok.p, Na, e->L_a2p, L, d_kva.p, d_kha.p, (size_t)Na * 256);
   launch_kv(e, d_mtok.p, Nm, e->L_m2p, L, d_kvm.p, d_khm.p, (size_t)Nm * 256);
-  const int pe_mode = use_c16(e, A) ? 2 : 1;
-  launch_radius(e, ea, d_ragent.p, nullptr, d_ppos.p, d_pscene.p, A, c.pol_agent_radius, c.pol_max_neigh, -1, d_ori.p, d_pori.p, nullptr, 0, pe_mode);
-  launch_radius(e, em, d_rmap.p, nullptr, d_ppos.p, d_pscene.p, A, c.pol_map_radius, c.pol_max_neigh, -1, d_ori.p, d_pori.p, nullptr, 0, pe_mode);
+  const int pe_mode = use_c16(e, A, 2) ? 2 : 1;
+  const PeLearnW* la = e->pe_on[2] ? &e->pe_learn[4] : nullptr;
+  const PeLearnW* lm = e->pe_on[2] ? &e->pe_learn[5] : nullptr;
+  launch_radius(e, ea, d_ragent.p, nullptr, d_ppos.p, d_pscene.p, A, c.pol_agent_radius, c.pol_max_neigh, -1, d_ori.p, d_pori.p, nullptr, 0, pe_mode, la);
+  launch_radius(e, em, d_rmap.p, nullptr, d_ppos.p, d_pscene.p, A, c.pol_map_radius, c.pol_max_neigh, -1, d_ori.p, d_pori.p, nullptr, 0, pe_mode, lm);
   std::vector<ChainStep> hs;
   for (int i = 0; i < L; ++i) {
     ChainStep s1;
-    s1.w = e->a2p[i]; s1.kv = d_kva.p + (size_t)i * Na * 256 - (size_t)Nm * 256; s1.eoff = ea.eoff.p; s1.esrc = ea.esrc.p; s1.toff = ea.toff.p; s1.rtT = ea.rtT.p; s1.rtA = ea.rtA.p; s1.kr = 3; s1.geo = ea.geo.p; s1.khl = d_kha.p + (size_t)i * Na * 256 - (size_t)Nm * 256;
+    s1.w = e->a2p[i]; s1.kv = d_kva.p + (size_t)i * Na * 256 - (size_t)Nm * 256; s1.eoff = ea.eoff.p; s1.esrc = ea.esrc.p; s1.toff = ea.toff.p; s1.rtT = ea.rtT.p; s1.rtA = ea.rtA.p; s1.kr = la ? 4 : 3; s1.geo = ea.geo.p; s1.khl = d_kha.p + (size_t)i * Na * 256 - (size_t)Nm * 256;
     hs.push_back(s1);
     ChainStep s2;
-    s2.w = e->m2p[i]; s2.kv = d_kvm.p + (size_t)i * Nm * 256; s2.eoff = em.eoff.p; s2.esrc = em.esrc.p; s2.toff = em.toff.p; s2.rtT = em.rtT.p; s2.rtA = em.rtA.p; s2.kr = 3; s2.geo = em.geo.p; s2.khl = d_khm.p + (size_t)i * Nm * 256;
+    s2.w = e->m2p[i]; s2.kv = d_kvm.p + (size_t)i * Nm * 256; s2.eoff = em.eoff.p; s2.esrc = em.esrc.p; s2.toff = em.toff.p; s2.rtT = em.rtT.p; s2.rtA = em.rtA.p; s2.kr = lm ? 4 : 3; s2.geo = em.geo.p; s2.khl = d_khm.p + (size_t)i * Nm * 256;
     hs.push_back(s2);
   }
   int rc = 0;
   if (upload(d_steps, hs.data(), hs.size(), st)) rc = fail(PS_E_HIP, "step upload failed");
-  if (!rc) rc = use_c16(e, A) ? launch_chain16(e, d_x.p, A, d_steps.p, 2 * L, false, nullptr, false)
-                                   : launch_chain(e, d_x.p, A, 0, 2 * L, std::max(da, dm), false, d_steps.p);
+  if (!rc) rc = use_c16(e, A, 2) ? launch_chain16(e, d_x.p, A, d_steps.p, 2 * L, false, nullptr, false)
+                                      : launch_chain(e, d_x.p, A, 0, 2 * L, std::max(da, dm), false, d_steps.p, 0, la ? 4 : 0);
   if (!rc) {
     // head with a neutral state (last pose = origin, heading 0): only motion_pred is read back
     (void)hipMemsetAsync(d_traj.p, 0, sizeof(float) * (size_t)A * 16 * 4, st);

@@ -83,8 +83,10 @@ struct GeoSet {
 struct GeoSets {
   GeoSet s[2];
 };
+// raw != 0: the three inputs as they are (dist, rel_ori, angle), no Fourier statistics -- what the learnable embedding
+// (ps_pe_learn.h) consumes.
 __global__ __launch_bounds__(256) void k_edge_geo(GeoSets sets, const float* __restrict__ src_pos, const float* __restrict__ div32,
-                                                 float eps) {
+                                                 float eps, int raw) {
   const GeoSet& S = sets.s[blockIdx.y];
   const int E = S.eoff[S.nq];
   float dv[16], rdv[16];
@@ -104,6 +106,14 @@ __global__ __launch_bounds__(256) void k_edge_geo(GeoSets sets, const float* __r
     // torch's .sum(dim=-1) accumulates from +0, so a dot of (-0, -0) is +0 there: keep the explicit 0.f + ...
     const float dot = (0.f + cx * dx) + cy * dy;
     xin[2] = atan2f(cx * dy - cy * dx, dot);
+    if (raw) {
+      EdgeGeo g;
+      g.a0 = xin[0]; g.a1 = xin[1]; g.a2 = xin[2];
+      g.rstd = 0.f; g.nmr = 0.f;
+      g.src = s; g.pad0 = 0; g.pad1 = 0;
+      S.geo[e] = g;
+      continue;
+    }
     float xs[3];
     bool fast = true;
 #pragma unroll

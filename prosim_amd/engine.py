@@ -38,6 +38,8 @@ class PsConfig(C.Structure):
         ("replan_freq", C.c_int32), ("max_steps", C.c_int32),
         ("dt", C.c_float), ("ln_eps", C.c_float),
         ("device", C.c_int32),
+        ("enc_learnable_pe", C.c_int32), ("dec_learnable_pe", C.c_int32), ("pol_learnable_pe", C.c_int32),
+        ("pe_num_freq", C.c_int32),
     ]
 
 
@@ -156,7 +158,9 @@ class Engine:
                        obs_pre_layers=spec.obs_pre_layers, obs_mlp_layers=spec.obs_mlp_layers,
                        target_steps=spec.target_steps, state_dim=spec.state_dim, motion_k=spec.motion_k,
                        num_agent_types=spec.num_agent_types, prompt_dim=spec.prompt_dim, replan_freq=spec.replan_freq,
-                       max_steps=spec.max_steps, dt=spec.dt, ln_eps=spec.ln_eps, device=device)
+                       max_steps=spec.max_steps, dt=spec.dt, ln_eps=spec.ln_eps, device=device,
+                       enc_learnable_pe=int(spec.enc_learnable_pe), dec_learnable_pe=int(spec.dec_learnable_pe),
+                       pol_learnable_pe=int(spec.pol_learnable_pe), pe_num_freq=spec.pe_num_freq)
         tensors = dict(weights)
         tensors.update(fourier_tables())
         names = sorted(tensors)

@@ -85,6 +85,14 @@ class ModelSpec:
     dt: float = 0.1                    # DATASET.MOTION.DT
     ln_eps: float = 1e-5
     fourier_temperature: float = 10000.0
+    # *.ATTN.LEARNABLE_PE / PE_NUM_FREQ (default.py:472-473, :594-595, :665-666; False in the demo, no_text.yaml:229,246,273):
+    # the relative-PE rows of the scene encoder's (a2a, s2s), the generator's (p2p, s2p) and the policy's (a2p, m2p)
+    # edge sets come from a learnable FourierEmbedding (layers/fourier_embedding.py:11-54) over 3 inputs instead of the
+    # fixed FourierEmbeddingFix over 4.  The condition layers always use the fixed one (condition_attns.py:93).
+    enc_learnable_pe: bool = False
+    dec_learnable_pe: bool = False
+    pol_learnable_pe: bool = False
+    pe_num_freq: int = 64
 
     @property
     def agent_knn(self) -> int:

@@ -93,6 +93,35 @@ def _attn_shapes(out: Dict, prefix: str, d: int, hd: int, bipartite: bool) -> No
         out[f"{prefix}.{n}.bias"] = (d,)
 
 
+def _pe_emb_shapes(out: Dict, prefix: str, d: int, nf: int) -> None:
+    """FourierEmbedding(input_dim=3, hidden_dim=d, num_freq_bands=nf) (layers/fourier_embedding.py:11-35)."""
+    out[f"{prefix}.freqs.weight"] = (3, nf)
+    for i in range(3):
+        out[f"{prefix}.mlps.{i}.0.weight"] = (d, 2 * nf + 1)
+        out[f"{prefix}.mlps.{i}.0.bias"] = (d,)
+        out[f"{prefix}.mlps.{i}.1.weight"] = (d,)
+        out[f"{prefix}.mlps.{i}.1.bias"] = (d,)
+        out[f"{prefix}.mlps.{i}.3.weight"] = (d, d)
+        out[f"{prefix}.mlps.{i}.3.bias"] = (d,)
+    out[f"{prefix}.to_out.0.weight"] = (d,)
+    out[f"{prefix}.to_out.0.bias"] = (d,)
+    out[f"{prefix}.to_out.2.weight"] = (d, d)
+    out[f"{prefix}.to_out.2.bias"] = (d,)
+
+
+def pe_emb_prefixes(spec: ModelSpec) -> List[str]:
+    """State-dict prefixes of the learnable relative-PE embeddings this spec has (attn_fusion.py:24-26,
+    sym_coord.py:22-24, act_decoder.py:181-183)."""
+    out = []
+    if spec.enc_learnable_pe:
+        out += ["scene_encoder.a2a_rel_pe_emb", "scene_encoder.s2s_rel_pe_emb"]
+    if spec.dec_learnable_pe:
+        out += ["decoder.p2p_rel_pe_emb", "decoder.s2p_rel_pe_emb"]
+    if spec.pol_learnable_pe:
+        out += ["policy.act_decoder.a2p_rel_pe_emb", "policy.act_decoder.m2p_rel_pe_emb"]
+    return out
+
+
 def param_shapes(spec: ModelSpec) -> "OrderedDict[str, Tuple[int, ...]]":
     """Every learnable tensor on the rollout path, reference state_dict naming.
 
@@ -142,12 +171,15 @@ def param_shapes(spec: ModelSpec) -> "OrderedDict[str, Tuple[int, ...]]":
     # DragPointEncoder (condition_encoders.py:152-191): a PointNet over the [x, y] drag points
     if spec.drag_mlp_layers > 0:   # 0: a checkpoint trained without 'drag_point' in PROMPT.CONDITION.TYPES
         _pointnet_shapes(out, f"{ct}.{DRAG_ENCODER}", 2, d, spec.drag_pre_layers, spec.drag_mlp_layers)
+    for prefix in pe_emb_prefixes(spec):
+        _pe_emb_shapes(out, prefix, d, spec.pe_num_freq)
     return out
 
 
 DRAG_ENCODER = "condition_encoders.drag_point.pointnet_encoder"
 OBS_UPDATE_MLP = "scene_encoder.obs_update_mlp"
-_LATE = (DRAG_ENCODER, OBS_UPDATE_MLP)   # tensor groups added after the first fixtures: each draws from its own generator
+PE_EMB = "_rel_pe_emb."
+_LATE = (DRAG_ENCODER, OBS_UPDATE_MLP, PE_EMB)   # tensor groups added after the first fixtures: each draws from its own generator
 
 
 def init_weights(spec: ModelSpec, seed: int = 0) -> Dict[str, np.ndarray]:
@@ -166,16 +198,19 @@ def init_weights(spec: ModelSpec, seed: int = 0) -> Dict[str, np.ndarray]:
     for name in sorted(shapes, key=lambda n: (late(n), n)):
         g = g_late[late(name)] if late(name) >= 0 else g_main
         shp = shapes[name]
+        pe_ln = PE_EMB in name and (".1." in name.split(PE_EMB)[1] or "to_out.0." in name)
         is_ln = len(shp) == 1 and name.endswith(".weight") and (
-            "norm" in name or ".MLP.1." in name or _is_mlp_ln(name, shapes))
+            "norm" in name or ".MLP.1." in name or _is_mlp_ln(name, shapes) or pe_ln)
         is_ln_bias = len(shp) == 1 and name.endswith(".bias") and (
-            "norm" in name or ".MLP.1." in name or _is_mlp_ln(name[:-5] + ".weight", shapes))
+            "norm" in name or ".MLP.1." in name or _is_mlp_ln(name[:-5] + ".weight", shapes) or pe_ln)
         if is_ln:
             t = 1.0 + 0.1 * torch.randn(shp, generator=g)
         elif is_ln_bias:
             t = 0.1 * torch.randn(shp, generator=g)
         elif "motion_anchors" in name or "tag_encoder" in name:
             t = torch.randn(shp, generator=g)
+        elif name.endswith(".freqs.weight"):   # (the reference initialises N(0, 0.02), weight_init.py:18-19; wider here so
+            t = 0.05 * torch.randn(shp, generator=g)   # that a 100 m distance sweeps several periods)
         elif len(shp) == 2:
             bound = 1.0 / np.sqrt(shp[1])
             t = (torch.rand(shp, generator=g) * 2 - 1) * bound

@@ -296,3 +296,46 @@ def test_bench_two_ranks_on_one_gpu():
     for k, v in one["rollout_metrics"].items():      # scenes 0..3 either way (i % 2 sharding): identical sums up to order
         assert abs(two["rollout_metrics"][k] - v) <= 1e-5 * max(1.0, abs(v)), (k, two["rollout_metrics"][k], v)
     assert abs(two["value"] - 4 * 128 * 80 / (two["ms_per_step"] * 1e-3)) < 1e-3 * two["value"]
+
+
+# ------------------------------------------------------------------ (f4) learnable relative positional encoding
+@pytest.mark.parametrize("shape", ["small", "split_s2s", "policy_only"])
+def test_learnable_rel_pe_vs_oracle(shape):
+    """*.ATTN.LEARNABLE_PE (layers/fourier_embedding.py:11-54): the edge-MLP kernel (k_pe_learn) behind every edge set of the
+    scene encoder, the generator and the policy -- stage outputs and the closed loop against the fp64 oracle (the oracle is
+    pinned to the reference by tests/golden/ref_standins_small_lpe_b2.npz, which test_hip_parity checks as well).
+    'split_s2s': >= 2048 scene tokens, the s2s layers take the split launches with 128-column rows; 'policy_only': the
+    flags are independent per part of the model."""
+    from gen_golden import SPECS
+    from prosim_amd.engine import Engine
+    spec = SPECS["small_lpe"]
+    if shape == "policy_only":
+        spec = spec.replace(enc_learnable_pe=False, dec_learnable_pe=False)
+    w = weights.init_weights(spec, 0)
+    if shape == "split_s2s":
+        scene = synth.make_scene(spec, 40, 1100, batch=2, seed=31, goal=True, ragged=True)
+    else:
+        scene = synth.make_scene(spec, 24, 90, batch=3, seed=30, goal=True, tags=True, ragged=True, replay=0.2)
+    with torch.no_grad():
+        o64 = orc.rollout(w, spec, scene, dtype=torch.float64, collect=True)
+        o32 = orc.rollout(w, spec, scene, dtype=torch.float32)
+    floor = float((o32["traj"].double() - o64["traj"]).abs().max())
+    eng = Engine(spec, w)
+    try:
+        eng.set_scene(scene)
+        if shape == "split_s2s":
+            assert eng.num_agents + eng.num_map_tokens >= 2048
+        eng.encode_scene()
+        assert err(eng.get("scene_tokens"), o64["trace"]["scene_tokens"].numpy()) < TOL
+        eng.generate_policy()
+        pm = scene["prompt_mask"].astype(bool)
+        assert err(eng.padded("policy_emd")[pm], o64["policy_emd"].numpy()[pm]) < 2 * TOL
+        eng.rollout()
+        pol = eng.policy_rows
+        e0 = err(eng.get("motion_pred")[0][pol], o64["motion_pred"][:int(pol.sum())].numpy())
+        assert e0 < TOL
+        d = np.abs(eng.padded("traj") - o64["traj"].numpy())[pm].reshape(int(pm.sum()), -1).max(1)
+        record(f"learnable_pe/{shape}", replan0_max=e0, fp32_floor=floor, **per_agent(d))
+        assert d.max() < 3 * floor + TOL and np.median(d) < floor + TOL, (d.max(), floor)
+    finally:
+        eng.close()
