@@ -169,6 +169,12 @@ int ps_sync(ps_engine* e);
  * ps_set_scene.  ps_policy_step does this on the device from the simulated state; this entry point serves callers
  * that drive the encoder by hand.  Read the tokens back with ps_get("scene_tokens"). */
 int ps_update_obs(ps_engine* e, const float* obs_input, const uint8_t* obs_mask, const float* obs_pos, const float* obs_head);
+/* update_scene_emb with ANOTHER agent set (_replace_old_obs, attn_fusion.py:205-236: the map part of scene_embs is kept, the
+ * agent part is whatever the new observation lists): the caller reads the map tokens (ps_get "scene_tokens", first
+ * ps_num_map_tokens rows), uploads the new batch with ps_set_scene (same map arrays), hands the map tokens back with this
+ * call -- tokens [ps_num_map_tokens, hidden] on the HOST -- and re-encodes the agents with ps_update_obs.  The scene then
+ * counts as encoded. */
+int ps_set_map_tokens(ps_engine* e, const float* tokens, int64_t count);
 /* Destination rows per workgroup of the fused attention launches = the engine's operating mode:
  *   0       latency mode, ONE rollout on the GPU: from 1024 destination rows up the fused chains run on k_chain16 with 4 rows
  *           per 8-wave workgroup (256 workgroups per 1024-row policy launch, two waves per row); smaller launches on

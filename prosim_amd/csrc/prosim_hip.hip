@@ -1957,6 +1957,23 @@ extern "C" int ps_update_obs(ps_engine* e, const float* obs_input, const uint8_t
   return PS_OK;
 }
 
+// The map tokens of an encoded scene, handed back after a ps_set_scene with the SAME map and ANOTHER agent set:
+// update_scene_emb keeps the map part of scene_embs and takes whatever agents the new observation lists
+// (_replace_old_obs, attn_fusion.py:205-236).  Marks the scene encoded; the agent tokens are whatever the next
+// ps_update_obs makes them.
+extern "C" int ps_set_map_tokens(ps_engine* e, const float* tokens, int64_t count) {
+  if (!e || !e->have_scene) return fail(PS_E_STATE, "ps_set_map_tokens before ps_set_scene");
+  if (!tokens || count != (int64_t)e->Mv * D) return fail(PS_E_ARG, "ps_set_map_tokens: expected [map tokens, hidden] floats");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  HIPCHK(hipMemcpyAsync(e->d_tok.p, tokens, sizeof(float) * (size_t)count, hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipMemsetAsync(e->d_tok.p + (size_t)e->Mv * D, 0, sizeof(float) * (size_t)e->A * D, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  e->encoded = true;
+  e->generated = false;
+  drop_graph(e);
+  return PS_OK;
+}
+
 extern "C" int ps_set_chain_rows(ps_engine* e, int32_t rows) {
   if (!e) return fail(PS_E_ARG, "null engine");
   if (rows < 0 || rows > 16 || (rows < 8 && rows != 0 && rows != 1 && rows != 2 && rows != 4)) return fail(PS_E_ARG, "ps_set_chain_rows: 0 (auto), 1, 2, 4, or 8..16");

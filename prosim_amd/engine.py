@@ -78,6 +78,7 @@ def load_library():
     lib.ps_num_policy_agents.argtypes = [vp]
     lib.ps_num_policy_agents.restype = C.c_int32
     lib.ps_update_obs.argtypes = [vp, fp, u8p, fp, fp]
+    lib.ps_set_map_tokens.argtypes = [vp, fp, C.c_int64]
     lib.ps_declare_agent_rows.argtypes = [vp, C.c_int32, C.c_int32, u8p]
     lib.ps_set_chain_rows.argtypes = [vp, C.c_int32]
     lib.ps_set_chain_impl.argtypes = [vp, C.c_int32]
@@ -110,7 +111,7 @@ def load_library():
 
 
 EXPORTS = ["ps_create", "ps_destroy", "ps_last_error", "ps_set_scene", "ps_set_prompt", "ps_policy_forward", "ps_set_conditions", "ps_set_drag_points", "ps_set_future_obs", "ps_set_future_log", "ps_set_mode_choice", "ps_set_replicas", "ps_num_replicas", "ps_world_trajs", "ps_num_policy_agents", "ps_policy_flags",
-           "ps_encode_scene", "ps_generate_policy", "ps_reset_rollout", "ps_policy_step", "ps_rollout", "ps_sync", "ps_stream", "ps_set_chain_rows", "ps_set_chain_impl", "ps_enable_policy_events", "ps_policy_event_times", "ps_update_obs", "ps_declare_agent_rows",
+           "ps_encode_scene", "ps_generate_policy", "ps_reset_rollout", "ps_policy_step", "ps_rollout", "ps_sync", "ps_stream", "ps_set_chain_rows", "ps_set_chain_impl", "ps_enable_policy_events", "ps_policy_event_times", "ps_update_obs", "ps_set_map_tokens", "ps_declare_agent_rows",
            "ps_set_state", "ps_get", "ps_rollout_metric", "ps_pair_metric", "ps_num_agents", "ps_num_map_tokens", "ps_time_rollout", "ps_time_policy_kernel",
            "ps_test_pointnet", "ps_test_fourier", "ps_test_wrap", "ps_test_attn", "ps_test_get_edges", "ps_test_stream"]
 
@@ -341,6 +342,12 @@ class Engine:
         if a[0].shape[:2] != self._shape or a[1].shape != a[0].shape:
             raise ValueError("update_obs: the observation must keep the [B, N] layout of set_scene")
         self._check(self.lib.ps_update_obs(self.h, _f(a[0]), _u8(a[1]), _f(a[2]), _f(a[3])))
+
+    def set_map_tokens(self, tokens: np.ndarray):
+        """Hand the map tokens of an encoded scene back after a ``set_scene`` with the same map and another agent set
+        (update_scene_emb with a changing agent set); the agents are then re-encoded with ``update_obs``."""
+        t = np.ascontiguousarray(tokens, np.float32)
+        self._check(self.lib.ps_set_map_tokens(self.h, _f(t), t.size))
 
     def policy_step(self, t_idx: int):
         self._check(self.lib.ps_policy_step(self.h, t_idx))

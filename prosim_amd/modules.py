@@ -266,16 +266,34 @@ class HipSceneEncoder:
     def update_scene_emb(self, scene_embs, batch_obs, old_obs_agent_ids):
         """``update_scene_emb`` (attn_fusion.py:238-252) for the demo config's OBS_UPDATE (FUSION 'replace', ATTN_UPDATE
         False): agents re-encoded from ``batch_obs``, map tokens reused.  Inside a rollout the engine does this on
-        the device (ps_policy_step); this call serves code that drives the encoder itself."""
+        the device (ps_policy_step); this call serves code that drives the encoder itself.  The agents of ``batch_obs``
+        may be ANY set (``_replace_old_obs`` :205-236 takes whatever the new observation lists -- agents that left are
+        gone, new ones are there, in the new order): the engine is then given the new batch and the old map tokens."""
         if not scene_embs.get("_hip_resident") or self.s.scene is None:
             raise ValueError("scene_embs must come from HipSceneEncoder (tokens are device-resident)")
+        eng, old = self.s.engine, self.s.scene
         new_ids = _g(batch_obs, "agent_ids")
-        if new_ids is not None and old_obs_agent_ids is not None and [list(a) for a in new_ids] != [list(a) for a in old_obs_agent_ids]:
-            raise NotImplementedError("update_scene_emb: agents entering or leaving the scene between replans are not built")
-        scene = dict(self.s.scene)
-        scene.update(obs_input=_np(_g(batch_obs, "input")), obs_mask=_np(_g(batch_obs, "mask"), bool),
-                     obs_pos=_np(_g(batch_obs, "position")), obs_head=_np(_g(batch_obs, "heading")).reshape(scene["obs_head"].shape))
-        self.s.engine.update_obs(scene["obs_input"], scene["obs_mask"], scene["obs_pos"], scene["obs_head"])
+        obs_in, obs_mask = _np(_g(batch_obs, "input")), _np(_g(batch_obs, "mask"), bool)
+        B, N = obs_in.shape[:2]
+        same = (new_ids is None or old_obs_agent_ids is None or [list(a) for a in new_ids] == [list(a) for a in old_obs_agent_ids]) \
+            and obs_in.shape[:2] == old["obs_input"].shape[:2] \
+            and np.array_equal(obs_mask.all(-1).any(-1), old["obs_mask"].astype(bool).all(-1).any(-1))
+        scene = dict(old)
+        scene.update(obs_input=obs_in, obs_mask=obs_mask, obs_pos=_np(_g(batch_obs, "position")),
+                     obs_head=_np(_g(batch_obs, "heading")).reshape(B, N))
+        if not same:
+            # another agent set: upload the new batch (same map), give the map tokens back, re-encode the agents
+            map_tok = eng.get("scene_tokens")[:eng.num_map_tokens]
+            valid = obs_mask.all(-1).any(-1)
+            if not valid.any(1).all():
+                raise ValueError("update_scene_emb: a scene of the new observation has no observed agent")
+            scene.update(prompt=np.zeros((B, N, self.s.spec.prompt_dim), np.float32), prompt_mask=valid,
+                         agent_type=np.ones((B, N), np.int64), _obs_ids=new_ids)
+            for k in ("prompt_pos", "prompt_head", "cond", "mode_choice", "fut_obs_input", "fut_obs_mask", "fut_obs_pos", "fut_obs_head", "_policy_slots"):
+                scene.pop(k, None)
+            eng.set_scene(scene)
+            eng.set_map_tokens(map_tok)
+        eng.update_obs(scene["obs_input"], scene["obs_mask"], scene["obs_pos"], scene["obs_head"])
         self.s.scene = scene
         return self._result(scene)
 

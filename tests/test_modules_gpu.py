@@ -289,6 +289,26 @@ def test_staged_components_and_stateless_policy(model):
     assert err(se2["scene_tokens"][Mv:].numpy(), emb[valid].numpy()) < 1e-4
     assert err(se2["scene_pos"][Mv:].numpy(), new_obs["position"][valid].numpy()) == 0
     assert err(se2["scene_tokens"][Mv:].numpy(), se["scene_tokens"][Mv:].numpy()) > 1e-2   # and they did change
-    moved = dict(new_obs, agent_ids=[list(reversed(a)) for a in batch["init_obs"]["agent_ids"]])
-    with pytest.raises(NotImplementedError):
-        model.scene_encoder.update_scene_emb(se2, moved, batch["init_obs"]["agent_ids"])
+    # ... with ANOTHER agent set (_replace_old_obs :205-236 takes whatever the new observation lists): per scene the first
+    # agent has left, the others arrive in reversed order, and one that was never seen enters (a copy of an agent, moved)
+    ids0 = batch["init_obs"]["agent_ids"]
+    B_, N_ = new_obs["input"].shape[:2]
+    cnt = new_obs["mask"].all(-1).any(-1).sum(1)
+    ch = {k: torch.zeros_like(new_obs[k]) for k in ("input", "mask", "position", "heading")}
+    ch_ids = []
+    for b_ in range(B_):
+        order = list(range(int(cnt[b_]) - 1, 0, -1))                     # agents 1.. reversed; agent 0 is gone
+        n = len(order)
+        for k in ch:
+            ch[k][b_, :n] = new_obs[k][b_, order]
+            ch[k][b_, n] = new_obs[k][b_, order[0]]                          # the newcomer: same history ...
+        ch["position"][b_, n] += 7.0                                         # ... elsewhere
+        ch_ids.append([ids0[b_][j] for j in order] + ["newcomer"])
+    changed = dict(new_obs, agent_ids=ch_ids, **ch)
+    se3 = model.scene_encoder.update_scene_emb(se2, changed, ids0)
+    emb3, valid3 = orc.encode_obs(Wt, spec, torch.nan_to_num(changed["input"]), changed["mask"])
+    assert int(valid3.sum()) == int(cnt.sum()) and se3["scene_tokens"].shape[0] == Mv + int(valid3.sum())
+    assert torch.equal(se3["scene_tokens"][:Mv], se["scene_tokens"][:Mv])               # the map tokens are still the encoder's
+    assert err(se3["scene_tokens"][Mv:].numpy(), emb3[valid3].numpy()) < 1e-4
+    assert err(se3["scene_pos"][Mv:].numpy(), changed["position"][valid3].numpy()) == 0
+    assert torch.equal(se3["scene_batch_idx"][Mv:], orc._flat_batch_idx(valid3))
