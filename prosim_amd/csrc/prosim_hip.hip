@@ -683,10 +683,11 @@ extern "C" int ps_create(const ps_config* cfg, int32_t n_tensors, const char* co
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_chain<1, 4, 3, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_chain<2, 4, 3, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_chain<4, 4, 3, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain16<8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c16_lds_bytes<8>());
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain16<8, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c16_lds_bytes<8>());
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain16<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c16_lds_bytes<4>());
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain16<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c16_lds_bytes<4>());
+#define PS_C16_ATTR(NWW, POL, ONE) \
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain16<NWW, POL, ONE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c16_lds_bytes<NWW>())
+  PS_C16_ATTR(8, true, true); PS_C16_ATTR(8, true, false); PS_C16_ATTR(8, false, true); PS_C16_ATTR(8, false, false);
+  PS_C16_ATTR(4, true, true); PS_C16_ATTR(4, true, false); PS_C16_ATTR(4, false, true); PS_C16_ATTR(4, false, false);
+#undef PS_C16_ATTR
 #define PS_ATTR(TT, NWW, KRR) \
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_chain<TT, NWW, KRR>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
   PS_ATTR(1, 4, 3); PS_ATTR(2, 4, 3); PS_ATTR(4, 4, 3); PS_ATTR(4, 8, 3);
@@ -1515,13 +1516,15 @@ int launch_chain16(ps_engine* e, float* x, int Nd, const ChainStep* steps, int n
     if (d_prof) (void)hipMemsetAsync(d_prof, 0, 48 * sizeof(unsigned long long), st);
     prof = d_prof;
   }
-#define PS_C16(NWW, POL) \
-  hipLaunchKernelGGL((k_chain16<NWW, POL>), grid, dim3(64 * NWW), c16_lds_bytes<NWW>(), st, x, x_in, Nd, rows, steps, nsteps, io, e->div32, e->cfg.ln_eps, xcd ? 1 : 0, prof)
+#define PS_C16_(NWW, POL, ONE) \
+  hipLaunchKernelGGL((k_chain16<NWW, POL, ONE>), grid, dim3(64 * NWW), c16_lds_bytes<NWW>(), st, x, x_in, Nd, rows, steps, nsteps, io, e->div32, e->cfg.ln_eps, xcd ? 1 : 0, prof)
+#define PS_C16(NWW, POL) do { if (W == 1) PS_C16_(NWW, POL, true); else PS_C16_(NWW, POL, false); } while (0)
   if (nw == 8) {
     if (timed) PS_C16(8, true); else PS_C16(8, false);
   } else {
     if (timed) PS_C16(4, true); else PS_C16(4, false);
   }
+#undef PS_C16_
 #undef PS_C16
   if (timed && e->time_chain) {
     (void)hipEventRecord(e->ev1, st);

@@ -167,7 +167,8 @@ constexpr int C16_FS = 112;   // feature-tile row stride in halfs: 96 features +
                               // half-wave's transposed read touches (and the 8 rows of a b128 write group) fall on distinct banks
 constexpr size_t C16_NODE_BYTES = ND_LDS_BYTES;
 constexpr size_t C16_PLANES_BYTES = (size_t)2 * ND_ROWS * ND_AS * 2 + (size_t)2 * ND_ROWS * ND_AS5 * 2 + (size_t)ND_ROWS * ND_CS * 4;   // P0 | P1 | C
-constexpr size_t C16_WAVE_BYTES = 4096 + 512 + (size_t)16 * C16_FS * 2 + 128;
+constexpr size_t C16_STASH_OFF = 4096 + 512 + (size_t)16 * C16_FS * 2 + 128;   // 32 x float4 a_v + 8 x (m, l): the even tiles' sums of a row (ONEW)
+constexpr size_t C16_WAVE_BYTES = C16_STASH_OFF + 512 + 64;
 // q~ (PRE -> edge phase) and the edge phase's a_r sums (-> POST) stay in LDS: 16 slots of [8 heads][96 (+4)] floats.  One
 // wave per row: the row's a_r overwrites its q~ (slot = row).  W waves per row (rows <= 4): a_r slots row * W + part (8 at
 // most), q~ of row r in slot 8 + r.  Slot stride 808 floats = 8 mod 64: the 16 rows of a fold A-fragment read spread over
@@ -220,7 +221,14 @@ __device__ __forceinline__ void feat_slow_row(float a0, float a1, float a2, floa
 // the layer loop its register pressure makes the allocator spill the weight-fragment ring of the node GEMMs; as a
 // function it gets an allocation of its own.  smem = the workgroup's dynamic LDS (wave areas from its start), AG / CQ /
 // ctr = the node phase's q rows, <q, kb> and the row counter.
-template <int NWV>
+//
+// ONE summation order for every tiling from 4 rows per workgroup up: a row's 16-edge tiles are ALWAYS split by parity into
+// two partial softmax sums that are merged as (even, odd).  With W = 2 (4 rows per workgroup: latency mode) two waves take
+// one parity each and the POST half merges their partials.  ONEW (W = 1: 8 .. 16 rows per workgroup, throughput mode):
+// the one wave of a row walks the even tiles, parks their sums (a_r in the row's LDS slot, a_v / m / l in a wave-private
+// stash), walks the odd tiles in the same software pipeline (the first odd tile is prefetched under the last even one),
+// and merges with the POST half's own operations -- so both modes return bit-identical results.
+template <int NWV, bool ONEW>
 __device__ __noinline__ void c16_edge_phase(const ChainStep* __restrict__ stp, EdgeIO io, unsigned char* c16_smem, const float* AG,
                                             const float* CQ, int* ctr, float* QA, const float* __restrict__ div32, int row0, int nrows, int W, int Nd,
                                             unsigned long long* __restrict__ prof) {
@@ -276,7 +284,8 @@ __device__ __noinline__ void c16_edge_phase(const ChainStep* __restrict__ stp, E
         const int r = row0 + lr;
         const int e_beg = ldgi(st.eoff + r);
         const int deg = ldgi(st.eoff + r + 1) - e_beg;
-        const int tstep = 16 * W;
+        const int tstep = ONEW ? 32 : 16 * W;
+        const bool two = ONEW && deg > 16;   // the row has odd tiles: two partial sums
         // Tiles of 16 edges (one score block).  Tile t0's geometry and source rows are requested one tile ahead (registers).
         int t0 = 16 * part;
         float4 ng;
@@ -342,14 +351,19 @@ __device__ __noinline__ void c16_edge_phase(const ChainStep* __restrict__ stp, E
           if (lane < 16) Ss[lane] = nsrc;
           kload(t0, 0);
         }
+        float* stash = reinterpret_cast<float*>(wbase + C16_STASH_OFF);
 #pragma unroll 1
-        for (; t0 < deg; t0 += tstep) {
+        for (int tn = 0; t0 < deg; t0 = tn) {
           const int n = min(16, deg - t0);
+          // the tile after this one: same parity, or (ONEW) the first odd tile after the last even one
+          tn = t0 + tstep;
+          const bool turn = two && tn >= deg && (t0 & 16) == 0;
+          if (turn) tn = 16;
           // this tile's records (requested a tile ago); the next tile's leave now
           const float4 g0 = ng;
           const float nmr = nn;
           const int* Sc = Ss + 16 * sb;
-          prefetch(t0 + tstep);
+          prefetch(tn);
           C16_EMARK(4);
           if (prof && threadIdx.x == 0) atomicAdd(prof + 12, 1ull);
           float sreg[4];
@@ -389,9 +403,9 @@ __device__ __noinline__ void c16_edge_phase(const ChainStep* __restrict__ stp, E
             for (int ks = 0; ks < 4; ++ks) stw[4 * (ks ^ swa)] = nkl[ks];
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) ak[ks] = str[4 * (ks ^ sra)];
-            if (t0 + tstep < deg) {   // the next tile's source rows arrived with the prefetch: publish them, request its k rows
+            if (tn < deg) {   // the next tile's source rows arrived with the prefetch: publish them, request its k rows
               if (lane < 16) Ss[16 * (sb ^ 1) + lane] = nsrc;
-              kload(t0 + tstep, sb ^ 1);
+              kload(tn, sb ^ 1);
             }
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
@@ -479,15 +493,70 @@ __device__ __noinline__ void c16_edge_phase(const ChainStep* __restrict__ stp, E
             av.w = fmaf(ph, vv[j].w, av.w);
           }
           sb ^= 1;
+          if (ONEW && turn) {   // the even tiles are done: park their sums, start the odd tiles' from zero
+            av.x += __shfl_xor(av.x, 32); av.y += __shfl_xor(av.y, 32); av.z += __shfl_xor(av.z, 32); av.w += __shfl_xor(av.w, 32);
+            if (lane < 32) *reinterpret_cast<float4*>(stash + 4 * lane) = av;
+            if (lane < 8) { stash[128 + 2 * lane] = m_run; stash[128 + 2 * lane + 1] = l_run; }
+#pragma unroll
+            for (int cb = 0; cb < 6; cb += 2) {
+#pragma unroll
+              for (int r4 = 0; r4 < 4; ++r4) {
+                const float v = swap_add32(ar[cb][r4], ar[cb + 1][r4]);
+                QA[lr * C16_QSL + (4 * ((lane >> 4) & 1) + r4) * C16_QH + (cb + (lane >> 5)) * 16 + (lane & 15)] = v;
+              }
+            }
+            m_run = -INFINITY;
+            l_run = 0.f;
+#pragma unroll
+            for (int cb = 0; cb < 6; ++cb) ar[cb] = floatx4{0.f, 0.f, 0.f, 0.f};
+            av = make_float4(0.f, 0.f, 0.f, 0.f);
+          }
         }
         C16_EMARK(9);
         // ---- the row's (partial) sums leave for the POST half: slot = part * Nd + row
         const size_t slot = (size_t)part * Nd + r;
+        av.x += __shfl_xor(av.x, 32); av.y += __shfl_xor(av.y, 32); av.z += __shfl_xor(av.z, 32); av.w += __shfl_xor(av.w, 32);
+        if (ONEW && two) {   // merge (even, odd) with the operations of the POST half's merge of two waves' partials
+          const float m0 = stash[128 + 2 * (lane & 7)], l0 = stash[128 + 2 * (lane & 7) + 1];   // head lane & 7
+          const float mh = __shfl(m_run, lane & 7), lh = __shfl(l_run, lane & 7);              // (lane h holds head h)
+          float mm = -INFINITY;
+          mm = fmaxf(mm, m0);
+          mm = fmaxf(mm, mh);
+          const float sc0 = (m0 == -INFINITY) ? 0.f : exp2f(m0 - mm);
+          const float sc1 = (mh == -INFINITY) ? 0.f : exp2f(mh - mm);
+          float lm = 0.f;
+          lm = fmaf(l0, sc0, lm);
+          lm = fmaf(lh, sc1, lm);
+          if (lane < 8) io.l[slot * 8 + lane] = lm;
+          {
+            const float s0 = __shfl(sc0, hv), s1 = __shfl(sc1, hv);   // a_v columns 4 (lane & 31) ..+3 belong to head hv
+            if (lane < 32) {
+              const float4 a0 = *reinterpret_cast<const float4*>(stash + 4 * lane);
+              float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+              o.x = fmaf(a0.x, s0, o.x); o.y = fmaf(a0.y, s0, o.y); o.z = fmaf(a0.z, s0, o.z); o.w = fmaf(a0.w, s0, o.w);
+              o.x = fmaf(av.x, s1, o.x); o.y = fmaf(av.y, s1, o.y); o.z = fmaf(av.z, s1, o.z); o.w = fmaf(av.w, s1, o.w);
+              *reinterpret_cast<float4*>(io.av + slot * 128 + 4 * lane) = o;
+            }
+          }
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4) {
+            const int hh = 4 * ((lane >> 4) & 1) + r4;
+            const float s0 = __shfl(sc0, hh), s1 = __shfl(sc1, hh);
+#pragma unroll
+            for (int cb = 0; cb < 6; cb += 2) {
+              const float v1 = swap_add32(ar[cb][r4], ar[cb + 1][r4]);
+              float* qp_ = QA + lr * C16_QSL + hh * C16_QH + (cb + (lane >> 5)) * 16 + (lane & 15);
+              float o = 0.f;
+              o = fmaf(*qp_, s0, o);
+              o = fmaf(v1, s1, o);
+              *qp_ = o;
+            }
+          }
+        } else {
         if (lane < 8) {   // lane h (mi = h, kq = 0) holds head h
           io.l[slot * 8 + lane] = l_run;
           if (W > 1) io.m[slot * 8 + lane] = m_run;
         }
-        av.x += __shfl_xor(av.x, 32); av.y += __shfl_xor(av.y, 32); av.z += __shfl_xor(av.z, 32); av.w += __shfl_xor(av.w, 32);
         if (lane < 32) *reinterpret_cast<float4*>(io.av + slot * 128 + 4 * lane) = av;
         // rows h (p hi) and h + 8 (p lo) sit 32 lanes apart: one half-wave swap folds two column blocks at a time
 #pragma unroll
@@ -497,6 +566,7 @@ __device__ __noinline__ void c16_edge_phase(const ChainStep* __restrict__ stp, E
             const float v = swap_add32(ar[cb][r4], ar[cb + 1][r4]);   // lanes < 32: block cb, lanes >= 32: block cb + 1
             QA[(W == 1 ? lr : lr * W + part) * C16_QSL + (4 * ((lane >> 4) & 1) + r4) * C16_QH + (cb + (lane >> 5)) * 16 + (lane & 15)] = v;
           }
+        }
         }
         C16_EMARK(10);
       }
@@ -810,8 +880,9 @@ __device__ __noinline__ void c16_node_phase(const ChainStep* __restrict__ post, 
 // POLICY: own symbol for the per-replan policy launch (kernel traces, bench.py) + the XCD-aware block -> row mapping.
 // rows: destination rows per workgroup (<= 16; the MFMA tiles are 16 rows, the rest zero).  With rows < NWV a row's edge
 // list is shared by W = NWV / rows waves (tiles w, w + W, ...): every wave keeps its own running maximum and sums, the
-// POST half merges the W partials.
-template <int NWV, bool POLICY>
+// POST half merges the W partials.  ONEW: rows >= NWV (W = 1) -- a template parameter and not a branch, so that every kernel
+// has ONE edge-phase callee (two would cost the inter-procedural register allocation: 113 registers saved per call).
+template <int NWV, bool POLICY, bool ONEW>
 __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void k_chain16(float* __restrict__ x, const float* __restrict__ x_in, int Nd, int rows,
                                                     const ChainStep* __restrict__ steps, int nsteps, EdgeIO io,
                                                     const float* __restrict__ div32, float eps, int xcd,
@@ -855,7 +926,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void k_chain16(float* _
   c16_node_phase<NWV>(nullptr, steps, io, c16_smem, nullptr, row0, nrows, W, Nd, eps, prof);
   C16_MARK(0);
   for (int s = 0; s < nsteps; ++s) {
-    c16_edge_phase<NWV>(steps + s, io, c16_smem, AG, CQ, ctr, QA, div32, row0, nrows, W, Nd, prof);
+    c16_edge_phase<NWV, ONEW>(steps + s, io, c16_smem, AG, CQ, ctr, QA, div32, row0, nrows, W, Nd, prof);
     __syncthreads();   // every row's sums are in place; the wave-private areas are dead
     C16_MARK(1);
     const bool last = s + 1 == nsteps;

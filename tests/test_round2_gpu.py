@@ -339,3 +339,27 @@ def test_learnable_rel_pe_vs_oracle(shape):
         assert d.max() < 3 * floor + TOL and np.median(d) < floor + TOL, (d.max(), floor)
     finally:
         eng.close()
+
+
+def test_k_chain16_results_do_not_depend_on_the_tiling():
+    """From 4 rows per workgroup up k_chain16 has ONE summation order (a row's 16-edge tiles by parity, merged (even, odd):
+    two waves at 4 rows, one wave in two parity runs from 8 rows up), so latency mode and throughput mode return the same
+    bits -- trajectories, predictions, fused features."""
+    from prosim_amd.engine import Engine
+    spec = SMALL_SPEC
+    w = weights.init_weights(spec, 0)
+    scene = synth.make_scene(spec, 150, 96, batch=4, seed=71, goal=True, tags=True, ragged=True)
+    eng = Engine(spec, w)
+    try:
+        eng.set_chain_impl(2)
+        outs = []
+        for rows in (4, 8, 11, 16):
+            eng.set_chain_rows(rows)
+            eng.set_scene(scene)
+            eng.rollout()
+            outs.append((eng.get("traj"), eng.get("motion_pred"), eng.get("fused")))
+        for o in outs[1:]:
+            for a, b in zip(outs[0], o):
+                assert np.array_equal(a, b)
+    finally:
+        eng.close()

@@ -18,7 +18,7 @@ import sqlite3, sys
 db = sqlite3.connect(sys.argv[1])
 tabs = [r[0] for r in db.execute("select name from sqlite_master where type in ('table','view')")]
 cc = [t for t in tabs if t.startswith("counters_collection")]
-rows = db.execute(f"select counter_name, count(*), avg(value) from {cc[0]} where kernel_name like '%k_chain16<8, true>%' group by counter_name").fetchall()
+rows = db.execute(f"select counter_name, count(*), avg(value) from {cc[0]} where kernel_name like '%k_chain16<8, true,%' group by counter_name").fetchall()
 for n, c, a in rows: print(f"{n:34s} launches {c:4d}  avg per launch {a:18.1f}")
 PY
 done
