@@ -56,6 +56,10 @@ typedef struct ps_config {
    * relative-PE rows of that part's two edge sets come from a learnable FourierEmbedding (layers/fourier_embedding.py:11-54;
    * weights "<part>.<set>_rel_pe_emb.*") instead of the fixed one.  pe_num_freq = PE_NUM_FREQ, must be 64 (the default). */
   int32_t enc_learnable_pe, dec_learnable_pe, pol_learnable_pe, pe_num_freq;
+  /* Binary (agent-pair) tags: bit t set = V2V_MotionTag value t (Following, ParallelDriving, Merging, ByPassing, Overtaking;
+   * dataset/motion_tag_utils.py:17-22) is among PROMPT.CONDITION.MOTION_TAG.USED_TAGS -> weight
+   * "condition_transformers.policy_decoder.condition_encoders.v2v_tag.tag_encoder.<tag>" [2 * hidden].  0 in the demo. */
+  int32_t v2v_tag_mask;
 } ps_config;
 
 /* Create an engine and upload weights.  names[i] are reference state_dict keys
@@ -113,6 +117,14 @@ int ps_set_conditions(ps_engine* e, int32_t C_goal, const float* goal_input, con
 int ps_set_drag_points(ps_engine* e, int32_t C_drag, int32_t T, const float* drag_input, const uint8_t* drag_mask,
                        const int32_t* drag_pidx);
 
+/* Binary conditions 'v2v_tag' (V2V_MotionTagEncoder condition_encoders.py:148-150; _construct_cond_edge_matrix
+ * condition_attns.py:141-166): pair_input [B, C, 3] = (V2V tag value, t0, t1), pair_mask [B, C], pair_pidx [B, C, 2] = the
+ * prompt SLOTS of (source s, target t).  A valid row puts two edges into the condition layers' graph: s -> t with the
+ * source half of the tag's parameter, t -> s with the target half (+ the temporal embedding on both); entries that share
+ * an edge with other condition keys are mean-pooled with them; the edges' relative-PE rows use the two prompts' poses.
+ * C_pair = 0 / NULL clears.  Independent of ps_set_conditions / ps_set_drag_points (each call replaces its own types). */
+int ps_set_pair_conditions(ps_engine* e, int32_t C_pair, const float* pair_input, const uint8_t* pair_mask,
+                           const int32_t* pair_pidx);
 /* Optional per-replan observation frames fut_obs[t] for replans 1..R-1
  * (dataset/format_utils.py:667-687): input [R-1,B,N,hist,obs_dim]; only columns 8.. (extent,
  * type, time one-hot) are used -- columns 0..7 are overwritten by step_env

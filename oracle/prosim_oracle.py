@@ -410,9 +410,9 @@ def condition_transform(Wt: W, spec: ModelSpec, cond: Optional[Dict], emd: T, pr
                         prompt_pos: T, prompt_head: T) -> T:
     """ConditionTransformer.forward at 'policy_decoder' (condition_transformer/base.py:38-60)
     with GoalConditionEncoder (condition_encoders.py:21-51), V_ActionTagEncoder (:76-141), DragPointEncoder
-    (:152-191) and GNNConditionAttn (condition_attns.py:114-228), restricted to UNARY conditions (each
-    condition attaches to one prompt agent -> self-loop edges), mean pooling over the
-    condition entries present on an edge.  ``cond`` = {'goal': {'input' [B,C,3], 'mask' [B,C],
+    (:152-191), V2V_MotionTagEncoder (:148-150) and GNNConditionAttn (condition_attns.py:114-228): unary conditions
+    attach to one prompt agent (self-loop edges), binary ones to an ordered pair (edges s -> t and t -> s); mean pooling
+    over the condition keys present on an edge.  ``cond`` = {'goal': {'input' [B,C,3], 'mask' [B,C],
     'prompt_idx' [B,C,1]}, 'v_action_tag': {...}}; None / {} -> identity."""
     if not cond:
         return emd
@@ -420,6 +420,7 @@ def condition_transform(Wt: W, spec: ModelSpec, cond: Optional[Dict], emd: T, pr
     D = spec.hidden
     ct = "condition_transformers.policy_decoder"
     entries = []  # per condition key (insertion order of the reference): (emd [B,C,D], mask [B,C], pidx [B,C])
+    pair_entries = []  # binary keys: (source emd [B,C,D], target emd [B,C,D], mask [B,C], pidx [B,C,2])
     if "goal" in cond and cond["goal"]["input"].shape[1] > 0:
         ci = cond["goal"]
         e = mlp(Wt, f"{ct}.condition_encoders.goal.goal_encoder", [2, D, D], ci["input"][..., :2], True, True)
@@ -442,28 +443,49 @@ def condition_transform(Wt: W, spec: ModelSpec, cond: Optional[Dict], emd: T, pr
         e = pointnet(Wt, f"{ct}.condition_encoders.drag_point.pointnet_encoder", 2, D, spec.drag_pre_layers,
                      spec.drag_mlp_layers, torch.nan_to_num(pts), pmask)
         entries.append((e, ci["mask"], ci["prompt_idx"][..., 0]))
-    if not entries:
+    if "v2v_tag" in cond and cond["v2v_tag"]["input"].shape[1] > 0:
+        # V2V_MotionTagEncoder (condition_encoders.py:148-150 over :76-141): a [2 D] parameter per tag, source half |
+        # target half, the temporal embedding added to both halves
+        from prosim_amd.spec import V2V_TAGS
+        ci = cond["v2v_tag"]
+        for tag in spec.used_v2v_tags:
+            sel = ci["input"][..., 0] == V2V_TAGS.index(tag)
+            if sel.sum() == 0:
+                continue
+            par = Wt[f"{ct}.condition_encoders.v2v_tag.tag_encoder.{tag}"]
+            te = fourier_fix(ci["input"][..., 1:3], D // 2)
+            pair_entries.append((par[None, None, :D] + te, par[None, None, D:] + te, ci["mask"] & sel, ci["prompt_idx"]))
+    if not entries and not pair_entries:
         return emd
-    # _construct_cond_edge_matrix + _pool_edges('mean') for self-loop edges only
-    attr = torch.zeros(B, N, D, dtype=emd.dtype)
-    cnt = torch.zeros(B, N, dtype=emd.dtype)
+    # _construct_cond_edge_matrix + _pool_edges('mean') (condition_attns.py:114-188): edge_attr[b, i, j] = mean over the
+    # condition keys that put an entry on (i -> j); unary keys on (s, s), binary keys s_emd on (s, t) and t_emd on (t, s)
+    attr = torch.zeros(B, N, N, D, dtype=emd.dtype)
+    cnt = torch.zeros(B, N, N, dtype=emd.dtype)
     for e, m, pidx in entries:
         bi, ci_ = m.nonzero(as_tuple=True)
         ni = pidx[bi, ci_]
-        attr.index_put_((bi, ni), e[bi, ci_], accumulate=True)
-        cnt.index_put_((bi, ni), torch.ones(bi.numel(), dtype=emd.dtype), accumulate=True)
-    has = cnt > 0
+        attr.index_put_((bi, ni, ni), e[bi, ci_], accumulate=True)
+        cnt.index_put_((bi, ni, ni), torch.ones(bi.numel(), dtype=emd.dtype), accumulate=True)
+    for es, et, m, pidx in pair_entries:
+        bi, ci_ = m.nonzero(as_tuple=True)
+        si, ti = pidx[bi, ci_, 0], pidx[bi, ci_, 1]
+        one = torch.ones(bi.numel(), dtype=emd.dtype)
+        attr.index_put_((bi, si, ti), es[bi, ci_], accumulate=True)
+        cnt.index_put_((bi, si, ti), one, accumulate=True)
+        attr.index_put_((bi, ti, si), et[bi, ci_], accumulate=True)
+        cnt.index_put_((bi, ti, si), one, accumulate=True)
     attr = attr / cnt.clamp(min=1)[..., None]
-    edge_ok = has & prompt_mask
+    edge_ok = (cnt > 0) & prompt_mask[:, :, None] & prompt_mask[:, None, :]
     node_index = torch.full((B, N), -1, dtype=torch.long)
     node_index[prompt_mask] = torch.arange(int(prompt_mask.sum()))
-    e_node = node_index[edge_ok]
+    eb, ei, ej = edge_ok.nonzero(as_tuple=True)          # row-major (b, i, j): edge i -> j  (attn_utils.py:37-48)
+    e_src, e_dst = node_index[eb, ei], node_index[eb, ej]
     ppos = prompt_pos[prompt_mask]
     pori = prompt_head.reshape(B, N, 1)[prompt_mask]
-    r = attr[edge_ok] + rel_pe(spec, e_node, e_node, pori, ppos, pori, ppos)
+    r = attr[eb, ei, ej] + rel_pe(spec, e_src, e_dst, pori, ppos, pori, ppos)
     xp = emd[prompt_mask]
     for i in range(spec.cond_layers):
-        xp = attention_layer(Wt, f"{ct}.condition_attn.attn_layers.{i}", spec, xp, xp, r, e_node, e_node, False)
+        xp = attention_layer(Wt, f"{ct}.condition_attn.attn_layers.{i}", spec, xp, xp, r, e_src, e_dst, False)
     out = emd.clone()
     out[prompt_mask] = out[prompt_mask] + xp
     return out

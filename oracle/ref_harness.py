@@ -338,8 +338,11 @@ def make_batch(scene_in, spec):
     for k, v in (scene_in.get("cond") or {}).items():
         # conditions index policy agents: slot indices -> rows of the dense prompt tensor; conditions of
         # non-policy slots are dropped (their mask is False)
-        idx = np.take_along_axis(slot2pol, v["prompt_idx"][..., 0].astype(np.int64), 1)[..., None]
-        cm = v["mask"].astype(bool) & np.take_along_axis(pm, v["prompt_idx"][..., 0].astype(np.int64), 1)
+        pi = v["prompt_idx"].astype(np.int64)                    # [B, C, 1] unary / [B, C, 2] binary (source, target)
+        idx = np.stack([np.take_along_axis(slot2pol, pi[..., j], 1) for j in range(pi.shape[-1])], -1)
+        cm = v["mask"].astype(bool)
+        for j in range(pi.shape[-1]):
+            cm = cm & np.take_along_axis(pm, pi[..., j], 1)
         cond[k] = dict(input=t(v["input"]), mask=t(cm, torch.bool), prompt_idx=t(idx, torch.long),
                        prompt_mask=t(pmask, torch.bool))
     extras["condition"] = cond

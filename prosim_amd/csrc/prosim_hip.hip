@@ -134,11 +134,13 @@ struct ps_engine {
   DevBuf<float> d_ent_val;
   // host copy of the condition entries (goal / tag from ps_set_conditions, drag from ps_set_drag_points); the device
   // CSR is rebuilt from both whenever either call changes them
-  struct CondEnt { int agent, type, id; float v[3]; };
-  std::vector<CondEnt> ents_gt, ents_drag;
+  struct CondEnt { int agent, type, id; float v[3]; int src = -1; };   // src < 0: a unary condition (self loop on `agent`)
+  std::vector<CondEnt> ents_gt, ents_drag, ents_pair;
+  DevBuf<CondEdge> d_cond_edges;            // one record per edge of the condition graph (k_cond_edges)
+  int n_cond_tiles = 0;
   // a condition TYPE that is present in the batch makes the reference run the condition layers over every policy
   // agent, even when each of its entries is masked off (condition_transformer/base.py:43-49, condition_attns.py:203-204)
-  bool cond_present_gt = false, cond_present_drag = false;
+  bool cond_present_gt = false, cond_present_drag = false, cond_present_pair = false;
   int n_drag = 0, drag_T = 0;
   DevBuf<float> d_drag_in, d_drag_emd;      // [n_drag][T][2] (NaN -> 0), [n_drag][128]
   DevBuf<uint8_t> d_drag_mask;              // [n_drag][T]
@@ -624,6 +626,16 @@ extern "C" int ps_create(const ps_config* cfg, int32_t n_tensors, const char* co
       if (s) std::copy(s, s + D, tags.begin() + (size_t)t * D);
     }
     b.slot(&e->cond.tag_emb, b.put(tags));
+    if (cfg->v2v_tag_mask) {   // V2V_MotionTagEncoder: [2 D] per used tag (source half | target half), V2V_MotionTag order
+      static const char* kV2V[5] = {"Following", "ParallelDriving", "Merging", "ByPassing", "Overtaking"};
+      std::vector<float> v2v((size_t)5 * 2 * D, 0.f);
+      for (int t = 0; t < 5; ++t)
+        if (cfg->v2v_tag_mask & (1 << t)) {
+          const float* s_ = b.get(ct + ".v2v_tag.tag_encoder." + kV2V[t], 2 * D);
+          if (s_) std::copy(s_, s_ + 2 * D, v2v.begin() + (size_t)t * 2 * D);
+        }
+      b.slot(&e->cond.v2v_emb, b.put(v2v));
+    }
   }
   b.plain(&e->cond.div32, "const.fourier_div32", 32);
   b.plain(&e->cond.div64, "const.fourier_div64", 64);
@@ -718,7 +730,7 @@ extern "C" void ps_destroy(ps_engine* e) {
   for (EdgeSet* s : {&e->e_a2a, &e->e_s2s, &e->e_p2p, &e->e_s2p, &e->e_a2p, &e->e_m2p, &e->e_cnd, &e->e_ua, &e->e_um}) {
     s->cnt.release(); s->eoff.release(); s->esrc.release(); s->edst.release(); s->toff.release(); s->tdst.release(); s->rtA.release(); s->rtT.release(); s->geo.release();
   }
-  e->d_steps.release(); e->d_ent_off.release(); e->d_ent_type.release(); e->d_ent_val.release();
+  e->d_steps.release(); e->d_ent_off.release(); e->d_ent_type.release(); e->d_ent_val.release(); e->d_cond_edges.release();
   e->d_drag_in.release(); e->d_drag_emd.release(); e->d_drag_mask.release();
   e->d_obs_new.release(); e->d_kv_um.release(); e->d_kh_um.release();
   e->io_q.release(); e->io_qt.release(); e->io_cq.release(); e->io_ar.release(); e->io_av.release(); e->io_l.release();
@@ -1035,8 +1047,9 @@ extern "C" int ps_set_scene(ps_engine* e, int32_t B, int32_t M, int32_t P, int32
   e->n_cond_edges = 0;
   e->ents_gt.clear();
   e->ents_drag.clear();
+  e->ents_pair.clear();
   e->n_drag = 0;
-  e->cond_present_gt = e->cond_present_drag = false;
+  e->cond_present_gt = e->cond_present_drag = e->cond_present_pair = false;
   HIPCHK(hipStreamSynchronize(st));
   e->have_scene = true;
   e->encoded = e->generated = e->reset = false;
@@ -1078,37 +1091,68 @@ extern "C" int ps_set_prompt(ps_engine* e, const float* prompt, const float* pro
   return PS_OK;
 }
 
-// Device CSR of the condition entries: per conditioned agent (one self-loop edge each) the list of its entries
-// (type, id, 3 floats) in the reference's pooling order goal, tags, drag points (PROMPT.CONDITION.TYPES).
+// Device form of the condition layers' graph (_construct_cond_edge_matrix + _pool_edges, condition_attns.py:114-188):
+// the distinct (source -> destination) pairs that carry a condition entry -- self loops for unary conditions, s -> t and
+// t -> s for binary ones -- as a CSR by destination with 32-edge tiles, and per edge the list of its entries (type, id,
+// 3 floats) in the order goal, tags, drag points, binary tags.
 static int rebuild_conditions(ps_engine* e) {
   const int A = e->Ap;   // (with replicas the condition layers run once, over the first replica's rows)
-  std::vector<std::vector<const ps_engine::CondEnt*>> per(A);
-  for (const auto& en : e->ents_gt) per[en.agent].push_back(&en);
-  for (const auto& en : e->ents_drag) per[en.agent].push_back(&en);
-  std::vector<int> eoff(A + 1, 0), esrc, ent_off(1, 0), ent_type;
+  struct Key { int dst, src; };
+  std::vector<std::pair<Key, const ps_engine::CondEnt*>> all;
+  for (const auto* list : {&e->ents_gt, &e->ents_drag, &e->ents_pair})
+    for (const auto& en : *list) all.push_back({Key{en.agent, en.src < 0 ? en.agent : en.src}, &en});
+  std::stable_sort(all.begin(), all.end(), [](const auto& x, const auto& y) {
+    return x.first.dst != y.first.dst ? x.first.dst < y.first.dst : x.first.src < y.first.src;
+  });
+  std::vector<int> eoff(A + 1, 0), toff(A + 1, 0), esrc, tdst, ent_off(1, 0), ent_type;
   std::vector<float> ent_val;
+  std::vector<CondEdge> edges;
+  int maxdeg = 1;
+  size_t i = 0;
   for (int a = 0; a < A; ++a) {
-    if (!per[a].empty()) {
-      esrc.push_back(a);
-      for (const auto* en : per[a]) {
+    int deg = 0;
+    while (i < all.size() && all[i].first.dst == a) {
+      const int src = all[i].first.src;
+      for (; i < all.size() && all[i].first.dst == a && all[i].first.src == src; ++i) {
+        const auto* en = all[i].second;
         ent_type.push_back(en->type);
         ent_type.push_back(en->id);
         ent_val.insert(ent_val.end(), en->v, en->v + 3);
       }
       ent_off.push_back((int)ent_type.size() / 2);
+      esrc.push_back(src);
+      edges.push_back(CondEdge{src, a, (toff[a] + deg / 32) * 32 + (deg & 31)});
+      ++deg;
     }
     eoff[a + 1] = (int)esrc.size();
+    toff[a + 1] = toff[a] + (deg + 31) / 32;
+    for (int t = toff[a]; t < toff[a + 1]; ++t) tdst.push_back(a);
+    maxdeg = std::max(maxdeg, deg);
   }
+  if (maxdeg > 2047) return fail(PS_E_ARG, "more than 2047 condition edges into one prompt");
   e->n_cond_edges = (int)esrc.size();
-  e->have_cond = e->cond_present_gt || e->cond_present_drag;
+  e->n_cond_tiles = toff[A];
+  e->have_cond = e->cond_present_gt || e->cond_present_drag || e->cond_present_pair;
   e->edge_counts[6] = (float)e->n_cond_edges;
   hipStream_t st = e->stream;
-  // at most one self-loop edge per destination: tile offsets coincide with edge offsets
-  if (upload(e->e_cnd.eoff, eoff.data(), eoff.size(), st) || upload(e->e_cnd.toff, eoff.data(), eoff.size(), st) ||
-      upload(e->e_cnd.esrc, esrc.data(), esrc.size(), st) ||
+  // (the set was sized for one self loop per prompt; binary conditions add edges: grow, and re-point the layers' steps)
+  const _Float16 *oa = e->e_cnd.rtA.p, *ot = e->e_cnd.rtT.p;
+  const int *oo = e->e_cnd.eoff.p, *os_ = e->e_cnd.esrc.p, *of = e->e_cnd.toff.p;
+  e->e_cnd.maxdeg = maxdeg;
+  if (e->e_cnd.rtA.ensure((size_t)(e->n_cond_tiles + 1) * 8192) || e->e_cnd.rtT.ensure((size_t)(e->n_cond_tiles + 1) * 8192) ||
+      upload(e->e_cnd.eoff, eoff.data(), eoff.size(), st) || upload(e->e_cnd.toff, toff.data(), toff.size(), st) ||
+      upload(e->e_cnd.esrc, esrc.data(), esrc.size(), st) || upload(e->e_cnd.tdst, tdst.data(), tdst.size(), st) ||
+      upload(e->d_cond_edges, edges.data(), edges.size(), st) ||
       upload(e->d_ent_off, ent_off.data(), ent_off.size(), st) || upload(e->d_ent_type, ent_type.data(), ent_type.size(), st) ||
       upload(e->d_ent_val, ent_val.data(), ent_val.size(), st))
     return fail(PS_E_HIP, "condition upload failed");
+  if (oa != e->e_cnd.rtA.p || ot != e->e_cnd.rtT.p || oo != e->e_cnd.eoff.p || os_ != e->e_cnd.esrc.p || of != e->e_cnd.toff.p) {
+    for (int l = 0; l < e->cfg.cond_layers; ++l) {
+      ChainStep& sp_ = e->h_steps[e->step_cnd + l];
+      sp_.rtA = e->e_cnd.rtA.p; sp_.rtT = e->e_cnd.rtT.p; sp_.eoff = e->e_cnd.eoff.p; sp_.esrc = e->e_cnd.esrc.p; sp_.toff = e->e_cnd.toff.p;
+    }
+    if (upload(e->d_steps, e->h_steps.data(), e->h_steps.size(), st)) return fail(PS_E_HIP, "step table upload failed");
+  }
   HIPCHK(hipStreamSynchronize(st));
   e->generated = false;
   drop_graph(e);
@@ -1199,6 +1243,41 @@ extern "C" int ps_set_drag_points(ps_engine* e, int32_t C_drag, int32_t T, const
       return fail(PS_E_HIP, "drag-point upload failed");
   }
   e->ents_drag.swap(ents);
+  return rebuild_conditions(e);
+}
+
+// Binary (agent-pair) tag conditions: 'v2v_tag' (condition_encoders.py:148-150; condition_attns.py:141-166).
+extern "C" int ps_set_pair_conditions(ps_engine* e, int32_t C_pair, const float* pair_input, const uint8_t* pair_mask,
+                                      const int32_t* pair_pidx) {
+  if (!e || !e->have_scene) return fail(PS_E_STATE, "ps_set_pair_conditions before ps_set_scene");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  e->ents_pair.clear();
+  e->cond_present_pair = false;
+  if (C_pair <= 0 || !pair_input) return rebuild_conditions(e);
+  if (!pair_mask || !pair_pidx) return fail(PS_E_ARG, "pair_mask / pair_pidx missing");
+  if (!e->cfg.v2v_tag_mask) return fail(PS_E_ARG, "this engine was created without binary tags (v2v_tag_mask = 0)");
+  const int N = e->N;
+  std::vector<int> slot2a((size_t)e->B * N, -1);
+  for (int i = 0; i < e->Ap; ++i) slot2a[e->agent_rows[i]] = i;
+  std::vector<ps_engine::CondEnt> ents;
+  bool present = false;
+  for (int b = 0; b < e->B; ++b)
+    for (int c = 0; c < C_pair; ++c) {
+      const size_t i = (size_t)b * C_pair + c;
+      const int tag = (int)pair_input[3 * i];
+      if (tag < 0 || tag > 4 || !(e->cfg.v2v_tag_mask & (1 << tag))) continue;   // not a used V2V tag value: no entry (:106-111)
+      present = true;                                                           // the tag's key exists whatever the mask says
+      if (!pair_mask[i]) continue;
+      const int ns = pair_pidx[2 * i], nt = pair_pidx[2 * i + 1];
+      if (ns < 0 || ns >= N || nt < 0 || nt >= N || ns == nt || slot2a[(size_t)b * N + ns] < 0 || slot2a[(size_t)b * N + nt] < 0)
+        return fail(PS_E_ARG, "pair condition on an invalid pair of prompt slots");
+      const int rs = slot2a[(size_t)b * N + ns], rt = slot2a[(size_t)b * N + nt];
+      const float t0 = pair_input[3 * i + 1], t1 = pair_input[3 * i + 2];
+      ents.push_back({rt, 3, 2 * tag, {0.f, t0, t1}, rs});       // edge s -> t carries the source half
+      ents.push_back({rs, 3, 2 * tag + 1, {0.f, t0, t1}, rt});   // edge t -> s the target half
+    }
+  e->cond_present_pair = present;
+  e->ents_pair.swap(ents);
   return rebuild_conditions(e);
 }
 
@@ -1718,14 +1797,17 @@ extern "C" int ps_generate_policy(ps_engine* e) {
   if (e->have_cond && c.cond_layers > 0) {
     if (e->n_drag > 0)
       launch_pointnet(e, e->pn_drag, e->d_drag_in.p, e->d_drag_mask.p, nullptr, e->n_drag, e->drag_T, 0, e->d_drag_emd.p);
-    if (e->n_cond_edges > 0)   // (a present type whose entries are all masked off: the layers still run, without edges)
-    hipLaunchKernelGGL(k_cond_edges, dim3(e->n_cond_edges), dim3(128), 0, st, e->cond, (const int*)e->d_ent_off.p,
-                       (const int*)e->d_ent_type.p, (const float*)e->d_ent_val.p, (const float*)e->d_drag_emd.p, e->n_cond_edges,
-                       e->e_cnd.rtA.p, e->e_cnd.rtT.p, c.ln_eps);
+    if (e->n_cond_edges > 0) {   // (a present type whose entries are all masked off: the layers still run, without edges)
+      HIPCHK(hipMemsetAsync(e->e_cnd.rtA.p, 0, sizeof(_Float16) * (size_t)e->n_cond_tiles * 8192, st));
+      HIPCHK(hipMemsetAsync(e->e_cnd.rtT.p, 0, sizeof(_Float16) * (size_t)e->n_cond_tiles * 8192, st));
+      hipLaunchKernelGGL(k_cond_edges, dim3(e->n_cond_edges), dim3(128), 0, st, e->cond, (const int*)e->d_ent_off.p,
+                         (const int*)e->d_ent_type.p, (const float*)e->d_ent_val.p, (const float*)e->d_drag_emd.p, e->n_cond_edges,
+                         (const CondEdge*)e->d_cond_edges.p, ppos, pori, e->e_cnd.rtA.p, e->e_cnd.rtT.p, c.ln_eps);
+    }
     HIPCHK(hipMemcpyAsync(e->d_xc.p, e->d_emd.p, sizeof(float) * (size_t)Ap * D, hipMemcpyDeviceToDevice, st));
     for (int i = 0; i < c.cond_layers; ++i) {
       launch_kv(e, e->d_xc.p, Ap, e->L_cnd + i, 1, e->d_kv.p, e->d_kh.p, 0);
-      if (launch_chain(e, e->d_xc.p, Ap, e->step_cnd + i, 1, 1)) return PS_E_HIP;
+      if (launch_chain(e, e->d_xc.p, Ap, e->step_cnd + i, 1, e->e_cnd.maxdeg)) return PS_E_HIP;
     }
     hipLaunchKernelGGL(k_add_rows, dim3((Ap * D + 255) / 256), dim3(256), 0, st, e->d_emd.p, (const float*)e->d_xc.p, Ap * D);
   }

@@ -719,18 +719,27 @@ __global__ void k_world_traj(const float* __restrict__ traj, int stride_steps, i
 }
 
 // Condition encoders + mean pooling over the condition entries attached to one agent
-// (condition_encoders.py:21-51, :76-141; condition_attns.py:114-188 for self-loop edges), then
-// r = pooled + relPE(self-loop) and the affine-free LayerNorm.  One WG (128 threads) per
-// conditioned agent; entries are a host-built CSR: type (0 goal, 1 tag, 2 drag points), tag id | row of the
-// drag-point embeddings (DragPointEncoder :152-191 = k_pointnet_mfma over the [x, y] points), 3 floats.
+// (condition_encoders.py:21-51, :76-141, :148-150; condition_attns.py:114-188), then
+// r = pooled + relPE(edge) and the affine-free LayerNorm.  One WG (128 threads) per EDGE of the condition graph;
+// entries are a host-built CSR: type (0 goal, 1 unary tag, 2 drag points, 3 binary tag), tag id | row of the drag-point
+// embeddings (DragPointEncoder :152-191 = k_pointnet_mfma over the [x, y] points) | 2 * tag + half, 3 floats.  The
+// operand images are zeroed by the caller; an edge writes its own slot.
 struct CondW {
   Mlp3W goal;                 // MLP 2 -> 128 (ReLU) -> 128, no norm
   const float* tag_emb;       // [11][128] indexed by V_Action_MotionTag value
+  const float* v2v_emb;       // [5][256] indexed by V2V_MotionTag value: source half | target half (binary tags; may be null)
   const float *div32, *div64, *div128;
+};
+// one edge of the condition layers' graph: unary conditions make self loops, binary ones the edges s -> t and t -> s
+struct CondEdge {
+  int src, dst;               // agent rows
+  int img;                    // tile * 32 + slot of its row in the operand images
 };
 __global__ __launch_bounds__(128) void k_cond_edges(CondW w, const int* __restrict__ ent_off, const int* __restrict__ ent_type,
                                                    const float* __restrict__ ent_val, const float* __restrict__ drag_emd, int n_nodes,
-                                                   _Float16* __restrict__ rtA, _Float16* __restrict__ rtT, float eps) {
+                                                   const CondEdge* __restrict__ edges, const float* __restrict__ ppos,
+                                                   const float* __restrict__ pori, _Float16* __restrict__ rtA,
+                                                   _Float16* __restrict__ rtT, float eps) {
   __shared__ float a[128], b[128], accum[128];
   const int node = blockIdx.x, tid = threadIdx.x;
   accum[tid] = 0.f;
@@ -747,6 +756,12 @@ __global__ __launch_bounds__(128) void k_cond_edges(CondW w, const int* __restri
       accum[tid] += a[tid] + ((tid & 1) ? cosf(v) : sinf(v));
     } else if (ent_type[2 * e] == 2) {
       accum[tid] += drag_emd[(size_t)ent_type[2 * e + 1] * 128 + tid];
+    } else if (ent_type[2 * e] == 3) {
+      // binary tag: this edge's half of the [2 D] parameter + the same temporal embedding on both halves (:129-133)
+      const int slot = tid & 63;
+      const float x = tid < 64 ? v1 : v2;
+      const float v = (x * PS_TWO_PI_F) / w.div64[slot];
+      accum[tid] += w.v2v_emb[(size_t)ent_type[2 * e + 1] * 128 + tid] + ((slot & 1) ? cosf(v) : sinf(v));
     } else {
       // tag parameter + FourierEmbeddingFix(64)([t0, t1]): two channels x 64 slots
       const int slot = tid & 63;
@@ -756,30 +771,37 @@ __global__ __launch_bounds__(128) void k_cond_edges(CondW w, const int* __restri
     }
     __syncthreads();
   }
-  // mean pool, + relPE of a self-loop (dist 0, rel_ori 0, angle atan2(0,0)=0 -> [sin 0, cos 0, ...])
-  const float pe = (tid & 1) ? cosf(0.f) : sinf(0.f);
+  // mean pool, + relPE of the edge (condition_attns.py:95-112, the rows of k_relpe_tiles; a self loop: dist 0, rel_ori 0,
+  // angle atan2(+-0, +0) = +-0)
+  const CondEdge ce = edges[node];
+  float pe;
+  {
+    const float px = ppos[2 * ce.dst], py = ppos[2 * ce.dst + 1], od = pori[ce.dst];
+    const float cx = cosf(od), cy = sinf(od);
+    const float dx = ppos[2 * ce.src] - px, dy = ppos[2 * ce.src + 1] - py;
+    const int blk = tid >> 5;
+    float x;
+    if (blk == 0) x = sqrtf(dx * dx + dy * dy);
+    else if (blk == 1) x = wrap_angle(pori[ce.src] - od);
+    else x = atan2f(cx * dy - cy * dx, (0.f + cx * dx) + cy * dy);
+    pe = fourier_feat(x, tid & 31, w.div32);
+  }
   a[tid] = accum[tid] / (float)(e1 - e0) + pe;
   __syncthreads();
   if (tid < 64) ln_row_wave(a, b, nullptr, nullptr, eps, tid, false);
   __syncthreads();
   const float y = b[tid];
-  // edge `node` is the only edge of its destination: tile `node`, slot 0 of both operand images (see
-  // k_tile_transpose); every other slot of the tile is zero
+  // slot `sl` of tile `tile` of both operand images (layouts: k_relpe_tiles); the images were zeroed before the launch
+  const int tile = ce.img >> 5, sl = ce.img & 31;
   {
     const int ks = tid >> 5, kq = (tid >> 3) & 3, j = tid & 7;
-    _Float16* ta = rtA + (size_t)node * 8192;
-    for (int i = tid; i < 1024; i += 128) *reinterpret_cast<half8*>(ta + (size_t)i * 8) = half8{0, 0, 0, 0, 0, 0, 0, 0};
-    __syncthreads();
-    ta[(size_t)((0 * 4 + ks) * 64 + kq * 16) * 8 + j] = f16_hi(y);   // sub 0, part hi, lane (m = 0, kq)
-    ta[(size_t)((1 * 4 + ks) * 64 + kq * 16) * 8 + j] = f16_lo(y);   // sub 0, part lo
+    _Float16* ta = rtA + (size_t)tile * 8192;
+    const int P0 = (sl & 15) + 16 * kq + 64 * ks + 512 * (sl >> 4);
+    ta[(size_t)P0 * 8 + j] = f16_hi(y);            // part hi
+    ta[(size_t)(P0 + 256) * 8 + j] = f16_lo(y);    // part lo
   }
-  half8 z = {0, 0, 0, 0, 0, 0, 0, 0}, vh = z, vl = z;
-  vh[0] = f16_hi(y);
-  vl[0] = f16_lo(y);
-  half8* oh = reinterpret_cast<half8*>(rtT + (size_t)node * 8192 + tid * 32);
-  half8* ol = reinterpret_cast<half8*>(rtT + (size_t)node * 8192 + 4096 + tid * 32);
-  oh[0] = vh; oh[1] = z; oh[2] = z; oh[3] = z;
-  ol[0] = vl; ol[1] = z; ol[2] = z; ol[3] = z;
+  rtT[(size_t)tile * 8192 + tid * 32 + sl] = f16_hi(y);
+  rtT[(size_t)tile * 8192 + 4096 + tid * 32 + sl] = f16_lo(y);
 }
 
 // fp32 rows [n][128] -> split fp16 rows [n][256] (hi | lo); used by the test hooks

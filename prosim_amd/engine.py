@@ -12,7 +12,7 @@ from typing import Dict, Optional
 import numpy as np
 import torch
 
-from .spec import ModelSpec
+from .spec import ModelSpec, V2V_TAGS
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libprosim_hip.so")
 _lib = None
@@ -39,7 +39,7 @@ class PsConfig(C.Structure):
         ("dt", C.c_float), ("ln_eps", C.c_float),
         ("device", C.c_int32),
         ("enc_learnable_pe", C.c_int32), ("dec_learnable_pe", C.c_int32), ("pol_learnable_pe", C.c_int32),
-        ("pe_num_freq", C.c_int32),
+        ("pe_num_freq", C.c_int32), ("v2v_tag_mask", C.c_int32),
     ]
 
 
@@ -68,6 +68,7 @@ def load_library():
                                       fp, fp, fp, i32p, i32p, fp, fp]
     lib.ps_set_conditions.argtypes = [vp, C.c_int32, fp, u8p, i32p, C.c_int32, fp, u8p, i32p]
     lib.ps_set_drag_points.argtypes = [vp, C.c_int32, C.c_int32, fp, u8p, i32p]
+    lib.ps_set_pair_conditions.argtypes = [vp, C.c_int32, fp, u8p, i32p]
     lib.ps_set_future_obs.argtypes = [vp, fp]
     lib.ps_set_future_log.argtypes = [vp, fp, u8p, fp, fp]
     lib.ps_set_mode_choice.argtypes = [vp, i32p]
@@ -110,7 +111,7 @@ def load_library():
     return lib
 
 
-EXPORTS = ["ps_create", "ps_destroy", "ps_last_error", "ps_set_scene", "ps_set_prompt", "ps_policy_forward", "ps_set_conditions", "ps_set_drag_points", "ps_set_future_obs", "ps_set_future_log", "ps_set_mode_choice", "ps_set_replicas", "ps_num_replicas", "ps_world_trajs", "ps_num_policy_agents", "ps_policy_flags",
+EXPORTS = ["ps_create", "ps_destroy", "ps_last_error", "ps_set_scene", "ps_set_prompt", "ps_policy_forward", "ps_set_conditions", "ps_set_drag_points", "ps_set_pair_conditions", "ps_set_future_obs", "ps_set_future_log", "ps_set_mode_choice", "ps_set_replicas", "ps_num_replicas", "ps_world_trajs", "ps_num_policy_agents", "ps_policy_flags",
            "ps_encode_scene", "ps_generate_policy", "ps_reset_rollout", "ps_policy_step", "ps_rollout", "ps_sync", "ps_stream", "ps_set_chain_rows", "ps_set_chain_impl", "ps_enable_policy_events", "ps_policy_event_times", "ps_update_obs", "ps_set_map_tokens", "ps_declare_agent_rows",
            "ps_set_state", "ps_get", "ps_rollout_metric", "ps_pair_metric", "ps_num_agents", "ps_num_map_tokens", "ps_time_rollout", "ps_time_policy_kernel",
            "ps_test_pointnet", "ps_test_fourier", "ps_test_wrap", "ps_test_attn", "ps_test_get_edges", "ps_test_stream"]
@@ -161,7 +162,8 @@ class Engine:
                        num_agent_types=spec.num_agent_types, prompt_dim=spec.prompt_dim, replan_freq=spec.replan_freq,
                        max_steps=spec.max_steps, dt=spec.dt, ln_eps=spec.ln_eps, device=device,
                        enc_learnable_pe=int(spec.enc_learnable_pe), dec_learnable_pe=int(spec.dec_learnable_pe),
-                       pol_learnable_pe=int(spec.pol_learnable_pe), pe_num_freq=spec.pe_num_freq)
+                       pol_learnable_pe=int(spec.pol_learnable_pe), pe_num_freq=spec.pe_num_freq,
+                       v2v_tag_mask=sum(1 << V2V_TAGS.index(t) for t in spec.used_v2v_tags))
         tensors = dict(weights)
         tensors.update(fourier_tables())
         names = sorted(tensors)
@@ -274,12 +276,13 @@ class Engine:
         self._check(self.lib.ps_set_mode_choice(self.h, _i32(c)))
 
     def set_conditions(self, cond):
-        """``cond`` = {'goal' | 'v_action_tag' | 'drag_point': {'input', 'mask', 'prompt_idx' [B,C,1] = prompt SLOT}} or
-        None; replaces every condition of the uploaded batch (batch.extras['condition'] after the id -> slot mapping)."""
+        """``cond`` = {'goal' | 'v_action_tag' | 'drag_point': {'input', 'mask', 'prompt_idx' [B,C,1] = prompt SLOT},
+        'v2v_tag': {'input' [B,C,3], 'mask', 'prompt_idx' [B,C,2] = the SLOTS of (source, target)}} or None; replaces every
+        condition of the uploaded batch (batch.extras['condition'] after the id -> slot mapping)."""
         cond = cond or {}
-        unknown = [k for k in cond if k not in ("goal", "v_action_tag", "drag_point")]
+        unknown = [k for k in cond if k not in ("goal", "v_action_tag", "drag_point", "v2v_tag")]
         if unknown:
-            raise NotImplementedError(f"condition types {unknown}: only goal, v_action_tag and drag_point are built")
+            raise NotImplementedError(f"condition types {unknown}: goal, v_action_tag, drag_point and v2v_tag are built")
         args, keep = [], []
         for c in (cond.get("goal"), cond.get("v_action_tag")):
             if c is None or np.asarray(c["input"]).shape[1] == 0:
@@ -292,6 +295,19 @@ class Engine:
                 args += [ci.shape[1], _f(ci), _u8(cm), _i32(cp)]
         self._check(self.lib.ps_set_conditions(self.h, *args))
         self.set_drag_points(cond.get("drag_point"))
+        self.set_pair_conditions(cond.get("v2v_tag"))
+
+    def set_pair_conditions(self, c):
+        """``c`` = {'input' [B,C,3] (V2V tag value, t0, t1), 'mask' [B,C], 'prompt_idx' [B,C,2] (source, target slots)} or None."""
+        if c is None or np.asarray(c["input"]).shape[1] == 0:
+            self._check(self.lib.ps_set_pair_conditions(self.h, 0, None, None, None))
+            return
+        ci = np.ascontiguousarray(c["input"], dtype=np.float32)
+        cm = np.ascontiguousarray(c["mask"]).astype(np.uint8)
+        cp = np.ascontiguousarray(np.asarray(c["prompt_idx"]), dtype=np.int32)
+        if cp.shape != ci.shape[:2] + (2,):
+            raise ValueError("v2v_tag prompt_idx must be [B, C, 2]")
+        self._check(self.lib.ps_set_pair_conditions(self.h, ci.shape[1], _f(ci), _u8(cm), _i32(cp)))
 
     def set_drag_points(self, c):
         """``c`` = {'input' [B,C,T,2] (NaN = absent point), 'mask' [B,C], 'prompt_idx' [B,C,1]} or None (clears)."""

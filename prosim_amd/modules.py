@@ -108,7 +108,8 @@ def prompt_to_slots(pr, ids_o, B, N, obs_pos, obs_head):
     return slots, prompt, prompt_mask, agent_type, prompt_pos, prompt_head
 
 
-COND_TYPES = ("goal", "v_action_tag", "drag_point")   # PROMPT.CONDITION.TYPES of prosim_demo/cfg/no_text.yaml:65
+# PROMPT.CONDITION.TYPES of prosim_demo/cfg/no_text.yaml:65, plus the binary 'v2v_tag' (default.py:337)
+COND_TYPES = ("goal", "v_action_tag", "drag_point", "v2v_tag")
 
 
 def cond_to_slots(c, slots, Np):
@@ -120,7 +121,7 @@ def cond_to_slots(c, slots, Np):
     for b in range(idx.shape[0]):
         lut = np.array(list(slots[b]) + [0] * (Np - len(slots[b])), np.int64)
         sl[b] = lut[np.clip(idx[b], 0, Np - 1)]
-        cm[b] &= idx[b, :, 0] < len(slots[b])
+        cm[b] &= (idx[b] < len(slots[b])).all(-1)                # (binary conditions: both ends)
     return dict(input=_np(_g(c, "input")), mask=cm, prompt_idx=sl)
 
 
@@ -155,7 +156,7 @@ def scene_from_extras(extras, spec: ModelSpec, task: str = "motion_pred") -> Dic
         unsupported = [k for k in cond.keys() if k not in COND_TYPES and _g(cond[k], "input").shape[1] > 0]
         if unsupported:
             raise NotImplementedError(f"condition types {unsupported} are not built (the demo config's unary types "
-                                      f"{COND_TYPES} are; v2v_tag and the text types are out of scope)")
+                                      f"{COND_TYPES} are; the text types are out of scope)")
         if out:
             scene["cond"] = out
     fut = extras.get("fut_obs") if hasattr(extras, "get") else None

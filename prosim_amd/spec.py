@@ -23,6 +23,8 @@ USED_V_ACTION_TAGS: Tuple[str, ...] = (
     "Accelerate", "Decelerate", "KeepSpeed", "Stopping", "LeftLaneChange",
     "RightLaneChange", "KeepLane", "LeftTurn", "RightTurn", "Straight", "Parked",
 )
+# V2V_MotionTag enum order (motion_tag_utils.py:17-22): binary (agent-pair) tags
+V2V_TAGS: Tuple[str, ...] = ("Following", "ParallelDriving", "Merging", "ByPassing", "Overtaking")
 
 
 @dataclass(frozen=True)
@@ -89,6 +91,10 @@ class ModelSpec:
     # the relative-PE rows of the scene encoder's (a2a, s2s), the generator's (p2p, s2p) and the policy's (a2p, m2p)
     # edge sets come from a learnable FourierEmbedding (layers/fourier_embedding.py:11-54) over 3 inputs instead of the
     # fixed FourierEmbeddingFix over 4.  The condition layers always use the fixed one (condition_attns.py:93).
+    # the V2V (agent-pair) tags among PROMPT.CONDITION.MOTION_TAG.USED_TAGS, in that list's order (condition_encoders.py:58):
+    # a 'v2v_tag' condition between prompts s and t puts an edge s -> t and an edge t -> s into the condition layers'
+    # graph (condition_attns.py:114-188).  Empty in the demo config ('v2v_tag' is not among its PROMPT.CONDITION.TYPES).
+    used_v2v_tags: Tuple[str, ...] = ()
     enc_learnable_pe: bool = False
     dec_learnable_pe: bool = False
     pol_learnable_pe: bool = False

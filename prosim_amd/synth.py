@@ -25,7 +25,7 @@ from .spec import ModelSpec
 
 def make_scene(spec: ModelSpec, n_agents: int, n_polylines: int, batch: int = 1, seed: int = 0,
                square: float = 200.0, points: int = 19, goal: bool = False, tags: bool = False,
-               ragged: bool = False, clustered: bool = False, replay: float = 0.0, drag: bool = False,
+               ragged: bool = False, clustered: bool = False, replay: float = 0.0, drag: bool = False, v2v: bool = False,
                enter: float = 0.0) -> Dict[str, np.ndarray]:
     """One batch of ``batch`` scenes.  ``ragged``: later scenes in the batch get fewer agents /
     polylines / points, and some history steps are masked (NaN), to exercise the mask paths.
@@ -181,6 +181,33 @@ def make_scene(spec: ModelSpec, n_agents: int, n_polylines: int, batch: int = 1,
         keep &= dm[..., None]
         dp = np.where(keep[..., None], dp, np.nan).astype(f32)
         cond["drag_point"] = dict(input=dp, mask=dm, prompt_idx=np.tile(np.arange(N)[None, :, None], (B, 1, 1)).astype(np.int64))
+    if v2v:
+        # binary tags (condition_utils: 'v2v_tag'): per scene up to N pairs of distinct policy agents, a tag of the spec's
+        # used V2V tags, a time span; every (tag, s, t) at most once (the reference writes its edge matrix by assignment)
+        from .spec import V2V_TAGS
+        if not spec.used_v2v_tags:
+            raise ValueError("v2v conditions need spec.used_v2v_tags")
+        C = N
+        vi = np.zeros((B, C, 3), f32)
+        vi[..., 0] = -1.0
+        vm = np.zeros((B, C), bool)
+        vp = np.zeros((B, C, 2), np.int64)
+        for b in range(B):
+            pol = np.nonzero(prompt_mask[b])[0]
+            seen = set()
+            if len(pol) < 2:
+                continue
+            for c in range(C):
+                s_, t_ = rng.choice(pol, 2, replace=False)
+                tag = V2V_TAGS.index(spec.used_v2v_tags[rng.randint(len(spec.used_v2v_tags))])
+                if (tag, int(s_), int(t_)) in seen or (tag, int(t_), int(s_)) in seen:
+                    continue
+                seen.add((tag, int(s_), int(t_)))
+                t0 = float(rng.randint(0, spec.max_steps // 2))
+                vi[b, c] = (tag, t0, t0 + float(rng.randint(5, spec.max_steps // 2)))
+                vp[b, c] = (s_, t_)
+                vm[b, c] = (rng.rand() < 0.7) if ragged else True
+        cond["v2v_tag"] = dict(input=vi, mask=vm, prompt_idx=vp)
     if cond:
         scene["cond"] = cond
     return scene

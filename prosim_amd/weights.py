@@ -166,6 +166,8 @@ def param_shapes(spec: ModelSpec) -> "OrderedDict[str, Tuple[int, ...]]":
     _mlp_shapes(out, f"{ct}.condition_encoders.goal.goal_encoder", [2, d, d], True, True)
     for tag in USED_V_ACTION_TAGS:
         out[f"{ct}.condition_encoders.v_action_tag.tag_encoder.{tag}"] = (d,)
+    for tag in spec.used_v2v_tags:   # V2V_MotionTagEncoder: one [2 d] parameter per used tag (source half | target half)
+        out[f"{ct}.condition_encoders.v2v_tag.tag_encoder.{tag}"] = (2 * d,)
     for i in range(spec.cond_layers):
         _attn_shapes(out, f"{ct}.condition_attn.attn_layers.{i}", d, hd, False)
     # DragPointEncoder (condition_encoders.py:152-191): a PointNet over the [x, y] drag points
@@ -179,7 +181,8 @@ def param_shapes(spec: ModelSpec) -> "OrderedDict[str, Tuple[int, ...]]":
 DRAG_ENCODER = "condition_encoders.drag_point.pointnet_encoder"
 OBS_UPDATE_MLP = "scene_encoder.obs_update_mlp"
 PE_EMB = "_rel_pe_emb."
-_LATE = (DRAG_ENCODER, OBS_UPDATE_MLP, PE_EMB)   # tensor groups added after the first fixtures: each draws from its own generator
+V2V_ENCODER = "condition_encoders.v2v_tag."
+_LATE = (DRAG_ENCODER, OBS_UPDATE_MLP, PE_EMB, V2V_ENCODER)   # tensor groups added after the first fixtures: each draws from its own generator
 
 
 def init_weights(spec: ModelSpec, seed: int = 0) -> Dict[str, np.ndarray]:

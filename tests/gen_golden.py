@@ -26,7 +26,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 from prosim_amd import synth, weights  # noqa: E402
-from prosim_amd.spec import SMALL_SPEC, DEMO_SPEC, ModelSpec  # noqa: E402
+from prosim_amd.spec import SMALL_SPEC, DEMO_SPEC, ModelSpec, USED_V_ACTION_TAGS  # noqa: E402
 from oracle import prosim_oracle as orc, ref_harness as rh  # noqa: E402
 
 GOLD = os.path.join(ROOT, "tests", "golden")
@@ -66,12 +66,15 @@ FULL_CASES = {
     # TRAJ.K = 3 motion modes, ROLLOUT.POLICY.TOP_K = 3: every replan follows a randomly drawn mode (traj_sam.py:300-313);
     # the fixture keeps the reference's draws (mode_choice) and the torch seed they came from
     "small_topk3_b2": ("small_k3", dict(n_agents=16, n_polylines=128, batch=2, seed=12, goal=True, ragged=True, replay=0.3), 0),
+    # binary (agent-pair) conditions: 'v2v_tag' beside the unary types (condition_attns.py:114-188: edges s -> t and t -> s)
+    "small_v2v_b2": ("small_v2v", dict(n_agents=16, n_polylines=128, batch=2, seed=15, goal=True, tags=True, v2v=True, ragged=True), 0),
     # *.ATTN.LEARNABLE_PE: the relative-PE rows of all six edge sets from learnable FourierEmbedding modules
     "small_lpe_b2": ("small_lpe", dict(n_agents=16, n_polylines=128, batch=2, seed=13, goal=True, tags=True, ragged=True), 0),
 }
 SPECS = {"small": SMALL_SPEC, "demo": DEMO_SPEC, "small_mlp": SMALL_SPEC.replace(obs_fusion="mlp"),
          "small_mlp_attn": SMALL_SPEC.replace(obs_fusion="mlp", obs_attn_update=True),
          "small_k3": SMALL_SPEC.replace(motion_k=3, rollout_top_k=3),
+         "small_v2v": SMALL_SPEC.replace(used_v2v_tags=("Following", "Merging", "Overtaking")),
          "small_lpe": SMALL_SPEC.replace(enc_learnable_pe=True, dec_learnable_pe=True, pol_learnable_pe=True, pe_num_freq=64)}
 TOPK_SEED = 777   # torch.manual_seed before a forward whose rollout draws modes
 
@@ -83,13 +86,15 @@ def ref_overrides(spec: ModelSpec):
             "MODEL.SCENE_ENCODER.ATTN.AGENT_RADIUS", spec.enc_agent_radius, "MODEL.SCENE_ENCODER.ATTN.SCENE_RADIUS", spec.enc_scene_radius,
             "MODEL.POLICY.ACT_DECODER.TRAJ.K", spec.motion_k, "ROLLOUT.POLICY.TOP_K", spec.rollout_top_k,
             "MODEL.DECODER.GOAL_PRED.ENABLE", spec.goal_pred_k > 0, "MODEL.DECODER.GOAL_PRED.K", max(spec.goal_pred_k, 1),
+            "PROMPT.CONDITION.MOTION_TAG.USED_TAGS", list(USED_V_ACTION_TAGS) + list(spec.used_v2v_tags),
             "MODEL.SCENE_ENCODER.ATTN.LEARNABLE_PE", spec.enc_learnable_pe, "MODEL.SCENE_ENCODER.ATTN.PE_NUM_FREQ", spec.pe_num_freq,
             "MODEL.DECODER.ATTN.LEARNABLE_PE", spec.dec_learnable_pe, "MODEL.DECODER.ATTN.PE_NUM_FREQ", spec.pe_num_freq,
             "MODEL.POLICY.ACT_DECODER.ATTN.LEARNABLE_PE", spec.pol_learnable_pe, "MODEL.POLICY.ACT_DECODER.ATTN.PE_NUM_FREQ", spec.pe_num_freq]
 
 
 def run_reference(spec, w, scene):
-    cfg = rh.get_config(overrides=ref_overrides(spec))
+    cond_types = ("goal", "v_action_tag", "drag_point") + (("v2v_tag",) if spec.used_v2v_tags else ())
+    cfg = rh.get_config(cond_types=cond_types, overrides=ref_overrides(spec))
     model = rh.build_model(cfg)
     missing, unexpected = model.load_state_dict(weights.to_reference_state_dict(spec, w), strict=False)
     assert not unexpected, unexpected

@@ -363,3 +363,48 @@ def test_k_chain16_results_do_not_depend_on_the_tiling():
                 assert np.array_equal(a, b)
     finally:
         eng.close()
+
+
+# ------------------------------------------------------------------ binary (agent-pair) conditions
+@pytest.mark.parametrize("shape", ["mixed", "pairs_only", "hub"])
+def test_pair_conditions_vs_oracle(shape):
+    """'v2v_tag' conditions (condition_encoders.py:148-150, condition_attns.py:141-166): edges s -> t and t -> s in the
+    condition layers' graph, pooled with the unary keys that share an edge.  'hub': one prompt is the target of 40 pairs
+    (two 32-edge tiles into one destination); masked rows and tag values outside the used list make no edge.  The oracle
+    is pinned to the reference by tests/golden/ref_standins_small_v2v_b2.npz (test_hip_parity checks the engine on it)."""
+    from gen_golden import SPECS
+    from prosim_amd.engine import Engine
+    spec = SPECS["small_v2v"]
+    w = weights.init_weights(spec, 0)
+    scene = synth.make_scene(spec, 48 if shape == "hub" else 20, 60, batch=2, seed=41, goal=(shape == "mixed"), tags=(shape == "mixed"),
+                             drag=(shape == "mixed"), v2v=True, ragged=True)
+    if shape == "hub":
+        c = scene["cond"]["v2v_tag"]
+        pol = np.nonzero(scene["prompt_mask"][0])[0]
+        n = min(40, len(pol) - 1)
+        c["input"][0, :n, 0] = 2.0                                   # Merging
+        c["prompt_idx"][0, :n, 0] = pol[1:n + 1]
+        c["prompt_idx"][0, :n, 1] = pol[0]
+        c["mask"][0, :n] = True
+        c["mask"][0, n:] = False
+        c["input"][1, :3, 0] = 1.0                                   # ParallelDriving: not among the used tags -> no entry
+    with torch.no_grad():
+        o64 = orc.rollout(w, spec, scene, dtype=torch.float64, collect=True)
+    eng = Engine(spec, w)
+    try:
+        eng.set_scene(scene)
+        eng.encode_scene()
+        eng.generate_policy()
+        pm = scene["prompt_mask"].astype(bool)
+        assert err(eng.padded("policy_emd")[pm], o64["policy_emd"].numpy()[pm]) < 2 * TOL
+        # the conditions matter: without them the embeddings are elsewhere
+        plain = dict(scene, cond={k: v for k, v in scene["cond"].items() if k != "v2v_tag"})
+        eng.set_scene(plain)
+        eng.encode_scene(); eng.generate_policy()
+        assert err(eng.padded("policy_emd")[pm], o64["policy_emd"].numpy()[pm]) > 1e-2
+        eng.set_scene(scene)
+        eng.rollout()
+        A = eng.num_agents
+        assert err(eng.get("motion_pred")[0], o64["motion_pred"][:A].numpy()) < TOL
+    finally:
+        eng.close()

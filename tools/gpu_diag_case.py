@@ -15,6 +15,8 @@ cases = {
 }
 cases["t70"] = (SMALL_SPEC.replace(obs_fusion="mlp"), dict(n_agents=1, n_polylines=300, batch=5, seed=189543, goal=False, tags=False, drag=False, ragged=False, clustered=True, replay=0.0, square=30.0))
 cases["t80"] = (SMALL_SPEC, dict(n_agents=3, n_polylines=128, batch=5, seed=587658, goal=False, tags=False, drag=False, ragged=True, clustered=False, replay=0.0, square=100.0))
+# round 2, k_chain16 forced for every chain (PS_IMPL=2): the one case of 160 the sweep flagged
+cases["r2_131"] = (SMALL_SPEC, dict(n_agents=33, n_polylines=5, batch=3, seed=95645, goal=False, tags=False, drag=False, ragged=True, clustered=False, replay=0.3, square=100.0))
 for name in sys.argv[1:] or list(cases):
     spec, kw = cases[name]
     scene = synth.make_scene(spec, **kw)
@@ -23,6 +25,7 @@ for name in sys.argv[1:] or list(cases):
         o64 = orc.rollout(w, spec, scene, dtype=torch.float64)
         o32 = orc.rollout(w, spec, scene)
     eng = Engine(spec, w)
+    eng.set_chain_impl(int(os.environ.get("PS_IMPL", "0")))
     eng.set_scene(scene)
     eng.encode_scene(); eng.generate_policy(); eng.reset_rollout()
     pol = eng.policy_rows

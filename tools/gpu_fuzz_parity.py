@@ -52,6 +52,7 @@ for case in range(n_cases):
     if key not in engines:
         engines[key] = (Engine(spec, weights.init_weights(spec, 0)), weights.init_weights(spec, 0))
         engines[key][0].set_chain_rows(FUZZ_ROWS)
+        engines[key][0].set_chain_impl(int(os.environ.get("FUZZ_IMPL", "0")))   # 2: every fused chain on k_chain16, whatever the size
     eng, w = engines[key]
     with torch.no_grad():
         o64 = orc.rollout(w, spec, scene, dtype=torch.float64)
