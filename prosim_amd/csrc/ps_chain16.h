@@ -121,19 +121,16 @@ __global__ __launch_bounds__(256) void k_edge_geo(GeoSets sets, const float* __r
       xs[i] = xin[i] * PS_TWO_PI_F;
       fast = fast && fdiv16_ok(xs[i]);
     }
-    // two passes like torch's LayerNorm (mean, then centred squares) over the 48 distinct pairs, which stay in registers
-    // between the passes (96 values: the kernel has the registers to spare, and the transcendental work is done once)
-    float sv[48], cv[48];
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-      for (int k = 0; k < 16; ++k) fourier_pair(xs[i], dv[k], rdv[k], fast, sv[16 * i + k], cv[16 * i + k]);
+    // two passes like torch's LayerNorm (mean, then centred squares); the pairs are recomputed instead of stored
     float sm = 0.f;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       float part = 0.f;
-#pragma unroll
-      for (int k = 0; k < 16; ++k) part += sv[16 * i + k] + cv[16 * i + k];
+      for (int k = 0; k < 16; ++k) {
+        float sv, cv;
+        fourier_pair(xs[i], dv[k], rdv[k], fast, sv, cv);
+        part += sv + cv;
+      }
       sm += (i == 2) ? 2.f * part : part;
     }
     const float mean = sm * (1.f / 128.f);
@@ -141,11 +138,13 @@ __global__ __launch_bounds__(256) void k_edge_geo(GeoSets sets, const float* __r
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       float part = 0.f;
-#pragma unroll
       for (int k = 0; k < 16; ++k) {
-        const float a_ = sv[16 * i + k] - mean, b_ = cv[16 * i + k] - mean;
-        part = fmaf(a_, a_, part);
-        part = fmaf(b_, b_, part);
+        float sv, cv;
+        fourier_pair(xs[i], dv[k], rdv[k], fast, sv, cv);
+        sv -= mean;
+        cv -= mean;
+        part = fmaf(sv, sv, part);
+        part = fmaf(cv, cv, part);
       }
       sq += (i == 2) ? 2.f * part : part;
     }
