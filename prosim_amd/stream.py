@@ -30,9 +30,9 @@ class RolloutPipeline:
         if depth < 1:
             raise ValueError("depth must be >= 1")
         self.engines: List[Engine] = [Engine(spec, weights, device=device) for _ in range(depth)]
-        if depth > 1:   # throughput mode: one workgroup per CU and launch, launches of different rollouts co-reside
+        if depth > 1:   # throughput mode (k_chain16, 16 rows per workgroup): the launches of the rollouts in flight share the chip
             for e in self.engines:
-                e.set_chain_rows(4)
+                e.set_chain_rows(16)
         self.outputs = tuple(outputs)
         self._pending: List[Optional[int]] = [None] * depth      # ticket each engine is working on
         self._next = 0

@@ -15,14 +15,22 @@ def test_pipeline_equals_single_engine_and_keeps_order():
     w = weights.init_weights(spec, 0)
     scenes = [synth.make_scene(spec, 6 + 5 * (i % 3), 20 + 17 * i, batch=1 + i % 2, seed=60 + i, goal=bool(i % 2), ragged=bool(i % 3 == 0),
                                replay=0.4 if i % 4 == 1 else 0.0) for i in range(7)]
-    eng = Engine(spec, w)
-    want = []
-    for sc in scenes:
-        eng.set_scene(sc)
-        eng.rollout()
-        want.append((eng.padded("traj"), eng.get("motion_pred")))
-    eng.close()
+    # one engine in the mode the pipeline runs its engines in: latency mode at depth 1, throughput mode (16 rows per
+    # workgroup, every fused chain on k_chain16) beyond -- two kernels, two summation orders
+    wants = {}
+    for rows in (0, 16):
+        eng = Engine(spec, w)
+        eng.set_chain_rows(rows)
+        wants[rows] = []
+        for sc in scenes:
+            eng.set_scene(sc)
+            eng.rollout()
+            wants[rows].append((eng.padded("traj"), eng.get("motion_pred")))
+        eng.close()
+    for a, b in zip(wants[0], wants[16]):
+        assert np.abs(a[1][0] - b[1][0]).max() < 2e-5                      # replan 0: the modes agree to fp32 rounding
     for depth in (1, 2, 3):
+        want = wants[0 if depth == 1 else 16]
         with RolloutPipeline(spec, w, depth=depth, outputs=("traj", "motion_pred")) as pipe:
             got = list(pipe.run(scenes))
             assert [i for i, _ in got] == list(range(len(scenes)))
