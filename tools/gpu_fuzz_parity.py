@@ -16,12 +16,18 @@ rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 torch.set_num_threads(32)
 variants = [SMALL_SPEC, SMALL_SPEC.replace(obs_fusion="mlp"), SMALL_SPEC.replace(obs_attn_update=True),
             SMALL_SPEC.replace(obs_fusion="mlp", obs_attn_update=True)]
+if os.environ.get("FUZZ_R2"):   # round-2 variants: learnable rel-PE (all parts / policy only), binary tags, K = 3 modes with random draws
+    variants = [SMALL_SPEC.replace(enc_learnable_pe=True, dec_learnable_pe=True, pol_learnable_pe=True),
+                SMALL_SPEC.replace(pol_learnable_pe=True, obs_fusion="mlp"),
+                SMALL_SPEC.replace(used_v2v_tags=("Following", "Merging", "Overtaking")),
+                SMALL_SPEC.replace(used_v2v_tags=("ParallelDriving",), dec_learnable_pe=True),
+                SMALL_SPEC.replace(motion_k=3, rollout_top_k=3)]
 engines = {}
 worst = 0.0
 bad = []
 t0 = time.time()
 for case in range(n_cases):
-    spec = variants[rng.randint(len(variants)) if rng.rand() < 0.4 else 0]
+    spec = variants[rng.randint(len(variants)) if (rng.rand() < 0.4 or os.environ.get("FUZZ_R2")) else 0]
     if rng.rand() < 0.35:   # small neighbour caps / radii: the index-order truncation and the degree-bound paths
         spec = spec.replace(dec_max_neigh=int(rng.choice([4, 16, 512])), pol_max_neigh=int(rng.choice([3, 12, 768])),
                             scene_knn=int(rng.choice([2, 8, 32])), dec_prompt_radius=float(rng.choice([20.0, 300.0])),
@@ -38,12 +44,16 @@ for case in range(n_cases):
         kw["replay"] = 0.0
     if kw["replay"] > 0 and rng.rand() < 0.5:
         kw["enter"] = 0.5                                   # some log-replay agents enter the scene at a later replan
+    if spec.used_v2v_tags:
+        kw["v2v"] = True
     try:
         scene = synth.make_scene(spec, **kw)
     except Exception as ex:   # a generator corner (e.g. nothing left to replay): not an engine case
         print(case, "skip (generator):", type(ex).__name__, ex, kw, flush=True)
         continue
-    key = (spec.obs_fusion, spec.obs_attn_update, spec.dec_max_neigh, spec.pol_max_neigh, spec.scene_knn, spec.dec_prompt_radius,
+    if spec.motion_k > 1:
+        scene["mode_choice"] = rng.randint(0, spec.motion_k, (spec.n_replans,) + scene["prompt_mask"].shape).astype(np.int32)
+    key = (spec.enc_learnable_pe, spec.dec_learnable_pe, spec.pol_learnable_pe, spec.used_v2v_tags, spec.motion_k, spec.obs_fusion, spec.obs_attn_update, spec.dec_max_neigh, spec.pol_max_neigh, spec.scene_knn, spec.dec_prompt_radius,
            spec.dec_scene_radius, spec.pol_agent_radius, spec.pol_map_radius, spec.enc_agent_radius, spec.enc_scene_radius)
     if len(engines) > 12:   # bounded number of live engines
         for eng_, _ in engines.values():
