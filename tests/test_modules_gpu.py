@@ -233,9 +233,15 @@ def test_agents_entering_the_scene_vs_fixture(model):
         assert err(listed_form["rollout_trajs"][k]["traj"].numpy(), r["traj"].numpy()) < 3 * floor + 1e-4
 
 
-def test_staged_components_and_stateless_policy(model):
-    """scene_encoder(...) -> decoder(...) -> policy(...) with the reference's argument layouts."""
+@pytest.mark.parametrize("variant", ["fixed_pe", "learnable_pe"])
+def test_staged_components_and_stateless_policy(model, variant):
+    """scene_encoder(...) -> decoder(...) -> policy(...) with the reference's argument layouts (with the fixed Fourier
+    rel-PE and with the learnable one: the stateless policy call builds its own edge sets and rows)."""
     spec = SMALL_SPEC
+    if variant == "learnable_pe":
+        from prosim_amd import modules
+        spec = SMALL_SPEC.replace(enc_learnable_pe=True, dec_learnable_pe=True, pol_learnable_pe=True)
+        model = modules.registry.get_model("prosim_policy_relpe_T_step_temporal_close_loop")(spec, weights.init_weights(spec, 0)).eval()
     scene = synth.make_scene(spec, 12, 40, batch=2, seed=4, ragged=True)
     w = weights.init_weights(spec, 0)
     with torch.no_grad():
@@ -312,3 +318,5 @@ def test_staged_components_and_stateless_policy(model):
     assert err(se3["scene_tokens"][Mv:].numpy(), emb3[valid3].numpy()) < 1e-4
     assert err(se3["scene_pos"][Mv:].numpy(), changed["position"][valid3].numpy()) == 0
     assert torch.equal(se3["scene_batch_idx"][Mv:], orc._flat_batch_idx(valid3))
+    if variant == "learnable_pe":
+        model.engine.close()
