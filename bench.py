@@ -306,6 +306,11 @@ def main():
         eng.set_scene(parts[0])
         ms_rep, st_rep = eng.time_rollout(1, 3)
         A_rep = eng.num_agents
+        # its policy launch has 4096 rows = 256 workgroups of 16: ONE launch fills the chip, so here the per-launch rate is
+        # the chip's rate (the 8-scene launch of the headline has 64 workgroups and shares the chip with three others)
+        ms_chain_rep = eng.time_policy_kernel(3)
+        ec_rep = eng.get("edge_counts")
+        fl_rep = algorithmic_flops_chain(A_rep, float(ec_rep[4]), float(ec_rep[5]), spec.pol_layers)
         world_buf = torch.zeros(A_rep, spec.max_steps, 3, device="cuda")
         tf = np.array([[0.6, -0.8, 3418.7], [0.8, 0.6, -1650.2], [0, 0, 1]], np.float32)
         eng.world_trajs(tf, world_buf.data_ptr())
@@ -324,6 +329,9 @@ def main():
                    "replicated_batch": {"note": "the reference's layout: every tensor .repeat(32) on the batch dim, whole path per replica",
                                         "ms_per_rollout": ms_tiled,
                                         "stage_ms": {"encode_scene": st_tiled[0], "generate_policy": st_tiled[1], "replan_loop": st_tiled[2]}},
+                   "policy_chain_launch": {"rows": A_rep, "workgroups": (A_rep + 15) // 16, "ms": ms_chain_rep,
+                                           "algorithmic_flops": fl_rep, "algorithmic_tflops": fl_rep / (ms_chain_rep * 1e-3) / 1e12,
+                                           "frac_of_f16_mfma_peak": fl_rep / (ms_chain_rep * 1e-3) / 1e12 / 2500.0},
                    "speedup_vs_replicated_batch": ms_tiled / ms_rep,
                    "world_frame_kernel_ms": ms_world}
         fl_alg = algorithmic_flops_chain(A, float(ec[4]), float(ec[5]), spec.pol_layers)
