@@ -713,7 +713,7 @@ extern "C" void ps_destroy(ps_engine* e) {
   if (!e) return;
   (void)hipSetDevice(e->cfg.device);
   (void)hipDeviceSynchronize();
-  // DevBuf members are plain structs without destructors: release explicitly
+  // (DevBuf members free themselves when the engine is deleted; the explicit releases keep the order: buffers before the stream)
   e->d_map_input.release(); e->d_obs_input.release(); e->d_prompt.release(); e->d_fut.release();
   e->d_is_policy.release(); e->d_tok_live.release(); e->d_live0.release(); e->d_obs_in_mask.release(); e->d_fut_mask.release();
   e->d_obs_mask_rows.release();
