@@ -12,6 +12,7 @@ so this module restates the arithmetic of those formatters on plain arrays:
                                -heading), NaN + mask for missing steps, extent / type / time one-hots, and the
                                status prompt ``AgentStatusGenerator.prompt_for_scene_batch``
                                (prompt_utils.py:111-150): [v_local(2), extent(2), type one-hot(3)];
+* ``agent_types_from_scene_metadata`` -- the cache's pickled ``Scene`` -> agent id -> type, read without trajdata;
 * ``polylines_to_map``      -- ``local_map_to_sym_coord`` + ``get_center_vec_init_map`` (format_utils.py:184-263):
                                per-polyline frame = midpoint / tangent of (first start, last valid end), segments in
                                that frame, type one-hot, unit direction;
@@ -49,6 +50,42 @@ def tracks_from_table(cols: Dict[str, np.ndarray], n_steps: Optional[int] = None
         arr = np.full((len(uniq), T), np.nan, np.float64)
         arr[rows[keep], ts[keep]] = np.asarray(cols[c], np.float64)[keep]
         out[c] = arr
+    return out
+
+
+def agent_types_from_scene_metadata(path: str) -> Dict[str, int]:
+    """The cache's ``scene_metadata_dt*.dill`` (a pickled trajdata ``Scene``) -> {agent id: AgentType value} WITHOUT trajdata:
+    the pickle is read with structural stand-ins for every ``trajdata.*`` class (they keep their state dict, an enum keeps
+    its value).  trajdata's AgentType: 0 unknown, 1 vehicle, 2 pedestrian, 3 bicycle, 4 motorcycle; the reference's model
+    types are 1 vehicle, 2 pedestrian, 3 cyclist (DATASET.USE_PED_CYCLIST; prompt / observation one-hots over 1..3)."""
+    import pickle
+
+    class _Stub:
+        def __init__(self, *a, **k):
+            self._args = a
+            self.__dict__.update(k)
+
+        def __setstate__(self, st):
+            if isinstance(st, dict):
+                self.__dict__.update(st)
+            else:
+                self._state = st
+
+    class _Unpickler(pickle.Unpickler):
+        def find_class(self, module, name):
+            if module.split(".")[0] == "trajdata":
+                return type(name, (_Stub,), {"__module__": module})
+            if module.split(".")[0] == "dill":
+                import dill._dill as dd                                   # (the cache is written with dill)
+                return getattr(dd, name)
+            return super().find_class(module, name)
+
+    with open(path, "rb") as f:
+        scene = _Unpickler(f).load()
+    out = {}
+    for a in scene.__dict__["agents"]:
+        t = a.__dict__["type"]
+        out[str(a.__dict__["name"])] = int(t._args[0]) if getattr(t, "_args", None) else int(getattr(t, "_state", 0) or 0)
     return out
 
 

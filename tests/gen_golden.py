@@ -316,6 +316,9 @@ def gen_demo_map(scene: str = "scene_1", map_name: str = "waymo_train_1"):
     root = os.path.join(os.environ.get("PROSIM_REF", "/root/reference"), "demo_dataset", "trajdata_cache", "waymo_train")
     shutil.copyfile(os.path.join(root, "maps", map_name + ".pb"), os.path.join(GOLD, f"demo_{map_name}_map.pb"))
     os.chmod(os.path.join(GOLD, f"demo_{map_name}_map.pb"), 0o644)
+    # ... and the scene's metadata (agent types, first / last steps, extents), as the cache stores it
+    shutil.copyfile(os.path.join(root, scene, "scene_metadata_dt0.10.dill"), os.path.join(GOLD, f"demo_{scene}_metadata.dill"))
+    os.chmod(os.path.join(GOLD, f"demo_{scene}_metadata.dill"), 0o644)
     with open(os.path.join(root, scene, "tls_data_dt0.10.feather"), "rb") as f:
         t = ipc.open_file(f).read_all()
     np.savez_compressed(os.path.join(GOLD, f"demo_{scene}_tls_table.npz"),

@@ -209,14 +209,29 @@ def demo_scene_real_lanes(spec, t0=10, max_agents=16):
     mp = vm.map_for_scene(spec, _pb(), world, center_z=z, tls=vm.tls_at(tl["lane_id"], tl["scene_ts"], tl["status"], t0))
     present = np.isfinite(tr["x"][:, t0])
     order = [ego] + [i for i in np.nonzero(present)[0] if i != ego]           # the centred agent is agent 0 (format_utils.py:229)
-    sc = fmt.scene_from_tracks(spec, tr, t0, agents=order, max_agents=max_agents, frame=f, map_fields=mp)
+    # the agents' types from the cache's scene metadata (vehicle 1, pedestrian 2, bicycle 3), read without trajdata
+    meta = fmt.agent_types_from_scene_metadata(os.path.join(GOLD, "demo_scene_1_metadata.dill"))
+    types = np.array([meta[a] for a in tr["agent_ids"]], np.int64)
+    sc = fmt.scene_from_tracks(spec, tr, t0, agents=order, max_agents=max_agents, frame=f, map_fields=mp, agent_types=types)
     sc.pop("agent_ids")
     return sc
 
 
+def test_scene_metadata_is_read_without_trajdata():
+    meta = fmt.agent_types_from_scene_metadata(os.path.join(GOLD, "demo_scene_1_metadata.dill"))
+    tr, _, _ = _tracks()
+    assert set(meta) == set(tr["agent_ids"].tolist()) and meta["ego"] == 1
+    vals = np.array(list(meta.values()))
+    assert (vals == 1).sum() == 50 and (vals == 2).sum() == 2 and (vals == 3).sum() == 6     # vehicles, pedestrians, bicycles
+    # the types line up with the tracks they name: pedestrians are the short ones, vehicles the long ones
+    ln = {a: float(np.nanmedian(tr["length"][i])) for i, a in enumerate(tr["agent_ids"])}
+    assert max(ln[a] for a, t in meta.items() if t == 2) < 1.5 < np.median([ln[a] for a, t in meta.items() if t == 1])
+
+
 def test_real_lane_scene_rolls_out_and_is_frame_invariant():
     spec = SMALL_SPEC.replace(max_steps=20)
-    sc = demo_scene_real_lanes(spec)
+    sc = demo_scene_real_lanes(spec, max_agents=24)
+    assert set(np.unique(sc["agent_type"])) >= {1, 3}                              # more than one type among the first 24
     assert sc["map_input"].shape[1] > 300 and np.abs(sc["obs_pos"][0, 0]).max() < 1e-4 and abs(sc["obs_head"][0, 0]) < 1e-6
     # agents drive on the lanes: every moving agent is within a lane width of some centre-line chunk
     d = np.linalg.norm(sc["obs_pos"][0][:, None] - sc["map_pos"][0][None], axis=-1).min(1)
@@ -232,6 +247,6 @@ def test_real_lane_scene_rolls_out_and_is_frame_invariant():
     with torch.no_grad():
         a = orc.rollout(w, spec, sc, dtype=torch.float64)
         b = orc.rollout(w, spec, sc2, dtype=torch.float64)
-    assert a["traj"].shape == (1, 16, 20, 4) and torch.isfinite(a["traj"]).all()
+    assert a["traj"].shape == (1, 24, 20, 4) and torch.isfinite(a["traj"]).all()
     # (rows of replan 0: later replans start from poses that already carry the float32 rounding of the moved frame)
-    assert (a["motion_pred"][:16] - b["motion_pred"][:16]).abs().max() < 2e-4
+    assert (a["motion_pred"][:24] - b["motion_pred"][:24]).abs().max() < 2e-4
