@@ -11,15 +11,17 @@
 //   * a workgroup (4 waves) owns R <= 16 rows; every node Linear is a 16-row split-fp16 MFMA GEMM against pre-split
 //     weight fragments (k_node's machinery: the fragment ring stays in flight across epilogues and barriers), so the
 //     weights cross the CU once per 16 rows;
-//   * the edge phase takes one WAVE per destination (rows are handed out through an LDS counter), walks the edge list
-//     in 32-edge tiles with an online softmax (no workgroup barrier inside), and rebuilds each tile's normalised
-//     Fourier rows in registers from (2 pi dist, 2 pi rel_ori, 2 pi angle, rstd, -mean rstd): per (edge, frequency)
-//     one exact division by reciprocal + correction, one Cody-Waite reduction and two degree-7 polynomials.  The rows
-//     feed the score MFMAs straight from registers and the aggregation MFMAs through a wave-private row-major LDS tile
-//     read back with ds_read_b64_tr_b16 (recipe: tools/mb/mb_trread.hip);
-//   * per-destination vectors (q~, s, g, a_r, a_v, l) pass between the phases through the workgroup's own rows of the
-//     EdgeIO scratch (L2-resident; same-CU visibility needs only the workgroup barrier).
-// The 12 policy layers stay one launch per replan; LDS <= 78 KB and <= 256 registers: two workgroups per CU.
+//   * the edge phase takes one WAVE per destination (rows are handed out longest first through an LDS counter; W = 8 / rows
+//     waves per row below 8 rows per workgroup), walks the edge list in 16-edge tiles with an online softmax (no workgroup
+//     barrier inside), and rebuilds each tile's normalised Fourier rows in registers from (2 pi dist, 2 pi rel_ori,
+//     2 pi angle, rstd, -mean rstd): per (edge, frequency) one exact division by reciprocal + correction, one reduction to
+//     revolutions, v_sin_f32 / v_cos_f32.  The rows feed the score MFMAs straight from registers and the aggregation
+//     MFMAs through a wave-private row-major LDS tile read back with ds_read_b64_tr_b16 (recipe: tools/mb/mb_trread.hip);
+//     a row's tiles are always summed in two parity classes merged (even, odd), whatever the tiling (c16_edge_phase);
+//   * q~ and a_r pass between the phases through LDS slots of the workgroup, the other per-destination vectors (s, g,
+//     a_v, l) through the workgroup's own rows of the EdgeIO scratch (L2-resident; same-CU visibility needs only the
+//     workgroup barrier).
+// The 12 policy layers stay one launch per replan; 8 waves per workgroup, one workgroup per CU (150 KB LDS, 256 registers).
 #pragma once
 #include "ps_attn.h"
 
