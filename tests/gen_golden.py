@@ -307,15 +307,20 @@ def gen_demo_tracks(scene: str = "scene_0"):
     print("demo tracks written:", scene, len(out["scene_ts"]), "rows,", len(set(out["agent_id"].tolist())), "agents")
 
 
-def gen_demo_map(scene: str = "scene_1", map_name: str = "waymo_train_1"):
+def gen_demo_map(scene: str = "scene_1", map_name: str = "waymo_train_1", compress: bool = False):
     """DATA fixtures for the real-lane plumbing config: the scene's vector map as the cache stores it (a protobuf data
     file of the reference's sample data, copied byte for byte -- prosim_amd/vecmap.py decodes its wire format) and its
     traffic-light table (lane_id, scene_ts, status; empty for scene_1)."""
     import shutil
     import pyarrow.ipc as ipc
     root = os.path.join(os.environ.get("PROSIM_REF", "/root/reference"), "demo_dataset", "trajdata_cache", "waymo_train")
-    shutil.copyfile(os.path.join(root, "maps", map_name + ".pb"), os.path.join(GOLD, f"demo_{map_name}_map.pb"))
-    os.chmod(os.path.join(GOLD, f"demo_{map_name}_map.pb"), 0o644)
+    if compress:   # (a 1 MB map: the same bytes, xz-compressed)
+        import lzma
+        with open(os.path.join(root, "maps", map_name + ".pb"), "rb") as f, open(os.path.join(GOLD, f"demo_{map_name}_map.pb.xz"), "wb") as g:
+            g.write(lzma.compress(f.read(), preset=9))
+    else:
+        shutil.copyfile(os.path.join(root, "maps", map_name + ".pb"), os.path.join(GOLD, f"demo_{map_name}_map.pb"))
+        os.chmod(os.path.join(GOLD, f"demo_{map_name}_map.pb"), 0o644)
     # ... and the scene's metadata (agent types, first / last steps, extents), as the cache stores it
     shutil.copyfile(os.path.join(root, scene, "scene_metadata_dt0.10.dill"), os.path.join(GOLD, f"demo_{scene}_metadata.dill"))
     os.chmod(os.path.join(GOLD, f"demo_{scene}_metadata.dill"), 0o644)
@@ -325,7 +330,7 @@ def gen_demo_map(scene: str = "scene_1", map_name: str = "waymo_train_1"):
                         lane_id=np.asarray(t.column("lane_id").to_numpy(zero_copy_only=False)).astype(str),
                         scene_ts=np.asarray(t.column("scene_ts").to_numpy(zero_copy_only=False), np.int64),
                         status=np.asarray(t.column("status").to_numpy(zero_copy_only=False), np.int64))
-    print("demo map written:", map_name, os.path.getsize(os.path.join(GOLD, f"demo_{map_name}_map.pb")), "bytes; tls rows", t.num_rows)
+    print("demo map written:", map_name, "; tls rows", t.num_rows)
 
 
 def make_world_inputs(seed: int, n_scenes: int = 3, n_agents: int = 7, T: int = 80):
@@ -430,6 +435,7 @@ if __name__ == "__main__":
     elif len(sys.argv) > 1 and sys.argv[1] == "map":
         gen_demo_tracks("scene_1")
         gen_demo_map()
+        gen_demo_map("scene_0", "waymo_train_0", compress=True)
     elif len(sys.argv) > 1 and sys.argv[1] == "world":
         gen_world()
     elif len(sys.argv) > 1 and sys.argv[1] == "metric":
@@ -442,6 +448,7 @@ if __name__ == "__main__":
         gen_demo_tracks()
         gen_demo_tracks("scene_1")
         gen_demo_map()
+        gen_demo_map("scene_0", "waymo_train_0", compress=True)
         gen_pair_metric()
         gen_world()
         gen_goal_heads()

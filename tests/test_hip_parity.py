@@ -417,7 +417,8 @@ def test_demo_dataset_scene_config0():
     eng.close()
 
 
-def test_demo_dataset_real_lanes_config0():
+@pytest.mark.parametrize("demo_scene", ["scene_1", "scene_0"])
+def test_demo_dataset_real_lanes_config0(demo_scene):
     """BASELINE configs[0] on the scene's REAL lanes: demo scene_1 (agent table + the cache's VectorMap protobuf decoded by
     prosim_amd/vecmap.py, chunked and framed as data_utils.py:156-255 / format_utils.py:150-263 do), centred on the ego,
     16 agents (vehicles, a pedestrian, bicycles: the cache's own types), 20-step unconditional rollout.  Replan-0 predictions
@@ -429,7 +430,8 @@ def test_demo_dataset_real_lanes_config0():
     from prosim_amd.engine import Engine
     from test_vecmap_cpu import demo_scene_real_lanes
     spec = DEMO_SPEC.replace(max_steps=20)
-    scene = demo_scene_real_lanes(spec)
+    # scene_0: 2048 map tokens (the MAX_POINTS cap), traffic-light records, >= 2048 scene tokens -> the split s2s layers
+    scene = demo_scene_real_lanes(spec, scene=demo_scene)
     assert scene["map_input"].shape[1] > 300
     w = weights.init_weights(spec, 0)
     with torch.no_grad():

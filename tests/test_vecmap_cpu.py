@@ -198,23 +198,48 @@ def test_vectors_to_map_frames():
     assert np.abs(wx - vec[:M, 0, 0]).max() < 1e-3 and np.abs(wy - vec[:M, 0, 1]).max() < 1e-3
 
 
-def demo_scene_real_lanes(spec, t0=10, max_agents=16):
-    """BASELINE configs[0] on the scene's real lanes: demo scene_1 at step t0 in the frame of its ego."""
-    tr, origin, g = _tracks()
+def demo_scene_real_lanes(spec, t0=10, max_agents=16, scene="scene_1"):
+    """BASELINE configs[0] on a demo scene's real lanes and agent types, at step t0 in the frame of its ego.  scene_1: a
+    small map (144 lanes, no traffic-light records); scene_0: 1056 lanes with traffic-light records -- more chunks in
+    range than DATASET.FORMAT.MAP.MAX_POINTS (2048), so the closest 2048 are kept (format_utils.py:168-176)."""
+    import lzma
+    g = np.load(os.path.join(GOLD, f"demo_{scene}_agent_table.npz"))
+    tr = fmt.tracks_from_table({k: g[k] for k in g.files if k != "origin"})
+    origin = g["origin"].astype(np.float64)
     f = fmt.ego_frame(tr, t0)
     ego = list(tr["agent_ids"]).index("ego")
-    z = float(g["z"][(g["agent_id"] == "ego") & (g["scene_ts"] == t0)][0])
-    tl = np.load(os.path.join(GOLD, "demo_scene_1_tls_table.npz"))
+    z = float(g["z"][(g["agent_id"] == "ego") & (g["scene_ts"] == t0)][0]) if "z" in g.files else None
+    tl = np.load(os.path.join(GOLD, f"demo_{scene}_tls_table.npz"))
     world = np.array([f[0] + origin[0], f[1] + origin[1], f[2]])                # the table is re-centred, the map is not
-    mp = vm.map_for_scene(spec, _pb(), world, center_z=z, tls=vm.tls_at(tl["lane_id"], tl["scene_ts"], tl["status"], t0))
+    if scene == "scene_1":
+        pb = _pb()
+    else:
+        with open(os.path.join(GOLD, "demo_waymo_train_0_map.pb.xz"), "rb") as fh:
+            pb = lzma.decompress(fh.read())
+    mp = vm.map_for_scene(spec, pb, world, center_z=z, tls=vm.tls_at(tl["lane_id"], tl["scene_ts"], tl["status"], t0))
     present = np.isfinite(tr["x"][:, t0])
     order = [ego] + [i for i in np.nonzero(present)[0] if i != ego]           # the centred agent is agent 0 (format_utils.py:229)
     # the agents' types from the cache's scene metadata (vehicle 1, pedestrian 2, bicycle 3), read without trajdata
-    meta = fmt.agent_types_from_scene_metadata(os.path.join(GOLD, "demo_scene_1_metadata.dill"))
+    meta = fmt.agent_types_from_scene_metadata(os.path.join(GOLD, f"demo_{scene}_metadata.dill"))
     types = np.array([meta[a] for a in tr["agent_ids"]], np.int64)
     sc = fmt.scene_from_tracks(spec, tr, t0, agents=order, max_agents=max_agents, frame=f, map_fields=mp, agent_types=types)
     sc.pop("agent_ids")
     return sc
+
+
+def test_big_demo_map_traffic_lights_and_the_2048_chunk_cap():
+    sc = demo_scene_real_lanes(DEMO_SPEC.replace(max_steps=20), scene="scene_0")
+    inp, msk = sc["map_input"][0], sc["map_mask"][0]
+    assert inp.shape == (2048, 19, 11)                                         # 3066 chunks in range: the closest 2048 stay
+    tl = inp[..., 5][msk]
+    assert set(np.unique(tl)) == {-1.0, 0.0, 1.0, 2.0}                         # no record / unknown / green / red at this step
+    # closest first: the kept chunks are ordered by the distance of their mean start point (get_local_vec_map :174-176)
+    d = np.linalg.norm(sc["map_pos"][0], axis=-1)
+    assert np.median(d[:200]) < np.median(d[-200:]) and d.max() < 230.0
+    # the reference takes the point mask from the chunks BEFORE that re-ordering (:168-171): kept as it is there, so some
+    # rows' masks belong to another chunk -- a mask bit over a padding segment carries the frame-shifted zero row
+    own = inp[..., 4] > 0
+    assert (own != msk).any() and msk.any(1).all()
 
 
 def test_scene_metadata_is_read_without_trajdata():
