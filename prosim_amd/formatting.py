@@ -12,6 +12,8 @@ so this module restates the arithmetic of those formatters on plain arrays:
                                -heading), NaN + mask for missing steps, extent / type / time one-hots, and the
                                status prompt ``AgentStatusGenerator.prompt_for_scene_batch``
                                (prompt_utils.py:111-150): [v_local(2), extent(2), type one-hot(3)];
+* ``rollout_batch_from_tracks`` -- the above plus ``get_future_obs`` (format_utils.py:667-687): the observation frames of the later
+                               replans for policy and log-replay agents (agents that leave or enter keep their slots);
 * ``agent_types_from_scene_metadata`` -- the cache's pickled ``Scene`` -> agent id -> type, read without trajdata;
 * ``polylines_to_map``      -- ``local_map_to_sym_coord`` + ``get_center_vec_init_map`` (format_utils.py:184-263):
                                per-polyline frame = midpoint / tangent of (first start, last valid end), segments in
@@ -98,19 +100,21 @@ def scene_from_tracks(spec: ModelSpec, tracks: Dict[str, np.ndarray], t0: int,
                       map_polylines: Optional[Sequence[np.ndarray]] = None, agent_types: Optional[np.ndarray] = None,
                       max_agents: Optional[int] = None, points: int = 19,
                       agents: Optional[Sequence[int]] = None, frame: Optional[Sequence[float]] = None,
-                      map_fields: Optional[Dict[str, np.ndarray]] = None) -> Dict[str, np.ndarray]:
+                      map_fields: Optional[Dict[str, np.ndarray]] = None, keep_absent: bool = False) -> Dict[str, np.ndarray]:
     """One scene (batch 1) at current step ``t0``.  Agents whose state at ``t0`` is not finite are dropped
     (get_center_obs skips non-target agents with a NaN origin, :383-388).  ``agents``: row indices of the track
     table to consider (default: all), ``max_agents``: keep the first so many of those that are present.
     ``frame`` = (x, y, heading) of the centre agent at ``t0`` (``ego_frame``): agent poses are reported in that frame, as
     the scene-centric batch of the reference is (its obs positions are relative to the centred agent); default: the
     table's own frame.  ``map_fields``: the map_* entries made by ``prosim_amd.vecmap`` in the SAME frame (the scene's
-    real lanes); without them (and without ``map_polylines``) lanes are drawn along the driven paths."""
+    real lanes); without them (and without ``map_polylines``) lanes are drawn along the driven paths.
+    ``keep_absent``: keep the slots of ``agents`` that are not in the scene at ``t0`` (fully masked rows) instead of dropping
+    them -- the frames of ``rollout_batch_from_tracks`` need the same slots at every replan."""
     H = spec.hist_steps
     if t0 < 0 or t0 >= tracks["x"].shape[1]:
         raise ValueError("t0 outside the track table")
     valid0 = np.isfinite(tracks["x"][:, t0]) & np.isfinite(tracks["y"][:, t0]) & np.isfinite(tracks["heading"][:, t0])
-    sel = np.nonzero(valid0)[0] if agents is None else np.array([i for i in agents if valid0[i]], np.int64)
+    sel = np.nonzero(valid0)[0] if agents is None else np.array([i for i in agents if valid0[i] or keep_absent], np.int64)
     if max_agents is not None:
         sel = sel[:max_agents]
     N = len(sel)
@@ -155,8 +159,10 @@ def scene_from_tracks(spec: ModelSpec, tracks: Dict[str, np.ndarray], t0: int,
     if frame is not None:
         px, py = _rotate(px - frame[0], py - frame[1], -frame[2])
         ph = ph - frame[2]
+    if keep_absent:   # an absent agent has no pose: keep the arrays finite, its mask says it is not there
+        px, py, ph = np.nan_to_num(px), np.nan_to_num(py), np.nan_to_num(ph)
     scene = dict(obs_input=obs.astype(f32), obs_mask=mask, obs_pos=np.stack([px, py], -1)[None].astype(f32),
-                 obs_head=ph[None].astype(f32), prompt=prompt, prompt_mask=np.ones((1, N), bool),
+                 obs_head=ph[None].astype(f32), prompt=prompt, prompt_mask=valid0[sel][None].copy(),
                  agent_type=types[None], agent_ids=tracks["agent_ids"][sel])
     if map_fields is not None:
         scene.update({k: map_fields[k] for k in ("map_input", "map_mask", "map_pos", "map_head")})
@@ -167,6 +173,34 @@ def scene_from_tracks(spec: ModelSpec, tracks: Dict[str, np.ndarray], t0: int,
         map_polylines = lanes_from_tracks(tracks, points=points)
     scene.update(polylines_to_map(spec, map_polylines, points=points))
     return scene
+
+
+def rollout_batch_from_tracks(spec: ModelSpec, tracks: Dict[str, np.ndarray], t0: int, policy: Sequence[int],
+                              replay: Sequence[int] = (), **kw) -> Dict[str, np.ndarray]:
+    """The whole input of a closed-loop rollout from a track table: ``scene_from_tracks`` at ``t0`` plus the later
+    replans' observation frames ``fut_obs_*`` [R - 1, 1, N, ...] (``get_future_obs``, format_utils.py:667-687, FUTURE_OBS_TYPE
+    'latest': the history window that ends at step t0 + t of every agent, in its own frame there -- ``get_center_obs`` again).
+    ``policy``: table rows the simulation drives (present at ``t0``); ``replay``: rows that follow their log -- they may
+    leave (masked frames from then on) or enter later (no history at ``t0``, listed from their first frame on).  ``kw`` goes
+    to ``scene_from_tracks`` (frame, map_fields, agent_types)."""
+    rows = list(policy) + [r for r in replay if r not in set(policy)]
+    sc = scene_from_tracks(spec, tracks, t0, agents=rows, keep_absent=True, **kw)
+    n_pol = len(list(policy))
+    if not sc["prompt_mask"][0, :n_pol].all():
+        raise ValueError("a policy agent is not in the scene at t0")
+    sc["prompt_mask"][0, n_pol:] = False
+    T = tracks["x"].shape[1]
+    frames = []
+    for t in spec.all_t_indices[1:]:
+        if t0 + t >= T:
+            raise ValueError("the track table ends before the last replan")
+        frames.append(scene_from_tracks(spec, tracks, t0 + t, agents=rows, keep_absent=True, **kw))
+    if frames:
+        sc["fut_obs_input"] = np.stack([f["obs_input"] for f in frames])
+        sc["fut_obs_mask"] = np.stack([f["obs_mask"] for f in frames])
+        sc["fut_obs_pos"] = np.stack([f["obs_pos"] for f in frames])
+        sc["fut_obs_head"] = np.stack([f["obs_head"] for f in frames])
+    return sc
 
 
 def ego_frame(tracks: Dict[str, np.ndarray], t0: int, agent_id: str = "ego") -> np.ndarray:

@@ -457,6 +457,34 @@ def test_demo_dataset_real_lanes_config0(demo_scene):
         eng.close()
 
 
+def test_demo_dataset_full_rollout_with_real_log_replay():
+    """The whole path on the reference's sample data: demo scene_1 at step 10 -- real lanes, real agent types, 12 policy
+    agents, the 33 other agents of the scene replaying their real logs through the fut_obs frames (agents that leave and
+    agents that enter), 80 steps -- against the oracle: replan 0 to 1e-4, trajectories to the scene's fp32 floor."""
+    from prosim_amd.engine import Engine
+    from test_vecmap_cpu import demo_rollout_batch
+    spec = DEMO_SPEC
+    scene, _, policy, replay = demo_rollout_batch(spec)
+    w = weights.init_weights(spec, 0)
+    with torch.no_grad():
+        o64 = orc.rollout(w, spec, scene, dtype=torch.float64)
+        o32 = orc.rollout(w, spec, scene)
+    eng = Engine(spec, w)
+    try:
+        eng.set_scene(scene)
+        eng.rollout()
+        assert eng.num_agents == len(policy) + len(replay) and eng.num_policy_agents == len(policy)
+        pol = eng.policy_rows
+        P = int(pol.sum())
+        assert err(eng.get("motion_pred")[0][pol], o64["motion_pred"][:P].numpy()) < TOL
+        pm = scene["prompt_mask"].astype(bool)
+        d = np.abs(eng.padded("traj") - o64["traj"].numpy())[pm].reshape(P, -1).max(1)
+        floor = float((o32["traj"].double() - o64["traj"]).abs()[torch.from_numpy(pm)].max())
+        assert d.max() < 3 * floor + TOL and np.median(d) < floor + TOL, (d, floor)
+    finally:
+        eng.close()
+
+
 def test_split_s2s_layers_on_a_ragged_batch(demo_engine):
     """>= 2048 scene tokens switch the s2s layers to the split launches (k_node + k_edge_small): a ragged 2-scene
     batch (token counts that are no multiple of the 16-row tiles, polylines with few valid points, incomplete

@@ -242,6 +242,61 @@ def test_big_demo_map_traffic_lights_and_the_2048_chunk_cap():
     assert (own != msk).any() and msk.any(1).all()
 
 
+def demo_rollout_batch(spec, t0=10, n_policy=12, scene="scene_1"):
+    """A whole 80-step rollout input from the demo cache: the ego and the next agents that stay in the scene for all 80
+    steps are policy agents, every other agent that is there at some replan replays its log -- some leave, some enter."""
+    import lzma
+    g = np.load(os.path.join(GOLD, f"demo_{scene}_agent_table.npz"))
+    tr = fmt.tracks_from_table({k: g[k] for k in g.files if k != "origin"})
+    origin = g["origin"].astype(np.float64)
+    f = fmt.ego_frame(tr, t0)
+    ego = list(tr["agent_ids"]).index("ego")
+    pres = np.isfinite(tr["x"]) & np.isfinite(tr["heading"])
+    ever = [i for i in range(pres.shape[0]) if any(pres[i, t0 + t] for t in spec.all_t_indices)]
+    stay = [i for i in ever if pres[i, t0:t0 + spec.max_steps + 1].all()]
+    policy = [ego] + [i for i in stay if i != ego][:n_policy - 1]
+    replay = [i for i in ever if i not in policy]
+    tl = np.load(os.path.join(GOLD, f"demo_{scene}_tls_table.npz"))
+    world = np.array([f[0] + origin[0], f[1] + origin[1], f[2]])
+    if scene == "scene_1":
+        pb = _pb()
+    else:
+        with open(os.path.join(GOLD, "demo_waymo_train_0_map.pb.xz"), "rb") as fh:
+            pb = lzma.decompress(fh.read())
+    mp = vm.map_for_scene(spec, pb, world, tls=vm.tls_at(tl["lane_id"], tl["scene_ts"], tl["status"], t0))
+    meta = fmt.agent_types_from_scene_metadata(os.path.join(GOLD, f"demo_{scene}_metadata.dill"))
+    types = np.array([meta[a] for a in tr["agent_ids"]], np.int64)
+    sc = fmt.rollout_batch_from_tracks(spec, tr, t0, policy, replay, frame=f, map_fields=mp, agent_types=types)
+    sc.pop("agent_ids")
+    return sc, tr, policy, replay
+
+
+def test_rollout_batch_from_tracks_log_replay_on_real_data():
+    spec = SMALL_SPEC
+    sc, tr, policy, replay = demo_rollout_batch(spec)
+    R, N = spec.n_replans, len(policy) + len(replay)
+    assert sc["fut_obs_input"].shape == (R - 1, 1, N, spec.hist_steps, spec.obs_dim) and sc["prompt_mask"].sum() == len(policy)
+    seen0 = sc["obs_mask"][0].all(-1).any(-1)
+    seen = sc["fut_obs_mask"][:, 0].all(-1).any(-1)                            # [R - 1, N]
+    assert seen0[:len(policy)].all() and seen[:, :len(policy)].all()           # policy agents are listed in every frame
+    enters = ~seen0 & seen.any(0)
+    leaves = seen0 & ~seen[-1]
+    assert enters.sum() >= 5 and leaves.sum() >= 5                             # the real log has both kinds
+    # a frame is the agent's own 11-step window ending at that replan: its last step sits at the origin of its frame,
+    # and its pose in the scene frame is where the table says the agent is at t0 + 10 k
+    k, j = 2, int(np.nonzero(seen[2])[0][-1])
+    assert np.abs(sc["fut_obs_input"][k, 0, j, -1, 0:2]).max() == 0
+    row = (policy + replay)[j]
+    f = fmt.ego_frame(tr, 10)
+    dx, dy = tr["x"][row, 10 + spec.all_t_indices[k + 1]] - f[0], tr["y"][row, 10 + spec.all_t_indices[k + 1]] - f[1]
+    c, s_ = np.cos(-f[2]), np.sin(-f[2])
+    assert np.allclose(sc["fut_obs_pos"][k, 0, j], [dx * c - dy * s_, dx * s_ + dy * c], atol=1e-3)
+    w = weights.init_weights(spec, 0)
+    with torch.no_grad():
+        o = orc.rollout(w, spec, sc)
+    assert o["traj"].shape == (1, N, spec.max_steps, 4) and torch.isfinite(o["traj"][0, :len(policy)]).all()
+
+
 def test_scene_metadata_is_read_without_trajdata():
     meta = fmt.agent_types_from_scene_metadata(os.path.join(GOLD, "demo_scene_1_metadata.dill"))
     tr, _, _ = _tracks()
