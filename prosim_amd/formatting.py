@@ -14,6 +14,8 @@ so this module restates the arithmetic of those formatters on plain arrays:
                                (prompt_utils.py:111-150): [v_local(2), extent(2), type one-hot(3)];
 * ``rollout_batch_from_tracks`` -- the above plus ``get_future_obs`` (format_utils.py:667-687): the observation frames of the later
                                replans for policy and log-replay agents (agents that leave or enter keep their slots);
+* ``pair_targets_from_tracks`` -- ``get_local_io_pairs_T_step_batch`` (format_utils.py:498-616): the metric's ground truth, per replan
+                               the next target_steps logged states in the agent's frame at that replan, NaN gaps kept;
 * ``agent_types_from_scene_metadata`` -- the cache's pickled ``Scene`` -> agent id -> type, read without trajdata;
 * ``polylines_to_map``      -- ``local_map_to_sym_coord`` + ``get_center_vec_init_map`` (format_utils.py:184-263):
                                per-polyline frame = midpoint / tangent of (first start, last valid end), segments in
@@ -201,6 +203,40 @@ def rollout_batch_from_tracks(spec: ModelSpec, tracks: Dict[str, np.ndarray], t0
         sc["fut_obs_pos"] = np.stack([f["obs_pos"] for f in frames])
         sc["fut_obs_head"] = np.stack([f["obs_head"] for f in frames])
     return sc
+
+
+def pair_targets_from_tracks(spec: ModelSpec, tracks: Dict[str, np.ndarray], t0: int, rows: Sequence[int]) -> Dict[str, np.ndarray]:
+    """The ground truth of the validation metric from a track table: ``io_pairs_batch['tgt' | 'mask']``
+    (``get_local_io_pairs_T_step_batch``, format_utils.py:498-616, TAIL_PADDING, SAMPLE_RATE = replan_freq).  Per replan t
+    and agent: the next ``target_steps`` logged states (x, y, h, xd, yd) in the frame of the agent's logged state at
+    t0 + t (offset, rotate by -heading; velocities rotated, heading relative), NaN where the log has no state; the pair is
+    valid iff that centre state is complete and the target is not all NaN.  Returns tgt [1, R, N, S, 5] float32 and
+    mask [1, R, N]."""
+    rows = np.asarray(list(rows), np.int64)
+    R, S, N, T = spec.n_replans, spec.target_steps, len(rows), tracks["x"].shape[1]
+    tgt = np.full((1, R, N, S, 5), np.nan, np.float64)
+    mask = np.zeros((1, R, N), bool)
+    cols = ("x", "y", "heading", "vx", "vy", "ax", "ay")
+    for r, t in enumerate(spec.all_t_indices):
+        tc = t0 + t
+        if tc >= T:
+            continue
+        ctr = {c: tracks[c][rows, tc] for c in cols}
+        ok = np.all([np.isfinite(ctr[c]) for c in cols], 0)                    # HISTORY.ELEMENTS x,y,s,c,xd,yd,xdd,ydd all there
+        steps = np.arange(tc + 1, tc + 1 + S)
+        inside = steps < T
+        fut = {c: np.full((N, S), np.nan) for c in ("x", "y", "heading", "vx", "vy")}
+        for c in fut:
+            fut[c][:, inside] = tracks[c][rows][:, steps[inside]]
+        lx, ly = _rotate(fut["x"] - ctr["x"][:, None], fut["y"] - ctr["y"][:, None], -ctr["heading"][:, None])
+        lvx, lvy = _rotate(fut["vx"], fut["vy"], -ctr["heading"][:, None])
+        lh = fut["heading"] - ctr["heading"][:, None]
+        lh = (lh + np.pi) % (2 * np.pi) - np.pi
+        tg = np.stack([lx, ly, lh, lvx, lvy], -1)
+        valid = ok & ~np.isnan(tg).all(-1).all(-1)
+        tgt[0, r, valid] = tg[valid]
+        mask[0, r] = valid
+    return dict(tgt=tgt.astype(np.float32), mask=mask)
 
 
 def ego_frame(tracks: Dict[str, np.ndarray], t0: int, agent_id: str = "ego") -> np.ndarray:

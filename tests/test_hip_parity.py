@@ -481,6 +481,30 @@ def test_demo_dataset_full_rollout_with_real_log_replay():
         d = np.abs(eng.padded("traj") - o64["traj"].numpy())[pm].reshape(P, -1).max(1)
         floor = float((o32["traj"].double() - o64["traj"]).abs()[torch.from_numpy(pm)].max())
         assert d.max() < 3 * floor + TOL and np.median(d) < floor + TOL, (d, floor)
+        # ... and the validation metric against the REAL log (pair_targets_from_tracks), on the device and through the oracle
+        from oracle import metric_oracle as mo
+        from prosim_amd import formatting as fmt
+        from prosim_amd.distributed import reduce_pair_metrics, rows_to_slots
+        g = np.load(os.path.join(os.path.dirname(__file__), "golden", "demo_scene_1_agent_table.npz"))
+        tr = fmt.tracks_from_table({k: g[k] for k in g.files if k != "origin"})
+        gt = fmt.pair_targets_from_tracks(spec, tr, 10, policy + replay)
+        slots, A, R = eng.row_slots, eng.num_agents, spec.n_replans
+        tgt_rows = np.ascontiguousarray(gt["tgt"][0][:, slots])                  # [R, A, S, 5]
+        mask_rows = np.ascontiguousarray(gt["mask"][0][:, slots] & pol[None])
+        dev = torch.device("cuda", 0)
+        t_tgt, t_mask = torch.from_numpy(tgt_rows).to(dev), torch.from_numpy(mask_rows.astype(np.uint8)).to(dev)
+        out = torch.zeros(A, 10, device=dev)
+        eng.pair_metric(out.data_ptr(), t_tgt.data_ptr(), t_mask.data_ptr())
+        eng.sync()
+        got = out.cpu().numpy()
+        mp = eng.get("motion_pred")
+        r_idx, a_idx = np.nonzero(mask_rows)
+        o = mo.pair_motion_pred(torch.from_numpy(mp[r_idx, a_idx]), torch.ones(len(r_idx), 1), torch.from_numpy(tgt_rows.transpose(1, 0, 2, 3)[None].transpose(0, 2, 1, 3, 4).copy()),
+                                torch.from_numpy(mask_rows[None].copy()), np.zeros_like(r_idx), r_idx, a_idx, spec.replan_freq)
+        red = reduce_pair_metrics(rows_to_slots(torch.from_numpy(got), torch.from_numpy(slots), 1, len(slots)))
+        for k in ("ade", "fde", "min_ade", "min_fde", "rollout_ade"):
+            assert abs(red[k] - float(o[k])) < 1e-4 * max(1.0, abs(float(o[k]))), (k, red[k], float(o[k]))
+        assert red["ade"] > 0.5                                                   # random weights against a real log: far off, finite
     finally:
         eng.close()
 

@@ -295,6 +295,16 @@ def test_rollout_batch_from_tracks_log_replay_on_real_data():
     with torch.no_grad():
         o = orc.rollout(w, spec, sc)
     assert o["traj"].shape == (1, N, spec.max_steps, 4) and torch.isfinite(o["traj"][0, :len(policy)]).all()
+    # the metric's ground truth from the same table: local targets per replan, gaps where an agent has left the log
+    gt = fmt.pair_targets_from_tracks(spec, tr, 10, policy + replay)
+    assert gt["tgt"].shape == (1, R, N, spec.target_steps, 5) and gt["mask"][0, :, :len(policy)].all()
+    assert not gt["mask"][0, -1, len(policy):].all() and np.isnan(gt["tgt"][0][~gt["mask"][0]]).all()
+    # chained back to the scene frame a policy agent's targets ARE its logged path: the first target step is the log's
+    # next state in the agent's frame at t0
+    j, row = 1, policy[1]
+    dx, dy = tr["x"][row, 11] - tr["x"][row, 10], tr["y"][row, 11] - tr["y"][row, 10]
+    c, s_ = np.cos(-tr["heading"][row, 10]), np.sin(-tr["heading"][row, 10])
+    assert np.allclose(gt["tgt"][0, 0, j, 0, :2], [dx * c - dy * s_, dx * s_ + dy * c], atol=1e-4)
 
 
 def test_scene_metadata_is_read_without_trajdata():
