@@ -16,6 +16,7 @@ so this module restates the arithmetic of those formatters on plain arrays:
                                replans for policy and log-replay agents (agents that leave or enter keep their slots);
 * ``pair_targets_from_tracks`` -- ``get_local_io_pairs_T_step_batch`` (format_utils.py:498-616): the metric's ground truth, per replan
                                the next target_steps logged states in the agent's frame at that replan, NaN gaps kept;
+* ``conditions_from_tracks`` -- the log-derived goal and drag-point conditions (condition_utils.py:126-175, :401-447);
 * ``agent_types_from_scene_metadata`` -- the cache's pickled ``Scene`` -> agent id -> type, read without trajdata;
 * ``polylines_to_map``      -- ``local_map_to_sym_coord`` + ``get_center_vec_init_map`` (format_utils.py:184-263):
                                per-polyline frame = midpoint / tangent of (first start, last valid end), segments in
@@ -237,6 +238,37 @@ def pair_targets_from_tracks(spec: ModelSpec, tracks: Dict[str, np.ndarray], t0:
         tgt[0, r, valid] = tg[valid]
         mask[0, r] = valid
     return dict(tgt=tgt.astype(np.float32), mask=mask)
+
+
+def conditions_from_tracks(spec: ModelSpec, tracks: Dict[str, np.ndarray], t0: int, rows: Sequence[int],
+                           policy_mask: np.ndarray, drag_rate: int = 5) -> Dict[str, Dict[str, np.ndarray]]:
+    """The log-derived prompt conditions of the reference, for the slots ``rows`` (one condition row per slot, valid on the
+    policy slots): ``goal`` (get_goal_condition_batch, condition_utils.py:126-175: the last logged position of the agent's
+    future in its frame at ``t0`` -- GOAL.LOCAL --, and the number of future steps it is there) and ``drag_point``
+    (get_drag_points_condition_batch :401-447: every ``drag_rate``-th step of the agent's future path in that frame;
+    the reference then keeps a random consecutive subset and adds noise -- training-time randomisation, left out here:
+    all valid points, no noise).  Futures span ``max_steps`` steps (the ROLLOUT split)."""
+    rows = np.asarray(list(rows), np.int64)
+    N, T = len(rows), tracks["x"].shape[1]
+    pm = np.asarray(policy_mask, bool).reshape(N)
+    steps = np.arange(t0 + 1, min(t0 + 1 + spec.max_steps, T))
+    fx, fy = tracks["x"][rows][:, steps], tracks["y"][rows][:, steps]
+    x0, y0, h0 = tracks["x"][rows, t0][:, None], tracks["y"][rows, t0][:, None], tracks["heading"][rows, t0][:, None]
+    lx, ly = _rotate(fx - x0, fy - y0, -h0)                                   # [N, F] the future path in the agent's frame at t0
+    ok = np.isfinite(lx) & np.isfinite(ly)
+    fut_len = np.where(ok.any(1), ok.shape[1] - np.argmax(ok[:, ::-1], 1), 0)  # steps up to the last logged one
+    goal = np.zeros((1, N, 3), np.float32)
+    gmask = pm & (fut_len > 0)
+    idx = np.clip(fut_len - 1, 0, None)
+    goal[0, :, 0] = np.where(gmask, np.nan_to_num(lx[np.arange(N), idx]), 0.0)
+    goal[0, :, 1] = np.where(gmask, np.nan_to_num(ly[np.arange(N), idx]), 0.0)
+    goal[0, :, 2] = fut_len
+    pidx = np.arange(N, dtype=np.int64)[None, :, None]
+    dpts = np.stack([lx, ly], -1)[:, ::drag_rate][None].astype(np.float32)    # [1, N, Td, 2], NaN where the log has no state
+    dmask = pm & np.isfinite(dpts[0]).all(-1).any(-1)
+    dpts[0, ~dmask] = np.nan
+    return {"goal": dict(input=goal, mask=gmask[None], prompt_idx=pidx.copy()),
+            "drag_point": dict(input=dpts, mask=dmask[None], prompt_idx=pidx.copy())}
 
 
 def ego_frame(tracks: Dict[str, np.ndarray], t0: int, agent_id: str = "ego") -> np.ndarray:

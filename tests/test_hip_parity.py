@@ -460,7 +460,7 @@ def test_demo_dataset_real_lanes_config0(demo_scene):
 def test_demo_dataset_full_rollout_with_real_log_replay():
     """The whole path on the reference's sample data: demo scene_1 at step 10 -- real lanes, real agent types, 12 policy
     agents, the 33 other agents of the scene replaying their real logs through the fut_obs frames (agents that leave and
-    agents that enter), 80 steps -- against the oracle: replan 0 to 1e-4, trajectories to the scene's fp32 floor."""
+    agents that enter), goal and drag-point prompts taken from the log, 80 steps -- against the oracle: replan 0 to 1e-4, trajectories to the scene's fp32 floor."""
     from prosim_amd.engine import Engine
     from test_vecmap_cpu import demo_rollout_batch
     spec = DEMO_SPEC

@@ -242,7 +242,7 @@ def test_big_demo_map_traffic_lights_and_the_2048_chunk_cap():
     assert (own != msk).any() and msk.any(1).all()
 
 
-def demo_rollout_batch(spec, t0=10, n_policy=12, scene="scene_1"):
+def demo_rollout_batch(spec, t0=10, n_policy=12, scene="scene_1", conditions=True):
     """A whole 80-step rollout input from the demo cache: the ego and the next agents that stay in the scene for all 80
     steps are policy agents, every other agent that is there at some replan replays its log -- some leave, some enter."""
     import lzma
@@ -268,6 +268,8 @@ def demo_rollout_batch(spec, t0=10, n_policy=12, scene="scene_1"):
     types = np.array([meta[a] for a in tr["agent_ids"]], np.int64)
     sc = fmt.rollout_batch_from_tracks(spec, tr, t0, policy, replay, frame=f, map_fields=mp, agent_types=types)
     sc.pop("agent_ids")
+    if conditions:   # the log-derived goal and drag-point prompts of the policy agents
+        sc["cond"] = fmt.conditions_from_tracks(spec, tr, t0, policy + replay, sc["prompt_mask"][0])
     return sc, tr, policy, replay
 
 
@@ -295,6 +297,14 @@ def test_rollout_batch_from_tracks_log_replay_on_real_data():
     with torch.no_grad():
         o = orc.rollout(w, spec, sc)
     assert o["traj"].shape == (1, N, spec.max_steps, 4) and torch.isfinite(o["traj"][0, :len(policy)]).all()
+    # the log-derived conditions: the goal is the end of the agent's logged future in its frame at t0, the drag points its path
+    cg, cd = sc["cond"]["goal"], sc["cond"]["drag_point"]
+    assert cg["mask"][0, :len(policy)].all() and not cg["mask"][0, len(policy):].any() and (cg["input"][0, :len(policy), 2] == spec.max_steps).all()
+    assert cd["input"].shape == (1, N, spec.max_steps // 5, 2) and cd["mask"][0, :len(policy)].all()
+    row1 = policy[1]
+    gx, gy = tr["x"][row1, 90] - tr["x"][row1, 10], tr["y"][row1, 90] - tr["y"][row1, 10]
+    c1, s1 = np.cos(-tr["heading"][row1, 10]), np.sin(-tr["heading"][row1, 10])
+    assert np.allclose(cg["input"][0, 1, :2], [gx * c1 - gy * s1, gx * s1 + gy * c1], atol=1e-3)
     # the metric's ground truth from the same table: local targets per replan, gaps where an agent has left the log
     gt = fmt.pair_targets_from_tracks(spec, tr, 10, policy + replay)
     assert gt["tgt"].shape == (1, R, N, spec.target_steps, 5) and gt["mask"][0, :, :len(policy)].all()
