@@ -1030,10 +1030,12 @@ extern "C" int ps_set_scene(ps_engine* e, int32_t B, int32_t M, int32_t P, int32
   e->step_cnd = (int)e->h_steps.size();
   for (int i = 0; i < c.cond_layers; ++i) push(e->cnd[i], e->d_kv.p, e->d_kh.p, e->e_cnd);
   e->step_pol = (int)e->h_steps.size();
-  for (int i = 0; i < c.pol_layers; ++i) {
+  static const int abl = getenv("PS_C16_ABL") ? atoi(getenv("PS_C16_ABL")) : 0;   // experiments only (timing, wrong results): 1 = every policy layer reads layer 0's k | v
+  for (int i0 = 0; i0 < c.pol_layers; ++i0) {
+    const int i = (abl & 1) ? 0 : i0;
     // a2p edges carry GLOBAL agent rows (Mv + j); the kv buffer is agent-local -> bias the base by -Mv rows
-    push(e->a2p[i], e->d_kv_a2p.p + (size_t)i * A * 256 - (size_t)Mv * 256, e->d_kh_a2p.p + (size_t)i * A * 256 - (size_t)Mv * 256, e->e_a2p);
-    push(e->m2p[i], e->d_kv_m2p.p + (size_t)i * Mv * 256, e->d_kh_m2p.p + (size_t)i * Mv * 256, e->e_m2p);
+    push(e->a2p[i0], e->d_kv_a2p.p + (size_t)i * A * 256 - (size_t)Mv * 256, e->d_kh_a2p.p + (size_t)i * A * 256 - (size_t)Mv * 256, e->e_a2p);
+    push(e->m2p[i0], e->d_kv_m2p.p + (size_t)i * Mv * 256, e->d_kh_m2p.p + (size_t)i * Mv * 256, e->e_m2p);
   }
   e->step_upd = (int)e->h_steps.size();
   if (c.obs_attn_update)
@@ -1377,6 +1379,17 @@ namespace {
 // split-path exchange buffers, grown on demand (never inside a captured rollout: ps_set_scene sizes them first)
 int io_for(ps_engine* e, int Nd, EdgeIO& io) {
   const size_t n = (size_t)std::max(Nd, 1);
+  // a captured rollout holds these pointers by value: if a later caller (ps_policy_forward with more rows than
+  // ps_set_scene sized the buffers for) makes any of them grow, the graph must be re-captured
+  const float* before[9] = {e->io_q.p, e->io_qt.p, e->io_cq.p, e->io_ar.p, e->io_av.p, e->io_l.p, e->io_s.p, e->io_g.p, e->io_m.p};
+  struct Regrow {
+    ps_engine* e; const float* const* b;
+    ~Regrow() {
+      const float* after[9] = {e->io_q.p, e->io_qt.p, e->io_cq.p, e->io_ar.p, e->io_av.p, e->io_l.p, e->io_s.p, e->io_g.p, e->io_m.p};
+      for (int i = 0; i < 9; ++i)
+        if (b[i] && after[i] != b[i]) { drop_graph(e); break; }
+    }
+  } regrow{e, before};
   if (e->io_q.ensure(n * 128) || e->io_qt.ensure(n * 1024) || e->io_cq.ensure(n * 8) || e->io_ar.ensure(n * 1024) ||
       e->io_av.ensure(n * 128) || e->io_l.ensure(n * 8) || e->io_s.ensure(n * 128) || e->io_g.ensure(n * 128) || e->io_m.ensure(n * 8))
     return -1;
@@ -1582,9 +1595,7 @@ int launch_chain16(ps_engine* e, float* x, int Nd, const ChainStep* steps, int n
   const int nw = env_nw == 4 ? 4 : 8;
   const int rows = chain16_rows(e, Nd);
   const int W = rows < nw ? nw / rows : 1;   // waves per row: each leaves its own partial sums (slot = part * Nd + row)
-  EdgeIO io{};
-  if (io_for(e, Nd * W, io)) return fail(PS_E_HIP, "chain scratch buffers");
-  const dim3 grid((Nd + rows - 1) / rows);
+  const dim3 grid((Nd + rows - 1) / rows);   // (no exchange buffers: the phases of k_chain16 meet in LDS)
   hipStream_t st = e->stream;
   if (timed && e->time_chain) (void)hipEventRecord(e->ev0, st);
   static const bool want_prof = getenv("PS_CHAIN_PROF") != nullptr;   // tools only: in-kernel phase clocks of the timed launches
@@ -1596,7 +1607,7 @@ int launch_chain16(ps_engine* e, float* x, int Nd, const ChainStep* steps, int n
     prof = d_prof;
   }
 #define PS_C16_(NWW, POL, ONE) \
-  hipLaunchKernelGGL((k_chain16<NWW, POL, ONE>), grid, dim3(64 * NWW), c16_lds_bytes<NWW>(), st, x, x_in, Nd, rows, steps, nsteps, io, e->div32, e->cfg.ln_eps, xcd ? 1 : 0, prof)
+  hipLaunchKernelGGL((k_chain16<NWW, POL, ONE>), grid, dim3(64 * NWW), c16_lds_bytes<NWW>(), st, x, x_in, Nd, rows, steps, nsteps, e->div32, e->cfg.ln_eps, xcd ? 1 : 0, prof)
 #define PS_C16(NWW, POL) do { if (W == 1) PS_C16_(NWW, POL, true); else PS_C16_(NWW, POL, false); } while (0)
   if (nw == 8) {
     if (timed) PS_C16(8, true); else PS_C16(8, false);

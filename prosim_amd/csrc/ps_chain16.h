@@ -200,9 +200,10 @@ __device__ __forceinline__ void feat8(float xs, float rstd, float nmr, const flo
   }
 }
 // the same outside fdiv16's checked range (a distance beyond 10 km): true division, libm sincos.  Rolled, and through LDS
-// (hi halfs into the feature tile row, lo halfs into `lrow`): the rare path must not cost the common one registers.
+// (this lane's 24 halfs of the feature tile row; `lo` selects which halves are written): the rare path must not cost the
+// common one registers.
 __device__ __forceinline__ void feat_slow_row(float a0, float a1, float a2, float rstd, float nmr, const float (&dv)[4], int kq,
-                                              _Float16* __restrict__ hrow, _Float16* __restrict__ lrow) {
+                                              _Float16* __restrict__ frow, bool lo) {
 #pragma unroll 1
   for (int i = 0; i < 12; ++i) {
     const int ks = i >> 2, j = i & 3;
@@ -212,12 +213,30 @@ __device__ __forceinline__ void feat_slow_row(float a0, float a1, float a2, floa
     sincosf(xs / d, &sv, &cv);
     const float ys = fmaf(sv, rstd, nmr), yc = fmaf(cv, rstd, nmr);
     const int c = 32 * ks + 8 * kq + 2 * j;
-    hrow[c] = f16_hi(ys);
-    hrow[c + 1] = f16_hi(yc);
-    lrow[c] = f16_lo(ys);
-    lrow[c + 1] = f16_lo(yc);
+    frow[c] = lo ? f16_lo(ys) : f16_hi(ys);
+    frow[c + 1] = lo ? f16_lo(yc) : f16_hi(yc);
   }
 }
+
+// ---- LDS-DMA of a tile's k rows (global_load_lds_dwordx4: 16 B per lane straight into LDS, no VGPRs; the LDS address is
+// M0 + 16 * lane, wave-uniform base, so a bank-friendly layout is made by permuting the SOURCE pieces).  One round moves the
+// hi (or lo) halves of 16 rows = 16 x 256 B: instruction i, lane l fills slot s = l & 15 of row rr = 4 i + (l >> 4) with piece
+// s ^ rr of that row; the fragment reads (lane = row mi + 16 kq wants piece 4 ks + kq) then hit slot (4 ks + kq) ^ mi, and the 16
+// lanes of every ds_read_b128 service group land on 16 distinct 16-byte slots mod 256 B (cdna guide, LDS section).
+// (tools/mb/mb_glds.hip checks the recipe, also above 64 KB of LDS.)  Inline asm: hipcc neither counts these in vmcnt nor waits for them -- c16_wait_vm0() before the stage is read.
+__device__ __forceinline__ void c16_glds16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void c16_wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void c16_wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// Where a row's sums wait for the POST half (all in LDS; nothing of the exchange touches global memory):
+//   a_r [8][96]  the row's QA slot (ONEW: slot = row, over its q~; W waves per row: slot = row * W + part, q~ in slot 8 + row)
+//   l, m  [8]    columns 96 / 97 of the slot's head rows (C16_QH = 100: four spare floats per head)
+//   a_v [128]    ONEW: the row's own AG row (its q, read once at the start of the row); W > 1: AG row 8 + row * W + part
+__device__ __forceinline__ int c16_av_row(int lr, int part, int W) { return W == 1 ? lr : 8 + lr * W + part; }
 
 // The edge phase of one layer for the rows of a workgroup (called once per layer).  Out of line on purpose: inlined into
 // the layer loop its register pressure makes the allocator spill the weight-fragment ring of the node GEMMs; as a
@@ -230,351 +249,346 @@ __device__ __forceinline__ void feat_slow_row(float a0, float a1, float a2, floa
 // the one wave of a row walks the even tiles, parks their sums (a_r in the row's LDS slot, a_v / m / l in a wave-private
 // stash), walks the odd tiles in the same software pipeline (the first odd tile is prefetched under the last even one),
 // and merges with the POST half's own operations -- so both modes return bit-identical results.
+//
+// Round 3: the k rows of a tile arrive by LDS-DMA (no registers, no ds_write pass; hi halves one tile ahead, lo halves under
+// the tile's Fourier rows); the aggregation MFMAs take their probabilities from the registers the softmax left them in (the
+// C layout of the score MFMA IS the A layout of the 16x16x16 aggregation MFMA: row 4 kq + j of column mi); the transposed
+// feature reads of a pass are issued together; the row's sums stay in LDS (see above).  The arithmetic -- every operation
+// and its order -- is the round-2 kernel's: results are bit-identical to it.
 template <int NWV, bool ONEW>
-__device__ __noinline__ void c16_edge_phase(const ChainStep* __restrict__ stp, EdgeIO io, unsigned char* c16_smem, const float* AG,
-                                            const float* CQ, int* ctr, float* QA, const float* __restrict__ div32, int row0, int nrows, int W, int Nd,
-                                            unsigned long long* __restrict__ prof) {
+__device__ __noinline__ void c16_edge_phase(const ChainStep* __restrict__ stp, unsigned char* c16_smem, float* AG,
+                                            const float* CQ, int* ctr, float* QA, const float* __restrict__ div32, int row0, int nrows, int W) {
   const ChainStep& st = *stp;
-  long long tprev = (prof && threadIdx.x == 0) ? clock64() : 0;
-#define C16_EMARK(i)                                                  \
-  do {                                                                \
-    if (prof && threadIdx.x == 0) {                                   \
-      const long long now_ = clock64();                               \
-      atomicAdd(prof + (i), (unsigned long long)(now_ - tprev));      \
-      tprev = now_;                                                   \
-    }                                                                 \
-  } while (0)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int mi = lane & 15, kq = lane >> 4;
-    // =========================================================== EDGE: W waves per destination row (or a queue of rows per wave)
-    {
-      // this lane's four frequencies (pairs 4 kq .. 4 kq + 3 of every 32-feature block) and their reciprocals
-      float dv[4], rdv[4];
+  // this lane's four frequencies (pairs 4 kq .. 4 kq + 3 of every 32-feature block) and their reciprocals
+  float dv[4], rdv[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        dv[j] = ldg1(div32 + 2 * (4 * kq + j));
-        rdv[j] = 1.0f / dv[j];
+  for (int j = 0; j < 4; ++j) {
+    dv[j] = ldg1(div32 + 2 * (4 * kq + j));
+    rdv[j] = 1.0f / dv[j];
+  }
+  unsigned char* wbase = c16_smem + (size_t)wave * C16_WAVE_BYTES;
+  const half8* stg = reinterpret_cast<const half8*>(wbase);                    // k staging: [16 rows][16 slots of 16 B], hi or lo halves
+  float* Pt = reinterpret_cast<float*>(wbase + 4096);                         // [16 edges][8 heads] probabilities (for a_v)
+  _Float16* Ft = reinterpret_cast<_Float16*>(wbase + 4096 + 512);             // [16 edges][C16_FS] feature tile (hi, then lo)
+  int* Ss = reinterpret_cast<int*>(wbase + 4096 + 512 + 16 * C16_FS * 2);     // [2][16] source rows of this tile and the next
+  float* stash = reinterpret_cast<float*>(wbase + C16_STASH_OFF);
+  const unsigned stg_lds = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)wbase);   // LDS byte address of the staging area
+  const EdgeGeo* __restrict__ geo = reinterpret_cast<const EdgeGeo*>(st.geo);
+  // fragment reads of the staging area: row mi, piece 4 ks + kq at slot (4 ks + kq) ^ mi
+  const half8* str = stg + mi * 16 + (kq ^ (mi & 3));
+  const int sra = mi >> 2;
+  // DMA sources: row 4 i + (lane >> 4), piece (lane & 15) ^ row
+  const int dr = lane >> 4, ds_ = lane & 15;
+  const bool loA = mi >= 8;
+  const int hv = (lane & 31) >> 2, eh = lane >> 5;
+  for (int it = 0;; ++it) {
+    int lr, part;
+    if (W > 1) {   // static: wave -> (row wave / W, part wave % W)
+      if (it > 0) break;
+      lr = wave / W;
+      part = wave - lr * W;
+    } else {       // dynamic: the next row of the workgroup
+      lr = 0;
+      if (lane == 0) lr = atomicAdd(ctr, 1);
+      lr = __builtin_amdgcn_readfirstlane(lr);
+      if (lr >= nrows) break;
+      lr = ctr[1 + lr];
+      part = 0;
+    }
+    if (lr >= nrows) break;
+    const int r = row0 + lr;
+    const int e_beg = ldgi(st.eoff + r);
+    const int deg = ldgi(st.eoff + r + 1) - e_beg;
+    const int tstep = ONEW ? 32 : 16 * W;
+    const bool two = ONEW && deg > 16;   // the row has odd tiles: two partial sums
+    // Tiles of 16 edges (one score block).  A tile's geometry and source rows are requested one tile ahead (registers).
+    int t0 = 16 * part;
+    float4 ng;
+    float nn = 0.f;
+    int nsrc = 0;
+    auto prefetch = [&](int tt) {
+      const int n_ = min(16, deg - tt);
+      if (n_ > 0) {
+        const EdgeGeo* gp = geo + e_beg + tt + min(mi, n_ - 1);
+        ng = ldg4(reinterpret_cast<const float*>(gp));
+        nn = ldg1(reinterpret_cast<const float*>(gp) + 4);
+        nsrc = ldgi(reinterpret_cast<const int*>(gp) + 5);   // (lanes 0-15 publish it)
       }
-      unsigned char* wbase = c16_smem + (size_t)wave * C16_WAVE_BYTES;
-      half8* stg = reinterpret_cast<half8*>(wbase);                               // k staging (swizzled, as in k_attn_chain)
-      float* Pt = reinterpret_cast<float*>(wbase + 4096);                         // [16 edges][8 heads] probabilities
-      _Float16* Ft = reinterpret_cast<_Float16*>(wbase + 4096 + 512);             // [16 edges][C16_FS] feature tile (hi, then lo)
-      int* Ss = reinterpret_cast<int*>(wbase + 4096 + 512 + 16 * C16_FS * 2);     // [2][16] source rows of this tile and the next
-      const EdgeGeo* __restrict__ geo = reinterpret_cast<const EdgeGeo*>(st.geo);
-      const int rq = lane >> 2, pq = lane & 3;
-      half8* stw = stg + rq * 16 + (pq ^ (rq >> 2));
-      const half8* str = stg + mi * 16 + (kq ^ (mi >> 2));
-      const int swa = rq & 3, sra = mi & 3;
-      const bool loA = mi >= 8;
-      const int hv = (lane & 31) >> 2, eh = lane >> 5;
-      for (int it = 0;; ++it) {
-        int lr, part;
-        if (W > 1) {   // static: wave -> (row wave / W, part wave % W)
-          if (it > 0) break;
-          lr = wave / W;
-          part = wave - lr * W;
-        } else {       // dynamic: the next row of the workgroup
-          lr = 0;
-          if (lane == 0) lr = atomicAdd(ctr, 1);
-          lr = __builtin_amdgcn_readfirstlane(lr);
-          if (lr >= nrows) break;
-          lr = ctr[1 + lr];
-          part = 0;
+    };
+    prefetch(t0);
+    // B operands of the score MFMAs: lane -> column n = mi (head mi & 7, hi | lo half), k-block kq
+    half8 bq[3], bk[4];
+    float cqm;
+    {
+      const int hB = mi & 7;
+      const float* qtp = QA + ((W == 1 ? 0 : 8) + lr) * C16_QSL + hB * C16_QH + 8 * kq;
+      const float* qp = AG + lr * ND_XS + 8 * kq;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        if (ks < 3) {
+          const float4 v0 = *reinterpret_cast<const float4*>(qtp + 32 * ks), v1 = *reinterpret_cast<const float4*>(qtp + 32 * ks + 4);
+          const float qv_[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+          for (int j = 0; j < 8; ++j) bq[ks < 3 ? ks : 0][j] = loA ? f16_lo(qv_[j]) : f16_hi(qv_[j]);
         }
-        if (lr >= nrows) break;
-        const int r = row0 + lr;
-        const int e_beg = ldgi(st.eoff + r);
-        const int deg = ldgi(st.eoff + r + 1) - e_beg;
-        const int tstep = ONEW ? 32 : 16 * W;
-        const bool two = ONEW && deg > 16;   // the row has odd tiles: two partial sums
-        // Tiles of 16 edges (one score block).  Tile t0's geometry and source rows are requested one tile ahead (registers).
-        int t0 = 16 * part;
-        float4 ng;
-        float nn = 0.f;
-        int nsrc = 0;
-        auto prefetch = [&](int tt) {
-          const int n_ = min(16, deg - tt);
-          if (n_ > 0) {
-            const EdgeGeo* gp = geo + e_beg + tt + min(mi, n_ - 1);
-            ng = ldg4(reinterpret_cast<const float*>(gp));
-            nn = ldg1(reinterpret_cast<const float*>(gp) + 4);
-            nsrc = ldgi(reinterpret_cast<const int*>(gp) + 5);   // (lanes 0-15 publish it)
-          }
-        };
-        prefetch(t0);
-        // B operands of the score MFMAs: lane -> column n = mi (head mi & 7, hi | lo half), k-block kq
-        half8 bq[3], bk[4];
-        float cqm;
-        {
-          const int hB = mi & 7;
-          const float* qtp = QA + ((W == 1 ? 0 : 8) + lr) * C16_QSL + hB * C16_QH + 8 * kq;
-          const float* qp = AG + lr * ND_XS + 8 * kq;
+        const bool mine = (2 * ks + (kq >> 1)) == hB;   // the 8 columns 32 ks + 8 kq lie inside head 2 ks + (kq >> 1)
+        const float4 w0 = *reinterpret_cast<const float4*>(qp + 32 * ks), w1 = *reinterpret_cast<const float4*>(qp + 32 * ks + 4);
+        const float kv_[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
 #pragma unroll
-          for (int ks = 0; ks < 4; ++ks) {
-            if (ks < 3) {
-              const float4 v0 = *reinterpret_cast<const float4*>(qtp + 32 * ks), v1 = *reinterpret_cast<const float4*>(qtp + 32 * ks + 4);
-              const float qv_[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-#pragma unroll
-              for (int j = 0; j < 8; ++j) bq[ks < 3 ? ks : 0][j] = loA ? f16_lo(qv_[j]) : f16_hi(qv_[j]);
-            }
-            const bool mine = (2 * ks + (kq >> 1)) == hB;   // the 8 columns 32 ks + 8 kq lie inside head 2 ks + (kq >> 1)
-            const float4 w0 = *reinterpret_cast<const float4*>(qp + 32 * ks), w1 = *reinterpret_cast<const float4*>(qp + 32 * ks + 4);
-            const float kv_[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-              const float kk = mine ? kv_[j] : 0.f;
-              bk[ks][j] = loA ? f16_lo(kk) : f16_hi(kk);
-            }
-          }
-          cqm = CQ[lr * 8 + hB];
+        for (int j = 0; j < 8; ++j) {
+          const float kk = mine ? kv_[j] : 0.f;
+          bk[ks][j] = loA ? f16_lo(kk) : f16_hi(kk);
         }
-        C16_EMARK(11);
-        float m_run = -INFINITY, l_run = 0.f;   // of head mi & 7 (the lanes mi and mi + 8, all kq, carry copies)
-        floatx4 ar[6];
+      }
+      cqm = CQ[lr * 8 + hB];
+    }
+    float m_run = -INFINITY, l_run = 0.f;   // of head mi & 7 (the lanes mi and mi + 8, all kq, carry copies)
+    floatx4 ar[6];
 #pragma unroll
-        for (int cb = 0; cb < 6; ++cb) ar[cb] = floatx4{0.f, 0.f, 0.f, 0.f};
-        float4 av = make_float4(0.f, 0.f, 0.f, 0.f);   // a_v partial: columns 4 (lane & 31) ..+3, edges of parity lane >> 5
-        const float* vbase = st.kv + 128 + 4 * (lane & 31);
-        // the k rows of a tile are requested one tile ahead as well, as soon as the previous tile's rows have been staged
-        // (their registers are free then): they fly under that tile's softmax / aggregation and this tile's Fourier rows
-        half8 nkh[4], nkl[4];
-        int sb = 0;   // Ss buffer holding this tile's source rows
-        auto kload = [&](int tt, int buf) {
-          const int n_ = min(16, deg - tt);
-          const _Float16* kp = st.khl + (size_t)Ss[16 * buf + min(rq, n_ - 1)] * 256 + 8 * pq;
+    for (int cb = 0; cb < 6; ++cb) ar[cb] = floatx4{0.f, 0.f, 0.f, 0.f};
+    float4 av = make_float4(0.f, 0.f, 0.f, 0.f);   // a_v partial: columns 4 (lane & 31) ..+3, edges of parity lane >> 5
+    const float* vbase = st.kv + 128 + 4 * (lane & 31);
+    // the DMA source pointers of a tile's k rows (hi halves; the lo halves sit 256 bytes further)
+    const _Float16* kp[4];
+    int sb = 0;   // Ss buffer holding this tile's source rows
+    auto kaddr = [&](int tt, int buf) {
+      const int n_ = min(16, deg - tt);
 #pragma unroll
-          for (int ks = 0; ks < 4; ++ks) {
-            nkh[ks] = ldgh8(kp + 32 * ks);
-            nkl[ks] = ldgh8(kp + 128 + 32 * ks);
-          }
-        };
-        if (t0 < deg) {
-          if (lane < 16) Ss[lane] = nsrc;
-          kload(t0, 0);
-        }
-        float* stash = reinterpret_cast<float*>(wbase + C16_STASH_OFF);
+      for (int i = 0; i < 4; ++i) {
+        const int rr = 4 * i + dr;
+        kp[i] = st.khl + (size_t)Ss[16 * buf + min(rr, n_ - 1)] * 256 + 8 * (ds_ ^ rr);
+      }
+    };
+    if (t0 < deg) {
+      if (lane < 16) Ss[lane] = nsrc;   // (prefetch(t0)'s loads are hipcc's own: it waits for them here)
+      kaddr(t0, 0);
+      c16_wait_lgkm0();                 // the previous row's last reads of the staging area are done
+#pragma unroll
+      for (int i = 0; i < 4; ++i) c16_glds16(kp[i], stg_lds + 1024 * i);
+    }
 #pragma unroll 1
-        for (int tn = 0; t0 < deg; t0 = tn) {
-          const int n = min(16, deg - t0);
-          // the tile after this one: same parity, or (ONEW) the first odd tile after the last even one
-          tn = t0 + tstep;
-          const bool turn = two && tn >= deg && (t0 & 16) == 0;
-          if (turn) tn = 16;
-          // this tile's records (requested a tile ago); the next tile's leave now
-          const float4 g0 = ng;
-          const float nmr = nn;
-          const int* Sc = Ss + 16 * sb;
-          prefetch(tn);
-          C16_EMARK(4);
-          if (prof && threadIdx.x == 0) atomicAdd(prof + 12, 1ull);
-          float sreg[4];
-          half8 fl[3];
-          {
-            const bool fast = !__any(!(fdiv16_ok(g0.x) && fdiv16_ok(g0.y) && fdiv16_ok(g0.z)));
-            half8 fh[3];
-            if (fast) {
-              feat8(g0.x, g0.w, nmr, dv, rdv, fh[0], fl[0]);
-              feat8(g0.y, g0.w, nmr, dv, rdv, fh[1], fl[1]);
-              feat8(g0.z, g0.w, nmr, dv, rdv, fh[2], fl[2]);
+    for (int tn = 0; t0 < deg; t0 = tn) {
+      const int n = min(16, deg - t0);
+      // the tile after this one: same parity, or (ONEW) the first odd tile after the last even one
+      tn = t0 + tstep;
+      const bool turn = two && tn >= deg && (t0 & 16) == 0;
+      if (turn) tn = 16;
+      // this tile's records (requested a tile ago)
+      const float4 g0 = ng;
+      const float nmr = nn;
+      const int* Sc = Ss + 16 * sb;
+      float sreg[4];
+      half8 fl[3];
+      {
+        // ---- k hi halves (in flight since the previous tile): fragments, then the lo halves take the staging area
+        half8 ak[4];
+        c16_wait_vm0();
 #pragma unroll
-              for (int ks = 0; ks < 3; ++ks) *reinterpret_cast<half8*>(Ft + mi * C16_FS + 32 * ks + 8 * kq) = fh[ks];
-            } else {   // (the staging area is free until the k rows are staged below)
-              _Float16* lrow = reinterpret_cast<_Float16*>(stg) + mi * C16_FS;
-              feat_slow_row(g0.x, g0.y, g0.z, g0.w, nmr, dv, kq, Ft + mi * C16_FS, lrow);
+        for (int ks = 0; ks < 4; ++ks) ak[ks] = str[4 * (ks ^ sra)];
+        c16_wait_lgkm0();
 #pragma unroll
-              for (int ks = 0; ks < 3; ++ks) {
-                fh[ks] = *reinterpret_cast<const half8*>(Ft + mi * C16_FS + 32 * ks + 8 * kq);
-                fl[ks] = *reinterpret_cast<const half8*>(lrow + 32 * ks + 8 * kq);
-              }
-            }
-            C16_EMARK(5);
-            // k rows: quad-contiguous gather -> fragments through the swizzled staging area; scores on the matrix cores
-            floatx4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
-            half8 ak[4];
+        for (int i = 0; i < 4; ++i) c16_glds16(kp[i] + 128, stg_lds + 1024 * i);   // (an instruction offset would move the LDS destination too)
+        prefetch(tn);   // the next tile's records leave now
+        floatx4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) stw[4 * (ks ^ swa)] = nkh[ks];
+        for (int ks = 0; ks < 4; ++ks) acc2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ak[ks], bk[ks], acc2, 0, 0, 0);
+        // ---- this tile's Fourier rows, in registers (A fragments of the score MFMAs) and as a row-major LDS tile
+        const bool fast = !__any(!(fdiv16_ok(g0.x) && fdiv16_ok(g0.y) && fdiv16_ok(g0.z)));
+        half8 fh[3];
+        if (fast) {
+          feat8(g0.x, g0.w, nmr, dv, rdv, fh[0], fl[0]);
+          feat8(g0.y, g0.w, nmr, dv, rdv, fh[1], fl[1]);
+          feat8(g0.z, g0.w, nmr, dv, rdv, fh[2], fl[2]);
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) ak[ks] = str[4 * (ks ^ sra)];
+          for (int ks = 0; ks < 3; ++ks) *reinterpret_cast<half8*>(Ft + mi * C16_FS + 32 * ks + 8 * kq) = fh[ks];
+        } else {   // (a distance beyond 10 km: true division + libm, rolled, through the feature tile -- twice, the hi halfs last)
+          _Float16* frow = Ft + mi * C16_FS;
+          feat_slow_row(g0.x, g0.y, g0.z, g0.w, nmr, dv, kq, frow, true);
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-              if (ks < 3) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[ks < 3 ? ks : 0], bq[ks < 3 ? ks : 0], acc, 0, 0, 0);
-              acc2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ak[ks], bk[ks], acc2, 0, 0, 0);
-            }
+          for (int ks = 0; ks < 3; ++ks) fl[ks] = *reinterpret_cast<const half8*>(frow + 32 * ks + 8 * kq);
+          feat_slow_row(g0.x, g0.y, g0.z, g0.w, nmr, dv, kq, frow, false);
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) stw[4 * (ks ^ swa)] = nkl[ks];
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) ak[ks] = str[4 * (ks ^ sra)];
-            if (tn < deg) {   // the next tile's source rows arrived with the prefetch: publish them, request its k rows
-              if (lane < 16) Ss[16 * (sb ^ 1) + lane] = nsrc;
-              kload(tn, sb ^ 1);
-            }
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-              if (ks < 3) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl[ks < 3 ? ks : 0], bq[ks < 3 ? ks : 0], acc, 0, 0, 0);
-              acc2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ak[ks], bk[ks], acc2, 0, 0, 0);
-            }
-            acc += acc2;
-#pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) {
-              const float v = acc[r4] + dpp_xor8(acc[r4]);   // columns h and h + 8 (q hi | q lo)
-              sreg[r4] = (4 * kq + r4 < n) ? (v + cqm) * (0.25f * 1.44269504088896341f) : -INFINITY;   // in units of log2: exp(x) = exp2(x log2 e)
-            }
-          }
-          C16_EMARK(6);
-          // v rows of the tile leave now (the k registers are dead) and fly under the softmax and the a_r MFMAs:
-          // gathered by source, two rows per load instruction
-          float4 vv[8];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) vv[j] = ldg4(vbase + (size_t)Sc[min(2 * j + eh, n - 1)] * 256);
-          // ---- online softmax over the tile (torch_geometric.utils.softmax: max-shift, exp, / (sum + 1e-16))
-          float tmax = fmaxf(fmaxf(sreg[0], sreg[1]), fmaxf(sreg[2], sreg[3]));
-          tmax = kq_max(tmax);
-          const float m_new = fmaxf(m_run, tmax);   // finite: the tile has at least one edge
-          const float scale = (m_run == -INFINITY) ? 0.f : exp2f(m_run - m_new);
-          float psum = 0.f;
-#pragma unroll
-          for (int r4 = 0; r4 < 4; ++r4) {
-            const float p = exp2f(sreg[r4] - m_new);   // 2^-inf = 0 for the slots past the edge list
-            psum += p;
-            if (mi < 8) Pt[(4 * kq + r4) * 8 + mi] = p;
-          }
-          psum = kq_sum(psum);
-          l_run = l_run * scale + psum;
-          m_run = m_new;
-          // what is already accumulated shrinks by the head's scale: accumulator row 4 (lane >> 4) + r belongs to head
-          // (4 (lane >> 4) + r) & 7; the a_v columns of this lane to head hv.  Skipped while no head's maximum moves
-          // (most tiles after a row's first few).
-          if (__any(scale != 1.f)) {
-            float scl[8];
-#pragma unroll
-            for (int h = 0; h < 8; ++h) scl[h] = __shfl(scale, h);
-            const bool up = kq & 1;
-            const float s0 = up ? scl[4] : scl[0], s1 = up ? scl[5] : scl[1], s2 = up ? scl[6] : scl[2], s3 = up ? scl[7] : scl[3];
-#pragma unroll
-            for (int cb = 0; cb < 6; ++cb) { ar[cb][0] *= s0; ar[cb][1] *= s1; ar[cb][2] *= s2; ar[cb][3] *= s3; }
-            float sh = scl[0];
-#pragma unroll
-            for (int h = 1; h < 8; ++h) sh = (hv == h) ? scl[h] : sh;
-            av.x *= sh; av.y *= sh; av.z *= sh; av.w *= sh;
-          }
-          C16_EMARK(7);
-          // ---- a_r[h][c] += sum_e p_e,h r~_e[c] on the matrix cores (16x16x16): A = (p hi | p lo) x head from the probability
-          //      tile (lane: 4 consecutive edges), B = the feature tile read back transposed (4 consecutive EDGES of one
-          //      feature per lane: one ds_read_b64_tr_b16), hi pass then lo pass
-          half4v ap;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const float pv = Pt[(4 * kq + j) * 8 + (mi & 7)];
-            ap[j] = loA ? f16_lo(pv) : f16_hi(pv);
-          }
-          const _Float16* tp = Ft + (kq * 4 + (mi >> 2)) * C16_FS + (lane & 3) * 4;
-#pragma unroll
-          for (int pass = 0; pass < 2; ++pass) {
-            if (pass == 1) {
-#pragma unroll
-              for (int ks = 0; ks < 3; ++ks) *reinterpret_cast<half8*>(Ft + mi * C16_FS + 32 * ks + 8 * kq) = fl[ks];
-            }
-#pragma unroll
-            for (int cb = 0; cb < 6; ++cb) {
-              const fp16x4 tv = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)(tp + cb * 16));
-              half4v bfr;
-#pragma unroll
-              for (int j = 0; j < 4; ++j) bfr[j] = (_Float16)tv[j];
-              ar[cb] = __builtin_amdgcn_mfma_f32_16x16x16f16(ap, bfr, ar[cb], 0, 0, 0);
-            }
-          }
-          C16_EMARK(8);
-          // ---- a_v[hd] += sum_e p_e,h v_src[hd] on the VALU
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const float ph = Pt[(2 * j + eh) * 8 + hv];   // 0 past the edge list
-            av.x = fmaf(ph, vv[j].x, av.x);
-            av.y = fmaf(ph, vv[j].y, av.y);
-            av.z = fmaf(ph, vv[j].z, av.z);
-            av.w = fmaf(ph, vv[j].w, av.w);
-          }
-          sb ^= 1;
-          if (ONEW && turn) {   // the even tiles are done: park their sums, start the odd tiles' from zero
-            av.x += __shfl_xor(av.x, 32); av.y += __shfl_xor(av.y, 32); av.z += __shfl_xor(av.z, 32); av.w += __shfl_xor(av.w, 32);
-            if (lane < 32) *reinterpret_cast<float4*>(stash + 4 * lane) = av;
-            if (lane < 8) { stash[128 + 2 * lane] = m_run; stash[128 + 2 * lane + 1] = l_run; }
-#pragma unroll
-            for (int cb = 0; cb < 6; cb += 2) {
-#pragma unroll
-              for (int r4 = 0; r4 < 4; ++r4) {
-                const float v = swap_add32(ar[cb][r4], ar[cb + 1][r4]);
-                QA[lr * C16_QSL + (4 * ((lane >> 4) & 1) + r4) * C16_QH + (cb + (lane >> 5)) * 16 + (lane & 15)] = v;
-              }
-            }
-            m_run = -INFINITY;
-            l_run = 0.f;
-#pragma unroll
-            for (int cb = 0; cb < 6; ++cb) ar[cb] = floatx4{0.f, 0.f, 0.f, 0.f};
-            av = make_float4(0.f, 0.f, 0.f, 0.f);
-          }
+          for (int ks = 0; ks < 3; ++ks) fh[ks] = *reinterpret_cast<const half8*>(frow + 32 * ks + 8 * kq);
         }
-        C16_EMARK(9);
-        // ---- the row's (partial) sums leave for the POST half: slot = part * Nd + row
-        const size_t slot = (size_t)part * Nd + r;
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[ks], bq[ks], acc, 0, 0, 0);
+        // ---- k lo halves
+        c16_wait_vm0();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) ak[ks] = str[4 * (ks ^ sra)];
+        c16_wait_lgkm0();
+        if (tn < deg) {   // the next tile's source rows arrived with the prefetch: publish them, start the DMA of its k hi halves
+          if (lane < 16) Ss[16 * (sb ^ 1) + lane] = nsrc;
+          kaddr(tn, sb ^ 1);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) c16_glds16(kp[i], stg_lds + 1024 * i);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl[ks], bq[ks], acc, 0, 0, 0);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) acc2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ak[ks], bk[ks], acc2, 0, 0, 0);
+        acc += acc2;
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const float v = acc[r4] + dpp_xor8(acc[r4]);   // columns h and h + 8 (q hi | q lo)
+          sreg[r4] = (4 * kq + r4 < n) ? (v + cqm) * (0.25f * 1.44269504088896341f) : -INFINITY;   // in units of log2: exp(x) = exp2(x log2 e)
+        }
+      }
+      // v rows of the tile leave now and fly under the softmax and the a_r MFMAs: gathered by source, two rows per load instruction
+      float4 vv[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) vv[j] = ldg4(vbase + (size_t)Sc[min(2 * j + eh, n - 1)] * 256);
+      // ---- online softmax over the tile (torch_geometric.utils.softmax: max-shift, exp, / (sum + 1e-16))
+      float tmax = fmaxf(fmaxf(sreg[0], sreg[1]), fmaxf(sreg[2], sreg[3]));
+      tmax = kq_max(tmax);
+      const float m_new = fmaxf(m_run, tmax);   // finite: the tile has at least one edge
+      const float scale = (m_run == -INFINITY) ? 0.f : exp2f(m_run - m_new);
+      float psum = 0.f;
+      float pr[4];
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const float p = exp2f(sreg[r4] - m_new);   // 2^-inf = 0 for the slots past the edge list
+        pr[r4] = p;
+        psum += p;
+        if (mi < 8) Pt[(4 * kq + r4) * 8 + mi] = p;
+      }
+      psum = kq_sum(psum);
+      l_run = l_run * scale + psum;
+      m_run = m_new;
+      // what is already accumulated shrinks by the head's scale: accumulator row 4 (lane >> 4) + r belongs to head
+      // (4 (lane >> 4) + r) & 7; the a_v columns of this lane to head hv.  Skipped while no head's maximum moves
+      // (most tiles after a row's first few).
+      if (__any(scale != 1.f)) {
+        float scl[8];
+#pragma unroll
+        for (int h = 0; h < 8; ++h) scl[h] = __shfl(scale, h);
+        const bool up = kq & 1;
+        const float s0 = up ? scl[4] : scl[0], s1 = up ? scl[5] : scl[1], s2 = up ? scl[6] : scl[2], s3 = up ? scl[7] : scl[3];
+#pragma unroll
+        for (int cb = 0; cb < 6; ++cb) { ar[cb][0] *= s0; ar[cb][1] *= s1; ar[cb][2] *= s2; ar[cb][3] *= s3; }
+        float sh = scl[0];
+#pragma unroll
+        for (int h = 1; h < 8; ++h) sh = (hv == h) ? scl[h] : sh;
+        av.x *= sh; av.y *= sh; av.z *= sh; av.w *= sh;
+      }
+      // ---- a_r[h][c] += sum_e p_e,h r~_e[c] on the matrix cores (16x16x16): A = (p hi | p lo) x head, straight from this
+      //      lane's probabilities (row 4 kq + j of column mi = edge 4 kq + j of head mi & 7), B = the feature tile read back
+      //      transposed (4 consecutive EDGES of one feature per lane: one ds_read_b64_tr_b16), hi pass then lo pass
+      half4v ap;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) ap[j] = loA ? f16_lo(pr[j]) : f16_hi(pr[j]);
+      const _Float16* tp = Ft + (kq * 4 + (mi >> 2)) * C16_FS + (lane & 3) * 4;
+#pragma unroll
+      for (int pass = 0; pass < 2; ++pass) {
+        if (pass == 1) {
+#pragma unroll
+          for (int ks = 0; ks < 3; ++ks) *reinterpret_cast<half8*>(Ft + mi * C16_FS + 32 * ks + 8 * kq) = fl[ks];
+        }
+        fp16x4 tv[6];
+#pragma unroll
+        for (int cb = 0; cb < 6; ++cb) tv[cb] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)(tp + cb * 16));
+#pragma unroll
+        for (int cb = 0; cb < 6; ++cb) {
+          half4v bfr;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) bfr[j] = (_Float16)tv[cb][j];
+          ar[cb] = __builtin_amdgcn_mfma_f32_16x16x16f16(ap, bfr, ar[cb], 0, 0, 0);
+        }
+      }
+      // ---- a_v[hd] += sum_e p_e,h v_src[hd] on the VALU
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float ph = Pt[(2 * j + eh) * 8 + hv];   // 0 past the edge list
+        av.x = fmaf(ph, vv[j].x, av.x);
+        av.y = fmaf(ph, vv[j].y, av.y);
+        av.z = fmaf(ph, vv[j].z, av.z);
+        av.w = fmaf(ph, vv[j].w, av.w);
+      }
+      sb ^= 1;
+      if (ONEW && turn) {   // the even tiles are done: park their sums, start the odd tiles' from zero
         av.x += __shfl_xor(av.x, 32); av.y += __shfl_xor(av.y, 32); av.z += __shfl_xor(av.z, 32); av.w += __shfl_xor(av.w, 32);
-        if (ONEW && two) {   // merge (even, odd) with the operations of the POST half's merge of two waves' partials
-          const float m0 = stash[128 + 2 * (lane & 7)], l0 = stash[128 + 2 * (lane & 7) + 1];   // head lane & 7
-          const float mh = __shfl(m_run, lane & 7), lh = __shfl(l_run, lane & 7);              // (lane h holds head h)
-          float mm = -INFINITY;
-          mm = fmaxf(mm, m0);
-          mm = fmaxf(mm, mh);
-          const float sc0 = (m0 == -INFINITY) ? 0.f : exp2f(m0 - mm);
-          const float sc1 = (mh == -INFINITY) ? 0.f : exp2f(mh - mm);
-          float lm = 0.f;
-          lm = fmaf(l0, sc0, lm);
-          lm = fmaf(lh, sc1, lm);
-          if (lane < 8) io.l[slot * 8 + lane] = lm;
-          {
-            const float s0 = __shfl(sc0, hv), s1 = __shfl(sc1, hv);   // a_v columns 4 (lane & 31) ..+3 belong to head hv
-            if (lane < 32) {
-              const float4 a0 = *reinterpret_cast<const float4*>(stash + 4 * lane);
-              float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-              o.x = fmaf(a0.x, s0, o.x); o.y = fmaf(a0.y, s0, o.y); o.z = fmaf(a0.z, s0, o.z); o.w = fmaf(a0.w, s0, o.w);
-              o.x = fmaf(av.x, s1, o.x); o.y = fmaf(av.y, s1, o.y); o.z = fmaf(av.z, s1, o.z); o.w = fmaf(av.w, s1, o.w);
-              *reinterpret_cast<float4*>(io.av + slot * 128 + 4 * lane) = o;
-            }
-          }
-#pragma unroll
-          for (int r4 = 0; r4 < 4; ++r4) {
-            const int hh = 4 * ((lane >> 4) & 1) + r4;
-            const float s0 = __shfl(sc0, hh), s1 = __shfl(sc1, hh);
-#pragma unroll
-            for (int cb = 0; cb < 6; cb += 2) {
-              const float v1 = swap_add32(ar[cb][r4], ar[cb + 1][r4]);
-              float* qp_ = QA + lr * C16_QSL + hh * C16_QH + (cb + (lane >> 5)) * 16 + (lane & 15);
-              float o = 0.f;
-              o = fmaf(*qp_, s0, o);
-              o = fmaf(v1, s1, o);
-              *qp_ = o;
-            }
-          }
-        } else {
-        if (lane < 8) {   // lane h (mi = h, kq = 0) holds head h
-          io.l[slot * 8 + lane] = l_run;
-          if (W > 1) io.m[slot * 8 + lane] = m_run;
-        }
-        if (lane < 32) *reinterpret_cast<float4*>(io.av + slot * 128 + 4 * lane) = av;
-        // rows h (p hi) and h + 8 (p lo) sit 32 lanes apart: one half-wave swap folds two column blocks at a time
+        if (lane < 32) *reinterpret_cast<float4*>(stash + 4 * lane) = av;
+        if (lane < 8) { stash[128 + 2 * lane] = m_run; stash[128 + 2 * lane + 1] = l_run; }
 #pragma unroll
         for (int cb = 0; cb < 6; cb += 2) {
 #pragma unroll
           for (int r4 = 0; r4 < 4; ++r4) {
-            const float v = swap_add32(ar[cb][r4], ar[cb + 1][r4]);   // lanes < 32: block cb, lanes >= 32: block cb + 1
-            QA[(W == 1 ? lr : lr * W + part) * C16_QSL + (4 * ((lane >> 4) & 1) + r4) * C16_QH + (cb + (lane >> 5)) * 16 + (lane & 15)] = v;
+            const float v = swap_add32(ar[cb][r4], ar[cb + 1][r4]);
+            QA[lr * C16_QSL + (4 * ((lane >> 4) & 1) + r4) * C16_QH + (cb + (lane >> 5)) * 16 + (lane & 15)] = v;
           }
         }
-        }
-        C16_EMARK(10);
+        m_run = -INFINITY;
+        l_run = 0.f;
+#pragma unroll
+        for (int cb = 0; cb < 6; ++cb) ar[cb] = floatx4{0.f, 0.f, 0.f, 0.f};
+        av = make_float4(0.f, 0.f, 0.f, 0.f);
       }
     }
+    // ---- the row's (partial) sums wait in LDS for the POST half
+    const int aslot = W == 1 ? lr : lr * W + part;
+    float* avrow = AG + c16_av_row(lr, part, W) * ND_XS;
+    av.x += __shfl_xor(av.x, 32); av.y += __shfl_xor(av.y, 32); av.z += __shfl_xor(av.z, 32); av.w += __shfl_xor(av.w, 32);
+    if (ONEW && two) {   // merge (even, odd) with the operations of the POST half's merge of two waves' partials
+      const float m0 = stash[128 + 2 * (lane & 7)], l0 = stash[128 + 2 * (lane & 7) + 1];   // head lane & 7
+      const float mh = __shfl(m_run, lane & 7), lh = __shfl(l_run, lane & 7);              // (lane h holds head h)
+      float mm = -INFINITY;
+      mm = fmaxf(mm, m0);
+      mm = fmaxf(mm, mh);
+      const float sc0 = (m0 == -INFINITY) ? 0.f : exp2f(m0 - mm);
+      const float sc1 = (mh == -INFINITY) ? 0.f : exp2f(mh - mm);
+      float lm = 0.f;
+      lm = fmaf(l0, sc0, lm);
+      lm = fmaf(lh, sc1, lm);
+      if (lane < 8) QA[aslot * C16_QSL + lane * C16_QH + 96] = lm;
+      {
+        const float s0 = __shfl(sc0, hv), s1 = __shfl(sc1, hv);   // a_v columns 4 (lane & 31) ..+3 belong to head hv
+        if (lane < 32) {
+          const float4 a0 = *reinterpret_cast<const float4*>(stash + 4 * lane);
+          float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+          o.x = fmaf(a0.x, s0, o.x); o.y = fmaf(a0.y, s0, o.y); o.z = fmaf(a0.z, s0, o.z); o.w = fmaf(a0.w, s0, o.w);
+          o.x = fmaf(av.x, s1, o.x); o.y = fmaf(av.y, s1, o.y); o.z = fmaf(av.z, s1, o.z); o.w = fmaf(av.w, s1, o.w);
+          *reinterpret_cast<float4*>(avrow + 4 * lane) = o;
+        }
+      }
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const int hh = 4 * ((lane >> 4) & 1) + r4;
+        const float s0 = __shfl(sc0, hh), s1 = __shfl(sc1, hh);
+#pragma unroll
+        for (int cb = 0; cb < 6; cb += 2) {
+          const float v1 = swap_add32(ar[cb][r4], ar[cb + 1][r4]);
+          float* qp_ = QA + lr * C16_QSL + hh * C16_QH + (cb + (lane >> 5)) * 16 + (lane & 15);
+          float o = 0.f;
+          o = fmaf(*qp_, s0, o);
+          o = fmaf(v1, s1, o);
+          *qp_ = o;
+        }
+      }
+    } else {
+      if (lane < 8) {   // lane h (mi = h, kq = 0) holds head h
+        QA[aslot * C16_QSL + lane * C16_QH + 96] = l_run;
+        if (W > 1) QA[aslot * C16_QSL + lane * C16_QH + 97] = m_run;
+      }
+      if (lane < 32) *reinterpret_cast<float4*>(avrow + 4 * lane) = av;
+      // rows h (p hi) and h + 8 (p lo) sit 32 lanes apart: one half-wave swap folds two column blocks at a time
+#pragma unroll
+      for (int cb = 0; cb < 6; cb += 2) {
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const float v = swap_add32(ar[cb][r4], ar[cb + 1][r4]);   // lanes < 32: block cb, lanes >= 32: block cb + 1
+          QA[aslot * C16_QSL + (4 * ((lane >> 4) & 1) + r4) * C16_QH + (cb + (lane >> 5)) * 16 + (lane & 15)] = v;
+        }
+      }
     }
+  }
+}
 
+// phase clocks of the node phases (tools only: build with -DPS_C16_PROF and run with PS_CHAIN_PROF=1; compiled out of the
+// product library -- the marks split basic blocks)
+#ifdef PS_C16_PROF
 #define C16_MARK(i)                                                   \
   do {                                                                \
     if (prof && threadIdx.x == 0) {                                   \
@@ -583,14 +597,17 @@ __device__ __noinline__ void c16_edge_phase(const ChainStep* __restrict__ stp, E
       tprev = now_;                                                   \
     }                                                                 \
   } while (0)
+#else
+#define C16_MARK(i) do { (void)prof; (void)tprev; } while (0)
+#endif
 
 // The node phases between two edge phases: POST of layer `post` (to_v_r fold, gate, to_out, norms, FFN) and PRE of layer
 // `pre` (LN_dst, q | s | g, q~, <q, kb>, the row queue); either may be null.  Out of line like the edge phase, so that the
 // weight-fragment ring gets a register allocation that no other phase's pressure can push into scratch.  x_out: where the
 // residual rows go after the last layer (null otherwise).
 template <int NWV>
-__device__ __noinline__ void c16_node_phase(const ChainStep* __restrict__ post, const ChainStep* __restrict__ pre, EdgeIO io,
-                                            unsigned char* c16_smem, float* __restrict__ x_out, int row0, int nrows, int W, int Nd,
+__device__ __noinline__ void c16_node_phase(const ChainStep* __restrict__ post, const ChainStep* __restrict__ pre,
+                                            unsigned char* c16_smem, float* __restrict__ x_out, int row0, int nrows, int W,
                                             float eps, unsigned long long* __restrict__ prof) {
   long long tprev = (prof && threadIdx.x == 0) ? clock64() : 0;
   constexpr int NT = 64 * NWV;
@@ -627,24 +644,44 @@ __device__ __noinline__ void c16_node_phase(const ChainStep* __restrict__ post, 
       const AttnW& w = st.w;
     // =========================================================== POST: to_v_r fold, gate, to_out, norms, FFN   (:76-77, :100-107)
     {
+      // to_s / to_g's x_dst half of LN_dst(x) (:106-107): x has not changed since this layer's PRE half made q from the same
+      // rows, so the two projections are made HERE, next to their only use, instead of crossing the edge phase (round 2: 1 KB
+      // per row and layer through a global scratch buffer).  Same GEMM, same operands, same bits.
+      frag_prefetch<4, Ring, NWV>(R, w.Fqsg + (size_t)8 * 4 * 1024, 16, wave, lane);
+      if (epi) {
+        float xn[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) xn[i] = X[er * ND_XS + ec + i];
+        row16_ln(xn, sp + SP_LN_DST_W, sp + SP_LN_DST_B, ec, eps);
+        planes_store8(P0h + er * ND_AS + ec, P0l + er * ND_AS + ec, xn);
+      }
+      __syncthreads();
+      gemm16<4, Ring, NWV>(R, P0h, P0l, ND_AS, w.Fqsg + (size_t)8 * 4 * 1024, 16, Cw, ND_CW, wave, lane);
       frag_prefetch<4, Ring, NWV>(R, w.Fga, 8, wave, lane);
+      __syncthreads();
+      C16_MARK(16);
       float4 in_av0 = make_float4(0.f, 0.f, 0.f, 0.f), in_av1 = in_av0, in_g0 = in_av0, in_g1 = in_av0, in_s0 = in_av0, in_s1 = in_av0;
       float in_l = 0.f;
       if (live) {
-        in_g0 = ldg4(io.g + (size_t)grow * 128 + ec); in_g1 = ldg4(io.g + (size_t)grow * 128 + ec + 4);
-        in_s0 = ldg4(io.s + (size_t)grow * 128 + ec); in_s1 = ldg4(io.s + (size_t)grow * 128 + ec + 4);
+        const float* cs_ = Cw + er * ND_CW + ec;
+        in_s0 = make_float4(cs_[0] + sp[SP_BS + ec], cs_[1] + sp[SP_BS + ec + 1], cs_[2] + sp[SP_BS + ec + 2], cs_[3] + sp[SP_BS + ec + 3]);
+        in_s1 = make_float4(cs_[4] + sp[SP_BS + ec + 4], cs_[5] + sp[SP_BS + ec + 5], cs_[6] + sp[SP_BS + ec + 6], cs_[7] + sp[SP_BS + ec + 7]);
+        in_g0 = make_float4(cs_[128] + sp[SP_BG + ec], cs_[129] + sp[SP_BG + ec + 1], cs_[130] + sp[SP_BG + ec + 2], cs_[131] + sp[SP_BG + ec + 3]);
+        in_g1 = make_float4(cs_[132] + sp[SP_BG + ec + 4], cs_[133] + sp[SP_BG + ec + 5], cs_[134] + sp[SP_BG + ec + 6], cs_[135] + sp[SP_BG + ec + 7]);
+        const int hd = ec >> 4;
         if (W == 1) {
-          in_l = ldg1(io.l + (size_t)grow * 8 + (ec >> 4));
-          in_av0 = ldg4(io.av + (size_t)grow * 128 + ec); in_av1 = ldg4(io.av + (size_t)grow * 128 + ec + 4);
+          in_l = QA[er * C16_QSL + hd * C16_QH + 96];
+          in_av0 = *reinterpret_cast<const float4*>(AG + er * ND_XS + ec); in_av1 = *reinterpret_cast<const float4*>(AG + er * ND_XS + ec + 4);
         } else {   // merge the W partial softmax sums of the row (head ec >> 4): common maximum, rescale, add
           float mm = -INFINITY;
-          for (int p = 0; p < W; ++p) mm = fmaxf(mm, ldg1(io.m + ((size_t)p * Nd + grow) * 8 + (ec >> 4)));
+          for (int p = 0; p < W; ++p) mm = fmaxf(mm, QA[(er * W + p) * C16_QSL + hd * C16_QH + 97]);
           for (int p = 0; p < W; ++p) {
-            const size_t slot = (size_t)p * Nd + grow;
-            const float mp = ldg1(io.m + slot * 8 + (ec >> 4));
+            const int slot = er * W + p;
+            const float mp = QA[slot * C16_QSL + hd * C16_QH + 97];
             const float sc = (mp == -INFINITY) ? 0.f : exp2f(mp - mm);
-            in_l = fmaf(ldg1(io.l + slot * 8 + (ec >> 4)), sc, in_l);
-            const float4 a0 = ldg4(io.av + slot * 128 + ec), a1 = ldg4(io.av + slot * 128 + ec + 4);
+            in_l = fmaf(QA[slot * C16_QSL + hd * C16_QH + 96], sc, in_l);
+            const float* avp = AG + (8 + slot) * ND_XS + ec;
+            const float4 a0 = *reinterpret_cast<const float4*>(avp), a1 = *reinterpret_cast<const float4*>(avp + 4);
             in_av0.x = fmaf(a0.x, sc, in_av0.x); in_av0.y = fmaf(a0.y, sc, in_av0.y); in_av0.z = fmaf(a0.z, sc, in_av0.z); in_av0.w = fmaf(a0.w, sc, in_av0.w);
             in_av1.x = fmaf(a1.x, sc, in_av1.x); in_av1.y = fmaf(a1.y, sc, in_av1.y); in_av1.z = fmaf(a1.z, sc, in_av1.z); in_av1.w = fmaf(a1.w, sc, in_av1.w);
           }
@@ -676,10 +713,9 @@ __device__ __noinline__ void c16_node_phase(const ChainStep* __restrict__ post, 
             }
           } else if (mi < nrows) {      // W partial sums: common maximum, rescale, add
             float mm = -INFINITY;
-            for (int p = 0; p < W; ++p) mm = fmaxf(mm, ldg1(io.m + ((size_t)p * Nd + row0 + mi) * 8 + h));
+            for (int p = 0; p < W; ++p) mm = fmaxf(mm, QA[(mi * W + p) * C16_QSL + h * C16_QH + 97]);
             for (int p = 0; p < W; ++p) {
-              const size_t slot = (size_t)p * Nd + row0 + mi;
-              const float mp = ldg1(io.m + slot * 8 + h);
+              const float mp = QA[(mi * W + p) * C16_QSL + h * C16_QH + 97];
               const float sc = (mp == -INFINITY) ? 0.f : exp2f(mp - mm);
 #pragma unroll
               for (int ks = 0; ks < 3; ++ks) {
@@ -707,7 +743,6 @@ __device__ __noinline__ void c16_node_phase(const ChainStep* __restrict__ post, 
         }
       }
       __syncthreads();
-      C16_MARK(16);
       float agg[8];
       if (epi) {   // agg = (a_v + fold + l * vb) / (l + 1e-16)   (:89, :100)
         const float l = in_l;
@@ -768,7 +803,7 @@ __device__ __noinline__ void c16_node_phase(const ChainStep* __restrict__ post, 
       __syncthreads();
       C16_MARK(24);
       gemm16<16, Ring, NWV>(R, P1h, P1l, ND_AS5, w.F2, 8, C, ND_CS, wave, lane);
-      if (pre) frag_prefetch<4, Ring, NWV>(R, pre->w.Fqsg, 24, wave, lane);   // (the next PRE's first GEMM)
+      if (pre) frag_prefetch<4, Ring, NWV>(R, pre->w.Fqsg, 8, wave, lane);   // (the next PRE's first GEMM)
       __syncthreads();
       C16_MARK(25);
       if (epi) {   // x = x + LN_ffpost(FFN)
@@ -797,7 +832,7 @@ __device__ __noinline__ void c16_node_phase(const ChainStep* __restrict__ post, 
     // =========================================================== PRE: LN_dst, q | s | g, q~, <q, kb>   (:61-69, :106-107, :114)
     stage_sp(w.sp);
     if (tid < 16) ctr[17 + tid] = tid < nrows ? ldgi(st.eoff + row0 + tid + 1) - ldgi(st.eoff + row0 + tid) : -1;   // (for the row queue)
-    if (!post) frag_prefetch<4, Ring, NWV>(R, w.Fqsg, 24, wave, lane);   // (later layers: requested at the end of the previous POST)
+    if (!post) frag_prefetch<4, Ring, NWV>(R, w.Fqsg, 8, wave, lane);   // (later layers: requested at the end of the previous POST)
     __syncthreads();
     C16_MARK(32);
     if (epi) {
@@ -809,26 +844,18 @@ __device__ __noinline__ void c16_node_phase(const ChainStep* __restrict__ post, 
     }
     __syncthreads();
     C16_MARK(33);
-    gemm16<4, Ring, NWV>(R, P0h, P0l, ND_AS, w.Fqsg, 24, Cw, ND_CW, wave, lane);
+    gemm16<4, Ring, NWV>(R, P0h, P0l, ND_AS, w.Fqsg, 8, C, ND_CS, wave, lane);   // q (to_s / to_g: the POST half)
     frag_prefetch<1, Ring, NWV>(R, w.Fkr3, 8 * 6, wave, lane);
     __syncthreads();
     C16_MARK(34);
     if (epi) {
-      float q[8], sv[8], gv[8];
+      float q[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        q[i] = Cw[er * ND_CW + ec + i] + sp[SP_BQ + ec + i];
-        sv[i] = Cw[er * ND_CW + 128 + ec + i] + sp[SP_BS + ec + i];
-        gv[i] = Cw[er * ND_CW + 256 + ec + i] + sp[SP_BG + ec + i];
+        q[i] = C[er * ND_CS + ec + i] + sp[SP_BQ + ec + i];
         AG[er * ND_XS + ec + i] = q[i];
       }
       planes_store8(P0h + er * ND_AS + ec, P0l + er * ND_AS + ec, q);
-      if (live) {
-        *reinterpret_cast<float4*>(io.s + (size_t)grow * 128 + ec) = make_float4(sv[0], sv[1], sv[2], sv[3]);
-        *reinterpret_cast<float4*>(io.s + (size_t)grow * 128 + ec + 4) = make_float4(sv[4], sv[5], sv[6], sv[7]);
-        *reinterpret_cast<float4*>(io.g + (size_t)grow * 128 + ec) = make_float4(gv[0], gv[1], gv[2], gv[3]);
-        *reinterpret_cast<float4*>(io.g + (size_t)grow * 128 + ec + 4) = make_float4(gv[4], gv[5], gv[6], gv[7]);
-      }
     }
     __syncthreads();
     C16_MARK(35);
@@ -884,9 +911,12 @@ __device__ __noinline__ void c16_node_phase(const ChainStep* __restrict__ post, 
 // list is shared by W = NWV / rows waves (tiles w, w + W, ...): every wave keeps its own running maximum and sums, the
 // POST half merges the W partials.  ONEW: rows >= NWV (W = 1) -- a template parameter and not a branch, so that every kernel
 // has ONE edge-phase callee (two would cost the inter-procedural register allocation: 113 registers saved per call).
+// disable_tail_calls: a call that hipcc may mark `tail` makes its callee unsafe for the no-callee-saved-registers treatment
+// (TargetFrameLowering::isSafeForNoCSROpt), and each phase function would then save and restore ~90 registers through
+// scratch on every call (the round-2 kernel escaped that only because it passed a struct by value).
 template <int NWV, bool POLICY, bool ONEW>
-__global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void k_chain16(float* __restrict__ x, const float* __restrict__ x_in, int Nd, int rows,
-                                                    const ChainStep* __restrict__ steps, int nsteps, EdgeIO io,
+__global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) __attribute__((disable_tail_calls)) void k_chain16(float* __restrict__ x, const float* __restrict__ x_in, int Nd, int rows,
+                                                    const ChainStep* __restrict__ steps, int nsteps,
                                                     const float* __restrict__ div32, float eps, int xcd,
                                                     unsigned long long* __restrict__ prof) {
   // prof (PS_CHAIN_PROF=1; nullptr in every product launch): thread 0 of each workgroup charges the cycles since the
@@ -925,14 +955,14 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void k_chain16(float* _
   // PRE(0); then per layer EDGE(s), POST(s) + PRE(s + 1).  Every phase is a function of its own: the phases' register
   // needs differ (the edge phase's accumulators and operands, the node phases' weight-fragment ring) and inlined into one
   // body each pushed the other's into scratch.
-  c16_node_phase<NWV>(nullptr, steps, io, c16_smem, nullptr, row0, nrows, W, Nd, eps, prof);
+  c16_node_phase<NWV>(nullptr, steps, c16_smem, nullptr, row0, nrows, W, eps, prof);
   C16_MARK(0);
   for (int s = 0; s < nsteps; ++s) {
-    c16_edge_phase<NWV, ONEW>(steps + s, io, c16_smem, AG, CQ, ctr, QA, div32, row0, nrows, W, Nd, prof);
+    c16_edge_phase<NWV, ONEW>(steps + s, c16_smem, AG, CQ, ctr, QA, div32, row0, nrows, W);
     __syncthreads();   // every row's sums are in place; the wave-private areas are dead
     C16_MARK(1);
     const bool last = s + 1 == nsteps;
-    c16_node_phase<NWV>(steps + s, last ? nullptr : steps + s + 1, io, c16_smem, last ? x : nullptr, row0, nrows, W, Nd, eps, prof);
+    c16_node_phase<NWV>(steps + s, last ? nullptr : steps + s + 1, c16_smem, last ? x : nullptr, row0, nrows, W, eps, prof);
     C16_MARK(2);
   }
 }

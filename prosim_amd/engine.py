@@ -52,10 +52,11 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(_LIB_PATH):
-        raise RuntimeError(f"{_LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+    path = os.environ.get("PS_LIB", _LIB_PATH)   # (tools: A/B against another build of the same ABI)
+    if not os.path.exists(path):
+        raise RuntimeError(f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(there is no CPU fallback for the rollout path)")
-    lib = C.CDLL(_LIB_PATH)
+    lib = C.CDLL(path)
     fp, u8p, i32p = C.POINTER(C.c_float), C.POINTER(C.c_uint8), C.POINTER(C.c_int32)
     vp = C.c_void_p
     lib.ps_last_error.restype = C.c_char_p
@@ -175,7 +176,7 @@ class Engine:
         rc = self.lib.ps_create(C.byref(cfg), len(names), c_names, c_ptrs, c_numel, C.byref(h))
         self.h = h if rc == 0 else None
         self._check(rc)
-        self._shape = None
+        self._shape = self._in_shape = None
         self._slots = None
 
     def _check(self, rc: int):
@@ -221,7 +222,8 @@ class Engine:
                                           _f(obs_input), _u8(obs_mask), _f(keep[11]), _f(keep[12]), _f(prompt), _u8(pm),
                                           _i32(at), _f(ppos), _f(phead)))
         Mrep = self.replicas
-        self._shape = (B, N) if Mrep == 1 else (Mrep, N)
+        self._shape = (B, N) if Mrep == 1 else (Mrep, N)   # layout of the per-agent RESULTS (replica-major with replicas)
+        self._in_shape = (B, N)                              # layout of the per-scene INPUTS (replicas share one scene)
         # rows in slot order; policy agents are the rows whose slot carries a prompt, the others replay the log
         # (ps_set_future_log); live0_rows: the row is a scene token at the initial step
         in_slots = np.nonzero(seen.reshape(-1))[0]
@@ -252,7 +254,7 @@ class Engine:
         result has ``m * agents`` rows (``padded`` returns [m, N, ...]); ``mode_choice`` is [R, m, N]."""
         self._check(self.lib.ps_set_replicas(self.h, int(m)))
         self._replicas = int(m)
-        self._shape = self._slots = None
+        self._shape = self._in_shape = self._slots = None
 
     def world_trajs(self, center_to_world=None, out_dev_ptr: int = 0):
         """obtain_rollout_trajs_in_world (rollout/gpu_utils.py:230-281) on the device.  ``center_to_world``: 3 x 3 or None
@@ -321,7 +323,7 @@ class Engine:
 
     def set_prompt(self, prompt, prompt_pos, prompt_head, agent_type):
         a = [np.ascontiguousarray(prompt, np.float32), np.ascontiguousarray(prompt_pos, np.float32),
-             np.ascontiguousarray(prompt_head, np.float32).reshape(self._shape), np.ascontiguousarray(agent_type, np.int32)]
+             np.ascontiguousarray(prompt_head, np.float32).reshape(self._in_shape), np.ascontiguousarray(agent_type, np.int32)]
         self._check(self.lib.ps_set_prompt(self.h, _f(a[0]), _f(a[1]), _f(a[2]), _i32(a[3])))
 
     def policy_forward(self, n_scenes, a_tok, a_pos, a_ori, a_scene, m_tok, m_pos, m_ori, m_scene, p_emd, p_pos, p_ori,
@@ -354,8 +356,8 @@ class Engine:
     def update_obs(self, obs_input, obs_mask, obs_pos, obs_head):
         """Re-encode the agents from a new observation ([B,N,hist,obs_dim], mask, [B,N,2], [B,N]); map tokens are kept."""
         a = [np.ascontiguousarray(obs_input, np.float32), np.ascontiguousarray(obs_mask).astype(np.uint8),
-             np.ascontiguousarray(obs_pos, np.float32), np.ascontiguousarray(obs_head, np.float32).reshape(self._shape)]
-        if a[0].shape[:2] != self._shape or a[1].shape != a[0].shape:
+             np.ascontiguousarray(obs_pos, np.float32), np.ascontiguousarray(obs_head, np.float32).reshape(self._in_shape)]
+        if a[0].shape[:2] != self._in_shape or a[1].shape != a[0].shape:
             raise ValueError("update_obs: the observation must keep the [B, N] layout of set_scene")
         self._check(self.lib.ps_update_obs(self.h, _f(a[0]), _u8(a[1]), _f(a[2]), _f(a[3])))
 

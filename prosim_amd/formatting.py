@@ -76,14 +76,31 @@ def agent_types_from_scene_metadata(path: str) -> Dict[str, int]:
             else:
                 self._state = st
 
+    # Globals a Scene pickle of the cache needs besides the trajdata classes (measured over the 16 demo scenes).  Anything
+    # else -- dill's _create_function / _import_module, os, builtins.eval ... -- is refused: a cache directory is user input.
+    allowed = {("collections", "defaultdict"), ("collections", "OrderedDict"), ("pathlib", "PosixPath"), ("pathlib", "PurePosixPath"),
+               ("pathlib", "Path"), ("numpy", "dtype"), ("numpy", "ndarray"), ("numpy.core.multiarray", "scalar"),
+               ("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "scalar"), ("numpy._core.multiarray", "_reconstruct"),
+               ("builtins", "set"), ("builtins", "frozenset"), ("builtins", "dict"), ("builtins", "list"), ("builtins", "tuple")}
+
+    def _load_type(name):   # dill._dill._load_type: a builtin TYPE by name; only plain containers / scalars are honoured
+        import builtins
+        if name not in ("dict", "list", "tuple", "set", "frozenset", "int", "float", "str", "bool", "bytes", "NoneType", "type", "PartialType"):
+            raise pickle.UnpicklingError(f"scene metadata pickle asks for type {name!r}: refused")
+        if name == "PartialType":   # the Scene holds defaultdict(partial(const_lambda, ...)); it can only wrap what find_class lets through
+            import functools
+            return functools.partial
+        return type(None) if name == "NoneType" else getattr(builtins, name)
+
     class _Unpickler(pickle.Unpickler):
         def find_class(self, module, name):
             if module.split(".")[0] == "trajdata":
                 return type(name, (_Stub,), {"__module__": module})
-            if module.split(".")[0] == "dill":
-                import dill._dill as dd                                   # (the cache is written with dill)
-                return getattr(dd, name)
-            return super().find_class(module, name)
+            if (module, name) == ("dill._dill", "_load_type"):            # (the cache is written with dill)
+                return _load_type
+            if (module, name) in allowed:
+                return super().find_class(module, name)
+            raise pickle.UnpicklingError(f"scene metadata pickle references {module}.{name}: refused (not on the allow-list)")
 
     with open(path, "rb") as f:
         scene = _Unpickler(f).load()

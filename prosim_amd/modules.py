@@ -321,6 +321,7 @@ class HipDecoder:
             raise NotImplementedError("staged decoder(): prompt agents must be the observed agents; "
                                       "use the model's forward(batch) for scenes with log-replay agents")
         eng.set_prompt(prompt, p_pos, p_head, a_type.astype(np.int32))
+        sc["_policy_slots"] = slots   # (a scene that came from update_scene_emb with another agent set has none yet)
         Np = _np(_g(prompt_enc, "prompt_mask")).shape[1]
         if condition:
             unsupported = [k for k in condition.keys() if k not in COND_TYPES and np.asarray(condition[k]["input"]).shape[1] > 0]
@@ -460,6 +461,7 @@ class ProSimHip:
             if not np.array_equal(pm, sc["prompt_mask"]):
                 raise ValueError("generate_policy: the prompt agents differ from the ones encode_scene saw")
             self.engine.set_prompt(prompt, p_pos, p_head, a_type.astype(np.int32))
+            sc["_policy_slots"] = slots
             Np = _np(_g(pe, "prompt_mask")).shape[1]
             if cond:
                 unsupported = [k for k in cond.keys() if k not in COND_TYPES and _g(cond[k], "input").shape[1] > 0]
@@ -538,6 +540,9 @@ class ProSimHip:
         """``ProSim._process_rollout`` (:562-595): outputs of the policy agents, in prompt order."""
         spec, eng = self.spec, self.engine
         B, N = scene["prompt_mask"].shape
+        if "_policy_slots" not in scene:
+            raise ValueError("rollout: the scene has no policy agents yet -- after update_scene_emb with another agent set, "
+                             "call the decoder / generate_policy again before rolling out")
         pslots = scene["_policy_slots"]                          # per scene: observation slot of every policy agent, prompt order
         ids = _g(extras["prompt"]["motion_pred"], "agent_ids")
         if ids is None:
