@@ -218,16 +218,27 @@ __device__ __forceinline__ void feat_slow_row(float a0, float a1, float a2, floa
   }
 }
 
-// ---- LDS-DMA of a tile's k rows (global_load_lds_dwordx4: 16 B per lane straight into LDS, no VGPRs; the LDS address is
+// ---- LDS-DMA of a tile's k rows (buffer_load_dwordx4 ... lds: 16 B per lane straight into LDS, no VGPRs; the LDS address is
 // M0 + 16 * lane, wave-uniform base, so a bank-friendly layout is made by permuting the SOURCE pieces).  One round moves the
 // hi (or lo) halves of 16 rows = 16 x 256 B: instruction i, lane l fills slot s = l & 15 of row rr = 4 i + (l >> 4) with piece
 // s ^ rr of that row; the fragment reads (lane = row mi + 16 kq wants piece 4 ks + kq) then hit slot (4 ks + kq) ^ mi, and the 16
 // lanes of every ds_read_b128 service group land on 16 distinct 16-byte slots mod 256 B (cdna guide, LDS section).
 // (tools/mb/mb_glds.hip checks the recipe, also above 64 KB of LDS.)  Inline asm: hipcc neither counts these in vmcnt nor waits for them -- c16_wait_vm0() before the stage is read.
-__device__ __forceinline__ void c16_glds16(const void* gsrc, unsigned lds_dst) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+__device__ __forceinline__ void c16_blds16(unsigned voff, __amdgpu_buffer_rsrc_t rsrc, unsigned soff, unsigned lds_dst) {
+  unsigned keep;   // MUBUF form: 32-bit per-lane byte offset; `soff` (SGPR) moves the memory address only -- an instruction offset would move the LDS side too
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_dst) : "memory");
+}
+// raw buffer over a device array (stride 0, no format conversion): 32-bit offsets instead of 64-bit pointer arithmetic per lane
+// (the pointer goes through readfirstlane: a descriptor that hipcc cannot prove wave-uniform costs a waterfall loop per load)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t c16_rsrc(const void* p) {
+  const unsigned long long a = (unsigned long long)p;
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));
+  return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ float4 c16_bld4(__amdgpu_buffer_rsrc_t r, unsigned off) {
+  const v4f v = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+  return make_float4(v.x, v.y, v.z, v.w);
 }
 __device__ __forceinline__ void c16_wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ void c16_wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
@@ -276,7 +287,7 @@ __device__ __noinline__ void c16_edge_phase(const ChainStep* __restrict__ stp, u
   int* Ss = reinterpret_cast<int*>(wbase + 4096 + 512 + 16 * C16_FS * 2);     // [2][16] source rows of this tile and the next
   float* stash = reinterpret_cast<float*>(wbase + C16_STASH_OFF);
   const unsigned stg_lds = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)wbase);   // LDS byte address of the staging area
-  const EdgeGeo* __restrict__ geo = reinterpret_cast<const EdgeGeo*>(st.geo);
+  const __amdgpu_buffer_rsrc_t rs_geo = c16_rsrc(st.geo), rs_k = c16_rsrc(st.khl), rs_v = c16_rsrc(st.kv);
   // fragment reads of the staging area: row mi, piece 4 ks + kq at slot (4 ks + kq) ^ mi
   const half8* str = stg + mi * 16 + (kq ^ (mi & 3));
   const int sra = mi >> 2;
@@ -300,8 +311,8 @@ __device__ __noinline__ void c16_edge_phase(const ChainStep* __restrict__ stp, u
     }
     if (lr >= nrows) break;
     const int r = row0 + lr;
-    const int e_beg = ldgi(st.eoff + r);
-    const int deg = ldgi(st.eoff + r + 1) - e_beg;
+    const int e_beg = __builtin_amdgcn_readfirstlane(ldgi(st.eoff + r));   // (wave-uniform: the tile loop's control stays on the scalar unit)
+    const int deg = __builtin_amdgcn_readfirstlane(ldgi(st.eoff + r + 1)) - e_beg;
     const int tstep = ONEW ? 32 : 16 * W;
     const bool two = ONEW && deg > 16;   // the row has odd tiles: two partial sums
     // Tiles of 16 edges (one score block).  A tile's geometry and source rows are requested one tile ahead (registers).
@@ -309,16 +320,16 @@ __device__ __noinline__ void c16_edge_phase(const ChainStep* __restrict__ stp, u
     float4 ng;
     float nn = 0.f;
     int nsrc = 0;
+    // lane mi asks for the record of edge tt + mi, or of the row's last edge past the end: the 16 source rows that lanes 0-15
+    // publish are all valid (a short tile repeats its last edge; the scores of the repeats are masked)
     auto prefetch = [&](int tt) {
-      const int n_ = min(16, deg - tt);
-      if (n_ > 0) {
-        const EdgeGeo* gp = geo + e_beg + tt + min(mi, n_ - 1);
-        ng = ldg4(reinterpret_cast<const float*>(gp));
-        nn = ldg1(reinterpret_cast<const float*>(gp) + 4);
-        nsrc = ldgi(reinterpret_cast<const int*>(gp) + 5);   // (lanes 0-15 publish it)
-      }
+      const unsigned off = (unsigned)(e_beg + min(tt + mi, deg - 1)) * 32u;
+      ng = c16_bld4(rs_geo, off);
+      const float2 g2 = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rs_geo, off + 16, 0, 0));
+      nn = g2.x;
+      nsrc = __float_as_int(g2.y);
     };
-    prefetch(t0);
+    if (t0 < deg) prefetch(t0);
     // B operands of the score MFMAs: lane -> column n = mi (head mi & 7, hi | lo half), k-block kq
     half8 bq[3], bk[4];
     float cqm;
@@ -350,24 +361,23 @@ __device__ __noinline__ void c16_edge_phase(const ChainStep* __restrict__ stp, u
 #pragma unroll
     for (int cb = 0; cb < 6; ++cb) ar[cb] = floatx4{0.f, 0.f, 0.f, 0.f};
     float4 av = make_float4(0.f, 0.f, 0.f, 0.f);   // a_v partial: columns 4 (lane & 31) ..+3, edges of parity lane >> 5
-    const float* vbase = st.kv + 128 + 4 * (lane & 31);
-    // the DMA source pointers of a tile's k rows (hi halves; the lo halves sit 256 bytes further)
-    const _Float16* kp[4];
+    const unsigned vcol = 512u + 16u * (lane & 31);   // the v half of a k | v row, this lane's four columns
+    // the DMA source offsets of a tile's k rows (hi halves; the lo halves sit 256 bytes further: the DMA's scalar offset)
+    unsigned kp[4];
     int sb = 0;   // Ss buffer holding this tile's source rows
-    auto kaddr = [&](int tt, int buf) {
-      const int n_ = min(16, deg - tt);
+    auto kaddr = [&](int buf) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int rr = 4 * i + dr;
-        kp[i] = st.khl + (size_t)Ss[16 * buf + min(rr, n_ - 1)] * 256 + 8 * (ds_ ^ rr);
+        kp[i] = (unsigned)Ss[16 * buf + rr] * 512u + 16u * (ds_ ^ rr);
       }
     };
     if (t0 < deg) {
       if (lane < 16) Ss[lane] = nsrc;   // (prefetch(t0)'s loads are hipcc's own: it waits for them here)
-      kaddr(t0, 0);
+      kaddr(0);
       c16_wait_lgkm0();                 // the previous row's last reads of the staging area are done
 #pragma unroll
-      for (int i = 0; i < 4; ++i) c16_glds16(kp[i], stg_lds + 1024 * i);
+      for (int i = 0; i < 4; ++i) c16_blds16(kp[i], rs_k, 0u, stg_lds + 1024 * i);
     }
 #pragma unroll 1
     for (int tn = 0; t0 < deg; t0 = tn) {
@@ -390,21 +400,19 @@ __device__ __noinline__ void c16_edge_phase(const ChainStep* __restrict__ stp, u
         for (int ks = 0; ks < 4; ++ks) ak[ks] = str[4 * (ks ^ sra)];
         c16_wait_lgkm0();
 #pragma unroll
-        for (int i = 0; i < 4; ++i) c16_glds16(kp[i] + 128, stg_lds + 1024 * i);   // (an instruction offset would move the LDS destination too)
-        prefetch(tn);   // the next tile's records leave now
+        for (int i = 0; i < 4; ++i) c16_blds16(kp[i], rs_k, 256u, stg_lds + 1024 * i);
+        prefetch(tn);   // the next tile's records leave now (past the row's end: its last edge again, unused)
         floatx4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) acc2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ak[ks], bk[ks], acc2, 0, 0, 0);
         // ---- this tile's Fourier rows, in registers (A fragments of the score MFMAs) and as a row-major LDS tile
-        const bool fast = !__any(!(fdiv16_ok(g0.x) && fdiv16_ok(g0.y) && fdiv16_ok(g0.z)));
         half8 fh[3];
-        if (fast) {
-          feat8(g0.x, g0.w, nmr, dv, rdv, fh[0], fl[0]);
-          feat8(g0.y, g0.w, nmr, dv, rdv, fh[1], fl[1]);
-          feat8(g0.z, g0.w, nmr, dv, rdv, fh[2], fl[2]);
-#pragma unroll
-          for (int ks = 0; ks < 3; ++ks) *reinterpret_cast<half8*>(Ft + mi * C16_FS + 32 * ks + 8 * kq) = fh[ks];
-        } else {   // (a distance beyond 10 km: true division + libm, rolled, through the feature tile -- twice, the hi halfs last)
+        feat8(g0.x, g0.w, nmr, dv, rdv, fh[0], fl[0]);
+        feat8(g0.y, g0.w, nmr, dv, rdv, fh[1], fl[1]);
+        feat8(g0.z, g0.w, nmr, dv, rdv, fh[2], fl[2]);
+        if (__builtin_expect(__any(!(fdiv16_ok(g0.x) && fdiv16_ok(g0.y) && fdiv16_ok(g0.z))), 0)) {
+          // (a distance beyond 10 km, outside fdiv16's checked range: true division + libm, rolled, through the feature
+          // tile -- twice, the hi halfs last; out of the common path's basic block)
           _Float16* frow = Ft + mi * C16_FS;
           feat_slow_row(g0.x, g0.y, g0.z, g0.w, nmr, dv, kq, frow, true);
 #pragma unroll
@@ -414,6 +422,8 @@ __device__ __noinline__ void c16_edge_phase(const ChainStep* __restrict__ stp, u
           for (int ks = 0; ks < 3; ++ks) fh[ks] = *reinterpret_cast<const half8*>(frow + 32 * ks + 8 * kq);
         }
 #pragma unroll
+        for (int ks = 0; ks < 3; ++ks) *reinterpret_cast<half8*>(Ft + mi * C16_FS + 32 * ks + 8 * kq) = fh[ks];
+#pragma unroll
         for (int ks = 0; ks < 3; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[ks], bq[ks], acc, 0, 0, 0);
         // ---- k lo halves
         c16_wait_vm0();
@@ -422,9 +432,9 @@ __device__ __noinline__ void c16_edge_phase(const ChainStep* __restrict__ stp, u
         c16_wait_lgkm0();
         if (tn < deg) {   // the next tile's source rows arrived with the prefetch: publish them, start the DMA of its k hi halves
           if (lane < 16) Ss[16 * (sb ^ 1) + lane] = nsrc;
-          kaddr(tn, sb ^ 1);
+          kaddr(sb ^ 1);
 #pragma unroll
-          for (int i = 0; i < 4; ++i) c16_glds16(kp[i], stg_lds + 1024 * i);
+          for (int i = 0; i < 4; ++i) c16_blds16(kp[i], rs_k, 0u, stg_lds + 1024 * i);
         }
 #pragma unroll
         for (int ks = 0; ks < 3; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl[ks], bq[ks], acc, 0, 0, 0);
@@ -440,7 +450,7 @@ __device__ __noinline__ void c16_edge_phase(const ChainStep* __restrict__ stp, u
       // v rows of the tile leave now and fly under the softmax and the a_r MFMAs: gathered by source, two rows per load instruction
       float4 vv[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) vv[j] = ldg4(vbase + (size_t)Sc[min(2 * j + eh, n - 1)] * 256);
+      for (int j = 0; j < 8; ++j) vv[j] = c16_bld4(rs_v, (unsigned)Sc[2 * j + eh] * 1024u + vcol);
       // ---- online softmax over the tile (torch_geometric.utils.softmax: max-shift, exp, / (sum + 1e-16))
       float tmax = fmaxf(fmaxf(sreg[0], sreg[1]), fmaxf(sreg[2], sreg[3]));
       tmax = kq_max(tmax);
