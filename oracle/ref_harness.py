@@ -431,3 +431,199 @@ def load_world_output():
         if v is not None:
             sys.modules[k] = v
     return gu.obtain_rollout_trajs_in_world, gu.replica_batch_for_parallel_rollout
+
+
+# --------------------------------------------------------------------------- the reference's input formatters
+class _StateArray(np.ndarray):
+    """trajdata's ``StateArray`` (trajdata/utils/state_utils.py -- third party, absent here) restated from its published
+    interface for the calls the reference's formatters make: a float array whose last axis follows a comma-separated
+    ``_format`` ('x,y,z,xd,yd,xdd,ydd,s,c' | '...,h'); ``position`` = (x, y), ``velocity`` = (xd, yd), ``acceleration`` =
+    (xdd, ydd), ``heading_vector`` = (c, s), ``heading`` = h or atan2(s, c) with a trailing axis of one; ``as_format``
+    re-orders / derives columns (s = sin h, c = cos h).  ARITHMETIC-BEARING stand-in: what it pins is labelled
+    'ref + trajdata stand-ins'."""
+    _format = ""
+
+    @classmethod
+    def from_array(cls, a, format):
+        out = np.asarray(a).view(cls)
+        out._format = format
+        return out
+
+    def __array_finalize__(self, obj):
+        self._format = getattr(obj, "_format", "")
+
+    @property
+    def _format_dict(self):
+        return {k: i for i, k in enumerate(self._format.split(","))}
+
+    def _cols(self, names):
+        d = self._format_dict
+        return np.asarray(self)[..., [d[n] for n in names]]
+
+    def _set(self, names, v):
+        d = self._format_dict
+        np.asarray(self)[..., [d[n] for n in names]] = v
+
+    position = property(lambda s: s._cols("xy"), lambda s, v: s._set("xy", v))
+    velocity = property(lambda s: s._cols(["xd", "yd"]), lambda s, v: s._set(["xd", "yd"], v))
+    acceleration = property(lambda s: s._cols(["xdd", "ydd"]), lambda s, v: s._set(["xdd", "ydd"], v))
+    heading_vector = property(lambda s: s._cols("cs"), lambda s, v: s._set("cs", v))
+
+    @property
+    def heading(self):
+        d = self._format_dict
+        if "h" in d:
+            return self._cols("h")
+        sc = self._cols("sc")
+        return np.arctan2(sc[..., :1], sc[..., 1:])
+
+    @heading.setter
+    def heading(self, v):
+        self._set("h", v)
+
+    def as_format(self, fmt):
+        d = self._format_dict
+        a = np.asarray(self)
+        cols = []
+        for k in fmt.split(","):
+            if k in d:
+                cols.append(a[..., d[k]])
+            elif k == "s":
+                cols.append(np.sin(a[..., d["h"]]))
+            elif k == "c":
+                cols.append(np.cos(a[..., d["h"]]))
+            elif k == "h":
+                cols.append(np.arctan2(a[..., d["s"]], a[..., d["c"]]))
+            else:
+                raise KeyError(k)
+        return _StateArray.from_array(np.stack(cols, -1), fmt)
+
+    def copy(self, *a, **k):
+        return _StateArray.from_array(np.array(self), self._format)
+
+
+class _StateTensor:
+    """trajdata's ``StateTensor`` for the same calls: a thin wrapper around a torch tensor with a ``_format``."""
+
+    def __init__(self, t, fmt):
+        self.t, self._format = t, fmt
+
+    @classmethod
+    def from_array(cls, a, format):
+        return cls(a.t if isinstance(a, _StateTensor) else torch.as_tensor(a), format)
+
+    @classmethod
+    def from_numpy(cls, a):
+        return cls(torch.from_numpy(np.array(a)), a._format)
+
+    def numpy(self):
+        return _StateArray.from_array(self.t.numpy().copy(), self._format)
+
+    @property
+    def shape(self):
+        return self.t.shape
+
+    def __getitem__(self, idx):
+        return _StateTensor(self.t[idx], self._format)
+
+    def _cols(self, names):
+        d = {k: i for i, k in enumerate(self._format.split(","))}
+        return self.t[..., [d[n] for n in names]]
+
+    @property
+    def position(self):
+        return self._cols("xy")
+
+    @property
+    def heading(self):
+        d = self._format.split(",")
+        if "h" in d:
+            return self._cols("h")
+        sc = self._cols("sc")
+        return torch.atan2(sc[..., :1], sc[..., 1:])
+
+    def as_format(self, fmt):
+        return _StateTensor(torch.from_numpy(np.asarray(self.numpy().as_format(fmt))), fmt)
+
+    def as_tensor(self):
+        return self.t
+
+    def float(self):
+        return self.t.float()
+
+    def isnan(self):
+        return self.t.isnan()
+
+    def __torch_function__(self, func, types, args=(), kwargs=None):   # torch.cat([StateTensor, ...]) -> plain tensor
+        unwrap = lambda x: x.t if isinstance(x, _StateTensor) else ([unwrap(y) for y in x] if isinstance(x, (list, tuple)) else x)
+        return func(*unwrap(args), **(kwargs or {}))
+
+
+class _SceneBatch:
+    """Duck type of trajdata's ``SceneBatch`` with the attributes the formatters read."""
+
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+def load_format():
+    """The reference's own ``dataset/format_utils.py`` and ``dataset/data_utils.py`` (the rollout path's input formatters)
+    under stand-ins for trajdata: structural for the batch / dataset classes, arithmetic-bearing for ``StateArray`` /
+    ``StateTensor`` (above) and for three two-line helpers of trajdata.utils.arr_utils (``rotation_matrix``,
+    ``angle_wrap``, ``transform_coords_np``).  ``data_utils.py`` unpickles two id lists at import, one of which
+    (waymo_train_IDs.pkl) is not in the tree: ``open`` is shimmed for that one file.  Returns (format_utils, data_utils,
+    SceneBatch, StateTensor)."""
+    install()
+    import builtins
+    import io
+    import pickle
+    from enum import IntEnum
+
+    class AgentType(IntEnum):
+        UNKNOWN = 0
+        VEHICLE = 1
+        PEDESTRIAN = 2
+        BICYCLE = 3
+        MOTORCYCLE = 4
+
+    def rotation_matrix(angle):
+        c, s = np.cos(angle), np.sin(angle)
+        return np.stack([np.stack([c, -s], -1), np.stack([s, c], -1)], -2)
+
+    def angle_wrap(r):
+        return (r + np.pi) % (2 * np.pi) - np.pi
+
+    def transform_coords_np(coords, tf, translate=True):
+        out = np.einsum("...ij,...j->...i", tf[..., :-1, :-1], coords)
+        return out + tf[..., :-1, -1] if translate else out
+
+    td = _mod("trajdata", AgentBatch=type("AgentBatch", (), {}), AgentType=AgentType)
+    td.maps = _mod("trajdata.maps")
+    td.maps.map_api = _mod("trajdata.maps.map_api", MapAPI=None)
+    td.data_structures = _mod("trajdata.data_structures")
+    td.data_structures.batch_element = _mod("trajdata.data_structures.batch_element", AgentBatchElement=object, SceneBatchElement=object)
+    td.data_structures.batch = _mod("trajdata.data_structures.batch", AgentBatch=td.AgentBatch, SceneBatch=_SceneBatch)
+    td.utils = _mod("trajdata.utils")
+    td.utils.arr_utils = _mod("trajdata.utils.arr_utils", transform_coords_np=transform_coords_np, rotation_matrix=rotation_matrix,
+                              angle_wrap=angle_wrap)
+    td.utils.state_utils = _mod("trajdata.utils.state_utils", StateArray=_StateArray, StateTensor=_StateTensor, transform_state_np_2d=None)
+    td.augmentation = _mod("trajdata.augmentation", BatchAugmentation=object)
+    _mod("prosim.models.utils.data", get_agent_pos_dict=None, extract_agent_obs_from_center_obs=None)
+    _mod("prosim.dataset.condition_utils", ConditionGenerator=None, BatchCondition=None)
+    real_open = builtins.open
+
+    def shim(path, *a, **k):
+        if str(path).endswith("waymo_train_IDs.pkl") and not os.path.exists(path):
+            return io.BytesIO(pickle.dumps([]))
+        return real_open(path, *a, **k)
+
+    for k in ("prosim.dataset.data_utils", "prosim.dataset.format_utils", "prosim.dataset.prompt_utils", "prosim.dataset.motion_tag_utils"):
+        sys.modules.pop(k, None)
+    builtins.open = shim
+    try:
+        du = importlib.import_module("prosim.dataset.data_utils")
+        fu = importlib.import_module("prosim.dataset.format_utils")
+        pu = importlib.import_module("prosim.dataset.prompt_utils")
+    finally:
+        builtins.open = real_open
+    return fu, du, pu, _SceneBatch, _StateTensor

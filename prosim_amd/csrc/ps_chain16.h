@@ -379,6 +379,9 @@ __device__ __noinline__ void c16_edge_phase(const ChainStep* __restrict__ stp, u
 #pragma unroll
       for (int i = 0; i < 4; ++i) c16_blds16(kp[i], rs_k, 0u, stg_lds + 1024 * i);
     }
+#ifdef PS_C16_ABL_NOEDGE
+    t0 = deg;
+#endif
 #pragma unroll 1
     for (int tn = 0; t0 < deg; t0 = tn) {
       const int n = min(16, deg - t0);
@@ -407,9 +410,14 @@ __device__ __noinline__ void c16_edge_phase(const ChainStep* __restrict__ stp, u
         for (int ks = 0; ks < 4; ++ks) acc2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ak[ks], bk[ks], acc2, 0, 0, 0);
         // ---- this tile's Fourier rows, in registers (A fragments of the score MFMAs) and as a row-major LDS tile
         half8 fh[3];
+#ifdef PS_C16_ABL_NOFEAT   // (timing experiment: what the Fourier rows cost; wrong results)
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) { fh[ks] = __builtin_bit_cast(half8, ng); fl[ks] = fh[ks]; }
+#else
         feat8(g0.x, g0.w, nmr, dv, rdv, fh[0], fl[0]);
         feat8(g0.y, g0.w, nmr, dv, rdv, fh[1], fl[1]);
         feat8(g0.z, g0.w, nmr, dv, rdv, fh[2], fl[2]);
+#endif
         if (__builtin_expect(__any(!(fdiv16_ok(g0.x) && fdiv16_ok(g0.y) && fdiv16_ok(g0.z))), 0)) {
           // (a distance beyond 10 km, outside fdiv16's checked range: true division + libm, rolled, through the feature
           // tile -- twice, the hi halfs last; out of the common path's basic block)
@@ -449,8 +457,13 @@ __device__ __noinline__ void c16_edge_phase(const ChainStep* __restrict__ stp, u
       }
       // v rows of the tile leave now and fly under the softmax and the a_r MFMAs: gathered by source, two rows per load instruction
       float4 vv[8];
+#ifdef PS_C16_ABL_NOAV
+#pragma unroll
+      for (int j = 0; j < 8; ++j) vv[j] = make_float4(sreg[0], sreg[1], sreg[2], sreg[3]);
+#else
 #pragma unroll
       for (int j = 0; j < 8; ++j) vv[j] = c16_bld4(rs_v, (unsigned)Sc[2 * j + eh] * 1024u + vcol);
+#endif
       // ---- online softmax over the tile (torch_geometric.utils.softmax: max-shift, exp, / (sum + 1e-16))
       float tmax = fmaxf(fmaxf(sreg[0], sreg[1]), fmaxf(sreg[2], sreg[3]));
       tmax = kq_max(tmax);
@@ -491,6 +504,9 @@ __device__ __noinline__ void c16_edge_phase(const ChainStep* __restrict__ stp, u
 #pragma unroll
       for (int j = 0; j < 4; ++j) ap[j] = loA ? f16_lo(pr[j]) : f16_hi(pr[j]);
       const _Float16* tp = Ft + (kq * 4 + (mi >> 2)) * C16_FS + (lane & 3) * 4;
+#ifdef PS_C16_ABL_NOAR
+      ar[0][0] += (float)ap[0] + (float)fl[0][0] + (float)fl[1][0] + (float)fl[2][0];
+#else
 #pragma unroll
       for (int pass = 0; pass < 2; ++pass) {
         if (pass == 1) {
@@ -508,7 +524,11 @@ __device__ __noinline__ void c16_edge_phase(const ChainStep* __restrict__ stp, u
           ar[cb] = __builtin_amdgcn_mfma_f32_16x16x16f16(ap, bfr, ar[cb], 0, 0, 0);
         }
       }
+#endif
       // ---- a_v[hd] += sum_e p_e,h v_src[hd] on the VALU
+#ifdef PS_C16_ABL_NOAV
+      av.x += vv[0].x;
+#else
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const float ph = Pt[(2 * j + eh) * 8 + hv];   // 0 past the edge list
@@ -517,6 +537,7 @@ __device__ __noinline__ void c16_edge_phase(const ChainStep* __restrict__ stp, u
         av.z = fmaf(ph, vv[j].z, av.z);
         av.w = fmaf(ph, vv[j].w, av.w);
       }
+#endif
       sb ^= 1;
       if (ONEW && turn) {   // the even tiles are done: park their sums, start the odd tiles' from zero
         av.x += __shfl_xor(av.x, 32); av.y += __shfl_xor(av.y, 32); av.z += __shfl_xor(av.z, 32); av.w += __shfl_xor(av.w, 32);
