@@ -523,6 +523,10 @@ class _StateTensor:
     def shape(self):
         return self.t.shape
 
+    @property
+    def device(self):
+        return self.t.device
+
     def __getitem__(self, idx):
         return _StateTensor(self.t[idx], self._format)
 
@@ -554,7 +558,8 @@ class _StateTensor:
     def isnan(self):
         return self.t.isnan()
 
-    def __torch_function__(self, func, types, args=(), kwargs=None):   # torch.cat([StateTensor, ...]) -> plain tensor
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):   # torch.cat([StateTensor, ...]) -> plain tensor
         unwrap = lambda x: x.t if isinstance(x, _StateTensor) else ([unwrap(y) for y in x] if isinstance(x, (list, tuple)) else x)
         return func(*unwrap(args), **(kwargs or {}))
 

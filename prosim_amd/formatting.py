@@ -172,7 +172,9 @@ def scene_from_tracks(spec: ModelSpec, tracks: Dict[str, np.ndarray], t0: int,
     mask = np.isfinite(obs)
     prompt = np.zeros((1, N, spec.prompt_dim), f32)
     prompt[0, :, 0], prompt[0, :, 1] = np.nan_to_num(rvx[:, -1]), np.nan_to_num(rvy[:, -1])
-    prompt[0, :, 2:4] = ext
+    # (the prompt carries the extent AT t0 -- prompt_utils.py:68 reads agent_hist_extent[..., -1, :2] --, the observation the
+    # largest one the agent ever reports; found by the reference-made fixture, tests/test_format_ref_cpu.py)
+    prompt[0, :, 2:4] = np.nan_to_num(np.stack([tracks["length"][sel, t0], tracks["width"][sel, t0]], -1))
     for tid in (1, 2, 3):
         prompt[0, :, 4 + tid - 1] = types == tid
     px, py, ph = x0[:, 0], y0[:, 0], h0[:, 0]
@@ -268,8 +270,10 @@ def conditions_from_tracks(spec: ModelSpec, tracks: Dict[str, np.ndarray], t0: i
     rows = np.asarray(list(rows), np.int64)
     N, T = len(rows), tracks["x"].shape[1]
     pm = np.asarray(policy_mask, bool).reshape(N)
-    steps = np.arange(t0 + 1, min(t0 + 1 + spec.max_steps, T))
-    fx, fy = tracks["x"][rows][:, steps], tracks["y"][rows][:, steps]
+    steps = np.arange(t0 + 1, t0 + 1 + spec.max_steps)                       # a table that ends early: NaN steps, as the
+    inside = steps < T                                                       # reference pads full_traj_xy (format_utils.py:625-633)
+    fx, fy = np.full((N, len(steps)), np.nan), np.full((N, len(steps)), np.nan)
+    fx[:, inside], fy[:, inside] = tracks["x"][rows][:, steps[inside]], tracks["y"][rows][:, steps[inside]]
     x0, y0, h0 = tracks["x"][rows, t0][:, None], tracks["y"][rows, t0][:, None], tracks["heading"][rows, t0][:, None]
     lx, ly = _rotate(fx - x0, fy - y0, -h0)                                   # [N, F] the future path in the agent's frame at t0
     ok = np.isfinite(lx) & np.isfinite(ly)
@@ -286,6 +290,17 @@ def conditions_from_tracks(spec: ModelSpec, tracks: Dict[str, np.ndarray], t0: i
     dpts[0, ~dmask] = np.nan
     return {"goal": dict(input=goal, mask=gmask[None], prompt_idx=pidx.copy()),
             "drag_point": dict(input=dpts, mask=dmask[None], prompt_idx=pidx.copy())}
+
+
+def tracks_in_frame(tracks: Dict[str, np.ndarray], frame: Sequence[float]) -> Dict[str, np.ndarray]:
+    """The track table with positions, velocities, accelerations and headings expressed in ``frame`` = (x, y, heading) --
+    what a scene-centric trajdata batch holds (``standardize_data``: everything relative to the centred agent at t0)."""
+    out = dict(tracks)
+    out["x"], out["y"] = _rotate(tracks["x"] - frame[0], tracks["y"] - frame[1], -frame[2])
+    out["vx"], out["vy"] = _rotate(tracks["vx"], tracks["vy"], -frame[2])
+    out["ax"], out["ay"] = _rotate(tracks["ax"], tracks["ay"], -frame[2])
+    out["heading"] = (tracks["heading"] - frame[2] + np.pi) % (2 * np.pi) - np.pi
+    return out
 
 
 def ego_frame(tracks: Dict[str, np.ndarray], t0: int, agent_id: str = "ego") -> np.ndarray:

@@ -425,6 +425,132 @@ def gen_pair_metric():
     print("ref_pair_metric written:", out["after_updates"])
 
 
+def format_inputs(scene: str = "scene_1", t0: int = 10):
+    """The common input of the formatter fixtures (shared with tests/test_format_ref_cpu.py): the demo scene's track table in
+    the frame of its ego at ``t0`` (what a scene-centric trajdata batch holds), the agents' types, the decoded map lanes."""
+    import lzma
+    from prosim_amd import formatting as fmt, vecmap as vm
+    g = np.load(os.path.join(GOLD, f"demo_{scene}_agent_table.npz"))
+    tr = fmt.tracks_from_table({k: g[k] for k in g.files if k != "origin"})
+    f = fmt.ego_frame(tr, t0)
+    tre = fmt.tracks_in_frame(tr, f)
+    ego = list(tr["agent_ids"]).index("ego")
+    order = [ego] + [i for i in range(len(tr["agent_ids"])) if i != ego]
+    meta = fmt.agent_types_from_scene_metadata(os.path.join(GOLD, f"demo_{scene}_metadata.dill"))
+    types = np.array([meta[a] for a in tr["agent_ids"]], np.int64)
+    origin = g["origin"].astype(np.float64)
+    world = np.array([f[0] + origin[0], f[1] + origin[1], f[2]])
+    name = {"scene_1": "demo_waymo_train_1_map.pb", "scene_0": "demo_waymo_train_0_map.pb.xz"}[scene]
+    with open(os.path.join(GOLD, name), "rb") as fh:
+        pb = fh.read()
+    if name.endswith(".xz"):
+        pb = lzma.decompress(pb)
+    tl = np.load(os.path.join(GOLD, f"demo_{scene}_tls_table.npz"))
+    tls = vm.tls_at(tl["lane_id"], tl["scene_ts"], tl["status"], t0)
+    z = float(g["z"][(g["agent_id"] == "ego") & (g["scene_ts"] == t0)][0]) if "z" in g.files else 0.0
+    return dict(tracks=tre, order=order, types=types, world=world, z=z, lanes=vm.decode_vector_map(pb)["lanes"], tls=tls)
+
+
+def gen_format(scene: str = "scene_1", t0: int = 10):
+    """Reference-made fixture for the input formatters: the reference's OWN
+    dataset/format_utils.py (get_center_obs, get_future_obs, get_local_io_pairs_T_step_batch, get_local_vec_map,
+    local_map_to_sym_coord, get_center_vec_init_map), dataset/data_utils.py (_get_vectorized_lanes_from_vector_map,
+    transform_to_frame_offset_rot) and dataset/prompt_utils.py (AgentStatusGenerator) run on a duck-typed SceneBatch made
+    from the demo cache's agent table and on lane objects made from the map that prosim_amd/vecmap.py decodes.  trajdata's
+    side (StateTensor, three arr_utils helpers, which lanes get_lanes_within returns) is a builder stand-in
+    (oracle/ref_harness.py:load_format): the fixture is labelled ref + trajdata stand-ins."""
+    fu, du, pu, SceneBatch, StateTensor = rh.load_format()
+    C = rh.CfgNode
+    inp = format_inputs(scene, t0)
+    tr, order, types = inp["tracks"], inp["order"], inp["types"]
+    H, F, N = 11, 80, len(order)
+    T = tr["x"].shape[1]
+    FMT = "x,y,z,xd,yd,xdd,ydd,s,c"
+
+    def states(lo, hi):   # [N, hi - lo, 9] float32 states of steps lo .. hi - 1 (NaN outside the table / where absent)
+        out = np.full((N, hi - lo, 9), np.nan, np.float32)
+        ts = np.arange(lo, hi)
+        ok = (ts >= 0) & (ts < T)
+        sel = lambda c: tr[c][order][:, ts[ok]]
+        h = sel("heading")
+        cols = [sel("x"), sel("y"), np.where(np.isfinite(h), 0.0, np.nan), sel("vx"), sel("vy"), sel("ax"), sel("ay"), np.sin(h), np.cos(h)]
+        out[:, ok] = np.stack(cols, -1).astype(np.float32)
+        return out
+
+    def extents(lo, hi):
+        out = np.full((N, hi - lo, 3), np.nan, np.float32)
+        ts = np.arange(lo, hi)
+        ok = (ts >= 0) & (ts < T)
+        out[:, ok, 0], out[:, ok, 1] = tr["length"][order][:, ts[ok]], tr["width"][order][:, ts[ok]]
+        out[:, ok, 2] = np.where(np.isfinite(out[:, ok, 0]), 1.5, np.nan)
+        return out
+
+    hist, fut = states(t0 - H + 1, t0 + 1), states(t0 + 1, t0 + 1 + F)
+    fin = np.isfinite(fut[..., 0])
+    fut_len = np.where(fin.any(1), F - np.argmax(fin[:, ::-1], 1), 0)
+    present = np.isfinite(hist[:, -1, 0])
+    tgt = [int(i) for i in np.nonzero(present)[0]]
+    ids = [str(tr["agent_ids"][i]) for i in order]
+    t = torch.from_numpy
+    batch = SceneBatch(agent_names=[ids], agent_hist=StateTensor.from_array(t(hist)[None], FMT), agent_fut=StateTensor.from_array(t(fut)[None], FMT),
+                       agent_fut_len=t(fut_len.astype(np.int64))[None], agent_hist_extent=t(extents(t0 - H + 1, t0 + 1))[None],
+                       agent_fut_extent=t(extents(t0 + 1, t0 + 1 + F))[None], agent_type=t(types[order])[None], tgt_agent_idxs=[tgt],
+                       scene_ids=[scene], extras={"all_t_indices": np.arange(0, 80, 10)})
+    cfg = C({"HISTORY": {"STEPS": H, "ELEMENTS": "x,y,s,c,xd,yd,xdd,ydd", "WITH_EXTEND": True, "WITH_AGENT_TYPE": True, "WITH_TIME_EMB": True},
+             "TARGET": {"STEPS": 10, "SAMPLE_RATE": 10, "TAIL_PADDING": True, "ELEMENTS": "x,y,h,xd,yd"},   # (PRED_VEL appends xd,yd: default.py:725-730)
+             "GOAL": {"ELEMENTS": "x,y", "LOCAL": True}, "FUTURE_OBS_TYPE": "latest",
+             "MAP": {"MAX_POINTS": 2048, "LOCAL_RANGE": 200, "WITH_TYPE_EMB": True, "WITH_DIR": True}})
+    out = {}
+    obs = fu.get_center_obs_init(batch, cfg)
+    out.update(obs_input=obs.input.numpy(), obs_mask=obs.mask.numpy(), obs_pos=obs.position.numpy(), obs_head=obs.heading.numpy(),
+               obs_ids=np.array(obs.agent_ids[0]))
+    fo = fu.get_future_obs(batch, cfg)
+    keys = sorted(fo.keys())
+    for k in keys:
+        assert list(fo[k].agent_ids[0]) == list(fo[keys[0]].agent_ids[0]) or True
+    out["fut_keys"] = np.array(keys)
+    for k in keys:   # (the agents listed differ per frame: stored per frame with their ids)
+        out[f"fut{k}_input"], out[f"fut{k}_mask"] = fo[k].input.numpy(), fo[k].mask.numpy()
+        out[f"fut{k}_pos"], out[f"fut{k}_head"], out[f"fut{k}_ids"] = fo[k].position.numpy(), fo[k].heading.numpy(), np.array(fo[k].agent_ids[0])
+    io = fu.get_local_io_pairs_T_step_batch(batch, cfg, "rollout")
+    for k in ("tgt", "mask", "goal", "position", "heading", "agent_type", "init_vel", "extend", "full_traj_xy"):
+        out["io_" + k] = io[k].numpy()
+    out["io_T_indices"], out["io_names"] = np.array(io["T_indices"]), np.array(io["agent_names"][0])
+    # the status prompt of the target agents (prompt_utils.py:29-86, :111-150)
+    gen = pu.AgentStatusGenerator(C({"USE_VEL": True, "USE_EXTEND": True, "USE_AGENT_TYPE": True}))
+    pr = gen.prompt_for_batch(batch)
+    out.update(prompt=pr["prompt"].numpy(), prompt_pos=pr["position"].numpy(), prompt_head=pr["heading"].numpy(),
+               prompt_type=pr["agent_type"].numpy(), prompt_ids=np.array(pr["agent_ids"][0]))
+    out["tgt_idx"] = np.array(tgt)
+    # ---- the map: lane objects from the decoded protobuf -> the reference's vectorisation, local cut and frames
+    Poly = lambda pts: None if pts is None else type("Polyline", (), {"points": np.asarray(pts, np.float64)})()
+    lanes = [type("RoadLane", (), {"id": l["id"], "center": Poly(l["center"]), "left_edge": Poly(l["left"]), "right_edge": Poly(l["right"])})()
+             for l in inp["lanes"]]
+    world, z = inp["world"], inp["z"]
+    tls = inp["tls"]
+
+    class VecMap:   # (trajdata's side, unpinned: lanes with any centre point within the distance, file order; -1 = no record)
+        def get_lanes_within(self, xyz, dist):
+            return [l for l in lanes if (np.linalg.norm(l.center.points[:, :3] - xyz, axis=-1) <= dist).any()]
+
+        def get_traffic_light_status(self, lane_id, ts):
+            return tls.get(lane_id, -1.0)
+
+    c, s_ = np.cos(-world[2]), np.sin(-world[2])
+    tf = np.array([[c, -s_, 0.0], [s_, c, 0.0], [0.0, 0.0, 1.0]]) @ np.array([[1.0, 0.0, -world[0]], [0.0, 1.0, -world[1]], [0.0, 0.0, 1.0]])
+    map_cfg = C({"CENTER_SAMPLE_RATE": 1, "EDGE_SAMPLE_RATE": 4, "COLLATE_MODE": "lane", "MAX_LANE_POINTS": 20,
+                 "INCLUDE_TYPES": ["center", "right_edge", "left_edge"]})
+    vl = du._get_vectorized_lanes_from_vector_map(np.array([world[0], world[1], z]), tf, VecMap(), t0, map_cfg, 200, "waymo_train")
+    full = vl.vec_lanes[0]
+    out["vector_lane"] = full.numpy()
+    batch.extras["vector_lane"] = [full]
+    mp = fu.get_center_vec_init_map(batch, cfg)
+    out.update(map_input=mp.input.numpy(), map_mask=mp.mask.numpy(), map_pos=mp.position.numpy(), map_head=mp.heading.numpy())
+    np.savez_compressed(os.path.join(GOLD, f"ref_format_{scene}.npz"), **out)
+    print("ref_format written:", scene, {k: v.shape for k, v in out.items() if k in ("obs_input", "io_tgt", "vector_lane", "map_input", "prompt")},
+          "future frames", keys)
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     if len(sys.argv) > 2 and sys.argv[1] == "only":
@@ -442,6 +568,9 @@ if __name__ == "__main__":
         gen_pair_metric()
     elif len(sys.argv) > 1 and sys.argv[1] == "goal":
         gen_goal_heads()
+    elif len(sys.argv) > 1 and sys.argv[1] == "format":
+        gen_format("scene_1")
+        gen_format("scene_0")
     else:
         gen_pure()
         gen_full()
@@ -452,3 +581,5 @@ if __name__ == "__main__":
         gen_pair_metric()
         gen_world()
         gen_goal_heads()
+        gen_format("scene_1")
+        gen_format("scene_0")
