@@ -334,6 +334,23 @@ def main():
                                            "frac_of_f16_mfma_peak": fl_rep / (ms_chain_rep * 1e-3) / 1e12 / 2500.0},
                    "speedup_vs_replicated_batch": ms_tiled / ms_rep,
                    "world_frame_kernel_ms": ms_world}
+        # the headline's honest sibling: a stream of NEW batches (RolloutPipeline, throughput mode): every step uploads a fresh
+        # 8-scene batch from host arrays (ps_set_scene), captures and runs its rollout and reads traj / vel back
+        eng.set_replicas(1)
+        from prosim_amd.stream import RolloutPipeline
+        new_batches = [synth.baseline_scene(spec, args.config, seed=1000 + i, batch=S) for i in range(6)]
+        streaming = {"workload": f"stream of NEW {S}-scene batches (host arrays -> ps_set_scene -> rollout -> traj / vel read back), RolloutPipeline, "
+                                 "16 rows per workgroup from depth 2", "agent_steps_per_s_by_depth": {}, "ms_per_batch_by_depth": {}}
+        for depth in (1, 2, 3, 4):
+            with RolloutPipeline(spec, w, device=dev_index, depth=depth) as pipe:
+                for _ in pipe.run(new_batches[:depth]):
+                    pass
+                t_s = time.perf_counter()
+                n_b = sum(1 for _ in pipe.run(new_batches * 2))
+                dt_s = time.perf_counter() - t_s
+            streaming["agent_steps_per_s_by_depth"][str(depth)] = n_b * A * spec.max_steps / dt_s
+            streaming["ms_per_batch_by_depth"][str(depth)] = 1e3 * dt_s / n_b
+        streaming["agent_steps_per_s"] = max(streaming["agent_steps_per_s_by_depth"].values())
         fl_alg = algorithmic_flops_chain(A, float(ec[4]), float(ec[5]), spec.pol_layers)
         # per-destination degrees of the last replan's edge sets -> 16-edge tiles the edge phase walked
         eng.set_chain_rows(chain_rows)
@@ -351,13 +368,13 @@ def main():
         # HBM-side traffic of the launch comes from separate rocprofv3 --pmc passes (tools/gpu_round_profile.sh; counters
         # cannot be read from inside this process): offline, valid for the default workload only, stamped with its source
         traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", "r02_pmc_policy_chain.json")
+        pmc = os.path.join(ROOT, "profiles", "r03_pmc_policy_chain.json")
         if os.path.exists(pmc) and S == 8 and args.config == 2:
             with open(pmc) as f:
                 pj = json.load(f)
             if pj.get("chain_rows") == chain_rows:
                 traffic = pj["hbm_bytes_per_launch"]
-                traffic_src = {"file": "profiles/r02_pmc_policy_chain.json", "git": pj.get("git"), "measured": "offline rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), not in this run"}
+                traffic_src = {"file": "profiles/r03_pmc_policy_chain.json", "git": pj.get("git"), "measured": "offline rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), not in this run"}
         achieved = fl_alg / (ms_launch * 1e-3) / 1e12
         kern = (f"k_chain16<8, policy> (12 fused attention layers per launch, {chain_rows} rows per 8-wave workgroup, {n_wg} workgroups)" if c16
                 else f"k_attn_chain (policy: 12 fused attention layers per launch; {chain_rows or 2} rows per workgroup)")
@@ -373,7 +390,10 @@ def main():
                        "scenes_per_gpu": S, "rollouts_in_flight": n_fl, "chain_rows_per_workgroup": chain_rows,
                        "parallelism": f"scene-sharded x{world}, RCCL all-gather of the per-agent PairMotionPred sums; consecutive steps pipelined over "
                                       f"{n_fl} engine(s) per GPU"},
-            "roofline": {"bound": "mfma", "kernel": kern,
+            # bound: what the counters of the launch say (profiles/r03_*_pmc_chain16.txt: the VALU busy more than half of the SIMD
+            # cycles, the waves parked a third of theirs, MFMA 13 %, HBM < 5 %); peak / frac stay on the dense f16 MFMA yardstick
+            # that BASELINE.json's north_star names
+            "roofline": {"bound": "valu-issue/latency", "yardstick": "mfma", "kernel": kern,
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                          "traffic_source": traffic_src,
                          "note": "achieved = ALGORITHMIC FLOPs of the reference formulation per launch (SURVEY.md section 8(d): per-edge to_k_r / "
@@ -383,8 +403,8 @@ def main():
                                  "instruction; the PMC pass SQ_INSTS_VALU_MFMA_MOPS_F16 under profiles/ counts the same instructions).  "
                                  "A launch occupies `workgroups` of the 256 CUs and `rollouts_in_flight` launches overlap, so the per-launch "
                                  "rate understates the chip: chip_algorithmic_tflops = all policy launches of the timed region / its wall time.  "
-                                 "What bounds the launch: DESIGN.md section 4 (edge phase: fp32 VALU issue of the recomputed Fourier rows; "
-                                 "node phase: per-CU L1 fill rate of the weight fragments).",
+                                 "What bounds the launch: DESIGN.md section 4 (edge phase: fp32 VALU issue -- the recomputed Fourier rows are 58 % of it -- "
+                                 "and the dependent LDS / MFMA chain of a 16-edge tile at two waves per SIMD; node phase: per-CU L1 fill rate of the weight fragments).",
                          "algorithmic_flops_per_launch": fl_alg,
                          "executed_mfma_flops_per_launch": fl_mfma,
                          "executed_mfma_tflops": (fl_mfma / (ms_launch * 1e-3) / 1e12) if fl_mfma else None,
@@ -398,6 +418,9 @@ def main():
                                           f"{float(ev_ms.max()):.3f} ms); alone on the GPU the same launch takes launch_alone_ms",
                          "launch_alone_ms": ms_chain,
                          "workgroups": n_wg if c16 else None,
+                         "occupied_cus": min(n_wg, 256) if c16 else None,
+                         "chip_frac": fl_alg * spec.n_replans / (ms_per_step * 1e-3) / 1e12 / peak,
+                         "full_chip_launch_frac": fl_rep / (ms_chain_rep * 1e-3) / 1e12 / peak,
                          "edges_per_launch": {"a2p": float(ec[4]), "m2p": float(ec[5])}, "tiles16_per_layer_pair": tiles},
             "stage_ms": {"rollout_events": ms_roll, "encode_scene": stages[0], "generate_policy": stages[1], "replan_loop": stages[2]},
             "latency_mode": {"note": "ps_set_chain_rows(0): one rollout alone on the GPU", "ms_per_rollout": ms_roll_lat,
@@ -408,6 +431,7 @@ def main():
                              "agent_steps_per_s_pipelined": pipe1,   # key = rollouts in flight
                              "stage_ms": {"encode_scene": stages1[0], "generate_policy": stages1[1], "replan_loop": stages1[2]}},
             "replica_fanout": replica,
+            "streaming": streaming,
             "rollout_metrics": metrics,
         }
         if world == 1 and not args.no_cpu_baseline:

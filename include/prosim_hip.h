@@ -60,6 +60,9 @@ typedef struct ps_config {
    * dataset/motion_tag_utils.py:17-22) is among PROMPT.CONDITION.MOTION_TAG.USED_TAGS -> weight
    * "condition_transformers.policy_decoder.condition_encoders.v2v_tag.tag_encoder.<tag>" [2 * hidden].  0 in the demo. */
   int32_t v2v_tag_mask;
+  /* MODEL.POLICY.ACT_DECODER.TRAJ.PRED_GMM (act_decoder.py:26-27; 0 in the demo): state_dim 8 = x, y, h, (std1, std2, rho), xd, yd;
+   * the rollout then appends the velocity of columns 6:8 instead of 3:5 (traj_sam.py:337-340). */
+  int32_t pred_gmm;
 } ps_config;
 
 /* Create an engine and upload weights.  names[i] are reference state_dict keys
@@ -145,6 +148,12 @@ int ps_set_future_log(ps_engine* e, const float* fut_input, const uint8_t* fut_m
  * (TOP_K = 1: torch.topk of equal probabilities returns index 0).  The table survives until the next ps_set_scene.
  * With replicas (below) the table is [R, replicas, N]: every replica draws its own modes. */
 int ps_set_mode_choice(ps_engine* e, const int32_t* choice);
+/* MODEL.POLICY.ACT_DECODER.RANDOM_NOISE_STD (act_decoder.py:113-115: motion[..., :2] += randn_like(...) * std, before the
+ * cumulative sum, in every policy call): the reference's other source of replica diversity.  Like the mode pick, the draw
+ * does not depend on the model's output, so the caller draws the whole table -- with the reference's own torch.randn_like
+ * call, to replay its stream -- and hands it over before the rollout: noise [R, B (or replicas), N, motion_k, target_steps, 2]
+ * float32 in slot layout, ALREADY scaled by the std; NULL switches the noise off.  Survives until the next ps_set_scene. */
+int ps_set_action_noise(ps_engine* e, const float* noise);
 /* M replicas of ONE scene rolled out side by side -- parallel_rollout_batch / replica_batch_for_parallel_rollout
  * (rollout/gpu_utils.py:59-123, :179-228: scene_embs, policy_emds, prompt_encs, agent_trajs and fut_obs .repeat(M, ...) on
  * the batch dim, then one rollout_batch over the M-batch).  Call before ps_set_scene (B must be 1 there); it holds until

@@ -494,7 +494,7 @@ def condition_transform(Wt: W, spec: ModelSpec, cond: Optional[Dict], emd: T, pr
 # --------------------------------------------------------------------------- policy
 
 def policy_forward(Wt: W, spec: ModelSpec, scene: Dict, policy_emd: T, agent_type: T, policy_b: T,
-                   pos: T, head: T) -> Dict:
+                   pos: T, head: T, noise: Optional[T] = None) -> Dict:
     """Policy_RelPE_Temporal.forward -> PolicyNoRNN.forward -> AttnRelPE.attn_fuse +
     ActDecoder._compute_traj (policy/base.py:19, temporal_ar.py:75-92, act_decoder.py:239-283,
     :78-140).  policy_emd [A, D], agent_type [A] (1..3), policy_b [A] scene index, pos [A,2],
@@ -513,7 +513,7 @@ def policy_forward(Wt: W, spec: ModelSpec, scene: Dict, policy_emd: T, agent_typ
     for i in range(spec.pol_layers):
         xp = attention_layer(Wt, f"{pa}.a2p_attn_layers.{i}", spec, x_a, xp, ap_pe, ap_src, ap_dst, True)
         xp = attention_layer(Wt, f"{pa}.m2p_attn_layers.{i}", spec, x_m, xp, mp_pe, mp_src, mp_dst, True)
-    out = compute_traj(Wt, spec, xp, agent_type, policy_emd)
+    out = compute_traj(Wt, spec, xp, agent_type, policy_emd, noise)
     out["fused"] = xp
     out["edges"] = dict(a2p=int(ap_src.numel()), m2p=int(mp_src.numel()))
     return out
@@ -535,8 +535,9 @@ def cg_stacked(Wt: W, prefix: str, inp: T, context: T) -> Tuple[T, T]:
     return inp_, ctx_
 
 
-def compute_traj(Wt: W, spec: ModelSpec, pred_feat: T, agent_type: T, policy_emd: T) -> Dict:
-    """ActDecoder._compute_traj, anchor mode (act_decoder.py:78-140)."""
+def compute_traj(Wt: W, spec: ModelSpec, pred_feat: T, agent_type: T, policy_emd: T, noise: Optional[T] = None) -> Dict:
+    """ActDecoder._compute_traj, anchor mode (act_decoder.py:78-140).  ``noise`` [A, K, steps, 2]: RANDOM_NOISE_STD's draw,
+    already scaled (:113-115: added to the xy steps before the cumulative sum)."""
     pa = "policy.act_decoder"
     A = pred_feat.shape[0]
     K = spec.motion_k
@@ -547,6 +548,8 @@ def compute_traj(Wt: W, spec: ModelSpec, pred_feat: T, agent_type: T, policy_emd
     d = spec.hidden
     motion = mlp(Wt, f"{pa}.motion_head", [d, d, d // 2, spec.out_dim], pred_emd, True, False)
     motion = motion.view(A, K, spec.target_steps, spec.state_dim)
+    if noise is not None:
+        motion = torch.cat([motion[..., :2] + noise.to(motion.dtype), motion[..., 2:]], dim=-1)
     traj = motion[..., :2].cumsum(dim=-2)
     headp = wrap_angle(motion[..., 2:3].cumsum(dim=-2))
     motion_pred = torch.cat([traj, headp, motion[..., 3:]], dim=-1)
@@ -662,7 +665,8 @@ def rollout(w: Dict[str, np.ndarray], spec: ModelSpec, scene_in: Dict, dtype=tor
             if collect:
                 trace[f"obs_in_{ti}"] = f_in
         # decode_output -> policy (traj_sam.py:178-202, 441-525)
-        out = policy_forward(Wt, spec, scene, p_emd, p_type, pb, a_pos[prompt_mask], a_head[prompt_mask])
+        nz = tt(scene_in["action_noise"][ti])[prompt_mask] if scene_in.get("action_noise") is not None else None   # [R, B, N, K, S, 2]
+        out = policy_forward(Wt, spec, scene, p_emd, p_type, pb, a_pos[prompt_mask], a_head[prompt_mask], nz)
         motion_preds.append(out["motion_pred"])
         fused.append(out["fused"])
         step_edges.append(out["edges"])
@@ -681,7 +685,7 @@ def rollout(w: Dict[str, np.ndarray], spec: ModelSpec, scene_in: Dict, dtype=tor
         new_t = torch.zeros(B, N, spec.replan_freq, 4, dtype=dtype)
         new_t[prompt_mask] = fut
         new_v = torch.zeros(B, N, spec.replan_freq, 2, dtype=dtype)
-        new_v[prompt_mask] = batch_rotate_2d(pred[..., 3:5], lth)
+        new_v[prompt_mask] = batch_rotate_2d(pred[..., spec.vel_col:spec.vel_col + 2], lth)   # (6:8 with PRED_GMM, traj_sam.py:337-340)
         traj[:, :, last:last + spec.replan_freq] = new_t
         vel[:, :, last:last + spec.replan_freq] = new_v
         last += spec.replan_freq

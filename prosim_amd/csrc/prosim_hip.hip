@@ -122,6 +122,8 @@ struct ps_engine {
   DevBuf<float> d_xp, d_emd, d_xc, d_fused, d_obs_in, d_static_in, d_kv, d_kv_s2p, d_kv_m2p, d_kv_a2p;
   DevBuf<float> d_traj, d_vel, d_motion, d_reconst, d_goal_prob, d_goal_point, d_world;
   DevBuf<int> d_choice;                     // [R][A] motion mode each agent follows at each replan (ps_set_mode_choice; zeros = mode 0)
+  DevBuf<float> d_noise;                    // [R][A][K][target_steps][2] action noise (ps_set_action_noise), used while have_noise
+  bool have_noise = false;
   DevBuf<_Float16> d_kh, d_kh_s2p, d_kh_m2p, d_kh_a2p;   // split-fp16 k rows beside each kv buffer
   EdgeSet e_a2a, e_s2s, e_p2p, e_s2p, e_a2p, e_m2p, e_cnd;
   DevBuf<ChainStep> d_steps;
@@ -529,8 +531,8 @@ extern "C" int ps_create(const ps_config* cfg, int32_t n_tensors, const char* co
   if (!cfg || !out) return fail(PS_E_ARG, "null argument");
   if (cfg->hidden != D || cfg->heads != H || cfg->head_dim != DH)
     return fail(PS_E_ARG, "this build supports hidden=128, heads=8, head_dim=16 only");
-  if (cfg->hist_steps > 15 || cfg->obs_dim > 24 || cfg->map_dim > 24 || cfg->motion_k < 1 || cfg->motion_k > 16 || cfg->state_dim < 5 ||
-      cfg->target_steps * cfg->state_dim > 64 || cfg->map_pre_layers > 4 || cfg->obs_pre_layers > 4 ||
+  if (cfg->hist_steps > 15 || cfg->obs_dim > 24 || cfg->map_dim > 24 || cfg->motion_k < 1 || cfg->motion_k > 16 || cfg->state_dim != (cfg->pred_gmm ? 8 : 5) ||
+      cfg->target_steps * cfg->state_dim > 128 || cfg->map_pre_layers > 4 || cfg->obs_pre_layers > 4 ||
       cfg->map_mlp_layers - cfg->map_pre_layers > 4 || cfg->obs_mlp_layers - cfg->obs_pre_layers > 4)
     return fail(PS_E_ARG, "unsupported config (hist<=15, obs_dim<=24, map_dim<=24, 1<=motion_k<=16, steps*state<=64)");
   if (cfg->goal_pred_k < 0 || cfg->goal_pred_k > 64) return fail(PS_E_ARG, "goal_pred_k must be in 0..64");
@@ -598,14 +600,15 @@ extern "C" int ps_create(const ps_config* cfg, int32_t n_tensors, const char* co
     const float* w2 = b.get(mh + "6.weight", (int64_t)OUT * (D / 2));
     const float* b2 = b.get(mh + "6.bias", OUT);
     if (w2 && b2) {
-      std::vector<float> t((size_t)64 * 64, 0.f), bb(64, 0.f);
+      // (zero-padded to 128 output columns = 8 MFMA n-tiles: 50 with the demo's 10 x 5, 80 with PRED_GMM's 10 x 8)
+      std::vector<float> t((size_t)64 * 128, 0.f), bb(128, 0.f);
       for (int k = 0; k < 64; ++k)
-        for (int n = 0; n < OUT && n < 64; ++n) t[(size_t)k * 64 + n] = w2[(size_t)n * 64 + k];
-      for (int n = 0; n < OUT && n < 64; ++n) bb[n] = b2[n];
+        for (int n = 0; n < OUT && n < 128; ++n) t[(size_t)k * 128 + n] = w2[(size_t)n * 64 + k];
+      for (int n = 0; n < OUT && n < 128; ++n) bb[n] = b2[n];
       b.slot(&e->head.m2t, b.put(t));
-      std::vector<float> w2p((size_t)64 * 64, 0.f);   // torch layout [out 64 (zero rows past OUT)][in 64]
-      for (int n = 0; n < OUT && n < 64; ++n) std::copy(w2 + (size_t)n * 64, w2 + (size_t)(n + 1) * 64, w2p.begin() + (size_t)n * 64);
-      b.fragments_raw(&e->head.m2F, w2p.data(), 64, 64, 0, 64);
+      std::vector<float> w2p((size_t)128 * 64, 0.f);   // torch layout [out 128 (zero rows past OUT)][in 64]
+      for (int n = 0; n < OUT && n < 128; ++n) std::copy(w2 + (size_t)n * 64, w2 + (size_t)(n + 1) * 64, w2p.begin() + (size_t)n * 64);
+      b.fragments_raw(&e->head.m2F, w2p.data(), 128, 64, 0, 64);
       b.slot(&e->head.m2b, b.put(bb));
     }
   }
@@ -945,6 +948,7 @@ extern "C" int ps_set_scene(ps_engine* e, int32_t B, int32_t M, int32_t P, int32
       e->d_goal_point.ensure((size_t)A * 2 * std::max(1, c.goal_pred_k)))
     return fail(PS_E_HIP, "device allocation failed");
   HIPCHK(hipMemsetAsync(e->d_choice.p, 0, sizeof(int) * (size_t)R * A, st));   // mode 0 until ps_set_mode_choice
+  e->have_noise = false;                                                        // no action noise until ps_set_action_noise
   // ---- edge sets: capacities from worst-case degrees
   auto mn = [](int a, int b) { return a < b ? a : b; };
   const int tokS = e->maxA_scene + e->maxM_scene;
@@ -1361,6 +1365,35 @@ extern "C" int ps_set_mode_choice(ps_engine* e, const int32_t* choice) {
   // (the captured graph reads the table through its device pointer: no re-capture)
   HIPCHK(hipMemcpyAsync(e->d_choice.p, rows.data(), sizeof(int) * rows.size(), hipMemcpyHostToDevice, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
+  return PS_OK;
+}
+
+extern "C" int ps_set_action_noise(ps_engine* e, const float* noise) {
+  if (!e || !e->have_scene) return fail(PS_E_STATE, "ps_set_action_noise before ps_set_scene");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  const ps_config& c = e->cfg;
+  const int R = (c.max_steps + c.replan_freq - 1) / c.replan_freq, A = e->A;
+  const bool was = e->have_noise;
+  if (!noise) {
+    e->have_noise = false;
+    if (was) drop_graph(e);   // (the head launch carries the table pointer or NULL by value)
+    return PS_OK;
+  }
+  const size_t per = (size_t)c.motion_k * c.target_steps * 2;
+  std::vector<float> rows((size_t)R * A * per, 0.f);
+  const size_t slots = (size_t)std::max(e->B, e->replicas) * e->N;
+  for (int r = 0; r < R; ++r)
+    for (int i = 0; i < A; ++i) {
+      if (!e->is_policy_h[i]) continue;
+      const float* src = noise + ((size_t)r * slots + e->agent_slot[i]) * per;
+      std::copy(src, src + per, rows.begin() + ((size_t)r * A + i) * per);
+    }
+  const float* before = e->d_noise.p;
+  if (e->d_noise.ensure(rows.size())) return fail(PS_E_HIP, "device allocation failed");
+  HIPCHK(hipMemcpyAsync(e->d_noise.p, rows.data(), sizeof(float) * rows.size(), hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  e->have_noise = true;
+  if (!was || before != e->d_noise.p) drop_graph(e);
   return PS_OK;
 }
 
@@ -1937,7 +1970,9 @@ extern "C" int ps_policy_step(ps_engine* e, int32_t t_idx) {
     hipLaunchKernelGGL(k_policy_head_mfma, dim3((A + G - 1) / G), dim3(256), 0, st, e->head, (const float*)e->d_fused.p,
                        (const int*)e->d_agent_type.p, A, c.motion_k, c.target_steps, c.state_dim,
                        e->d_motion.p + (size_t)t_idx * A * c.motion_k * c.target_steps * c.state_dim,
-                       e->d_traj.p, e->d_vel.p, e->stride_steps, last, c.replan_freq, c.ln_eps, (const int*)(e->d_choice.p + (size_t)t_idx * A));
+                       e->d_traj.p, e->d_vel.p, e->stride_steps, last, c.replan_freq, c.ln_eps, (const int*)(e->d_choice.p + (size_t)t_idx * A),
+                       e->have_noise ? (const float*)(e->d_noise.p + (size_t)t_idx * A * c.motion_k * c.target_steps * 2) : (const float*)nullptr,
+                       c.pred_gmm ? 6 : 3);
   }
   HIPCHK(hipGetLastError());
   return PS_OK;
@@ -2558,7 +2593,8 @@ extern "C" int ps_policy_forward(ps_engine* e, int32_t n_scenes, int32_t Na, con
     for (size_t i = 0; i < (size_t)A * 16; ++i) unit[i * 4 + 3] = 1.f;
     (void)hipMemcpyAsync(d_traj.p, unit.data(), sizeof(float) * unit.size(), hipMemcpyHostToDevice, st);
     hipLaunchKernelGGL(k_policy_head_mfma, dim3((A + 16 / c.motion_k - 1) / (16 / c.motion_k)), dim3(256), 0, st, e->head, (const float*)d_x.p, (const int*)d_ptype.p, A,
-                       c.motion_k, c.target_steps, c.state_dim, d_motion.p, d_traj.p, d_vel.p, 16, 1, 0, c.ln_eps, (const int*)nullptr);
+                       c.motion_k, c.target_steps, c.state_dim, d_motion.p, d_traj.p, d_vel.p, 16, 1, 0, c.ln_eps, (const int*)nullptr,
+                       (const float*)nullptr, c.pred_gmm ? 6 : 3);
     if (hipStreamSynchronize(st) != hipSuccess) rc = fail(PS_E_HIP, "ps_policy_forward: kernel failure");
   }
   std::swap(e->d_tok_pos, d_pos);

@@ -943,7 +943,7 @@ struct HeadW {
   const float *cgWt[3], *cgb[3], *cglnw[3], *cglnb[3];    // CG_decode.CGs[i].MLP: Linear K-major [128][128] + LN
   const float *m0t, *m0b, *m0lnw, *m0lnb;                 // motion_head: 128 -> 128 (LN, ReLU)
   const float *m1t, *m1b, *m1lnw, *m1lnb;                 //              128 -> 64  (LN, ReLU), K-major [128][64]
-  const float *m2t, *m2b;                                 //              64 -> out, K-major [64][64] (zero-padded)
+  const float *m2t, *m2b;                                 //              64 -> out, K-major [64][128] (zero-padded)
   Mlp3W motion;                                           // (torch layout, kept for reference/tests)
   // the six Linears as split-fp16 MFMA B fragments (layout: pn_gemm); m2's output columns are zero-padded to 64
   const _Float16 *cgF[3], *m0F, *m1F, *m2F;
@@ -985,7 +985,8 @@ __global__ __launch_bounds__(256) void k_policy_head_mfma(HeadW w, const float* 
                                                          int n_agents, int motion_k, int steps, int sdim,
                                                          float* __restrict__ motion_pred, float* __restrict__ traj,
                                                          float* __restrict__ vel, int stride_steps, int last, int replan, float eps,
-                                                         const int* __restrict__ choice) {
+                                                         const int* __restrict__ choice, const float* __restrict__ noise /*[A][K][steps][2] or null*/,
+                                                         int vcol /*first velocity column: 3, or 6 with PRED_GMM*/) {
   __shared__ __attribute__((aligned(16))) _Float16 Ah[16 * PN_AS], Al[16 * PN_AS];
   __shared__ __attribute__((aligned(16))) float C[16 * PN_CS], ctx[16 * PN_CS], inp[16 * PN_CS], Y[16 * PN_CS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1061,7 +1062,8 @@ __global__ __launch_bounds__(256) void k_policy_head_mfma(HeadW w, const float* 
   }
   __syncthreads();
   pn_mma<1>(fr, Ah, Al, 4, C, PN_CS, 16, wave, lane, 4);
-  pn_load(fr, w.m2F, 2, wave, lane, 4);
+  const int nt2 = (steps * sdim + 15) / 16;   // n-tiles of the last Linear (<= 8)
+  pn_load(fr, w.m2F, 2, wave, lane, nt2);
   __syncthreads();
   if (tid < 64) {
     float a[16];
@@ -1074,7 +1076,7 @@ __global__ __launch_bounds__(256) void k_policy_head_mfma(HeadW w, const float* 
     }
   }
   __syncthreads();
-  pn_mma<1>(fr, Ah, Al, 2, C, PN_CS, 16, wave, lane, 4);
+  pn_mma<1>(fr, Ah, Al, 2, C, PN_CS, 16, wave, lane, nt2);
   __syncthreads();
   // cumsum over steps of (dx, dy, dtheta); wrap theta (act_decoder.py:117-121).  One thread per (row, step):
   // it re-adds the prefix in step order, so the sums round exactly like the sequential scan.
@@ -1084,9 +1086,12 @@ __global__ __launch_bounds__(256) void k_policy_head_mfma(HeadW w, const float* 
     if (ag >= n_agents) continue;
     const float* o = C + row * PN_CS;
     float cx = 0.f, cy = 0.f, ch = 0.f;
+    const float* nz = noise ? noise + ((size_t)ag * K + k) * steps * 2 : nullptr;
     for (int j = 0; j <= s; ++j) {
-      cx += o[j * sdim] + w.m2b[j * sdim];
-      cy += o[j * sdim + 1] + w.m2b[j * sdim + 1];
+      // (act_decoder.py:113-117: the noise joins the step before the cumulative sum)
+      const float dx = o[j * sdim] + w.m2b[j * sdim], dy = o[j * sdim + 1] + w.m2b[j * sdim + 1];
+      cx += nz ? dx + nz[2 * j] : dx;
+      cy += nz ? dy + nz[2 * j + 1] : dy;
       ch += o[j * sdim + 2] + w.m2b[j * sdim + 2];
     }
     const float hh = wrap_angle(ch);
@@ -1109,7 +1114,7 @@ __global__ __launch_bounds__(256) void k_policy_head_mfma(HeadW w, const float* 
       const float pth = wrap_angle(lth + hh);
       t[2] = sinf(pth);
       t[3] = cosf(pth);
-      const float vx = o[s * sdim + 3] + w.m2b[s * sdim + 3], vy = o[s * sdim + 4] + w.m2b[s * sdim + 4];
+      const float vx = o[s * sdim + vcol] + w.m2b[s * sdim + vcol], vy = o[s * sdim + vcol + 1] + w.m2b[s * sdim + vcol + 1];
       v[0] = vx * cl - vy * sl;
       v[1] = vy * cl + vx * sl;
     }

@@ -39,7 +39,7 @@ class PsConfig(C.Structure):
         ("dt", C.c_float), ("ln_eps", C.c_float),
         ("device", C.c_int32),
         ("enc_learnable_pe", C.c_int32), ("dec_learnable_pe", C.c_int32), ("pol_learnable_pe", C.c_int32),
-        ("pe_num_freq", C.c_int32), ("v2v_tag_mask", C.c_int32),
+        ("pe_num_freq", C.c_int32), ("v2v_tag_mask", C.c_int32), ("pred_gmm", C.c_int32),
     ]
 
 
@@ -73,6 +73,7 @@ def load_library():
     lib.ps_set_future_obs.argtypes = [vp, fp]
     lib.ps_set_future_log.argtypes = [vp, fp, u8p, fp, fp]
     lib.ps_set_mode_choice.argtypes = [vp, i32p]
+    lib.ps_set_action_noise.argtypes = [vp, fp]
     lib.ps_set_replicas.argtypes = [vp, C.c_int32]
     lib.ps_num_replicas.argtypes = [vp]
     lib.ps_num_replicas.restype = C.c_int32
@@ -112,7 +113,7 @@ def load_library():
     return lib
 
 
-EXPORTS = ["ps_create", "ps_destroy", "ps_last_error", "ps_set_scene", "ps_set_prompt", "ps_policy_forward", "ps_set_conditions", "ps_set_drag_points", "ps_set_pair_conditions", "ps_set_future_obs", "ps_set_future_log", "ps_set_mode_choice", "ps_set_replicas", "ps_num_replicas", "ps_world_trajs", "ps_num_policy_agents", "ps_policy_flags",
+EXPORTS = ["ps_create", "ps_destroy", "ps_last_error", "ps_set_scene", "ps_set_prompt", "ps_policy_forward", "ps_set_conditions", "ps_set_drag_points", "ps_set_pair_conditions", "ps_set_future_obs", "ps_set_future_log", "ps_set_mode_choice", "ps_set_action_noise", "ps_set_replicas", "ps_num_replicas", "ps_world_trajs", "ps_num_policy_agents", "ps_policy_flags",
            "ps_encode_scene", "ps_generate_policy", "ps_reset_rollout", "ps_policy_step", "ps_rollout", "ps_sync", "ps_stream", "ps_set_chain_rows", "ps_set_chain_impl", "ps_enable_policy_events", "ps_policy_event_times", "ps_update_obs", "ps_set_map_tokens", "ps_declare_agent_rows",
            "ps_set_state", "ps_get", "ps_rollout_metric", "ps_pair_metric", "ps_num_agents", "ps_num_map_tokens", "ps_time_rollout", "ps_time_policy_kernel",
            "ps_test_pointnet", "ps_test_fourier", "ps_test_wrap", "ps_test_attn", "ps_test_get_edges", "ps_test_stream"]
@@ -164,7 +165,7 @@ class Engine:
                        max_steps=spec.max_steps, dt=spec.dt, ln_eps=spec.ln_eps, device=device,
                        enc_learnable_pe=int(spec.enc_learnable_pe), dec_learnable_pe=int(spec.dec_learnable_pe),
                        pol_learnable_pe=int(spec.pol_learnable_pe), pe_num_freq=spec.pe_num_freq,
-                       v2v_tag_mask=sum(1 << V2V_TAGS.index(t) for t in spec.used_v2v_tags))
+                       v2v_tag_mask=sum(1 << V2V_TAGS.index(t) for t in spec.used_v2v_tags), pred_gmm=int(spec.pred_gmm))
         tensors = dict(weights)
         tensors.update(fourier_tables())
         names = sorted(tensors)
@@ -234,6 +235,8 @@ class Engine:
         self.set_conditions(s.get("cond"))
         if s.get("mode_choice") is not None:
             self.set_mode_choice(s["mode_choice"])
+        if s.get("action_noise") is not None:
+            self.set_action_noise(s["action_noise"])
         if s.get("fut_obs_input") is not None:
             fo = np.ascontiguousarray(s["fut_obs_input"], dtype=np.float32)
             if s.get("fut_obs_mask") is not None and s.get("fut_obs_pos") is not None and s.get("fut_obs_head") is not None:
@@ -276,6 +279,19 @@ class Engine:
         if c.shape != (self.spec.n_replans,) + tuple(self._shape):
             raise ValueError(f"mode choice must be [R, B, N] = {(self.spec.n_replans,) + tuple(self._shape)}, got {c.shape}")
         self._check(self.lib.ps_set_mode_choice(self.h, _i32(c)))
+
+    def set_action_noise(self, noise):
+        """``noise`` [R, B, N, K, target_steps, 2] float ([R, replicas, N, ...] with replicas), already scaled by
+        RANDOM_NOISE_STD: added to every predicted xy step of the policy agents before the cumulative sum
+        (act_decoder.py:113-115); None switches it off."""
+        if noise is None:
+            self._check(self.lib.ps_set_action_noise(self.h, None))
+            return
+        a = np.ascontiguousarray(noise, dtype=np.float32)
+        want = (self.spec.n_replans,) + tuple(self._shape) + (self.spec.motion_k, self.spec.target_steps, 2)
+        if a.shape != want:
+            raise ValueError(f"action noise must be {want}, got {a.shape}")
+        self._check(self.lib.ps_set_action_noise(self.h, _f(a)))
 
     def set_conditions(self, cond):
         """``cond`` = {'goal' | 'v_action_tag' | 'drag_point': {'input', 'mask', 'prompt_idx' [B,C,1] = prompt SLOT},

@@ -481,9 +481,134 @@ class ProSimHip:
         return out
 
     def init_agent_trajs(self, policy_agent_ids, batch) -> Dict[str, Any]:
-        """``ProSim.init_agent_trajs`` (:597-633): the trajectory state lives on the device (ps_reset_rollout)."""
+        """``ProSim.init_agent_trajs`` (:597-633).  The trajectory state lives on the device (ps_reset_rollout); the dict
+        that comes back mirrors the reference's (``traj`` [B, N, hist, 4], ``vel`` [B, N, hist, 2] from the history with NaN ->
+        0, ``init_pos``, ``init_heading``, ``last_step`` = hist) in policy-agent order, for callers that read it."""
         self.engine.reset_rollout()
-        return {task: dict(_hip_resident=True, last_step=0) for task in self.tasks}
+        sc, spec = self._shared.scene, self.spec
+        pslots = sc["_policy_slots"]
+        B, N, H = len(pslots), max(len(p) for p in pslots), spec.hist_steps
+        traj, vel = torch.zeros(B, N, H, 4), torch.zeros(B, N, H, 2)
+        pos, head = torch.zeros(B, N, 2), torch.zeros(B, N, 1)
+        obs = torch.nan_to_num(torch.from_numpy(np.asarray(sc["obs_input"], np.float32)), nan=0.0)
+        for b in range(B):
+            for j, n in enumerate(pslots[b]):
+                traj[b, j], vel[b, j] = obs[b, n, :, :4], obs[b, n, :, 4:6]
+                pos[b, j] = torch.from_numpy(np.asarray(sc["obs_pos"][b, n], np.float32))
+                head[b, j, 0] = float(np.asarray(sc["obs_head"]).reshape(len(pslots), -1)[b, n])
+        self._step_state = dict(next=0, out=None)
+        return {task: dict(traj=traj, vel=vel, init_pos=pos, init_heading=head, last_step=H, _hip_resident=True) for task in self.tasks}
+
+    # ---- one iteration of rollout_batch, call by call (traj_sam.py:159-172) ---------------------------------------------------
+    # The engine runs an iteration as ONE entry point (ps_policy_step: observation refresh, policy, trajectory append, all on
+    # the device).  The three methods below keep the reference's call sequence and return values: step_env reports the poses the
+    # iteration starts from, decode_output runs ps_policy_step and returns the policy's output, step_agent_traj mirrors the
+    # appended steps into ``agent_trajs`` -- and when it is handed a ``model_output`` other than the one decode_output returned
+    # (a caller that edits the prediction), it applies the reference's update (:311-347) on the host and pushes the state to
+    # the device (ps_set_state).
+    def _replan_index(self, t) -> int:
+        want = list(self.spec.all_t_indices)
+        if int(t) not in want:
+            raise ValueError(f"t = {t} is not a replan step of the spec ({want})")
+        return want.index(int(t))
+
+    def step_env(self, scene_embs, a_traj, batch, policy_agent_ids, t, all_t_indices):
+        """``ProSim.step_env`` (:205-274) -> (scene_embs, a_pos).  ``a_pos`` = the poses replan ``t`` starts from, by the
+        reference's formula (:212-216: init_pos + last xy, wrap(atan2(last sin, last cos) + init_heading)); the observation
+        refresh and the scene-token update of the replan (K12 + update_scene_emb) are the first part of ps_policy_step,
+        which ``decode_output`` runs for the same ``t``."""
+        from .spec import wrap_angle_np
+        i = self._replan_index(t)
+        st = getattr(self, "_step_state", None)
+        if st is None or i != st["next"]:
+            raise RuntimeError(f"step_env: replan {i} out of order (expected {None if st is None else st['next']}; call init_agent_trajs first)")
+        tr = a_traj["motion_pred"]
+        last = tr["traj"][..., tr["last_step"] - 1, :]
+        a_pos = {"position": tr["init_pos"] + last[..., :2],
+                 "heading": torch.from_numpy(wrap_angle_np((torch.atan2(last[..., 2], last[..., 3])[..., None] + tr["init_heading"]).numpy()))}
+        return scene_embs, a_pos
+
+    def decode_output(self, policy_emds, scene_embs, policy_agent_ids, batch, agent_positions=None, target_t=None, latent_state_dict=None):
+        """``ProSim.decode_output`` (:178-203): the policy's output for every policy agent at replan ``target_t`` --
+        ``{task: {'motion_pred' [P, K, S, D], 'motion_prob' [P, K], 'latent_state', 'pair_names'}}``, rows in the order of
+        ``pair_names`` (scene-major, prompt order; :478)."""
+        i = self._replan_index(target_t)
+        st = self._step_state
+        if i != st["next"]:
+            raise RuntimeError(f"decode_output: replan {i} out of order (expected {st['next']})")
+        eng, sc, spec = self.engine, self._shared.scene, self.spec
+        if i == 0:
+            self._last_mode_choice = self._draw_mode_choice()
+            eng.set_mode_choice(self._last_mode_choice)
+        eng.policy_step(i)
+        B, N = sc["prompt_mask"].shape
+        pslots = sc["_policy_slots"]
+        row_of_slot = {int(sl): r for r, sl in enumerate(eng._slots)}
+        order = [row_of_slot[b * N + n] for b in range(B) for n in pslots[b]]
+        mp = torch.from_numpy(eng.get("motion_pred")[i][order])
+        extras = batch.extras if hasattr(batch, "extras") else batch
+        ids = _g(extras["prompt"]["motion_pred"], "agent_ids") or [[str(j) for j in range(len(pslots[b]))] for b in range(B)]
+        names = [f"{b}-{ids[b][j]}-{int(target_t)}" for b in range(B) for j in range(len(pslots[b]))]
+        out = {"motion_pred": mp, "motion_prob": torch.ones(mp.shape[0], mp.shape[1]), "latent_state": None, "pair_names": names,
+               "reconst_pred": torch.from_numpy(eng.get("reconst_pred")[order])}
+        st["out"] = (i, mp)
+        return {"motion_pred": out}
+
+    def get_action(self, policy_emb, obs_data, map_data, pos_data, pair_names, latent_state=None):
+        """``ProSim.get_action`` (:635-640): the stateless policy call on explicit tokens."""
+        return self.policy(policy_emb, obs_data, map_data, pos_data, [n for group in pair_names for n in group], latent_state)
+
+    def step_agent_traj(self, a_traj, model_output, policy_agent_ids, t, mode="val"):
+        """``ProSim.step_agent_traj`` (:276-349): the next ``replan_freq`` steps appended to ``a_traj`` (in place, as there)."""
+        i = self._replan_index(t)
+        st, spec, eng, sc = self._step_state, self.spec, self.engine, self._shared.scene
+        if i != st["next"] or st["out"] is None or st["out"][0] != i:
+            raise RuntimeError(f"step_agent_traj: replan {i} has not been decoded (call decode_output first)")
+        tr = a_traj["motion_pred"]
+        S, H = spec.replan_freq, spec.hist_steps
+        pslots = sc["_policy_slots"]
+        B, N = sc["prompt_mask"].shape
+        mine = model_output["motion_pred"]["motion_pred"] is st["out"][1]
+        if mine:   # the device has appended these very steps: mirror them
+            traj, vel = eng.padded("traj"), eng.padded("vel")
+            new_t, new_v = torch.zeros(tr["traj"].shape[0], tr["traj"].shape[1], S, 4), torch.zeros(tr["traj"].shape[0], tr["traj"].shape[1], S, 2)
+            for b in range(len(pslots)):
+                for j, n in enumerate(pslots[b]):
+                    new_t[b, j] = torch.from_numpy(traj[b, n, i * S:(i + 1) * S])
+                    new_v[b, j] = torch.from_numpy(vel[b, n, i * S:(i + 1) * S])
+        else:      # an edited prediction: the reference's update on the host (:311-347), then the state goes to the device
+            from .spec import wrap_angle_np
+            mp = model_output["motion_pred"]["motion_pred"]
+            mc = self._last_mode_choice
+            new_t, new_v = torch.zeros(tr["traj"].shape[0], tr["traj"].shape[1], S, 4), torch.zeros(tr["traj"].shape[0], tr["traj"].shape[1], S, 2)
+            p = 0
+            for b in range(len(pslots)):
+                for j, n in enumerate(pslots[b]):
+                    k = 0 if mc is None else int(mc[i, b, n])
+                    pred = mp[p, k, :S]
+                    cur = tr["traj"][b, j, tr["last_step"] - 1]
+                    th = torch.atan2(cur[2], cur[3])
+                    c, s_ = torch.cos(th), torch.sin(th)
+                    xy = torch.stack([c * pred[:, 0] - s_ * pred[:, 1], s_ * pred[:, 0] + c * pred[:, 1]], -1) + cur[:2]
+                    ang = torch.from_numpy(wrap_angle_np((th + pred[:, 2]).numpy()))
+                    new_t[b, j] = torch.cat([xy, torch.sin(ang)[:, None], torch.cos(ang)[:, None]], -1)
+                    v = pred[:, 6:8] if spec.pred_gmm else pred[:, 3:5]
+                    new_v[b, j] = torch.stack([c * v[:, 0] - s_ * v[:, 1], s_ * v[:, 0] + c * v[:, 1]], -1)
+                    p += 1
+        tr["traj"] = torch.cat([tr["traj"], new_t], 2)
+        tr["vel"] = torch.cat([tr["vel"], new_v], 2)
+        tr["last_step"] += S
+        if not mine:
+            rows_t, rows_v = [], []
+            for b in range(len(pslots)):
+                for j in range(len(pslots[b])):
+                    rows_t.append(tr["traj"][b, j].numpy())
+                    rows_v.append(tr["vel"][b, j].numpy())
+            if len(rows_t) != eng.num_agents:
+                raise NotImplementedError("an edited prediction with log-replay agents in the scene: ps_set_state takes the policy agents only")
+            eng.set_state(np.stack(rows_t), np.stack(rows_v))
+        st["next"], st["out"] = i + 1, None
+        return a_traj
 
     def rollout_batch(self, batch, scene_embs, policy_emds, policy_agent_ids, agent_trajs, all_t_indices, mode="val"):
         """``ProSim.rollout_batch`` (:144-176): per replan step_env -> decode_output -> step_agent_traj = one
@@ -497,25 +622,35 @@ class ProSimHip:
             raise ValueError("rollout_batch needs the device-resident results of encode_scene / generate_policy / init_agent_trajs")
         self._last_mode_choice = self._draw_mode_choice()
         self.engine.set_mode_choice(self._last_mode_choice)
+        self._step_state = None
         for i in range(len(want)):
             self.engine.policy_step(i)
         extras = batch.extras if hasattr(batch, "extras") else batch
         return self._process_rollout(extras, self._shared.scene)
 
     def _draw_mode_choice(self):
-        """``ProSim.step_agent_traj`` (:300-313) with ROLLOUT.POLICY.TOP_K > 1: per replan torch.topk over the (all-ones)
-        motion_prob of the P pairs and a torch.randint among the top k -- the reference's own two calls, in its order, so
-        a seeded torch generator yields the reference's draws.  motion_prob does not depend on the model, so the whole
-        table is drawn before the rollout and handed to the engine (ps_set_mode_choice).  None for TOP_K = 1."""
+        """The rollout's random draws, made on the host with the reference's own calls in the reference's order, so that a
+        seeded torch generator yields the reference's stream: per replan ``torch.randn_like`` of the xy slice of the policy's
+        [P, K, S, D] output when RANDOM_NOISE_STD > 0 (act_decoder.py:113-115), then ``ProSim.step_agent_traj``'s
+        ``torch.topk`` over the (all-ones) motion_prob of the P pairs and ``torch.randint`` among the top k (:300-313).
+        Neither depends on the model's output, so both tables are drawn before the rollout and handed to the engine
+        (ps_set_mode_choice, ps_set_action_noise).  Returns the mode table ([R, B, N] or None when TOP_K = 1) and keeps the
+        noise table ([R, B, N, K, S, 2] or None) in ``self._last_action_noise`` (set on the engine here)."""
         spec, scene = self.spec, self._shared.scene
         k = min(spec.rollout_top_k, spec.motion_k)
-        if k <= 1:
+        std = float(spec.action_noise_std)
+        if k <= 1 and std <= 0:
+            self._last_action_noise = None
+            self.engine.set_action_noise(None)
             return None
         B, N = scene["prompt_mask"].shape
         pslots = scene["_policy_slots"]
         P = sum(len(p) for p in pslots)
         choice = np.zeros((spec.n_replans, B, N), np.int32)
+        noise = np.zeros((spec.n_replans, B, N, spec.motion_k, spec.target_steps, 2), np.float32) if std > 0 else None
         for t in range(spec.n_replans):
+            if std > 0:   # (the same call on a tensor of the same shape and strides: motion[..., :2] of a [P, K, S, D] view)
+                nz = (torch.randn_like(torch.empty(P, spec.motion_k, spec.target_steps, spec.state_dim)[..., :2]) * std).numpy()
             _, top = torch.topk(torch.ones(P, spec.motion_k), k, dim=1)
             rnd = torch.randint(0, k, (P,))
             pick = top[torch.arange(P), rnd].numpy()
@@ -523,8 +658,12 @@ class ProSimHip:
             for b in range(B):
                 for n in pslots[b]:
                     choice[t, b, n] = pick[i]
+                    if std > 0:
+                        noise[t, b, n] = nz[i]
                     i += 1
-        return choice
+        self._last_action_noise = noise
+        self.engine.set_action_noise(noise)
+        return choice if k > 1 else None
 
     def decode_batch(self, scene_embs, prompt_encs, batch, mode="val"):
         """``ProSim.decode_batch`` (:105-116)."""

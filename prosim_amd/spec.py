@@ -77,6 +77,14 @@ class ModelSpec:
     # DATASET.FORMAT.TARGET (no_text.yaml:186-190 + default.py:725-730): x,y,h,xd,yd
     target_steps: int = 10
     state_dim: int = 5
+    # MODEL.POLICY.ACT_DECODER.TRAJ.PRED_GMM (act_decoder.py:26-27; False in the demo, no_text.yaml:262): three more regressed
+    # channels per step (std1, std2, rho; read by the training loss only) -- state_dim 8, laid out x, y, h, (std1, std2, rho),
+    # xd, yd: the rollout then takes the velocity from columns 6:8 instead of 3:5 (traj_sam.py:337-340)
+    pred_gmm: bool = False
+    # MODEL.POLICY.ACT_DECODER.RANDOM_NOISE_STD (act_decoder.py:113-115; 0 in the demo): Gaussian noise on every predicted
+    # xy step before the cumulative sum -- what makes the M replicas of parallel_rollout_batch differ when TOP_K = K = 1.
+    # Drawn by the host with the reference's own torch.randn_like call (ProSimHip), handed to the engine as a table.
+    action_noise_std: float = 0.0
     motion_k: int = 1                  # MODEL.POLICY.ACT_DECODER.TRAJ.K
     rollout_top_k: int = 1             # ROLLOUT.POLICY.TOP_K (default.py:136): modes a rollout step draws from (host-side draw)
     num_agent_types: int = 3           # DATASET.USE_PED_CYCLIST -> anchors K*3 (act_decoder.py:66-68)
@@ -117,8 +125,25 @@ class ModelSpec:
     def out_dim(self) -> int:
         return self.target_steps * self.state_dim
 
+    @property
+    def vel_col(self) -> int:
+        """First of the two velocity columns of a predicted step (traj_sam.py:337-340)."""
+        return 6 if self.pred_gmm else 3
+
     def replace(self, **kw) -> "ModelSpec":
-        return dataclasses.replace(self, **kw)
+        out = dataclasses.replace(self, **kw)
+        if out.pred_gmm and out.state_dim != 8:
+            out = dataclasses.replace(out, state_dim=8)
+        if not out.pred_gmm and out.state_dim == 8:
+            raise ValueError("state_dim 8 is the PRED_GMM layout: set pred_gmm=True")
+        return out
+
+
+def wrap_angle_np(a):
+    """models/utils/geometry.py:13-17 on a float32 numpy array (torch '%' is floor-mod)."""
+    import numpy as np
+    a = np.asarray(a, np.float32)
+    return (-np.float32(np.pi) + np.mod(a + np.float32(np.pi), np.float32(2 * np.pi))).astype(np.float32)
 
 
 DEMO_SPEC = ModelSpec()

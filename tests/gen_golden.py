@@ -70,12 +70,16 @@ FULL_CASES = {
     "small_v2v_b2": ("small_v2v", dict(n_agents=16, n_polylines=128, batch=2, seed=15, goal=True, tags=True, v2v=True, ragged=True), 0),
     # *.ATTN.LEARNABLE_PE: the relative-PE rows of all six edge sets from learnable FourierEmbedding modules
     "small_lpe_b2": ("small_lpe", dict(n_agents=16, n_polylines=128, batch=2, seed=13, goal=True, tags=True, ragged=True), 0),
+    # TRAJ.PRED_GMM (state_dim 8: the rollout's velocity sits in columns 6:8) with RANDOM_NOISE_STD > 0 (act_decoder.py:113-115):
+    # the fixture keeps the reference's noise draws (action_noise) and the torch seed they came from
+    "small_noise_gmm_b2": ("small_noise_gmm", dict(n_agents=16, n_polylines=128, batch=2, seed=17, goal=True, ragged=True, replay=0.3), 0),
 }
 SPECS = {"small": SMALL_SPEC, "demo": DEMO_SPEC, "small_mlp": SMALL_SPEC.replace(obs_fusion="mlp"),
          "small_mlp_attn": SMALL_SPEC.replace(obs_fusion="mlp", obs_attn_update=True),
          "small_k3": SMALL_SPEC.replace(motion_k=3, rollout_top_k=3),
          "small_v2v": SMALL_SPEC.replace(used_v2v_tags=("Following", "Merging", "Overtaking")),
-         "small_lpe": SMALL_SPEC.replace(enc_learnable_pe=True, dec_learnable_pe=True, pol_learnable_pe=True, pe_num_freq=64)}
+         "small_lpe": SMALL_SPEC.replace(enc_learnable_pe=True, dec_learnable_pe=True, pol_learnable_pe=True, pe_num_freq=64),
+         "small_noise_gmm": SMALL_SPEC.replace(pred_gmm=True, action_noise_std=0.05)}
 TOPK_SEED = 777   # torch.manual_seed before a forward whose rollout draws modes
 
 
@@ -89,7 +93,8 @@ def ref_overrides(spec: ModelSpec):
             "PROMPT.CONDITION.MOTION_TAG.USED_TAGS", list(USED_V_ACTION_TAGS) + list(spec.used_v2v_tags),
             "MODEL.SCENE_ENCODER.ATTN.LEARNABLE_PE", spec.enc_learnable_pe, "MODEL.SCENE_ENCODER.ATTN.PE_NUM_FREQ", spec.pe_num_freq,
             "MODEL.DECODER.ATTN.LEARNABLE_PE", spec.dec_learnable_pe, "MODEL.DECODER.ATTN.PE_NUM_FREQ", spec.pe_num_freq,
-            "MODEL.POLICY.ACT_DECODER.ATTN.LEARNABLE_PE", spec.pol_learnable_pe, "MODEL.POLICY.ACT_DECODER.ATTN.PE_NUM_FREQ", spec.pe_num_freq]
+            "MODEL.POLICY.ACT_DECODER.ATTN.LEARNABLE_PE", spec.pol_learnable_pe, "MODEL.POLICY.ACT_DECODER.ATTN.PE_NUM_FREQ", spec.pe_num_freq,
+            "MODEL.POLICY.ACT_DECODER.TRAJ.PRED_GMM", spec.pred_gmm, "MODEL.POLICY.ACT_DECODER.RANDOM_NOISE_STD", spec.action_noise_std]
 
 
 def run_reference(spec, w, scene):
@@ -116,13 +121,26 @@ def run_reference(spec, w, scene):
             draws[-1][1] = r.clone()
         return r
 
+    noises = []
+    real_randn_like = torch.randn_like
+
+    def randn_like_rec(x, *a, **kw):   # (ActDecoder._compute_traj's draw: one per policy call)
+        r = real_randn_like(x, *a, **kw)
+        if x.dim() == 4 and x.shape[1:] == (spec.motion_k, spec.target_steps, 2):
+            noises.append(r.clone())
+        return r
+
     torch.manual_seed(TOPK_SEED)
-    torch.topk, torch.randint = topk_rec, randint_rec
+    torch.topk, torch.randint, torch.randn_like = topk_rec, randint_rec, randn_like_rec
+    import builtins
+    real_print = builtins.print
+    builtins.print = lambda *a, **k: None if (a and str(a[0]).startswith("WARNING: add random noise")) else real_print(*a, **k)
     try:
         with torch.no_grad():
             out = model(batch, "val")["motion_pred"]
     finally:
-        torch.topk, torch.randint = real_topk, real_randint
+        torch.topk, torch.randint, torch.randn_like = real_topk, real_randint, real_randn_like
+        builtins.print = real_print
     B, N = scene["prompt_mask"].shape
     R = spec.n_replans * spec.replan_freq
     traj = np.zeros((B, N, R, 4), np.float32)
@@ -140,6 +158,13 @@ def run_reference(spec, w, scene):
         for t, (top, rnd) in enumerate(draws):
             choice[t][pm] = top[torch.arange(top.shape[0]), rnd].numpy()     # pairs come in (scene, policy agent) order
         res["mode_choice"] = choice
+    if spec.action_noise_std > 0:
+        assert len(noises) == spec.n_replans
+        pm = scene["prompt_mask"].astype(bool)
+        table = np.zeros((spec.n_replans, B, N, spec.motion_k, spec.target_steps, 2), np.float32)
+        for t, nz in enumerate(noises):
+            table[t][pm] = (nz * spec.action_noise_std).numpy()                # pairs come in (scene, policy agent) order
+        res["action_noise"] = table
     return res
 
 
@@ -151,6 +176,8 @@ def gen_full():
         ref = run_reference(spec, w, scene)
         if "mode_choice" in ref:
             scene = dict(scene, mode_choice=ref["mode_choice"])
+        if "action_noise" in ref:
+            scene = dict(scene, action_noise=ref["action_noise"])
         with torch.no_grad():
             o = orc.rollout(w, spec, scene)
             o64 = orc.rollout(w, spec, scene, dtype=torch.float64)
@@ -172,8 +199,9 @@ def gen_full():
                             traj=ref["traj"], vel=ref["vel"], motion_pred=ref["motion_pred"],
                             reconst_pred=ref["reconst_pred"][:A],
                             fp32_floor=np.array([floor["traj"], floor["vel"], floor["motion_pred"]]),
-                            scene_digest=np.array(digest({k: v for k, v in scene.items() if k != "mode_choice"})), weight_digest=np.array(digest(w)),
+                            scene_digest=np.array(digest({k: v for k, v in scene.items() if k not in ("mode_choice", "action_noise")})), weight_digest=np.array(digest(w)),
                             **({"mode_choice": ref["mode_choice"], "torch_seed": np.array(TOPK_SEED)} if "mode_choice" in ref else {}),
+                            **({"action_noise": ref["action_noise"], "torch_seed": np.array(TOPK_SEED)} if "action_noise" in ref else {}),
                             label=np.array("reference Python + builder stand-ins for torch_cluster/torch_geometric"))
 
 

@@ -154,6 +154,8 @@ def test_rollout_vs_reference_fixture(name):
     assert digest(scene) == str(g["scene_digest"]) and digest(w) == str(g["weight_digest"])
     if "mode_choice" in g.files:      # TOP_K > 1: the reference's own mode draws (ps_set_mode_choice)
         scene["mode_choice"] = g["mode_choice"]
+    if "action_noise" in g.files:     # RANDOM_NOISE_STD > 0: the reference's own noise draws, replayed
+        scene["action_noise"] = g["action_noise"]
     eng = Engine(spec, w)
     eng.set_scene(scene)
     eng.rollout()

@@ -75,6 +75,8 @@ def test_rollout_ref_standins(name):
     assert digest(scene) == str(g["scene_digest"]) and digest(w) == str(g["weight_digest"])
     if "mode_choice" in g.files:      # TOP_K > 1: the reference's own mode draws, replayed
         scene["mode_choice"] = g["mode_choice"]
+    if "action_noise" in g.files:     # RANDOM_NOISE_STD > 0: the reference's own noise draws, replayed
+        scene["action_noise"] = g["action_noise"]
     with torch.no_grad():
         o = orc.rollout(w, spec, scene)
     A = int(scene["prompt_mask"].sum())
