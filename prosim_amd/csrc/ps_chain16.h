@@ -689,35 +689,7 @@ __device__ __noinline__ void c16_node_phase(const ChainStep* __restrict__ post, 
       __syncthreads();
       gemm16<4, Ring, NWV>(R, P0h, P0l, ND_AS, w.Fqsg + (size_t)8 * 4 * 1024, 16, Cw, ND_CW, wave, lane);
       frag_prefetch<4, Ring, NWV>(R, w.Fga, 8, wave, lane);
-      __syncthreads();
-      C16_MARK(16);
-      float4 in_av0 = make_float4(0.f, 0.f, 0.f, 0.f), in_av1 = in_av0, in_g0 = in_av0, in_g1 = in_av0, in_s0 = in_av0, in_s1 = in_av0;
-      float in_l = 0.f;
-      if (live) {
-        const float* cs_ = Cw + er * ND_CW + ec;
-        in_s0 = make_float4(cs_[0] + sp[SP_BS + ec], cs_[1] + sp[SP_BS + ec + 1], cs_[2] + sp[SP_BS + ec + 2], cs_[3] + sp[SP_BS + ec + 3]);
-        in_s1 = make_float4(cs_[4] + sp[SP_BS + ec + 4], cs_[5] + sp[SP_BS + ec + 5], cs_[6] + sp[SP_BS + ec + 6], cs_[7] + sp[SP_BS + ec + 7]);
-        in_g0 = make_float4(cs_[128] + sp[SP_BG + ec], cs_[129] + sp[SP_BG + ec + 1], cs_[130] + sp[SP_BG + ec + 2], cs_[131] + sp[SP_BG + ec + 3]);
-        in_g1 = make_float4(cs_[132] + sp[SP_BG + ec + 4], cs_[133] + sp[SP_BG + ec + 5], cs_[134] + sp[SP_BG + ec + 6], cs_[135] + sp[SP_BG + ec + 7]);
-        const int hd = ec >> 4;
-        if (W == 1) {
-          in_l = QA[er * C16_QSL + hd * C16_QH + 96];
-          in_av0 = *reinterpret_cast<const float4*>(AG + er * ND_XS + ec); in_av1 = *reinterpret_cast<const float4*>(AG + er * ND_XS + ec + 4);
-        } else {   // merge the W partial softmax sums of the row (head ec >> 4): common maximum, rescale, add
-          float mm = -INFINITY;
-          for (int p = 0; p < W; ++p) mm = fmaxf(mm, QA[(er * W + p) * C16_QSL + hd * C16_QH + 97]);
-          for (int p = 0; p < W; ++p) {
-            const int slot = er * W + p;
-            const float mp = QA[slot * C16_QSL + hd * C16_QH + 97];
-            const float sc = (mp == -INFINITY) ? 0.f : exp2f(mp - mm);
-            in_l = fmaf(QA[slot * C16_QSL + hd * C16_QH + 96], sc, in_l);
-            const float* avp = AG + (8 + slot) * ND_XS + ec;
-            const float4 a0 = *reinterpret_cast<const float4*>(avp), a1 = *reinterpret_cast<const float4*>(avp + 4);
-            in_av0.x = fmaf(a0.x, sc, in_av0.x); in_av0.y = fmaf(a0.y, sc, in_av0.y); in_av0.z = fmaf(a0.z, sc, in_av0.z); in_av0.w = fmaf(a0.w, sc, in_av0.w);
-            in_av1.x = fmaf(a1.x, sc, in_av1.x); in_av1.y = fmaf(a1.y, sc, in_av1.y); in_av1.z = fmaf(a1.z, sc, in_av1.z); in_av1.w = fmaf(a1.w, sc, in_av1.w);
-          }
-        }
-      }
+      // (no barrier here: the fold below reads the edge phase's sums and writes C, neither of which this GEMM touches)
       {   // fold: C[row][16h + d] = sum_c a_r[row][h][c] * Wvr_g3[c][16h + d]; one head at a time, 8 / NWV heads per wave
 #pragma unroll 1
         for (int t = 0; t < 8 / NWV; ++t) {
@@ -774,6 +746,34 @@ __device__ __noinline__ void c16_node_phase(const ChainStep* __restrict__ post, 
         }
       }
       __syncthreads();
+      C16_MARK(16);
+      float4 in_av0 = make_float4(0.f, 0.f, 0.f, 0.f), in_av1 = in_av0, in_g0 = in_av0, in_g1 = in_av0, in_s0 = in_av0, in_s1 = in_av0;
+      float in_l = 0.f;
+      if (live) {
+        const float* cs_ = Cw + er * ND_CW + ec;
+        in_s0 = make_float4(cs_[0] + sp[SP_BS + ec], cs_[1] + sp[SP_BS + ec + 1], cs_[2] + sp[SP_BS + ec + 2], cs_[3] + sp[SP_BS + ec + 3]);
+        in_s1 = make_float4(cs_[4] + sp[SP_BS + ec + 4], cs_[5] + sp[SP_BS + ec + 5], cs_[6] + sp[SP_BS + ec + 6], cs_[7] + sp[SP_BS + ec + 7]);
+        in_g0 = make_float4(cs_[128] + sp[SP_BG + ec], cs_[129] + sp[SP_BG + ec + 1], cs_[130] + sp[SP_BG + ec + 2], cs_[131] + sp[SP_BG + ec + 3]);
+        in_g1 = make_float4(cs_[132] + sp[SP_BG + ec + 4], cs_[133] + sp[SP_BG + ec + 5], cs_[134] + sp[SP_BG + ec + 6], cs_[135] + sp[SP_BG + ec + 7]);
+        const int hd = ec >> 4;
+        if (W == 1) {
+          in_l = QA[er * C16_QSL + hd * C16_QH + 96];
+          in_av0 = *reinterpret_cast<const float4*>(AG + er * ND_XS + ec); in_av1 = *reinterpret_cast<const float4*>(AG + er * ND_XS + ec + 4);
+        } else {   // merge the W partial softmax sums of the row (head ec >> 4): common maximum, rescale, add
+          float mm = -INFINITY;
+          for (int p = 0; p < W; ++p) mm = fmaxf(mm, QA[(er * W + p) * C16_QSL + hd * C16_QH + 97]);
+          for (int p = 0; p < W; ++p) {
+            const int slot = er * W + p;
+            const float mp = QA[slot * C16_QSL + hd * C16_QH + 97];
+            const float sc = (mp == -INFINITY) ? 0.f : exp2f(mp - mm);
+            in_l = fmaf(QA[slot * C16_QSL + hd * C16_QH + 96], sc, in_l);
+            const float* avp = AG + (8 + slot) * ND_XS + ec;
+            const float4 a0 = *reinterpret_cast<const float4*>(avp), a1 = *reinterpret_cast<const float4*>(avp + 4);
+            in_av0.x = fmaf(a0.x, sc, in_av0.x); in_av0.y = fmaf(a0.y, sc, in_av0.y); in_av0.z = fmaf(a0.z, sc, in_av0.z); in_av0.w = fmaf(a0.w, sc, in_av0.w);
+            in_av1.x = fmaf(a1.x, sc, in_av1.x); in_av1.y = fmaf(a1.y, sc, in_av1.y); in_av1.z = fmaf(a1.z, sc, in_av1.z); in_av1.w = fmaf(a1.w, sc, in_av1.w);
+          }
+        }
+      }
       float agg[8];
       if (epi) {   // agg = (a_v + fold + l * vb) / (l + 1e-16)   (:89, :100)
         const float l = in_l;

@@ -579,6 +579,32 @@ def gen_format(scene: str = "scene_1", t0: int = 10):
           "future frames", keys)
 
 
+def oracle_cache_workloads():
+    """(key, spec, weights, scene, collect, floor, slim) of every BASELINE-size oracle run the -m gpu suite compares against."""
+    out = []
+    spec = DEMO_SPEC
+    w = weights.init_weights(spec, 0)
+    parts = [synth.baseline_scene(spec, 2, seed=i, batch=1) for i in range(8)]
+    scene = {k: (np.concatenate([p[k] for p in parts]) if not isinstance(parts[0][k], dict) else
+                 {ck: {f: np.concatenate([p[k][ck][f] for p in parts]) for f in parts[0][k][ck]} for ck in parts[0][k]}) for k in parts[0]}
+    out.append(("bench_workload", spec, w, scene, False, True, True))
+    for cfg_idx, batch, seed in [(1, None, 0), (2, None, 0), (3, 2, 0), (3, 2, 1), (4, None, 0)]:
+        out.append((f"baseline_cfg{cfg_idx}_b{batch}_s{seed}", spec, w, synth.baseline_scene(spec, cfg_idx, seed=seed, batch=batch), True, False, False))
+    for cfg_idx in (1, 2, 4):
+        kw = synth.BASELINE_CONFIGS[cfg_idx]
+        cap = kw["n_agents"] + kw["n_polylines"]
+        sp = DEMO_SPEC.replace(dec_max_neigh=cap, pol_max_neigh=max(DEMO_SPEC.pol_max_neigh, min(cap, 2047)))
+        out.append((f"no_truncation_cfg{cfg_idx}", sp, weights.init_weights(sp, 0), synth.baseline_scene(sp, cfg_idx, seed=0), False, False, True))
+    return out
+
+
+def gen_oracle_cache():
+    from oracle_cache import oracle64
+    for key, spec, w, scene, collect, floor, slim in oracle_cache_workloads():
+        o = oracle64(key, spec, w, scene, collect=collect, floor=floor, write=True, slim=slim)
+        print("oracle cache written:", key, tuple(o["traj"].shape))
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     if len(sys.argv) > 2 and sys.argv[1] == "only":
@@ -596,6 +622,8 @@ if __name__ == "__main__":
         gen_pair_metric()
     elif len(sys.argv) > 1 and sys.argv[1] == "goal":
         gen_goal_heads()
+    elif len(sys.argv) > 1 and sys.argv[1] == "oracle_cache":
+        gen_oracle_cache()
     elif len(sys.argv) > 1 and sys.argv[1] == "format":
         gen_format("scene_1")
         gen_format("scene_0")

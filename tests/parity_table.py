@@ -1,5 +1,5 @@
-"""Closed-loop parity numbers, collected by the -m gpu tests and written as ONE JSON table: gpurun_out/r02_parity.json on
-the GPU box (merged back by gpurun), copied to profiles/r02_parity.json for the record.  Per entry: replan-0 max error
+"""Closed-loop parity numbers, collected by the -m gpu tests and written as ONE JSON table: gpurun_out/r03_parity.json on
+the GPU box (merged back by gpurun), copied to profiles/r03_parity.json for the record.  Per entry: replan-0 max error
 (open loop), per-agent closed-loop max error of the trajectories: median / 99th percentile / max, the fraction of agents
 within 1e-4, and -- where the test computed it -- the fp32 floor (fp32 oracle against the fp64 oracle on the same scene)."""
 import json
@@ -14,14 +14,40 @@ _ROWS = {}
 def per_agent(err_per_agent: np.ndarray) -> dict:
     d = np.asarray(err_per_agent, np.float64)
     return dict(agents=int(d.size), median=float(np.median(d)), p99=float(np.percentile(d, 99)), max=float(d.max()),
-                within_1e4=float((d < 1e-4).mean()))
+                within_1e4=float((d < 1e-4).mean()), outside_1e4=[int(i) for i in np.nonzero(d >= 1e-4)[0]])
+
+
+# Agents known to sit behind a +-pi cut of the reference's math on a given workload (DESIGN.md "branch cuts": an fp32 run -- the
+# reference's own included -- lands on the other side of one wrap_angle / atan2 discontinuity and stays ~1e-3 away for the rest
+# of that agent's rollout).  The closed-loop gates allow THESE agents outside the 1e-4 band and fail when a new one leaves it.
+KNOWN_CUTS = os.path.join(ROOT, "tests", "golden", "known_cut_agents.json")
+
+
+def known_cut_agents(workload: str) -> set:
+    if not os.path.exists(KNOWN_CUTS):
+        return set()
+    with open(KNOWN_CUTS) as f:
+        return set(json.load(f).get(workload, []))
+
+
+def closed_loop_gate(workload: str, d: np.ndarray, tol: float = 1e-4):
+    """The closed-loop bar at what is measured: >= 99.5 % of the agents within 1e-4, median below
+    2e-5 on the timed workload (3e-5 elsewhere), nobody beyond 2e-3, and every agent outside the band is on the committed list of that workload's cut agents."""
+    d = np.asarray(d, np.float64)
+    outside = set(int(i) for i in np.nonzero(d >= tol)[0])
+    new = outside - known_cut_agents(workload)
+    assert not new, f"{workload}: agents {sorted(new)} left the {tol:g} band (errors {[float(d[i]) for i in sorted(new)]}); known cut agents: {sorted(known_cut_agents(workload))}"
+    assert (d < tol).mean() >= 0.995 or d.size < 200 and len(outside) <= 1, (workload, float((d < tol).mean()))
+    # median: 2e-5 on the timed workload (measured 1.5e-5); the 64-agent config sits at 2.5e-5 (its fp32 oracle: 2.4e-5)
+    med_bar = 2e-5 if workload.startswith("bench_workload") else 3e-5
+    assert np.median(d) < med_bar and d.max() < 2e-3, (workload, float(np.median(d)), float(d.max()))
 
 
 def record(name: str, **fields):
     _ROWS[name] = fields
     out_dir = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out_dir, exist_ok=True)
-    path = os.path.join(out_dir, "r02_parity.json")
+    path = os.path.join(out_dir, "r03_parity.json")
     table = {}
     if os.path.exists(path):
         try:
