@@ -210,8 +210,10 @@ int ps_set_map_tokens(ps_engine* e, const float* tokens, int64_t count);
  * Results do not depend on it beyond fp32 summation order. */
 int ps_set_chain_rows(ps_engine* e, int32_t rows);
 /* Which fused-chain kernel runs the policy layers: 0 (default) = by mode as above, 1 = k_attn_chain always, 2 = k_chain16
- * always.  Both stay in the library: each is the other's cross-check in the parity tests.  Resets ps_set_chain_rows to 0
- * and invalidates the encoded / generated stages. */
+ * always, 3 = k_chain16 always AND for the scene encoder's s2s layers (one k | v projection + one-step chain per layer
+ * instead of the split k_node / k_edge_small launches: faster, another fp32 evaluation order of the scene tokens).  Both
+ * kernels stay in the library: each is the other's cross-check in the parity tests.  Resets ps_set_chain_rows to 0 and
+ * invalidates the encoded / generated stages. */
 int ps_set_chain_impl(ps_engine* e, int32_t impl);
 /* The engine's hipStream_t (every entry point enqueues on it), so a host can order its own streams against the
  * engine with events instead of ps_sync -- bench.py overlaps the RCCL metric gather of rollout k with rollout k+1. */

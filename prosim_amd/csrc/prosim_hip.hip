@@ -169,7 +169,7 @@ struct ps_engine {
   hipGraph_t graph = nullptr;
   hipGraphExec_t graph_exec = nullptr;
   int chain_rows = 0;   // ps_set_chain_rows: 0 = latency-optimal choice, else rows per workgroup of the fused attention launches
-  int chain_impl = 0;   // ps_set_chain_impl: 0 = by mode (k_chain16 in throughput mode: chain_rows >= 8; k_attn_chain otherwise), 1 = k_attn_chain, 2 = k_chain16
+  int chain_impl = 0;   // ps_set_chain_impl: 0 = by mode (k_chain16 in throughput mode: chain_rows >= 8; k_attn_chain otherwise), 1 = k_attn_chain, 2 = k_chain16, 3 = k_chain16 + the encoder's s2s layers on it
   bool graph_ok = false;
   bool use_graph = true;
   // ps_enable_policy_events: an event pair around every policy-chain launch of a rollout, recorded on the engine's stream
@@ -1591,9 +1591,9 @@ void launch_geo(ps_engine* e, const PeArgs* a, int nsets, bool raw = false) {
   for (int i = 0; i < nsets; ++i) {
     EdgeSet& es = *a[i].es;
     gs.s[i] = GeoSet{es.esrc.p, es.edst.p, es.eoff.p, es.nq, a[i].src_ori, a[i].dst_pos, a[i].dst_ori, es.geo.p};
-    grid = std::max(grid, std::min<size_t>(2048, es.cap_edges / 256 + 1));
+    grid = std::max(grid, std::min<size_t>(4096, es.cap_edges / GEO_THREADS + 1));
   }
-  hipLaunchKernelGGL(k_edge_geo, dim3((unsigned)grid, nsets), dim3(256), 0, e->stream, gs, (const float*)e->d_tok_pos.p, e->div32, e->cfg.ln_eps, raw ? 1 : 0);
+  hipLaunchKernelGGL(k_edge_geo, dim3((unsigned)grid, nsets), dim3(GEO_THREADS), GEO_LDS_BYTES, e->stream, gs, (const float*)e->d_tok_pos.p, e->div32, e->cfg.ln_eps, raw ? 1 : 0);
 }
 
 // the learnable rel-PE rows of one edge set (after launch_geo made its geometry records): both operand images, KR = 4
@@ -1613,7 +1613,7 @@ void launch_pe_learn(ps_engine* e, EdgeSet& es, const PeLearnW& w) {
 // records inside the kernel: it reads the operand images the edge-MLP kernel made, on k_attn_chain)
 bool use_c16(const ps_engine* e, int Nd, int part) {
   if (e->pe_on[part]) return false;
-  return e->chain_impl == 2 || (e->chain_impl == 0 && (e->chain_rows >= 8 || (e->chain_rows == 0 && Nd >= 1024)));
+  return e->chain_impl >= 2 || (e->chain_impl == 0 && (e->chain_rows >= 8 || (e->chain_rows == 0 && Nd >= 1024)));
 }
 int chain16_rows(ps_engine* e, int Nd) {
   static const int env_rows = getenv("PS_C16_ROWS") ? atoi(getenv("PS_C16_ROWS")) : 0;   // experiments only
@@ -1741,6 +1741,12 @@ extern "C" int ps_encode_scene(ps_engine* e) {
   // knn graphs (attn_fusion.py:107-109) + rel-PE (:111-112).  Agent rows that only enter the scene with a later fut_obs
   // frame are no tokens yet: not a candidate of any query (their own rows are computed and ignored).
   const int* live0 = e->have_dead0 ? (const int*)e->d_live0.p : nullptr;
+  // the s2s layers as one-step k_chain16 launches (k | v projection + chain) instead of the split path: in throughput mode
+  // (ps_set_chain_impl 3 -- NOT the default: 9 % more throughput on the benchmark workload (22.4 against 20.4 M agent-steps/s),
+  // but another fp32 evaluation of the scene tokens than the split path's, and on that workload it lands six agents of one
+  // scene on the other side of a +-pi cut; the default keeps the path whose parity table holds 1024 / 1024)
+  static const int env_s2s = getenv("PS_S2S_C16") ? atoi(getenv("PS_S2S_C16")) : -1;   // experiments only: 0 / 1 force
+  const bool s2s_c16 = !e->pe_on[0] && use_c16(e, Mv + Ap, 0) && (env_s2s >= 0 ? env_s2s != 0 : e->chain_impl == 3);
   {
     CandSet ca{e->d_tok_pos.p, e->d_r_agent.p, nullptr};
     hipLaunchKernelGGL(k_knn, dim3((Ap + 3) / 4), dim3(256), 0, st, ca, (const float*)(e->d_tok_pos.p + 2 * (size_t)Mv),
@@ -1757,11 +1763,14 @@ extern "C" int ps_encode_scene(ps_engine* e) {
       launch_geo(e, pe, 2, true);
       launch_pe_learn(e, e->e_a2a, e->pe_learn[0]);
       launch_pe_learn(e, e->e_s2s, e->pe_learn[1]);
-    } else if (use_c16(e, Ap, 0)) {   // the a2a layers run on k_chain16 (geometry records), the s2s layers keep the operand images
-      launch_geo(e, &pe[0], 1);
-      launch_relpe(e, &pe[1], 1);
-    } else {
-      launch_relpe(e, pe, 2);
+    } else {   // per set: geometry records for the layers that run on k_chain16, operand images for the others
+      const bool ga = use_c16(e, Ap, 0);
+      if (ga && s2s_c16) launch_geo(e, pe, 2);
+      else if (!ga && !s2s_c16) launch_relpe(e, pe, 2);
+      else {
+        if (ga) launch_geo(e, &pe[0], 1); else launch_relpe(e, &pe[0], 1);
+        if (s2s_c16) launch_geo(e, &pe[1], 1); else launch_relpe(e, &pe[1], 1);
+      }
     }
   }
   // 6 x (a2a on the agent rows in place, s2s on all rows)  (attn_fusion.py:117-119).  kv is indexed by
@@ -1773,7 +1782,10 @@ extern "C" int ps_encode_scene(ps_engine* e) {
     if (use_c16(e, Ap, 0)) {
       if (launch_chain16(e, tok + (size_t)Mv * D, Ap, e->d_steps.p + e->step_a2a + i, 1, false, nullptr, false)) return PS_E_HIP;
     } else if (launch_chain(e, tok + (size_t)Mv * D, Ap, e->step_a2a + i, 1, e->e_a2a.maxdeg, false, nullptr, 0, 0, nullptr, xcd_on(1, false))) return PS_E_HIP;
-    if (split_s2s) {
+    if (s2s_c16) {
+      launch_kv(e, tok, Mv + Ap, e->L_s2s + i, 1, e->d_kv.p, e->d_kh.p, 0);
+      if (launch_chain16(e, tok, Mv + Ap, e->d_steps.p + e->step_s2s + i, 1, false, nullptr, false)) return PS_E_HIP;
+    } else if (split_s2s) {
       // split layer: node work as 16-row MFMA GEMMs (k_node; its PRE half also makes the rows'
       // k | v, they are this self-attention layer's sources), the 32-neighbour edge phase one wave per token
       const ChainStep* stp = e->d_steps.p + e->step_s2s + i;
@@ -2116,7 +2128,7 @@ extern "C" int ps_set_chain_rows(ps_engine* e, int32_t rows) {
 
 extern "C" int ps_set_chain_impl(ps_engine* e, int32_t impl) {
   if (!e) return fail(PS_E_ARG, "null engine");
-  if (impl < 0 || impl > 2) return fail(PS_E_ARG, "ps_set_chain_impl: 0 (by mode), 1 (k_attn_chain) or 2 (k_chain16)");
+  if (impl < 0 || impl > 3) return fail(PS_E_ARG, "ps_set_chain_impl: 0 (by mode), 1 (k_attn_chain), 2 (k_chain16) or 3 (k_chain16, the encoder's s2s layers too)");
   if (impl != e->chain_impl) {
     drop_graph(e);
     e->chain_rows = 0;

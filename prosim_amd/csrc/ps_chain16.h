@@ -87,8 +87,14 @@ struct GeoSets {
 };
 // raw != 0: the three inputs as they are (dist, rel_ori, angle), no Fourier statistics -- what the learnable embedding
 // (ps_pe_learn.h) consumes.
-__global__ __launch_bounds__(256) void k_edge_geo(GeoSets sets, const float* __restrict__ src_pos, const float* __restrict__ div32,
-                                                 float eps, int raw) {
+// The 96 (sin, cos) values of an edge are made ONCE and kept in LDS between the two LayerNorm passes ([value][thread]: a
+// wave's 64 lanes on 64 banks); round 2 recomputed them for the second pass (half of the kernel's instructions).
+constexpr int GEO_THREADS = 128;
+constexpr size_t GEO_LDS_BYTES = (size_t)96 * GEO_THREADS * 4;
+__global__ __launch_bounds__(GEO_THREADS) void k_edge_geo(GeoSets sets, const float* __restrict__ src_pos, const float* __restrict__ div32,
+                                                         float eps, int raw) {
+  extern __shared__ __attribute__((aligned(16))) float geo_sc[];
+  float* sc = geo_sc + threadIdx.x;
   const GeoSet& S = sets.s[blockIdx.y];
   const int E = S.eoff[S.nq];
   float dv[16], rdv[16];
@@ -123,14 +129,17 @@ __global__ __launch_bounds__(256) void k_edge_geo(GeoSets sets, const float* __r
       xs[i] = xin[i] * PS_TWO_PI_F;
       fast = fast && fdiv16_ok(xs[i]);
     }
-    // two passes like torch's LayerNorm (mean, then centred squares); the pairs are recomputed instead of stored
+    // two passes like torch's LayerNorm (mean, then centred squares) over the same values
     float sm = 0.f;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       float part = 0.f;
+#pragma unroll
       for (int k = 0; k < 16; ++k) {
         float sv, cv;
         fourier_pair(xs[i], dv[k], rdv[k], fast, sv, cv);
+        sc[(2 * (16 * i + k)) * GEO_THREADS] = sv;
+        sc[(2 * (16 * i + k) + 1) * GEO_THREADS] = cv;
         part += sv + cv;
       }
       sm += (i == 2) ? 2.f * part : part;
@@ -140,9 +149,9 @@ __global__ __launch_bounds__(256) void k_edge_geo(GeoSets sets, const float* __r
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       float part = 0.f;
+#pragma unroll
       for (int k = 0; k < 16; ++k) {
-        float sv, cv;
-        fourier_pair(xs[i], dv[k], rdv[k], fast, sv, cv);
+        float sv = sc[(2 * (16 * i + k)) * GEO_THREADS], cv = sc[(2 * (16 * i + k) + 1) * GEO_THREADS];
         sv -= mean;
         cv -= mean;
         part = fmaf(sv, sv, part);

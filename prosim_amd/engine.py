@@ -397,7 +397,8 @@ class Engine:
         self._check(self.lib.ps_set_chain_rows(self.h, rows))
 
     def set_chain_impl(self, impl: int):
-        """0: by mode (default); 1: k_attn_chain always; 2: k_chain16 always (A/B measurements, cross-checks)."""
+        """0: by mode (default); 1: k_attn_chain always; 2: k_chain16 always (A/B measurements, cross-checks); 3: k_chain16
+        always and for the scene encoder's s2s layers as well (faster; another fp32 evaluation order of the scene tokens)."""
         self._check(self.lib.ps_set_chain_impl(self.h, impl))
 
     @property

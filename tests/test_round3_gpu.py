@@ -249,3 +249,34 @@ def test_stateless_policy_call_beside_a_captured_rollout():
         assert np.array_equal(eng.padded("traj"), before)
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("rows", [0, 16])
+def test_encoder_s2s_layers_on_k_chain16(rows):
+    """ps_set_chain_impl(3): the scene encoder's s2s layers as one-step k_chain16 launches (k | v projection + chain) instead of
+    the split k_node / k_edge_small path -- the same layer math, another fp32 evaluation order.  Open-loop quantities against the
+    fp64 oracle at 1e-4 (scene tokens, generator output, replan 0); the closed loop per agent with the usual branch-cut allowance
+    (this is NOT the default path: on the benchmark workload it flips six agents of one scene)."""
+    from prosim_amd.engine import Engine
+    from oracle_cache import oracle64
+    spec = DEMO_SPEC
+    w = weights.init_weights(spec, 0)
+    scene = synth.baseline_scene(spec, 3, seed=1, batch=2)
+    o64 = oracle64("baseline_cfg3_b2_s1", spec, w, scene, collect=True)
+    eng = Engine(spec, w)
+    try:
+        eng.set_chain_impl(3)
+        eng.set_chain_rows(rows)
+        eng.set_scene(scene)
+        eng.encode_scene()
+        assert err(eng.get("scene_tokens"), o64["trace"]["scene_tokens"].numpy()) < TOL
+        eng.generate_policy()
+        pm = scene["prompt_mask"].astype(bool)
+        assert err(eng.get("policy_emd"), o64["policy_emd"][torch.from_numpy(pm)].numpy()) < 2 * TOL
+        eng.rollout()
+        A = eng.num_agents
+        assert err(eng.get("motion_pred")[0], o64["motion_pred"][:A].numpy()) < TOL
+        d = np.abs(eng.padded("traj") - o64["traj"].numpy())[pm].reshape(A, -1).max(1)
+        assert (d < TOL).mean() >= 0.97 and np.median(d) < 3e-5, ((d < TOL).mean(), np.median(d), d.max())
+    finally:
+        eng.close()
