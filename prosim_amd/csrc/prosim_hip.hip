@@ -695,18 +695,15 @@ extern "C" int ps_create(const ps_config* cfg, int32_t n_tensors, const char* co
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pe_learn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PL_LDS_BYTES);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_node<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ND_LDS_BYTES);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_node<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ND_LDS_BYTES);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_chain<1, 4, 3, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_chain<2, 4, 3, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_chain<4, 4, 3, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 #define PS_C16_ATTR(NWW, POL, ONE) \
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain16<NWW, POL, ONE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c16_lds_bytes<NWW>())
   PS_C16_ATTR(8, true, true); PS_C16_ATTR(8, true, false); PS_C16_ATTR(8, false, true); PS_C16_ATTR(8, false, false);
-  PS_C16_ATTR(4, true, true); PS_C16_ATTR(4, true, false); PS_C16_ATTR(4, false, true); PS_C16_ATTR(4, false, false);
 #undef PS_C16_ATTR
-#define PS_ATTR(TT, NWW, KRR) \
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_chain<TT, NWW, KRR>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
-  PS_ATTR(1, 4, 3); PS_ATTR(2, 4, 3); PS_ATTR(4, 4, 3); PS_ATTR(4, 8, 3);
-  PS_ATTR(1, 4, 4); PS_ATTR(2, 4, 4); PS_ATTR(4, 4, 4); PS_ATTR(4, 8, 4);
+#define PS_ATTR(TT, KRR, POL) \
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_chain<TT, 4, KRR, false, POL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+  PS_ATTR(1, 3, true); PS_ATTR(2, 3, true); PS_ATTR(4, 3, true);
+  PS_ATTR(1, 3, false); PS_ATTR(2, 3, false); PS_ATTR(4, 3, false);
+  PS_ATTR(1, 4, false); PS_ATTR(2, 4, false); PS_ATTR(4, 4, false);
 #undef PS_ATTR
   *out = e;
   return PS_OK;
@@ -1476,7 +1473,7 @@ int launch_chain(ps_engine* e, float* x, int Nd, int step0, int nsteps, int maxd
   // workgroups per CU (code 11: 256 registers, late weight prefetch): 274 us per 128-agent policy launch, against 280
   // for eight waves per row (code 18) and 292 for four waves with the whole register file and early prefetch (code 1)
   // -- and the workgroups of two pipelined rollouts co-reside on a CU.
-  int T = Nd >= 2048 ? 4 : (Nd >= 512 ? 2 : 11);
+  int T = Nd >= 2048 ? 4 : (Nd >= 512 ? 2 : 11);   // (11 = ONE row on a four-wave workgroup built for two workgroups per CU)
   static const int env_T = getenv("PS_CHAIN_T") ? atoi(getenv("PS_CHAIN_T")) : 0;   // experiments only
   if (env_T && Nd >= 512) T = env_T;
   if ((e->chain_rows == 2 || e->chain_rows == 4) && Nd >= 512) T = e->chain_rows;   // (1 / 8 / 16 address k_chain16 only)
@@ -1500,33 +1497,28 @@ int launch_chain(ps_engine* e, float* x, int Nd, int step0, int nsteps, int maxd
     prof = d_prof;
   }
   if (timed && e->time_chain) (void)hipEventRecord(e->ev0, st);
-  const size_t lds18 = attn_lds_floats<1, 8>(maxdeg) * sizeof(float);
-  const size_t lds84 = attn_lds_floats<4, 8>(maxdeg) * sizeof(float), lds4 = attn_lds_floats<4>(maxdeg) * sizeof(float),
-               lds2 = attn_lds_floats<2>(maxdeg) * sizeof(float), lds1 = attn_lds_floats<1>(maxdeg) * sizeof(float);
+  const size_t lds4 = attn_lds_floats<4>(maxdeg) * sizeof(float), lds2 = attn_lds_floats<2>(maxdeg) * sizeof(float),
+               lds1 = attn_lds_floats<1>(maxdeg) * sizeof(float);
   const int kr = steps_host_kr;   // every step of a launch has the same rel-PE width
-#define PS_LAUNCH(TT, NWW, KRR, GRID, LDS) \
-  hipLaunchKernelGGL((k_attn_chain<TT, NWW, KRR>), dim3(GRID), dim3(64 * NWW), LDS, st, x, x_in, Nd, steps, nsteps, maxdeg, eps, flags, prof)
+  // k_attn_chain builds in the library: 1 row (code 11: four waves, two workgroups per CU), 2 rows, 4 rows; rel-PE width 3 | 4;
+  // the policy launch under its own symbol.  (Round 3 dropped the builds that were measured, parity-tested and never
+  // selected: 1 row on 8 waves, 4 rows on 8 waves, 1 row with the whole register file.)
+  if (T != 11 && T != 2 && T != 4) return fail(PS_E_ARG, "k_attn_chain takes 1 (code 11), 2 or 4 rows per workgroup");
+#define PS_LAUNCH(TT, KRR, POL, GRID, LDS) \
+  hipLaunchKernelGGL((k_attn_chain<TT, 4, KRR, false, POL>), dim3(GRID), dim3(WG), LDS, st, x, x_in, Nd, steps, nsteps, maxdeg, eps, flags, prof)
+  const bool pol = timed && kr == 3;
   if (T == 11) {
-    if (kr == 3 && timed) hipLaunchKernelGGL((k_attn_chain<1, 4, 3, false, true>), dim3(Nd), dim3(WG), lds1, st, x, x_in, Nd, steps, nsteps, maxdeg, eps, flags, prof);
-    else if (kr == 3) hipLaunchKernelGGL((k_attn_chain<1, 4, 3, false, false>), dim3(Nd), dim3(WG), lds1, st, x, x_in, Nd, steps, nsteps, maxdeg, eps, flags, prof);
-    else hipLaunchKernelGGL((k_attn_chain<1, 4, 4, false, false>), dim3(Nd), dim3(WG), lds1, st, x, x_in, Nd, steps, nsteps, maxdeg, eps, flags, prof);
-  } else if (timed && kr == 3 && (T == 1 || T == 2 || T == 4 || T == 18)) {   // the policy launch under its own symbol
-    if (T == 4) hipLaunchKernelGGL((k_attn_chain<4, 4, 3, false, true>), dim3((Nd + 3) / 4), dim3(WG), lds4, st, x, x_in, Nd, steps, nsteps, maxdeg, eps, flags, prof);
-    else if (T == 2) hipLaunchKernelGGL((k_attn_chain<2, 4, 3, false, true>), dim3((Nd + 1) / 2), dim3(WG), lds2, st, x, x_in, Nd, steps, nsteps, maxdeg, eps, flags, prof);
-    else if (T == 18) hipLaunchKernelGGL((k_attn_chain<1, 8, 3, false, true>), dim3(Nd), dim3(512), lds18, st, x, x_in, Nd, steps, nsteps, maxdeg, eps, flags, prof);
-    else hipLaunchKernelGGL((k_attn_chain<1, 4, 3, true, true>), dim3(Nd), dim3(WG), lds1, st, x, x_in, Nd, steps, nsteps, maxdeg, eps, flags, prof);
-  } else if (kr == 3) {
-    if (T == 18) hipLaunchKernelGGL((k_attn_chain<1, 8, 3, false>), dim3(Nd), dim3(512), lds18, st, x, x_in, Nd, steps, nsteps, maxdeg, eps, flags, prof);
-    else if (T == 84) PS_LAUNCH(4, 8, 3, (Nd + 3) / 4, lds84);
-    else if (T == 4) PS_LAUNCH(4, 4, 3, (Nd + 3) / 4, lds4);
-    else if (T == 2) PS_LAUNCH(2, 4, 3, (Nd + 1) / 2, lds2);
-    else PS_LAUNCH(1, 4, 3, Nd, lds1);
+    if (pol) PS_LAUNCH(1, 3, true, Nd, lds1);
+    else if (kr == 3) PS_LAUNCH(1, 3, false, Nd, lds1);
+    else PS_LAUNCH(1, 4, false, Nd, lds1);
+  } else if (T == 2) {
+    if (pol) PS_LAUNCH(2, 3, true, (Nd + 1) / 2, lds2);
+    else if (kr == 3) PS_LAUNCH(2, 3, false, (Nd + 1) / 2, lds2);
+    else PS_LAUNCH(2, 4, false, (Nd + 1) / 2, lds2);
   } else {
-    if (T == 18) hipLaunchKernelGGL((k_attn_chain<1, 8, 4, false>), dim3(Nd), dim3(512), lds18, st, x, x_in, Nd, steps, nsteps, maxdeg, eps, flags, prof);
-    else if (T == 84) PS_LAUNCH(4, 8, 4, (Nd + 3) / 4, lds84);
-    else if (T == 4) PS_LAUNCH(4, 4, 4, (Nd + 3) / 4, lds4);
-    else if (T == 2) PS_LAUNCH(2, 4, 4, (Nd + 1) / 2, lds2);
-    else PS_LAUNCH(1, 4, 4, Nd, lds1);
+    if (pol) PS_LAUNCH(4, 3, true, (Nd + 3) / 4, lds4);
+    else if (kr == 3) PS_LAUNCH(4, 3, false, (Nd + 3) / 4, lds4);
+    else PS_LAUNCH(4, 4, false, (Nd + 3) / 4, lds4);
   }
 #undef PS_LAUNCH
   if (timed && e->time_chain) {
@@ -1537,7 +1529,7 @@ int launch_chain(ps_engine* e, float* x, int Nd, int step0, int nsteps, int maxd
     if (prof) {
       unsigned long long h[16];
       (void)hipMemcpy(h, prof, sizeof(h), hipMemcpyDeviceToHost);
-      const int Tr = T == 84 ? 4 : T, nwg = (Nd + Tr - 1) / Tr;
+      const int Tr = T == 11 ? 1 : T, nwg = (Nd + Tr - 1) / Tr;
       double tot = 0;
       for (int i = 0; i < 16; ++i) tot += (double)h[i];
       fprintf(stderr, "[chain prof] T=%d wgs=%d %.1f us; mean cycles per workgroup per phase (share):", T, nwg, ms * 1e3);
@@ -1624,8 +1616,7 @@ int chain16_rows(ps_engine* e, int Nd) {
 }
 int launch_chain16(ps_engine* e, float* x, int Nd, const ChainStep* steps, int nsteps, bool timed, const float* x_in, bool xcd) {
   if (!x_in) x_in = x;
-  static const int env_nw = getenv("PS_C16_NW") ? atoi(getenv("PS_C16_NW")) : 0;   // experiments only: 4 = two 4-wave workgroups per CU
-  const int nw = env_nw == 4 ? 4 : 8;
+  const int nw = 8;   // eight waves per workgroup, one workgroup per CU (the two-workgroups-of-four build of round 2 was never selected: dropped)
   const int rows = chain16_rows(e, Nd);
   const int W = rows < nw ? nw / rows : 1;   // waves per row: each leaves its own partial sums (slot = part * Nd + row)
   const dim3 grid((Nd + rows - 1) / rows);   // (no exchange buffers: the phases of k_chain16 meet in LDS)
@@ -1642,11 +1633,7 @@ int launch_chain16(ps_engine* e, float* x, int Nd, const ChainStep* steps, int n
 #define PS_C16_(NWW, POL, ONE) \
   hipLaunchKernelGGL((k_chain16<NWW, POL, ONE>), grid, dim3(64 * NWW), c16_lds_bytes<NWW>(), st, x, x_in, Nd, rows, steps, nsteps, e->div32, e->cfg.ln_eps, xcd ? 1 : 0, prof)
 #define PS_C16(NWW, POL) do { if (W == 1) PS_C16_(NWW, POL, true); else PS_C16_(NWW, POL, false); } while (0)
-  if (nw == 8) {
-    if (timed) PS_C16(8, true); else PS_C16(8, false);
-  } else {
-    if (timed) PS_C16(4, true); else PS_C16(4, false);
-  }
+  if (timed) PS_C16(8, true); else PS_C16(8, false);
 #undef PS_C16_
 #undef PS_C16
   if (timed && e->time_chain) {

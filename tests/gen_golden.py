@@ -595,12 +595,18 @@ def oracle_cache_workloads():
         cap = kw["n_agents"] + kw["n_polylines"]
         sp = DEMO_SPEC.replace(dec_max_neigh=cap, pol_max_neigh=max(DEMO_SPEC.pol_max_neigh, min(cap, 2047)))
         out.append((f"no_truncation_cfg{cfg_idx}", sp, weights.init_weights(sp, 0), synth.baseline_scene(sp, cfg_idx, seed=0), False, False, True))
+    out.append(("split_s2s_ragged", DEMO_SPEC, weights.init_weights(DEMO_SPEC, 0),
+                synth.make_scene(DEMO_SPEC, 160, 1100, batch=2, seed=21, goal=True, ragged=True), True, False, False))
+    out.append(("maximum_scene_size", SMALL_SPEC, weights.init_weights(SMALL_SPEC, 0),
+                synth.make_scene(SMALL_SPEC, 512, 2048, batch=1, seed=77, goal=True, points=32, square=400.0), False, False, True))
     return out
 
 
-def gen_oracle_cache():
+def gen_oracle_cache(only=None):
     from oracle_cache import oracle64
     for key, spec, w, scene, collect, floor, slim in oracle_cache_workloads():
+        if only and key not in only:
+            continue
         o = oracle64(key, spec, w, scene, collect=collect, floor=floor, write=True, slim=slim)
         print("oracle cache written:", key, tuple(o["traj"].shape))
 
@@ -623,7 +629,7 @@ if __name__ == "__main__":
     elif len(sys.argv) > 1 and sys.argv[1] == "goal":
         gen_goal_heads()
     elif len(sys.argv) > 1 and sys.argv[1] == "oracle_cache":
-        gen_oracle_cache()
+        gen_oracle_cache(sys.argv[2:] or None)
     elif len(sys.argv) > 1 and sys.argv[1] == "format":
         gen_format("scene_1")
         gen_format("scene_0")

@@ -89,7 +89,7 @@ def test_attention_layer_vs_oracle(small_engine, group, prefix, bip, shape):
     eoff = np.cumsum(eoff)
     rt = _rnorm(r) if E else np.zeros((1, 128), np.float32)
     li = small_engine.layer_index(group, int(prefix[-1]))
-    for T in (1, 11, 18, 2, 4, 84, 16):   # rows per workgroup; 11 = 1 row on 4 waves, two workgroups per CU; 18 = 1 row on 8 waves; 84 = 4 rows on 8 waves; 16 = split layer (k_node + k_edge_small) when degree <= 128
+    for T in (11, 2, 4, 16):   # rows per workgroup of k_attn_chain; 11 = 1 row on 4 waves, two workgroups per CU; 16 = split layer (k_node + k_edge_small) when degree <= 128
         out = small_engine.test_attn(li, xs.numpy(), xd.numpy(), rt, eoff, src.numpy(), T)
         assert err(out, ref) < 2e-5, (T, err(out, ref))
 
@@ -518,8 +518,8 @@ def test_split_s2s_layers_on_a_ragged_batch(demo_engine):
     spec = DEMO_SPEC
     scene = synth.make_scene(spec, 160, 1100, batch=2, seed=21, goal=True, ragged=True)
     w = weights.init_weights(spec, 0)
-    with torch.no_grad():
-        o64 = orc.rollout(w, spec, scene, dtype=torch.float64, collect=True)
+    from oracle_cache import oracle64
+    o64 = oracle64("split_s2s_ragged", spec, w, scene, collect=True)
     eng = demo_engine
     eng.set_scene(scene)
     assert eng.num_agents + eng.num_map_tokens >= 2048
@@ -602,8 +602,8 @@ def test_maximum_scene_size(small_engine):
     spec = SMALL_SPEC
     w = weights.init_weights(spec, 0)
     scene = synth.make_scene(spec, 512, 2048, batch=1, seed=77, goal=True, points=32, square=400.0)
-    with torch.no_grad():
-        o64 = orc.rollout(w, spec, scene, dtype=torch.float64)
+    from oracle_cache import oracle64
+    o64 = oracle64("maximum_scene_size", spec, w, scene)
     small_engine.set_scene(scene)
     small_engine.rollout()
     A = small_engine.num_agents

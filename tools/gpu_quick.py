@@ -20,7 +20,7 @@ for (grp, pre, bip) in (("s2s", "scene_encoder.s2s_attn_layers.0", False), ("a2p
         src = torch.randint(0, Ns, (E,), generator=g); dst = torch.sort(torch.randint(0, max(Nd - 1, 1), (E,), generator=g))[0]
         ref = orc.attention_layer(Wt, pre, spec, xs, xd, r, src, dst, bip).numpy()
         eoff = np.zeros(Nd + 1, np.int64); np.add.at(eoff, dst.numpy() + 1, 1); eoff = np.cumsum(eoff)
-        for T in (1, 11, 18, 2, 4, 84, 16):   # rows per workgroup; 11 = 1 row on 4 waves, two workgroups per CU; 18 = 1 row on 8 waves; 84 = 4 rows on 8 waves; 16 = split layer (k_node + k_edge_small) when degree <= 128
+        for T in (11, 2, 4, 16):   # rows per workgroup of k_attn_chain; 11 = 1 row on 4 waves, two workgroups per CU; 16 = split layer (k_node + k_edge_small) when degree <= 128
             out = eng.test_attn(eng.layer_index(grp, int(pre[-1])), xs.numpy(), xd.numpy(), rnorm(r) if E else np.zeros((1, 128), np.float32), eoff, src.numpy(), T)
             print(grp, Ns, Nd, E, "T", T, "err", np.abs(out - ref).max())
 eng.close()
