@@ -249,7 +249,11 @@ __device__ __forceinline__ float4 c16_bld4(__amdgpu_buffer_rsrc_t r, unsigned of
   const v4f v = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
   return make_float4(v.x, v.y, v.z, v.w);
 }
+#ifdef PS_C16_ABL_NOWAIT   // (timing experiment: how much DMA latency the two waits of a tile expose; wrong results)
+__device__ __forceinline__ void c16_wait_vm0() { asm volatile("" ::: "memory"); }
+#else
 __device__ __forceinline__ void c16_wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+#endif
 __device__ __forceinline__ void c16_wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 // Where a row's sums wait for the POST half (all in LDS; nothing of the exchange touches global memory):
