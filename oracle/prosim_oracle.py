@@ -461,14 +461,30 @@ def condition_transform(Wt: W, spec: ModelSpec, cond: Optional[Dict], emd: T, pr
     # condition keys that put an entry on (i -> j); unary keys on (s, s), binary keys s_emd on (s, t) and t_emd on (t, s)
     attr = torch.zeros(B, N, N, D, dtype=emd.dtype)
     cnt = torch.zeros(B, N, N, dtype=emd.dtype)
+    # The reference fills one [B, N, N, D] plane per condition key BY ASSIGNMENT (:155-166): of several entries of one key on
+    # one edge the last one (in entry order) survives, and the edge counts once in the mean pool.
+    def last_wins(bi, ci_, a, b):
+        keep = torch.ones(bi.numel(), dtype=torch.bool)
+        seen = set()
+        for k in range(bi.numel() - 1, -1, -1):
+            key = (int(bi[k]), int(a[k]), int(b[k]))
+            if key in seen:
+                keep[k] = False
+            seen.add(key)
+        return keep
+
     for e, m, pidx in entries:
         bi, ci_ = m.nonzero(as_tuple=True)
         ni = pidx[bi, ci_]
+        kp = last_wins(bi, ci_, ni, ni)
+        bi, ci_, ni = bi[kp], ci_[kp], ni[kp]
         attr.index_put_((bi, ni, ni), e[bi, ci_], accumulate=True)
         cnt.index_put_((bi, ni, ni), torch.ones(bi.numel(), dtype=emd.dtype), accumulate=True)
     for es, et, m, pidx in pair_entries:
         bi, ci_ = m.nonzero(as_tuple=True)
         si, ti = pidx[bi, ci_, 0], pidx[bi, ci_, 1]
+        kp = last_wins(bi, ci_, si, ti)
+        bi, ci_, si, ti = bi[kp], ci_[kp], si[kp], ti[kp]
         one = torch.ones(bi.numel(), dtype=emd.dtype)
         attr.index_put_((bi, si, ti), es[bi, ci_], accumulate=True)
         cnt.index_put_((bi, si, ti), one, accumulate=True)

@@ -1116,8 +1116,15 @@ static int rebuild_conditions(ps_engine* e) {
     int deg = 0;
     while (i < all.size() && all[i].first.dst == a) {
       const int src = all[i].first.src;
-      for (; i < all.size() && all[i].first.dst == a && all[i].first.src == src; ++i) {
+      size_t j_end = i;
+      while (j_end < all.size() && all[j_end].first.dst == a && all[j_end].first.src == src) ++j_end;
+      for (; i < j_end; ++i) {
         const auto* en = all[i].second;
+        // the reference writes one plane per condition key by assignment (condition_attns.py:155-166): of several entries of one
+        // key (type, id) on one edge the LAST one survives (the stable sort kept the entries' order) and counts once
+        bool later = false;
+        for (size_t j = i + 1; j < j_end && !later; ++j) later = all[j].second->type == en->type && all[j].second->id == en->id;
+        if (later) continue;
         ent_type.push_back(en->type);
         ent_type.push_back(en->id);
         ent_val.insert(ent_val.end(), en->v, en->v + 3);

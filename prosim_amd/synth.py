@@ -24,7 +24,7 @@ from .spec import ModelSpec
 
 
 def make_scene(spec: ModelSpec, n_agents: int, n_polylines: int, batch: int = 1, seed: int = 0,
-               square: float = 200.0, points: int = 19, goal: bool = False, tags: bool = False,
+               square: float = 200.0, points: int = 19, goal: bool = False, tags: bool = False, dup_tags: bool = False,
                ragged: bool = False, clustered: bool = False, replay: float = 0.0, drag: bool = False, v2v: bool = False,
                enter: float = 0.0) -> Dict[str, np.ndarray]:
     """One batch of ``batch`` scenes.  ``ragged``: later scenes in the batch get fewer agents /
@@ -162,8 +162,19 @@ def make_scene(spec: ModelSpec, n_agents: int, n_polylines: int, batch: int = 1,
         tm = prompt_mask.copy()
         if ragged:
             tm &= rng.rand(B, N) < 0.6
-        cond["v_action_tag"] = dict(input=tg, mask=tm,
-                                    prompt_idx=np.tile(np.arange(N)[None, :, None], (B, 1, 1)).astype(np.int64))
+        pidx = np.tile(np.arange(N)[None, :, None], (B, 1, 1)).astype(np.int64)
+        if dup_tags:
+            # a second tag entry per prompt over the second half of the horizon: the SAME tag for every other prompt (the reference
+            # writes its edge matrix by assignment, condition_attns.py:155-166: of two entries of one tag on one prompt the later
+            # one survives), another tag for the rest (both count in the mean pool)
+            tg[..., 2] = float(spec.max_steps // 2)
+            tg2 = tg.copy()
+            tg2[..., 1], tg2[..., 2] = float(spec.max_steps // 2), float(spec.max_steps)
+            other = (np.arange(N)[None, :] % 2 == 1)
+            tg2[..., 0] = np.where(other, (tg[..., 0] + 1 + rng.randint(0, 10, (B, N))) % 11, tg[..., 0])
+            tm2 = tm & (rng.rand(B, N) < 0.8)
+            tg, tm, pidx = np.concatenate([tg, tg2], 1), np.concatenate([tm, tm2], 1), np.concatenate([pidx, pidx], 1)
+        cond["v_action_tag"] = dict(input=tg, mask=tm, prompt_idx=pidx)
     if drag:
         # drag points (condition_utils.py:401-447): every 5th step of a path in the agent's start frame, a
         # consecutive subset of the points kept, the others NaN; a condition without any point is masked off

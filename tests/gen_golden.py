@@ -72,6 +72,9 @@ FULL_CASES = {
     "small_lpe_b2": ("small_lpe", dict(n_agents=16, n_polylines=128, batch=2, seed=13, goal=True, tags=True, ragged=True), 0),
     # TRAJ.PRED_GMM (state_dim 8: the rollout's velocity sits in columns 6:8) with RANDOM_NOISE_STD > 0 (act_decoder.py:113-115):
     # the fixture keeps the reference's noise draws (action_noise) and the torch seed they came from
+    # two entries of one action tag on one prompt (the reference's edge matrix is written by assignment: the later one survives)
+    # beside prompts with two DIFFERENT tags (both count in the mean pool)
+    "small_duptag_b2": ("small", dict(n_agents=16, n_polylines=128, batch=2, seed=19, goal=True, tags=True, dup_tags=True, ragged=True), 0),
     "small_noise_gmm_b2": ("small_noise_gmm", dict(n_agents=16, n_polylines=128, batch=2, seed=17, goal=True, ragged=True, replay=0.3), 0),
 }
 SPECS = {"small": SMALL_SPEC, "demo": DEMO_SPEC, "small_mlp": SMALL_SPEC.replace(obs_fusion="mlp"),
