@@ -864,9 +864,12 @@ constexpr size_t ND_LDS_BYTES = (size_t)2 * ND_ROWS * ND_AS * 2 + (size_t)2 * ND
 // Wave w makes tiles w, w+4, ...; its work is a list of (tile, 4-k-block) groups of <= 8 fragment loads + <= 12 MFMAs.
 // Weights do not depend on activations, so a ring of ND_DEPTH groups stays in flight ACROSS the epilogues and
 // barriers between GEMMs: frag_prefetch() requests the first groups of the next GEMM as soon as the ring is free,
-// gemm16() consumes group g and requests group g + ND_DEPTH.  (One group ahead hid ~10 % of a 1-2 us round trip:
-// a group's MFMAs take 0.1 us.  k_node runs one workgroup per CU, so the ~160 registers of the ring are free.)
-constexpr int ND_DEPTH = 4;
+// gemm16() consumes group g and requests group g + ND_DEPTH.  (One group ahead hid ~10 % of a 1-2 us round trip: a group's
+// MFMAs take 0.1 us.)  Round 3: with every fragment load made an L1 hit the node phases are only 10 % faster -- the
+// dependent stage chain (GEMM -> LDS -> barrier -> epilogue -> LDS -> barrier) bounds them, not the weight fetch -- so
+// k_node keeps a ring of 2 (214 registers) and TWO workgroups share a CU (2 x 75 KB of LDS): one's stage waits are the
+// other's issue slots.  Same bits, +1.8 % on the pipelined benchmark over a ring of 4 at one workgroup per CU.
+constexpr int ND_DEPTH = 2;
 template <int DEPTH_>
 struct FragRingT {
   static constexpr int DEPTH = DEPTH_;
@@ -876,7 +879,11 @@ typedef FragRingT<ND_DEPTH> FragRing;
 template <int K32, class RingT, int NWV = 4>
 __device__ __forceinline__ void frag_issue(RingT& R, int slot, const _Float16* __restrict__ F, int g, int wave, int lane) {
   constexpr int KB = K32 < 4 ? K32 : 4, KG = (K32 + KB - 1) / KB;
+#ifdef PS_ABL_FRAG0   // timing ablation: every group of every wave reads the GEMM's first 8 KB (L1 hits)
+  const _Float16* f = F + lane * 8;
+#else
   const _Float16* f = F + ((size_t)(wave + NWV * (g / KG)) * K32 + (g % KG) * KB) * 1024 + lane * 8;
+#endif
 #pragma unroll
   for (int j = 0; j < KB; ++j) {
     R.h[slot][j] = ldgh8(f + j * 1024);
@@ -982,7 +989,7 @@ __device__ __forceinline__ void planes_store8(_Float16* __restrict__ Ph, _Float1
 // kv_out / khl_out (optional, PRE of a SELF-attention layer, where LN_src == LN_dst): the rows are also the
 // layer's sources, so their k | v projection (k_kv_proj's job) is one more GEMM on the normed rows already in LDS.
 template <int KR>
-__global__ __launch_bounds__(256) void k_node(float* __restrict__ x, int Nd, const ChainStep* __restrict__ post,
+__global__ __launch_bounds__(256, 2) void k_node(float* __restrict__ x, int Nd, const ChainStep* __restrict__ post,
                                               const ChainStep* __restrict__ pre, EdgeIO io, float eps,
                                               float* __restrict__ kv_out, _Float16* __restrict__ khl_out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char nd_smem[];

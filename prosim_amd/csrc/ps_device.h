@@ -174,36 +174,48 @@ __device__ __forceinline__ void pn_load(PnFrags& f, const _Float16* __restrict__
     }
   }
 }
+// (Both column tiles of the wave share one pass over the A fragments: an A fragment is read from LDS once and meets the
+// B fragments of tile w and of tile w + 4 -- half the LDS reads of a tile-by-tile order.  Every accumulator still sees its
+// products in the order ks ascending, hi*hi, hi*lo, lo*hi: the same bits.)
 template <int MT>
 __device__ __forceinline__ void pn_mma(const PnFrags& f, const _Float16* __restrict__ Ah, const _Float16* __restrict__ Al, int k32,
                                        float* __restrict__ C, int cs, int row_lim, int wave, int lane, int ntiles = 8) {
   const int mi = lane & 15, kq = lane >> 4;
+  const bool two = wave + 4 < ntiles;
+  if (wave >= ntiles) return;
+  floatx4 acc[2][MT];
 #pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    const int nt = wave + 4 * t;
-    if (nt >= ntiles) break;
-    floatx4 acc[MT];
+  for (int t = 0; t < 2; ++t)
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) acc[mt] = floatx4{0.f, 0.f, 0.f, 0.f};
+    for (int mt = 0; mt < MT; ++mt) acc[t][mt] = floatx4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      if (ks < k32) {
+  for (int ks = 0; ks < 4; ++ks) {
+    if (ks < k32) {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          const half8 ah = *reinterpret_cast<const half8*>(Ah + (mt * 16 + mi) * PN_AS + ks * 32 + kq * 8);
-          const half8 al = *reinterpret_cast<const half8*>(Al + (mt * 16 + mi) * PN_AS + ks * 32 + kq * 8);
-          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, f.bh[t][ks], acc[mt], 0, 0, 0);
-          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, f.bl[t][ks], acc[mt], 0, 0, 0);
-          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, f.bh[t][ks], acc[mt], 0, 0, 0);
+      for (int mt = 0; mt < MT; ++mt) {
+        const half8 ah = *reinterpret_cast<const half8*>(Ah + (mt * 16 + mi) * PN_AS + ks * 32 + kq * 8);
+        const half8 al = *reinterpret_cast<const half8*>(Al + (mt * 16 + mi) * PN_AS + ks * 32 + kq * 8);
+        acc[0][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, f.bh[0][ks], acc[0][mt], 0, 0, 0);
+        acc[0][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, f.bl[0][ks], acc[0][mt], 0, 0, 0);
+        acc[0][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, f.bh[0][ks], acc[0][mt], 0, 0, 0);
+        if (two) {
+          acc[1][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, f.bh[1][ks], acc[1][mt], 0, 0, 0);
+          acc[1][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, f.bl[1][ks], acc[1][mt], 0, 0, 0);
+          acc[1][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, f.bh[1][ks], acc[1][mt], 0, 0, 0);
         }
       }
     }
+  }
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    if (t == 1 && !two) break;
+    const int nt = wave + 4 * t;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = mt * 16 + 4 * kq + r;
-        if (row < row_lim) C[row * cs + nt * 16 + mi] = acc[mt][r];
+        if (row < row_lim) C[row * cs + nt * 16 + mi] = acc[t][mt][r];
       }
   }
 }
