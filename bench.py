@@ -432,7 +432,7 @@ def main():
                                  "A launch occupies `workgroups` of the 256 CUs and `rollouts_in_flight` launches overlap, so the per-launch "
                                  "rate understates the chip: chip_algorithmic_tflops = all policy launches of the timed region / its wall time.  "
                                  "What bounds the launch: DESIGN.md section 4 (edge phase: fp32 VALU issue -- the recomputed Fourier rows are 58 % of it -- "
-                                 "and the dependent LDS / MFMA chain of a 16-edge tile at two waves per SIMD; node phase: per-CU L1 fill rate of the weight fragments).",
+                                 "and the dependent LDS / MFMA chain of a 16-edge tile at two waves per SIMD; node phase: the dependent stage chain of a 16-row layer -- GEMM, LDS, barrier, epilogue, 17 barriers per layer; with every weight-fragment load an L1 hit it is only 10 % faster).",
                          "algorithmic_flops_per_launch": fl_alg,
                          "executed_mfma_flops_per_launch": fl_mfma,
                          "executed_mfma_tflops": (fl_mfma / (ms_launch * 1e-3) / 1e12) if fl_mfma else None,
