@@ -17,7 +17,7 @@ scene = {k: (np.concatenate([p[k] for p in parts]) if not isinstance(parts[0][k]
 engines = [Engine(spec, w) for _ in range(n_fl)]
 for e in engines:
     e.set_chain_impl(int(os.environ.get("PS_IMPL", "0")))
-    e.set_chain_rows(16)
+    e.set_chain_rows(int(os.environ.get("PS_ROWS", "16")))
     e.set_scene(scene)
 for k in range(2 * n_fl):
     engines[k % n_fl].rollout()
