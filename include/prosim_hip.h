@@ -63,6 +63,11 @@ typedef struct ps_config {
   /* MODEL.POLICY.ACT_DECODER.TRAJ.PRED_GMM (act_decoder.py:26-27; 0 in the demo): state_dim 8 = x, y, h, (std1, std2, rho), xd, yd;
    * the rollout then appends the velocity of columns 6:8 instead of 3:5 (traj_sam.py:337-340). */
   int32_t pred_gmm;
+  /* MODEL.POLICY.ACT_DECODER.TRAJ.PRED_MODE (act_decoder.py:47-76, :90-110): 0 = 'anchor' (every released config) and 'cluster'
+   * (whose anchors cluster_mlp(FourierEmbeddingFix(k_goals)) do not depend on the input: the host folds them into
+   * "policy.act_decoder.motion_anchors.weight", K rows repeated per agent type); 1 = 'mlp': no anchors, no CG_decode, the last
+   * Linear of motion_head has motion_k * target_steps * state_dim (<= 128) outputs, mode-major. */
+  int32_t k_pred_mlp;
 } ps_config;
 
 /* Create an engine and upload weights.  names[i] are reference state_dict keys

@@ -552,17 +552,24 @@ def cg_stacked(Wt: W, prefix: str, inp: T, context: T) -> Tuple[T, T]:
 
 
 def compute_traj(Wt: W, spec: ModelSpec, pred_feat: T, agent_type: T, policy_emd: T, noise: Optional[T] = None) -> Dict:
-    """ActDecoder._compute_traj, anchor mode (act_decoder.py:78-140).  ``noise`` [A, K, steps, 2]: RANDOM_NOISE_STD's draw,
+    """ActDecoder._compute_traj, TRAJ.PRED_MODE anchor / cluster / mlp (act_decoder.py:78-140).  ``noise`` [A, K, steps, 2]: RANDOM_NOISE_STD's draw,
     already scaled (:113-115: added to the xy steps before the cumulative sum)."""
     pa = "policy.act_decoder"
     A = pred_feat.shape[0]
     K = spec.motion_k
-    type_idx = ((agent_type - 1) * K).unsqueeze(-1).repeat(1, K)
-    anchor_index = torch.arange(K)[None, :].repeat(A, 1) + type_idx
-    anchor = Wt[f"{pa}.motion_anchors.weight"][anchor_index]
-    pred_emd, _ = cg_stacked(Wt, f"{pa}.CG_decode", anchor, pred_feat)
     d = spec.hidden
-    motion = mlp(Wt, f"{pa}.motion_head", [d, d, d // 2, spec.out_dim], pred_emd, True, False)
+    if spec.k_pred_mode == "mlp":       # (:90-91) all K modes from one head, no anchors
+        motion = mlp(Wt, f"{pa}.motion_head", [d, d, d // 2, spec.head_out_dim], pred_feat, True, False)
+    else:
+        if spec.k_pred_mode == "cluster":   # (:70-74, :103-105) anchors from the K goal clusters, the same for every agent
+            pe = fourier_fix(Wt["policy.act_decoder.k_goals"], d // 2)
+            anchor = mlp(Wt, f"{pa}.cluster_mlp", [d, d], pe, False, False)[None].repeat(A, 1, 1)
+        else:                               # (:93-101) learned anchors per (agent type, mode)
+            type_idx = ((agent_type - 1) * K).unsqueeze(-1).repeat(1, K)
+            anchor_index = torch.arange(K)[None, :].repeat(A, 1) + type_idx
+            anchor = Wt[f"{pa}.motion_anchors.weight"][anchor_index]
+        pred_emd, _ = cg_stacked(Wt, f"{pa}.CG_decode", anchor, pred_feat)
+        motion = mlp(Wt, f"{pa}.motion_head", [d, d, d // 2, spec.out_dim], pred_emd, True, False)
     motion = motion.view(A, K, spec.target_steps, spec.state_dim)
     if noise is not None:
         motion = torch.cat([motion[..., :2] + noise.to(motion.dtype), motion[..., 2:]], dim=-1)

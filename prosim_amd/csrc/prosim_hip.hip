@@ -532,9 +532,9 @@ extern "C" int ps_create(const ps_config* cfg, int32_t n_tensors, const char* co
   if (cfg->hidden != D || cfg->heads != H || cfg->head_dim != DH)
     return fail(PS_E_ARG, "this build supports hidden=128, heads=8, head_dim=16 only");
   if (cfg->hist_steps > 15 || cfg->obs_dim > 24 || cfg->map_dim > 24 || cfg->motion_k < 1 || cfg->motion_k > 16 || cfg->state_dim != (cfg->pred_gmm ? 8 : 5) ||
-      cfg->target_steps * cfg->state_dim > 128 || cfg->map_pre_layers > 4 || cfg->obs_pre_layers > 4 ||
+      cfg->target_steps * cfg->state_dim * (cfg->k_pred_mlp ? cfg->motion_k : 1) > 128 || cfg->map_pre_layers > 4 || cfg->obs_pre_layers > 4 ||
       cfg->map_mlp_layers - cfg->map_pre_layers > 4 || cfg->obs_mlp_layers - cfg->obs_pre_layers > 4)
-    return fail(PS_E_ARG, "unsupported config (hist<=15, obs_dim<=24, map_dim<=24, 1<=motion_k<=16, steps*state<=64)");
+    return fail(PS_E_ARG, "unsupported config (hist<=15, obs_dim<=24, map_dim<=24, 1<=motion_k<=16, steps*state (x motion_k with PRED_MODE mlp) <=128)");
   if (cfg->goal_pred_k < 0 || cfg->goal_pred_k > 64) return fail(PS_E_ARG, "goal_pred_k must be in 0..64");
   if (cfg->replan_freq < 1 || cfg->replan_freq > cfg->target_steps)
     return fail(PS_E_ARG, "replan_freq must be in 1..target_steps (a replan appends replan_freq of the target_steps predicted states)");
@@ -581,11 +581,13 @@ extern "C" int ps_create(const ps_config* cfg, int32_t n_tensors, const char* co
   }
   const std::string pa = "policy.act_decoder";
   build_mlp3(b, pa + ".pred_mlp", {D, D, D / 2, 2}, false, e->mlp_pred);
-  build_mlp3(b, pa + ".motion_head", {D, D, D / 2, cfg->target_steps * cfg->state_dim}, false, e->head.motion);
-  b.plain(&e->head.anchors, pa + ".motion_anchors.weight", (int64_t)cfg->motion_k * cfg->num_agent_types * D);
+  // (TRAJ.PRED_MODE 'mlp': the head's last Linear carries all K modes, and there are no anchors / CG_decode blocks)
+  const int head_out = cfg->target_steps * cfg->state_dim * (cfg->k_pred_mlp ? cfg->motion_k : 1);
+  build_mlp3(b, pa + ".motion_head", {D, D, D / 2, head_out}, false, e->head.motion);
+  if (!cfg->k_pred_mlp) b.plain(&e->head.anchors, pa + ".motion_anchors.weight", (int64_t)cfg->motion_k * cfg->num_agent_types * D);
   {
     // K-major copies of the motion head (reference MLP [128,128,64,out]: seq 0 Lin,1 LN,3 Lin,4 LN,6 Lin)
-    const int OUT = cfg->target_steps * cfg->state_dim;
+    const int OUT = head_out;
     const std::string mh = pa + ".motion_head.mlp.";
     b.fragments(&e->head.m0F, mh + "0.weight", D, D, 0, D);
     b.fragments(&e->head.m1F, mh + "3.weight", D / 2, D, 0, D);
@@ -612,7 +614,7 @@ extern "C" int ps_create(const ps_config* cfg, int32_t n_tensors, const char* co
       b.slot(&e->head.m2b, b.put(bb));
     }
   }
-  for (int i = 0; i < 3; ++i) {
+  for (int i = 0; i < 3 && !cfg->k_pred_mlp; ++i) {
     const std::string q = pa + ".CG_decode.CGs." + std::to_string(i) + ".MLP.";
     b.fragments(&e->head.cgF[i], q + "0.weight", D, D, 0, D);
     b.transposed(&e->head.cgWt[i], q + "0.weight", D, D);
@@ -1972,13 +1974,13 @@ extern "C" int ps_policy_step(ps_engine* e, int32_t t_idx) {
   if (e->policy_events && (int)e->pev.size() >= 2 * R) HIPCHK(hipEventRecord(e->pev[2 * t_idx + 1], st));
   // _compute_traj + step_agent_traj
   {
-    const int G = 16 / c.motion_k;   // agents per workgroup: one 16-row tile holds G agents x K modes
+    const int G = c.k_pred_mlp ? 16 : 16 / c.motion_k;   // agents per workgroup: one 16-row tile holds G agents x K modes (PRED_MODE mlp: 16 agents)
     hipLaunchKernelGGL(k_policy_head_mfma, dim3((A + G - 1) / G), dim3(256), 0, st, e->head, (const float*)e->d_fused.p,
                        (const int*)e->d_agent_type.p, A, c.motion_k, c.target_steps, c.state_dim,
                        e->d_motion.p + (size_t)t_idx * A * c.motion_k * c.target_steps * c.state_dim,
                        e->d_traj.p, e->d_vel.p, e->stride_steps, last, c.replan_freq, c.ln_eps, (const int*)(e->d_choice.p + (size_t)t_idx * A),
                        e->have_noise ? (const float*)(e->d_noise.p + (size_t)t_idx * A * c.motion_k * c.target_steps * 2) : (const float*)nullptr,
-                       c.pred_gmm ? 6 : 3);
+                       c.pred_gmm ? 6 : 3, c.k_pred_mlp ? 1 : 0);
   }
   HIPCHK(hipGetLastError());
   return PS_OK;
@@ -2598,9 +2600,10 @@ extern "C" int ps_policy_forward(ps_engine* e, int32_t n_scenes, int32_t Na, con
     std::vector<float> unit((size_t)A * 16 * 4, 0.f);
     for (size_t i = 0; i < (size_t)A * 16; ++i) unit[i * 4 + 3] = 1.f;
     (void)hipMemcpyAsync(d_traj.p, unit.data(), sizeof(float) * unit.size(), hipMemcpyHostToDevice, st);
-    hipLaunchKernelGGL(k_policy_head_mfma, dim3((A + 16 / c.motion_k - 1) / (16 / c.motion_k)), dim3(256), 0, st, e->head, (const float*)d_x.p, (const int*)d_ptype.p, A,
+    const int Gh = c.k_pred_mlp ? 16 : 16 / c.motion_k;
+    hipLaunchKernelGGL(k_policy_head_mfma, dim3((A + Gh - 1) / Gh), dim3(256), 0, st, e->head, (const float*)d_x.p, (const int*)d_ptype.p, A,
                        c.motion_k, c.target_steps, c.state_dim, d_motion.p, d_traj.p, d_vel.p, 16, 1, 0, c.ln_eps, (const int*)nullptr,
-                       (const float*)nullptr, c.pred_gmm ? 6 : 3);
+                       (const float*)nullptr, c.pred_gmm ? 6 : 3, c.k_pred_mlp ? 1 : 0);
     if (hipStreamSynchronize(st) != hipSuccess) rc = fail(PS_E_HIP, "ps_policy_forward: kernel failure");
   }
   std::swap(e->d_tok_pos, d_pos);

@@ -986,26 +986,30 @@ __global__ __launch_bounds__(256) void k_policy_head_mfma(HeadW w, const float* 
                                                          float* __restrict__ motion_pred, float* __restrict__ traj,
                                                          float* __restrict__ vel, int stride_steps, int last, int replan, float eps,
                                                          const int* __restrict__ choice, const float* __restrict__ noise /*[A][K][steps][2] or null*/,
-                                                         int vcol /*first velocity column: 3, or 6 with PRED_GMM*/) {
+                                                         int vcol /*first velocity column: 3, or 6 with PRED_GMM*/,
+                                                         int mlp_mode /*TRAJ.PRED_MODE 'mlp' (act_decoder.py:90-91): one row per AGENT, no
+                                                                        anchors and no CG_decode, the K modes are column blocks of the last Linear*/) {
   __shared__ __attribute__((aligned(16))) _Float16 Ah[16 * PN_AS], Al[16 * PN_AS];
   __shared__ __attribute__((aligned(16))) float C[16 * PN_CS], ctx[16 * PN_CS], inp[16 * PN_CS], Y[16 * PN_CS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int K = motion_k, G = 16 / K;          // agents per workgroup; rows g * K + k, rows >= G * K idle
+  const int K = motion_k, G = mlp_mode ? 16 : 16 / K;   // agents per workgroup; rows g * K + k (mlp: row g), the other rows idle
+  const int KR = mlp_mode ? 1 : K;                      // rows per agent
   const int ag0 = blockIdx.x * G;
   PnFrags fr;   // the next GEMM's weight fragments always leave before the barrier / epilogue in front of it
-  pn_load(fr, w.cgF[0], 4, wave, lane);
+  pn_load(fr, mlp_mode ? w.m0F : w.cgF[0], 4, wave, lane);
   for (int i = tid; i < 16 * 128; i += 256) {
     const int row = i >> 7, c = i & 127;
-    const int g = row / K, k = row - g * K;
+    const int g = row / KR, k = row - g * KR;
     const int ag = (g < G && ag0 + g < n_agents) ? ag0 + g : n_agents - 1;
-    ctx[row * PN_CS + c] = fused[(size_t)ag * 128 + c];      // (every mode row carries its agent's context)
-    const float av = w.anchors[(size_t)((agent_type[ag] - 1) * K + (g < G ? k : 0)) * 128 + c];   // anchor of (type, mode)
+    const float cv = fused[(size_t)ag * 128 + c];
+    ctx[row * PN_CS + c] = cv;      // (every mode row carries its agent's context)
+    const float av = mlp_mode ? cv : w.anchors[(size_t)((agent_type[ag] - 1) * K + (g < G ? k : 0)) * 128 + c];   // anchor of (type, mode)
     Ah[row * PN_AS + c] = f16_hi(av);
     Al[row * PN_AS + c] = f16_lo(av);
   }
   __syncthreads();
   // CG_stacked(3): block i: y = relu(LN(W inp + b)) * context; context' = max over the agent's modes of y
-  for (int i = 0; i < 3; ++i) {
+  for (int i = 0; i < (mlp_mode ? 0 : 3); ++i) {
     pn_mma<1>(fr, Ah, Al, 4, C, PN_CS, 16, wave, lane);
     pn_load(fr, i < 2 ? w.cgF[i + 1] : w.m0F, 4, wave, lane);
     __syncthreads();
@@ -1062,7 +1066,7 @@ __global__ __launch_bounds__(256) void k_policy_head_mfma(HeadW w, const float* 
   }
   __syncthreads();
   pn_mma<1>(fr, Ah, Al, 4, C, PN_CS, 16, wave, lane, 4);
-  const int nt2 = (steps * sdim + 15) / 16;   // n-tiles of the last Linear (<= 8)
+  const int nt2 = (steps * sdim * (mlp_mode ? K : 1) + 15) / 16;   // n-tiles of the last Linear (<= 8)
   pn_load(fr, w.m2F, 2, wave, lane, nt2);
   __syncthreads();
   if (tid < 64) {
@@ -1084,22 +1088,24 @@ __global__ __launch_bounds__(256) void k_policy_head_mfma(HeadW w, const float* 
     const int row = i / steps, s = i - row * steps;
     const int g = row / K, k = row - g * K, ag = ag0 + g;
     if (ag >= n_agents) continue;
-    const float* o = C + row * PN_CS;
+    // the (agent, mode)'s steps * sdim outputs: its own row, or (mlp) the mode's column block of the agent's row
+    const float* o = mlp_mode ? C + g * PN_CS + k * steps * sdim : C + row * PN_CS;
+    const float* ob = mlp_mode ? w.m2b + k * steps * sdim : w.m2b;
     float cx = 0.f, cy = 0.f, ch = 0.f;
     const float* nz = noise ? noise + ((size_t)ag * K + k) * steps * 2 : nullptr;
     for (int j = 0; j <= s; ++j) {
       // (act_decoder.py:113-117: the noise joins the step before the cumulative sum)
-      const float dx = o[j * sdim] + w.m2b[j * sdim], dy = o[j * sdim + 1] + w.m2b[j * sdim + 1];
+      const float dx = o[j * sdim] + ob[j * sdim], dy = o[j * sdim + 1] + ob[j * sdim + 1];
       cx += nz ? dx + nz[2 * j] : dx;
       cy += nz ? dy + nz[2 * j + 1] : dy;
-      ch += o[j * sdim + 2] + w.m2b[j * sdim + 2];
+      ch += o[j * sdim + 2] + ob[j * sdim + 2];
     }
     const float hh = wrap_angle(ch);
     float* mp = motion_pred + ((size_t)ag * K + k) * steps * sdim + s * sdim;
     mp[0] = cx;
     mp[1] = cy;
     mp[2] = hh;
-    for (int f = 3; f < sdim; ++f) mp[f] = o[s * sdim + f] + w.m2b[s * sdim + f];
+    for (int f = 3; f < sdim; ++f) mp[f] = o[s * sdim + f] + ob[s * sdim + f];
     const int pick = choice ? choice[ag] : 0;
     if (s < replan && k == pick) {
       // step_agent_traj (traj_sam.py:322-347): rotate into the agent-init frame, append
@@ -1114,7 +1120,7 @@ __global__ __launch_bounds__(256) void k_policy_head_mfma(HeadW w, const float* 
       const float pth = wrap_angle(lth + hh);
       t[2] = sinf(pth);
       t[3] = cosf(pth);
-      const float vx = o[s * sdim + vcol] + w.m2b[s * sdim + vcol], vy = o[s * sdim + vcol + 1] + w.m2b[s * sdim + vcol + 1];
+      const float vx = o[s * sdim + vcol] + ob[s * sdim + vcol], vy = o[s * sdim + vcol + 1] + ob[s * sdim + vcol + 1];
       v[0] = vx * cl - vy * sl;
       v[1] = vy * cl + vx * sl;
     }

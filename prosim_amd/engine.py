@@ -39,7 +39,7 @@ class PsConfig(C.Structure):
         ("dt", C.c_float), ("ln_eps", C.c_float),
         ("device", C.c_int32),
         ("enc_learnable_pe", C.c_int32), ("dec_learnable_pe", C.c_int32), ("pol_learnable_pe", C.c_int32),
-        ("pe_num_freq", C.c_int32), ("v2v_tag_mask", C.c_int32), ("pred_gmm", C.c_int32),
+        ("pe_num_freq", C.c_int32), ("v2v_tag_mask", C.c_int32), ("pred_gmm", C.c_int32), ("k_pred_mlp", C.c_int32),
     ]
 
 
@@ -165,8 +165,10 @@ class Engine:
                        max_steps=spec.max_steps, dt=spec.dt, ln_eps=spec.ln_eps, device=device,
                        enc_learnable_pe=int(spec.enc_learnable_pe), dec_learnable_pe=int(spec.dec_learnable_pe),
                        pol_learnable_pe=int(spec.pol_learnable_pe), pe_num_freq=spec.pe_num_freq,
-                       v2v_tag_mask=sum(1 << V2V_TAGS.index(t) for t in spec.used_v2v_tags), pred_gmm=int(spec.pred_gmm))
-        tensors = dict(weights)
+                       v2v_tag_mask=sum(1 << V2V_TAGS.index(t) for t in spec.used_v2v_tags), pred_gmm=int(spec.pred_gmm),
+                       k_pred_mlp=int(spec.k_pred_mode == "mlp"))
+        from .weights import engine_tensors
+        tensors = dict(engine_tensors(spec, weights))   # ('cluster' anchors folded into the anchor table)
         tensors.update(fourier_tables())
         names = sorted(tensors)
         arrs = [np.ascontiguousarray(tensors[n], dtype=np.float32) for n in names]

@@ -86,6 +86,12 @@ class ModelSpec:
     # Drawn by the host with the reference's own torch.randn_like call (ProSimHip), handed to the engine as a table.
     action_noise_std: float = 0.0
     motion_k: int = 1                  # MODEL.POLICY.ACT_DECODER.TRAJ.K
+    # MODEL.POLICY.ACT_DECODER.TRAJ.PRED_MODE (act_decoder.py:47-76, :90-110; 'anchor' in every released config, 'mlp' is
+    # default.py:650's default): 'anchor' -- K learned anchors per agent type through CG_decode; 'cluster' -- the K anchors are
+    # cluster_mlp(FourierEmbeddingFix(k_goals)) of the K x 2 goal clusters in TRAJ.CLUSTER_PATH, the same for every type (a
+    # constant of the checkpoint: folded into the anchor table when the weights are handed to the engine); 'mlp' -- no anchors
+    # and no CG_decode, motion_head regresses all K modes at once (its last Linear has K * steps * state_dim outputs)
+    k_pred_mode: str = "anchor"
     rollout_top_k: int = 1             # ROLLOUT.POLICY.TOP_K (default.py:136): modes a rollout step draws from (host-side draw)
     num_agent_types: int = 3           # DATASET.USE_PED_CYCLIST -> anchors K*3 (act_decoder.py:66-68)
     prompt_dim: int = 7                # v_local(2)+extent(2)+type one-hot(3) (prompt_utils.py:111-150)
@@ -126,6 +132,11 @@ class ModelSpec:
         return self.target_steps * self.state_dim
 
     @property
+    def head_out_dim(self) -> int:
+        """Outputs of motion_head's last Linear (act_decoder.py:58-61)."""
+        return self.out_dim * (self.motion_k if self.k_pred_mode == "mlp" else 1)
+
+    @property
     def vel_col(self) -> int:
         """First of the two velocity columns of a predicted step (traj_sam.py:337-340)."""
         return 6 if self.pred_gmm else 3
@@ -136,6 +147,8 @@ class ModelSpec:
             out = dataclasses.replace(out, state_dim=8)
         if not out.pred_gmm and out.state_dim == 8:
             raise ValueError("state_dim 8 is the PRED_GMM layout: set pred_gmm=True")
+        if out.k_pred_mode not in ("anchor", "cluster", "mlp"):
+            raise ValueError(f"k_pred_mode {out.k_pred_mode!r}: 'anchor', 'cluster' or 'mlp'")
         return out
 
 

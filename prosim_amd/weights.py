@@ -152,14 +152,19 @@ def param_shapes(spec: ModelSpec) -> "OrderedDict[str, Tuple[int, ...]]":
     for i in range(spec.pol_layers):
         _attn_shapes(out, f"{pa}.a2p_attn_layers.{i}", d, hd, True)
         _attn_shapes(out, f"{pa}.m2p_attn_layers.{i}", d, hd, True)
-    # act_decoder.py:47-76 (anchor mode, USE_GOAL_PRED_LOSS)
-    _mlp_shapes(out, f"{pa}.motion_head", [d, d, d // 2, spec.out_dim], True, False)
-    for i in range(3):
-        out[f"{pa}.CG_decode.CGs.{i}.MLP.0.weight"] = (d, d)
-        out[f"{pa}.CG_decode.CGs.{i}.MLP.0.bias"] = (d,)
-        out[f"{pa}.CG_decode.CGs.{i}.MLP.1.weight"] = (d,)
-        out[f"{pa}.CG_decode.CGs.{i}.MLP.1.bias"] = (d,)
-    out[f"{pa}.motion_anchors.weight"] = (spec.motion_k * spec.num_agent_types, d)
+    # act_decoder.py:47-76 (TRAJ.PRED_MODE, USE_GOAL_PRED_LOSS)
+    _mlp_shapes(out, f"{pa}.motion_head", [d, d, d // 2, spec.head_out_dim], True, False)
+    if spec.k_pred_mode != "mlp":
+        for i in range(3):
+            out[f"{pa}.CG_decode.CGs.{i}.MLP.0.weight"] = (d, d)
+            out[f"{pa}.CG_decode.CGs.{i}.MLP.0.bias"] = (d,)
+            out[f"{pa}.CG_decode.CGs.{i}.MLP.1.weight"] = (d,)
+            out[f"{pa}.CG_decode.CGs.{i}.MLP.1.bias"] = (d,)
+    if spec.k_pred_mode == "anchor":
+        out[f"{pa}.motion_anchors.weight"] = (spec.motion_k * spec.num_agent_types, d)
+    elif spec.k_pred_mode == "cluster":
+        _mlp_shapes(out, f"{pa}.{CLUSTER_MLP}", [d, d], False, False)   # Linear + ReLU (:74)
+        out[CLUSTER_GOALS] = (spec.motion_k, 2)   # the content of TRAJ.CLUSTER_PATH (:72): not a state_dict entry
     _mlp_shapes(out, f"{pa}.pred_mlp", [d, d, d // 2, 2], True, False)
     # condition transformer at 'policy_decoder' (traj_sam.py:47-52; condition_encoders.py, condition_attns.py)
     ct = "condition_transformers.policy_decoder"
@@ -182,7 +187,9 @@ DRAG_ENCODER = "condition_encoders.drag_point.pointnet_encoder"
 OBS_UPDATE_MLP = "scene_encoder.obs_update_mlp"
 PE_EMB = "_rel_pe_emb."
 V2V_ENCODER = "condition_encoders.v2v_tag."
-_LATE = (DRAG_ENCODER, OBS_UPDATE_MLP, PE_EMB, V2V_ENCODER)   # tensor groups added after the first fixtures: each draws from its own generator
+CLUSTER_MLP = "cluster_mlp"
+CLUSTER_GOALS = "policy.act_decoder.k_goals"
+_LATE = (DRAG_ENCODER, OBS_UPDATE_MLP, PE_EMB, V2V_ENCODER, CLUSTER_MLP, CLUSTER_GOALS)   # tensor groups added after the first fixtures: each draws from its own generator
 
 
 def init_weights(spec: ModelSpec, seed: int = 0) -> Dict[str, np.ndarray]:
@@ -212,6 +219,8 @@ def init_weights(spec: ModelSpec, seed: int = 0) -> Dict[str, np.ndarray]:
             t = 0.1 * torch.randn(shp, generator=g)
         elif "motion_anchors" in name or "tag_encoder" in name:
             t = torch.randn(shp, generator=g)
+        elif name == CLUSTER_GOALS:   # goal clusters: points a few tens of metres out
+            t = 20.0 * torch.randn(shp, generator=g)
         elif name.endswith(".freqs.weight"):   # (the reference initialises N(0, 0.02), weight_init.py:18-19; wider here so
             t = 0.05 * torch.randn(shp, generator=g)   # that a 100 m distance sweeps several periods)
         elif len(shp) == 2:
@@ -230,10 +239,15 @@ def _is_mlp_ln(weight_name: str, shapes) -> bool:
     return ".mlp." in weight_name and weight_name in shapes and len(shapes[weight_name]) == 1
 
 
-def from_state_dict(spec: ModelSpec, state_dict) -> Dict[str, np.ndarray]:
-    """Pick the rollout-path tensors out of a reference ``state_dict`` (torch tensors or arrays)."""
+def from_state_dict(spec: ModelSpec, state_dict, k_goals=None) -> Dict[str, np.ndarray]:
+    """Pick the rollout-path tensors out of a reference ``state_dict`` (torch tensors or arrays).  ``k_goals`` [K, 2]: the content
+    of TRAJ.CLUSTER_PATH with TRAJ.PRED_MODE 'cluster' (the module keeps it as a plain attribute, not in the state_dict)."""
     w = {}
     for name, shp in param_shapes(spec).items():
+        if name == CLUSTER_GOALS:
+            if k_goals is None:
+                raise KeyError("TRAJ.PRED_MODE 'cluster': pass k_goals = np.load(TRAJ.CLUSTER_PATH)")
+            state_dict = dict(state_dict, **{name: np.asarray(k_goals, np.float32)})
         if name not in state_dict:
             raise KeyError(f"checkpoint lacks '{name}'")
         t = state_dict[name]
@@ -244,9 +258,36 @@ def from_state_dict(spec: ModelSpec, state_dict) -> Dict[str, np.ndarray]:
     return w
 
 
+def cluster_anchors(spec: ModelSpec, w: Dict[str, np.ndarray]) -> np.ndarray:
+    """TRAJ.PRED_MODE 'cluster' (act_decoder.py:70-74, :103-105): anchor_emd = cluster_mlp(FourierEmbeddingFix(d / 2)(k_goals)),
+    [K, d] -- input-independent, so it is a constant of the checkpoint.  fp32 like the module would compute it."""
+    g = np.asarray(w[CLUSTER_GOALS], np.float32)                                   # [K, 2]
+    n = spec.hidden // 2
+    dim_t = np.float32(spec.fourier_temperature) ** (2 * (np.arange(n, dtype=np.float32) // 2) / np.float32(n))   # fourier_embedding.py:68-69
+    dim_t = dim_t.astype(np.float32)
+    pos = g * np.float32(2 * np.pi)
+    cols = []
+    for i in range(2):
+        a = (pos[:, i, None] / dim_t).astype(np.float32)                           # [K, n]
+        cols.append(np.stack([np.sin(a[:, 0::2]), np.cos(a[:, 1::2])], axis=-1).reshape(g.shape[0], n))
+    pe = np.concatenate(cols, axis=-1).astype(np.float32)                          # [K, d]
+    pa = f"policy.act_decoder.{CLUSTER_MLP}.mlp.0"
+    return np.maximum(pe @ np.asarray(w[pa + ".weight"], np.float32).T + np.asarray(w[pa + ".bias"], np.float32), 0).astype(np.float32)
+
+
+def engine_tensors(spec: ModelSpec, w: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
+    """The tensors ps_create takes: the checkpoint's, with its input-independent sub-graphs folded -- 'cluster' anchors become
+    the (type-independent) rows of the anchor table the head kernel indexes by (agent type, mode)."""
+    if spec.k_pred_mode != "cluster":
+        return w
+    out = {k: v for k, v in w.items() if k != CLUSTER_GOALS and f".{CLUSTER_MLP}." not in k}
+    out["policy.act_decoder.motion_anchors.weight"] = np.ascontiguousarray(np.tile(cluster_anchors(spec, w), (spec.num_agent_types, 1)))
+    return out
+
+
 def to_reference_state_dict(spec: ModelSpec, w: Dict[str, np.ndarray]) -> Dict[str, torch.Tensor]:
     """Our dict + the aliased ``attn_prenorm_x_dst`` keys the reference state_dict carries."""
-    sd = {k: torch.from_numpy(np.array(v)) for k, v in w.items()}
+    sd = {k: torch.from_numpy(np.array(v)) for k, v in w.items() if k != CLUSTER_GOALS}
     for k in list(sd):
         if ".attn_prenorm_x_src." in k:
             alias = k.replace(".attn_prenorm_x_src.", ".attn_prenorm_x_dst.")

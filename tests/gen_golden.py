@@ -76,13 +76,20 @@ FULL_CASES = {
     # beside prompts with two DIFFERENT tags (both count in the mean pool)
     "small_duptag_b2": ("small", dict(n_agents=16, n_polylines=128, batch=2, seed=19, goal=True, tags=True, dup_tags=True, ragged=True), 0),
     "small_noise_gmm_b2": ("small_noise_gmm", dict(n_agents=16, n_polylines=128, batch=2, seed=17, goal=True, ragged=True, replay=0.3), 0),
+    # TRAJ.PRED_MODE 'cluster' (act_decoder.py:70-74, :103-105: the K anchors from a goal-cluster file through cluster_mlp) and
+    # 'mlp' (:57-58, :90-91: no anchors, no CG_decode, all K modes from motion_head) -- default.py:650's default is 'mlp',
+    # every released yaml says 'anchor'.  Both with K > 1 and TOP_K = K, so the recorded mode draws pick every column block.
+    "small_cluster_b2": ("small_cluster", dict(n_agents=16, n_polylines=128, batch=2, seed=21, goal=True, ragged=True, replay=0.3), 0),
+    "small_mlphead_b2": ("small_mlphead", dict(n_agents=16, n_polylines=128, batch=2, seed=22, goal=True, tags=True, ragged=True), 0),
 }
 SPECS = {"small": SMALL_SPEC, "demo": DEMO_SPEC, "small_mlp": SMALL_SPEC.replace(obs_fusion="mlp"),
          "small_mlp_attn": SMALL_SPEC.replace(obs_fusion="mlp", obs_attn_update=True),
          "small_k3": SMALL_SPEC.replace(motion_k=3, rollout_top_k=3),
          "small_v2v": SMALL_SPEC.replace(used_v2v_tags=("Following", "Merging", "Overtaking")),
          "small_lpe": SMALL_SPEC.replace(enc_learnable_pe=True, dec_learnable_pe=True, pol_learnable_pe=True, pe_num_freq=64),
-         "small_noise_gmm": SMALL_SPEC.replace(pred_gmm=True, action_noise_std=0.05)}
+         "small_noise_gmm": SMALL_SPEC.replace(pred_gmm=True, action_noise_std=0.05),
+         "small_cluster": SMALL_SPEC.replace(k_pred_mode="cluster", motion_k=3, rollout_top_k=3),
+         "small_mlphead": SMALL_SPEC.replace(k_pred_mode="mlp", motion_k=2, rollout_top_k=2)}
 TOPK_SEED = 777   # torch.manual_seed before a forward whose rollout draws modes
 
 
@@ -97,12 +104,22 @@ def ref_overrides(spec: ModelSpec):
             "MODEL.SCENE_ENCODER.ATTN.LEARNABLE_PE", spec.enc_learnable_pe, "MODEL.SCENE_ENCODER.ATTN.PE_NUM_FREQ", spec.pe_num_freq,
             "MODEL.DECODER.ATTN.LEARNABLE_PE", spec.dec_learnable_pe, "MODEL.DECODER.ATTN.PE_NUM_FREQ", spec.pe_num_freq,
             "MODEL.POLICY.ACT_DECODER.ATTN.LEARNABLE_PE", spec.pol_learnable_pe, "MODEL.POLICY.ACT_DECODER.ATTN.PE_NUM_FREQ", spec.pe_num_freq,
-            "MODEL.POLICY.ACT_DECODER.TRAJ.PRED_GMM", spec.pred_gmm, "MODEL.POLICY.ACT_DECODER.RANDOM_NOISE_STD", spec.action_noise_std]
+            "MODEL.POLICY.ACT_DECODER.TRAJ.PRED_GMM", spec.pred_gmm, "MODEL.POLICY.ACT_DECODER.RANDOM_NOISE_STD", spec.action_noise_std,
+            "MODEL.POLICY.ACT_DECODER.TRAJ.PRED_MODE", spec.k_pred_mode]
 
 
 def run_reference(spec, w, scene):
     cond_types = ("goal", "v_action_tag", "drag_point") + (("v2v_tag",) if spec.used_v2v_tags else ())
     cfg = rh.get_config(cond_types=cond_types, overrides=ref_overrides(spec))
+    if spec.k_pred_mode == "cluster":
+        # the module reads its K x 2 goal clusters from TRAJ.CLUSTER_PATH when it is built (act_decoder.py:71-72) -- a key that
+        # config/default.py does not declare: set on the node directly
+        import tempfile
+        path = os.path.join(tempfile.mkdtemp(), "k_goals.npy")
+        np.save(path, np.asarray(w[weights.CLUSTER_GOALS], np.float32))
+        cfg.defrost()
+        cfg.MODEL.POLICY.ACT_DECODER.TRAJ.CLUSTER_PATH = path
+        cfg.freeze()
     model = rh.build_model(cfg)
     missing, unexpected = model.load_state_dict(weights.to_reference_state_dict(spec, w), strict=False)
     assert not unexpected, unexpected

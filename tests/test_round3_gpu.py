@@ -280,3 +280,34 @@ def test_encoder_s2s_layers_on_k_chain16(rows):
         assert (d < TOL).mean() >= 0.97 and np.median(d) < 3e-5, ((d < TOL).mean(), np.median(d), d.max())
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("name", ["small_cluster_b2", "small_mlphead_b2"])
+def test_pred_mode_cluster_and_mlp_through_the_model(name):
+    """TRAJ.PRED_MODE 'cluster' (anchors folded from the goal-cluster file) and 'mlp' (all K modes from motion_head, no
+    CG_decode) through the registry-level model with TOP_K = K: the fixture's seed reproduces the reference's mode draws, and
+    the engine its trajectories; motion_pred carries K modes per agent."""
+    from prosim_amd import modules
+    sname, kw, wseed = FULL_CASES[name]
+    spec = SPECS[sname]
+    g = np.load(os.path.join(GOLD, f"ref_standins_{name}.npz"))
+    scene = synth.make_scene(spec, **kw)
+    model = modules.ProSimHip(spec, weights.init_weights(spec, wseed))
+    try:
+        batch = rh.make_batch(scene, spec)
+        torch.manual_seed(int(g["torch_seed"]))
+        out = model.forward(batch, "val")["motion_pred"]
+        pm = scene["prompt_mask"].astype(bool)
+        assert np.array_equal(model._last_mode_choice[:, pm], g["mode_choice"][:, pm])
+        assert len(np.unique(g["mode_choice"][:, pm])) == spec.motion_k           # every mode is followed somewhere
+        A = int(pm.sum())
+        assert out["motion_pred"].shape == (spec.n_replans * A, spec.motion_k, spec.target_steps, spec.state_dim)
+        assert err(out["motion_pred"][:A].numpy(), g["motion_pred"][:A]) < TOL
+        floor = dict(zip(("traj", "vel", "motion_pred"), g["fp32_floor"]))
+        for b in range(pm.shape[0]):
+            for n in np.nonzero(pm[b])[0]:
+                r = out["rollout_trajs"][f"{b}-a{n}"]
+                assert err(r["traj"].numpy(), g["traj"][b, n]) < 3 * floor["traj"] + TOL
+                assert err(r["vel"].numpy(), g["vel"][b, n]) < 3 * floor["vel"] + TOL
+    finally:
+        model.close()
