@@ -345,10 +345,9 @@ def update_scene_attn(Wt: W, spec: ModelSpec, scene: Dict) -> Dict:
     m_b, o_b = scene["scene_batch_idx"][mt], scene["scene_batch_idx"][ot]
     a_dst, a_src = radius_edges(o_pos, o_b, o_pos, o_b, spec.enc_agent_radius, spec.scene_knn, drop_self=True)
     m_dst, m_src = radius_edges(m_pos, m_b, o_pos, o_b, spec.enc_scene_radius, spec.scene_knn)
-    if spec.enc_learnable_pe:
-        raise NotImplementedError("OBS_UPDATE.ATTN_UPDATE with a learnable scene-encoder PE is not restated")
-    a_pe = rel_pe(spec, a_src, a_dst, o_ori, o_pos, o_ori, o_pos)
-    m_pe = rel_pe(spec, m_src, m_dst, o_ori, o_pos, m_ori, m_pos)
+    # (:158-159, :44-76: the agent-agent rows from a2a_rel_pe_emb, the map -> agent rows from s2s_rel_pe_emb when LEARNABLE_PE)
+    a_pe = rel_pe(spec, a_src, a_dst, o_ori, o_pos, o_ori, o_pos, Wt, _emb(spec, "scene_encoder", "a2a"))
+    m_pe = rel_pe(spec, m_src, m_dst, o_ori, o_pos, m_ori, m_pos, Wt, _emb(spec, "scene_encoder", "s2s"))
     x_a, x_m = scene["scene_tokens"][ot], scene["scene_tokens"][mt]
     for i in range(spec.scene_layers):
         x_a = attention_layer(Wt, f"scene_encoder.a2a_attn_layers.{i}", spec, x_a, x_a, a_pe, a_src, a_dst, False)

@@ -186,6 +186,10 @@ const PeLearnW* pe_of(const ps_engine* e, const EdgeSet* es) {
   const EdgeSet* sets[6] = {&e->e_a2a, &e->e_s2s, &e->e_p2p, &e->e_s2p, &e->e_a2p, &e->e_m2p};
   for (int i = 0; i < 6; ++i)
     if (es == sets[i]) return e->pe_on[i / 2] ? &e->pe_learn[i] : nullptr;
+  // ATTN_UPDATE's sets take the scene encoder's embeddings: agents <- agents a2a_rel_pe_emb, agents <- map s2s_rel_pe_emb
+  // (attn_fusion.py:158-159 through :44-76)
+  if (es == &e->e_ua) return e->pe_on[0] ? &e->pe_learn[0] : nullptr;
+  if (es == &e->e_um) return e->pe_on[0] ? &e->pe_learn[1] : nullptr;
   return nullptr;
 }
 }
@@ -543,8 +547,6 @@ extern "C" int ps_create(const ps_config* cfg, int32_t n_tensors, const char* co
   const bool any_lpe = cfg->enc_learnable_pe || cfg->dec_learnable_pe || cfg->pol_learnable_pe;
   if (any_lpe && cfg->pe_num_freq != 64)
     return fail(PS_E_ARG, "learnable rel-PE: this build supports PE_NUM_FREQ = 64 (the reference's default) only");
-  if (cfg->enc_learnable_pe && cfg->obs_attn_update)
-    return fail(PS_E_ARG, "OBS_UPDATE.ATTN_UPDATE together with a learnable scene-encoder rel-PE is not supported");
   if (hipSetDevice(cfg->device) != hipSuccess) return fail(PS_E_HIP, "hipSetDevice failed (no GPU?)");
   ps_engine* e = new ps_engine();
   e->cfg = *cfg;
@@ -1943,8 +1945,8 @@ extern "C" int ps_policy_step(ps_engine* e, int32_t t_idx) {
       // the map (radius) through the scene encoder's own a2a / s2s layers, at their new poses
       const float* qpos = e->d_tok_pos.p + 2 * (size_t)Mv;
       const float* qori = e->d_tok_ori.p + Mv;
-      const RadArgs ru[2] = {{&e->e_ua, e->d_r_agent.p, nullptr, c.enc_agent_radius, c.scene_knn, Mv, live, Mv},
-                             {&e->e_um, e->d_r_map.p, nullptr, c.enc_scene_radius, c.scene_knn, -1}};
+      const RadArgs ru[2] = {{&e->e_ua, e->d_r_agent.p, nullptr, c.enc_agent_radius, c.scene_knn, Mv, live, Mv, pe_of(e, &e->e_ua)},
+                             {&e->e_um, e->d_r_map.p, nullptr, c.enc_scene_radius, c.scene_knn, -1, nullptr, 0, pe_of(e, &e->e_um)}};
       launch_radius(e, ru, 2, qpos, e->d_tok_scene.p + Mv, A, e->d_tok_ori.p, qori);
       const int mdu = std::max(e->e_ua.maxdeg, e->e_um.maxdeg);
       for (int i = 0; i < c.scene_layers; ++i) {

@@ -79,6 +79,9 @@ FULL_CASES = {
     # TRAJ.PRED_MODE 'cluster' (act_decoder.py:70-74, :103-105: the K anchors from a goal-cluster file through cluster_mlp) and
     # 'mlp' (:57-58, :90-91: no anchors, no CG_decode, all K modes from motion_head) -- default.py:650's default is 'mlp',
     # every released yaml says 'anchor'.  Both with K > 1 and TOP_K = K, so the recorded mode draws pick every column block.
+    # OBS_UPDATE.ATTN_UPDATE with SCENE_ENCODER.ATTN.LEARNABLE_PE: the re-attention's two edge sets take their rows from the
+    # scene encoder's learnable embeddings (attn_fusion.py:158-159: a2a_rel_pe_emb / s2s_rel_pe_emb)
+    "small_attn_update_lpe_b2": ("small_attn_lpe", dict(n_agents=16, n_polylines=128, batch=2, seed=24, goal=True, ragged=True, replay=0.3), 0),
     "small_cluster_b2": ("small_cluster", dict(n_agents=16, n_polylines=128, batch=2, seed=21, goal=True, ragged=True, replay=0.3), 0),
     "small_mlphead_b2": ("small_mlphead", dict(n_agents=16, n_polylines=128, batch=2, seed=22, goal=True, tags=True, ragged=True), 0),
 }
@@ -88,6 +91,7 @@ SPECS = {"small": SMALL_SPEC, "demo": DEMO_SPEC, "small_mlp": SMALL_SPEC.replace
          "small_v2v": SMALL_SPEC.replace(used_v2v_tags=("Following", "Merging", "Overtaking")),
          "small_lpe": SMALL_SPEC.replace(enc_learnable_pe=True, dec_learnable_pe=True, pol_learnable_pe=True, pe_num_freq=64),
          "small_noise_gmm": SMALL_SPEC.replace(pred_gmm=True, action_noise_std=0.05),
+         "small_attn_lpe": SMALL_SPEC.replace(obs_attn_update=True, enc_learnable_pe=True, pe_num_freq=64),
          "small_cluster": SMALL_SPEC.replace(k_pred_mode="cluster", motion_k=3, rollout_top_k=3),
          "small_mlphead": SMALL_SPEC.replace(k_pred_mode="mlp", motion_k=2, rollout_top_k=2)}
 TOPK_SEED = 777   # torch.manual_seed before a forward whose rollout draws modes
