@@ -22,12 +22,19 @@ if os.environ.get("FUZZ_R2"):   # round-2 variants: learnable rel-PE (all parts 
                 SMALL_SPEC.replace(used_v2v_tags=("Following", "Merging", "Overtaking")),
                 SMALL_SPEC.replace(used_v2v_tags=("ParallelDriving",), dec_learnable_pe=True),
                 SMALL_SPEC.replace(motion_k=3, rollout_top_k=3)]
+if os.environ.get("FUZZ_R3"):   # round-3 variants: noise + GMM head, PRED_MODE cluster / mlp, ATTN_UPDATE with a learnable encoder PE
+    variants = [SMALL_SPEC.replace(pred_gmm=True, action_noise_std=0.05),
+                SMALL_SPEC.replace(k_pred_mode="cluster", motion_k=3, rollout_top_k=3),
+                SMALL_SPEC.replace(k_pred_mode="mlp", motion_k=2, rollout_top_k=2),
+                SMALL_SPEC.replace(k_pred_mode="mlp", motion_k=1, pred_gmm=True),
+                SMALL_SPEC.replace(obs_attn_update=True, enc_learnable_pe=True),
+                SMALL_SPEC.replace(obs_attn_update=True, enc_learnable_pe=True, obs_fusion="mlp", k_pred_mode="cluster", motion_k=2)]
 engines = {}
 worst = 0.0
 bad = []
 t0 = time.time()
 for case in range(n_cases):
-    spec = variants[rng.randint(len(variants)) if (rng.rand() < 0.4 or os.environ.get("FUZZ_R2")) else 0]
+    spec = variants[rng.randint(len(variants)) if (rng.rand() < 0.4 or os.environ.get("FUZZ_R2") or os.environ.get("FUZZ_R3")) else 0]
     if rng.rand() < 0.35:   # small neighbour caps / radii: the index-order truncation and the degree-bound paths
         spec = spec.replace(dec_max_neigh=int(rng.choice([4, 16, 512])), pol_max_neigh=int(rng.choice([3, 12, 768])),
                             scene_knn=int(rng.choice([2, 8, 32])), dec_prompt_radius=float(rng.choice([20.0, 300.0])),
@@ -53,8 +60,9 @@ for case in range(n_cases):
         continue
     if spec.motion_k > 1:
         scene["mode_choice"] = rng.randint(0, spec.motion_k, (spec.n_replans,) + scene["prompt_mask"].shape).astype(np.int32)
-    key = (spec.enc_learnable_pe, spec.dec_learnable_pe, spec.pol_learnable_pe, spec.used_v2v_tags, spec.motion_k, spec.obs_fusion, spec.obs_attn_update, spec.dec_max_neigh, spec.pol_max_neigh, spec.scene_knn, spec.dec_prompt_radius,
-           spec.dec_scene_radius, spec.pol_agent_radius, spec.pol_map_radius, spec.enc_agent_radius, spec.enc_scene_radius)
+    if spec.action_noise_std > 0:
+        scene["action_noise"] = (rng.standard_normal((spec.n_replans,) + scene["prompt_mask"].shape + (spec.motion_k, spec.target_steps, 2)) * spec.action_noise_std).astype(np.float32)
+    key = repr(spec)
     if len(engines) > 12:   # bounded number of live engines
         for eng_, _ in engines.values():
             eng_.close()
