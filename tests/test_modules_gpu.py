@@ -233,14 +233,16 @@ def test_agents_entering_the_scene_vs_fixture(model):
         assert err(listed_form["rollout_trajs"][k]["traj"].numpy(), r["traj"].numpy()) < 3 * floor + 1e-4
 
 
-@pytest.mark.parametrize("variant", ["fixed_pe", "learnable_pe"])
+@pytest.mark.parametrize("variant", ["fixed_pe", "learnable_pe", "mlp_head", "cluster_head"])
 def test_staged_components_and_stateless_policy(model, variant):
     """scene_encoder(...) -> decoder(...) -> policy(...) with the reference's argument layouts (with the fixed Fourier
     rel-PE and with the learnable one: the stateless policy call builds its own edge sets and rows)."""
     spec = SMALL_SPEC
-    if variant == "learnable_pe":
+    if variant != "fixed_pe":
         from prosim_amd import modules
-        spec = SMALL_SPEC.replace(enc_learnable_pe=True, dec_learnable_pe=True, pol_learnable_pe=True)
+        spec = {"learnable_pe": SMALL_SPEC.replace(enc_learnable_pe=True, dec_learnable_pe=True, pol_learnable_pe=True),
+                "mlp_head": SMALL_SPEC.replace(k_pred_mode="mlp", motion_k=2),          # TRAJ.PRED_MODE through ps_policy_forward
+                "cluster_head": SMALL_SPEC.replace(k_pred_mode="cluster", motion_k=3)}[variant]
         model = modules.registry.get_model("prosim_policy_relpe_T_step_temporal_close_loop")(spec, weights.init_weights(spec, 0)).eval()
     scene = synth.make_scene(spec, 12, 40, batch=2, seed=4, ragged=True)
     w = weights.init_weights(spec, 0)
@@ -279,7 +281,8 @@ def test_staged_components_and_stateless_policy(model, variant):
     A = int(pm.sum())
     assert out["latent_state"] is None and model.policy.format_latent_state({}, [names]) is None
     assert err(out["motion_pred"].numpy(), o["motion_pred"][:A].numpy()) < 1e-4
-    assert torch.equal(out["motion_prob"], torch.ones(A, 1))
+    assert out["motion_pred"].shape == (A, spec.motion_k, spec.target_steps, spec.state_dim)
+    assert torch.equal(out["motion_prob"], torch.ones(A, spec.motion_k))
     with pytest.raises(AssertionError):
         model.policy(pol_emd, bo, bm, pos, names[:-1], None)
     # update_scene_emb (attn_fusion.py:238-252, FUSION 'replace'): agents re-encoded from a new observation, map tokens kept
@@ -318,5 +321,5 @@ def test_staged_components_and_stateless_policy(model, variant):
     assert err(se3["scene_tokens"][Mv:].numpy(), emb3[valid3].numpy()) < 1e-4
     assert err(se3["scene_pos"][Mv:].numpy(), changed["position"][valid3].numpy()) == 0
     assert torch.equal(se3["scene_batch_idx"][Mv:], orc._flat_batch_idx(valid3))
-    if variant == "learnable_pe":
+    if variant != "fixed_pe":
         model.engine.close()
