@@ -54,7 +54,8 @@ typedef struct ps_config {
   int32_t device;                              /* HIP device ordinal */
   /* *.ATTN.LEARNABLE_PE of the scene encoder / the decoder / the policy (default.py:472, :594, :665; 0 in the demo): the
    * relative-PE rows of that part's two edge sets come from a learnable FourierEmbedding (layers/fourier_embedding.py:11-54;
-   * weights "<part>.<set>_rel_pe_emb.*") instead of the fixed one.  pe_num_freq = PE_NUM_FREQ, must be 64 (the default). */
+   * weights "<part>.<set>_rel_pe_emb.*") instead of the fixed one.  pe_num_freq must be 64 (the reference's default): an embedding
+   * with fewer bands is handed over zero-padded (freqs [3][64], mlps.i.0.weight [128][129] = cos 64 | sin 64 | x; extra bands 0). */
   int32_t enc_learnable_pe, dec_learnable_pe, pol_learnable_pe, pe_num_freq;
   /* Binary (agent-pair) tags: bit t set = V2V_MotionTag value t (Following, ParallelDriving, Merging, ByPassing, Overtaking;
    * dataset/motion_tag_utils.py:17-22) is among PROMPT.CONDITION.MOTION_TAG.USED_TAGS -> weight

@@ -164,7 +164,8 @@ class Engine:
                        num_agent_types=spec.num_agent_types, prompt_dim=spec.prompt_dim, replan_freq=spec.replan_freq,
                        max_steps=spec.max_steps, dt=spec.dt, ln_eps=spec.ln_eps, device=device,
                        enc_learnable_pe=int(spec.enc_learnable_pe), dec_learnable_pe=int(spec.dec_learnable_pe),
-                       pol_learnable_pe=int(spec.pol_learnable_pe), pe_num_freq=spec.pe_num_freq,
+                       pol_learnable_pe=int(spec.pol_learnable_pe),
+                       pe_num_freq=64 if spec.pe_num_freq <= 64 else spec.pe_num_freq,   # (fewer bands: zero-padded by weights.engine_tensors)
                        v2v_tag_mask=sum(1 << V2V_TAGS.index(t) for t in spec.used_v2v_tags), pred_gmm=int(spec.pred_gmm),
                        k_pred_mlp=int(spec.k_pred_mode == "mlp"))
         from .weights import engine_tensors

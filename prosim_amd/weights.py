@@ -188,6 +188,7 @@ OBS_UPDATE_MLP = "scene_encoder.obs_update_mlp"
 PE_EMB = "_rel_pe_emb."
 V2V_ENCODER = "condition_encoders.v2v_tag."
 CLUSTER_MLP = "cluster_mlp"
+ENGINE_PE_FREQ = 64   # frequency bands of the engine's learnable relative-PE kernel (k_pe_learn)
 CLUSTER_GOALS = "policy.act_decoder.k_goals"
 _LATE = (DRAG_ENCODER, OBS_UPDATE_MLP, PE_EMB, V2V_ENCODER, CLUSTER_MLP, CLUSTER_GOALS)   # tensor groups added after the first fixtures: each draws from its own generator
 
@@ -278,10 +279,28 @@ def cluster_anchors(spec: ModelSpec, w: Dict[str, np.ndarray]) -> np.ndarray:
 def engine_tensors(spec: ModelSpec, w: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
     """The tensors ps_create takes: the checkpoint's, with its input-independent sub-graphs folded -- 'cluster' anchors become
     the (type-independent) rows of the anchor table the head kernel indexes by (agent type, mode)."""
-    if spec.k_pred_mode != "cluster":
-        return w
-    out = {k: v for k, v in w.items() if k != CLUSTER_GOALS and f".{CLUSTER_MLP}." not in k}
-    out["policy.act_decoder.motion_anchors.weight"] = np.ascontiguousarray(np.tile(cluster_anchors(spec, w), (spec.num_agent_types, 1)))
+    out = w
+    if spec.k_pred_mode == "cluster":
+        out = {k: v for k, v in w.items() if k != CLUSTER_GOALS and f".{CLUSTER_MLP}." not in k}
+        out["policy.act_decoder.motion_anchors.weight"] = np.ascontiguousarray(np.tile(cluster_anchors(spec, w), (spec.num_agent_types, 1)))
+    nf = spec.pe_num_freq
+    if pe_emb_prefixes(spec) and nf != ENGINE_PE_FREQ:
+        # *.ATTN.PE_NUM_FREQ below the engine's 64 bands: the embedding is the 64-band one whose extra bands have frequency 0 and
+        # zero weights -- their features (cos 0 = 1, sin 0 = 0) meet zero columns of the first Linear, exact zeros in every sum
+        if not 1 <= nf < ENGINE_PE_FREQ:
+            raise ValueError(f"PE_NUM_FREQ {nf}: the engine's learnable relative-PE takes up to {ENGINE_PE_FREQ} frequency bands")
+        out = dict(out)
+        for prefix in pe_emb_prefixes(spec):
+            fr = np.zeros((3, ENGINE_PE_FREQ), np.float32)
+            fr[:, :nf] = w[f"{prefix}.freqs.weight"]
+            out[f"{prefix}.freqs.weight"] = fr
+            for i in range(3):   # columns of mlps[i][0]: [cos (nf) | sin (nf) | x]  (fourier_embedding.py:45-49)
+                W0 = np.asarray(w[f"{prefix}.mlps.{i}.0.weight"], np.float32)
+                P = np.zeros((W0.shape[0], 2 * ENGINE_PE_FREQ + 1), np.float32)
+                P[:, :nf] = W0[:, :nf]
+                P[:, ENGINE_PE_FREQ:ENGINE_PE_FREQ + nf] = W0[:, nf:2 * nf]
+                P[:, 2 * ENGINE_PE_FREQ] = W0[:, 2 * nf]
+                out[f"{prefix}.mlps.{i}.0.weight"] = P
     return out
 
 

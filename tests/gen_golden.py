@@ -82,6 +82,8 @@ FULL_CASES = {
     # OBS_UPDATE.ATTN_UPDATE with SCENE_ENCODER.ATTN.LEARNABLE_PE: the re-attention's two edge sets take their rows from the
     # scene encoder's learnable embeddings (attn_fusion.py:158-159: a2a_rel_pe_emb / s2s_rel_pe_emb)
     "small_attn_update_lpe_b2": ("small_attn_lpe", dict(n_agents=16, n_polylines=128, batch=2, seed=24, goal=True, ragged=True, replay=0.3), 0),
+    # LEARNABLE_PE with PE_NUM_FREQ = 16 (the engine's kernel has 64 bands: zero-padded on the host)
+    "small_lpe16_b2": ("small_lpe16", dict(n_agents=16, n_polylines=128, batch=2, seed=25, goal=True, tags=True, ragged=True), 0),
     "small_cluster_b2": ("small_cluster", dict(n_agents=16, n_polylines=128, batch=2, seed=21, goal=True, ragged=True, replay=0.3), 0),
     "small_mlphead_b2": ("small_mlphead", dict(n_agents=16, n_polylines=128, batch=2, seed=22, goal=True, tags=True, ragged=True), 0),
 }
@@ -92,6 +94,7 @@ SPECS = {"small": SMALL_SPEC, "demo": DEMO_SPEC, "small_mlp": SMALL_SPEC.replace
          "small_lpe": SMALL_SPEC.replace(enc_learnable_pe=True, dec_learnable_pe=True, pol_learnable_pe=True, pe_num_freq=64),
          "small_noise_gmm": SMALL_SPEC.replace(pred_gmm=True, action_noise_std=0.05),
          "small_attn_lpe": SMALL_SPEC.replace(obs_attn_update=True, enc_learnable_pe=True, pe_num_freq=64),
+         "small_lpe16": SMALL_SPEC.replace(enc_learnable_pe=True, dec_learnable_pe=True, pol_learnable_pe=True, pe_num_freq=16),
          "small_cluster": SMALL_SPEC.replace(k_pred_mode="cluster", motion_k=3, rollout_top_k=3),
          "small_mlphead": SMALL_SPEC.replace(k_pred_mode="mlp", motion_k=2, rollout_top_k=2)}
 TOPK_SEED = 777   # torch.manual_seed before a forward whose rollout draws modes

@@ -53,3 +53,20 @@ def test_head_shapes_by_mode():
         assert ("policy.act_decoder.motion_anchors.weight" in sh) == anchors
     with pytest.raises(ValueError):
         SMALL_SPEC.replace(k_pred_mode="vel_pred")
+
+
+def test_fewer_pe_frequency_bands_are_zero_padded_exactly():
+    """*.ATTN.PE_NUM_FREQ below the engine's 64 bands: weights.engine_tensors hands over the 64-band embedding whose extra bands have
+    frequency 0 and zero first-Linear columns -- the oracle's FourierEmbedding on the padded tensors equals the original's."""
+    spec = SMALL_SPEC.replace(pol_learnable_pe=True, pe_num_freq=16)
+    w = weights.init_weights(spec, 0)
+    et = weights.engine_tensors(spec, w)
+    p = "policy.act_decoder.a2p_rel_pe_emb"
+    assert et[p + ".freqs.weight"].shape == (3, 64) and et[p + ".mlps.1.0.weight"].shape == (spec.hidden, 129)
+    assert w[p + ".freqs.weight"].shape == (3, 16)                          # the caller's dict is untouched
+    x = torch.tensor(np.random.RandomState(0).uniform(-3, 3, (50, 3)), dtype=torch.float64)
+    a = orc.fourier_learn({k: torch.from_numpy(v).double() for k, v in w.items()}, p, x)
+    b = orc.fourier_learn({k: torch.from_numpy(np.asarray(v)).double() for k, v in et.items()}, p, x)
+    assert float((a - b).abs().max()) < 1e-12
+    with pytest.raises(ValueError):
+        weights.engine_tensors(spec.replace(pe_num_freq=128), weights.init_weights(spec.replace(pe_num_freq=128), 0))
