@@ -69,6 +69,11 @@ typedef struct ps_config {
    * "policy.act_decoder.motion_anchors.weight", K rows repeated per agent type); 1 = 'mlp': no anchors, no CG_decode, the last
    * Linear of motion_head has motion_k * target_steps * state_dim (<= 128) outputs, mode-major. */
   int32_t k_pred_mlp;
+  /* !MODEL.POLICY.ACT_DECODER.TRAJ.PRED_VEL (1 = PRED_VEL False, default.py:652's default; every released yaml sets True = 0 here):
+   * the predicted state has no xd, yd -- state_dim 3, or 6 with pred_gmm -- no velocity track is kept ("vel" reads zeros), and
+   * step_env takes the observation's velocity / acceleration columns from position differences over hist_steps + 2 steps
+   * (traj_sam.py:251-260, :552-560); needs replan_freq >= 2. */
+  int32_t no_pred_vel;
 } ps_config;
 
 /* Create an engine and upload weights.  names[i] are reference state_dict keys

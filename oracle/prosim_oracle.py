@@ -668,7 +668,10 @@ def rollout(w: Dict[str, np.ndarray], spec: ModelSpec, scene_in: Dict, dtype=tor
             abs_tr = traj[:, :, last - H - 2:last]
             rel_tr = rel_traj_coord_to_last_step(abs_tr)
             th_last = torch.atan2(abs_tr[..., 2], abs_tr[..., 3])[..., -1:]
-            rel_v = batch_rotate_2d(vel[:, :, last - H - 1:last], -th_last)      # rel_vel_coord_to_last_step
+            if spec.pred_vel:
+                rel_v = batch_rotate_2d(vel[:, :, last - H - 1:last], -th_last)  # rel_vel_coord_to_last_step
+            else:                                                                # (:259, :553-554) velocities from the positions
+                rel_v = torch.diff(rel_tr[..., :2], dim=2) / spec.dt
             rel_acc = torch.diff(rel_v, dim=2) / spec.dt                            # _get_rel_vel_acc
             rva = torch.cat([rel_v[:, :, 1:], rel_acc], dim=-1)
             f_in[prompt_mask, :, :4] = rel_tr[prompt_mask][:, -H:]
@@ -707,7 +710,8 @@ def rollout(w: Dict[str, np.ndarray], spec: ModelSpec, scene_in: Dict, dtype=tor
         new_t = torch.zeros(B, N, spec.replan_freq, 4, dtype=dtype)
         new_t[prompt_mask] = fut
         new_v = torch.zeros(B, N, spec.replan_freq, 2, dtype=dtype)
-        new_v[prompt_mask] = batch_rotate_2d(pred[..., spec.vel_col:spec.vel_col + 2], lth)   # (6:8 with PRED_GMM, traj_sam.py:337-340)
+        if spec.pred_vel:
+            new_v[prompt_mask] = batch_rotate_2d(pred[..., spec.vel_col:spec.vel_col + 2], lth)   # (6:8 with PRED_GMM, traj_sam.py:337-340)
         traj[:, :, last:last + spec.replan_freq] = new_t
         vel[:, :, last:last + spec.replan_freq] = new_v
         last += spec.replan_freq

@@ -535,11 +535,13 @@ extern "C" int ps_create(const ps_config* cfg, int32_t n_tensors, const char* co
   if (!cfg || !out) return fail(PS_E_ARG, "null argument");
   if (cfg->hidden != D || cfg->heads != H || cfg->head_dim != DH)
     return fail(PS_E_ARG, "this build supports hidden=128, heads=8, head_dim=16 only");
-  if (cfg->hist_steps > 15 || cfg->obs_dim > 24 || cfg->map_dim > 24 || cfg->motion_k < 1 || cfg->motion_k > 16 || cfg->state_dim != (cfg->pred_gmm ? 8 : 5) ||
+  if (cfg->hist_steps > 15 || cfg->obs_dim > 24 || cfg->map_dim > 24 || cfg->motion_k < 1 || cfg->motion_k > 16 || cfg->state_dim != 3 + (cfg->no_pred_vel ? 0 : 2) + (cfg->pred_gmm ? 3 : 0) ||
       cfg->target_steps * cfg->state_dim * (cfg->k_pred_mlp ? cfg->motion_k : 1) > 128 || cfg->map_pre_layers > 4 || cfg->obs_pre_layers > 4 ||
       cfg->map_mlp_layers - cfg->map_pre_layers > 4 || cfg->obs_mlp_layers - cfg->obs_pre_layers > 4)
     return fail(PS_E_ARG, "unsupported config (hist<=15, obs_dim<=24, map_dim<=24, 1<=motion_k<=16, steps*state (x motion_k with PRED_MODE mlp) <=128)");
   if (cfg->goal_pred_k < 0 || cfg->goal_pred_k > 64) return fail(PS_E_ARG, "goal_pred_k must be in 0..64");
+  if (cfg->no_pred_vel && cfg->replan_freq < 2)
+    return fail(PS_E_ARG, "PRED_VEL False needs replan_freq >= 2 (velocities from position differences over hist_steps + 2 steps)");
   if (cfg->replan_freq < 1 || cfg->replan_freq > cfg->target_steps)
     return fail(PS_E_ARG, "replan_freq must be in 1..target_steps (a replan appends replan_freq of the target_steps predicted states)");
   if (cfg->pol_max_neigh < 1 || cfg->pol_max_neigh > 2047 || cfg->dec_max_neigh < 1 || cfg->dec_max_neigh > 2047)
@@ -1927,7 +1929,7 @@ extern "C" int ps_policy_step(ps_engine* e, int32_t t_idx) {
   hipLaunchKernelGGL(k_step_env, dim3(A), dim3(64), 0, st, (const float*)e->d_traj.p, (const float*)e->d_vel.p, e->stride_steps, last,
                      c.hist_steps, c.dt, (const float*)e->d_init_pos.p, (const float*)e->d_init_head.p, stat, c.obs_dim, e->d_obs_in.p,
                      e->d_cur_pos.p, e->d_cur_ori.p, t_idx > 0 ? 1 : 0, t_idx > 0 ? e->d_tok_pos.p + 2 * (size_t)Mv : (float*)nullptr,
-                     t_idx > 0 ? e->d_tok_ori.p + Mv : (float*)nullptr, lg);
+                     t_idx > 0 ? e->d_tok_ori.p + Mv : (float*)nullptr, lg, c.no_pred_vel ? 1 : 0);
   float* atok = e->d_tok.p + (size_t)Mv * D;
   if (t_idx > 0) {
     // update_scene_emb / _replace_old_obs (attn_fusion.py:205-250): re-encode agents, swap tokens + poses
@@ -1982,7 +1984,7 @@ extern "C" int ps_policy_step(ps_engine* e, int32_t t_idx) {
                        e->d_motion.p + (size_t)t_idx * A * c.motion_k * c.target_steps * c.state_dim,
                        e->d_traj.p, e->d_vel.p, e->stride_steps, last, c.replan_freq, c.ln_eps, (const int*)(e->d_choice.p + (size_t)t_idx * A),
                        e->have_noise ? (const float*)(e->d_noise.p + (size_t)t_idx * A * c.motion_k * c.target_steps * 2) : (const float*)nullptr,
-                       c.pred_gmm ? 6 : 3, c.k_pred_mlp ? 1 : 0);
+                       c.no_pred_vel ? -1 : (c.pred_gmm ? 6 : 3), c.k_pred_mlp ? 1 : 0);
   }
   HIPCHK(hipGetLastError());
   return PS_OK;
@@ -2605,7 +2607,7 @@ extern "C" int ps_policy_forward(ps_engine* e, int32_t n_scenes, int32_t Na, con
     const int Gh = c.k_pred_mlp ? 16 : 16 / c.motion_k;
     hipLaunchKernelGGL(k_policy_head_mfma, dim3((A + Gh - 1) / Gh), dim3(256), 0, st, e->head, (const float*)d_x.p, (const int*)d_ptype.p, A,
                        c.motion_k, c.target_steps, c.state_dim, d_motion.p, d_traj.p, d_vel.p, 16, 1, 0, c.ln_eps, (const int*)nullptr,
-                       (const float*)nullptr, c.pred_gmm ? 6 : 3, c.k_pred_mlp ? 1 : 0);
+                       (const float*)nullptr, c.no_pred_vel ? -1 : (c.pred_gmm ? 6 : 3), c.k_pred_mlp ? 1 : 0);
     if (hipStreamSynchronize(st) != hipSuccess) rc = fail(PS_E_HIP, "ps_policy_forward: kernel failure");
   }
   std::swap(e->d_tok_pos, d_pos);

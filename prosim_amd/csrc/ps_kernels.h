@@ -832,7 +832,8 @@ __global__ __launch_bounds__(64) void k_step_env(const float* __restrict__ traj,
                                                  const float* __restrict__ init_head, const float* __restrict__ static_in,
                                                  int obs_dim, float* __restrict__ obs_in, float* __restrict__ cur_pos,
                                                  float* __restrict__ cur_ori, int write_obs, float* __restrict__ tok_pos,
-                                                 float* __restrict__ tok_ori, StepLog lg) {
+                                                 float* __restrict__ tok_ori, StepLog lg,
+                                                 int fd_vel /*PRED_VEL False: velocities from position differences (traj_sam.py:259, :553-554)*/) {
   const int a = blockIdx.x, tid = threadIdx.x;
   if (lg.is_policy && !lg.is_policy[a]) {
     // log-replay agent (observed, not policy-controlled): observation, validity and pose of this replan come from
@@ -893,10 +894,22 @@ __global__ __launch_bounds__(64) void k_step_env(const float* __restrict__ traj,
     }
   }
   if (!write_obs) return;
-  __shared__ float rvx[16], rvy[16];
+  __shared__ float rvx[16], rvy[16], rpx[18], rpy[18];
   const float ct = cosf(-th_last), st = sinf(-th_last);
   const int nv = hist + 1;  // rel_vel over the last hist+1 steps
-  if (tid < nv) {
+  if (fd_vel) {   // positions of the last hist + 2 steps in the last step's frame, then their differences / dt
+    if (tid < hist + 2) {
+      const int s = last - hist - 2 + tid;
+      const float dx = tr[s * 4] - lx, dy = tr[s * 4 + 1] - ly;
+      rpx[tid] = dx * ct - dy * st;
+      rpy[tid] = dy * ct + dx * st;
+    }
+    __syncthreads();
+    if (tid < nv) {
+      rvx[tid] = (rpx[tid + 1] - rpx[tid]) / dt;
+      rvy[tid] = (rpy[tid + 1] - rpy[tid]) / dt;
+    }
+  } else if (tid < nv) {
     const int s = last - nv + tid;
     const float vx = vl[s * 2], vy = vl[s * 2 + 1];
     rvx[tid] = vx * ct - vy * st;
@@ -986,7 +999,7 @@ __global__ __launch_bounds__(256) void k_policy_head_mfma(HeadW w, const float* 
                                                          float* __restrict__ motion_pred, float* __restrict__ traj,
                                                          float* __restrict__ vel, int stride_steps, int last, int replan, float eps,
                                                          const int* __restrict__ choice, const float* __restrict__ noise /*[A][K][steps][2] or null*/,
-                                                         int vcol /*first velocity column: 3, or 6 with PRED_GMM*/,
+                                                         int vcol /*first velocity column: 3, or 6 with PRED_GMM; -1: no velocity (PRED_VEL False)*/,
                                                          int mlp_mode /*TRAJ.PRED_MODE 'mlp' (act_decoder.py:90-91): one row per AGENT, no
                                                                         anchors and no CG_decode, the K modes are column blocks of the last Linear*/) {
   __shared__ __attribute__((aligned(16))) _Float16 Ah[16 * PN_AS], Al[16 * PN_AS];
@@ -1120,9 +1133,11 @@ __global__ __launch_bounds__(256) void k_policy_head_mfma(HeadW w, const float* 
       const float pth = wrap_angle(lth + hh);
       t[2] = sinf(pth);
       t[3] = cosf(pth);
-      const float vx = o[s * sdim + vcol] + ob[s * sdim + vcol], vy = o[s * sdim + vcol + 1] + ob[s * sdim + vcol + 1];
-      v[0] = vx * cl - vy * sl;
-      v[1] = vy * cl + vx * sl;
+      if (vcol >= 0) {   // (PRED_VEL; without it the rollout keeps no velocity track, traj_sam.py:337)
+        const float vx = o[s * sdim + vcol] + ob[s * sdim + vcol], vy = o[s * sdim + vcol + 1] + ob[s * sdim + vcol + 1];
+        v[0] = vx * cl - vy * sl;
+        v[1] = vy * cl + vx * sl;
+      }
     }
   }
 }

@@ -592,8 +592,9 @@ class ProSimHip:
                     xy = torch.stack([c * pred[:, 0] - s_ * pred[:, 1], s_ * pred[:, 0] + c * pred[:, 1]], -1) + cur[:2]
                     ang = torch.from_numpy(wrap_angle_np((th + pred[:, 2]).numpy()))
                     new_t[b, j] = torch.cat([xy, torch.sin(ang)[:, None], torch.cos(ang)[:, None]], -1)
-                    v = pred[:, 6:8] if spec.pred_gmm else pred[:, 3:5]
-                    new_v[b, j] = torch.stack([c * v[:, 0] - s_ * v[:, 1], s_ * v[:, 0] + c * v[:, 1]], -1)
+                    if spec.pred_vel:   # (traj_sam.py:337-345; without PRED_VEL no velocity track is kept)
+                        v = pred[:, spec.vel_col:spec.vel_col + 2]
+                        new_v[b, j] = torch.stack([c * v[:, 0] - s_ * v[:, 1], s_ * v[:, 0] + c * v[:, 1]], -1)
                     p += 1
         tr["traj"] = torch.cat([tr["traj"], new_t], 2)
         tr["vel"] = torch.cat([tr["vel"], new_v], 2)
@@ -699,7 +700,9 @@ class ProSimHip:
                "pair_names": names, "reconst_pred": torch.from_numpy(rec_rows[order]).repeat(R, 1), "rollout_trajs": {}}
         for b in range(B):
             for j, n in enumerate(pslots[b]):
-                out["rollout_trajs"][f"{b}-{ids[b][j]}"] = dict(
-                    traj=torch.from_numpy(traj[b, n]), vel=torch.from_numpy(vel[b, n]),
-                    init_pos=torch.from_numpy(scene["obs_pos"][b, n]), init_heading=torch.from_numpy(scene["obs_head"][b, n:n + 1]))
+                r_ = dict(traj=torch.from_numpy(traj[b, n]), init_pos=torch.from_numpy(scene["obs_pos"][b, n]),
+                          init_heading=torch.from_numpy(scene["obs_head"][b, n:n + 1]))
+                if spec.pred_vel:   # (traj_sam.py:592-593)
+                    r_["vel"] = torch.from_numpy(vel[b, n])
+                out["rollout_trajs"][f"{b}-{ids[b][j]}"] = r_
         return {"motion_pred": out}

@@ -81,6 +81,10 @@ class ModelSpec:
     # channels per step (std1, std2, rho; read by the training loss only) -- state_dim 8, laid out x, y, h, (std1, std2, rho),
     # xd, yd: the rollout then takes the velocity from columns 6:8 instead of 3:5 (traj_sam.py:337-340)
     pred_gmm: bool = False
+    # MODEL.POLICY.ACT_DECODER.TRAJ.PRED_VEL (True in every released yaml; default.py:652 says False): without it the target has no
+    # xd, yd (default.py:725-730) -- state_dim 3 (6 with PRED_GMM) -- the rollout keeps no velocity track, and step_env derives the
+    # observation's velocity / acceleration from position differences over hist + 2 steps (traj_sam.py:251-260, :552-560)
+    pred_vel: bool = True
     # MODEL.POLICY.ACT_DECODER.RANDOM_NOISE_STD (act_decoder.py:113-115; 0 in the demo): Gaussian noise on every predicted
     # xy step before the cumulative sum -- what makes the M replicas of parallel_rollout_batch differ when TOP_K = K = 1.
     # Drawn by the host with the reference's own torch.randn_like call (ProSimHip), handed to the engine as a table.
@@ -138,15 +142,14 @@ class ModelSpec:
 
     @property
     def vel_col(self) -> int:
-        """First of the two velocity columns of a predicted step (traj_sam.py:337-340)."""
-        return 6 if self.pred_gmm else 3
+        """First of the two velocity columns of a predicted step (traj_sam.py:337-340); -1 without PRED_VEL."""
+        return (6 if self.pred_gmm else 3) if self.pred_vel else -1
 
     def replace(self, **kw) -> "ModelSpec":
         out = dataclasses.replace(self, **kw)
-        if out.pred_gmm and out.state_dim != 8:
-            out = dataclasses.replace(out, state_dim=8)
-        if not out.pred_gmm and out.state_dim == 8:
-            raise ValueError("state_dim 8 is the PRED_GMM layout: set pred_gmm=True")
+        if "state_dim" in kw and kw["state_dim"] != 3 + 2 * out.pred_vel + 3 * out.pred_gmm:
+            raise ValueError("state_dim follows from the head options: 3 (x, y, h) + 2 with pred_vel + 3 with pred_gmm")
+        out = dataclasses.replace(out, state_dim=3 + 2 * out.pred_vel + 3 * out.pred_gmm)
         if out.k_pred_mode not in ("anchor", "cluster", "mlp"):
             raise ValueError(f"k_pred_mode {out.k_pred_mode!r}: 'anchor', 'cluster' or 'mlp'")
         return out

@@ -84,6 +84,9 @@ FULL_CASES = {
     "small_attn_update_lpe_b2": ("small_attn_lpe", dict(n_agents=16, n_polylines=128, batch=2, seed=24, goal=True, ragged=True, replay=0.3), 0),
     # LEARNABLE_PE with PE_NUM_FREQ = 16 (the engine's kernel has 64 bands: zero-padded on the host)
     "small_lpe16_b2": ("small_lpe16", dict(n_agents=16, n_polylines=128, batch=2, seed=25, goal=True, tags=True, ragged=True), 0),
+    # TRAJ.PRED_VEL False (default.py:652's default; every released yaml says True): 3-wide states, no velocity track, the
+    # observation's velocity / acceleration columns from position differences over hist + 2 steps
+    "small_novel_b2": ("small_novel", dict(n_agents=16, n_polylines=128, batch=2, seed=26, goal=True, ragged=True, replay=0.3), 0),
     "small_cluster_b2": ("small_cluster", dict(n_agents=16, n_polylines=128, batch=2, seed=21, goal=True, ragged=True, replay=0.3), 0),
     "small_mlphead_b2": ("small_mlphead", dict(n_agents=16, n_polylines=128, batch=2, seed=22, goal=True, tags=True, ragged=True), 0),
 }
@@ -95,6 +98,7 @@ SPECS = {"small": SMALL_SPEC, "demo": DEMO_SPEC, "small_mlp": SMALL_SPEC.replace
          "small_noise_gmm": SMALL_SPEC.replace(pred_gmm=True, action_noise_std=0.05),
          "small_attn_lpe": SMALL_SPEC.replace(obs_attn_update=True, enc_learnable_pe=True, pe_num_freq=64),
          "small_lpe16": SMALL_SPEC.replace(enc_learnable_pe=True, dec_learnable_pe=True, pol_learnable_pe=True, pe_num_freq=16),
+         "small_novel": SMALL_SPEC.replace(pred_vel=False),
          "small_cluster": SMALL_SPEC.replace(k_pred_mode="cluster", motion_k=3, rollout_top_k=3),
          "small_mlphead": SMALL_SPEC.replace(k_pred_mode="mlp", motion_k=2, rollout_top_k=2)}
 TOPK_SEED = 777   # torch.manual_seed before a forward whose rollout draws modes
@@ -112,7 +116,9 @@ def ref_overrides(spec: ModelSpec):
             "MODEL.DECODER.ATTN.LEARNABLE_PE", spec.dec_learnable_pe, "MODEL.DECODER.ATTN.PE_NUM_FREQ", spec.pe_num_freq,
             "MODEL.POLICY.ACT_DECODER.ATTN.LEARNABLE_PE", spec.pol_learnable_pe, "MODEL.POLICY.ACT_DECODER.ATTN.PE_NUM_FREQ", spec.pe_num_freq,
             "MODEL.POLICY.ACT_DECODER.TRAJ.PRED_GMM", spec.pred_gmm, "MODEL.POLICY.ACT_DECODER.RANDOM_NOISE_STD", spec.action_noise_std,
-            "MODEL.POLICY.ACT_DECODER.TRAJ.PRED_MODE", spec.k_pred_mode]
+            "MODEL.POLICY.ACT_DECODER.TRAJ.PRED_MODE", spec.k_pred_mode,
+            "MODEL.POLICY.ACT_DECODER.TRAJ.PRED_VEL", spec.pred_vel,
+            "DATASET.FORMAT.TARGET.ELEMENTS", "x,y,h,xd,yd" if spec.pred_vel else "x,y,h"]
 
 
 def run_reference(spec, w, scene):
@@ -176,7 +182,8 @@ def run_reference(spec, w, scene):
         for n in np.nonzero(scene["prompt_mask"][b])[0]:          # policy agents keep their observation slot's id
             r = out["rollout_trajs"][f"{b}-a{n}"]
             traj[b, n] = r["traj"].numpy()
-            vel[b, n] = r["vel"].numpy()
+            if "vel" in r:   # (absent without PRED_VEL)
+                vel[b, n] = r["vel"].numpy()
     res = dict(traj=traj, vel=vel, motion_pred=out["motion_pred"].numpy(), reconst_pred=out["reconst_pred"].numpy())
     if spec.motion_k > 1:
         assert len(draws) == spec.n_replans and all(d[1] is not None for d in draws)

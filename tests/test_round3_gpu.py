@@ -311,3 +311,31 @@ def test_pred_mode_cluster_and_mlp_through_the_model(name):
                 assert err(r["vel"].numpy(), g["vel"][b, n]) < 3 * floor["vel"] + TOL
     finally:
         model.close()
+
+
+def test_without_pred_vel_the_rollout_keeps_no_velocity_track():
+    """TRAJ.PRED_VEL False through the registry-level model: 3-wide states, rollout_trajs without 'vel' (traj_sam.py:592-593), the
+    observation's velocity / acceleration columns from position differences -- the fixture's trajectories."""
+    from prosim_amd import modules
+    name = "small_novel_b2"
+    sname, kw, wseed = FULL_CASES[name]
+    spec = SPECS[sname]
+    assert spec.state_dim == 3 and spec.vel_col == -1
+    g = np.load(os.path.join(GOLD, f"ref_standins_{name}.npz"))
+    scene = synth.make_scene(spec, **kw)
+    model = modules.ProSimHip(spec, weights.init_weights(spec, wseed))
+    try:
+        out = model.forward(rh.make_batch(scene, spec), "val")["motion_pred"]
+        pm = scene["prompt_mask"].astype(bool)
+        A = int(pm.sum())
+        assert out["motion_pred"].shape == (spec.n_replans * A, 1, spec.target_steps, 3)
+        assert err(out["motion_pred"][:A].numpy(), g["motion_pred"][:A]) < TOL
+        floor = dict(zip(("traj", "vel", "motion_pred"), g["fp32_floor"]))
+        for b in range(pm.shape[0]):
+            for n in np.nonzero(pm[b])[0]:
+                r = out["rollout_trajs"][f"{b}-a{n}"]
+                assert "vel" not in r
+                assert err(r["traj"].numpy(), g["traj"][b, n]) < 3 * floor["traj"] + TOL
+        assert float(np.abs(model.engine.padded("vel")).max()) == 0.0
+    finally:
+        model.close()
