@@ -74,6 +74,9 @@ typedef struct ps_config {
    * step_env takes the observation's velocity / acceleration columns from position differences over hist_steps + 2 steps
    * (traj_sam.py:251-260, :552-560); needs replan_freq >= 2. */
   int32_t no_pred_vel;
+  /* !LOSS.ROLLOUT_TRAJ.USE_GOAL_PRED_LOSS (1 = False, default.py:440's default; the released yamls set True = 0 here): the checkpoint
+   * has no "policy.act_decoder.pred_mlp.*" tensors and there is no "reconst_pred" result (act_decoder.py:75-76, :128-130). */
+  int32_t no_reconst_pred;
 } ps_config;
 
 /* Create an engine and upload weights.  names[i] are reference state_dict keys

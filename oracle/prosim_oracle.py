@@ -575,8 +575,10 @@ def compute_traj(Wt: W, spec: ModelSpec, pred_feat: T, agent_type: T, policy_emd
     traj = motion[..., :2].cumsum(dim=-2)
     headp = wrap_angle(motion[..., 2:3].cumsum(dim=-2))
     motion_pred = torch.cat([traj, headp, motion[..., 3:]], dim=-1)
-    reconst = mlp(Wt, f"{pa}.pred_mlp", [d, d, d // 2, 2], policy_emd, True, False)
-    return dict(motion_pred=motion_pred, motion_prob=torch.ones(A, K, dtype=motion.dtype), reconst_pred=reconst)
+    res = dict(motion_pred=motion_pred, motion_prob=torch.ones(A, K, dtype=motion.dtype))
+    if spec.use_goal_pred_loss:   # (:128-130)
+        res["reconst_pred"] = mlp(Wt, f"{pa}.pred_mlp", [d, d, d // 2, 2], policy_emd, True, False)
+    return res
 
 
 # --------------------------------------------------------------------------- closed-loop rollout
@@ -717,8 +719,10 @@ def rollout(w: Dict[str, np.ndarray], spec: ModelSpec, scene_in: Dict, dtype=tor
         last += spec.replan_freq
 
     res = dict(traj=traj[:, :, H:], vel=vel[:, :, H:], init_pos=init_pos, init_heading=init_head,
-               motion_pred=torch.cat(motion_preds, dim=0), reconst_pred=out["reconst_pred"],
+               motion_pred=torch.cat(motion_preds, dim=0),
                policy_emd=emd, edges=edges, step_edges=step_edges)
+    if "reconst_pred" in out:
+        res["reconst_pred"] = out["reconst_pred"]
     if goal is not None:
         res.update(goal_prob=goal[0], goal_point=goal[1])
     if collect:

@@ -584,7 +584,7 @@ extern "C" int ps_create(const ps_config* cfg, int32_t n_tensors, const char* co
     build_mlp3(b, "decoder.goal_point_head", {D, D / 2, 2 * cfg->goal_pred_k}, false, e->mlp_goal_point);
   }
   const std::string pa = "policy.act_decoder";
-  build_mlp3(b, pa + ".pred_mlp", {D, D, D / 2, 2}, false, e->mlp_pred);
+  if (!cfg->no_reconst_pred) build_mlp3(b, pa + ".pred_mlp", {D, D, D / 2, 2}, false, e->mlp_pred);
   // (TRAJ.PRED_MODE 'mlp': the head's last Linear carries all K modes, and there are no anchors / CG_decode blocks)
   const int head_out = cfg->target_steps * cfg->state_dim * (cfg->k_pred_mlp ? cfg->motion_k : 1);
   build_mlp3(b, pa + ".motion_head", {D, D, D / 2, head_out}, false, e->head.motion);
@@ -1868,14 +1868,15 @@ extern "C" int ps_generate_policy(ps_engine* e) {
     hipLaunchKernelGGL(k_add_rows, dim3((Ap * D + 255) / 256), dim3(256), 0, st, e->d_emd.p, (const float*)e->d_xc.p, Ap * D);
   }
   // reconst_pred = pred_mlp(policy_emd) (act_decoder.py:133-135) -- constant over the replans
-  hipLaunchKernelGGL(k_mlp_rows, dim3(Ap), dim3(128), 0, st, e->mlp_pred, (const float*)e->d_emd.p, (const int*)nullptr, D,
-                     e->d_reconst.p, 2, c.ln_eps);
+  if (!c.no_reconst_pred)   // (USE_GOAL_PRED_LOSS)
+    hipLaunchKernelGGL(k_mlp_rows, dim3(Ap), dim3(128), 0, st, e->mlp_pred, (const float*)e->d_emd.p, (const int*)nullptr, D,
+                       e->d_reconst.p, 2, c.ln_eps);
   if (e->replicas > 1) {   // the replicas share the prompts' embeddings (gpu_utils.py:73-82): fan the Ap computed rows out
     auto fan = [&](float* p, int w) {
       hipLaunchKernelGGL(k_fan_out_rows, dim3(std::min(2048, (A - Ap) * std::max(w / 4, 1) / 256 + 1)), dim3(256), 0, st, p, Ap, A, w);
     };
     fan(e->d_emd.p, D);
-    fan(e->d_reconst.p, 2);
+    if (!c.no_reconst_pred) fan(e->d_reconst.p, 2);
     if (c.goal_pred_k > 0) { fan(e->d_goal_prob.p, c.goal_pred_k); fan(e->d_goal_point.p, 2 * c.goal_pred_k); }
   }
   // k|v of the map tokens for all m2p layers: map tokens never change during the rollout
@@ -2254,7 +2255,10 @@ extern "C" int64_t ps_get(ps_engine* e, const char* name, float* dst, int64_t ca
     return copy(e->d_world.p, (int64_t)A * R * c.replan_freq * 3);
   }
   if (n == "motion_pred") return copy(e->d_motion.p, (int64_t)R * A * c.motion_k * c.target_steps * c.state_dim);
-  if (n == "reconst_pred") return copy(e->d_reconst.p, (int64_t)A * 2);
+  if (n == "reconst_pred") {
+    if (c.no_reconst_pred) return fail(PS_E_ARG, "no reconst_pred: the model was built without USE_GOAL_PRED_LOSS (ps_config.no_reconst_pred)");
+    return copy(e->d_reconst.p, (int64_t)A * 2);
+  }
   if (n == "policy_emd") return copy(e->d_emd.p, (int64_t)A * D);
   if (n == "goal_prob" || n == "goal_point") {
     if (c.goal_pred_k <= 0) return fail(PS_E_ARG, "the engine was created without goal heads (goal_pred_k = 0)");

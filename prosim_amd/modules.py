@@ -549,8 +549,9 @@ class ProSimHip:
         extras = batch.extras if hasattr(batch, "extras") else batch
         ids = _g(extras["prompt"]["motion_pred"], "agent_ids") or [[str(j) for j in range(len(pslots[b]))] for b in range(B)]
         names = [f"{b}-{ids[b][j]}-{int(target_t)}" for b in range(B) for j in range(len(pslots[b]))]
-        out = {"motion_pred": mp, "motion_prob": torch.ones(mp.shape[0], mp.shape[1]), "latent_state": None, "pair_names": names,
-               "reconst_pred": torch.from_numpy(eng.get("reconst_pred")[order])}
+        out = {"motion_pred": mp, "motion_prob": torch.ones(mp.shape[0], mp.shape[1]), "latent_state": None, "pair_names": names}
+        if self.spec.use_goal_pred_loss:   # (act_decoder.py:128-130)
+            out["reconst_pred"] = torch.from_numpy(eng.get("reconst_pred")[order])
         st["out"] = (i, mp)
         return {"motion_pred": out}
 
@@ -689,7 +690,7 @@ class ProSimHip:
             ids = [[str(j) for j in range(len(pslots[b]))] for b in range(B)]
         traj, vel = eng.padded("traj"), eng.padded("vel")
         mp_rows = eng.get("motion_pred")                           # [R, rows = observed agents, K, S, D]
-        rec_rows = eng.get("reconst_pred")
+        rec_rows = eng.get("reconst_pred") if spec.use_goal_pred_loss else None
         slot_of_row = eng._slots                                   # flat slot b * N + n of every agent row
         row_of_slot = {int(sl): i for i, sl in enumerate(slot_of_row)}
         order = [row_of_slot[b * N + n] for b in range(B) for n in pslots[b]]   # policy agents, scene-major, prompt order
@@ -697,7 +698,9 @@ class ProSimHip:
         R, A = mp.shape[0], mp.shape[1]
         names = [f"{b}-{ids[b][j]}-{t}" for t in spec.all_t_indices for b in range(B) for j in range(len(pslots[b]))]
         out = {"motion_pred": mp.reshape(R * A, *mp.shape[2:]), "motion_prob": torch.ones(R * A, mp.shape[2]),
-               "pair_names": names, "reconst_pred": torch.from_numpy(rec_rows[order]).repeat(R, 1), "rollout_trajs": {}}
+               "pair_names": names, "rollout_trajs": {}}
+        if rec_rows is not None:
+            out["reconst_pred"] = torch.from_numpy(rec_rows[order]).repeat(R, 1)
         for b in range(B):
             for j, n in enumerate(pslots[b]):
                 r_ = dict(traj=torch.from_numpy(traj[b, n]), init_pos=torch.from_numpy(scene["obs_pos"][b, n]),

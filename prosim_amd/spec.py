@@ -85,6 +85,10 @@ class ModelSpec:
     # xd, yd (default.py:725-730) -- state_dim 3 (6 with PRED_GMM) -- the rollout keeps no velocity track, and step_env derives the
     # observation's velocity / acceleration from position differences over hist + 2 steps (traj_sam.py:251-260, :552-560)
     pred_vel: bool = True
+    # LOSS.ROLLOUT_TRAJ.USE_GOAL_PRED_LOSS (True in the released yamls, no_text.yaml:111; default.py:440 says False): with it the act
+    # decoder carries pred_mlp and every policy call returns reconst_pred = pred_mlp(policy_emd) (act_decoder.py:75-76, :128-130);
+    # without it a checkpoint has no pred_mlp tensors and the output no 'reconst_pred'
+    use_goal_pred_loss: bool = True
     # MODEL.POLICY.ACT_DECODER.RANDOM_NOISE_STD (act_decoder.py:113-115; 0 in the demo): Gaussian noise on every predicted
     # xy step before the cumulative sum -- what makes the M replicas of parallel_rollout_batch differ when TOP_K = K = 1.
     # Drawn by the host with the reference's own torch.randn_like call (ProSimHip), handed to the engine as a table.

@@ -165,7 +165,8 @@ def param_shapes(spec: ModelSpec) -> "OrderedDict[str, Tuple[int, ...]]":
     elif spec.k_pred_mode == "cluster":
         _mlp_shapes(out, f"{pa}.{CLUSTER_MLP}", [d, d], False, False)   # Linear + ReLU (:74)
         out[CLUSTER_GOALS] = (spec.motion_k, 2)   # the content of TRAJ.CLUSTER_PATH (:72): not a state_dict entry
-    _mlp_shapes(out, f"{pa}.pred_mlp", [d, d, d // 2, 2], True, False)
+    if spec.use_goal_pred_loss:
+        _mlp_shapes(out, f"{pa}.pred_mlp", [d, d, d // 2, 2], True, False)
     # condition transformer at 'policy_decoder' (traj_sam.py:47-52; condition_encoders.py, condition_attns.py)
     ct = "condition_transformers.policy_decoder"
     _mlp_shapes(out, f"{ct}.condition_encoders.goal.goal_encoder", [2, d, d], True, True)

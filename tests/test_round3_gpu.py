@@ -339,3 +339,29 @@ def test_without_pred_vel_the_rollout_keeps_no_velocity_track():
         assert float(np.abs(model.engine.padded("vel")).max()) == 0.0
     finally:
         model.close()
+
+
+def test_without_goal_pred_loss_there_is_no_reconst_pred():
+    """LOSS.ROLLOUT_TRAJ.USE_GOAL_PRED_LOSS False through the registry-level model: a checkpoint without pred_mlp loads, the output
+    has no 'reconst_pred' (act_decoder.py:128-130), the per-replan calls neither; trajectories as the fixture's."""
+    from prosim_amd import modules
+    name = "small_nogoalloss_b2"
+    sname, kw, wseed = FULL_CASES[name]
+    spec = SPECS[sname]
+    w = weights.init_weights(spec, wseed)
+    assert not any(".pred_mlp." in k for k in w)
+    g = np.load(os.path.join(GOLD, f"ref_standins_{name}.npz"))
+    scene = synth.make_scene(spec, **kw)
+    model = modules.ProSimHip(spec, w)
+    try:
+        out = model.forward(rh.make_batch(scene, spec), "val")["motion_pred"]
+        assert "reconst_pred" not in out and {"motion_pred", "motion_prob", "pair_names", "rollout_trajs"} <= set(out)
+        pm = scene["prompt_mask"].astype(bool)
+        A = int(pm.sum())
+        assert err(out["motion_pred"][:A].numpy(), g["motion_pred"][:A]) < TOL
+        floor = dict(zip(("traj", "vel", "motion_pred"), g["fp32_floor"]))
+        for b in range(pm.shape[0]):
+            for n in np.nonzero(pm[b])[0]:
+                assert err(out["rollout_trajs"][f"{b}-a{n}"]["traj"].numpy(), g["traj"][b, n]) < 3 * floor["traj"] + TOL
+    finally:
+        model.close()
