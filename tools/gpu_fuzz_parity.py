@@ -28,7 +28,10 @@ if os.environ.get("FUZZ_R3"):   # round-3 variants: noise + GMM head, PRED_MODE 
                 SMALL_SPEC.replace(k_pred_mode="mlp", motion_k=2, rollout_top_k=2),
                 SMALL_SPEC.replace(k_pred_mode="mlp", motion_k=1, pred_gmm=True),
                 SMALL_SPEC.replace(obs_attn_update=True, enc_learnable_pe=True),
-                SMALL_SPEC.replace(obs_attn_update=True, enc_learnable_pe=True, obs_fusion="mlp", k_pred_mode="cluster", motion_k=2)]
+                SMALL_SPEC.replace(obs_attn_update=True, enc_learnable_pe=True, obs_fusion="mlp", k_pred_mode="cluster", motion_k=2),
+                SMALL_SPEC.replace(pred_vel=False), SMALL_SPEC.replace(pred_vel=False, pred_gmm=True, k_pred_mode="mlp", motion_k=2),
+                SMALL_SPEC.replace(use_goal_pred_loss=False, obs_fusion="mlp"),
+                SMALL_SPEC.replace(enc_learnable_pe=True, dec_learnable_pe=True, pol_learnable_pe=True, pe_num_freq=32)]
 engines = {}
 worst = 0.0
 bad = []
