@@ -122,6 +122,12 @@ class ModelSpec:
     pol_learnable_pe: bool = False
     pe_num_freq: int = 64
 
+    def __post_init__(self):
+        if self.state_dim != 3 + 2 * self.pred_vel + 3 * self.pred_gmm:
+            raise ValueError(f"state_dim {self.state_dim}: 3 (x, y, h) + 2 with pred_vel + 3 with pred_gmm (use ModelSpec.replace, which keeps it in step)")
+        if self.k_pred_mode not in ("anchor", "cluster", "mlp"):
+            raise ValueError(f"k_pred_mode {self.k_pred_mode!r}: 'anchor', 'cluster' or 'mlp'")
+
     @property
     def agent_knn(self) -> int:
         return min(self.scene_knn * 4, 100)
@@ -150,13 +156,9 @@ class ModelSpec:
         return (6 if self.pred_gmm else 3) if self.pred_vel else -1
 
     def replace(self, **kw) -> "ModelSpec":
-        out = dataclasses.replace(self, **kw)
-        if "state_dim" in kw and kw["state_dim"] != 3 + 2 * out.pred_vel + 3 * out.pred_gmm:
-            raise ValueError("state_dim follows from the head options: 3 (x, y, h) + 2 with pred_vel + 3 with pred_gmm")
-        out = dataclasses.replace(out, state_dim=3 + 2 * out.pred_vel + 3 * out.pred_gmm)
-        if out.k_pred_mode not in ("anchor", "cluster", "mlp"):
-            raise ValueError(f"k_pred_mode {out.k_pred_mode!r}: 'anchor', 'cluster' or 'mlp'")
-        return out
+        pv, pg = kw.get("pred_vel", self.pred_vel), kw.get("pred_gmm", self.pred_gmm)
+        kw.setdefault("state_dim", 3 + 2 * pv + 3 * pg)   # (the head options fix the state width; __post_init__ checks)
+        return dataclasses.replace(self, **kw)
 
 
 def wrap_angle_np(a):
