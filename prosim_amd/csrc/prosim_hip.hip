@@ -1776,7 +1776,11 @@ extern "C" int ps_encode_scene(ps_engine* e) {
   // 6 x (a2a on the agent rows in place, s2s on all rows)  (attn_fusion.py:117-119).  kv is indexed by
   // GLOBAL token row for both (the a2a projection fills rows Mv.. of the shared kv buffer).
   static const bool no_split = getenv("PS_NO_SPLIT") != nullptr;   // experiments only
-  const bool split_s2s = !no_split && Mv + Ap >= 2048 && e->e_s2s.maxdeg <= ES_MAXDEG;
+  // (every size: the split path is also the one that tracks the reference closest -- on a configs[2] scene whose fp64 rollout passes
+  // 2.4e-6 rad from a +-pi cut it is the only s2s kernel that keeps every agent on the reference's side, tools/gpu_cut_paths.py --
+  // and it is faster than the fused chain from one 1152-row scene up; PS_SPLIT_MIN: experiments)
+  static const int split_min = getenv("PS_SPLIT_MIN") ? atoi(getenv("PS_SPLIT_MIN")) : 0;
+  const bool split_s2s = !no_split && Mv + Ap >= split_min && e->e_s2s.maxdeg <= ES_MAXDEG;
   for (int i = 0; i < c.scene_layers; ++i) {
     launch_kv(e, tok + (size_t)Mv * D, Ap, e->L_a2a + i, 1, e->d_kv.p + (size_t)Mv * 256, e->d_kh.p + (size_t)Mv * 256, 0);
     if (use_c16(e, Ap, 0)) {

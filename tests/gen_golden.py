@@ -52,6 +52,12 @@ FULL_CASES = {
     "small_plain_b1": ("small", dict(n_agents=16, n_polylines=128, batch=1, seed=1), 1),
     "small_goal_64a": ("small", dict(n_agents=64, n_polylines=512, batch=1, seed=2, goal=True), 0),
     "demo_16a_128p": ("demo", dict(n_agents=16, n_polylines=128, batch=1, seed=3, goal=True), 0),
+    # the reference ITSELF at a BASELINE size: one configs[2] scene (128 agents, 1024 polylines, goal prompts; generator seed 0 = scene 0
+    # of bench.py's batch) through the full-depth demo model
+    "demo_cfg2_b1": ("demo", dict(n_agents=128, n_polylines=1024, batch=1, seed=0, goal=True), 0),
+    # ... and scene 5 of that batch, whose fp64 rollout passes 2.4e-6 / 3.9e-6 / 5.6e-6 rad from a +-pi cut (tools/cut_margin.py): the
+    # reference's own fp32 run stays on the fp64 side; so must the engine (its fused s2s kernels did not: tools/gpu_cut_paths.py)
+    "demo_cfg2_seed5": ("demo", dict(n_agents=128, n_polylines=1024, batch=1, seed=5, goal=True), 0),
     # policy agents are a SUBSET of the observed agents: the others replay a log (fut_obs frames)
     "small_replay_b2": ("small", dict(n_agents=16, n_polylines=128, batch=2, seed=5, goal=True, ragged=True, replay=0.4), 0),
     # all three condition types of the demo config (PROMPT.CONDITION.TYPES): goal, v_action_tag, drag_point
