@@ -663,11 +663,37 @@ def gen_oracle_cache(only=None):
         print("oracle cache written:", key, tuple(o["traj"].shape))
 
 
+def gen_near_cut(thr=1e-5):
+    """tests/golden/near_cut_rows.json: per workload of tests/golden/known_cut_agents.json, the policy-agent rows that the fp64 oracle
+    itself puts within `thr` rad of a +-pi cut as the DESTINATION of a generator / policy edge (oracle/cut_margin.py; calls >= 3: the
+    encoder's two calls index tokens, not policy agents) -- the rows an fp32 implementation may legitimately land on the other side of."""
+    import json
+    from oracle.cut_margin import near_cut_edges
+    keymap = {"baseline_configs/cfg3_seed0": "baseline_cfg3_b2_s0", "baseline_configs/cfg4_seed0": "baseline_cfg4_bNone_s0",
+              "no_truncation/cfg2": "no_truncation_cfg2", "no_truncation/cfg4": "no_truncation_cfg4"}
+    wl = {k: (spec, w, scene) for k, spec, w, scene, *_ in oracle_cache_workloads()}
+    out = {"_comment": "fp64 oracle (oracle/cut_margin.py): policy-agent rows that are the destination of a generator / policy relative-PE "
+                       f"edge within {thr:g} rad of a +-pi cut, with the smallest margin; written by tests/gen_golden.py near_cut"}
+    for name, key in keymap.items():
+        spec, w, scene = wl[key]
+        edges, _ = near_cut_edges(w, spec, scene, thr)
+        rows = {}
+        for m, kind, call, d, s_, n in edges:
+            if call >= 3:
+                rows[str(d)] = min(rows.get(str(d), 1.0), m)
+        out[name] = rows
+        print(name, rows)
+    with open(os.path.join(GOLD, "near_cut_rows.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     if len(sys.argv) > 2 and sys.argv[1] == "only":
         FULL_CASES = {k: v for k, v in FULL_CASES.items() if k in sys.argv[2:]}
         gen_full()
+    elif len(sys.argv) > 1 and sys.argv[1] == "near_cut":
+        gen_near_cut()
     elif len(sys.argv) > 1 and sys.argv[1] == "tracks":
         gen_demo_tracks()
     elif len(sys.argv) > 1 and sys.argv[1] == "map":
