@@ -58,6 +58,8 @@ FULL_CASES = {
     # ... and scene 5 of that batch, whose fp64 rollout passes 2.4e-6 / 3.9e-6 / 5.6e-6 rad from a +-pi cut (tools/cut_margin.py): the
     # reference's own fp32 run stays on the fp64 side; so must the engine (its fused s2s kernels did not: tools/gpu_cut_paths.py)
     "demo_cfg2_seed5": ("demo", dict(n_agents=128, n_polylines=1024, batch=1, seed=5, goal=True), 0),
+    # ... and the other six scenes of the batch: the engine's single-scene path against the REFERENCE on every scene bench.py times
+    **{f"demo_cfg2_seed{s_}": ("demo", dict(n_agents=128, n_polylines=1024, batch=1, seed=s_, goal=True), 0) for s_ in (1, 2, 3, 4, 6, 7)},
     # policy agents are a SUBSET of the observed agents: the others replay a log (fut_obs frames)
     "small_replay_b2": ("small", dict(n_agents=16, n_polylines=128, batch=2, seed=5, goal=True, ragged=True, replay=0.4), 0),
     # all three condition types of the demo config (PROMPT.CONDITION.TYPES): goal, v_action_tag, drag_point
@@ -694,6 +696,10 @@ if __name__ == "__main__":
         gen_full()
     elif len(sys.argv) > 1 and sys.argv[1] == "near_cut":
         gen_near_cut()
+    elif len(sys.argv) > 2 and sys.argv[1] == "cfg2_scenes":
+        # the reference on further scenes of the benchmark batch (tools/gpu_cut_paths.py reads them; not committed: 0.4 MB each)
+        FULL_CASES = {f"demo_cfg2_seed{int(s_)}": ("demo", dict(n_agents=128, n_polylines=1024, batch=1, seed=int(s_), goal=True), 0) for s_ in sys.argv[2:]}
+        gen_full()
     elif len(sys.argv) > 1 and sys.argv[1] == "tracks":
         gen_demo_tracks()
     elif len(sys.argv) > 1 and sys.argv[1] == "map":

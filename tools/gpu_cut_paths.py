@@ -8,7 +8,10 @@ from prosim_amd import synth, weights
 from prosim_amd.engine import Engine
 from gen_golden import FULL_CASES, SPECS, GOLD
 for name in sys.argv[1:] or ["demo_cfg2_b1", "demo_cfg2_seed5"]:
-    sname, kw, wseed = FULL_CASES[name]
+    if name in FULL_CASES:
+        sname, kw, wseed = FULL_CASES[name]
+    else:   # demo_cfg2_seed<N>: further scenes of the benchmark batch (fixtures from `tests/gen_golden.py cfg2_scenes N ...`, not committed)
+        sname, kw, wseed = "demo", dict(n_agents=128, n_polylines=1024, batch=1, seed=int(name.rsplit("seed", 1)[1]), goal=True), 0
     spec = SPECS[sname]
     g = np.load(os.path.join(GOLD, f"ref_standins_{name}.npz"))
     w = weights.init_weights(spec, wseed)
