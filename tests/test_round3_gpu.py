@@ -365,3 +365,35 @@ def test_without_goal_pred_loss_there_is_no_reconst_pred():
                 assert err(out["rollout_trajs"][f"{b}-a{n}"]["traj"].numpy(), g["traj"][b, n]) < 3 * floor["traj"] + TOL
     finally:
         model.close()
+
+
+@pytest.mark.parametrize("rows", [0, 16])
+def test_the_timed_batch_against_the_reference_itself(rows):
+    """bench.py's batch (8 x configs[2], seeds 0..7) in latency mode and in throughput mode (16 rows per workgroup: the headline's
+    kernels) against the REFERENCE's own fp32 forward of every scene (the model never mixes batch elements, so scene b of the batch is
+    fixture demo_cfg2 seed b): every one of the 1024 agents within the fixture test's bar, and how many within 1e-4 outright."""
+    from prosim_amd.engine import Engine
+    from parity_table import record, per_agent
+    spec = DEMO_SPEC
+    w = weights.init_weights(spec, 0)
+    parts = [synth.baseline_scene(spec, 2, seed=i, batch=1) for i in range(8)]
+    scene = {k: (np.concatenate([p[k] for p in parts]) if not isinstance(parts[0][k], dict) else
+                 {ck: {f: np.concatenate([p[k][ck][f] for p in parts]) for f in parts[0][k][ck]} for ck in parts[0][k]}) for k in parts[0]}
+    eng = Engine(spec, w)
+    try:
+        eng.set_chain_rows(rows)
+        eng.set_scene(scene)
+        eng.rollout()
+        traj = eng.padded("traj")
+        d_all = []
+        for b in range(8):
+            g = np.load(os.path.join(GOLD, "ref_standins_demo_cfg2_b1.npz" if b == 0 else f"ref_standins_demo_cfg2_seed{b}.npz"))
+            d = np.abs(traj[b] - g["traj"][0]).max(axis=(1, 2))                 # per agent, over the 80 steps
+            assert d.max() < 3 * float(g["fp32_floor"][0]) + TOL, (b, float(d.max()))
+            d_all.append(d)
+        d_all = np.concatenate(d_all)
+        record(f"bench_workload_vs_reference/rows{rows}", **per_agent(d_all))
+        print(f"batch vs the reference, rows {rows}: max {d_all.max():.2e} median {np.median(d_all):.2e} within 1e-4: {(d_all < 1e-4).sum()} / {d_all.size}")
+        assert (d_all < 1e-4).mean() >= 0.995 and np.median(d_all) < 3e-5
+    finally:
+        eng.close()
