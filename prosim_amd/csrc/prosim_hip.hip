@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <initializer_list>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -17,10 +18,31 @@
 #include "ps_kernels.h"
 #include "ps_chain16.h"
 #include "ps_pe_learn.h"
+#include "ps_rowtile.h"
 
 using namespace ps;
 
 static thread_local std::string g_err;
+// Experiment switches (ablations, forced kernel choices, in-kernel clocks) are read from the environment ONLY in tools builds
+// (-DPS_EXPERIMENTS: tools/README.md).  The product library compiles them out -- a stray PS_* variable cannot change which kernel
+// runs or corrupt a rollout -- and says so once, loudly, when it finds one set.
+static const char* const kExpEnv[] = {"PS_C16_ABL", "PS_XCD", "PS_CHAIN_T", "PS_CHAIN_TP", "PS_CHAIN_T1", "PS_CHAIN_FLAGS", "PS_CHAIN_PROF",
+                                      "PS_C16_ROWS", "PS_S2S_C16", "PS_NO_SPLIT", "PS_SPLIT_MIN", "PS_RT_MT", "PS_LEGACY_NODE"};
+#ifdef PS_EXPERIMENTS
+static const char* exp_env(const char* name) { return getenv(name); }
+#else
+static const char* exp_env(const char*) { return nullptr; }
+#endif
+static void warn_ignored_experiment_env() {
+#ifndef PS_EXPERIMENTS
+  static bool done = false;
+  if (done) return;
+  done = true;
+  for (const char* n : kExpEnv)
+    if (getenv(n)) fprintf(stderr, "[prosim_hip] %s is set, but this is the product build: experiment switches are compiled out and IGNORED "
+                                   "(tools builds: hipcc -DPS_EXPERIMENTS, tools/README.md)\n", n);
+#endif
+}
 extern "C" const char* ps_last_error(void) { return g_err.c_str(); }
 static int fail(int code, const std::string& msg) {
   g_err = msg;
@@ -168,6 +190,7 @@ struct ps_engine {
   // whole-rollout hipGraph (captured on the first ps_rollout after a scene / condition change)
   hipGraph_t graph = nullptr;
   hipGraphExec_t graph_exec = nullptr;
+  bool legacy_rows = false;   // ps_set_row_impl(1): the round-3 staged row kernels (k_pointnet_mfma, k_node) instead of the row-tile ones (A/B and parity tools)
   int chain_rows = 0;   // ps_set_chain_rows: 0 = latency-optimal choice, else rows per workgroup of the fused attention launches
   int chain_impl = 0;   // ps_set_chain_impl: 0 = by mode (k_chain16 in throughput mode: chain_rows >= 8; k_attn_chain otherwise), 1 = k_attn_chain, 2 = k_chain16, 3 = k_chain16 + the encoder's s2s layers on it
   bool graph_ok = false;
@@ -233,11 +256,13 @@ struct Builder {
   }
   // torch Linear weight [out = 128][in] -> split-fp16 MFMA B fragments over input columns [in0, in0+in_n), K padded
   // to a multiple of 32: [n-tile 8][k-block][hi|lo][lane 64][8], lane = (n & 15) + 16*kq holds k = 32*ks + 8*kq ..+8
-  void fragments(const _Float16** p, const std::string& name, int out, int in, int in0, int in_n) {
+  // perm: the K index inside a 32-wide k-block runs in the order the row-tile kernels hand a result tile on (ps_rowtile.h):
+  // lane group kq, element j <-> k = 32 ks + 16 (j >> 2) + 4 kq + (j & 3) instead of 32 ks + 8 kq + j
+  void fragments(const _Float16** p, const std::string& name, int out, int in, int in0, int in_n, bool perm = false) {
     const float* s = get(name, (int64_t)out * in);
-    if (s) fragments_raw(p, s, out, in, in0, in_n);
+    if (s) fragments_raw(p, s, out, in, in0, in_n, perm);
   }
-  void fragments_raw(const _Float16** p, const float* s, int out, int in, int in0, int in_n) {
+  void fragments_raw(const _Float16** p, const float* s, int out, int in, int in0, int in_n, bool perm = false) {
     const int k32 = (in_n + 31) / 32, nt_n = out / 16;
     std::vector<float> packed(((size_t)nt_n * k32 * 2 * 512 + 1) / 2);
     _Float16* h = reinterpret_cast<_Float16*>(packed.data());
@@ -245,7 +270,8 @@ struct Builder {
       for (int ks = 0; ks < k32; ++ks)
         for (int lane = 0; lane < 64; ++lane)
           for (int j = 0; j < 8; ++j) {
-            const int n = nt * 16 + (lane & 15), k = ks * 32 + (lane >> 4) * 8 + j;
+            const int n = nt * 16 + (lane & 15), kq = lane >> 4;
+            const int k = perm ? ks * 32 + 16 * (j >> 2) + 4 * kq + (j & 3) : ks * 32 + kq * 8 + j;
             const float v = k < in_n ? s[(size_t)n * in + in0 + k] : 0.f;
             const _Float16 hi = (_Float16)v;
             const size_t o = ((size_t)(nt * k32 + ks) * 2) * 512 + (size_t)lane * 8 + j;
@@ -455,6 +481,7 @@ void build_pointnet(Builder& b, const std::string& p, int in_dim, int n_pre, int
     const std::string q = p + ".pre_mlps.mlp." + std::to_string(sq[l].first);
     b.transposed(&w.pre_Wt[l], q + ".weight", D, K);
     b.fragments(&w.pre_F[l], q + ".weight", D, K, 0, K);
+    if (l > 0) b.fragments(&w.pre_Q[l], q + ".weight", D, K, 0, K, true);
     b.plain(&w.pre_b[l], q + ".bias", D);
     if (sq[l].second >= 0) {
       const std::string n = p + ".pre_mlps.mlp." + std::to_string(sq[l].second);
@@ -469,6 +496,8 @@ void build_pointnet(Builder& b, const std::string& p, int in_dim, int n_pre, int
     b.transposed(&w.mid_Wt[l], q + ".weight", D, K);
     b.fragments(&w.mid_F[l], q + ".weight", D, K, 0, D);   // layer 0: the point-feature half ...
     if (l == 0) b.fragments(&w.mid_P, q + ".weight", D, K, D, D);   // ... and the pooled half
+    b.fragments(&w.mid_Q[l], q + ".weight", D, K, 0, D, true);
+    if (l == 0) b.fragments(&w.mid_PQ, q + ".weight", D, K, D, D, true);
     b.plain(&w.mid_b[l], q + ".bias", D);
     if (sq[l].second >= 0) {
       const std::string n = p + ".mlps.mlp." + std::to_string(sq[l].second);
@@ -478,6 +507,8 @@ void build_pointnet(Builder& b, const std::string& p, int in_dim, int n_pre, int
   }
   b.fragments(&w.out_F0, p + ".out_mlps.mlp.0.weight", D, D, 0, D);
   b.fragments(&w.out_F1, p + ".out_mlps.mlp.2.weight", D, D, 0, D);
+  b.fragments(&w.out_Q0, p + ".out_mlps.mlp.0.weight", D, D, 0, D, true);
+  b.fragments(&w.out_Q1, p + ".out_mlps.mlp.2.weight", D, D, 0, D, true);
   b.transposed(&w.out_W0t, p + ".out_mlps.mlp.0.weight", D, D);
   b.plain(&w.out_b0, p + ".out_mlps.mlp.0.bias", D);
   b.transposed(&w.out_W1t, p + ".out_mlps.mlp.2.weight", D, D);
@@ -533,6 +564,7 @@ const char* kTagNames[11] = {"Stopping", "Accelerate", "Decelerate", "KeepSpeed"
 extern "C" int ps_create(const ps_config* cfg, int32_t n_tensors, const char* const* names, const float* const* data,
                          const int64_t* numel, ps_engine** out) {
   if (!cfg || !out) return fail(PS_E_ARG, "null argument");
+  warn_ignored_experiment_env();
   if (cfg->hidden != D || cfg->heads != H || cfg->head_dim != DH)
     return fail(PS_E_ARG, "this build supports hidden=128, heads=8, head_dim=16 only");
   if (cfg->hist_steps > 15 || cfg->obs_dim > 24 || cfg->map_dim > 24 || cfg->motion_k < 1 || cfg->motion_k > 16 || cfg->state_dim != 3 + (cfg->no_pred_vel ? 0 : 2) + (cfg->pred_gmm ? 3 : 0) ||
@@ -698,6 +730,11 @@ extern "C" int ps_create(const ps_config* cfg, int32_t n_tensors, const char* co
   // the chain kernel may use up to ~140 KiB of dynamic LDS
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_kv_proj), hipFuncAttributeMaxDynamicSharedMemorySize, (int)KV_LDS_BYTES);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pointnet_mfma), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PN_LDS_BYTES);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pointnet_rt<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * rt_pn_wave_bytes<1>()));
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pointnet_rt<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * rt_pn_wave_bytes<2>()));
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pointnet_rt<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * rt_pn_wave_bytes<3>()));
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pointnet_rt<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * rt_pn_wave_bytes<4>()));
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pointnet_rt<5>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * rt_pn_wave_bytes<5>()));
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pe_learn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PL_LDS_BYTES);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_node<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ND_LDS_BYTES);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_node<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ND_LDS_BYTES);
@@ -761,6 +798,18 @@ int upload(DevBuf<T>& b, const T* h, size_t n, hipStream_t s) {
   return hipMemcpyAsync(b.p, h, n * sizeof(T), hipMemcpyHostToDevice, s) == hipSuccess ? 0 : -1;
 }
 
+// k_chain16 gathers geometry records, k rows and v rows through raw buffer descriptors with 32-bit byte offsets (edge * 32,
+// source row * 512, source row * 1024 + 512; ps_chain16.h): beyond 2^31 bytes a buffer load returns 0 silently, so sizes that
+// would get there are refused here.  token_rows: the largest source-row index a step can name (+ 1).
+int check_c16_offsets(size_t token_rows, std::initializer_list<size_t> edge_caps) {
+  constexpr size_t LIM = (size_t)1 << 31;
+  if (token_rows * 1024 + 512 >= LIM)
+    return fail(PS_E_ARG, "too many token rows for the fused chain's 32-bit gather offsets (rows * 1024 bytes must stay below 2^31: < 2 097 151 rows per engine)");
+  for (size_t cap : edge_caps)
+    if ((cap + 1) * 32 >= LIM)
+      return fail(PS_E_ARG, "an edge set's capacity exceeds the fused chain's 32-bit record offsets (edges * 32 bytes must stay below 2^31: < 67 108 863 edges per set)");
+  return 0;
+}
 int edge_alloc(EdgeSet& s, int nq, size_t cap_edges, int maxdeg) {
   s.nq = nq;
   s.cap_edges = cap_edges;
@@ -967,6 +1016,9 @@ extern "C" int ps_set_scene(ps_engine* e, int32_t B, int32_t M, int32_t P, int32
         e->d_kv_um.ensure((size_t)c.scene_layers * std::max(Mv, 1) * 256) || e->d_kh_um.ensure((size_t)c.scene_layers * std::max(Mv, 1) * 256))
       return fail(PS_E_HIP, "edge allocation failed");
   }
+  if (check_c16_offsets((size_t)Mv + A, {(size_t)Ap * d_a2a, (size_t)(Mv + Ap) * d_s2s, (size_t)Ap * d_p2p, (size_t)Ap * d_s2p,
+                                          (size_t)A * d_a2p, (size_t)A * d_m2p}))
+    return PS_E_ARG;
   // (the scene encoder's and the generator's sets have Ap destination rows: with replicas they run once)
   if (edge_alloc(e->e_a2a, Ap, (size_t)Ap * d_a2a, d_a2a) || edge_alloc(e->e_s2s, Mv + Ap, (size_t)(Mv + Ap) * d_s2s, d_s2s) ||
       edge_alloc(e->e_p2p, Ap, (size_t)Ap * d_p2p, d_p2p) || edge_alloc(e->e_s2p, Ap, (size_t)Ap * d_s2p, d_s2p) ||
@@ -1037,7 +1089,7 @@ extern "C" int ps_set_scene(ps_engine* e, int32_t B, int32_t M, int32_t P, int32
   e->step_cnd = (int)e->h_steps.size();
   for (int i = 0; i < c.cond_layers; ++i) push(e->cnd[i], e->d_kv.p, e->d_kh.p, e->e_cnd);
   e->step_pol = (int)e->h_steps.size();
-  static const int abl = getenv("PS_C16_ABL") ? atoi(getenv("PS_C16_ABL")) : 0;   // experiments only (timing, wrong results): 1 = every policy layer reads layer 0's k | v
+  static const int abl = exp_env("PS_C16_ABL") ? atoi(exp_env("PS_C16_ABL")) : 0;   // experiments only (timing, wrong results): 1 = every policy layer reads layer 0's k | v
   for (int i0 = 0; i0 < c.pol_layers; ++i0) {
     const int i = (abl & 1) ? 0 : i0;
     // a2p edges carry GLOBAL agent rows (Mv + j); the kv buffer is agent-local -> bias the base by -Mv rows
@@ -1465,7 +1517,7 @@ int launch_split_layer(ps_engine* e, float* x, int Nd, const ChainStep* stp, int
 
 // which launches use the XCD-aware mapping (PS_XCD overrides for experiments: bit0 policy, bit1 a2a, bit2 generator)
 static bool xcd_on(int bit, bool dflt) {
-  static const int env = getenv("PS_XCD") ? atoi(getenv("PS_XCD")) : -1;
+  static const int env = exp_env("PS_XCD") ? atoi(exp_env("PS_XCD")) : -1;
   return env < 0 ? dflt : ((env >> bit) & 1) != 0;
 }
 int launch_chain(ps_engine* e, float* x, int Nd, int step0, int nsteps, int maxdeg, bool timed = false,
@@ -1487,21 +1539,21 @@ int launch_chain(ps_engine* e, float* x, int Nd, int step0, int nsteps, int maxd
   // for eight waves per row (code 18) and 292 for four waves with the whole register file and early prefetch (code 1)
   // -- and the workgroups of two pipelined rollouts co-reside on a CU.
   int T = Nd >= 2048 ? 4 : (Nd >= 512 ? 2 : 11);   // (11 = ONE row on a four-wave workgroup built for two workgroups per CU)
-  static const int env_T = getenv("PS_CHAIN_T") ? atoi(getenv("PS_CHAIN_T")) : 0;   // experiments only
+  static const int env_T = exp_env("PS_CHAIN_T") ? atoi(exp_env("PS_CHAIN_T")) : 0;   // experiments only
   if (env_T && Nd >= 512) T = env_T;
   if ((e->chain_rows == 2 || e->chain_rows == 4) && Nd >= 512) T = e->chain_rows;   // (1 / 8 / 16 address k_chain16 only)
   if (e->chain_rows >= 8 && Nd >= 512) T = 4;   // throughput mode of this kernel
-  static const int env_TP = getenv("PS_CHAIN_TP") ? atoi(getenv("PS_CHAIN_TP")) : 0;   // experiments only: the policy launch alone
+  static const int env_TP = exp_env("PS_CHAIN_TP") ? atoi(exp_env("PS_CHAIN_TP")) : 0;   // experiments only: the policy launch alone
   if (env_TP && timed && Nd >= 512) T = env_TP;
-  static const int env_T1 = getenv("PS_CHAIN_T1") ? atoi(getenv("PS_CHAIN_T1")) : 0;   // experiments only
+  static const int env_T1 = exp_env("PS_CHAIN_T1") ? atoi(exp_env("PS_CHAIN_T1")) : 0;   // experiments only
   if (env_T1 && Nd < 512) T = env_T1;
   if (force_T) T = force_T;
   if (attn_lds_floats<1>(maxdeg) * sizeof(float) > 150 * 1024) return fail(PS_E_ARG, "degree bound too large for LDS");
   const float eps = e->cfg.ln_eps;
-  static const int env_flags = getenv("PS_CHAIN_FLAGS") ? atoi(getenv("PS_CHAIN_FLAGS")) : 0;  // ablation only
+  static const int env_flags = exp_env("PS_CHAIN_FLAGS") ? atoi(exp_env("PS_CHAIN_FLAGS")) : 0;  // ablation only
   const int flags = env_flags | (xcd ? 1024 : 0);   // 1024: XCD-aware block -> row mapping (ps_device.h xcd_block)
   // phase clocks (tools/gpu_phase.py): PS_CHAIN_PROF=1 makes the timed policy launches accumulate cycles per phase
-  static const bool want_prof = getenv("PS_CHAIN_PROF") != nullptr;
+  static const bool want_prof = exp_env("PS_CHAIN_PROF") != nullptr;
   static unsigned long long* d_prof = nullptr;
   unsigned long long* prof = nullptr;
   if (want_prof && timed && e->time_chain) {
@@ -1561,9 +1613,44 @@ void launch_kv(ps_engine* e, const float* x, int Ns, int layer0, int nlayers, fl
                      (const AttnW*)(e->d_layers + layer0), kv, khl, layer_stride, e->cfg.ln_eps);
 }
 
+// Row-tile PointNet (ps_rowtile.h): a wave takes G = min(16, 16 MT / P) polylines.  MT by the row count: enough waves for the
+// chip's 1024 SIMDs first, then the tile count that wastes the fewest rows (P = 19: MT 5 -> 4 polylines = 76 of 80 rows).
+int pointnet_mt(int n_rows, int P) {
+  static const int env_mt = exp_env("PS_RT_MT") ? atoi(exp_env("PS_RT_MT")) : 0;   // experiments only
+  if (env_mt >= 1 && env_mt <= 5 && 16 * env_mt >= P) return env_mt;
+  int best = 0;
+  double best_cost = 0;
+  for (int mt = 1; mt <= 5; ++mt) {
+    const int G = std::min(16, 16 * mt / P);
+    if (G < 1) continue;
+    const long waves = (n_rows + G - 1) / G;
+    const long rounds = (waves + 1023) / 1024;          // one wave per SIMD (MT >= 3: more than 256 registers)
+    const double cost = (double)rounds * (mt + 0.6);    // a wave's time ~ tiles + a fixed part (pools, pooled-row GEMMs, fragment latency)
+    if (!best || cost < best_cost) { best = mt; best_cost = cost; }
+  }
+  return best;
+}
+template <int MT>
+void launch_pointnet_rt(ps_engine* e, const PointNetW& w, const float* pts, const uint8_t* mask, const int* rows, int n_rows, int P,
+                        int feat_mask_dim, float* out) {
+  const int G = std::min(16, 16 * MT / P);
+  const int waves = (n_rows + G - 1) / G;
+  hipLaunchKernelGGL(k_pointnet_rt<MT>, dim3((waves + 3) / 4), dim3(256), 4 * rt_pn_wave_bytes<MT>(), e->stream, w, pts, mask, rows, n_rows, P,
+                     feat_mask_dim, out, e->cfg.ln_eps);
+}
 void launch_pointnet(ps_engine* e, const PointNetW& w, const float* pts, const uint8_t* mask, const int* rows, int n_rows,
                      int P, int feat_mask_dim, float* out) {
   if (n_rows <= 0) return;
+  if (!e->legacy_rows && w.n_pre >= 1 && w.n_mid >= 1 && w.in_dim <= 32) {
+    switch (pointnet_mt(n_rows, P)) {
+      case 1: launch_pointnet_rt<1>(e, w, pts, mask, rows, n_rows, P, feat_mask_dim, out); return;
+      case 2: launch_pointnet_rt<2>(e, w, pts, mask, rows, n_rows, P, feat_mask_dim, out); return;
+      case 3: launch_pointnet_rt<3>(e, w, pts, mask, rows, n_rows, P, feat_mask_dim, out); return;
+      case 4: launch_pointnet_rt<4>(e, w, pts, mask, rows, n_rows, P, feat_mask_dim, out); return;
+      case 5: launch_pointnet_rt<5>(e, w, pts, mask, rows, n_rows, P, feat_mask_dim, out); return;
+      default: break;
+    }
+  }
   const int G = std::min(PN_G, PN_ROWS / P);   // polylines per workgroup (ps_set_scene bounds P <= 32)
   hipLaunchKernelGGL(k_pointnet_mfma, dim3((n_rows + G - 1) / G), dim3(256), PN_LDS_BYTES, e->stream, w, pts, mask, rows, n_rows, P,
                      feat_mask_dim, out, e->cfg.ln_eps);
@@ -1621,7 +1708,7 @@ bool use_c16(const ps_engine* e, int Nd, int part) {
   return e->chain_impl >= 2 || (e->chain_impl == 0 && (e->chain_rows >= 8 || (e->chain_rows == 0 && Nd >= 1024)));
 }
 int chain16_rows(ps_engine* e, int Nd) {
-  static const int env_rows = getenv("PS_C16_ROWS") ? atoi(getenv("PS_C16_ROWS")) : 0;   // experiments only
+  static const int env_rows = exp_env("PS_C16_ROWS") ? atoi(exp_env("PS_C16_ROWS")) : 0;   // experiments only
   int rows = Nd >= 4096 ? 16 : (Nd >= 2048 ? 8 : (Nd >= 512 ? 4 : (Nd >= 256 ? 2 : 1)));
   if (e->chain_rows >= 1 && e->chain_rows <= 16) rows = e->chain_rows;
   if (env_rows) rows = env_rows;
@@ -1635,7 +1722,7 @@ int launch_chain16(ps_engine* e, float* x, int Nd, const ChainStep* steps, int n
   const dim3 grid((Nd + rows - 1) / rows);   // (no exchange buffers: the phases of k_chain16 meet in LDS)
   hipStream_t st = e->stream;
   if (timed && e->time_chain) (void)hipEventRecord(e->ev0, st);
-  static const bool want_prof = getenv("PS_CHAIN_PROF") != nullptr;   // tools only: in-kernel phase clocks of the timed launches
+  static const bool want_prof = exp_env("PS_CHAIN_PROF") != nullptr;   // tools only: in-kernel phase clocks of the timed launches
   static unsigned long long* d_prof = nullptr;
   unsigned long long* prof = nullptr;
   if (want_prof && timed && e->time_chain) {
@@ -1745,7 +1832,7 @@ extern "C" int ps_encode_scene(ps_engine* e) {
   // (ps_set_chain_impl 3 -- NOT the default: 9 % more throughput on the benchmark workload (22.4 against 20.4 M agent-steps/s),
   // but another fp32 evaluation of the scene tokens than the split path's, and on that workload it lands six agents of one
   // scene on the other side of a +-pi cut; the default keeps the path whose parity table holds 1024 / 1024)
-  static const int env_s2s = getenv("PS_S2S_C16") ? atoi(getenv("PS_S2S_C16")) : -1;   // experiments only: 0 / 1 force
+  static const int env_s2s = exp_env("PS_S2S_C16") ? atoi(exp_env("PS_S2S_C16")) : -1;   // experiments only: 0 / 1 force
   const bool s2s_c16 = !e->pe_on[0] && use_c16(e, Mv + Ap, 0) && (env_s2s >= 0 ? env_s2s != 0 : e->chain_impl == 3);
   {
     CandSet ca{e->d_tok_pos.p, e->d_r_agent.p, nullptr};
@@ -1775,11 +1862,11 @@ extern "C" int ps_encode_scene(ps_engine* e) {
   }
   // 6 x (a2a on the agent rows in place, s2s on all rows)  (attn_fusion.py:117-119).  kv is indexed by
   // GLOBAL token row for both (the a2a projection fills rows Mv.. of the shared kv buffer).
-  static const bool no_split = getenv("PS_NO_SPLIT") != nullptr;   // experiments only
+  static const bool no_split = exp_env("PS_NO_SPLIT") != nullptr;   // experiments only
   // (every size: the split path is also the one that tracks the reference closest -- on a configs[2] scene whose fp64 rollout passes
   // 2.4e-6 rad from a +-pi cut it is the only s2s kernel that keeps every agent on the reference's side, tools/gpu_cut_paths.py --
   // and it is faster than the fused chain from one 1152-row scene up; PS_SPLIT_MIN: experiments)
-  static const int split_min = getenv("PS_SPLIT_MIN") ? atoi(getenv("PS_SPLIT_MIN")) : 0;
+  static const int split_min = exp_env("PS_SPLIT_MIN") ? atoi(exp_env("PS_SPLIT_MIN")) : 0;
   const bool split_s2s = !no_split && Mv + Ap >= split_min && e->e_s2s.maxdeg <= ES_MAXDEG;
   for (int i = 0; i < c.scene_layers; ++i) {
     launch_kv(e, tok + (size_t)Mv * D, Ap, e->L_a2a + i, 1, e->d_kv.p + (size_t)Mv * 256, e->d_kh.p + (size_t)Mv * 256, 0);
@@ -2140,6 +2227,14 @@ extern "C" int ps_set_chain_impl(ps_engine* e, int32_t impl) {
     e->encoded = e->generated = false;   // the edge sets of the finished stages carry the other kernel's rel-PE form
   }
   e->chain_impl = impl;
+  return PS_OK;
+}
+
+extern "C" int ps_set_row_impl(ps_engine* e, int32_t impl) {
+  if (!e) return fail(PS_E_ARG, "null engine");
+  if (impl != 0 && impl != 1) return fail(PS_E_ARG, "ps_set_row_impl: 0 = row-tile kernels (default), 1 = the round-3 staged kernels");
+  if (e->legacy_rows != (impl == 1)) drop_graph(e);
+  e->legacy_rows = impl == 1;
   return PS_OK;
 }
 
@@ -2573,6 +2668,7 @@ extern "C" int ps_policy_forward(ps_engine* e, int32_t n_scenes, int32_t Na, con
   const int L = c.pol_layers;
   const int OUT = c.motion_k * c.target_steps * c.state_dim;
   std::vector<int> ptype(p_type, p_type + A);
+  if (check_c16_offsets((size_t)Nm + Na, {(size_t)A * da, (size_t)A * dm})) return PS_E_ARG;
   if (upload(d_pos, pos.data(), pos.size(), st) || upload(d_ori, ori.data(), ori.size(), st) ||
       d_atok.ensure((size_t)std::max(Na, 1) * D) || d_mtok.ensure((size_t)std::max(Nm, 1) * D) ||
       (Na > 0 && upload(d_atok, a_tok, (size_t)Na * D, st)) || (Nm > 0 && upload(d_mtok, m_tok, (size_t)Nm * D, st)) ||

@@ -25,6 +25,12 @@ struct PointNetW {
   const _Float16* pre_F[4];
   const _Float16* mid_F[4];
   const _Float16 *mid_P, *out_F0, *out_F1;   // mlps[0] rows 128..255 (pooled half), out_mlps Linear 0 / 1
+  // the same Linears for the row-tile kernel (ps_rowtile.h): fragments whose K index runs in the order a result tile hands its
+  // features on (k-block ks, lane group kq, element i <-> input feature 32 ks + 16 (i >> 2) + 4 kq + (i & 3)); layer 0 of pre_mlps
+  // reads the input rows in the natural order and keeps pre_F[0]
+  const _Float16* pre_Q[4];
+  const _Float16* mid_Q[4];
+  const _Float16 *mid_PQ, *out_Q0, *out_Q1;
 };
 
 // The encoder on the matrix cores.  A workgroup (4 waves) takes G = 64 / P polylines = up to 64

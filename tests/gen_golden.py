@@ -689,8 +689,32 @@ def gen_near_cut(thr=1e-5):
         json.dump(out, f, indent=1, sort_keys=True)
 
 
+def manifest_entries():
+    """(relative path, sha256 of the file's bytes) of every fixture under tests/golden/ (MANIFEST.sha256 itself excluded)."""
+    out = []
+    for dirpath, _, files in os.walk(GOLD):
+        for fn in sorted(files):
+            if fn == "MANIFEST.sha256":
+                continue
+            path = os.path.join(dirpath, fn)
+            with open(path, "rb") as f:
+                out.append((os.path.relpath(path, GOLD).replace(os.sep, "/"), hashlib.sha256(f.read()).hexdigest()))
+    return sorted(out)
+
+
+def write_manifest():
+    """tests/golden/MANIFEST.sha256 (sha256sum format): written at the end of EVERY run of this script, checked by
+    tests/test_golden_manifest_cpu.py -- a fixture that no longer is what this script last wrote fails the CPU suite."""
+    with open(os.path.join(GOLD, "MANIFEST.sha256"), "w") as f:
+        for rel, h in manifest_entries():
+            f.write(f"{h}  {rel}\n")
+    print("manifest written:", len(manifest_entries()), "files")
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
+    import atexit
+    atexit.register(write_manifest)
     if len(sys.argv) > 2 and sys.argv[1] == "only":
         FULL_CASES = {k: v for k, v in FULL_CASES.items() if k in sys.argv[2:]}
         gen_full()

@@ -7,6 +7,7 @@ recomputes (and says so) when they do not -- the oracle is the repo's own code, 
 Stored as float32 of the float64 result (coordinates of tens of metres: 4e-6 of rounding against bars of 1e-4)."""
 from __future__ import annotations
 
+import dataclasses
 import hashlib
 import os
 from typing import Dict, Optional
@@ -30,6 +31,23 @@ def _digest(d) -> str:
             h.update(k.encode())
             h.update(str(a.dtype).encode())
             h.update(np.nan_to_num(a.astype(np.float64), nan=-12345.0).tobytes())
+    return h.hexdigest()
+
+
+def spec_digest(spec) -> str:
+    """Every field of the ModelSpec (the no_truncation_* keys differ from the baseline ones in the spec's caps only)."""
+    return hashlib.sha256(repr(sorted(dataclasses.asdict(spec).items())).encode()).hexdigest()
+
+
+def oracle_code_digest() -> str:
+    """sha256 over the source of the oracle modules a cached rollout went through: a later change of the oracle's semantics
+    (or of the spec / weight layout it reads) makes every cached file stale instead of silently 'matching'."""
+    import prosim_amd.spec as _spec
+    import prosim_amd.weights as _weights
+    h = hashlib.sha256()
+    for mod in (orc, _spec, _weights):
+        with open(mod.__file__, "rb") as f:
+            h.update(f.read())
     return h.hexdigest()
 
 
@@ -61,16 +79,19 @@ def oracle64(key: str, spec, w, scene, collect: bool = False, floor: bool = Fals
     it holds ``key`` for exactly these inputs.  ``floor``: also the per-agent max distance of the fp32 oracle's trajectories
     from the fp64 ones (the scene's fp32 floor) as ``o['fp32_floor']``."""
     path = os.path.join(CACHE, key + ".npz")
-    want = dict(scene=_digest({k: v for k, v in scene.items() if not k.startswith("_")}), weights=_digest(w))
+    want = dict(scene=_digest({k: v for k, v in scene.items() if not k.startswith("_")}), weights=_digest(w), spec=spec_digest(spec),
+                code=oracle_code_digest())
     if os.path.exists(path) and not write:
         g = np.load(path)
         if str(g["scene_digest"]) == want["scene"] and str(g["weight_digest"]) == want["weights"] and \
+                "spec_digest" in g.files and str(g["spec_digest"]) == want["spec"] and \
+                "oracle_code_digest" in g.files and str(g["oracle_code_digest"]) == want["code"] and \
                 (not collect or "scene_tokens" in g.files) and (not floor or "fp32_floor" in g.files):
             o = _unpack(g, collect)
             if floor:
                 o["fp32_floor"] = g["fp32_floor"]
             return o
-        print(f"[oracle_cache] {key}: inputs changed, recomputing")
+        print(f"[oracle_cache] {key}: inputs, spec or oracle code changed since the file was written, recomputing")
     torch.set_num_threads(min(32, os.cpu_count() or 8))
     with torch.no_grad():
         o = orc.rollout(w, spec, scene, dtype=torch.float64, collect=collect)
@@ -81,5 +102,6 @@ def oracle64(key: str, spec, w, scene, collect: bool = False, floor: bool = Fals
     if write:
         os.makedirs(CACHE, exist_ok=True)
         extra = {"fp32_floor": o["fp32_floor"]} if floor else {}
-        np.savez_compressed(path, scene_digest=np.array(want["scene"]), weight_digest=np.array(want["weights"]), **_pack(o, collect, slim), **extra)
+        np.savez_compressed(path, scene_digest=np.array(want["scene"]), weight_digest=np.array(want["weights"]),
+                            spec_digest=np.array(want["spec"]), oracle_code_digest=np.array(want["code"]), **_pack(o, collect, slim), **extra)
     return o

@@ -1,5 +1,5 @@
-"""Closed-loop parity numbers, collected by the -m gpu tests and written as ONE JSON table: gpurun_out/r03_parity.json on
-the GPU box (merged back by gpurun), copied to profiles/r03_parity.json for the record.  Per entry: replan-0 max error
+"""Closed-loop parity numbers, collected by the -m gpu tests and written as ONE JSON table: gpurun_out/r04_parity.json on
+the GPU box (merged back by gpurun), copied to profiles/r04_parity.json for the record.  Per entry: replan-0 max error
 (open loop), per-agent closed-loop max error of the trajectories: median / 99th percentile / max, the fraction of agents
 within 1e-4, and -- where the test computed it -- the fp32 floor (fp32 oracle against the fp64 oracle on the same scene)."""
 import json
@@ -31,16 +31,17 @@ def known_cut_agents(workload: str) -> set:
 
 
 def closed_loop_gate(workload: str, d: np.ndarray, tol: float = 1e-4):
-    """The closed-loop bar at what is measured: >= 99.5 % of the agents within 1e-4 (<= 256 agents: at most two outside), median below
+    """The closed-loop bar at what is measured: >= 99.5 % of the agents within 1e-4 (more outside only where the workload's committed cut list is that long), median below
     2e-5 on the timed workload (3e-5 elsewhere), nobody beyond 2e-3, and every agent outside the band is on the committed list of that workload's cut agents."""
     d = np.asarray(d, np.float64)
     outside = set(int(i) for i in np.nonzero(d >= tol)[0])
     new = outside - known_cut_agents(workload)
     assert not new, f"{workload}: agents {sorted(new)} left the {tol:g} band (errors {[float(d[i]) for i in sorted(new)]}); known cut agents: {sorted(known_cut_agents(workload))}"
-    # >= 99.5 % inside the band; a workload of <= 256 agents may have two listed cut agents (round 3: the dense 256-agent no-truncation
-    # scene has 16 relative angles within 2e-5 rad of a cut in the fp64 oracle, tools/cut_margin.py, and two agents outside: 79 at 2.4e-4,
-    # 204 at 6.5e-4 -- one of 204's own edges passes 4.7e-7 rad from the cut)
-    assert (d < tol).mean() >= 0.995 or d.size <= 256 and len(outside) <= 2, (workload, float((d < tol).mean()))
+    # >= 99.5 % inside the band.  The only workloads that may have more outside are the ones whose COMMITTED list is itself longer than
+    # 0.5 % of their agents (today one: the dense 256-agent no-truncation configs[4] scene, agents 79 and 204 -- its fp64 rollout has 16
+    # relative angles within 2e-5 rad of a cut, one of 204's own edges passes 4.7e-7 rad from it; tests/golden/near_cut_rows.json) --
+    # a per-workload exception that lives in known_cut_agents.json, not a rule about small workloads.
+    assert len(outside) <= max(int(0.005 * d.size), len(known_cut_agents(workload))), (workload, sorted(outside), float((d < tol).mean()))
     # median: 2e-5 on the timed workload (measured 1.5e-5); the 64-agent config sits at 2.5e-5 (its fp32 oracle: 2.4e-5)
     med_bar = 2e-5 if workload.startswith("bench_workload") else 3e-5
     assert np.median(d) < med_bar and d.max() < 2e-3, (workload, float(np.median(d)), float(d.max()))
@@ -50,7 +51,7 @@ def record(name: str, **fields):
     _ROWS[name] = fields
     out_dir = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out_dir, exist_ok=True)
-    path = os.path.join(out_dir, "r03_parity.json")
+    path = os.path.join(out_dir, "r04_parity.json")
     table = {}
     if os.path.exists(path):
         try:
