@@ -229,6 +229,11 @@ int ps_set_chain_rows(ps_engine* e, int32_t rows);
  * kernels stay in the library: each is the other's cross-check in the parity tests.  Resets ps_set_chain_rows to 0 and
  * invalidates the encoded / generated stages. */
 int ps_set_chain_impl(ps_engine* e, int32_t impl);
+/* Which kernels run the dense per-row stacks (PointNet encoders, the node half of the split s2s layers, k | v projections):
+ * 0 (default) = the row-tile kernels of round 4 (ps_rowtile.h: a wave carries 16..80 rows through the whole stack in registers,
+ * chained transposed MFMA GEMMs, no barriers), 1 = the staged kernels of rounds 1-3 (k_pointnet_mfma, k_node, k_kv_proj:
+ * GEMM -> LDS -> barrier -> epilogue per Linear).  Both stay in the library: each is the other's cross-check. */
+int ps_set_row_impl(ps_engine* e, int32_t impl);
 /* The engine's hipStream_t (every entry point enqueues on it), so a host can order its own streams against the
  * engine with events instead of ps_sync -- bench.py overlaps the RCCL metric gather of rollout k with rollout k+1. */
 void* ps_stream(ps_engine* e);
@@ -308,6 +313,10 @@ int ps_policy_event_times(ps_engine* e, float* ms, int32_t capacity);
 /* Unit-test hooks for single primitives (parity against tests/golden/ref_pure_primitives.npz). */
 int ps_test_pointnet(ps_engine* e, int32_t which /*0 map, 1 obs*/, int32_t n_poly, int32_t P,
                      const float* x, const uint8_t* point_mask, float* out);
+/* the same with the row-tile kernel forced to `mt` row tiles per wave (1..5; 0 = the engine's choice, -1 = the staged kernel of
+ * rounds 1-3), and, with iters > 0, the mean launch time in ms (HIP events on the engine's stream) */
+int ps_test_pointnet_mt(ps_engine* e, int32_t which, int32_t n_poly, int32_t P, const float* x, const uint8_t* point_mask,
+                        float* out, int32_t mt, int32_t iters, float* ms_out);
 int ps_test_fourier(ps_engine* e, int32_t n, const float* x4, float* out128);
 int ps_test_wrap(ps_engine* e, int32_t n, const float* x, float* out);
 /* One AttentionLayer (models/layers/attention_layer.py:56-121) on caller-supplied tokens and a

@@ -27,7 +27,7 @@ static thread_local std::string g_err;
 // (-DPS_EXPERIMENTS: tools/README.md).  The product library compiles them out -- a stray PS_* variable cannot change which kernel
 // runs or corrupt a rollout -- and says so once, loudly, when it finds one set.
 static const char* const kExpEnv[] = {"PS_C16_ABL", "PS_XCD", "PS_CHAIN_T", "PS_CHAIN_TP", "PS_CHAIN_T1", "PS_CHAIN_FLAGS", "PS_CHAIN_PROF",
-                                      "PS_C16_ROWS", "PS_S2S_C16", "PS_NO_SPLIT", "PS_SPLIT_MIN", "PS_RT_MT", "PS_LEGACY_NODE"};
+                                      "PS_C16_ROWS", "PS_S2S_C16", "PS_NO_SPLIT", "PS_SPLIT_MIN"};
 #ifdef PS_EXPERIMENTS
 static const char* exp_env(const char* name) { return getenv(name); }
 #else
@@ -730,11 +730,6 @@ extern "C" int ps_create(const ps_config* cfg, int32_t n_tensors, const char* co
   // the chain kernel may use up to ~140 KiB of dynamic LDS
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_kv_proj), hipFuncAttributeMaxDynamicSharedMemorySize, (int)KV_LDS_BYTES);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pointnet_mfma), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PN_LDS_BYTES);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pointnet_rt<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * rt_pn_wave_bytes<1>()));
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pointnet_rt<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * rt_pn_wave_bytes<2>()));
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pointnet_rt<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * rt_pn_wave_bytes<3>()));
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pointnet_rt<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * rt_pn_wave_bytes<4>()));
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pointnet_rt<5>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * rt_pn_wave_bytes<5>()));
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pe_learn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PL_LDS_BYTES);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_node<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ND_LDS_BYTES);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_node<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ND_LDS_BYTES);
@@ -1613,43 +1608,40 @@ void launch_kv(ps_engine* e, const float* x, int Ns, int layer0, int nlayers, fl
                      (const AttnW*)(e->d_layers + layer0), kv, khl, layer_stride, e->cfg.ln_eps);
 }
 
-// Row-tile PointNet (ps_rowtile.h): a wave takes G = min(16, 16 MT / P) polylines.  MT by the row count: enough waves for the
-// chip's 1024 SIMDs first, then the tile count that wastes the fewest rows (P = 19: MT 5 -> 4 polylines = 76 of 80 rows).
-int pointnet_mt(int n_rows, int P) {
-  static const int env_mt = exp_env("PS_RT_MT") ? atoi(exp_env("PS_RT_MT")) : 0;   // experiments only
-  if (env_mt >= 1 && env_mt <= 5 && 16 * env_mt >= P) return env_mt;
-  int best = 0;
+// Row-tile PointNet (ps_rowtile.h): a polyline's P points take L lanes x MT row tiles (MT L >= P), a wave G = 16 / L polylines.
+// (MT, L) by the row count: enough waves for the chip's 1024 SIMDs first, then the layout that wastes the fewest slots
+// (P = 19: 5 tiles x 4 lanes = 20 slots; P = 11: 3 x 4 = 12 when there are many polylines, 1 x 16 when there are few).
+int g_force_mt = 0;   // test hook (ps_test_pointnet_mt): row tiles per wave, -1 = the staged kernel
+struct RtShape { int mt, l; };
+constexpr RtShape kRtShapes[] = {{1, 4}, {1, 8}, {1, 16}, {2, 8}, {2, 16}, {3, 4}, {3, 8}, {4, 8}, {5, 4}};   // the builds in the library: every P <= 32 fits (2, 16)
+RtShape pointnet_shape(int n_rows, int P) {
+  RtShape best{0, 0};
   double best_cost = 0;
-  for (int mt = 1; mt <= 5; ++mt) {
-    const int G = std::min(16, 16 * mt / P);
-    if (G < 1) continue;
-    const long waves = (n_rows + G - 1) / G;
-    const long rounds = (waves + 1023) / 1024;          // one wave per SIMD (MT >= 3: more than 256 registers)
-    const double cost = (double)rounds * (mt + 0.6);    // a wave's time ~ tiles + a fixed part (pools, pooled-row GEMMs, fragment latency)
-    if (!best || cost < best_cost) { best = mt; best_cost = cost; }
+  for (const RtShape& sh : kRtShapes) {
+    if (g_force_mt >= 1 && sh.mt != g_force_mt) continue;
+    if (sh.mt * sh.l < P) continue;
+    const long waves = (n_rows + 16 / sh.l - 1) / (16 / sh.l);
+    const long rounds = (waves + (sh.mt <= 2 ? 2047 : 1023)) / (sh.mt <= 2 ? 2048 : 1024);   // (MT <= 2: two waves per SIMD)
+    const double cost = (double)rounds * (sh.mt + 1.2);    // a wave's time ~ tiles + a fixed part (pooled-row GEMMs, fragment latency)
+    if (!best.mt || cost < best_cost) { best = sh; best_cost = cost; }
   }
   return best;
 }
-template <int MT>
+template <int MT, int L>
 void launch_pointnet_rt(ps_engine* e, const PointNetW& w, const float* pts, const uint8_t* mask, const int* rows, int n_rows, int P,
                         int feat_mask_dim, float* out) {
-  const int G = std::min(16, 16 * MT / P);
-  const int waves = (n_rows + G - 1) / G;
-  hipLaunchKernelGGL(k_pointnet_rt<MT>, dim3((waves + 3) / 4), dim3(256), 4 * rt_pn_wave_bytes<MT>(), e->stream, w, pts, mask, rows, n_rows, P,
+  const int waves = (n_rows + 16 / L - 1) / (16 / L);
+  hipLaunchKernelGGL((k_pointnet_rt<MT, L>), dim3((waves + 3) / 4), dim3(256), 0, e->stream, w, pts, mask, rows, n_rows, P,
                      feat_mask_dim, out, e->cfg.ln_eps);
 }
 void launch_pointnet(ps_engine* e, const PointNetW& w, const float* pts, const uint8_t* mask, const int* rows, int n_rows,
                      int P, int feat_mask_dim, float* out) {
   if (n_rows <= 0) return;
-  if (!e->legacy_rows && w.n_pre >= 1 && w.n_mid >= 1 && w.in_dim <= 32) {
-    switch (pointnet_mt(n_rows, P)) {
-      case 1: launch_pointnet_rt<1>(e, w, pts, mask, rows, n_rows, P, feat_mask_dim, out); return;
-      case 2: launch_pointnet_rt<2>(e, w, pts, mask, rows, n_rows, P, feat_mask_dim, out); return;
-      case 3: launch_pointnet_rt<3>(e, w, pts, mask, rows, n_rows, P, feat_mask_dim, out); return;
-      case 4: launch_pointnet_rt<4>(e, w, pts, mask, rows, n_rows, P, feat_mask_dim, out); return;
-      case 5: launch_pointnet_rt<5>(e, w, pts, mask, rows, n_rows, P, feat_mask_dim, out); return;
-      default: break;
-    }
+  if (!e->legacy_rows && g_force_mt >= 0 && w.n_pre >= 1 && w.n_mid >= 1 && w.in_dim <= 32) {
+    const RtShape sh = pointnet_shape(n_rows, P);
+#define PS_RT(MT_, L_) if (sh.mt == MT_ && sh.l == L_) { launch_pointnet_rt<MT_, L_>(e, w, pts, mask, rows, n_rows, P, feat_mask_dim, out); return; }
+    PS_RT(1, 4) PS_RT(1, 8) PS_RT(1, 16) PS_RT(2, 8) PS_RT(2, 16) PS_RT(3, 4) PS_RT(3, 8) PS_RT(4, 8) PS_RT(5, 4)
+#undef PS_RT
   }
   const int G = std::min(PN_G, PN_ROWS / P);   // polylines per workgroup (ps_set_scene bounds P <= 32)
   hipLaunchKernelGGL(k_pointnet_mfma, dim3((n_rows + G - 1) / G), dim3(256), PN_LDS_BYTES, e->stream, w, pts, mask, rows, n_rows, P,
@@ -2455,6 +2447,51 @@ extern "C" int ps_test_pointnet(ps_engine* e, int32_t which, int32_t n_poly, int
     return fail(PS_E_HIP, "test upload failed");
   launch_pointnet(e, w, dx.p, dm.p, nullptr, n_poly, P, 0, dout.p);
   HIPCHK(hipStreamSynchronize(e->stream));
+  HIPCHK(hipMemcpy(out, dout.p, sizeof(float) * n_poly * D, hipMemcpyDeviceToHost));
+  dx.release(); dm.release(); dout.release();
+  return PS_OK;
+}
+
+extern "C" int ps_test_pointnet_mt(ps_engine* e, int32_t which, int32_t n_poly, int32_t P, const float* x, const uint8_t* point_mask,
+                                   float* out, int32_t mt, int32_t iters, float* ms_out) {
+  if (!e) return fail(PS_E_ARG, "null engine");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  const PointNetW& w = which == 0 ? e->pn_map : e->pn_obs;
+  DevBuf<float> dx, dout;
+  DevBuf<uint8_t> dm;
+  if (upload(dx, x, (size_t)n_poly * P * w.in_dim, e->stream) || upload(dm, point_mask, (size_t)n_poly * P, e->stream) ||
+      dout.ensure((size_t)n_poly * D))
+    return fail(PS_E_HIP, "test upload failed");
+  g_force_mt = mt;
+  launch_pointnet(e, w, dx.p, dm.p, nullptr, n_poly, P, 0, dout.p);
+  HIPCHK(hipStreamSynchronize(e->stream));
+  if (iters > 0 && ms_out) {
+    hipEvent_t a, b;
+    HIPCHK(hipEventCreate(&a));
+    HIPCHK(hipEventCreate(&b));
+    HIPCHK(hipEventRecord(a, e->stream));
+    for (int i = 0; i < iters; ++i) launch_pointnet(e, w, dx.p, dm.p, nullptr, n_poly, P, 0, dout.p);
+    HIPCHK(hipEventRecord(b, e->stream));
+    HIPCHK(hipEventSynchronize(b));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, a, b));
+    *ms_out = ms / iters;
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+  }
+  g_force_mt = 0;
+#ifdef PS_RT_PROF
+  {
+    unsigned long long h[32];
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_rt_prof), sizeof(h));
+    fprintf(stderr, "[rt prof] mt=%d cycles of wave 0 per launch:", mt);
+    static const char* nm[10] = {"input", "gemm0", "epi0", "pool1", "to_op", "pooledgemm", "midgemm", "midepi", "pool2", "out"};
+    for (int i = 0; i < 10; ++i) fprintf(stderr, " %s:%.0f", nm[i], (double)h[i] / (iters + 1));
+    fprintf(stderr, "\n");
+    unsigned long long z[32] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_rt_prof), z, sizeof(z));
+  }
+#endif
   HIPCHK(hipMemcpy(out, dout.p, sizeof(float) * n_poly * D, hipMemcpyDeviceToHost));
   dx.release(); dm.release(); dout.release();
   return PS_OK;

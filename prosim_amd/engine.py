@@ -86,6 +86,7 @@ def load_library():
     lib.ps_declare_agent_rows.argtypes = [vp, C.c_int32, C.c_int32, u8p]
     lib.ps_set_chain_rows.argtypes = [vp, C.c_int32]
     lib.ps_set_chain_impl.argtypes = [vp, C.c_int32]
+    lib.ps_set_row_impl.argtypes = [vp, C.c_int32]
     lib.ps_enable_policy_events.argtypes = [vp, C.c_int32]
     lib.ps_policy_event_times.argtypes = [vp, fp, C.c_int32]
     lib.ps_stream.argtypes = [vp]
@@ -104,6 +105,7 @@ def load_library():
     lib.ps_time_rollout.argtypes = [vp, C.c_int32, C.c_int32, fp, fp]
     lib.ps_time_policy_kernel.argtypes = [vp, C.c_int32, fp]
     lib.ps_test_pointnet.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, fp, u8p, fp]
+    lib.ps_test_pointnet_mt.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, fp, u8p, fp, C.c_int32, C.c_int32, fp]
     lib.ps_test_fourier.argtypes = [vp, C.c_int32, fp, fp]
     lib.ps_test_wrap.argtypes = [vp, C.c_int32, fp, fp]
     lib.ps_test_attn.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, fp, fp, fp, i32p, i32p, C.c_int32, fp]
@@ -115,9 +117,9 @@ def load_library():
 
 
 EXPORTS = ["ps_create", "ps_destroy", "ps_last_error", "ps_set_scene", "ps_set_prompt", "ps_policy_forward", "ps_set_conditions", "ps_set_drag_points", "ps_set_pair_conditions", "ps_set_future_obs", "ps_set_future_log", "ps_set_mode_choice", "ps_set_action_noise", "ps_set_replicas", "ps_num_replicas", "ps_world_trajs", "ps_num_policy_agents", "ps_policy_flags",
-           "ps_encode_scene", "ps_generate_policy", "ps_reset_rollout", "ps_policy_step", "ps_rollout", "ps_sync", "ps_stream", "ps_set_chain_rows", "ps_set_chain_impl", "ps_enable_policy_events", "ps_policy_event_times", "ps_update_obs", "ps_set_map_tokens", "ps_declare_agent_rows",
+           "ps_encode_scene", "ps_generate_policy", "ps_reset_rollout", "ps_policy_step", "ps_rollout", "ps_sync", "ps_stream", "ps_set_chain_rows", "ps_set_chain_impl", "ps_set_row_impl", "ps_enable_policy_events", "ps_policy_event_times", "ps_update_obs", "ps_set_map_tokens", "ps_declare_agent_rows",
            "ps_set_state", "ps_get", "ps_rollout_metric", "ps_pair_metric", "ps_num_agents", "ps_num_map_tokens", "ps_time_rollout", "ps_time_policy_kernel",
-           "ps_test_pointnet", "ps_test_fourier", "ps_test_wrap", "ps_test_attn", "ps_test_get_edges", "ps_test_stream"]
+           "ps_test_pointnet", "ps_test_pointnet_mt", "ps_test_fourier", "ps_test_wrap", "ps_test_attn", "ps_test_get_edges", "ps_test_stream"]
 
 
 def _f(a):
@@ -406,6 +408,10 @@ class Engine:
         always and for the scene encoder's s2s layers as well (faster; another fp32 evaluation order of the scene tokens)."""
         self._check(self.lib.ps_set_chain_impl(self.h, impl))
 
+    def set_row_impl(self, impl: int):
+        """0: the row-tile kernels (default); 1: the staged row kernels of rounds 1-3 (cross-checks, A/B measurements)."""
+        self._check(self.lib.ps_set_row_impl(self.h, impl))
+
     @property
     def stream_handle(self) -> int:
         """The engine's hipStream_t as an integer (``torch.cuda.ExternalStream(handle)``)."""
@@ -498,6 +504,17 @@ class Engine:
         out = np.empty((n, self.spec.hidden), np.float32)
         self._check(self.lib.ps_test_pointnet(self.h, which, n, P, _f(x), _u8(m), _f(out)))
         return out
+
+    def test_pointnet_mt(self, which: int, x: np.ndarray, mask: np.ndarray, mt: int, iters: int = 0):
+        """Test hook: the PointNet with ``mt`` row tiles per wave (0: the engine's choice, -1: the staged round-3 kernel);
+        returns (features, ms per launch over ``iters`` launches or None)."""
+        x = np.ascontiguousarray(x, np.float32)
+        m = np.ascontiguousarray(mask).astype(np.uint8)
+        n, P = m.shape
+        out = np.empty((n, self.spec.hidden), np.float32)
+        ms = C.c_float(0)
+        self._check(self.lib.ps_test_pointnet_mt(self.h, which, n, P, _f(x), _u8(m), _f(out), mt, iters, C.byref(ms)))
+        return out, (float(ms.value) if iters > 0 else None)
 
     def test_fourier(self, x4: np.ndarray) -> np.ndarray:
         x4 = np.ascontiguousarray(x4, np.float32)
