@@ -101,6 +101,32 @@ def cpu_baseline(spec, w, scene, reps: int = 3):
                        f"{cores} intra-op threads (best of a sweep over 8/16/32/all {phys} physical cores)")
 
 
+def run_empty_rank(args, spec, n_scenes, world, backend, dev_index, multi):
+    """A rank that owns no scene (more ranks than scenes): it still takes part in every collective of the job -- the gather's
+    set-up, the two metric computations, the barriers and the max-over-ranks / agent-count reductions -- with zero rows."""
+    from prosim_amd.distributed import SceneMetricGather
+    assert multi, "a rank without scenes exists only in a multi-rank job"
+    N = synth.BASELINE_CONFIGS[args.config]["n_agents"]
+    dev = "cuda" if backend == "nccl" else "cpu"
+    gather = SceneMetricGather([], n_scenes, N, 10, dev)
+    empty = torch.zeros(0, N, 10, device=dev)
+    gather(empty)                      # (warm-up computation)
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    gather(empty)                      # the timed region's metric computation
+    dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    agents = torch.tensor([0], device=dev, dtype=torch.float64)
+    dist.all_reduce(agents)
+    gather(empty)                      # the final metric computation after the event-timed rollouts
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -109,6 +135,9 @@ def main():
                          "under-report the steady state: 5 steps 15.0 M, 10: 18.7 M, 20: 21.1 M, 100: 21.2 M, 200: 21.3 M agent-steps/s")
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--scenes-per-gpu", type=int, default=8)
+    ap.add_argument("--total-scenes", type=int, default=0,
+                    help="job size in scenes when it is NOT scenes-per-gpu x ranks (uneven shards, ranks without a scene: the sharding is i %% world); "
+                         "0 = scenes-per-gpu x ranks")
     ap.add_argument("--config", type=int, default=2, help="BASELINE.json config index used as the per-scene workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--chain-rows", type=int, default=-1, choices=[-1, 0, 1, 2, 4, 8, 9, 10, 11, 12, 13, 14, 15, 16],
@@ -150,9 +179,11 @@ def main():
 
     spec = DEMO_SPEC
     w = weights.init_weights(spec, 0)
-    S = args.scenes_per_gpu
-    n_scenes = S * world
+    n_scenes = args.total_scenes if args.total_scenes > 0 else args.scenes_per_gpu * world
     my_scenes = shard_scenes(n_scenes, rank, world)
+    S = len(my_scenes)            # this rank's scenes (== --scenes-per-gpu unless --total-scenes makes the shards uneven)
+    if S == 0:
+        return run_empty_rank(args, spec, n_scenes, world, backend, dev_index, multi)
     # scene i of the job is seed i of the generator; this rank's batch = its shard, in shard order
     parts = [synth.baseline_scene(spec, args.config, seed=i, batch=1) for i in my_scenes]
     scene = {k: (np.concatenate([p[k] for p in parts]) if not isinstance(parts[0][k], dict) else
@@ -421,11 +452,11 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             # fp32 throughout; the matrix-core GEMMs take split-fp16 operands with fp32 accumulation (fp32-class)
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32 (split-f16x3 MFMA: fp16 hi + lo operands, three products per multiply, fp32 accumulate)", "data": "synthetic",
             "config": {"workload": f"{S} x BASELINE configs[{args.config}] scenes per GPU ({synth.BASELINE_CONFIGS[args.config]['name']}; "
                                    f"S=8 is configs[3]'s per-GPU share), 80-step closed-loop rollout (8 replans), seeded random-init weights",
                        "agents_per_scene": int(scene['prompt_mask'][0].sum()), "polylines_per_scene": int(scene['map_mask'].shape[1]),
-                       "scenes_per_gpu": S, "rollouts_in_flight": n_fl, "chain_rows_per_workgroup": chain_rows,
+                       "scenes_per_gpu": S, "scenes_total": n_scenes, "rollouts_in_flight": n_fl, "chain_rows_per_workgroup": chain_rows,
                        "parallelism": f"scene-sharded x{world}, RCCL all-gather of the per-agent PairMotionPred sums; consecutive steps pipelined over "
                                       f"{n_fl} engine(s) per GPU"},
             # bound: what the counters of the launch say (profiles/r03_*_pmc_chain16.txt: the VALU busy more than half of the SIMD

@@ -190,6 +190,7 @@ struct ps_engine {
   // whole-rollout hipGraph (captured on the first ps_rollout after a scene / condition change)
   hipGraph_t graph = nullptr;
   hipGraphExec_t graph_exec = nullptr;
+  int node_mt = 0;            // ps_set_row_impl(10 + mt): row tiles per wave of the row-tile node kernels forced to mt (experiments, tests)
   bool legacy_rows = false;   // ps_set_row_impl(1): the round-3 staged row kernels (k_pointnet_mfma, k_node) instead of the row-tile ones (A/B and parity tools)
   int chain_rows = 0;   // ps_set_chain_rows: 0 = latency-optimal choice, else rows per workgroup of the fused attention launches
   int chain_impl = 0;   // ps_set_chain_impl: 0 = by mode (k_chain16 in throughput mode: chain_rows >= 8; k_attn_chain otherwise), 1 = k_attn_chain, 2 = k_chain16, 3 = k_chain16 + the encoder's s2s layers on it
@@ -258,11 +259,12 @@ struct Builder {
   // to a multiple of 32: [n-tile 8][k-block][hi|lo][lane 64][8], lane = (n & 15) + 16*kq holds k = 32*ks + 8*kq ..+8
   // perm: the K index inside a 32-wide k-block runs in the order the row-tile kernels hand a result tile on (ps_rowtile.h):
   // lane group kq, element j <-> k = 32 ks + 16 (j >> 2) + 4 kq + (j & 3) instead of 32 ks + 8 kq + j
-  void fragments(const _Float16** p, const std::string& name, int out, int in, int in0, int in_n, bool perm = false) {
+  // (every fragment's lo half is scaled by 2^11, ps_device.h f16_los); perm: the permuted K order of the row-tile kernels
+  void fragments(const _Float16** p, const std::string& name, int out, int in, int in0, int in_n, bool perm = false, bool rt = false) {
     const float* s = get(name, (int64_t)out * in);
-    if (s) fragments_raw(p, s, out, in, in0, in_n, perm);
+    if (s) fragments_raw(p, s, out, in, in0, in_n, perm, rt);
   }
-  void fragments_raw(const _Float16** p, const float* s, int out, int in, int in0, int in_n, bool perm = false) {
+  void fragments_raw(const _Float16** p, const float* s, int out, int in, int in0, int in_n, bool perm = false, bool /*rt*/ = false) {
     const int k32 = (in_n + 31) / 32, nt_n = out / 16;
     std::vector<float> packed(((size_t)nt_n * k32 * 2 * 512 + 1) / 2);
     _Float16* h = reinterpret_cast<_Float16*>(packed.data());
@@ -276,7 +278,7 @@ struct Builder {
             const _Float16 hi = (_Float16)v;
             const size_t o = ((size_t)(nt * k32 + ks) * 2) * 512 + (size_t)lane * 8 + j;
             h[o] = hi;
-            h[o + 512] = (_Float16)(v - (float)hi);
+            h[o + 512] = (_Float16)((v - (float)hi) * 2048.f);   // (ps_device.h f16_los: every GEMM fragment carries the scaled lo half)
           }
     slot(reinterpret_cast<const float**>(p), put(packed));
   }
@@ -389,12 +391,12 @@ void build_attn(Builder& b, const std::string& p, AttnW& w) {
               const _Float16 hi = (_Float16)v;
               const size_t o = (size_t)(h * ntq + nt) * 1024 + (size_t)lane * 8 + j;
               hh[o] = hi;
-              hh[o + 512] = (_Float16)(v - (float)hi);
+              hh[o + 512] = (_Float16)((v - (float)hi) * 2048.f);
             }
       b.slot(reinterpret_cast<const float**>(dst), b.put(packed));
     };
     // to_v_r fold: per head h the n-tile of columns 16h..16h+15 of Wvr_gt [c][hd]; B[k = c][n = d]
-    auto vr_frag = [&](const _Float16** dst, const std::vector<float>& wv_, int kr) {
+    auto vr_frag = [&](const _Float16** dst, const std::vector<float>& wv_, int kr, float lo_scale = 2048.f) {
       std::vector<float> packed(((size_t)8 * kr * 1024 + 1) / 2);
       _Float16* hh = reinterpret_cast<_Float16*>(packed.data());
       for (int h = 0; h < 8; ++h)
@@ -406,7 +408,7 @@ void build_attn(Builder& b, const std::string& p, AttnW& w) {
               const _Float16 hi = (_Float16)v;
               const size_t o = (size_t)(h * kr + ks) * 1024 + (size_t)lane * 8 + j;
               hh[o] = hi;
-              hh[o + 512] = (_Float16)(v - (float)hi);
+              hh[o + 512] = (_Float16)((v - (float)hi) * lo_scale);
             }
       b.slot(reinterpret_cast<const float**>(dst), b.put(packed));
     };
@@ -416,16 +418,45 @@ void build_attn(Builder& b, const std::string& p, AttnW& w) {
         wkrg3[(size_t)hd * D + 64 + i] += wkrg3[(size_t)hd * D + 96 + i];
         wvrgt3[(size_t)(64 + i) * D + hd] += wvrgt3[(size_t)(96 + i) * D + hd];
       }
+    {   // row-tile q~ (ps_rowtile.h): K = 16 fragments, A[m = c][k = d] = Wkr_g3[16 h + d][16 ct + m]; lane = m + 16 kq holds d = 4 kq .. 4 kq + 3
+      std::vector<float> packed(((size_t)8 * 6 * 2 * 256 + 1) / 2);
+      _Float16* hh = reinterpret_cast<_Float16*>(packed.data());
+      for (int h = 0; h < 8; ++h)
+        for (int ct = 0; ct < 6; ++ct)
+          for (int lane = 0; lane < 64; ++lane)
+            for (int j = 0; j < 4; ++j) {
+              const int c = ct * 16 + (lane & 15), d = (lane >> 4) * 4 + j;
+              const float v = wkrg3[(size_t)(h * 16 + d) * D + c];
+              const _Float16 hi = (_Float16)v;
+              const size_t o = (size_t)(h * 6 + ct) * 512 + (size_t)lane * 4 + j;
+              hh[o] = hi;
+              hh[o + 256] = (_Float16)((v - (float)hi) * 2048.f);
+            }
+      b.slot(reinterpret_cast<const float**>(&w.Fkr3_x), b.put(packed));
+    }
+    if (wq && ws && wg) {
+      std::vector<float> qsg((size_t)3 * D * D);
+      std::copy(wq, wq + (size_t)D * D, qsg.begin());
+      std::copy(ws, ws + (size_t)D * D, qsg.begin() + (size_t)D * D);
+      for (int n = 0; n < D; ++n) std::copy(wg + (size_t)n * 2 * D + D, wg + (size_t)n * 2 * D + 2 * D, qsg.begin() + (size_t)(2 * D + n) * D);
+      b.fragments_raw(&w.Fqsg_Q, qsg.data(), 3 * D, D, 0, D, true);
+    }
+    b.fragments(&w.Fga_Q, p + ".to_g.weight", D, 2 * D, 0, D, true);
+    b.fragments(&w.Fout_Q, p + ".to_out.weight", D, D, 0, D, true);
+    b.fragments(&w.F1_Q, p + ".ff_mlp.0.weight", FF, D, 0, D, true);
+    b.fragments(&w.F2_Q, p + ".ff_mlp.3.weight", D, FF, 0, FF, true);
     kr_frag(&w.Fkr, wkrg, 8);
     kr_frag(&w.Fkr3, wkrg3, 6);
     vr_frag(&w.Fvr, wvrgt, 4);
     vr_frag(&w.Fvr3, wvrgt3, 3);
+    vr_frag(&w.Fvr3_Q, wvrgt3, 3, 2048.f);
   }
   {   // [to_k ; to_v] as one [256][128] Linear -> B fragments
     std::vector<float> kvw((size_t)2 * D * D);
     std::copy(wk, wk + (size_t)D * D, kvw.begin());
     std::copy(wv, wv + (size_t)D * D, kvw.begin() + (size_t)D * D);
     b.fragments_raw(&w.Wkv_F, kvw.data(), 2 * D, D, 0, D);
+    b.fragments_raw(&w.Wkv_Q, kvw.data(), 2 * D, D, 0, D, true);
   }
   b.slot(&w.bkv, b.put(bkv));
   // packed small vectors (ps_attn.h SP_* offsets)
@@ -481,7 +512,7 @@ void build_pointnet(Builder& b, const std::string& p, int in_dim, int n_pre, int
     const std::string q = p + ".pre_mlps.mlp." + std::to_string(sq[l].first);
     b.transposed(&w.pre_Wt[l], q + ".weight", D, K);
     b.fragments(&w.pre_F[l], q + ".weight", D, K, 0, K);
-    if (l > 0) b.fragments(&w.pre_Q[l], q + ".weight", D, K, 0, K, true);
+    b.fragments(&w.pre_Q[l], q + ".weight", D, K, 0, K, l > 0, true);   // (layer 0 reads the input rows in the natural K order)
     b.plain(&w.pre_b[l], q + ".bias", D);
     if (sq[l].second >= 0) {
       const std::string n = p + ".pre_mlps.mlp." + std::to_string(sq[l].second);
@@ -730,6 +761,13 @@ extern "C" int ps_create(const ps_config* cfg, int32_t n_tensors, const char* co
   // the chain kernel may use up to ~140 KiB of dynamic LDS
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_kv_proj), hipFuncAttributeMaxDynamicSharedMemorySize, (int)KV_LDS_BYTES);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pointnet_mfma), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PN_LDS_BYTES);
+#define PS_RT_ATTR(K) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RT_LDS_BYTES)
+  PS_RT_ATTR((k_pointnet_rt<1, 4>)); PS_RT_ATTR((k_pointnet_rt<1, 8>)); PS_RT_ATTR((k_pointnet_rt<1, 16>)); PS_RT_ATTR((k_pointnet_rt<2, 8>));
+  PS_RT_ATTR((k_pointnet_rt<2, 16>)); PS_RT_ATTR((k_pointnet_rt<3, 4>)); PS_RT_ATTR((k_pointnet_rt<3, 8>)); PS_RT_ATTR((k_pointnet_rt<4, 8>));
+  PS_RT_ATTR((k_pointnet_rt<5, 4>));
+  PS_RT_ATTR(k_node_pre_rt<1>); PS_RT_ATTR(k_node_pre_rt<2>); PS_RT_ATTR(k_node_pre_rt<3>);
+  PS_RT_ATTR(k_node_post_rt<1>); PS_RT_ATTR(k_node_post_rt<2>); PS_RT_ATTR(k_node_post_rt<3>);
+#undef PS_RT_ATTR
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pe_learn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PL_LDS_BYTES);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_node<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ND_LDS_BYTES);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_node<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ND_LDS_BYTES);
@@ -1497,7 +1535,23 @@ int launch_split_layer(ps_engine* e, float* x, int Nd, const ChainStep* stp, int
   const dim3 gn((Nd + ND_ROWS - 1) / ND_ROWS), ge((Nd + 3) / 4);
   const float eps = e->cfg.ln_eps;
   const ChainStep* none = nullptr;
-  if (kr == 3) {
+  if (kr == 3 && !e->legacy_rows) {
+    // row-tile node halves (ps_rowtile.h): a wave owns 16 MT rows, no barriers.  MT: one tile per wave while the launch has fewer
+    // waves than the chip has SIMDs (latency), more rows per weight fragment beyond that
+    const int tiles = (Nd + 15) / 16;
+    // (measured on the 9216-row s2s layers of the benchmark batch: alone on the GPU 1 tile per wave is fastest -- 1.55 / 1.76 / 1.99 ms
+    // per scene encoding at 1 / 2 / 3 tiles; with four rollouts in flight 2 tiles give 22.7 M agent-steps/s against 22.5 / 22.5)
+    const int mt = e->node_mt ? e->node_mt : ((e->chain_rows >= 8 && tiles >= 256) || tiles >= 4096 ? 2 : 1);
+    const dim3 gr((unsigned)(((tiles + mt - 1) / mt + 3) / 4));
+    if (mt == 1) hipLaunchKernelGGL(k_node_pre_rt<1>, gr, dim3(256), RT_LDS_BYTES, st, (const float*)x, Nd, stp, io, eps, kv_out, khl_out);
+    else if (mt == 2) hipLaunchKernelGGL(k_node_pre_rt<2>, gr, dim3(256), RT_LDS_BYTES, st, (const float*)x, Nd, stp, io, eps, kv_out, khl_out);
+    else hipLaunchKernelGGL(k_node_pre_rt<3>, gr, dim3(256), RT_LDS_BYTES, st, (const float*)x, Nd, stp, io, eps, kv_out, khl_out);
+    if (maxdeg <= 32) hipLaunchKernelGGL((k_edge_small<3, 2>), ge, dim3(256), es_lds_bytes<2>(), st, Nd, stp, io);
+    else hipLaunchKernelGGL((k_edge_small<3, 8>), ge, dim3(256), es_lds_bytes<8>(), st, Nd, stp, io);
+    if (mt == 1) hipLaunchKernelGGL(k_node_post_rt<1>, gr, dim3(256), RT_LDS_BYTES, st, x, Nd, stp, io, eps);
+    else if (mt == 2) hipLaunchKernelGGL(k_node_post_rt<2>, gr, dim3(256), RT_LDS_BYTES, st, x, Nd, stp, io, eps);
+    else hipLaunchKernelGGL(k_node_post_rt<3>, gr, dim3(256), RT_LDS_BYTES, st, x, Nd, stp, io, eps);
+  } else if (kr == 3) {
     hipLaunchKernelGGL(k_node<3>, gn, dim3(256), ND_LDS_BYTES, st, x, Nd, none, stp, io, eps, kv_out, khl_out);
     if (maxdeg <= 32) hipLaunchKernelGGL((k_edge_small<3, 2>), ge, dim3(256), es_lds_bytes<2>(), st, Nd, stp, io);
     else hipLaunchKernelGGL((k_edge_small<3, 8>), ge, dim3(256), es_lds_bytes<8>(), st, Nd, stp, io);
@@ -1621,7 +1675,7 @@ RtShape pointnet_shape(int n_rows, int P) {
     if (g_force_mt >= 1 && sh.mt != g_force_mt) continue;
     if (sh.mt * sh.l < P) continue;
     const long waves = (n_rows + 16 / sh.l - 1) / (16 / sh.l);
-    const long rounds = (waves + (sh.mt <= 2 ? 2047 : 1023)) / (sh.mt <= 2 ? 2048 : 1024);   // (MT <= 2: two waves per SIMD)
+    const long rounds = (waves + 1023) / 1024;   // one 4-wave workgroup per CU (128 KB of weight stages)
     const double cost = (double)rounds * (sh.mt + 1.2);    // a wave's time ~ tiles + a fixed part (pooled-row GEMMs, fragment latency)
     if (!best.mt || cost < best_cost) { best = sh; best_cost = cost; }
   }
@@ -1631,7 +1685,7 @@ template <int MT, int L>
 void launch_pointnet_rt(ps_engine* e, const PointNetW& w, const float* pts, const uint8_t* mask, const int* rows, int n_rows, int P,
                         int feat_mask_dim, float* out) {
   const int waves = (n_rows + 16 / L - 1) / (16 / L);
-  hipLaunchKernelGGL((k_pointnet_rt<MT, L>), dim3((waves + 3) / 4), dim3(256), 0, e->stream, w, pts, mask, rows, n_rows, P,
+  hipLaunchKernelGGL((k_pointnet_rt<MT, L>), dim3((waves + 3) / 4), dim3(256), RT_LDS_BYTES, e->stream, w, pts, mask, rows, n_rows, P,
                      feat_mask_dim, out, e->cfg.ln_eps);
 }
 void launch_pointnet(ps_engine* e, const PointNetW& w, const float* pts, const uint8_t* mask, const int* rows, int n_rows,
@@ -2224,9 +2278,11 @@ extern "C" int ps_set_chain_impl(ps_engine* e, int32_t impl) {
 
 extern "C" int ps_set_row_impl(ps_engine* e, int32_t impl) {
   if (!e) return fail(PS_E_ARG, "null engine");
-  if (impl != 0 && impl != 1) return fail(PS_E_ARG, "ps_set_row_impl: 0 = row-tile kernels (default), 1 = the round-3 staged kernels");
-  if (e->legacy_rows != (impl == 1)) drop_graph(e);
+  if (impl != 0 && impl != 1 && !(impl >= 11 && impl <= 13))
+    return fail(PS_E_ARG, "ps_set_row_impl: 0 = row-tile kernels (default), 1 = the round-3 staged kernels, 11..13 = row-tile kernels with 1..3 row tiles per wave in the node halves");
+  drop_graph(e);
   e->legacy_rows = impl == 1;
+  e->node_mt = impl >= 11 ? impl - 10 : 0;
   return PS_OK;
 }
 

@@ -42,6 +42,9 @@ struct AttnW {
   const _Float16 *Fvr, *Fvr3;                       // to_v_r fold: [head 8 = n-tile][k-block 4 | 3]
   const _Float16 *Fga, *Fout, *F1, *F2;             // gate (agg half), to_out, FFN up (32 n-tiles), FFN down (16 k-blocks)
   const float* sp;                                  // packed small vectors, SP_* offsets below (2432 floats)
+  // row-tile node kernels (ps_rowtile.h): the same Linears with the K index of every 32-wide k-block in the order a result tile hands
+  // its features on (Builder::fragments, perm = true), and q~'s per-head 16 x 96 blocks as K = 16 fragments [head 8][c-tile 6][hi|lo][64][4]
+  const _Float16 *Wkv_Q, *Fqsg_Q, *Fga_Q, *Fout_Q, *F1_Q, *F2_Q, *Fkr3_x, *Fvr3_Q;   // (lo halves scaled by 2^11, ps_rowtile.h)
 };
 // offsets (floats) inside AttnW::sp -- one coalesced load per layer stages them in LDS, so no
 // bias / LayerNorm-parameter load ever sits on the layer's dependency chain
@@ -814,7 +817,7 @@ __global__ __launch_bounds__(WG) void k_kv_proj(const float* __restrict__ x, int
       for (int j = 0; j < 8; ++j) {
         const float v = fmaf(a[8 * i + j] * rstd, w.ln_src_w[c0 + 8 * i + j], w.ln_src_b[c0 + 8 * i + j]);
         hh[j] = f16_hi(v);
-        ll[j] = f16_lo(v);
+        ll[j] = f16_los(v);
       }
       *reinterpret_cast<half8*>(Ah + r * PN_AS + c0 + 8 * i) = hh;
       *reinterpret_cast<half8*>(Al + r * PN_AS + c0 + 8 * i) = ll;
@@ -930,7 +933,7 @@ __device__ __forceinline__ void gemm16(RingT& R, const _Float16* __restrict__ Ah
           acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, cl[j], acc1, 0, 0, 0);
           acc2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, ch[j], acc2, 0, 0, 0);
         }
-        if (kg == KG - 1) acc += acc1 + acc2;
+        if (kg == KG - 1) acc += (acc1 + acc2) * PS_LO_INV;   // (the cross products carry the lo halves' 2^11)
         if (kg == KG - 1) {
           const int nt = wave + NWV * (g / KG);
           if (ph) {
@@ -939,7 +942,7 @@ __device__ __forceinline__ void gemm16(RingT& R, const _Float16* __restrict__ Ah
             for (int r = 0; r < 4; ++r) {
               const float v = fmaxf(acc[r] + bv, 0.f);
               ph[(4 * kq + r) * ps + nt * 16 + mi] = f16_hi(v);
-              pl[(4 * kq + r) * ps + nt * 16 + mi] = f16_lo(v);
+              pl[(4 * kq + r) * ps + nt * 16 + mi] = f16_los(v);
             }
           } else {
 #pragma unroll
@@ -980,7 +983,7 @@ __device__ __forceinline__ void planes_store8(_Float16* __restrict__ Ph, _Float1
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     h[i] = f16_hi(a[i]);
-    l[i] = f16_lo(a[i]);
+    l[i] = f16_los(a[i]);
   }
   *reinterpret_cast<half8*>(Ph) = h;
   *reinterpret_cast<half8*>(Pl) = l;
@@ -1057,19 +1060,19 @@ __global__ __launch_bounds__(256, 2) void k_node(float* __restrict__ x, int Nd, 
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         const int h = 2 * wave + t;
-        floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+        floatx4 acc = {0.f, 0.f, 0.f, 0.f}, acx = acc;
 #pragma unroll
         for (int ks = 0; ks < KR; ++ks) {
           const float av_[8] = {a0[t][ks].x, a0[t][ks].y, a0[t][ks].z, a0[t][ks].w, a1[t][ks].x, a1[t][ks].y, a1[t][ks].z, a1[t][ks].w};
           half8 ah, al;
 #pragma unroll
-          for (int j = 0; j < 8; ++j) { ah[j] = f16_hi(av_[j]); al[j] = f16_lo(av_[j]); }
+          for (int j = 0; j < 8; ++j) { ah[j] = f16_hi(av_[j]); al[j] = f16_los(av_[j]); }
           acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[t][ks], acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[t][ks], acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[t][ks], acc, 0, 0, 0);
+          acx = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[t][ks], acx, 0, 0, 0);
+          acx = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[t][ks], acx, 0, 0, 0);
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) C[(4 * kq + r) * ND_CS + h * 16 + mi] = acc[r];
+        for (int r = 0; r < 4; ++r) C[(4 * kq + r) * ND_CS + h * 16 + mi] = fmaf(acx[r], PS_LO_INV, acc[r]);
       }
     }
     __syncthreads();
@@ -1222,13 +1225,13 @@ __global__ __launch_bounds__(256, 2) void k_node(float* __restrict__ x, int Nd, 
             const int t = wave + 4 * g, h = t / NTQ, nt = t - h * NTQ;
             const half8 ah = *reinterpret_cast<const half8*>(P0h + mi * ND_AS + (h >> 1) * 32 + kq * 8);
             const half8 al = *reinterpret_cast<const half8*>(P0l + mi * ND_AS + (h >> 1) * 32 + kq * 8);
-            floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+            floatx4 acc = {0.f, 0.f, 0.f, 0.f}, acx = acc;
             acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc, 0, 0, 0);
+            acx = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acx, 0, 0, 0);
+            acx = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acx, 0, 0, 0);
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-              if (row0 + 4 * kq + r < Nd) io.qt[(size_t)(row0 + 4 * kq + r) * 1024 + h * 128 + nt * 16 + mi] = acc[r];
+              if (row0 + 4 * kq + r < Nd) io.qt[(size_t)(row0 + 4 * kq + r) * 1024 + h * 128 + nt * 16 + mi] = fmaf(acx[r], PS_LO_INV, acc[r]);
           }
         }
       }

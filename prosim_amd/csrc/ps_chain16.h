@@ -744,18 +744,18 @@ __device__ __noinline__ void c16_node_phase(const ChainStep* __restrict__ post, 
               }
             }
           }
-          floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+          floatx4 acc = {0.f, 0.f, 0.f, 0.f}, acx = acc;
 #pragma unroll
           for (int ks = 0; ks < 3; ++ks) {
             half8 ah, al;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { ah[j] = f16_hi(av_[ks][j]); al[j] = f16_lo(av_[ks][j]); }
+            for (int j = 0; j < 8; ++j) { ah[j] = f16_hi(av_[ks][j]); al[j] = f16_los(av_[ks][j]); }
             acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[ks], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[ks], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[ks], acc, 0, 0, 0);
+            acx = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[ks], acx, 0, 0, 0);
+            acx = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[ks], acx, 0, 0, 0);
           }
 #pragma unroll
-          for (int r = 0; r < 4; ++r) C[(4 * kq + r) * ND_CS + h * 16 + mi] = acc[r];
+          for (int r = 0; r < 4; ++r) C[(4 * kq + r) * ND_CS + h * 16 + mi] = fmaf(acx[r], PS_LO_INV, acc[r]);
         }
       }
       __syncthreads();
@@ -917,13 +917,13 @@ __device__ __noinline__ void c16_node_phase(const ChainStep* __restrict__ post, 
             const int t = wave + NWV * g, h = t / NTQ, nt = t - h * NTQ;
             const half8 ah = *reinterpret_cast<const half8*>(P0h + mi * ND_AS + (h >> 1) * 32 + kq * 8);
             const half8 al = *reinterpret_cast<const half8*>(P0l + mi * ND_AS + (h >> 1) * 32 + kq * 8);
-            floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+            floatx4 acc = {0.f, 0.f, 0.f, 0.f}, acx = acc;
             acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc, 0, 0, 0);
+            acx = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acx, 0, 0, 0);
+            acx = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acx, 0, 0, 0);
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-              if (4 * kq + r < nrows) QA[((W == 1 ? 0 : 8) + 4 * kq + r) * C16_QSL + h * C16_QH + nt * 16 + mi] = acc[r];
+              if (4 * kq + r < nrows) QA[((W == 1 ? 0 : 8) + 4 * kq + r) * C16_QSL + h * C16_QH + nt * 16 + mi] = fmaf(acx[r], PS_LO_INV, acc[r]);
           }
         }
       }

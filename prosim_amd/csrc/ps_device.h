@@ -55,6 +55,15 @@ typedef __attribute__((address_space(1))) const half8 g_chalf8;
 __device__ __forceinline__ half8 ldgh8(const _Float16* p) { return *(g_chalf8*)p; }
 __device__ __forceinline__ _Float16 f16_hi(float x) { return (_Float16)x; }
 __device__ __forceinline__ _Float16 f16_lo(float x) { return (_Float16)(x - (float)(_Float16)x); }
+// GEMM operands (round 4): the lo half SCALED by 2^11.  A weight of magnitude 0.05 has hi = fp16(w) with an ulp of 3e-5, so its lo part
+// is below 1.5e-5 -- a SUBNORMAL fp16 (step 6e-8): unscaled, the pair carries 20 - 21 bits, not 22 - 23, and that was most of the
+// engine's noise against the fp64 oracle (map tokens 4.4e-6 rms; torch fp32: 1.6e-6; with scaled lo halves: 1.3e-6,
+// profiles/r04_token_error.txt).  Scaled, lo is a normal fp16 for every |x| > 6e-8.  Every weight fragment the host packs
+// (Builder::fragments) and every activation plane a GEMM reads carries the scaled lo; the two cross products accumulate in a tile
+// of their own that joins the hi.hi tile as acc + 2^-11 x.  (Edge-phase operands -- k rows, rel-PE rows, probabilities -- keep f16_lo:
+// they are O(1) activations whose four products share one accumulator.)
+constexpr float PS_LO_SCALE = 2048.f, PS_LO_INV = 1.f / 2048.f;
+__device__ __forceinline__ _Float16 f16_los(float x) { return (_Float16)((x - (float)(_Float16)x) * PS_LO_SCALE); }
 
 // ---- cross-lane exchange without the LDS pipe (gfx950): v_permlane32_swap exchanges half-waves between TWO
 // registers, DPP covers xor 8 / 2 / 1 inside a row of 16.
@@ -183,11 +192,11 @@ __device__ __forceinline__ void pn_mma(const PnFrags& f, const _Float16* __restr
   const int mi = lane & 15, kq = lane >> 4;
   const bool two = wave + 4 < ntiles;
   if (wave >= ntiles) return;
-  floatx4 acc[2][MT];
+  floatx4 acc[2][MT], acx[2][MT];   // hi.hi | the two cross products (scaled lo halves)
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) acc[t][mt] = floatx4{0.f, 0.f, 0.f, 0.f};
+    for (int mt = 0; mt < MT; ++mt) { acc[t][mt] = floatx4{0.f, 0.f, 0.f, 0.f}; acx[t][mt] = acc[t][mt]; }
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) {
     if (ks < k32) {
@@ -196,12 +205,12 @@ __device__ __forceinline__ void pn_mma(const PnFrags& f, const _Float16* __restr
         const half8 ah = *reinterpret_cast<const half8*>(Ah + (mt * 16 + mi) * PN_AS + ks * 32 + kq * 8);
         const half8 al = *reinterpret_cast<const half8*>(Al + (mt * 16 + mi) * PN_AS + ks * 32 + kq * 8);
         acc[0][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, f.bh[0][ks], acc[0][mt], 0, 0, 0);
-        acc[0][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, f.bl[0][ks], acc[0][mt], 0, 0, 0);
-        acc[0][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, f.bh[0][ks], acc[0][mt], 0, 0, 0);
+        acx[0][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, f.bl[0][ks], acx[0][mt], 0, 0, 0);
+        acx[0][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, f.bh[0][ks], acx[0][mt], 0, 0, 0);
         if (two) {
           acc[1][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, f.bh[1][ks], acc[1][mt], 0, 0, 0);
-          acc[1][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, f.bl[1][ks], acc[1][mt], 0, 0, 0);
-          acc[1][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, f.bh[1][ks], acc[1][mt], 0, 0, 0);
+          acx[1][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, f.bl[1][ks], acx[1][mt], 0, 0, 0);
+          acx[1][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, f.bh[1][ks], acx[1][mt], 0, 0, 0);
         }
       }
     }
@@ -215,7 +224,7 @@ __device__ __forceinline__ void pn_mma(const PnFrags& f, const _Float16* __restr
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = mt * 16 + 4 * kq + r;
-        if (row < row_lim) C[row * cs + nt * 16 + mi] = acc[t][mt][r];
+        if (row < row_lim) C[row * cs + nt * 16 + mi] = fmaf(acx[t][mt][r], PS_LO_INV, acc[t][mt][r]);
       }
   }
 }

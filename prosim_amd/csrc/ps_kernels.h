@@ -92,7 +92,7 @@ __device__ __forceinline__ void pn_epilogue(float* __restrict__ C, _Float16* __r
     for (int j = 0; j < 8; ++j) {
       const float v = fmaxf(a[8 * i + j], 0.f);
       h[j] = f16_hi(v);
-      l[j] = f16_lo(v);
+      l[j] = f16_los(v);
     }
     *reinterpret_cast<half8*>(Ah + r * PN_AS + c0 + 8 * i) = h;
     *reinterpret_cast<half8*>(Al + r * PN_AS + c0 + 8 * i) = l;
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void k_pointnet_mfma(PointNetW w, const float*
       xv = pts[((size_t)row * P + p) * Cin + k];
     }
     Ah[r * PN_AS + k] = f16_hi(xv);
-    Al[r * PN_AS + k] = f16_lo(xv);
+    Al[r * PN_AS + k] = f16_los(xv);
   }
   __syncthreads();
   // ---- pre_mlps
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void k_pointnet_mfma(PointNetW w, const float*
     for (int i = tid; i < 16 * 128; i += 256, ++cnt) {
       const int g = i >> 7, col = i & 127;
       Ph[g * PN_AS + col] = f16_hi(m[cnt]);
-      Pl[g * PN_AS + col] = f16_lo(m[cnt]);
+      Pl[g * PN_AS + col] = f16_los(m[cnt]);
     }
     __syncthreads();
   };
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256) void k_pointnet_mfma(PointNetW w, const float*
     const int g = i >> 7, col = i & 127;
     const float a = g < PN_G ? fmaxf(pb[g * 128 + col] + w.out_b0[col], 0.f) : 0.f;
     Ph[g * PN_AS + col] = f16_hi(a);
-    Pl[g * PN_AS + col] = f16_lo(a);
+    Pl[g * PN_AS + col] = f16_los(a);
   }
   __syncthreads();
   pn_gemm<1>(Ph, Pl, 4, w.out_F1, pb, 128, PN_G, wave, lane);
@@ -1024,7 +1024,7 @@ __global__ __launch_bounds__(256) void k_policy_head_mfma(HeadW w, const float* 
     ctx[row * PN_CS + c] = cv;      // (every mode row carries its agent's context)
     const float av = mlp_mode ? cv : w.anchors[(size_t)((agent_type[ag] - 1) * K + (g < G ? k : 0)) * 128 + c];   // anchor of (type, mode)
     Ah[row * PN_AS + c] = f16_hi(av);
-    Al[row * PN_AS + c] = f16_lo(av);
+    Al[row * PN_AS + c] = f16_los(av);
   }
   __syncthreads();
   // CG_stacked(3): block i: y = relu(LN(W inp + b)) * context; context' = max over the agent's modes of y
@@ -1064,7 +1064,7 @@ __global__ __launch_bounds__(256) void k_policy_head_mfma(HeadW w, const float* 
         inp[r * PN_CS + c0 + j] = ni;
         ctx[r * PN_CS + c0 + j] = nc;
         Ah[r * PN_AS + c0 + j] = f16_hi(ni);
-        Al[r * PN_AS + c0 + j] = f16_lo(ni);
+        Al[r * PN_AS + c0 + j] = f16_los(ni);
       }
     }
     __syncthreads();
@@ -1080,7 +1080,7 @@ __global__ __launch_bounds__(256) void k_policy_head_mfma(HeadW w, const float* 
 #pragma unroll
     for (int j = 0; j < 32; ++j) {
       Ah[r * PN_AS + c0 + j] = f16_hi(a[j]);
-      Al[r * PN_AS + c0 + j] = f16_lo(a[j]);
+      Al[r * PN_AS + c0 + j] = f16_los(a[j]);
     }
   }
   __syncthreads();
@@ -1095,7 +1095,7 @@ __global__ __launch_bounds__(256) void k_policy_head_mfma(HeadW w, const float* 
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
       Ah[r * PN_AS + c0 + j] = f16_hi(a[j]);
-      Al[r * PN_AS + c0 + j] = f16_lo(a[j]);
+      Al[r * PN_AS + c0 + j] = f16_los(a[j]);
     }
   }
   __syncthreads();

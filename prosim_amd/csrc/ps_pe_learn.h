@@ -71,8 +71,8 @@ __global__ __launch_bounds__(256) void k_pe_learn(PeLearnW w, const EdgeGeo* __r
           const float v = ((x * w.freqs[in * 64 + k0 + k]) * 2.f) * PI_F;   // x * freqs * 2 * pi, left to right (:45)
           float sn, cs;
           sincosf(v, &sn, &cs);
-          ch[k >> 3][k & 7] = f16_hi(cs); cl[k >> 3][k & 7] = f16_lo(cs);
-          sh[k >> 3][k & 7] = f16_hi(sn); sl[k >> 3][k & 7] = f16_lo(sn);
+          ch[k >> 3][k & 7] = f16_hi(cs); cl[k >> 3][k & 7] = f16_los(cs);
+          sh[k >> 3][k & 7] = f16_hi(sn); sl[k >> 3][k & 7] = f16_los(sn);
         }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void k_pe_learn(PeLearnW w, const EdgeGeo* __r
             const int c = c0 + 8 * i + j;
             const float v = fmaxf(fmaf(a[8 * i + j] * rstd, w.ln1w[in][c], w.ln1b[in][c]), 0.f);
             h[j] = f16_hi(v);
-            l[j] = f16_lo(v);
+            l[j] = f16_los(v);
           }
           *reinterpret_cast<half8*>(Ah + r * PN_AS + c0 + 8 * i) = h;
           *reinterpret_cast<half8*>(Al + r * PN_AS + c0 + 8 * i) = l;
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void k_pe_learn(PeLearnW w, const EdgeGeo* __r
           const int c = c0 + 8 * i + j;
           const float v = fmaxf(fmaf(a[8 * i + j] * rstd, w.lnow[c], w.lnob[c]), 0.f);
           h[j] = f16_hi(v);
-          l[j] = f16_lo(v);
+          l[j] = f16_los(v);
         }
         *reinterpret_cast<half8*>(Ah + r * PN_AS + c0 + 8 * i) = h;
         *reinterpret_cast<half8*>(Al + r * PN_AS + c0 + 8 * i) = l;

@@ -13,9 +13,15 @@
 //     packs the next layer's weight fragments with the same K permutation (Builder::fragments, perm = true), so a result
 //     becomes an operand with NO data movement: bias / LayerNorm / ReLU / hi-lo split run on the accumulator registers
 //     (a row's 128 features sit in its 4 kq lanes: LayerNorm sums are 32 in-lane adds + two permlane swaps);
-//   * weights stream from L2 / L1 through a small register ring (every wave of a CU reads the same fragments);
-//   * no __syncthreads anywhere: waves are independent, LDS is only a wave-private scratch for the max-pools.
-// Split-fp16 operands as everywhere in this library (x = hi + lo; w.hi x.hi + w.lo x.hi + w.hi x.lo in fp32).
+//   * weights cross the CU ONCE per workgroup and GEMM: the workgroup's waves (each with its own rows) share every Linear, so a GEMM's
+//     fragments (<= 64 KB) are copied L2 -> LDS by DMA (buffer_load ... lds: no registers), each wave a share, into one of two
+//     stage buffers while the previous GEMM computes; one workgroup barrier per GEMM; the MFMA loop reads A fragments from LDS
+//     (conflict-free ds_read_b128).  (First version: every wave streamed its own copy through a register ring -- four waves x 64 KB
+//     per GEMM saturate the CU's 64 B/clk L1 path: 140 cycles per 2 KB fragment pair against 48 of MFMA work at one tile per wave.)
+//   * no LDS round trip for activations anywhere: the max-pools are DPP folds inside a polyline's lane group.
+// Split-fp16 operands (x = hi + lo; w.hi x.hi + w.lo x.hi + w.hi x.lo in fp32), the lo halves scaled by 2^11 (ps_device.h f16_los:
+// a weight's lo part would otherwise be a subnormal fp16): the two cross products of a (tile, k-sweep) accumulate in their own
+// fp32 tile, which joins the hi.hi tile as acc += 2^-11 x once per tile.
 //
 // Reference math: PointNetPolylineEncoder.forward (prosim/models/scene_encoder/pointnet_encoder.py:24-62),
 // AttentionLayer.forward's per-row half (prosim/models/layers/attention_layer.py:56-79, :100-121).
@@ -25,7 +31,8 @@
 
 namespace ps {
 
-constexpr int RT_PS = 132;     // row stride (floats) of the wave-private [16][128] LDS rows
+constexpr float RT_LO_INV = PS_LO_INV;
+__device__ __forceinline__ _Float16 rt_lo(float x) { return f16_los(x); }
 
 // Weight fragments are read through a raw buffer descriptor (SGPRs) with ONE per-lane byte offset (16 * lane) and the group's
 // offset as the instruction's scalar operand: with flat 64-bit addresses hipcc materialised a VGPR pair per 4 KB window of
@@ -38,75 +45,105 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t rt_rsrc(const void* p) {
 __device__ __forceinline__ half8 rt_ldfrag(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
   return __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
-// The ring of weight-fragment pairs a wave keeps in flight.  A GEMM consumes group g from slot g % DEPTH and requests group
-// g + DEPTH into it; rt_prefetch() requests the first DEPTH groups of the NEXT GEMM as soon as a GEMM's last group is consumed, so
-// the epilogue between two GEMMs (bias / LayerNorm / ReLU / split: a few hundred VALU instructions) covers their L2 round trip.
-template <int DEPTH>
-struct RtRing {
-  half8 h[DEPTH], l[DEPTH];
+// ---- weight stages in LDS.  A stage = the fragments of one GEMM as [piece][lane 64][16 B], piece = 1 KB = one DMA instruction
+// (a [hi] or [lo] fragment of a (tile, k-block) group: group g sits at 2048 g, its lo half 1024 further -- the global layout of
+// Builder::fragments, so a contiguous weight array is copied as it lies).  Two stage buffers of RT_STAGE_BYTES; protocol per GEMM:
+//   every wave: s_waitcnt vmcnt(0) (its share of THIS stage has landed) -> __syncthreads (everybody's has, and everybody is done
+//   reading the other buffer) -> issue its share of the NEXT stage into the other buffer -> MFMA loop over this buffer.
+// Waves that own no rows still copy their share and meet the barriers.
+constexpr int RT_STAGE_BYTES = 64 * 1024;
+struct RtStage {
+  unsigned lds0;          // LDS byte address of stage buffer 0
+  const unsigned char* p0;   // the same as a pointer
+  int cb, nb;             // buffer the next GEMM reads / the next fill writes
+  int wave, lane, nw;
 };
-template <int MT>
-constexpr int rt_depth() { return MT == 1 ? 8 : (MT <= 3 ? 6 : 4); }
+__device__ __forceinline__ RtStage rt_stage_init(unsigned char* smem, int wave, int lane, int nw) {
+  RtStage S;
+  S.lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem);
+  S.p0 = smem;
+  S.cb = 0; S.nb = 0;
+  S.wave = wave; S.lane = lane; S.nw = nw;
+  return S;
+}
+// one DMA instruction: 64 lanes x 16 B from (rsrc base + voff per lane + soff) to LDS [lds_dst + 16 lane] (M0 carries the LDS base;
+// inline asm: hipcc neither counts it in vmcnt nor waits for it -- rt_gemm's explicit wait does)
+__device__ __forceinline__ void rt_dma1k(unsigned voff, __amdgpu_buffer_rsrc_t rsrc, unsigned soff, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_dst) : "memory");
+}
 __device__ __forceinline__ unsigned rt_goff(int g, int K32, int KT, int k0) { return (unsigned)(((g / K32) * KT + (g % K32) + k0) * 2048); }
-template <int DEPTH, int K32, int KT, int NT>
-__device__ __forceinline__ void rt_prefetch(RtRing<DEPTH>& R, const _Float16* __restrict__ F, int k0, int lane) {
+// this wave's share of a stage of NT x K32 groups of F (k-blocks k0 .. k0 + K32 - 1 of KT per tile), pieces wave, wave + nw, ...
+template <int K32, int KT, int NT>
+__device__ __forceinline__ void rt_fill(RtStage& S, const _Float16* __restrict__ F, int k0) {
   const __amdgpu_buffer_rsrc_t rs = rt_rsrc(F);
-  const unsigned voff = 16u * (unsigned)lane;
+  const unsigned voff = 16u * (unsigned)S.lane;
+  const unsigned dst = S.lds0 + (unsigned)S.nb * RT_STAGE_BYTES;
+  for (int p = S.wave; p < 2 * NT * K32; p += S.nw) rt_dma1k(voff, rs, rt_goff(p >> 1, K32, KT, k0) + 1024u * (unsigned)(p & 1), dst + 1024u * (unsigned)p);
+  S.nb ^= 1;
+}
+// ... of `pieces` contiguous KB
+__device__ __forceinline__ void rt_fill_linear(RtStage& S, const void* __restrict__ F, int pieces) {
+  const __amdgpu_buffer_rsrc_t rs = rt_rsrc(F);
+  const unsigned voff = 16u * (unsigned)S.lane;
+  const unsigned dst = S.lds0 + (unsigned)S.nb * RT_STAGE_BYTES;
+  for (int p = S.wave; p < pieces; p += S.nw) rt_dma1k(voff, rs, 1024u * (unsigned)p, dst + 1024u * (unsigned)p);
+  S.nb ^= 1;
+}
+// the stage the next GEMM reads is complete and the other buffer is free: returns the stage's LDS pointer.  `next` issues the
+// following stage's fill (a lambda; may do nothing)
+template <class NextFill>
+__device__ __forceinline__ const unsigned char* rt_stage_ready(RtStage& S, NextFill next) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const unsigned char* buf = S.p0 + (size_t)S.cb * RT_STAGE_BYTES;
+  S.cb ^= 1;
+  next();
+  return buf;
+}
+// acc[t][mt] += W[16 t .. 16 t + 15][k] . X[k][16 mt + n]  for t < NT over K32 k-blocks, fragments from the current stage (group
+// g = t K32 + ks at 2048 g).  A dependent MFMA waits ~45 cycles for its accumulator, an independent one issues every 16: the
+// group's MFMAs go product-major over the wave's row tiles, and with a single tile the three products use separate partial
+// accumulators.
+template <int MT, int K32, int NT, class NextFill>
+__device__ __forceinline__ void rt_gemm(RtStage& S, floatx4 (&acc)[NT][MT], const half8 (&xh)[MT][4], const half8 (&xl)[MT][4], NextFill next) {
+  constexpr int NG = NT * K32;
+  constexpr int DEPTH = 3;
+  const half8* fb = reinterpret_cast<const half8*>(rt_stage_ready(S, next)) + S.lane;
+  half8 fh[DEPTH], fl[DEPTH];
 #pragma unroll
   for (int d = 0; d < DEPTH; ++d)
-    if (d < NT * K32) {
-      const unsigned so = rt_goff(d, K32, KT, k0);
-      R.h[d] = rt_ldfrag(rs, voff, so);
-      R.l[d] = rt_ldfrag(rs, voff, so + 1024u);
-    }
-}
-// acc[t][mt] += W[16 t .. 16 t + 15][k] . X[k][16 mt + n]  for t < NT; F: [t][k-block of KT][hi|lo][lane 64][8] (Builder::fragments),
-// k-blocks k0 .. k0 + K32 - 1 of it against the operand's blocks 0 .. K32 - 1.  The ring must hold the GEMM's first groups
-// (rt_prefetch with the same F / k0) on entry and is empty on return.
-template <int MT, int K32, int KT, int NT, int DEPTH>
-__device__ __forceinline__ void rt_gemm(RtRing<DEPTH>& R, floatx4 (&acc)[NT][MT], const half8 (&xh)[MT][4], const half8 (&xl)[MT][4],
-                                        const _Float16* __restrict__ F, int k0, int lane) {
-  constexpr int NG = NT * K32;
-  const __amdgpu_buffer_rsrc_t rs = rt_rsrc(F);
-  const unsigned voff = 16u * (unsigned)lane;
-  floatx4 p1[MT], p2[MT];
+    if (d < NG) { fh[d] = fb[d * 128]; fl[d] = fb[d * 128 + 64]; }
+  floatx4 p1[MT], p2[1];
 #pragma unroll
   for (int g = 0; g < NG; ++g) {
     const int s = g % DEPTH;
-    const half8 ah = R.h[s], al = R.l[s];
-    if (g + DEPTH < NG) {
-      const unsigned so = rt_goff(g + DEPTH, K32, KT, k0);
-      R.h[s] = rt_ldfrag(rs, voff, so);
-      R.l[s] = rt_ldfrag(rs, voff, so + 1024u);
-    }
-    // (left alone, the scheduler sinks every fragment load next to the MFMA that consumes it -- one exposed L2 round trip per
-    // group: 10x the MFMA time; the barrier pins the request DEPTH groups ahead of its use)
-    __builtin_amdgcn_sched_barrier(0);
-    // A dependent MFMA waits ~45 cycles for its accumulator (measured: SQ_WAIT_INST_ANY of the first version, three products
-    // back to back on one accumulator), an independent one issues every 16: the group's MFMAs go product-major over the
-    // wave's row tiles, and with a single tile the three products use separate partial accumulators.
+    const half8 ah = fh[s], al = fl[s];
+    if (g + DEPTH < NG) { fh[s] = fb[(g + DEPTH) * 128]; fl[s] = fb[(g + DEPTH) * 128 + 64]; }
+    __builtin_amdgcn_sched_barrier(0);   // (pins the LDS reads DEPTH groups ahead of their use: left alone the scheduler sinks them next to it)
     const int t = g / K32, ks = g % K32;
-    if (MT >= 2) {
+    if (ks == 0) {
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, xh[mt][ks], acc[t][mt], 0, 0, 0);
+      for (int mt = 0; mt < MT; ++mt) p1[mt] = floatx4{0.f, 0.f, 0.f, 0.f};
+    }
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, xh[mt][ks], acc[t][mt], 0, 0, 0);
+    for (int mt = 0; mt < MT; ++mt) acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, xh[mt][ks], acc[t][mt], 0, 0, 0);
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, xl[mt][ks], acc[t][mt], 0, 0, 0);
+    for (int mt = 0; mt < MT; ++mt) p1[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, xh[mt][ks], p1[mt], 0, 0, 0);
+    if (MT == 1) {   // (a single tile: the two cross products on separate accumulators, or the second waits ~45 cycles for the first)
+      if (ks == 0) p2[0] = floatx4{0.f, 0.f, 0.f, 0.f};
+      p2[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, xl[0][ks], p2[0], 0, 0, 0);
     } else {
-      if (ks == 0) {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) { p1[mt] = floatx4{0.f, 0.f, 0.f, 0.f}; p2[mt] = p1[mt]; }
-      }
+      for (int mt = 0; mt < MT; ++mt) p1[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, xl[mt][ks], p1[mt], 0, 0, 0);
+    }
+    if (ks == K32 - 1) {   // the cross products carry the lo halves' scale
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, xh[mt][ks], acc[t][mt], 0, 0, 0);
+      for (int mt = 0; mt < MT; ++mt) {
+        if (MT == 1) p1[mt] += p2[mt];
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) p1[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, xh[mt][ks], p1[mt], 0, 0, 0);
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) p2[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, xl[mt][ks], p2[mt], 0, 0, 0);
-      if (ks == K32 - 1) {
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[t][mt] += p1[mt] + p2[mt];
+        for (int j = 0; j < 4; ++j) acc[t][mt][j] = fmaf(p1[mt][j], RT_LO_INV, acc[t][mt][j]);
       }
     }
   }
@@ -129,7 +166,7 @@ __device__ __forceinline__ void rt_to_operand(const floatx4 (&a)[8][MT], half8 (
       for (int i = 0; i < 8; ++i) {
         const float v = a[2 * ks + (i >> 2)][mt][i & 3];
         xh[mt][ks][i] = f16_hi(v);
-        xl[mt][ks][i] = f16_lo(v);
+        xl[mt][ks][i] = rt_lo(v);
       }
 }
 // accumulators that start from bias[feature] (global, 128 floats) instead of zero: the Linear's bias costs no instruction
@@ -184,24 +221,6 @@ __device__ __forceinline__ void rt_relu(floatx4 (&a)[8][MT]) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) a[t][mt][j] = fmaxf(a[t][mt][j], 0.f);
 }
-// a [16][128] fp32 LDS row block as a one-tile operand (column n = row n of the block), K in the permuted order
-__device__ __forceinline__ void rt_operand_from_lds(const float* __restrict__ rows, int n, int kq, int nlive, half8 (&xh)[1][4], half8 (&xl)[1][4]) {
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) {
-    float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
-    if (n < nlive) {
-      v0 = *reinterpret_cast<const float4*>(rows + n * RT_PS + 32 * ks + 4 * kq);
-      v1 = *reinterpret_cast<const float4*>(rows + n * RT_PS + 32 * ks + 16 + 4 * kq);
-    }
-    const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      xh[0][ks][i] = f16_hi(v[i]);
-      xl[0][ks][i] = f16_lo(v[i]);
-    }
-  }
-}
-
 // ---- PointNet row layout.  A polyline's P points take L lanes (a power of two, consecutive lanes of the wave's 16 columns)
 // x MT row tiles: point p sits in tile p / L, lane g L + p % L.  A wave then carries G = 16 / L polylines, and both max-pools
 // (pointnet_encoder.py:47, :53: max over the zero-filled feature buffer, so a masked point counts as 0) are MT - 1 in-lane
@@ -245,15 +264,18 @@ __device__ unsigned long long g_rt_prof[32];
 #endif
 
 // PointNetPolylineEncoder on row tiles: MT * L >= P slots per polyline, G = 16 / L polylines per wave, 4 waves per workgroup.
+constexpr size_t RT_LDS_BYTES = 2 * (size_t)RT_STAGE_BYTES;
 template <int MT, int L>
-__global__ __launch_bounds__(256, (MT <= 2 ? 2 : 1)) void k_pointnet_rt(PointNetW w, const float* __restrict__ pts, const uint8_t* __restrict__ pmask,
-                                                                       const int* __restrict__ rows, int n_rows, int P, int feat_mask_dim,
-                                                                       float* __restrict__ out, float eps) {
+__global__ __launch_bounds__(256, 1) void k_pointnet_rt(PointNetW w, const float* __restrict__ pts, const uint8_t* __restrict__ pmask,
+                                                       const int* __restrict__ rows, int n_rows, int P, int feat_mask_dim,
+                                                       float* __restrict__ out, float eps) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char rt_smem[];
   constexpr int G = 16 / L;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int g0 = (blockIdx.x * 4 + wave) * G;
-  if (g0 >= n_rows) return;   // (no barrier in this kernel)
+  RtStage S = rt_stage_init(rt_smem, wave, lane, 4);
+  rt_fill<1, 1, 8>(S, w.pre_Q[0], 0);   // (weights do not depend on the rows: requested before the rows are)
+  const int g0 = (blockIdx.x * 4 + wave) * G;   // (a wave without polylines still copies its share of every stage and meets the barriers)
   const int n = lane & 15, kq = lane >> 4;
   const int g = n / L, q = n - g * L;
   const int Cin = w.in_dim;
@@ -261,9 +283,6 @@ __global__ __launch_bounds__(256, (MT <= 2 ? 2 : 1)) void k_pointnet_rt(PointNet
   const bool ok = g0 + g < n_rows;
   const int row = ok ? (rows ? rows[g0 + g] : g0 + g) : 0;
   floatx4 acc[8][MT];
-  constexpr int DP = rt_depth<MT>();
-  RtRing<DP> R;
-  rt_prefetch<DP, 1, 1, 8>(R, w.pre_F[0], 0, lane);   // (weights do not depend on the rows: requested before the rows are)
   bool vld[MT];
   half8 xh[MT][4], xl[MT][4];
   bool any = false;
@@ -298,7 +317,7 @@ __global__ __launch_bounds__(256, (MT <= 2 ? 2 : 1)) void k_pointnet_rt(PointNet
       for (int j = 0; j < 8; ++j) {
         const float x = v ? xv[mt][j] : 0.f;
         xh[mt][0][j] = f16_hi(x);
-        xl[mt][0][j] = f16_lo(x);
+        xl[mt][0][j] = rt_lo(x);
       }
     }
   }
@@ -306,20 +325,15 @@ __global__ __launch_bounds__(256, (MT <= 2 ? 2 : 1)) void k_pointnet_rt(PointNet
   RT_MARK(0);
   // ---- pre_mlps: Linear, LayerNorm, ReLU (the last one: Linear, ReLU)   (:33-38 through layers/mlp.py)
   rt_bias<MT>(acc, w.pre_b[0], kq);
-  rt_gemm<MT, 1, 1, 8>(R, acc, xh, xl, w.pre_F[0], 0, lane);
+  rt_gemm<MT, 1, 8>(S, acc, xh, xl, [&] { rt_fill<4, 4, 8>(S, w.n_pre > 1 ? w.pre_Q[1] : w.mid_PQ, 0); });
   RT_MARK(1);
-  // the next GEMM's fragments leave before this one's epilogue.  (A second, deeper ring for the pooled-row GEMMs -- one column
-  // tile, 96 MFMAs for 64 KB of fragments: pure streaming -- was tried: inside the run-time layer loops its 96 registers stay
-  // live across every iteration and the kernel spills 0.2 - 0.9 KB per lane.)
-  rt_prefetch<DP, 4, 4, 8>(R, w.n_pre > 1 ? w.pre_Q[1] : w.mid_PQ, 0, lane);
   if (w.pre_lnw[0]) rt_ln<MT>(acc, w.pre_lnw[0], w.pre_lnb[0], eps, kq);
   rt_relu<MT>(acc);
   RT_MARK(2);
   for (int l = 1; l < w.n_pre; ++l) {
     rt_to_operand<MT>(acc, xh, xl);
     rt_bias<MT>(acc, w.pre_b[l], kq);
-    rt_gemm<MT, 4, 4, 8>(R, acc, xh, xl, w.pre_Q[l], 0, lane);
-    rt_prefetch<DP, 4, 4, 8>(R, l + 1 < w.n_pre ? w.pre_Q[l + 1] : w.mid_PQ, 0, lane);
+    rt_gemm<MT, 4, 8>(S, acc, xh, xl, [&] { rt_fill<4, 4, 8>(S, l + 1 < w.n_pre ? w.pre_Q[l + 1] : w.mid_PQ, 0); });
     if (w.pre_lnw[l]) rt_ln<MT>(acc, w.pre_lnw[l], w.pre_lnb[l], eps, kq);
     rt_relu<MT>(acc);
   }
@@ -336,8 +350,7 @@ __global__ __launch_bounds__(256, (MT <= 2 ? 2 : 1)) void k_pointnet_rt(PointNet
     if (l == 0) {   // accumulators start from the row's polyline bias: pooled W[:, 128:256]^T + b, computed in the polyline's own lanes
       rt_to_operand<1>(pooled, ph, pl);
       rt_bias<1>(pooled, w.mid_b[0], kq);
-      rt_gemm<1, 4, 4, 8>(R, pooled, ph, pl, w.mid_PQ, 0, lane);
-      rt_prefetch<DP, 4, 4, 8>(R, w.mid_Q[0], 0, lane);
+      rt_gemm<1, 4, 8>(S, pooled, ph, pl, [&] { rt_fill<4, 4, 8>(S, w.mid_Q[0], 0); });
 #pragma unroll
       for (int t = 0; t < 8; ++t)
 #pragma unroll
@@ -346,9 +359,8 @@ __global__ __launch_bounds__(256, (MT <= 2 ? 2 : 1)) void k_pointnet_rt(PointNet
     } else {
       rt_bias<MT>(acc, w.mid_b[l], kq);
     }
-    rt_gemm<MT, 4, 4, 8>(R, acc, xh, xl, w.mid_Q[l], 0, lane);
+    rt_gemm<MT, 4, 8>(S, acc, xh, xl, [&] { rt_fill<4, 4, 8>(S, l + 1 < w.n_mid ? w.mid_Q[l + 1] : w.out_Q0, 0); });
     RT_MARK(6);
-    rt_prefetch<DP, 4, 4, 8>(R, l + 1 < w.n_mid ? w.mid_Q[l + 1] : w.out_Q0, 0, lane);
     if (w.mid_lnw[l]) rt_ln<MT>(acc, w.mid_lnw[l], w.mid_lnb[l], eps, kq);
     rt_relu<MT>(acc);
     RT_MARK(7);
@@ -359,12 +371,11 @@ __global__ __launch_bounds__(256, (MT <= 2 ? 2 : 1)) void k_pointnet_rt(PointNet
   {
     rt_to_operand<1>(pooled, ph, pl);
     rt_bias<1>(pooled, w.out_b0, kq);
-    rt_gemm<1, 4, 4, 8>(R, pooled, ph, pl, w.out_Q0, 0, lane);
-    rt_prefetch<DP, 4, 4, 8>(R, w.out_Q1, 0, lane);
+    rt_gemm<1, 4, 8>(S, pooled, ph, pl, [&] { rt_fill<4, 4, 8>(S, w.out_Q1, 0); });
     rt_relu<1>(pooled);
     rt_to_operand<1>(pooled, ph, pl);
     rt_bias<1>(pooled, w.out_b1, kq);
-    rt_gemm<1, 4, 4, 8>(R, pooled, ph, pl, w.out_Q1, 0, lane);
+    rt_gemm<1, 4, 8>(S, pooled, ph, pl, [] {});
     RT_MARK(9);
     if (ok && q == 0) {
 #pragma unroll
@@ -373,6 +384,283 @@ __global__ __launch_bounds__(256, (MT <= 2 ? 2 : 1)) void k_pointnet_rt(PointNet
             any ? make_float4(pooled[t][0][0], pooled[t][0][1], pooled[t][0][2], pooled[t][0][3]) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// The node half of a split attention layer on row tiles (replaces k_node for geometric edge sets; the edge half stays
+// k_edge_small, the per-destination exchange stays EdgeIO in global memory).  A wave owns 16 MT destination rows.
+//   PRE  (attention_layer.py:61-69, :106-107, :114): LN_dst, [k | v of the rows themselves for self-attention], q (+ q~, <q, kb>), s, g
+//   POST (:76-77, :89, :100-107): to_v_r fold, agg, gate, u, to_out, LN_post + residual, LN_ffpre, FFN in four 128-wide hidden chunks,
+//        LN_ffpost + residual
+typedef _Float16 rt_half4 __attribute__((ext_vector_type(4)));
+
+// rows of a [.][128] fp32 array into the C layout (lane (n, kq): features 16 t + 4 kq + j of row n); absent rows read as zero
+template <int MT>
+__device__ __forceinline__ void rt_load_rows(floatx4 (&a)[8][MT], const float* __restrict__ src, const long (&row)[MT], const bool (&live)[MT], int kq) {
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (live[mt]) v = ldg4(src + row[mt] * 128 + 16 * t + 4 * kq);
+      a[t][mt] = floatx4{v.x, v.y, v.z, v.w};
+    }
+}
+template <int MT>
+__device__ __forceinline__ void rt_store_rows(const floatx4 (&a)[8][MT], float* __restrict__ dst, long stride, long off, const long (&row)[MT],
+                                              const bool (&live)[MT], int kq) {
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+    if (live[mt]) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+        *reinterpret_cast<float4*>(dst + row[mt] * stride + off + 16 * t + 4 * kq) = make_float4(a[t][mt][0], a[t][mt][1], a[t][mt][2], a[t][mt][3]);
+    }
+}
+
+template <int MT>
+__global__ __launch_bounds__(256, 1) void k_node_pre_rt(const float* __restrict__ x, int Nd, const ChainStep* __restrict__ pre, EdgeIO io,
+                                                       float eps, float* __restrict__ kv_out, _Float16* __restrict__ khl_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char rt_smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int tile0 = (blockIdx.x * 4 + wave) * MT;   // (a wave without rows still copies its share of every stage and meets the barriers)
+  const int n = lane & 15, kq = lane >> 4;
+  const AttnW& w = pre->w;
+  RtStage S = rt_stage_init(rt_smem, wave, lane, 4);
+  if (kv_out) rt_fill<4, 4, 8>(S, w.Wkv_Q, 0);
+  else rt_fill<4, 4, 8>(S, w.Fqsg_Q, 0);
+  long row[MT];
+  bool live[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    row[mt] = 16L * (tile0 + mt) + n;
+    live[mt] = row[mt] < Nd;
+  }
+  floatx4 acc[8][MT];
+  half8 xh[MT][4], xl[MT][4];
+  rt_load_rows<MT>(acc, x, row, live, kq);
+  rt_ln<MT>(acc, w.ln_dst_w, w.ln_dst_b, eps, kq);   // xn = LN_dst(x)
+  rt_to_operand<MT>(acc, xh, xl);
+  if (kv_out) {   // the rows are also this self-attention layer's sources (LN_src == LN_dst): k | v (:61, :65, :115-116)
+    rt_zero<MT, 8>(acc);
+    rt_gemm<MT, 4, 8>(S, acc, xh, xl, [&] { rt_fill<4, 4, 8>(S, w.Wkv_Q + (size_t)8 * 4 * 1024, 0); });
+    rt_store_rows<MT>(acc, kv_out, 256, 0, row, live, kq);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+      if (live[mt]) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          rt_half4 hh, ll;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { hh[j] = f16_hi(acc[t][mt][j]); ll[j] = f16_lo(acc[t][mt][j]); }
+          *reinterpret_cast<rt_half4*>(khl_out + row[mt] * 256 + 16 * t + 4 * kq) = hh;
+          *reinterpret_cast<rt_half4*>(khl_out + row[mt] * 256 + 128 + 16 * t + 4 * kq) = ll;
+        }
+      }
+    rt_bias<MT>(acc, w.bkv + 128, kq);
+    rt_gemm<MT, 4, 8>(S, acc, xh, xl, [&] { rt_fill<4, 4, 8>(S, w.Fqsg_Q, 0); });
+    rt_store_rows<MT>(acc, kv_out, 256, 128, row, live, kq);
+  }
+  // ---- q = to_q(xn) + bq; q~[h][c] = sum_d q[16 h + d] Wkr_g3[16 h + d][c]; cq[h] = <q_h, kb_h>
+  rt_bias<MT>(acc, w.bq, kq);
+  rt_gemm<MT, 4, 8>(S, acc, xh, xl, [&] { rt_fill_linear(S, w.Fkr3_x, 48); });
+  rt_store_rows<MT>(acc, io.q, 128, 0, row, live, kq);
+  {
+    // tile t of q IS head t, and this lane's four values of it are a K = 16 MFMA's B operand as they are: per (head, 16-column
+    // tile of c) one v_mfma_f32_16x16x16_f16 per split product, A = the K = 16 fragments of Wkr_g3 (stage piece h 6 + ct: hi | lo halves)
+    const unsigned char* kb_ = rt_stage_ready(S, [&] { rt_fill<4, 4, 8>(S, w.Fqsg_Q + (size_t)8 * 4 * 1024, 0); });
+    const rt_half4* fk = reinterpret_cast<const rt_half4*>(kb_) + lane;
+#pragma unroll
+    for (int h = 0; h < 8; ++h) {
+      rt_half4 ah[6], al[6];
+#pragma unroll
+      for (int ct = 0; ct < 6; ++ct) {
+        ah[ct] = fk[(h * 6 + ct) * 128];
+        al[ct] = fk[(h * 6 + ct) * 128 + 64];
+      }
+      const float4 kb = ldg4(w.kb + 16 * h + 4 * kq);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        rt_half4 bh, bl;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { bh[j] = f16_hi(acc[h][mt][j]); bl[j] = rt_lo(acc[h][mt][j]); }
+        float c = 0.f;
+        c = fmaf(acc[h][mt][0], kb.x, c); c = fmaf(acc[h][mt][1], kb.y, c); c = fmaf(acc[h][mt][2], kb.z, c); c = fmaf(acc[h][mt][3], kb.w, c);
+        c = kq_sum(c);
+        if (live[mt] && kq == 0) io.cq[row[mt] * 8 + h] = c;
+#pragma unroll
+        for (int ct = 0; ct < 6; ++ct) {
+          floatx4 o = {0.f, 0.f, 0.f, 0.f}, ox = o;
+          o = __builtin_amdgcn_mfma_f32_16x16x16f16(ah[ct], bh, o, 0, 0, 0);
+          ox = __builtin_amdgcn_mfma_f32_16x16x16f16(al[ct], bh, ox, 0, 0, 0);
+          ox = __builtin_amdgcn_mfma_f32_16x16x16f16(ah[ct], bl, ox, 0, 0, 0);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] = fmaf(ox[j], RT_LO_INV, o[j]);
+          if (live[mt]) *reinterpret_cast<float4*>(io.qt + row[mt] * 1024 + h * 128 + 16 * ct + 4 * kq) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+      }
+    }
+  }
+  // ---- s = to_s(xn) + bs, g_x = to_g's x_dst half + bg   (:106-107; consumed by the POST half)
+  rt_bias<MT>(acc, w.bs, kq);
+  rt_gemm<MT, 4, 8>(S, acc, xh, xl, [&] { rt_fill<4, 4, 8>(S, w.Fqsg_Q + (size_t)16 * 4 * 1024, 0); });
+  rt_store_rows<MT>(acc, io.s, 128, 0, row, live, kq);
+  rt_bias<MT>(acc, w.bg, kq);
+  rt_gemm<MT, 4, 8>(S, acc, xh, xl, [] {});
+  rt_store_rows<MT>(acc, io.g, 128, 0, row, live, kq);
+}
+
+template <int MT>
+__global__ __launch_bounds__(256, 1) void k_node_post_rt(float* x, int Nd, const ChainStep* __restrict__ post, EdgeIO io, float eps) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char rt_smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int tile0 = (blockIdx.x * 4 + wave) * MT;   // (a wave without rows still copies its share of every stage and meets the barriers)
+  const int n = lane & 15, kq = lane >> 4;
+  const AttnW& w = post->w;
+  RtStage S = rt_stage_init(rt_smem, wave, lane, 4);
+  rt_fill_linear(S, w.Fvr3_Q, 48);
+  long row[MT];
+  bool live[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    row[mt] = 16L * (tile0 + mt) + n;
+    live[mt] = row[mt] < Nd;
+  }
+  floatx4 acc[8][MT];
+  half8 xh[MT][4], xl[MT][4];
+  // ---- to_v_r fold: fold[row][16 h + d] = sum_c a_r[row][h][c] Wvr_g3[c][16 h + d], c < 96: per head one 16-row tile of outputs,
+  //      K = 96 in the NATURAL order (the operand comes straight from the edge kernel's fp32 rows: Fvr3 as it is)
+  {
+    float4 cur[MT][3][2], nxt[MT][3][2];
+    auto ld_ar = [&](int h, float4 (&v)[MT][3][2]) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) {
+          v[mt][ks][0] = make_float4(0.f, 0.f, 0.f, 0.f);
+          v[mt][ks][1] = v[mt][ks][0];
+          if (live[mt]) {
+            const float* ap = io.ar + row[mt] * 1024 + h * 128 + 32 * ks + 8 * kq;
+            v[mt][ks][0] = ldg4(ap);
+            v[mt][ks][1] = ldg4(ap + 4);
+          }
+        }
+    };
+    ld_ar(0, cur);
+    const half8* fv = reinterpret_cast<const half8*>(rt_stage_ready(S, [&] { rt_fill<4, 4, 8>(S, w.Fga_Q, 0); })) + lane;
+#pragma unroll
+    for (int h = 0; h < 8; ++h) {
+      half8 fh[3], fl[3];
+#pragma unroll
+      for (int ks = 0; ks < 3; ++ks) {
+        fh[ks] = fv[(h * 3 + ks) * 128];
+        fl[ks] = fv[(h * 3 + ks) * 128 + 64];
+      }
+      if (h < 7) ld_ar(h + 1, nxt);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        floatx4 o = {0.f, 0.f, 0.f, 0.f}, ox = o;
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) {
+          const float v[8] = {cur[mt][ks][0].x, cur[mt][ks][0].y, cur[mt][ks][0].z, cur[mt][ks][0].w,
+                              cur[mt][ks][1].x, cur[mt][ks][1].y, cur[mt][ks][1].z, cur[mt][ks][1].w};
+          half8 bh, bl;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) { bh[i] = f16_hi(v[i]); bl[i] = rt_lo(v[i]); }
+          o = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[ks], bh, o, 0, 0, 0);
+          ox = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl[ks], bh, ox, 0, 0, 0);
+          ox = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[ks], bl, ox, 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = fmaf(ox[j], RT_LO_INV, o[j]);
+        acc[h][mt] = o;
+      }
+      if (h < 7) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int ks = 0; ks < 3; ++ks) { cur[mt][ks][0] = nxt[mt][ks][0]; cur[mt][ks][1] = nxt[mt][ks][1]; }
+      }
+    }
+  }
+  // ---- agg = (a_v + fold + l vb) / (l + 1e-16)   (:89, :100); tile t is head t
+  floatx4 agg[8][MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      float l = 0.f;
+      float4 av = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (live[mt]) {
+        l = ldg1(io.l + row[mt] * 8 + t);
+        av = ldg4(io.av + row[mt] * 128 + 16 * t + 4 * kq);
+      }
+      const float4 vb = ldg4(w.vb + 16 * t + 4 * kq);
+      const float inv = 1.f / (l + 1e-16f);
+      agg[t][mt][0] = (av.x + acc[t][mt][0] + l * vb.x) * inv;
+      agg[t][mt][1] = (av.y + acc[t][mt][1] + l * vb.y) * inv;
+      agg[t][mt][2] = (av.z + acc[t][mt][2] + l * vb.z) * inv;
+      agg[t][mt][3] = (av.w + acc[t][mt][3] + l * vb.w) * inv;
+    }
+  // ---- gated update (:106-107): g = sigmoid(Wg [agg | x_dst] + bg) (the x_dst half + bias: the PRE half's io.g); u = agg + g (s - agg)
+  rt_to_operand<MT>(agg, xh, xl);
+  rt_load_rows<MT>(acc, io.g, row, live, kq);
+  rt_gemm<MT, 4, 8>(S, acc, xh, xl, [&] { rt_fill<4, 4, 8>(S, w.Fout_Q, 0); });
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      float4 sv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (live[mt]) sv = ldg4(io.s + row[mt] * 128 + 16 * t + 4 * kq);
+      const float s4[4] = {sv.x, sv.y, sv.z, sv.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float g = 1.f / (1.f + expf(-acc[t][mt][j]));
+        agg[t][mt][j] = agg[t][mt][j] + g * (s4[j] - agg[t][mt][j]);
+      }
+    }
+  // ---- x = x + LN_post(to_out(u))  (:76), xn = LN_ffpre(x)  (:77)
+  rt_to_operand<MT>(agg, xh, xl);
+  rt_bias<MT>(acc, w.bout, kq);
+  rt_gemm<MT, 4, 8>(S, acc, xh, xl, [&] { rt_fill<4, 4, 8>(S, w.F1_Q, 0); });
+  rt_ln<MT>(acc, w.ln_post_w, w.ln_post_b, eps, kq);
+  {
+    floatx4 xr[8][MT];
+    rt_load_rows<MT>(xr, x, row, live, kq);
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[t][mt] += xr[t][mt];
+  }
+  // (the rows go back to x now and are read again for the last residual: five 32-register-per-tile sets would be live otherwise)
+  rt_store_rows<MT>(acc, x, 128, 0, row, live, kq);
+  rt_ln<MT>(acc, w.ln_ffpre_w, w.ln_ffpre_b, eps, kq);
+  rt_to_operand<MT>(acc, xh, xl);
+  // ---- FFN: relu(W1 xn + b1) in four 128-wide chunks, each straight into its quarter of W2's K; x = x + LN_ffpost(. + b2)
+  floatx4 y[8][MT];
+  rt_bias<MT>(y, w.b2, kq);
+#pragma unroll 1
+  for (int c = 0; c < 4; ++c) {
+    half8 hh[MT][4], hl[MT][4];
+    rt_bias<MT>(acc, w.b1 + 128 * c, kq);
+    rt_gemm<MT, 4, 8>(S, acc, xh, xl, [&] { rt_fill<4, 16, 8>(S, w.F2_Q, 4 * c); });
+    rt_relu<MT>(acc);
+    rt_to_operand<MT>(acc, hh, hl);
+    rt_gemm<MT, 4, 8>(S, y, hh, hl, [&] { if (c < 3) rt_fill<4, 4, 8>(S, w.F1_Q + (size_t)(c + 1) * 8 * 4 * 1024, 0); });
+  }
+  rt_ln<MT>(y, w.ln_ffpost_w, w.ln_ffpost_b, eps, kq);
+  {
+    const float* xr_src = x;
+    asm volatile("" : "+s"(xr_src));   // (opaque: the compiler must reload the rows instead of keeping the stored values live)
+    rt_load_rows<MT>(acc, xr_src, row, live, kq);
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) y[t][mt] += acc[t][mt];
+  }
+  rt_store_rows<MT>(y, x, 128, 0, row, live, kq);
 }
 
 }  // namespace ps

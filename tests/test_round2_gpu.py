@@ -295,6 +295,33 @@ def test_bench_two_ranks_on_one_gpu():
     assert abs(two["value"] - 4 * 128 * 80 / (two["ms_per_step"] * 1e-3)) < 1e-3 * two["value"]
 
 
+def test_bench_eight_ranks_on_one_gpu_with_uneven_shards():
+    """8-rank readiness without an 8-GPU node: bench.py --gpus 8 under torch.distributed.run, all eight ranks
+    on cuda:0, FIVE scenes over the eight ranks (i % 8: ranks 0..4 hold one scene, ranks 5..7 none) -- communicator set-up, ranks
+    without a scene inside every collective, uneven shards in the gather, the max-over-ranks timing.  The gathered metrics equal
+    those of one rank holding the five scenes."""
+    env = dict(os.environ, PS_BENCH_BACKEND="gloo", PS_BENCH_SAME_DEVICE="1")
+    common = ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--inflight", "1"]
+    r8 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                         "--master-port", "29613", os.path.join(ROOT, "bench.py"), "--gpus", "8", "--total-scenes", "5", *common],
+                        capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
+    assert r8.returncode == 0, r8.stdout[-3000:] + r8.stderr[-3000:]
+    lines = [l for l in r8.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    eight = json.loads(lines[0])
+    assert eight["n_gpus"] == 8 and eight["config"]["scenes_total"] == 5 and eight["config"]["scenes_per_gpu"] == 1
+    assert eight["rollout_metrics"]["scenes"] == 5 and eight["rollout_metrics"]["agents"] == 5 * 128
+    r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *common, "--scenes-per-gpu", "5"],
+                        capture_output=True, text=True, timeout=1200, env=dict(os.environ), cwd=ROOT)
+    assert r1.returncode == 0, r1.stdout[-3000:] + r1.stderr[-3000:]
+    one = json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][0])
+    for k, v in one["rollout_metrics"].items():
+        if k == "rollout_ade":   # (the mean over UPDATES of the per-update mean: eight single-scene updates against one five-scene update)
+            continue
+        assert abs(eight["rollout_metrics"][k] - v) <= 1e-5 * max(1.0, abs(v)), (k, eight["rollout_metrics"][k], v)
+    assert abs(eight["value"] - 5 * 128 * 80 / (eight["ms_per_step"] * 1e-3)) < 1e-3 * eight["value"]
+
+
 # ------------------------------------------------------------------ (f4) learnable relative positional encoding
 @pytest.mark.parametrize("shape", ["small", "split_s2s", "policy_only"])
 def test_learnable_rel_pe_vs_oracle(shape):

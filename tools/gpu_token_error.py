@@ -24,9 +24,12 @@ def stats(a, b):
 print("fp32 oracle                        : map tokens", stats(o32["trace"]["scene_tokens"].numpy()[:Mv], ref_tok), "| policy_emd", stats(o32["policy_emd"].numpy(), ref_emd))
 eng = Engine(spec, w)
 pm = scene["prompt_mask"].astype(bool)
-for label, impl in (("engine, default (split s2s)", 0), ("engine, impl 3 (s2s on k_chain16)", 3)):
-    eng.set_chain_impl(impl); eng.set_chain_rows(16 if impl == 3 else 0); eng.set_scene(scene); eng.rollout(); eng.sync()
+ref_traj = o["traj"].numpy()
+for label, impl, rimpl in (("engine, staged row kernels (r3)", 0, 1), ("engine, row-tile kernels", 0, 0), ("engine, row-tile, node mt 1", 0, 11), ("engine, impl 3 (s2s on k_chain16)", 3, 1)):
+    eng.set_row_impl(rimpl); eng.set_chain_impl(impl); eng.set_chain_rows(16 if impl == 3 else 0); eng.set_scene(scene); eng.rollout(); eng.sync()
     tok = eng.get("scene_tokens")[:Mv]
     emd = eng.padded("policy_emd")[pm]
-    print(f"{label:34s}: map tokens", stats(tok, ref_tok), "| policy_emd", stats(emd, ref_emd[pm]), flush=True)
+    d = np.abs(eng.padded("traj").astype(np.float64) - ref_traj)[pm].reshape(int(pm.sum()), -1).max(1)
+    print(f"{label:34s}: map tokens", stats(tok, ref_tok), "| policy_emd", stats(emd, ref_emd[pm]),
+          f"| closed loop: {int((d >= 1e-4).sum())} agents outside 1e-4, max {d.max():.2e}, median {np.median(d):.2e}", flush=True)
 eng.close()
