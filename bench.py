@@ -290,34 +290,6 @@ def main():
     for e_ in engines:
         e_.enable_policy_events(False)
     value = total_agents * spec.max_steps / (dt / args.steps)
-    # the same timed loop with the scene encoder's s2s layers on k_chain16 too (ps_set_chain_impl 3): reported beside the
-    # headline, not as it -- another fp32 evaluation order of the scene tokens, which on this workload puts six agents of one
-    # scene on the other side of a +-pi cut; the default path is the one whose parity table holds 1024 / 1024
-    fast_encoder = None
-    if chain_rows >= 8 and not multi:
-        for e_ in engines:
-            e_.set_chain_impl(3)
-            e_.set_chain_rows(chain_rows)
-            e_.set_scene(scene)
-        for _ in range(n_fl):
-            step()
-        for e_ in engines:
-            e_.sync()
-        t_f = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        compute_metrics()
-        torch.cuda.synchronize()
-        dt_f = time.perf_counter() - t_f
-        fast_encoder = {"what": "ps_set_chain_impl(3): the scene encoder's s2s layers as one-step k_chain16 launches instead of the split k_node / "
-                                "k_edge_small path; same timed loop",
-                        "agent_steps_per_s": A * spec.max_steps / (dt_f / args.steps), "ms_per_step": 1e3 * dt_f / args.steps,
-                        "parity": "NOT the default: scene tokens within 4e-5 of the fp64 oracle, but 6 of the workload's 1024 agents land on the "
-                                  "other side of a +-pi cut (closed-loop max 8.6e-3); the default path holds 1024 / 1024 within 1e-4"}
-        for e_ in engines:
-            e_.set_chain_impl(0)
-            e_.set_chain_rows(chain_rows)
-            e_.set_scene(scene)
     step()
     compute_metrics()
     for e_ in engines:
@@ -501,7 +473,6 @@ def main():
                              "stage_ms": {"encode_scene": stages1[0], "generate_policy": stages1[1], "replan_loop": stages1[2]}},
             "replica_fanout": replica,
             "streaming": streaming,
-            "fast_encoder": fast_encoder,
             "rollout_metrics": metrics,
         }
         if world == 1 and not args.no_cpu_baseline:

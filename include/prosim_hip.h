@@ -223,11 +223,11 @@ int ps_set_map_tokens(ps_engine* e, const float* tokens, int64_t count);
  *           takes 2 or 4) -- experiments.
  * Results do not depend on it beyond fp32 summation order. */
 int ps_set_chain_rows(ps_engine* e, int32_t rows);
-/* Which fused-chain kernel runs the policy layers: 0 (default) = by mode as above, 1 = k_attn_chain always, 2 = k_chain16
- * always, 3 = k_chain16 always AND for the scene encoder's s2s layers (one k | v projection + one-step chain per layer
- * instead of the split k_node / k_edge_small launches: faster, another fp32 evaluation order of the scene tokens).  Both
- * kernels stay in the library: each is the other's cross-check in the parity tests.  Resets ps_set_chain_rows to 0 and
- * invalidates the encoded / generated stages. */
+/* Which fused-chain kernel runs the attention layers: 0 (default) = by mode as above -- in throughput mode (ps_set_chain_rows >= 8)
+ * k_chain16 for everything INCLUDING the scene encoder's s2s layers (one k | v projection + one-step chain per layer), in latency mode
+ * the split launches (node halves + k_edge_small) for the s2s layers; 1 = k_attn_chain always, 2 = k_chain16 always with the split s2s
+ * path, 3 = k_chain16 always and for the s2s layers too.  Every choice holds the parity bar (profiles/r04_parity.json); they differ in
+ * fp32 summation order.  Resets ps_set_chain_rows to 0 and invalidates the encoded / generated stages. */
 int ps_set_chain_impl(ps_engine* e, int32_t impl);
 /* Which kernels run the dense per-row stacks (PointNet encoders, the node half of the split s2s layers, k | v projections):
  * 0 (default) = the row-tile kernels of round 4 (ps_rowtile.h: a wave carries 16..80 rows through the whole stack in registers,

@@ -766,6 +766,7 @@ extern "C" int ps_create(const ps_config* cfg, int32_t n_tensors, const char* co
   PS_RT_ATTR((k_pointnet_rt<2, 16>)); PS_RT_ATTR((k_pointnet_rt<3, 4>)); PS_RT_ATTR((k_pointnet_rt<3, 8>)); PS_RT_ATTR((k_pointnet_rt<4, 8>));
   PS_RT_ATTR((k_pointnet_rt<5, 4>));
   PS_RT_ATTR(k_node_pre_rt<1>); PS_RT_ATTR(k_node_pre_rt<2>); PS_RT_ATTR(k_node_pre_rt<3>);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_edge16), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c16_edge_lds_bytes());
   PS_RT_ATTR(k_node_post_rt<1>); PS_RT_ATTR(k_node_post_rt<2>); PS_RT_ATTR(k_node_post_rt<3>);
 #undef PS_RT_ATTR
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pe_learn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PL_LDS_BYTES);
@@ -1528,14 +1529,21 @@ int io_for(ps_engine* e, int Nd, EdgeIO& io) {
 
 // One attention layer as three launches: k_node PRE (+ the rows' own k | v when kv_out is given: self-attention),
 // k_edge_small (degree <= ES_MAXDEG), k_node POST.  `stp` is a device pointer to the layer's ChainStep.
-int launch_split_layer(ps_engine* e, float* x, int Nd, const ChainStep* stp, int kr, int maxdeg, float* kv_out, _Float16* khl_out) {
+// geo_edges: the edge half on k_edge16 (geometry records, ps_chain16.h) instead of k_edge_small (rel-PE operand images).
+bool split_uses_rt(const ps_engine* e, int Nd, int kr) {   // the row-tile node halves (and with them the geometry-record edge kernel)
+  return kr == 3 && !e->legacy_rows && ((Nd + 15) / 16 >= 256 || e->node_mt);
+}
+int launch_split_layer(ps_engine* e, float* x, int Nd, const ChainStep* stp, int kr, int maxdeg, float* kv_out, _Float16* khl_out, bool geo_edges = false) {
   EdgeIO io{};
   if (io_for(e, Nd, io)) return fail(PS_E_HIP, "split-path buffers");
   hipStream_t st = e->stream;
   const dim3 gn((Nd + ND_ROWS - 1) / ND_ROWS), ge((Nd + 3) / 4);
   const float eps = e->cfg.ln_eps;
   const ChainStep* none = nullptr;
-  if (kr == 3 && !e->legacy_rows) {
+  const int tiles = (Nd + 15) / 16;
+  // (below 256 row tiles -- a single 1152-token scene has 72 -- the staged k_node with its 16-row workgroups fills the chip better:
+  // 0.71 against 0.88 ms per scene encoding; from the 8-scene batch up the row-tile halves win, 1.53 against 1.73 ms)
+  if (split_uses_rt(e, Nd, kr)) {
     // row-tile node halves (ps_rowtile.h): a wave owns 16 MT rows, no barriers.  MT: one tile per wave while the launch has fewer
     // waves than the chip has SIMDs (latency), more rows per weight fragment beyond that
     const int tiles = (Nd + 15) / 16;
@@ -1546,7 +1554,8 @@ int launch_split_layer(ps_engine* e, float* x, int Nd, const ChainStep* stp, int
     if (mt == 1) hipLaunchKernelGGL(k_node_pre_rt<1>, gr, dim3(256), RT_LDS_BYTES, st, (const float*)x, Nd, stp, io, eps, kv_out, khl_out);
     else if (mt == 2) hipLaunchKernelGGL(k_node_pre_rt<2>, gr, dim3(256), RT_LDS_BYTES, st, (const float*)x, Nd, stp, io, eps, kv_out, khl_out);
     else hipLaunchKernelGGL(k_node_pre_rt<3>, gr, dim3(256), RT_LDS_BYTES, st, (const float*)x, Nd, stp, io, eps, kv_out, khl_out);
-    if (maxdeg <= 32) hipLaunchKernelGGL((k_edge_small<3, 2>), ge, dim3(256), es_lds_bytes<2>(), st, Nd, stp, io);
+    if (geo_edges) hipLaunchKernelGGL(k_edge16, dim3((unsigned)tiles), dim3(512), c16_edge_lds_bytes(), st, Nd, stp, io, (const float*)e->div32);
+    else if (maxdeg <= 32) hipLaunchKernelGGL((k_edge_small<3, 2>), ge, dim3(256), es_lds_bytes<2>(), st, Nd, stp, io);
     else hipLaunchKernelGGL((k_edge_small<3, 8>), ge, dim3(256), es_lds_bytes<8>(), st, Nd, stp, io);
     if (mt == 1) hipLaunchKernelGGL(k_node_post_rt<1>, gr, dim3(256), RT_LDS_BYTES, st, x, Nd, stp, io, eps);
     else if (mt == 2) hipLaunchKernelGGL(k_node_post_rt<2>, gr, dim3(256), RT_LDS_BYTES, st, x, Nd, stp, io, eps);
@@ -1668,7 +1677,7 @@ void launch_kv(ps_engine* e, const float* x, int Ns, int layer0, int nlayers, fl
 int g_force_mt = 0;   // test hook (ps_test_pointnet_mt): row tiles per wave, -1 = the staged kernel
 struct RtShape { int mt, l; };
 constexpr RtShape kRtShapes[] = {{1, 4}, {1, 8}, {1, 16}, {2, 8}, {2, 16}, {3, 4}, {3, 8}, {4, 8}, {5, 4}};   // the builds in the library: every P <= 32 fits (2, 16)
-RtShape pointnet_shape(int n_rows, int P) {
+RtShape pointnet_shape(int n_rows, int P, bool throughput) {
   RtShape best{0, 0};
   double best_cost = 0;
   for (const RtShape& sh : kRtShapes) {
@@ -1676,7 +1685,10 @@ RtShape pointnet_shape(int n_rows, int P) {
     if (sh.mt * sh.l < P) continue;
     const long waves = (n_rows + 16 / sh.l - 1) / (16 / sh.l);
     const long rounds = (waves + 1023) / 1024;   // one 4-wave workgroup per CU (128 KB of weight stages)
-    const double cost = (double)rounds * (sh.mt + 1.2);    // a wave's time ~ tiles + a fixed part (pooled-row GEMMs, fragment latency)
+    // a wave's time ~ tiles + a fixed part (pooled-row GEMMs, stage fills).  Alone on the GPU the launch's latency counts: rounds x
+    // that time; with several rollouts in flight (throughput mode) its CU time does: waves x that time -- 1024 agent histories are
+    // 1024 one-tile waves on all 256 CUs alone (18 us), 256 three-tile waves on 64 CUs when the other CUs have other work
+    const double cost = (throughput ? (double)waves : (double)rounds) * (sh.mt + 1.2);
     if (!best.mt || cost < best_cost) { best = sh; best_cost = cost; }
   }
   return best;
@@ -1692,7 +1704,7 @@ void launch_pointnet(ps_engine* e, const PointNetW& w, const float* pts, const u
                      int P, int feat_mask_dim, float* out) {
   if (n_rows <= 0) return;
   if (!e->legacy_rows && g_force_mt >= 0 && w.n_pre >= 1 && w.n_mid >= 1 && w.in_dim <= 32) {
-    const RtShape sh = pointnet_shape(n_rows, P);
+    const RtShape sh = pointnet_shape(n_rows, P, e->chain_rows >= 8);
 #define PS_RT(MT_, L_) if (sh.mt == MT_ && sh.l == L_) { launch_pointnet_rt<MT_, L_>(e, w, pts, mask, rows, n_rows, P, feat_mask_dim, out); return; }
     PS_RT(1, 4) PS_RT(1, 8) PS_RT(1, 16) PS_RT(2, 8) PS_RT(2, 16) PS_RT(3, 4) PS_RT(3, 8) PS_RT(4, 8) PS_RT(5, 4)
 #undef PS_RT
@@ -1874,12 +1886,18 @@ extern "C" int ps_encode_scene(ps_engine* e) {
   // knn graphs (attn_fusion.py:107-109) + rel-PE (:111-112).  Agent rows that only enter the scene with a later fut_obs
   // frame are no tokens yet: not a candidate of any query (their own rows are computed and ignored).
   const int* live0 = e->have_dead0 ? (const int*)e->d_live0.p : nullptr;
-  // the s2s layers as one-step k_chain16 launches (k | v projection + chain) instead of the split path: in throughput mode
-  // (ps_set_chain_impl 3 -- NOT the default: 9 % more throughput on the benchmark workload (22.4 against 20.4 M agent-steps/s),
-  // but another fp32 evaluation of the scene tokens than the split path's, and on that workload it lands six agents of one
-  // scene on the other side of a +-pi cut; the default keeps the path whose parity table holds 1024 / 1024)
+  // the s2s layers as one-step k_chain16 launches (k | v projection + chain) instead of the split path: the default in THROUGHPUT mode
+  // (ps_set_chain_rows >= 8; round 4: 23.4 against 22.6 M agent-steps/s on the benchmark workload with four rollouts in flight) and with
+  // ps_set_chain_impl(3); the split path (k_node_*_rt / k_node + k_edge_small) is the default in latency mode, where it is the
+  // faster one (one rollout alone on the GPU).  Round 3 kept this path behind a knob because another fp32 evaluation order of the
+  // scene tokens re-rolled the workload's near-cut edges; with the scaled lo halves of round 4 (ps_device.h f16_los) every path holds
+  // all 1024 agents of the workload within 1e-4 of the fp64 oracle (profiles/r04_parity.json).
   static const int env_s2s = exp_env("PS_S2S_C16") ? atoi(exp_env("PS_S2S_C16")) : -1;   // experiments only: 0 / 1 force
-  const bool s2s_c16 = !e->pe_on[0] && use_c16(e, Mv + Ap, 0) && (env_s2s >= 0 ? env_s2s != 0 : e->chain_impl == 3);
+  const bool s2s_c16 = !e->pe_on[0] && use_c16(e, Mv + Ap, 0) &&
+                       (env_s2s >= 0 ? env_s2s != 0 : (e->chain_impl == 3 || (e->chain_impl == 0 && e->chain_rows >= 8)));
+  // the split path's edge half on geometry records (k_edge16) whenever its node halves are the row-tile kernels
+  static const bool no_split0 = exp_env("PS_NO_SPLIT") != nullptr;
+  const bool s2s_split_geo = !s2s_c16 && !no_split0 && e->e_s2s.maxdeg <= ES_MAXDEG && split_uses_rt(e, Mv + Ap, e->pe_on[0] ? 4 : 3);
   {
     CandSet ca{e->d_tok_pos.p, e->d_r_agent.p, nullptr};
     hipLaunchKernelGGL(k_knn, dim3((Ap + 3) / 4), dim3(256), 0, st, ca, (const float*)(e->d_tok_pos.p + 2 * (size_t)Mv),
@@ -1896,13 +1914,14 @@ extern "C" int ps_encode_scene(ps_engine* e) {
       launch_geo(e, pe, 2, true);
       launch_pe_learn(e, e->e_a2a, e->pe_learn[0]);
       launch_pe_learn(e, e->e_s2s, e->pe_learn[1]);
-    } else {   // per set: geometry records for the layers that run on k_chain16, operand images for the others
+    } else {   // per set: geometry records for the layers whose edge phase rebuilds its rows (k_chain16, k_edge16), operand images for the others
       const bool ga = use_c16(e, Ap, 0);
-      if (ga && s2s_c16) launch_geo(e, pe, 2);
-      else if (!ga && !s2s_c16) launch_relpe(e, pe, 2);
+      const bool gs = s2s_c16 || (s2s_split_geo);
+      if (ga && gs) launch_geo(e, pe, 2);
+      else if (!ga && !gs) launch_relpe(e, pe, 2);
       else {
         if (ga) launch_geo(e, &pe[0], 1); else launch_relpe(e, &pe[0], 1);
-        if (s2s_c16) launch_geo(e, &pe[1], 1); else launch_relpe(e, &pe[1], 1);
+        if (gs) launch_geo(e, &pe[1], 1); else launch_relpe(e, &pe[1], 1);
       }
     }
   }
@@ -1926,7 +1945,7 @@ extern "C" int ps_encode_scene(ps_engine* e) {
       // split layer: node work as 16-row MFMA GEMMs (k_node; its PRE half also makes the rows'
       // k | v, they are this self-attention layer's sources), the 32-neighbour edge phase one wave per token
       const ChainStep* stp = e->d_steps.p + e->step_s2s + i;
-      if (launch_split_layer(e, tok, Mv + Ap, stp, e->pe_on[0] ? 4 : 3, e->e_s2s.maxdeg, e->d_kv.p, e->d_kh.p)) return PS_E_HIP;
+      if (launch_split_layer(e, tok, Mv + Ap, stp, e->pe_on[0] ? 4 : 3, e->e_s2s.maxdeg, e->d_kv.p, e->d_kh.p, s2s_split_geo)) return PS_E_HIP;
     } else {
       launch_kv(e, tok, Mv + Ap, e->L_s2s + i, 1, e->d_kv.p, e->d_kh.p, 0);
       if (launch_chain(e, tok, Mv + Ap, e->step_s2s + i, 1, e->e_s2s.maxdeg)) return PS_E_HIP;

@@ -90,11 +90,9 @@ struct GeoSets {
 // The 96 (sin, cos) values of an edge are made ONCE and kept in LDS between the two LayerNorm passes ([value][thread]: a
 // wave's 64 lanes on 64 banks); round 2 recomputed them for the second pass (half of the kernel's instructions).
 constexpr int GEO_THREADS = 128;
-constexpr size_t GEO_LDS_BYTES = (size_t)96 * GEO_THREADS * 4;
+constexpr size_t GEO_LDS_BYTES = 16;   // (round 3 kept the 96 values of an edge in LDS between two LayerNorm passes)
 __global__ __launch_bounds__(GEO_THREADS) void k_edge_geo(GeoSets sets, const float* __restrict__ src_pos, const float* __restrict__ div32,
                                                          float eps, int raw) {
-  extern __shared__ __attribute__((aligned(16))) float geo_sc[];
-  float* sc = geo_sc + threadIdx.x;
   const GeoSet& S = sets.s[blockIdx.y];
   const int E = S.eoff[S.nq];
   float dv[16], rdv[16];
@@ -129,7 +127,10 @@ __global__ __launch_bounds__(GEO_THREADS) void k_edge_geo(GeoSets sets, const fl
       xs[i] = xin[i] * PS_TWO_PI_F;
       fast = fast && fdiv16_ok(xs[i]);
     }
-    // two passes like torch's LayerNorm (mean, then centred squares) over the same values
+    // mean of the 128 features; their second moment needs no second pass: every (sin, cos) pair contributes sin^2 + cos^2 = 1, so the
+    // sum of squares of the 64 pairs (the angle block counts twice) is 64 and sum (f - mean)^2 = 64 - 128 mean^2.  (Round 2 kept
+    // torch's two passes bit for bit -- a last-bit change of rstd re-rolled the workload's near-cut edges; with the quieter GEMM
+    // operands of round 4 the parity table holds either way, and the pass was a third of this kernel: 96 LDS round trips per edge.)
     float sm = 0.f;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -138,27 +139,12 @@ __global__ __launch_bounds__(GEO_THREADS) void k_edge_geo(GeoSets sets, const fl
       for (int k = 0; k < 16; ++k) {
         float sv, cv;
         fourier_pair(xs[i], dv[k], rdv[k], fast, sv, cv);
-        sc[(2 * (16 * i + k)) * GEO_THREADS] = sv;
-        sc[(2 * (16 * i + k) + 1) * GEO_THREADS] = cv;
         part += sv + cv;
       }
       sm += (i == 2) ? 2.f * part : part;
     }
     const float mean = sm * (1.f / 128.f);
-    float sq = 0.f;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      float part = 0.f;
-#pragma unroll
-      for (int k = 0; k < 16; ++k) {
-        float sv = sc[(2 * (16 * i + k)) * GEO_THREADS], cv = sc[(2 * (16 * i + k) + 1) * GEO_THREADS];
-        sv -= mean;
-        cv -= mean;
-        part = fmaf(sv, sv, part);
-        part = fmaf(cv, cv, part);
-      }
-      sq += (i == 2) ? 2.f * part : part;
-    }
+    const float sq = 64.f - 128.f * mean * mean;
     const float rstd = 1.f / sqrtf(sq * (1.f / 128.f) + eps);
     EdgeGeo g;
     g.a0 = xs[0]; g.a1 = xs[1]; g.a2 = xs[2];
@@ -279,7 +265,9 @@ __device__ __forceinline__ int c16_av_row(int lr, int part, int W) { return W ==
 // C layout of the score MFMA IS the A layout of the 16x16x16 aggregation MFMA: row 4 kq + j of column mi); the transposed
 // feature reads of a pass are issued together; the row's sums stay in LDS (see above).  The arithmetic -- every operation
 // and its order -- is the round-2 kernel's: results are bit-identical to it.
-template <int NWV, bool ONEW>
+// (TAG: a second, independent copy of the function for the standalone edge kernel k_edge16 -- as a second CALLER of one copy it cost
+// the policy chain 9 %: the inter-procedural register allocation is per function)
+template <int NWV, bool ONEW, int TAG = 0>
 __device__ __noinline__ void c16_edge_phase(const ChainStep* __restrict__ stp, unsigned char* c16_smem, float* AG,
                                             const float* CQ, int* ctr, float* QA, const float* __restrict__ div32, int row0, int nrows, int W) {
   const ChainStep& st = *stp;
@@ -1009,6 +997,63 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) __attribute__((disable_
     c16_node_phase<NWV>(steps + s, last ? nullptr : steps + s + 1, c16_smem, last ? x : nullptr, row0, nrows, W, eps, prof);
     C16_MARK(2);
   }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// The edge phase alone, for the SPLIT attention layers (round 4): between the row-tile node halves (ps_rowtile.h) the scene encoder's
+// s2s layers ran k_edge_small over 768 bytes of rel-PE operand images per edge (k_relpe_tiles: 0.53 GB per launch out of L2 / MALL).
+// k_edge16 runs c16_edge_phase -- geometry records, rows rebuilt in registers, k rows by LDS-DMA -- on 16 destination rows per 8-wave
+// workgroup: q / q~ / <q, kb> come from the PRE half's EdgeIO rows into the slots the fused chain keeps them in, the sums go back the
+// same way.  Same arithmetic as a one-step k_chain16 launch's edge phase.
+constexpr size_t C16_EDGE_WAVES_BYTES = 8 * C16_WAVE_BYTES;
+constexpr size_t c16_edge_lds_bytes() { return C16_EDGE_WAVES_BYTES + (size_t)ND_ROWS * ND_XS * 4 + 16 * 8 * 4 + 144 + C16_QA_BYTES; }
+__global__ __launch_bounds__(512, 1) __attribute__((disable_tail_calls)) void k_edge16(int Nd, const ChainStep* __restrict__ step, EdgeIO io,
+                                                                                     const float* __restrict__ div32) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char c16_smem[];
+  float* AG = reinterpret_cast<float*>(c16_smem + C16_EDGE_WAVES_BYTES);   // [16][ND_XS] q rows, then a_v
+  float* CQ = AG + ND_ROWS * ND_XS;                                        // [16][8]
+  int* ctr = reinterpret_cast<int*>(CQ + 16 * 8);                          // [0] counter, [1..16] queue, [17..32] degrees
+  float* QA = reinterpret_cast<float*>(ctr + 36);                          // [16 slots][C16_QSL] q~ in, a_r | l out
+  const int tid = threadIdx.x;
+  const int row0 = blockIdx.x * 16;
+  const int nrows = min(16, Nd - row0);
+  for (int i = tid; i < 16 * 32; i += 512) {   // q rows
+    const int r = i >> 5, c = (i & 31) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < nrows) v = ldg4(io.q + (size_t)(row0 + r) * 128 + c);
+    *reinterpret_cast<float4*>(AG + r * ND_XS + c) = v;
+  }
+  for (int i = tid; i < 16 * 8 * 24; i += 512) {   // q~: [row][head][96 columns] into the slot layout
+    const int r = i / 192, rem = i - r * 192, h = rem / 24, c = (rem - h * 24) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < nrows) v = ldg4(io.qt + (size_t)(row0 + r) * 1024 + h * 128 + c);
+    *reinterpret_cast<float4*>(QA + r * C16_QSL + h * C16_QH + c) = v;
+  }
+  if (tid < 128) CQ[tid] = (tid >> 3) < nrows ? ldg1(io.cq + (size_t)row0 * 8 + tid) : 0.f;
+  if (tid < 16) ctr[17 + tid] = tid < nrows ? ldgi(step->eoff + row0 + tid + 1) - ldgi(step->eoff + row0 + tid) : -1;
+  __syncthreads();
+  if (tid == 0) ctr[0] = 0;
+  if (tid < 16) {   // queue order: rows by falling edge count (as the fused chain's PRE half)
+    const int mine = ctr[17 + tid];
+    int rank = 0;
+    for (int j = 0; j < 16; ++j) {
+      const int dj = ctr[17 + j];
+      rank += (dj > mine || (dj == mine && j < tid)) ? 1 : 0;
+    }
+    ctr[1 + rank] = tid;
+  }
+  __syncthreads();
+  c16_edge_phase<8, true, 1>(step, c16_smem, AG, CQ, ctr, QA, div32, row0, nrows, 1);
+  __syncthreads();
+  for (int i = tid; i < 16 * 8 * 24; i += 512) {   // a_r
+    const int r = i / 192, rem = i - r * 192, h = rem / 24, c = (rem - h * 24) * 4;
+    if (r < nrows) *reinterpret_cast<float4*>(io.ar + (size_t)(row0 + r) * 1024 + h * 128 + c) = *reinterpret_cast<const float4*>(QA + r * C16_QSL + h * C16_QH + c);
+  }
+  for (int i = tid; i < 16 * 32; i += 512) {   // a_v
+    const int r = i >> 5, c = (i & 31) * 4;
+    if (r < nrows) *reinterpret_cast<float4*>(io.av + (size_t)(row0 + r) * 128 + c) = *reinterpret_cast<const float4*>(AG + r * ND_XS + c);
+  }
+  if (tid < 128 && (tid >> 3) < nrows) io.l[(size_t)row0 * 8 + tid] = QA[(tid >> 3) * C16_QSL + (tid & 7) * C16_QH + 96];
 }
 
 }  // namespace ps
