@@ -96,7 +96,18 @@ def cpu_baseline(spec, w, scene, reps: int = 3):
             ts.append(time.perf_counter() - t0)
     A = int(scene["prompt_mask"].sum())
     med = float(np.median(ts))
-    return dict(value=A * spec.max_steps / med, unit="agent-steps/s", cores=cores, kind="port",
+    # the reference itself cannot travel to this box; its time on the BUILD container's cores, measured there beside the port
+    # (tools/time_reference_cpu.py), rides along for context
+    ref_ctx = None
+    rp = os.path.join(ROOT, "profiles", "r04_reference_cpu_time.json")
+    if os.path.exists(rp):
+        with open(rp) as f:
+            rj = json.load(f)
+        ref_ctx = {"source": "profiles/r04_reference_cpu_time.json (tools/time_reference_cpu.py, build container, NOT this box)", "threads": rj["threads"],
+                   "reference_plus_standins_s_per_rollout": rj["reference_plus_standins"]["best"],
+                   "reference_plus_standins_agent_steps_per_s": rj["reference_plus_standins"]["agent_steps_per_s"],
+                   "oracle_port_s_per_rollout_same_cores": rj["oracle_port"]["best"]}
+    return dict(value=A * spec.max_steps / med, unit="agent-steps/s", cores=cores, kind="port", reference_in_build_container=ref_ctx,
                 sample=f"{reps} full rollouts of ONE scene of the batch (CPU throughput does not depend on the batch; median {med:.3f} s each), torch {torch.__version__} fp32, "
                        f"{cores} intra-op threads (best of a sweep over 8/16/32/all {phys} physical cores)")
 
@@ -305,6 +316,7 @@ def main():
     if rank == 0:
         # dominant kernel: the fused policy attention chain (one launch per replan), timed with HIP
         # events on the engine's own stream
+        graph_nodes = eng.graph_nodes
         ms_chain = eng.time_policy_kernel(3)
         ec = eng.get("edge_counts")
         ms_roll, stages = eng.time_rollout(1, 5)
@@ -316,6 +328,8 @@ def main():
         # single-scene latency of the same workload (S = 1), same engine, same run, latency mode
         eng.set_chain_rows(0)
         eng.set_scene(parts[0])
+        eng.rollout(); eng.sync()
+        graph_nodes_single = eng.graph_nodes
         ms_single, stages1 = eng.time_rollout(2, 10)
         ms_chain1 = eng.time_policy_kernel(2)
         A1 = eng.num_agents
@@ -409,13 +423,13 @@ def main():
         # HBM-side traffic of the launch comes from separate rocprofv3 --pmc passes (tools/gpu_round_profile.sh; counters
         # cannot be read from inside this process): offline, valid for the default workload only, stamped with its source
         traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", "r03_pmc_policy_chain.json")
+        pmc = os.path.join(ROOT, "profiles", "r04_pmc_policy_chain.json")
         if os.path.exists(pmc) and S == 8 and args.config == 2:
             with open(pmc) as f:
                 pj = json.load(f)
             if pj.get("chain_rows") == chain_rows:
                 traffic = pj["hbm_bytes_per_launch"]
-                traffic_src = {"file": "profiles/r03_pmc_policy_chain.json", "git": pj.get("git"), "measured": "offline rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), not in this run"}
+                traffic_src = {"file": "profiles/r04_pmc_policy_chain.json", "git": pj.get("git"), "measured": "offline rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), not in this run"}
         achieved = fl_alg / (ms_launch * 1e-3) / 1e12
         kern = (f"k_chain16<8, policy> (12 fused attention layers per launch, {chain_rows} rows per 8-wave workgroup, {n_wg} workgroups)" if c16
                 else f"k_attn_chain (policy: 12 fused attention layers per launch; {chain_rows or 2} rows per workgroup)")
@@ -463,12 +477,13 @@ def main():
                          "chip_frac": fl_alg * spec.n_replans / (ms_per_step * 1e-3) / 1e12 / peak,
                          "full_chip_launch_frac": fl_rep / (ms_chain_rep * 1e-3) / 1e12 / peak,
                          "edges_per_launch": {"a2p": float(ec[4]), "m2p": float(ec[5])}, "tiles16_per_layer_pair": tiles},
+            "graph_nodes_per_rollout": graph_nodes,
             "stage_ms": {"rollout_events": ms_roll, "encode_scene": stages[0], "generate_policy": stages[1], "replan_loop": stages[2]},
             "latency_mode": {"note": "ps_set_chain_rows(0): one rollout alone on the GPU", "ms_per_rollout": ms_roll_lat,
                              "encode_scene": stages_lat[0], "generate_policy": stages_lat[1], "replan_loop": stages_lat[2],
                              "policy_chain_launch_ms": ms_chain_lat},
             "single_scene": {"ms_per_rollout": ms_single, "agent_steps_per_s": A1 * spec.max_steps / (ms_single * 1e-3),
-                             "policy_chain_launch_ms": ms_chain1,
+                             "policy_chain_launch_ms": ms_chain1, "graph_nodes_per_rollout": graph_nodes_single,
                              "agent_steps_per_s_pipelined": pipe1,   # key = rollouts in flight
                              "stage_ms": {"encode_scene": stages1[0], "generate_policy": stages1[1], "replan_loop": stages1[2]}},
             "replica_fanout": replica,

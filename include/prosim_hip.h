@@ -234,6 +234,8 @@ int ps_set_chain_impl(ps_engine* e, int32_t impl);
  * chained transposed MFMA GEMMs, no barriers), 1 = the staged kernels of rounds 1-3 (k_pointnet_mfma, k_node, k_kv_proj:
  * GEMM -> LDS -> barrier -> epilogue per Linear).  Both stay in the library: each is the other's cross-check. */
 int ps_set_row_impl(ps_engine* e, int32_t impl);
+/* Nodes (kernel launches and copies) of the captured rollout graph; 0 before the first ps_rollout or when the rollout runs eagerly. */
+int64_t ps_graph_nodes(ps_engine* e);
 /* The engine's hipStream_t (every entry point enqueues on it), so a host can order its own streams against the
  * engine with events instead of ps_sync -- bench.py overlaps the RCCL metric gather of rollout k with rollout k+1. */
 void* ps_stream(ps_engine* e);

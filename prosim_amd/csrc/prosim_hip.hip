@@ -2202,6 +2202,13 @@ extern "C" int ps_rollout(ps_engine* e) {
   return PS_OK;
 }
 
+extern "C" int64_t ps_graph_nodes(ps_engine* e) {
+  if (!e || !e->graph_ok || !e->graph) return 0;
+  size_t n = 0;
+  if (hipGraphGetNodes(e->graph, nullptr, &n) != hipSuccess) return -1;
+  return (int64_t)n;
+}
+
 extern "C" int ps_sync(ps_engine* e) {
   if (!e) return fail(PS_E_ARG, "null engine");
   HIPCHK(hipSetDevice(e->cfg.device));

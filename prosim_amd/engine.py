@@ -87,6 +87,8 @@ def load_library():
     lib.ps_set_chain_rows.argtypes = [vp, C.c_int32]
     lib.ps_set_chain_impl.argtypes = [vp, C.c_int32]
     lib.ps_set_row_impl.argtypes = [vp, C.c_int32]
+    lib.ps_graph_nodes.argtypes = [vp]
+    lib.ps_graph_nodes.restype = C.c_int64
     lib.ps_enable_policy_events.argtypes = [vp, C.c_int32]
     lib.ps_policy_event_times.argtypes = [vp, fp, C.c_int32]
     lib.ps_stream.argtypes = [vp]
@@ -117,7 +119,7 @@ def load_library():
 
 
 EXPORTS = ["ps_create", "ps_destroy", "ps_last_error", "ps_set_scene", "ps_set_prompt", "ps_policy_forward", "ps_set_conditions", "ps_set_drag_points", "ps_set_pair_conditions", "ps_set_future_obs", "ps_set_future_log", "ps_set_mode_choice", "ps_set_action_noise", "ps_set_replicas", "ps_num_replicas", "ps_world_trajs", "ps_num_policy_agents", "ps_policy_flags",
-           "ps_encode_scene", "ps_generate_policy", "ps_reset_rollout", "ps_policy_step", "ps_rollout", "ps_sync", "ps_stream", "ps_set_chain_rows", "ps_set_chain_impl", "ps_set_row_impl", "ps_enable_policy_events", "ps_policy_event_times", "ps_update_obs", "ps_set_map_tokens", "ps_declare_agent_rows",
+           "ps_encode_scene", "ps_generate_policy", "ps_reset_rollout", "ps_policy_step", "ps_rollout", "ps_sync", "ps_stream", "ps_set_chain_rows", "ps_set_chain_impl", "ps_set_row_impl", "ps_graph_nodes", "ps_enable_policy_events", "ps_policy_event_times", "ps_update_obs", "ps_set_map_tokens", "ps_declare_agent_rows",
            "ps_set_state", "ps_get", "ps_rollout_metric", "ps_pair_metric", "ps_num_agents", "ps_num_map_tokens", "ps_time_rollout", "ps_time_policy_kernel",
            "ps_test_pointnet", "ps_test_pointnet_mt", "ps_test_fourier", "ps_test_wrap", "ps_test_attn", "ps_test_get_edges", "ps_test_stream"]
 
@@ -407,6 +409,11 @@ class Engine:
         """0: by mode (default); 1: k_attn_chain always; 2: k_chain16 always (A/B measurements, cross-checks); 3: k_chain16
         always and for the scene encoder's s2s layers as well (faster; another fp32 evaluation order of the scene tokens)."""
         self._check(self.lib.ps_set_chain_impl(self.h, impl))
+
+    @property
+    def graph_nodes(self) -> int:
+        """Launches + copies in the captured rollout graph (0 before the first rollout)."""
+        return int(self.lib.ps_graph_nodes(self.h))
 
     def set_row_impl(self, impl: int):
         """0: the row-tile kernels (default); 1: the staged row kernels of rounds 1-3 (cross-checks, A/B measurements)."""
