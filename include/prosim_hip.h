@@ -77,6 +77,10 @@ typedef struct ps_config {
   /* !LOSS.ROLLOUT_TRAJ.USE_GOAL_PRED_LOSS (1 = False, default.py:440's default; the released yamls set True = 0 here): the checkpoint
    * has no "policy.act_decoder.pred_mlp.*" tensors and there is no "reconst_pred" result (act_decoder.py:75-76, :128-130). */
   int32_t no_reconst_pred;
+  /* MODEL.REL_POS_EDGE_FUNC == 'knn' (default.py:455; 'radius' in every released yaml): the generator's (p2p, s2p) and the policy's
+   * (a2p, m2p) edge sets are the *_max_neigh NEAREST tokens of the scene (torch_cluster.knn / knn_graph: sym_coord.py:85-96,
+   * act_decoder.py:249-261) instead of the first *_max_neigh inside the radii; at most 2560 candidate tokens per scene */
+  int32_t rel_pos_knn;
 } ps_config;
 
 /* Create an engine and upload weights.  names[i] are reference state_dict keys

@@ -157,9 +157,10 @@ def radius_edges(pos_x: T, batch_x: T, pos_y: T, batch_y: T, r: float, max_num: 
     return yi, xi
 
 
-def knn_edges(pos_x: T, batch_x: T, pos_y: T, batch_y: T, k: int) -> Tuple[T, T]:
+def knn_edges(pos_x: T, batch_x: T, pos_y: T, batch_y: T, k: int, drop_self: bool = False) -> Tuple[T, T]:
     """torch_cluster.knn(x, y, k, batch_x, batch_y) -> (y_idx, x_idx): the k nearest x of
-    each y within its example, ties to the lower x index; fewer than k if the example is small."""
+    each y within its example, ties to the lower x index; fewer than k if the example is small.
+    ``drop_self``: knn_graph(loop=False) = knn with k + 1, then remove the x == y pairs (torch_cluster/knn.py knn_graph)."""
     if pos_y.shape[0] == 0 or pos_x.shape[0] == 0:
         z = torch.zeros(0, dtype=torch.long)
         return z, z
@@ -167,11 +168,15 @@ def knn_edges(pos_x: T, batch_x: T, pos_y: T, batch_y: T, k: int) -> Tuple[T, T]
     same = batch_y[:, None] == batch_x[None, :]
     d2 = torch.where(same, d2, torch.full_like(d2, float("inf")))
     order = torch.sort(d2, dim=1, stable=True)[1]  # stable: ties keep index order
-    kk = min(k, pos_x.shape[0])
+    kk = min(k + 1 if drop_self else k, pos_x.shape[0])
     xi = order[:, :kk]
     yi = torch.arange(pos_y.shape[0])[:, None].expand(-1, kk)
     valid = torch.gather(same, 1, xi)
-    return yi[valid], xi[valid]
+    yi, xi = yi[valid], xi[valid]
+    if drop_self:
+        keep = yi != xi
+        yi, xi = yi[keep], xi[keep]
+    return yi, xi
 
 
 # --------------------------------------------------------------------------- rel-PE + attention
@@ -378,10 +383,17 @@ def decoder_fusion(Wt: W, spec: ModelSpec, scene: Dict, prompt_emd: T, prompt_ma
     ppos = prompt_pos.reshape(-1, 2)[prompt_mask.view(-1)]
     pori = prompt_head.reshape(-1, 1)[prompt_mask.view(-1)]
     # radius_graph(loop=False): (x=source j, y=target i)
-    pp_dst, pp_src = radius_edges(ppos, pb, ppos, pb, spec.dec_prompt_radius, spec.dec_max_neigh, drop_self=True)
+    knn = spec.rel_pos_edge_func == "knn"   # MODEL.REL_POS_EDGE_FUNC (sym_coord.py:85-96)
+    if knn:
+        pp_dst, pp_src = knn_edges(ppos, pb, ppos, pb, spec.dec_max_neigh, drop_self=True)
+    else:
+        pp_dst, pp_src = radius_edges(ppos, pb, ppos, pb, spec.dec_prompt_radius, spec.dec_max_neigh, drop_self=True)
     pp_pe = rel_pe(spec, pp_src, pp_dst, pori, ppos, pori, ppos, Wt, _emb(spec, "decoder", "p2p"))
-    sp_dst, sp_src = radius_edges(scene["scene_pos"], scene["scene_batch_idx"], ppos, pb,
-                                  spec.dec_scene_radius, spec.dec_max_neigh)
+    if knn:
+        sp_dst, sp_src = knn_edges(scene["scene_pos"], scene["scene_batch_idx"], ppos, pb, spec.dec_max_neigh)
+    else:
+        sp_dst, sp_src = radius_edges(scene["scene_pos"], scene["scene_batch_idx"], ppos, pb,
+                                      spec.dec_scene_radius, spec.dec_max_neigh)
     sp_pe = rel_pe(spec, sp_src, sp_dst, pori, ppos, scene["scene_ori"], scene["scene_pos"], Wt, _emb(spec, "decoder", "s2p"))
     xs = scene["scene_tokens"]
     for i in range(spec.dec_layers):
@@ -520,9 +532,13 @@ def policy_forward(Wt: W, spec: ModelSpec, scene: Dict, policy_emd: T, agent_typ
                               scene["scene_ori"][st == 1], scene["scene_batch_idx"][st == 1])
     x_m, m_pos, m_ori, m_b = (scene["scene_tokens"][st == 0], scene["scene_pos"][st == 0],
                               scene["scene_ori"][st == 0], scene["scene_batch_idx"][st == 0])
-    ap_dst, ap_src = radius_edges(a_pos, a_b, pos, policy_b, spec.pol_agent_radius, spec.pol_max_neigh)
+    if spec.rel_pos_edge_func == "knn":   # MODEL.REL_POS_EDGE_FUNC (act_decoder.py:249-261)
+        ap_dst, ap_src = knn_edges(a_pos, a_b, pos, policy_b, spec.pol_max_neigh)
+        mp_dst, mp_src = knn_edges(m_pos, m_b, pos, policy_b, spec.pol_max_neigh)
+    else:
+        ap_dst, ap_src = radius_edges(a_pos, a_b, pos, policy_b, spec.pol_agent_radius, spec.pol_max_neigh)
+        mp_dst, mp_src = radius_edges(m_pos, m_b, pos, policy_b, spec.pol_map_radius, spec.pol_max_neigh)
     ap_pe = rel_pe(spec, ap_src, ap_dst, head, pos, a_ori, a_pos, Wt, _emb(spec, "policy.act_decoder", "a2p"))
-    mp_dst, mp_src = radius_edges(m_pos, m_b, pos, policy_b, spec.pol_map_radius, spec.pol_max_neigh)
     mp_pe = rel_pe(spec, mp_src, mp_dst, head, pos, m_ori, m_pos, Wt, _emb(spec, "policy.act_decoder", "m2p"))
     xp = policy_emd
     for i in range(spec.pol_layers):

@@ -1831,7 +1831,7 @@ struct RadArgs {
   const PeLearnW* learn = nullptr;   // the set's learnable rel-PE embedding, or nullptr (fixed Fourier rows per pe_mode)
 };
 void launch_radius(ps_engine* e, const RadArgs* a, int nsets, const float* qpos, const int* qscene, int nq, const float* src_ori,
-                   const float* dst_ori, int pe_mode = 1) {
+                   const float* dst_ori, int pe_mode = 1, bool knn = false) {
   RadSets rs{};
   for (int i = 0; i < nsets; ++i) {
     EdgeSet& es = *a[i].es;
@@ -1840,13 +1840,19 @@ void launch_radius(ps_engine* e, const RadArgs* a, int nsets, const float* qpos,
   }
   const int wpb = 4, grid = (nq + wpb - 1) / wpb;
   hipStream_t st = e->stream;
-  hipLaunchKernelGGL(k_radius<0>, dim3(grid, nsets), dim3(64 * wpb), 0, st, rs, qpos, qscene, nq);
-  for (int i = 0; i < nsets; ++i)
-    if (a[i].self_base >= 0)
-      hipLaunchKernelGGL(k_radius_selfrank, dim3(grid), dim3(64 * wpb), 0, st, rs.s[i].cs, qpos, qscene, nq, rs.s[i].r2, a[i].cap,
-                         a[i].self_base, a[i].es->cnt.p, a[i].cand_ok, a[i].cand_base);
-  hipLaunchKernelGGL(k_exclusive_scan, dim3(nsets), dim3(1024), 0, st, rs, nq);
-  hipLaunchKernelGGL(k_radius<1>, dim3(grid, nsets), dim3(64 * wpb), 0, st, rs, qpos, qscene, nq);
+  if (knn) {   // MODEL.REL_POS_EDGE_FUNC 'knn': the cap nearest instead of the first cap inside the radius (same CSR plumbing)
+    hipLaunchKernelGGL(k_knn_sets<0>, dim3(grid, nsets), dim3(64 * wpb), 0, st, rs, qpos, qscene, nq);
+    hipLaunchKernelGGL(k_exclusive_scan, dim3(nsets), dim3(1024), 0, st, rs, nq);
+    hipLaunchKernelGGL(k_knn_sets<1>, dim3(grid, nsets), dim3(64 * wpb), 0, st, rs, qpos, qscene, nq);
+  } else {
+    hipLaunchKernelGGL(k_radius<0>, dim3(grid, nsets), dim3(64 * wpb), 0, st, rs, qpos, qscene, nq);
+    for (int i = 0; i < nsets; ++i)
+      if (a[i].self_base >= 0)
+        hipLaunchKernelGGL(k_radius_selfrank, dim3(grid), dim3(64 * wpb), 0, st, rs.s[i].cs, qpos, qscene, nq, rs.s[i].r2, a[i].cap,
+                           a[i].self_base, a[i].es->cnt.p, a[i].cand_ok, a[i].cand_base);
+    hipLaunchKernelGGL(k_exclusive_scan, dim3(nsets), dim3(1024), 0, st, rs, nq);
+    hipLaunchKernelGGL(k_radius<1>, dim3(grid, nsets), dim3(64 * wpb), 0, st, rs, qpos, qscene, nq);
+  }
   PeArgs pe[2];
   bool learn = false;
   for (int i = 0; i < nsets; ++i) {
@@ -1863,9 +1869,9 @@ void launch_radius(ps_engine* e, const RadArgs* a, int nsets, const float* qpos,
 }
 void launch_radius(ps_engine* e, EdgeSet& es, const int* r1, const int* r2, const float* qpos, const int* qscene, int nq, float r,
                    int cap, int self_base, const float* src_ori, const float* dst_ori, const int* cand_ok = nullptr,
-                   int cand_base = 0, int pe_mode = 1, const PeLearnW* learn = nullptr) {
+                   int cand_base = 0, int pe_mode = 1, const PeLearnW* learn = nullptr, bool knn = false) {
   RadArgs a{&es, r1, r2, r, cap, self_base, cand_ok, cand_base, learn};
-  launch_radius(e, &a, 1, qpos, qscene, nq, src_ori, dst_ori, pe_mode);
+  launch_radius(e, &a, 1, qpos, qscene, nq, src_ori, dst_ori, pe_mode, knn);
 }
 
 }  // namespace
@@ -1982,12 +1988,12 @@ extern "C" int ps_generate_policy(ps_engine* e) {
   // (with log-replay agents in the scene only the policy agents are prompts: candidate filter)
   const int pe_gen = use_c16(e, Ap, 1) ? 2 : 1;   // k_chain16 rebuilds the rel-PE rows from geometry records, k_attn_chain streams operand images
   launch_radius(e, e->e_p2p, e->d_r_agent.p, nullptr, ppos, pscene, Ap, c.dec_prompt_radius, c.dec_max_neigh, Mv, e->d_tok_ori.p, pori,
-                e->all_policy ? nullptr : (const int*)e->d_is_policy.p, Mv, pe_gen, pe_of(e, &e->e_p2p));
+                e->all_policy ? nullptr : (const int*)e->d_is_policy.p, Mv, pe_gen, pe_of(e, &e->e_p2p), c.rel_pos_knn != 0);
   // restore observed agent poses for the scene tokens, then s2p: radius over all scene tokens (:94)
   HIPCHK(hipMemcpyAsync(e->d_tok_pos.p + 2 * (size_t)Mv, e->d_init_pos.p, sizeof(float) * 2 * A, hipMemcpyDeviceToDevice, st));
   HIPCHK(hipMemcpyAsync(e->d_tok_ori.p + Mv, e->d_init_head.p, sizeof(float) * A, hipMemcpyDeviceToDevice, st));
   launch_radius(e, e->e_s2p, e->d_r_map.p, e->d_r_agent.p, ppos, pscene, Ap, c.dec_scene_radius, c.dec_max_neigh, -1,
-                e->d_tok_ori.p, pori, e->have_dead0 ? (const int*)e->d_live0.p : nullptr, Mv, pe_gen, pe_of(e, &e->e_s2p));
+                e->d_tok_ori.p, pori, e->have_dead0 ? (const int*)e->d_live0.p : nullptr, Mv, pe_gen, pe_of(e, &e->e_s2p), c.rel_pos_knn != 0);
   // k|v of the (fixed) scene tokens for all s2p layers in one launch
   launch_kv(e, e->d_tok.p, Mv + Ap, e->L_s2p, c.dec_layers, e->d_kv_s2p.p, e->d_kh_s2p.p, (size_t)(Mv + Ap) * 256);
   const int md = std::max(e->e_p2p.maxdeg, e->e_s2p.maxdeg);
@@ -2124,7 +2130,7 @@ extern "C" int ps_policy_step(ps_engine* e, int32_t t_idx) {
     const RadArgs ra[2] = {{&e->e_a2p, e->d_r_agent.p, nullptr, c.pol_agent_radius, c.pol_max_neigh, -1,
                             e->all_policy ? nullptr : (const int*)e->d_tok_live.p, Mv, pe_of(e, &e->e_a2p)},
                            {&e->e_m2p, e->d_r_map.p, nullptr, c.pol_map_radius, c.pol_max_neigh, -1, nullptr, 0, pe_of(e, &e->e_m2p)}};
-    launch_radius(e, ra, 2, e->d_cur_pos.p, pscene, A, e->d_tok_ori.p, e->d_cur_ori.p, use_c16(e, A, 2) ? 2 : 1);
+    launch_radius(e, ra, 2, e->d_cur_pos.p, pscene, A, e->d_tok_ori.p, e->d_cur_ori.p, use_c16(e, A, 2) ? 2 : 1, c.rel_pos_knn != 0);
   }
   const int md = std::max(e->e_a2p.maxdeg, e->e_m2p.maxdeg);
   if (e->policy_events && (int)e->pev.size() >= 2 * R) HIPCHK(hipEventRecord(e->pev[2 * t_idx], st));
@@ -2788,6 +2794,7 @@ extern "C" int ps_policy_forward(ps_engine* e, int32_t n_scenes, int32_t Na, con
   const int OUT = c.motion_k * c.target_steps * c.state_dim;
   std::vector<int> ptype(p_type, p_type + A);
   if (check_c16_offsets((size_t)Nm + Na, {(size_t)A * da, (size_t)A * dm})) return PS_E_ARG;
+  if (c.rel_pos_knn && std::max(maxA, maxM) > 64 * KNN_SLOTS) return fail(PS_E_ARG, "more than 2560 candidate tokens in one scene (knn candidate registers)");
   if (upload(d_pos, pos.data(), pos.size(), st) || upload(d_ori, ori.data(), ori.size(), st) ||
       d_atok.ensure((size_t)std::max(Na, 1) * D) || d_mtok.ensure((size_t)std::max(Nm, 1) * D) ||
       (Na > 0 && upload(d_atok, a_tok, (size_t)Na * D, st)) || (Nm > 0 && upload(d_mtok, m_tok, (size_t)Nm * D, st)) ||
@@ -2806,8 +2813,8 @@ extern "C" int ps_policy_forward(ps_engine* e, int32_t n_scenes, int32_t Na, con
   const int pe_mode = use_c16(e, A, 2) ? 2 : 1;
   const PeLearnW* la = e->pe_on[2] ? &e->pe_learn[4] : nullptr;
   const PeLearnW* lm = e->pe_on[2] ? &e->pe_learn[5] : nullptr;
-  launch_radius(e, ea, d_ragent.p, nullptr, d_ppos.p, d_pscene.p, A, c.pol_agent_radius, c.pol_max_neigh, -1, d_ori.p, d_pori.p, nullptr, 0, pe_mode, la);
-  launch_radius(e, em, d_rmap.p, nullptr, d_ppos.p, d_pscene.p, A, c.pol_map_radius, c.pol_max_neigh, -1, d_ori.p, d_pori.p, nullptr, 0, pe_mode, lm);
+  launch_radius(e, ea, d_ragent.p, nullptr, d_ppos.p, d_pscene.p, A, c.pol_agent_radius, c.pol_max_neigh, -1, d_ori.p, d_pori.p, nullptr, 0, pe_mode, la, c.rel_pos_knn != 0);
+  launch_radius(e, em, d_rmap.p, nullptr, d_ppos.p, d_pscene.p, A, c.pol_map_radius, c.pol_max_neigh, -1, d_ori.p, d_pori.p, nullptr, 0, pe_mode, lm, c.rel_pos_knn != 0);
   std::vector<ChainStep> hs;
   for (int i = 0; i < L; ++i) {
     ChainStep s1;

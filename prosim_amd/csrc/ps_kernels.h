@@ -481,6 +481,86 @@ __global__ void k_knn(CandSet cs, const float* __restrict__ qpos, const int* __r
   }
 }
 
+// MODEL.REL_POS_EDGE_FUNC 'knn' (decoder/sym_coord.py:85-96, policy/act_decoder.py:249-261): the generator's and the policy's edge
+// sets from the `cap` NEAREST candidates of the query's scene (torch_cluster.knn; knn_graph(loop = False) for the prompt graph: the
+// cap + 1 nearest, then without the query itself) instead of the first `cap` inside a radius.  Same RadSets plumbing as k_radius --
+// MODE 0 counts (cnt), k_exclusive_scan makes the CSR and tile offsets, MODE 1 selects and fills (k_knn's bisection: the k-th
+// smallest (d2, index) key, ties in index order) -- so everything downstream of the edge lists is shared.
+template <int MODE>
+__global__ void k_knn_sets(RadSets sets, const float* __restrict__ qpos, const int* __restrict__ qscene, int nq) {
+  const RadSet& S = sets.s[blockIdx.y];
+  const CandSet cs = S.cs;
+  const int q = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (q >= nq) return;
+  const int* __restrict__ cand_ok = S.cand_ok;
+  const int cand_base = S.cand_base;
+  const float qx = qpos[2 * q], qy = qpos[2 * q + 1];
+  const int b = qscene[q];
+  const int b1 = cs.r1[2 * b], n1 = cs.r1[2 * b + 1] - b1;
+  const int b2 = cs.r2 ? cs.r2[2 * b] : 0, n2 = cs.r2 ? cs.r2[2 * b + 1] - b2 : 0;
+  const int n = n1 + n2;
+  // (a query that is filtered out as a candidate has no self match to drop)
+  const int self = (S.self_base >= 0 && (!cand_ok || cand_ok[S.self_base + q - cand_base])) ? S.self_base + q : -1;
+  unsigned key[KNN_SLOTS];
+  int n_ok = 0;
+#pragma unroll
+  for (int s = 0; s < KNN_SLOTS; ++s) {
+    const int j = s * 64 + lane;
+    unsigned kk = 0xffffffffu;
+    if (j < n) {
+      const int i = j < n1 ? b1 + j : b2 + (j - n1);
+      if (!cand_ok || i < cand_base || cand_ok[i - cand_base])
+        kk = __float_as_uint(dist2(cs.pos[2 * i], cs.pos[2 * i + 1], qx, qy));
+    }
+    key[s] = kk;
+    n_ok += __popcll(__ballot(kk != 0xffffffffu));
+  }
+  const int want = S.cap + (S.self_base >= 0 ? 1 : 0);
+  const int kk_ = want < n_ok ? want : n_ok;
+  if (MODE == 0) {
+    // (the query's own key is 0, the smallest: it is among the kk_ selected whenever it is a candidate)
+    if (lane == 0) S.cnt[q] = kk_ - ((self >= 0 && kk_ > 0) ? 1 : 0);
+    return;
+  }
+  {
+    const int t0 = S.toff[q], nt = S.toff[q + 1] - t0;
+    for (int t = lane; t < nt; t += 64) S.tdst[t0 + t] = q;
+  }
+  unsigned vk = 0;
+  for (int bit = 31; bit >= 0; --bit) {
+    const unsigned trial = vk | (1u << bit);
+    int c = 0;
+#pragma unroll
+    for (int s = 0; s < KNN_SLOTS; ++s) c += __popcll(__ballot(key[s] < trial));
+    if (c < kk_) vk = trial;
+  }
+  int c_lt = 0;
+#pragma unroll
+  for (int s = 0; s < KNN_SLOTS; ++s) c_lt += __popcll(__ballot(key[s] < vk));
+  int ties_left = kk_ - c_lt;
+  int out = S.eoff[q];
+#pragma unroll
+  for (int s = 0; s < KNN_SLOTS; ++s) {
+    const int j = s * 64 + lane;
+    const int i = j < n1 ? b1 + j : b2 + (j - n1);
+    const bool lt = key[s] < vk, eq = key[s] == vk && j < n && key[s] != 0xffffffffu;
+    const unsigned long long meq = __ballot(eq);
+    const int eq_rank = __popcll(meq & ((1ull << lane) - 1ull));
+    const bool sel = lt || (eq && eq_rank < ties_left);
+    const bool take = sel && i != self;
+    const unsigned long long mt = __ballot(take);
+    if (take) {
+      const int o = out + __popcll(mt & ((1ull << lane) - 1ull));
+      S.esrc[o] = i;
+      S.edst[o] = q;
+    }
+    out += __popcll(mt);
+    const int neq = __popcll(meq);
+    ties_left -= neq < ties_left ? neq : ties_left;
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // K5  relative positional encoding of an edge (act_decoder.py:203-221 and twins) through
 // FourierEmbeddingFix(32) (fourier_embedding.py:63-78), then the affine-free LayerNorm that

@@ -117,6 +117,10 @@ class ModelSpec:
     # a 'v2v_tag' condition between prompts s and t puts an edge s -> t and an edge t -> s into the condition layers'
     # graph (condition_attns.py:114-188).  Empty in the demo config ('v2v_tag' is not among its PROMPT.CONDITION.TYPES).
     used_v2v_tags: Tuple[str, ...] = ()
+    # MODEL.REL_POS_EDGE_FUNC (default.py:455; 'radius' in every released yaml): 'knn' builds the generator's (p2p, s2p) and the policy's
+    # (a2p, m2p) edge sets from the max_neigh NEAREST tokens of the scene instead of the first max_neigh inside a radius
+    # (decoder/sym_coord.py:85-96, policy/act_decoder.py:249-261; the scene encoder always uses knn, attn_fusion.py:107-109)
+    rel_pos_edge_func: str = "radius"
     enc_learnable_pe: bool = False
     dec_learnable_pe: bool = False
     pol_learnable_pe: bool = False
@@ -125,6 +129,8 @@ class ModelSpec:
     def __post_init__(self):
         if self.state_dim != 3 + 2 * self.pred_vel + 3 * self.pred_gmm:
             raise ValueError(f"state_dim {self.state_dim}: 3 (x, y, h) + 2 with pred_vel + 3 with pred_gmm (use ModelSpec.replace, which keeps it in step)")
+        if self.rel_pos_edge_func not in ("radius", "knn"):
+            raise ValueError(f"rel_pos_edge_func {self.rel_pos_edge_func!r}: 'radius' or 'knn'")
         if self.k_pred_mode not in ("anchor", "cluster", "mlp"):
             raise ValueError(f"k_pred_mode {self.k_pred_mode!r}: 'anchor', 'cluster' or 'mlp'")
 

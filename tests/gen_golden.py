@@ -75,6 +75,9 @@ FULL_CASES = {
     # the fixture keeps the reference's draws (mode_choice) and the torch seed they came from
     "small_topk3_b2": ("small_k3", dict(n_agents=16, n_polylines=128, batch=2, seed=12, goal=True, ragged=True, replay=0.3), 0),
     # binary (agent-pair) conditions: 'v2v_tag' beside the unary types (condition_attns.py:114-188: edges s -> t and t -> s)
+    # MODEL.REL_POS_EDGE_FUNC 'knn': the generator's and the policy's edge sets from the nearest tokens (small caps, so that the k
+    # nearest are a proper subset: 6 prompts, 40 scene tokens, 10 agents / 24 polylines per policy agent)
+    "small_knn_b2": ("small_knn", dict(n_agents=16, n_polylines=128, batch=2, seed=17, goal=True, tags=True, ragged=True), 0),
     "small_v2v_b2": ("small_v2v", dict(n_agents=16, n_polylines=128, batch=2, seed=15, goal=True, tags=True, v2v=True, ragged=True), 0),
     # *.ATTN.LEARNABLE_PE: the relative-PE rows of all six edge sets from learnable FourierEmbedding modules
     "small_lpe_b2": ("small_lpe", dict(n_agents=16, n_polylines=128, batch=2, seed=13, goal=True, tags=True, ragged=True), 0),
@@ -103,6 +106,7 @@ FULL_CASES = {
 SPECS = {"small": SMALL_SPEC, "demo": DEMO_SPEC, "small_mlp": SMALL_SPEC.replace(obs_fusion="mlp"),
          "small_mlp_attn": SMALL_SPEC.replace(obs_fusion="mlp", obs_attn_update=True),
          "small_k3": SMALL_SPEC.replace(motion_k=3, rollout_top_k=3),
+         "small_knn": SMALL_SPEC.replace(rel_pos_edge_func="knn", dec_max_neigh=40, pol_max_neigh=24),
          "small_v2v": SMALL_SPEC.replace(used_v2v_tags=("Following", "Merging", "Overtaking")),
          "small_lpe": SMALL_SPEC.replace(enc_learnable_pe=True, dec_learnable_pe=True, pol_learnable_pe=True, pe_num_freq=64),
          "small_noise_gmm": SMALL_SPEC.replace(pred_gmm=True, action_noise_std=0.05),
@@ -130,7 +134,9 @@ def ref_overrides(spec: ModelSpec):
             "MODEL.POLICY.ACT_DECODER.TRAJ.PRED_MODE", spec.k_pred_mode,
             "MODEL.POLICY.ACT_DECODER.TRAJ.PRED_VEL", spec.pred_vel,
             "DATASET.FORMAT.TARGET.ELEMENTS", "x,y,h,xd,yd" if spec.pred_vel else "x,y,h",
-            "LOSS.ROLLOUT_TRAJ.USE_GOAL_PRED_LOSS", spec.use_goal_pred_loss]
+            "LOSS.ROLLOUT_TRAJ.USE_GOAL_PRED_LOSS", spec.use_goal_pred_loss,
+            "MODEL.REL_POS_EDGE_FUNC", spec.rel_pos_edge_func,
+            "MODEL.DECODER.ATTN.MAX_NUM_NEIGH", spec.dec_max_neigh, "MODEL.POLICY.ACT_DECODER.ATTN.MAX_NUM_NEIGH", spec.pol_max_neigh]
 
 
 def run_reference(spec, w, scene):
