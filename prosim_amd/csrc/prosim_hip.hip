@@ -27,7 +27,7 @@ static thread_local std::string g_err;
 // (-DPS_EXPERIMENTS: tools/README.md).  The product library compiles them out -- a stray PS_* variable cannot change which kernel
 // runs or corrupt a rollout -- and says so once, loudly, when it finds one set.
 static const char* const kExpEnv[] = {"PS_C16_ABL", "PS_XCD", "PS_CHAIN_T", "PS_CHAIN_TP", "PS_CHAIN_T1", "PS_CHAIN_FLAGS", "PS_CHAIN_PROF",
-                                      "PS_C16_ROWS", "PS_S2S_C16", "PS_NO_SPLIT", "PS_SPLIT_MIN"};
+                                      "PS_C16_ROWS", "PS_S2S_C16", "PS_NO_SPLIT", "PS_SPLIT_MIN", "PS_SKIP_S2S_EDGE"};
 #ifdef PS_EXPERIMENTS
 static const char* exp_env(const char* name) { return getenv(name); }
 #else
@@ -1554,7 +1554,9 @@ int launch_split_layer(ps_engine* e, float* x, int Nd, const ChainStep* stp, int
     if (mt == 1) hipLaunchKernelGGL(k_node_pre_rt<1>, gr, dim3(256), RT_LDS_BYTES, st, (const float*)x, Nd, stp, io, eps, kv_out, khl_out);
     else if (mt == 2) hipLaunchKernelGGL(k_node_pre_rt<2>, gr, dim3(256), RT_LDS_BYTES, st, (const float*)x, Nd, stp, io, eps, kv_out, khl_out);
     else hipLaunchKernelGGL(k_node_pre_rt<3>, gr, dim3(256), RT_LDS_BYTES, st, (const float*)x, Nd, stp, io, eps, kv_out, khl_out);
-    if (geo_edges) hipLaunchKernelGGL(k_edge16, dim3((unsigned)tiles), dim3(512), c16_edge_lds_bytes(), st, Nd, stp, io, (const float*)e->div32);
+    static const bool skip_edge = exp_env("PS_SKIP_S2S_EDGE") != nullptr;   // experiments only (timing; wrong results)
+    if (skip_edge) {}
+    else if (geo_edges) hipLaunchKernelGGL(k_edge16, dim3((unsigned)tiles), dim3(512), c16_edge_lds_bytes(), st, Nd, stp, io, (const float*)e->div32);
     else if (maxdeg <= 32) hipLaunchKernelGGL((k_edge_small<3, 2>), ge, dim3(256), es_lds_bytes<2>(), st, Nd, stp, io);
     else hipLaunchKernelGGL((k_edge_small<3, 8>), ge, dim3(256), es_lds_bytes<8>(), st, Nd, stp, io);
     if (mt == 1) hipLaunchKernelGGL(k_node_post_rt<1>, gr, dim3(256), RT_LDS_BYTES, st, x, Nd, stp, io, eps);
@@ -1842,7 +1844,6 @@ void launch_radius(ps_engine* e, const RadArgs* a, int nsets, const float* qpos,
   hipStream_t st = e->stream;
   if (knn) {   // MODEL.REL_POS_EDGE_FUNC 'knn': the cap nearest instead of the first cap inside the radius (same CSR plumbing)
     hipLaunchKernelGGL(k_knn_sets<0>, dim3(grid, nsets), dim3(64 * wpb), 0, st, rs, qpos, qscene, nq);
-    hipLaunchKernelGGL(k_exclusive_scan, dim3(nsets), dim3(1024), 0, st, rs, nq);
     hipLaunchKernelGGL(k_knn_sets<1>, dim3(grid, nsets), dim3(64 * wpb), 0, st, rs, qpos, qscene, nq);
   } else {
     hipLaunchKernelGGL(k_radius<0>, dim3(grid, nsets), dim3(64 * wpb), 0, st, rs, qpos, qscene, nq);
@@ -1850,7 +1851,7 @@ void launch_radius(ps_engine* e, const RadArgs* a, int nsets, const float* qpos,
       if (a[i].self_base >= 0)
         hipLaunchKernelGGL(k_radius_selfrank, dim3(grid), dim3(64 * wpb), 0, st, rs.s[i].cs, qpos, qscene, nq, rs.s[i].r2, a[i].cap,
                            a[i].self_base, a[i].es->cnt.p, a[i].cand_ok, a[i].cand_base);
-    hipLaunchKernelGGL(k_exclusive_scan, dim3(nsets), dim3(1024), 0, st, rs, nq);
+    // (no scan launch: the fill pass computes its own prefix, csr_prefix)
     hipLaunchKernelGGL(k_radius<1>, dim3(grid, nsets), dim3(64 * wpb), 0, st, rs, qpos, qscene, nq);
   }
   PeArgs pe[2];

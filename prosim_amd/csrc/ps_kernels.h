@@ -247,6 +247,34 @@ struct RadSet {
 struct RadSets {
   RadSet s[2];
 };
+// A query's CSR and tile offsets from the counts of the queries before it (round 4: the fill pass computes its own exclusive prefix --
+// one strided sweep of cnt[0..q) per wave, a few thousand integers at most -- and writes eoff / toff itself; the separate one-workgroup
+// scan launch between the count and the fill pass is gone: one dependent graph node less per neighbour search).
+__device__ __forceinline__ void csr_prefix(const int* __restrict__ cnt, int q, int nq, int lane, int* __restrict__ eoff, int* __restrict__ toff,
+                                           int& e0, int& t0, int& mine) {
+  int se = 0, stl = 0;
+  for (int i = lane; i < q; i += 64) {
+    const int c = cnt[i];
+    se += c;
+    stl += (c + 31) >> 5;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    se += __shfl_xor(se, o);
+    stl += __shfl_xor(stl, o);
+  }
+  mine = cnt[q];
+  e0 = se;
+  t0 = stl;
+  if (lane == 0) {
+    eoff[q] = se;
+    toff[q] = stl;
+    if (q == nq - 1) {
+      eoff[nq] = se + mine;
+      toff[nq] = stl + ((mine + 31) >> 5);
+    }
+  }
+}
 template <int MODE>
 __global__ void k_radius(RadSets sets, const float* __restrict__ qpos, const int* __restrict__ qscene, int nq) {
   const RadSet& S = sets.s[blockIdx.y];
@@ -256,16 +284,17 @@ __global__ void k_radius(RadSets sets, const float* __restrict__ qpos, const int
   const int* __restrict__ cand_ok = S.cand_ok;
   const int cand_base = S.cand_base;
   int* __restrict__ cnt = S.cnt;
-  const int* __restrict__ eoff = S.eoff;
-  const int* __restrict__ toff = S.toff;
   int* __restrict__ tdst = S.tdst;
   int* __restrict__ esrc = S.esrc;
   int* __restrict__ edst = S.edst;
   const int q = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (q >= nq) return;
-  if (MODE == 1) {   // tile -> destination map of the rel-PE operand images (<= 25 tiles per destination)
-    const int t0 = toff[q], nt = toff[q + 1] - t0;
+  int base_e = 0;
+  if (MODE == 1) {   // this query's offsets, and the tile -> destination map of the rel-PE operand images (<= 25 tiles per destination)
+    int t0, mine;
+    csr_prefix(cnt, q, nq, lane, S.eoff, S.toff, base_e, t0, mine);
+    const int nt = (mine + 31) >> 5;
     if (lane < nt) tdst[t0 + lane] = q;
   }
   const float qx = qpos[2 * q], qy = qpos[2 * q + 1];
@@ -274,7 +303,7 @@ __global__ void k_radius(RadSets sets, const float* __restrict__ qpos, const int
   // (a query that is filtered out as a candidate has no self match to drop)
   const int self = (self_base >= 0 && (!cand_ok || cand_ok[self_base + q - cand_base])) ? self_base + q : -1;
   int run = 0;
-  const int base_out = (MODE == 1) ? eoff[q] : 0;
+  const int base_out = base_e;
   for (int rg = 0; rg < 2 && run < capx; ++rg) {
     const int* rr = rg == 0 ? cs.r1 : cs.r2;
     if (!rr) break;
@@ -523,8 +552,11 @@ __global__ void k_knn_sets(RadSets sets, const float* __restrict__ qpos, const i
     if (lane == 0) S.cnt[q] = kk_ - ((self >= 0 && kk_ > 0) ? 1 : 0);
     return;
   }
+  int out;
   {
-    const int t0 = S.toff[q], nt = S.toff[q + 1] - t0;
+    int t0, mine;
+    csr_prefix(S.cnt, q, nq, lane, S.eoff, S.toff, out, t0, mine);
+    const int nt = (mine + 31) >> 5;
     for (int t = lane; t < nt; t += 64) S.tdst[t0 + t] = q;
   }
   unsigned vk = 0;
@@ -539,7 +571,6 @@ __global__ void k_knn_sets(RadSets sets, const float* __restrict__ qpos, const i
 #pragma unroll
   for (int s = 0; s < KNN_SLOTS; ++s) c_lt += __popcll(__ballot(key[s] < vk));
   int ties_left = kk_ - c_lt;
-  int out = S.eoff[q];
 #pragma unroll
   for (int s = 0; s < KNN_SLOTS; ++s) {
     const int j = s * 64 + lane;
