@@ -658,6 +658,8 @@ extern "C" int ps_create(const ps_config* cfg, int32_t n_tensors, const char* co
     const std::string mh = pa + ".motion_head.mlp.";
     b.fragments(&e->head.m0F, mh + "0.weight", D, D, 0, D);
     b.fragments(&e->head.m1F, mh + "3.weight", D / 2, D, 0, D);
+    b.fragments(&e->head.m0Q, mh + "0.weight", D, D, 0, D, true);
+    b.fragments(&e->head.m1Q, mh + "3.weight", D / 2, D, 0, D, true);
     b.transposed(&e->head.m0t, mh + "0.weight", D, D);
     b.plain(&e->head.m0b, mh + "0.bias", D);
     b.plain(&e->head.m0lnw, mh + "1.weight", D);
@@ -678,12 +680,14 @@ extern "C" int ps_create(const ps_config* cfg, int32_t n_tensors, const char* co
       std::vector<float> w2p((size_t)128 * 64, 0.f);   // torch layout [out 128 (zero rows past OUT)][in 64]
       for (int n = 0; n < OUT && n < 128; ++n) std::copy(w2 + (size_t)n * 64, w2 + (size_t)(n + 1) * 64, w2p.begin() + (size_t)n * 64);
       b.fragments_raw(&e->head.m2F, w2p.data(), 128, 64, 0, 64);
+      b.fragments_raw(&e->head.m2Q, w2p.data(), 128, 64, 0, 64, true);
       b.slot(&e->head.m2b, b.put(bb));
     }
   }
   for (int i = 0; i < 3 && !cfg->k_pred_mlp; ++i) {
     const std::string q = pa + ".CG_decode.CGs." + std::to_string(i) + ".MLP.";
     b.fragments(&e->head.cgF[i], q + "0.weight", D, D, 0, D);
+    b.fragments(&e->head.cgQ[i], q + "0.weight", D, D, 0, D, true);
     b.transposed(&e->head.cgWt[i], q + "0.weight", D, D);
     b.plain(&e->head.cgb[i], q + "0.bias", D);
     b.plain(&e->head.cglnw[i], q + "1.weight", D);
@@ -767,6 +771,7 @@ extern "C" int ps_create(const ps_config* cfg, int32_t n_tensors, const char* co
   PS_RT_ATTR((k_pointnet_rt<5, 4>));
   PS_RT_ATTR(k_node_pre_rt<1>); PS_RT_ATTR(k_node_pre_rt<2>); PS_RT_ATTR(k_node_pre_rt<3>);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_edge16), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c16_edge_lds_bytes());
+  PS_RT_ATTR(k_policy_head_rt);
   PS_RT_ATTR(k_node_post_rt<1>); PS_RT_ATTR(k_node_post_rt<2>); PS_RT_ATTR(k_node_post_rt<3>);
 #undef PS_RT_ATTR
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pe_learn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PL_LDS_BYTES);
@@ -2142,13 +2147,21 @@ extern "C" int ps_policy_step(ps_engine* e, int32_t t_idx) {
   if (e->policy_events && (int)e->pev.size() >= 2 * R) HIPCHK(hipEventRecord(e->pev[2 * t_idx + 1], st));
   // _compute_traj + step_agent_traj
   {
-    const int G = c.k_pred_mlp ? 16 : 16 / c.motion_k;   // agents per workgroup: one 16-row tile holds G agents x K modes (PRED_MODE mlp: 16 agents)
-    hipLaunchKernelGGL(k_policy_head_mfma, dim3((A + G - 1) / G), dim3(256), 0, st, e->head, (const float*)e->d_fused.p,
-                       (const int*)e->d_agent_type.p, A, c.motion_k, c.target_steps, c.state_dim,
-                       e->d_motion.p + (size_t)t_idx * A * c.motion_k * c.target_steps * c.state_dim,
-                       e->d_traj.p, e->d_vel.p, e->stride_steps, last, c.replan_freq, c.ln_eps, (const int*)(e->d_choice.p + (size_t)t_idx * A),
-                       e->have_noise ? (const float*)(e->d_noise.p + (size_t)t_idx * A * c.motion_k * c.target_steps * 2) : (const float*)nullptr,
-                       c.no_pred_vel ? -1 : (c.pred_gmm ? 6 : 3), c.k_pred_mlp ? 1 : 0);
+    float* mp_out = e->d_motion.p + (size_t)t_idx * A * c.motion_k * c.target_steps * c.state_dim;
+    const float* nz = e->have_noise ? (const float*)(e->d_noise.p + (size_t)t_idx * A * c.motion_k * c.target_steps * 2) : (const float*)nullptr;
+    const int vcol = c.no_pred_vel ? -1 : (c.pred_gmm ? 6 : 3);
+    if (c.motion_k == 1 && !c.k_pred_mlp && !e->legacy_rows) {
+      // row-tile head (ps_rowtile.h): a wave carries 16 agents through CG_decode and the motion head in registers
+      hipLaunchKernelGGL(k_policy_head_rt, dim3((A + 63) / 64), dim3(256), RT_LDS_BYTES, st, e->head, (const float*)e->d_fused.p,
+                         (const int*)e->d_agent_type.p, A, c.target_steps, c.state_dim, mp_out, e->d_traj.p, e->d_vel.p, e->stride_steps, last,
+                         c.replan_freq, c.ln_eps, nz, vcol);
+    } else {
+      const int G = c.k_pred_mlp ? 16 : 16 / c.motion_k;   // agents per workgroup: one 16-row tile holds G agents x K modes (PRED_MODE mlp: 16 agents)
+      hipLaunchKernelGGL(k_policy_head_mfma, dim3((A + G - 1) / G), dim3(256), 0, st, e->head, (const float*)e->d_fused.p,
+                         (const int*)e->d_agent_type.p, A, c.motion_k, c.target_steps, c.state_dim, mp_out,
+                         e->d_traj.p, e->d_vel.p, e->stride_steps, last, c.replan_freq, c.ln_eps, (const int*)(e->d_choice.p + (size_t)t_idx * A),
+                         nz, vcol, c.k_pred_mlp ? 1 : 0);
+    }
   }
   HIPCHK(hipGetLastError());
   return PS_OK;

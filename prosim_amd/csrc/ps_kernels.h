@@ -1077,6 +1077,7 @@ struct HeadW {
   Mlp3W motion;                                           // (torch layout, kept for reference/tests)
   // the six Linears as split-fp16 MFMA B fragments (layout: pn_gemm); m2's output columns are zero-padded to 64
   const _Float16 *cgF[3], *m0F, *m1F, *m2F;
+  const _Float16 *cgQ[3], *m0Q, *m1Q, *m2Q;               // the same with the row-tile kernels' K order (ps_rowtile.h k_policy_head_rt)
 };
 
 // relu(LayerNorm(C[r][0:N] + bias)) for 16 rows, a lane quad per row: thread t < 64 -> row t >> 2, columns

@@ -663,4 +663,170 @@ __global__ __launch_bounds__(256, 1) void k_node_post_rt(float* x, int Nd, const
   rt_store_rows<MT>(y, x, 128, 0, row, live, kq);
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// ActDecoder._compute_traj + step_agent_traj on row tiles (K = 1 motion mode, anchor mode: every released config; act_decoder.py:78-140,
+// CG_stacked mlp.py:207-241, traj_sam.py:300-347).  The staged k_policy_head_mfma takes 39 us per replan for 128 agents -- six
+// dependent 16-row GEMM stages with their LDS round trips; here a wave carries 16 agents through CG_decode (3 blocks) and the motion
+// head (128 -> 128 -> 64 -> steps * state) in registers, 64 agents per workgroup, and the trajectory tail (cumulative sums, heading
+// wrap, rotation into the agent-init frame, append) runs on the last GEMM's rows exactly as in the staged kernel.
+template <int MT, int NT>
+__device__ __forceinline__ void rt_bias_n(floatx4 (&a)[NT][MT], const float* __restrict__ bias, int kq) {
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const float4 b = ldg4(bias + 16 * t + 4 * kq);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) a[t][mt] = floatx4{b.x, b.y, b.z, b.w};
+  }
+}
+// LayerNorm over the 16 NT features of every row
+template <int MT, int NT>
+__device__ __forceinline__ void rt_ln_n(floatx4 (&a)[NT][MT], const float* __restrict__ w, const float* __restrict__ b, float eps, int kq) {
+  float rstd[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    float sm = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) sm += (a[t][mt][0] + a[t][mt][1]) + (a[t][mt][2] + a[t][mt][3]);
+    const float mean = kq_sum(sm) * (1.f / (16.f * NT));
+    float sq = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        a[t][mt][j] -= mean;
+        sq = fmaf(a[t][mt][j], a[t][mt][j], sq);
+      }
+    rstd[mt] = 1.f / sqrtf(kq_sum(sq) * (1.f / (16.f * NT)) + eps);
+  }
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const float4 wv = ldg4(w + 16 * t + 4 * kq), bv = ldg4(b + 16 * t + 4 * kq);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      a[t][mt][0] = fmaf(a[t][mt][0] * rstd[mt], wv.x, bv.x);
+      a[t][mt][1] = fmaf(a[t][mt][1] * rstd[mt], wv.y, bv.y);
+      a[t][mt][2] = fmaf(a[t][mt][2] * rstd[mt], wv.z, bv.z);
+      a[t][mt][3] = fmaf(a[t][mt][3] * rstd[mt], wv.w, bv.w);
+    }
+  }
+}
+__global__ __launch_bounds__(256, 1) void k_policy_head_rt(HeadW w, const float* __restrict__ fused, const int* __restrict__ agent_type, int n_agents,
+                                                          int steps, int sdim, float* __restrict__ motion_pred, float* __restrict__ traj,
+                                                          float* __restrict__ vel, int stride_steps, int last, int replan, float eps,
+                                                          const float* __restrict__ noise, int vcol) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char rt_smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  RtStage S = rt_stage_init(rt_smem, wave, lane, 4);
+  rt_fill<4, 4, 8>(S, w.cgQ[0], 0);
+  const int n = lane & 15, kq = lane >> 4;
+  const int ag_w = blockIdx.x * 64 + wave * 16 + n;
+  const int agc = ag_w < n_agents ? ag_w : n_agents - 1;
+  floatx4 inp[8][1], ctx[8][1], acc[8][1];
+  {
+    const float* an = w.anchors + (size_t)(agent_type[agc] - 1) * 128;   // anchor of (type, mode 0)   (act_decoder.py:66-68)
+    const float* fu = fused + (size_t)agc * 128;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const float4 a = ldg4(an + 16 * t + 4 * kq), c = ldg4(fu + 16 * t + 4 * kq);
+      inp[t][0] = floatx4{a.x, a.y, a.z, a.w};
+      ctx[t][0] = floatx4{c.x, c.y, c.z, c.w};
+    }
+  }
+  half8 xh[1][4], xl[1][4];
+  rt_to_operand<1>(inp, xh, xl);
+  // CG_stacked(3): block i: y = relu(LN(W inp + b)) * context; with one mode the context's maximum over the modes is y itself
+#pragma unroll 1
+  for (int i = 0; i < 3; ++i) {
+    rt_bias<1>(acc, w.cgb[i], kq);
+    rt_gemm<1, 4, 8>(S, acc, xh, xl, [&] { rt_fill<4, 4, 8>(S, i < 2 ? w.cgQ[i + 1] : w.m0Q, 0); });
+    rt_ln<1>(acc, w.cglnw[i], w.cglnb[i], eps, kq);
+    rt_relu<1>(acc);
+    const float fi = (float)i, fd = (float)(i + 1);
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float y = acc[t][0][j] * ctx[t][0][j];
+        if (i == 0) {
+          inp[t][0][j] = y;
+          ctx[t][0][j] = y;
+        } else {
+          inp[t][0][j] = (inp[t][0][j] * fi + y) / fd;
+          ctx[t][0][j] = (ctx[t][0][j] * fi + y) / fd;
+        }
+      }
+    rt_to_operand<1>(inp, xh, xl);
+  }
+  // motion_head: 128 -> 128 (LN, ReLU) -> 64 (LN, ReLU) -> steps * sdim (zero-padded to 128 columns; its bias joins in the tail)
+  rt_bias<1>(acc, w.m0b, kq);
+  rt_gemm<1, 4, 8>(S, acc, xh, xl, [&] { rt_fill<4, 4, 4>(S, w.m1Q, 0); });
+  rt_ln<1>(acc, w.m0lnw, w.m0lnb, eps, kq);
+  rt_relu<1>(acc);
+  rt_to_operand<1>(acc, xh, xl);
+  floatx4 h[4][1];
+  rt_bias_n<1, 4>(h, w.m1b, kq);
+  rt_gemm<1, 4, 4>(S, h, xh, xl, [&] { rt_fill<2, 2, 8>(S, w.m2Q, 0); });
+  rt_ln_n<1, 4>(h, w.m1lnw, w.m1lnb, eps, kq);
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float v = fmaxf(h[2 * ks + (i >> 2)][0][i & 3], 0.f);
+      xh[0][ks][i] = f16_hi(v);
+      xl[0][ks][i] = rt_lo(v);
+    }
+  rt_zero<1, 8>(acc);
+  rt_gemm<1, 2, 8>(S, acc, xh, xl, [] {});
+  // the rows of the last Linear meet in LDS (the stage buffer nobody reads any more) for the per-(agent, step) tail
+  float* C = reinterpret_cast<float*>(rt_smem + (size_t)S.cb * RT_STAGE_BYTES);
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+    *reinterpret_cast<float4*>(C + (wave * 16 + n) * PN_CS + 16 * t + 4 * kq) = make_float4(acc[t][0][0], acc[t][0][1], acc[t][0][2], acc[t][0][3]);
+  __syncthreads();
+  // cumsum over steps of (dx, dy, dtheta); wrap theta (act_decoder.py:117-121).  One thread per (agent, step): it re-adds the prefix in
+  // step order, so the sums round exactly like the sequential scan (the staged kernel's tail, K = 1)
+  const int ag0 = blockIdx.x * 64;
+  for (int i = tid; i < 64 * steps; i += 256) {
+    const int row = i / steps, s = i - row * steps;
+    const int ag = ag0 + row;
+    if (ag >= n_agents) continue;
+    const float* o = C + row * PN_CS;
+    const float* ob = w.m2b;
+    float cx = 0.f, cy = 0.f, ch = 0.f;
+    const float* nz = noise ? noise + (size_t)ag * steps * 2 : nullptr;
+    for (int j = 0; j <= s; ++j) {
+      const float dx = o[j * sdim] + ob[j * sdim], dy = o[j * sdim + 1] + ob[j * sdim + 1];
+      cx += nz ? dx + nz[2 * j] : dx;
+      cy += nz ? dy + nz[2 * j + 1] : dy;
+      ch += o[j * sdim + 2] + ob[j * sdim + 2];
+    }
+    const float hh = wrap_angle(ch);
+    float* mp = motion_pred + (size_t)ag * steps * sdim + s * sdim;
+    mp[0] = cx;
+    mp[1] = cy;
+    mp[2] = hh;
+    for (int f = 3; f < sdim; ++f) mp[f] = o[s * sdim + f] + ob[s * sdim + f];
+    if (s < replan) {
+      // step_agent_traj (traj_sam.py:322-347): rotate into the agent-init frame, append
+      const float* cur = traj + ((size_t)ag * stride_steps + last - 1) * 4;
+      const float c0 = cur[0], c1 = cur[1];
+      const float lth = atan2f(cur[2], cur[3]);
+      const float cl = cosf(lth), sl = sinf(lth);
+      float* t = traj + ((size_t)ag * stride_steps + last + s) * 4;
+      float* v = vel + ((size_t)ag * stride_steps + last + s) * 2;
+      t[0] = (cx * cl - cy * sl) + c0;
+      t[1] = (cy * cl + cx * sl) + c1;
+      const float pth = wrap_angle(lth + hh);
+      t[2] = sinf(pth);
+      t[3] = cosf(pth);
+      if (vcol >= 0) {
+        const float vx = o[s * sdim + vcol] + ob[s * sdim + vcol], vy = o[s * sdim + vcol + 1] + ob[s * sdim + vcol + 1];
+        v[0] = vx * cl - vy * sl;
+        v[1] = vy * cl + vx * sl;
+      }
+    }
+  }
+}
+
 }  // namespace ps
