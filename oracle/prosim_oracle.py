@@ -492,15 +492,20 @@ def condition_transform(Wt: W, spec: ModelSpec, cond: Optional[Dict], emd: T, pr
         attr.index_put_((bi, ni, ni), e[bi, ci_], accumulate=True)
         cnt.index_put_((bi, ni, ni), torch.ones(bi.numel(), dtype=emd.dtype), accumulate=True)
     for es, et, m, pidx in pair_entries:
+        # one [B, N, N, D] plane per binary key, filled by TWO assignment passes (:155-162): every entry's source half on (s, t) in entry
+        # order, then every entry's target half on (t, s) -- so a target half overwrites a source half that a REVERSED entry of the same
+        # key put on that edge, and the edge still counts once
+        plane = {}
         bi, ci_ = m.nonzero(as_tuple=True)
-        si, ti = pidx[bi, ci_, 0], pidx[bi, ci_, 1]
-        kp = last_wins(bi, ci_, si, ti)
-        bi, ci_, si, ti = bi[kp], ci_[kp], si[kp], ti[kp]
-        one = torch.ones(bi.numel(), dtype=emd.dtype)
-        attr.index_put_((bi, si, ti), es[bi, ci_], accumulate=True)
-        cnt.index_put_((bi, si, ti), one, accumulate=True)
-        attr.index_put_((bi, ti, si), et[bi, ci_], accumulate=True)
-        cnt.index_put_((bi, ti, si), one, accumulate=True)
+        for k in range(bi.numel()):
+            b_, c_ = int(bi[k]), int(ci_[k])
+            plane[(b_, int(pidx[b_, c_, 0]), int(pidx[b_, c_, 1]))] = es[b_, c_]
+        for k in range(bi.numel()):
+            b_, c_ = int(bi[k]), int(ci_[k])
+            plane[(b_, int(pidx[b_, c_, 1]), int(pidx[b_, c_, 0]))] = et[b_, c_]
+        for (b_, i_, j_), v in plane.items():
+            attr[b_, i_, j_] += v
+            cnt[b_, i_, j_] += 1
     attr = attr / cnt.clamp(min=1)[..., None]
     edge_ok = (cnt > 0) & prompt_mask[:, :, None] & prompt_mask[:, None, :]
     node_index = torch.full((B, N), -1, dtype=torch.long)

@@ -1221,6 +1221,13 @@ static int rebuild_conditions(ps_engine* e) {
         // key (type, id) on one edge the LAST one survives (the stable sort kept the entries' order) and counts once
         bool later = false;
         for (size_t j = i + 1; j < j_end && !later; ++j) later = all[j].second->type == en->type && all[j].second->id == en->id;
+        // a binary key's plane is written in TWO passes (:155-162: every source half on (s, t), then every target half on (t, s)): the
+        // target half of a REVERSED entry of the same tag overwrites a source half on this edge, wherever it stands in the entry order
+        if (!later && en->type == 3 && (en->id & 1) == 0) {
+          size_t j0 = i;
+          while (j0 > 0 && all[j0 - 1].first.dst == a && all[j0 - 1].first.src == src) --j0;
+          for (size_t j = j0; j < j_end && !later; ++j) later = all[j].second->type == 3 && all[j].second->id == en->id + 1;
+        }
         if (later) continue;
         ent_type.push_back(en->type);
         ent_type.push_back(en->id);

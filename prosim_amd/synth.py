@@ -25,7 +25,7 @@ from .spec import ModelSpec
 
 def make_scene(spec: ModelSpec, n_agents: int, n_polylines: int, batch: int = 1, seed: int = 0,
                square: float = 200.0, points: int = 19, goal: bool = False, tags: bool = False, dup_tags: bool = False,
-               ragged: bool = False, clustered: bool = False, replay: float = 0.0, drag: bool = False, v2v: bool = False,
+               ragged: bool = False, clustered: bool = False, replay: float = 0.0, drag: bool = False, v2v: bool = False, v2v_reverse: bool = False,
                enter: float = 0.0) -> Dict[str, np.ndarray]:
     """One batch of ``batch`` scenes.  ``ragged``: later scenes in the batch get fewer agents /
     polylines / points, and some history steps are masked (NaN), to exercise the mask paths.
@@ -218,6 +218,17 @@ def make_scene(spec: ModelSpec, n_agents: int, n_polylines: int, batch: int = 1,
                 vi[b, c] = (tag, t0, t0 + float(rng.randint(5, spec.max_steps // 2)))
                 vp[b, c] = (s_, t_)
                 vm[b, c] = (rng.rand() < 0.7) if ragged else True
+        if v2v_reverse:
+            # the corner case of the reference's two assignment passes (condition_attns.py:155-162): the SAME tag on a pair in both
+            # directions, (s, t) and (t, s) -- the later pass's target halves overwrite the source halves on both edges
+            for b in range(B):
+                free = [c for c in range(C) if not vm[b, c] and vi[b, c, 0] < 0]
+                have = [c for c in range(C) if vm[b, c]]
+                for c_src, c_new in zip(have[:3], free):
+                    vi[b, c_new] = vi[b, c_src]
+                    vi[b, c_new, 1] += 3.0          # (another time span: the two entries' embeddings differ)
+                    vp[b, c_new] = vp[b, c_src][::-1]
+                    vm[b, c_new] = True
         cond["v2v_tag"] = dict(input=vi, mask=vm, prompt_idx=vp)
     if cond:
         scene["cond"] = cond

@@ -78,6 +78,8 @@ FULL_CASES = {
     # MODEL.REL_POS_EDGE_FUNC 'knn': the generator's and the policy's edge sets from the nearest tokens (small caps, so that the k
     # nearest are a proper subset: 6 prompts, 40 scene tokens, 10 agents / 24 polylines per policy agent)
     "small_knn_b2": ("small_knn", dict(n_agents=16, n_polylines=128, batch=2, seed=17, goal=True, tags=True, ragged=True), 0),
+    # ... and the same V2V tag on a pair in BOTH directions: the reference's second assignment pass overwrites the first (condition_attns.py:155-162)
+    "small_v2vrev_b2": ("small_v2v", dict(n_agents=16, n_polylines=128, batch=2, seed=16, goal=True, v2v=True, v2v_reverse=True, ragged=True), 0),
     "small_v2v_b2": ("small_v2v", dict(n_agents=16, n_polylines=128, batch=2, seed=15, goal=True, tags=True, v2v=True, ragged=True), 0),
     # *.ATTN.LEARNABLE_PE: the relative-PE rows of all six edge sets from learnable FourierEmbedding modules
     "small_lpe_b2": ("small_lpe", dict(n_agents=16, n_polylines=128, batch=2, seed=13, goal=True, tags=True, ragged=True), 0),

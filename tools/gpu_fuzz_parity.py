@@ -32,13 +32,19 @@ if os.environ.get("FUZZ_R3"):   # round-3 variants: noise + GMM head, PRED_MODE 
                 SMALL_SPEC.replace(pred_vel=False), SMALL_SPEC.replace(pred_vel=False, pred_gmm=True, k_pred_mode="mlp", motion_k=2),
                 SMALL_SPEC.replace(use_goal_pred_loss=False, obs_fusion="mlp"),
                 SMALL_SPEC.replace(enc_learnable_pe=True, dec_learnable_pe=True, pol_learnable_pe=True, pe_num_freq=32)]
+if os.environ.get("FUZZ_R4"):   # round-4 variants: REL_POS_EDGE_FUNC knn with caps from "every token" down to 3
+    variants = [SMALL_SPEC.replace(rel_pos_edge_func="knn"), SMALL_SPEC.replace(rel_pos_edge_func="knn", dec_max_neigh=12, pol_max_neigh=9),
+                SMALL_SPEC.replace(rel_pos_edge_func="knn", dec_max_neigh=3, pol_max_neigh=40, obs_fusion="mlp"),
+                SMALL_SPEC.replace(rel_pos_edge_func="knn", dec_max_neigh=64, pol_max_neigh=5, obs_attn_update=True)]
+# FUZZ_ROW_IMPL: ps_set_row_impl (11..13: the row-tile node halves + k_edge16 at EVERY size, 1..3 row tiles per wave; 1: the staged kernels)
+FUZZ_ROW_IMPL = int(os.environ.get("FUZZ_ROW_IMPL", "0"))
 engines = {}
 worst = 0.0
 bad = []
 t0 = time.time()
 for case in range(n_cases):
-    spec = variants[rng.randint(len(variants)) if (rng.rand() < 0.4 or os.environ.get("FUZZ_R2") or os.environ.get("FUZZ_R3")) else 0]
-    if rng.rand() < 0.35:   # small neighbour caps / radii: the index-order truncation and the degree-bound paths
+    spec = variants[rng.randint(len(variants)) if (rng.rand() < 0.4 or os.environ.get("FUZZ_R2") or os.environ.get("FUZZ_R3") or os.environ.get("FUZZ_R4")) else 0]
+    if rng.rand() < 0.35 and not os.environ.get("FUZZ_R4"):   # small neighbour caps / radii: the index-order truncation and the degree-bound paths
         spec = spec.replace(dec_max_neigh=int(rng.choice([4, 16, 512])), pol_max_neigh=int(rng.choice([3, 12, 768])),
                             scene_knn=int(rng.choice([2, 8, 32])), dec_prompt_radius=float(rng.choice([20.0, 300.0])),
                             dec_scene_radius=float(rng.choice([30.0, 300.0])), pol_agent_radius=float(rng.choice([15.0, 100.0])),
@@ -72,8 +78,9 @@ for case in range(n_cases):
         engines.clear()
     if key not in engines:
         engines[key] = (Engine(spec, weights.init_weights(spec, 0)), weights.init_weights(spec, 0))
-        engines[key][0].set_chain_rows(FUZZ_ROWS)
+        engines[key][0].set_row_impl(FUZZ_ROW_IMPL)
         engines[key][0].set_chain_impl(int(os.environ.get("FUZZ_IMPL", "0")))   # 2: every fused chain on k_chain16, whatever the size
+        engines[key][0].set_chain_rows(FUZZ_ROWS)
     eng, w = engines[key]
     with torch.no_grad():
         o64 = orc.rollout(w, spec, scene, dtype=torch.float64)
