@@ -115,7 +115,7 @@ __device__ __forceinline__ void rt_gemm(RtStage& S, floatx4 (&acc)[NT][MT], cons
 #pragma unroll
   for (int d = 0; d < DEPTH; ++d)
     if (d < NG) { fh[d] = fb[d * 128]; fl[d] = fb[d * 128 + 64]; }
-  floatx4 p1[MT], p2[1];
+  floatx4 p1[MT], p2[MT];
 #pragma unroll
   for (int g = 0; g < NG; ++g) {
     const int s = g % DEPTH;
@@ -125,23 +125,21 @@ __device__ __forceinline__ void rt_gemm(RtStage& S, floatx4 (&acc)[NT][MT], cons
     const int t = g / K32, ks = g % K32;
     if (ks == 0) {
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) p1[mt] = floatx4{0.f, 0.f, 0.f, 0.f};
+      for (int mt = 0; mt < MT; ++mt) p1[mt] = p2[mt] = floatx4{0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, xh[mt][ks], acc[t][mt], 0, 0, 0);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) p1[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, xh[mt][ks], p1[mt], 0, 0, 0);
-    if (MT == 1) {   // (a single tile: the two cross products on separate accumulators, or the second waits ~45 cycles for the first)
-      if (ks == 0) p2[0] = floatx4{0.f, 0.f, 0.f, 0.f};
-      p2[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, xl[0][ks], p2[0], 0, 0, 0);
-    } else {
+    // (the two cross products on their OWN accumulators whatever the tile count: a row's bits must not depend on how many tiles
+    // its wave carries -- the shapes differ between latency and throughput mode -- and at a single tile the second product would
+    // otherwise wait ~45 cycles for the first)
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) p1[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, xl[mt][ks], p1[mt], 0, 0, 0);
-    }
+    for (int mt = 0; mt < MT; ++mt) p2[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, xl[mt][ks], p2[mt], 0, 0, 0);
     if (ks == K32 - 1) {   // the cross products carry the lo halves' scale
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
-        if (MT == 1) p1[mt] += p2[mt];
+        p1[mt] += p2[mt];
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[t][mt][j] = fmaf(p1[mt][j], RT_LO_INV, acc[t][mt][j]);
       }
