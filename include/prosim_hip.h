@@ -236,7 +236,9 @@ int ps_set_chain_impl(ps_engine* e, int32_t impl);
 /* Which kernels run the dense per-row stacks (PointNet encoders, the node half of the split s2s layers, k | v projections):
  * 0 (default) = the row-tile kernels of round 4 (ps_rowtile.h: a wave carries 16..80 rows through the whole stack in registers,
  * chained transposed MFMA GEMMs, no barriers), 1 = the staged kernels of rounds 1-3 (k_pointnet_mfma, k_node, k_kv_proj:
- * GEMM -> LDS -> barrier -> epilogue per Linear).  Both stay in the library: each is the other's cross-check. */
+ * GEMM -> LDS -> barrier -> epilogue per Linear).  Both stay in the library: each is the other's cross-check.
+ * 2 = as 0 with the split layers' edge half on the 16-row workgroup kernel (k_edge16) instead of the one-wave-per-row kernel
+ * (k_edge_rows); 11..13 = as 0 with 1..3 row tiles per wave forced in the node halves -- both bit-identical to 0 (tests, A/B timing). */
 int ps_set_row_impl(ps_engine* e, int32_t impl);
 /* Nodes (kernel launches and copies) of the captured rollout graph; 0 before the first ps_rollout or when the rollout runs eagerly. */
 int64_t ps_graph_nodes(ps_engine* e);

@@ -27,7 +27,7 @@ static thread_local std::string g_err;
 // (-DPS_EXPERIMENTS: tools/README.md).  The product library compiles them out -- a stray PS_* variable cannot change which kernel
 // runs or corrupt a rollout -- and says so once, loudly, when it finds one set.
 static const char* const kExpEnv[] = {"PS_C16_ABL", "PS_XCD", "PS_CHAIN_T", "PS_CHAIN_TP", "PS_CHAIN_T1", "PS_CHAIN_FLAGS", "PS_CHAIN_PROF",
-                                      "PS_C16_ROWS", "PS_S2S_C16", "PS_NO_SPLIT", "PS_SPLIT_MIN", "PS_SKIP_S2S_EDGE"};
+                                      "PS_C16_ROWS", "PS_S2S_C16", "PS_NO_SPLIT", "PS_SPLIT_MIN", "PS_SKIP_S2S_EDGE", "PS_POL_EDGE_PROBE"};
 #ifdef PS_EXPERIMENTS
 static const char* exp_env(const char* name) { return getenv(name); }
 #else
@@ -191,6 +191,7 @@ struct ps_engine {
   hipGraph_t graph = nullptr;
   hipGraphExec_t graph_exec = nullptr;
   int node_mt = 0;            // ps_set_row_impl(10 + mt): row tiles per wave of the row-tile node kernels forced to mt (experiments, tests)
+  bool wg_edges = false;      // ps_set_row_impl(2): the split path's edge half on the 16-row workgroup kernel (k_edge16) instead of k_edge_rows (A/B, cross-check)
   bool legacy_rows = false;   // ps_set_row_impl(1): the round-3 staged row kernels (k_pointnet_mfma, k_node) instead of the row-tile ones (A/B and parity tools)
   int chain_rows = 0;   // ps_set_chain_rows: 0 = latency-optimal choice, else rows per workgroup of the fused attention launches
   int chain_impl = 0;   // ps_set_chain_impl: 0 = by mode (k_chain16 in throughput mode: chain_rows >= 8; k_attn_chain otherwise), 1 = k_attn_chain, 2 = k_chain16, 3 = k_chain16 + the encoder's s2s layers on it
@@ -771,6 +772,7 @@ extern "C" int ps_create(const ps_config* cfg, int32_t n_tensors, const char* co
   PS_RT_ATTR((k_pointnet_rt<5, 4>));
   PS_RT_ATTR(k_node_pre_rt<1>); PS_RT_ATTR(k_node_pre_rt<2>); PS_RT_ATTR(k_node_pre_rt<3>);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_edge16), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c16_edge_lds_bytes());
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_edge_rows), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ER_LDS_BYTES);
   PS_RT_ATTR(k_policy_head_rt);
   PS_RT_ATTR(k_node_post_rt<1>); PS_RT_ATTR(k_node_post_rt<2>); PS_RT_ATTR(k_node_post_rt<3>);
 #undef PS_RT_ATTR
@@ -1542,6 +1544,7 @@ int io_for(ps_engine* e, int Nd, EdgeIO& io) {
 // One attention layer as three launches: k_node PRE (+ the rows' own k | v when kv_out is given: self-attention),
 // k_edge_small (degree <= ES_MAXDEG), k_node POST.  `stp` is a device pointer to the layer's ChainStep.
 // geo_edges: the edge half on k_edge16 (geometry records, ps_chain16.h) instead of k_edge_small (rel-PE operand images).
+static bool xcd_on(int bit, bool dflt);
 bool split_uses_rt(const ps_engine* e, int Nd, int kr) {   // the row-tile node halves (and with them the geometry-record edge kernel)
   return kr == 3 && !e->legacy_rows && ((Nd + 15) / 16 >= 256 || e->node_mt);
 }
@@ -1568,7 +1571,8 @@ int launch_split_layer(ps_engine* e, float* x, int Nd, const ChainStep* stp, int
     else hipLaunchKernelGGL(k_node_pre_rt<3>, gr, dim3(256), RT_LDS_BYTES, st, (const float*)x, Nd, stp, io, eps, kv_out, khl_out);
     static const bool skip_edge = exp_env("PS_SKIP_S2S_EDGE") != nullptr;   // experiments only (timing; wrong results)
     if (skip_edge) {}
-    else if (geo_edges) hipLaunchKernelGGL(k_edge16, dim3((unsigned)tiles), dim3(512), c16_edge_lds_bytes(), st, Nd, stp, io, (const float*)e->div32);
+    else if (geo_edges && e->wg_edges) hipLaunchKernelGGL(k_edge16, dim3((unsigned)tiles), dim3(512), c16_edge_lds_bytes(), st, Nd, stp, io, (const float*)e->div32);
+    else if (geo_edges) hipLaunchKernelGGL(k_edge_rows, dim3((unsigned)((Nd + ER_WAVES - 1) / ER_WAVES)), dim3(64 * ER_WAVES), ER_LDS_BYTES, st, Nd, stp, io, (const float*)e->div32, xcd_on(3, true) ? 1 : 0);
     else if (maxdeg <= 32) hipLaunchKernelGGL((k_edge_small<3, 2>), ge, dim3(256), es_lds_bytes<2>(), st, Nd, stp, io);
     else hipLaunchKernelGGL((k_edge_small<3, 8>), ge, dim3(256), es_lds_bytes<8>(), st, Nd, stp, io);
     if (mt == 1) hipLaunchKernelGGL(k_node_post_rt<1>, gr, dim3(256), RT_LDS_BYTES, st, x, Nd, stp, io, eps);
@@ -1587,7 +1591,7 @@ int launch_split_layer(ps_engine* e, float* x, int Nd, const ChainStep* stp, int
   return hipGetLastError() == hipSuccess ? 0 : fail(PS_E_HIP, "split layer launch failed");
 }
 
-// which launches use the XCD-aware mapping (PS_XCD overrides for experiments: bit0 policy, bit1 a2a, bit2 generator)
+// which launches use the XCD-aware mapping (PS_XCD overrides for experiments: bit0 policy, bit1 a2a, bit2 generator, bit3 s2s)
 static bool xcd_on(int bit, bool dflt) {
   static const int env = exp_env("PS_XCD") ? atoi(exp_env("PS_XCD")) : -1;
   return env < 0 ? dflt : ((env >> bit) & 1) != 0;
@@ -1959,7 +1963,7 @@ extern "C" int ps_encode_scene(ps_engine* e) {
     } else if (launch_chain(e, tok + (size_t)Mv * D, Ap, e->step_a2a + i, 1, e->e_a2a.maxdeg, false, nullptr, 0, 0, nullptr, xcd_on(1, false))) return PS_E_HIP;
     if (s2s_c16) {
       launch_kv(e, tok, Mv + Ap, e->L_s2s + i, 1, e->d_kv.p, e->d_kh.p, 0);
-      if (launch_chain16(e, tok, Mv + Ap, e->d_steps.p + e->step_s2s + i, 1, false, nullptr, false)) return PS_E_HIP;
+      if (launch_chain16(e, tok, Mv + Ap, e->d_steps.p + e->step_s2s + i, 1, false, nullptr, xcd_on(3, true))) return PS_E_HIP;
     } else if (split_s2s) {
       // split layer: node work as 16-row MFMA GEMMs (k_node; its PRE half also makes the rows'
       // k | v, they are this self-attention layer's sources), the 32-neighbour edge phase one wave per token
@@ -2152,6 +2156,15 @@ extern "C" int ps_policy_step(ps_engine* e, int32_t t_idx) {
     if (launch_chain16(e, e->d_fused.p, A, e->d_steps.p + e->step_pol, 2 * c.pol_layers, true, e->d_emd.p, xcd_on(0, true))) return PS_E_HIP;
   } else if (launch_chain(e, e->d_fused.p, A, e->step_pol, 2 * c.pol_layers, md, true, nullptr, 0, 0, e->d_emd.p, xcd_on(0, true))) return PS_E_HIP;
   if (e->policy_events && (int)e->pev.size() >= 2 * R) HIPCHK(hipEventRecord(e->pev[2 * t_idx + 1], st));
+  {
+    static const bool probe = exp_env("PS_POL_EDGE_PROBE") != nullptr;   // experiments only (timing: what the many-waves edge kernel needs for one a2p + m2p layer pair)
+    if (probe && use_c16(e, A, 2)) {
+      EdgeIO io{};
+      if (io_for(e, A, io)) return PS_E_HIP;
+      for (int k = 0; k < 2; ++k)
+        hipLaunchKernelGGL(k_edge_rows, dim3((unsigned)((A + ER_WAVES - 1) / ER_WAVES)), dim3(64 * ER_WAVES), ER_LDS_BYTES, st, A, e->d_steps.p + e->step_pol + k, io, (const float*)e->div32, 1);
+    }
+  }
   // _compute_traj + step_agent_traj
   {
     float* mp_out = e->d_motion.p + (size_t)t_idx * A * c.motion_k * c.target_steps * c.state_dim;
@@ -2331,10 +2344,11 @@ extern "C" int ps_set_chain_impl(ps_engine* e, int32_t impl) {
 
 extern "C" int ps_set_row_impl(ps_engine* e, int32_t impl) {
   if (!e) return fail(PS_E_ARG, "null engine");
-  if (impl != 0 && impl != 1 && !(impl >= 11 && impl <= 13))
-    return fail(PS_E_ARG, "ps_set_row_impl: 0 = row-tile kernels (default), 1 = the round-3 staged kernels, 11..13 = row-tile kernels with 1..3 row tiles per wave in the node halves");
+  if (impl != 0 && impl != 1 && impl != 2 && !(impl >= 11 && impl <= 13))
+    return fail(PS_E_ARG, "ps_set_row_impl: 0 = row-tile kernels (default), 1 = the round-3 staged kernels, 2 = row-tile kernels with the workgroup edge kernel, 11..13 = row-tile kernels with 1..3 row tiles per wave in the node halves");
   drop_graph(e);
   e->legacy_rows = impl == 1;
+  e->wg_edges = impl == 2;
   e->node_mt = impl >= 11 ? impl - 10 : 0;
   return PS_OK;
 }

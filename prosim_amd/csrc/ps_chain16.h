@@ -267,9 +267,16 @@ __device__ __forceinline__ int c16_av_row(int lr, int part, int W) { return W ==
 // and its order -- is the round-2 kernel's: results are bit-identical to it.
 // (TAG: a second, independent copy of the function for the standalone edge kernel k_edge16 -- as a second CALLER of one copy it cost
 // the policy chain 9 %: the inter-procedural register allocation is per function)
-template <int NWV, bool ONEW, int TAG = 0>
-__device__ __noinline__ void c16_edge_phase(const ChainStep* __restrict__ stp, unsigned char* c16_smem, float* AG,
-                                            const float* CQ, int* ctr, float* QA, const float* __restrict__ div32, int row0, int nrows, int W) {
+// (DIRECT: the standalone many-waves form, k_edge_rows below -- a wave takes row row0 + wave, reads q / q~ / <q, kb> straight from the
+// PRE half's EdgeIO rows and writes its sums there; the even tiles' a_r park in a wave-private LDS slot behind the wave area.  Same
+// operations in the same order: the results are those of the workgroup form bit for bit.)
+constexpr size_t C16_PARK_BYTES = (size_t)8 * C16_QH * 4;
+template <int NWV, bool ONEW, bool DIRECT>
+__device__ __forceinline__ void c16_edge_body(const ChainStep* __restrict__ stp, unsigned char* c16_smem, float* AG,
+                                             const float* CQ, int* ctr, float* QA, const float* __restrict__ div32, int row0, int nrows, int W,
+                                             const EdgeIO& io) {
+  static_assert(!DIRECT || ONEW, "the standalone form is one wave per row");
+  constexpr size_t WSTRIDE = C16_WAVE_BYTES + (DIRECT ? C16_PARK_BYTES : 0);
   const ChainStep& st = *stp;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -281,7 +288,7 @@ __device__ __noinline__ void c16_edge_phase(const ChainStep* __restrict__ stp, u
     dv[j] = ldg1(div32 + 2 * (4 * kq + j));
     rdv[j] = 1.0f / dv[j];
   }
-  unsigned char* wbase = c16_smem + (size_t)wave * C16_WAVE_BYTES;
+  unsigned char* wbase = c16_smem + (size_t)wave * WSTRIDE;
   const half8* stg = reinterpret_cast<const half8*>(wbase);                    // k staging: [16 rows][16 slots of 16 B], hi or lo halves
   float* Pt = reinterpret_cast<float*>(wbase + 4096);                         // [16 edges][8 heads] probabilities (for a_v)
   _Float16* Ft = reinterpret_cast<_Float16*>(wbase + 4096 + 512);             // [16 edges][C16_FS] feature tile (hi, then lo)
@@ -298,7 +305,11 @@ __device__ __noinline__ void c16_edge_phase(const ChainStep* __restrict__ stp, u
   const int hv = (lane & 31) >> 2, eh = lane >> 5;
   for (int it = 0;; ++it) {
     int lr, part;
-    if (W > 1) {   // static: wave -> (row wave / W, part wave % W)
+    if (DIRECT) {  // static: one row per wave
+      if (it > 0) break;
+      lr = wave;
+      part = 0;
+    } else if (W > 1) {   // static: wave -> (row wave / W, part wave % W)
       if (it > 0) break;
       lr = wave / W;
       part = wave - lr * W;
@@ -312,6 +323,7 @@ __device__ __noinline__ void c16_edge_phase(const ChainStep* __restrict__ stp, u
     }
     if (lr >= nrows) break;
     const int r = row0 + lr;
+    float* park = DIRECT ? reinterpret_cast<float*>(wbase + C16_WAVE_BYTES) : QA + lr * C16_QSL;   // the even tiles' a_r (ONEW)
     const int e_beg = __builtin_amdgcn_readfirstlane(ldgi(st.eoff + r));   // (wave-uniform: the tile loop's control stays on the scalar unit)
     const int deg = __builtin_amdgcn_readfirstlane(ldgi(st.eoff + r + 1)) - e_beg;
     const int tstep = ONEW ? 32 : 16 * W;
@@ -336,8 +348,8 @@ __device__ __noinline__ void c16_edge_phase(const ChainStep* __restrict__ stp, u
     float cqm;
     {
       const int hB = mi & 7;
-      const float* qtp = QA + ((W == 1 ? 0 : 8) + lr) * C16_QSL + hB * C16_QH + 8 * kq;
-      const float* qp = AG + lr * ND_XS + 8 * kq;
+      const float* qtp = DIRECT ? io.qt + (size_t)r * 1024 + hB * 128 + 8 * kq : QA + ((W == 1 ? 0 : 8) + lr) * C16_QSL + hB * C16_QH + 8 * kq;
+      const float* qp = DIRECT ? io.q + (size_t)r * 128 + 8 * kq : AG + lr * ND_XS + 8 * kq;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         if (ks < 3) {
@@ -355,7 +367,7 @@ __device__ __noinline__ void c16_edge_phase(const ChainStep* __restrict__ stp, u
           bk[ks][j] = loA ? f16_lo(kk) : f16_hi(kk);
         }
       }
-      cqm = CQ[lr * 8 + hB];
+      cqm = DIRECT ? io.cq[(size_t)r * 8 + hB] : CQ[lr * 8 + hB];
     }
     float m_run = -INFINITY, l_run = 0.f;   // of head mi & 7 (the lanes mi and mi + 8, all kq, carry copies)
     floatx4 ar[6];
@@ -549,7 +561,7 @@ __device__ __noinline__ void c16_edge_phase(const ChainStep* __restrict__ stp, u
 #pragma unroll
           for (int r4 = 0; r4 < 4; ++r4) {
             const float v = swap_add32(ar[cb][r4], ar[cb + 1][r4]);
-            QA[lr * C16_QSL + (4 * ((lane >> 4) & 1) + r4) * C16_QH + (cb + (lane >> 5)) * 16 + (lane & 15)] = v;
+            park[(4 * ((lane >> 4) & 1) + r4) * C16_QH + (cb + (lane >> 5)) * 16 + (lane & 15)] = v;
           }
         }
         m_run = -INFINITY;
@@ -561,7 +573,10 @@ __device__ __noinline__ void c16_edge_phase(const ChainStep* __restrict__ stp, u
     }
     // ---- the row's (partial) sums wait in LDS for the POST half
     const int aslot = W == 1 ? lr : lr * W + part;
-    float* avrow = AG + c16_av_row(lr, part, W) * ND_XS;
+    float* avrow = DIRECT ? io.av + (size_t)r * 128 : AG + c16_av_row(lr, part, W) * ND_XS;
+    float* oar = DIRECT ? io.ar + (size_t)r * 1024 : QA + aslot * C16_QSL;   // [8 heads][oh]: the row's a_r
+    const int oh = DIRECT ? 128 : C16_QH;
+    float* ol = DIRECT ? io.l + (size_t)r * 8 : nullptr;
     av.x += __shfl_xor(av.x, 32); av.y += __shfl_xor(av.y, 32); av.z += __shfl_xor(av.z, 32); av.w += __shfl_xor(av.w, 32);
     if (ONEW && two) {   // merge (even, odd) with the operations of the POST half's merge of two waves' partials
       const float m0 = stash[128 + 2 * (lane & 7)], l0 = stash[128 + 2 * (lane & 7) + 1];   // head lane & 7
@@ -574,7 +589,7 @@ __device__ __noinline__ void c16_edge_phase(const ChainStep* __restrict__ stp, u
       float lm = 0.f;
       lm = fmaf(l0, sc0, lm);
       lm = fmaf(lh, sc1, lm);
-      if (lane < 8) QA[aslot * C16_QSL + lane * C16_QH + 96] = lm;
+      if (lane < 8) { if (DIRECT) ol[lane] = lm; else QA[aslot * C16_QSL + lane * C16_QH + 96] = lm; }
       {
         const float s0 = __shfl(sc0, hv), s1 = __shfl(sc1, hv);   // a_v columns 4 (lane & 31) ..+3 belong to head hv
         if (lane < 32) {
@@ -592,16 +607,16 @@ __device__ __noinline__ void c16_edge_phase(const ChainStep* __restrict__ stp, u
 #pragma unroll
         for (int cb = 0; cb < 6; cb += 2) {
           const float v1 = swap_add32(ar[cb][r4], ar[cb + 1][r4]);
-          float* qp_ = QA + lr * C16_QSL + hh * C16_QH + (cb + (lane >> 5)) * 16 + (lane & 15);
+          const int col = (cb + (lane >> 5)) * 16 + (lane & 15);
           float o = 0.f;
-          o = fmaf(*qp_, s0, o);
+          o = fmaf(park[hh * C16_QH + col], s0, o);
           o = fmaf(v1, s1, o);
-          *qp_ = o;
+          oar[hh * oh + col] = o;
         }
       }
     } else {
       if (lane < 8) {   // lane h (mi = h, kq = 0) holds head h
-        QA[aslot * C16_QSL + lane * C16_QH + 96] = l_run;
+        if (DIRECT) ol[lane] = l_run; else QA[aslot * C16_QSL + lane * C16_QH + 96] = l_run;
         if (W > 1) QA[aslot * C16_QSL + lane * C16_QH + 97] = m_run;
       }
       if (lane < 32) *reinterpret_cast<float4*>(avrow + 4 * lane) = av;
@@ -611,11 +626,17 @@ __device__ __noinline__ void c16_edge_phase(const ChainStep* __restrict__ stp, u
 #pragma unroll
         for (int r4 = 0; r4 < 4; ++r4) {
           const float v = swap_add32(ar[cb][r4], ar[cb + 1][r4]);   // lanes < 32: block cb, lanes >= 32: block cb + 1
-          QA[aslot * C16_QSL + (4 * ((lane >> 4) & 1) + r4) * C16_QH + (cb + (lane >> 5)) * 16 + (lane & 15)] = v;
+          oar[(4 * ((lane >> 4) & 1) + r4) * oh + (cb + (lane >> 5)) * 16 + (lane & 15)] = v;
         }
       }
     }
   }
+}
+template <int NWV, bool ONEW, int TAG = 0>
+__device__ __noinline__ void c16_edge_phase(const ChainStep* __restrict__ stp, unsigned char* c16_smem, float* AG,
+                                            const float* CQ, int* ctr, float* QA, const float* __restrict__ div32, int row0, int nrows, int W) {
+  const EdgeIO none{};
+  c16_edge_body<NWV, ONEW, false>(stp, c16_smem, AG, CQ, ctr, QA, div32, row0, nrows, W, none);
 }
 
 // phase clocks of the node phases (tools only: build with -DPS_C16_PROF and run with PS_CHAIN_PROF=1; compiled out of the
@@ -1054,6 +1075,20 @@ __global__ __launch_bounds__(512, 1) __attribute__((disable_tail_calls)) void k_
     if (r < nrows) *reinterpret_cast<float4*>(io.av + (size_t)(row0 + r) * 128 + c) = *reinterpret_cast<const float4*>(AG + r * ND_XS + c);
   }
   if (tid < 128 && (tid >> 3) < nrows) io.l[(size_t)row0 * 8 + tid] = QA[(tid >> 3) * C16_QSL + (tid & 7) * C16_QH + 96];
+}
+
+
+// The edge phase with NO workgroup structure (round 4): one wave per destination row, four waves per workgroup, three workgroups per CU
+// (168 registers, 47 KB of LDS each) -- nothing is staged by the workgroup, there is no barrier and no row queue; a wave's latency chain
+// (records -> source rows -> k rows -> scores) is covered by the eleven other waves of its CU instead of by the row's next tile, which
+// is what the short rows of the scene encoder (two tiles) lack in the 16-row workgroup form.
+constexpr int ER_WAVES = 4;
+constexpr size_t ER_LDS_BYTES = ER_WAVES * (C16_WAVE_BYTES + C16_PARK_BYTES);
+__global__ __launch_bounds__(64 * ER_WAVES, 3) __attribute__((disable_tail_calls)) void k_edge_rows(int Nd, const ChainStep* __restrict__ step, EdgeIO io,
+                                                                                                   const float* __restrict__ div32, int xcd) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char c16_smem[];
+  const int row0 = xcd_block(blockIdx.x, gridDim.x, !xcd) * ER_WAVES;   // (rows are ordered by scene: an XCD's L2 holds the k | v rows of ~ 1/8 of the scenes)
+  c16_edge_body<ER_WAVES, true, true>(step, c16_smem, nullptr, nullptr, nullptr, nullptr, div32, row0, min(ER_WAVES, Nd - row0), 1, io);
 }
 
 }  // namespace ps

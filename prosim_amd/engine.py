@@ -416,7 +416,8 @@ class Engine:
         return int(self.lib.ps_graph_nodes(self.h))
 
     def set_row_impl(self, impl: int):
-        """0: the row-tile kernels (default); 1: the staged row kernels of rounds 1-3 (cross-checks, A/B measurements)."""
+        """0: the row-tile kernels (default); 1: the staged row kernels of rounds 1-3 (cross-checks, A/B measurements); 2: as 0 with
+        the workgroup edge kernel (k_edge16) in the split layers; 11..13: as 0 with 1..3 row tiles per wave forced (2, 11..13: same bits as 0)."""
         self._check(self.lib.ps_set_row_impl(self.h, impl))
 
     @property

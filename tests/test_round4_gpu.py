@@ -74,8 +74,10 @@ def test_row_tile_pointnet_equals_the_staged_kernel_for_every_tiling():
 
 @pytest.mark.parametrize("rows", [0, 16])
 def test_row_impls_agree_on_the_benchmark_batch(rows):
-    """ps_set_row_impl 0 (row-tile kernels, k_edge16 behind them in the split path) / 11..13 (forced tiles per wave) against 1 (the
-    staged kernels of rounds 1-3) on the 8-scene benchmark batch: scene tokens to 2e-5, the closed loop to 1e-4."""
+    """ps_set_row_impl 0 (row-tile kernels, k_edge_rows behind them in the split path) against 1 (the staged kernels of rounds 1-3) on
+    the 8-scene benchmark batch: scene tokens to 2e-5, the closed loop to 1e-4; and 2 (the 16-row workgroup edge kernel k_edge16) /
+    11..13 (forced row tiles per wave in the node halves) against 0 BIT FOR BIT -- a row's result depends neither on the tiling of the
+    node GEMMs nor on which form of the edge phase walked its edges."""
     from prosim_amd.engine import Engine
     spec = DEMO_SPEC
     w = weights.init_weights(spec, 0)
@@ -84,8 +86,8 @@ def test_row_impls_agree_on_the_benchmark_batch(rows):
                  {ck: {f: np.concatenate([p[k][ck][f] for p in parts]) for f in parts[0][k][ck]} for ck in parts[0][k]}) for k in parts[0]}
     eng = Engine(spec, w)
     try:
-        ref = None
-        for impl in (1, 0, 11, 12, 13):
+        ref = exact = None
+        for impl in (1, 0, 2, 11, 12, 13):
             eng.set_row_impl(impl)
             eng.set_chain_impl(2)            # (k_chain16 with the SPLIT s2s path in either mode: the node halves + edge kernel under test)
             eng.set_chain_rows(rows)
@@ -96,5 +98,9 @@ def test_row_impls_agree_on_the_benchmark_batch(rows):
             if ref is None:
                 ref = (tok, traj)
             assert err(tok, ref[0]) < 2e-5 and err(traj, ref[1]) < TOL, (impl, err(tok, ref[0]), err(traj, ref[1]))
+            if impl == 0:
+                exact = (tok, traj)
+            elif impl != 1:
+                assert np.array_equal(tok, exact[0]) and np.array_equal(traj, exact[1]), (impl, err(tok, exact[0]), err(traj, exact[1]))
     finally:
         eng.close()

@@ -11,7 +11,7 @@ for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY" \
            "SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_REQ SQ_IFETCH" \
            "SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAIT_INST_LDS SQ_ACTIVE_INST_SCA" \
            "GRBM_GUI_ACTIVE" "TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum"; do
-  rm -rf /tmp/prof_p && env "$@" rocprofv3 --kernel-trace --pmc $grp -d /tmp/prof_p -o p -- python tools/gpu_rt_prof.py > /tmp/prof_p.log 2>&1
+  rm -rf /tmp/prof_p && env "$@" rocprofv3 --kernel-trace --pmc $grp -d /tmp/prof_p -o p -- python ${PS_PMC_SCRIPT:-tools/gpu_rt_prof.py} > /tmp/prof_p.log 2>&1
   python - "$(find /tmp/prof_p -name '*.db' | head -1)" "$KL" >> $OUT <<'PY'
 import sqlite3, sys
 db = sqlite3.connect(sys.argv[1])
