@@ -1992,8 +1992,9 @@ extern "C" int ps_generate_policy(ps_engine* e) {
   const int Ap = e->Ap;   // rows the generator computes (== A without replicas)
   hipStream_t st = e->stream;
   // prompt encoder (prompt_encoder/base.py:36-46)
-  hipLaunchKernelGGL(k_mlp_rows, dim3(Ap), dim3(128), 0, st, e->mlp_prompt, (const float*)e->d_prompt.p, (const int*)e->d_agent_rows.p,
-                     c.prompt_dim, e->d_xp.p, D, c.ln_eps);
+  const dim3 gmlp((unsigned)((Ap + MLP_R - 1) / MLP_R));
+  hipLaunchKernelGGL(k_mlp_rows, gmlp, dim3(128), 0, st, e->mlp_prompt, (const float*)e->d_prompt.p, (const int*)e->d_agent_rows.p,
+                     c.prompt_dim, e->d_xp.p, D, c.ln_eps, Ap);
   // prompt poses (== the observed poses in the reference's batches; kept separate for generality)
   const float* ppos = e->d_prompt_pos.p;
   const float* pori = e->d_prompt_ori.p;
@@ -2023,10 +2024,10 @@ extern "C" int ps_generate_policy(ps_engine* e) {
   }
   HIPCHK(hipMemcpyAsync(e->d_emd.p, e->d_xp.p, sizeof(float) * (size_t)Ap * D, hipMemcpyDeviceToDevice, st));
   if (c.goal_pred_k > 0) {   // Decoder._goal_pred on the decoder's embedding (decoder/base.py:22-58, sym_coord.py:133-136)
-    hipLaunchKernelGGL(k_mlp_rows, dim3(Ap), dim3(128), 0, st, e->mlp_goal_prob, (const float*)e->d_xp.p, (const int*)nullptr, D,
-                       e->d_goal_prob.p, c.goal_pred_k, c.ln_eps);
-    hipLaunchKernelGGL(k_mlp_rows, dim3(Ap), dim3(128), 0, st, e->mlp_goal_point, (const float*)e->d_xp.p, (const int*)nullptr, D,
-                       e->d_goal_point.p, 2 * c.goal_pred_k, c.ln_eps);
+    hipLaunchKernelGGL(k_mlp_rows, gmlp, dim3(128), 0, st, e->mlp_goal_prob, (const float*)e->d_xp.p, (const int*)nullptr, D,
+                       e->d_goal_prob.p, c.goal_pred_k, c.ln_eps, Ap);
+    hipLaunchKernelGGL(k_mlp_rows, gmlp, dim3(128), 0, st, e->mlp_goal_point, (const float*)e->d_xp.p, (const int*)nullptr, D,
+                       e->d_goal_point.p, 2 * c.goal_pred_k, c.ln_eps, Ap);
   }
   // condition transformer at 'policy_decoder' (traj_sam.py:129-137)
   if (e->have_cond && c.cond_layers > 0) {
@@ -2048,8 +2049,8 @@ extern "C" int ps_generate_policy(ps_engine* e) {
   }
   // reconst_pred = pred_mlp(policy_emd) (act_decoder.py:133-135) -- constant over the replans
   if (!c.no_reconst_pred)   // (USE_GOAL_PRED_LOSS)
-    hipLaunchKernelGGL(k_mlp_rows, dim3(Ap), dim3(128), 0, st, e->mlp_pred, (const float*)e->d_emd.p, (const int*)nullptr, D,
-                       e->d_reconst.p, 2, c.ln_eps);
+    hipLaunchKernelGGL(k_mlp_rows, gmlp, dim3(128), 0, st, e->mlp_pred, (const float*)e->d_emd.p, (const int*)nullptr, D,
+                       e->d_reconst.p, 2, c.ln_eps, Ap);
   if (e->replicas > 1) {   // the replicas share the prompts' embeddings (gpu_utils.py:73-82): fan the Ap computed rows out
     auto fan = [&](float* p, int w) {
       hipLaunchKernelGGL(k_fan_out_rows, dim3(std::min(2048, (A - Ap) * std::max(w / 4, 1) / 256 + 1)), dim3(256), 0, st, p, Ap, A, w);

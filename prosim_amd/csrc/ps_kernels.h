@@ -483,16 +483,19 @@ __global__ void k_knn(CandSet cs, const float* __restrict__ qpos, const int* __r
     const unsigned trial = vk | (1u << bit);
     int c = 0;
 #pragma unroll
-    for (int s = 0; s < KNN_SLOTS; ++s) c += __popcll(__ballot(key[s] < trial));
+    for (int s = 0; s < KNN_SLOTS; ++s)
+      if (s * 64 < n) c += __popcll(__ballot(key[s] < trial));   // (wave-uniform guard: slots past the scene's candidates hold padding)
     if (c < kk_) vk = trial;
   }
   int c_lt = 0;
 #pragma unroll
-  for (int s = 0; s < KNN_SLOTS; ++s) c_lt += __popcll(__ballot(key[s] < vk));
+  for (int s = 0; s < KNN_SLOTS; ++s)
+    if (s * 64 < n) c_lt += __popcll(__ballot(key[s] < vk));
   int ties_left = kk_ - c_lt;   // how many keys == v_k still go out, in index order
   int out = eoff[q];
 #pragma unroll
   for (int s = 0; s < KNN_SLOTS; ++s) {
+    if (s * 64 >= n) continue;
     const int j = s * 64 + lane;
     const bool lt = key[s] < vk, eq = key[s] == vk && j < n && key[s] != 0xffffffffu;
     const unsigned long long meq = __ballot(eq);
@@ -564,15 +567,18 @@ __global__ void k_knn_sets(RadSets sets, const float* __restrict__ qpos, const i
     const unsigned trial = vk | (1u << bit);
     int c = 0;
 #pragma unroll
-    for (int s = 0; s < KNN_SLOTS; ++s) c += __popcll(__ballot(key[s] < trial));
+    for (int s = 0; s < KNN_SLOTS; ++s)
+      if (s * 64 < n) c += __popcll(__ballot(key[s] < trial));
     if (c < kk_) vk = trial;
   }
   int c_lt = 0;
 #pragma unroll
-  for (int s = 0; s < KNN_SLOTS; ++s) c_lt += __popcll(__ballot(key[s] < vk));
+  for (int s = 0; s < KNN_SLOTS; ++s)
+    if (s * 64 < n) c_lt += __popcll(__ballot(key[s] < vk));
   int ties_left = kk_ - c_lt;
 #pragma unroll
   for (int s = 0; s < KNN_SLOTS; ++s) {
+    if (s * 64 >= n) continue;
     const int j = s * 64 + lane;
     const int i = j < n1 ? b1 + j : b2 + (j - n1);
     const bool lt = key[s] < vk, eq = key[s] == vk && j < n && key[s] != 0xffffffffu;
@@ -762,14 +768,60 @@ __device__ __forceinline__ void mlp3_rows1(const Mlp3W& m, float* bufA, float* b
   }
 }
 
+// MLP_R rows per workgroup (round 4; one row per workgroup before): thread n still owns output n and walks k in order -- per row the
+// same fma chain, the same LayerNorm reduction (one wave per row), so the results are bit-identical -- but a weight element is loaded
+// once for MLP_R rows instead of once per row (1024 prompt rows: 34 -> 24 us; staging the weights through LDS as well was slower: the loop is bound by its LDS reads of the rows).  n_rows: rows of `out`; dims <= 128.
+constexpr int MLP_R = 8;
 __global__ __launch_bounds__(128) void k_mlp_rows(Mlp3W m, const float* __restrict__ in, const int* __restrict__ rows,
-                                                  int in_stride, float* __restrict__ out, int out_stride, float eps) {
-  __shared__ float a[128], b[128];
-  const int r = rows ? rows[blockIdx.x] : blockIdx.x;
-  for (int i = threadIdx.x; i < m.dims[0]; i += blockDim.x) a[i] = in[(size_t)r * in_stride + i];
+                                                  int in_stride, float* __restrict__ out, int out_stride, float eps, int n_rows) {
+  __shared__ float a[MLP_R][128], b[MLP_R][128];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int row0 = blockIdx.x * MLP_R, nr = min(MLP_R, n_rows - row0);
+  for (int r = 0; r < MLP_R; ++r) {
+    const int src = r < nr ? (rows ? rows[row0 + r] : row0 + r) : 0;
+    for (int i = tid; i < m.dims[0]; i += 128) a[r][i] = r < nr ? in[(size_t)src * in_stride + i] : 0.f;
+  }
   __syncthreads();
-  mlp3_rows1(m, a, b, eps);
-  for (int i = threadIdx.x; i < m.dims[m.n]; i += blockDim.x) out[(size_t)blockIdx.x * out_stride + i] = a[i];
+  for (int l = 0; l < m.n; ++l) {
+    const int K = m.dims[l], N = m.dims[l + 1];
+    for (int n = tid; n < N; n += 128) {
+      float s[MLP_R];
+      const float b0 = m.b[l] ? m.b[l][n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < MLP_R; ++r) s[r] = b0;
+      const float* __restrict__ wr = m.W[l] + (size_t)n * K;
+      for (int k = 0; k < K; ++k) {
+        const float w = wr[k];
+#pragma unroll
+        for (int r = 0; r < MLP_R; ++r) s[r] = fmaf(a[r][k], w, s[r]);
+      }
+#pragma unroll
+      for (int r = 0; r < MLP_R; ++r) b[r][n] = s[r];
+    }
+    __syncthreads();
+    if (l < m.n - 1) {
+      if (m.lnw[l]) {   // LayerNorm over N (64 or 128) features, one wave per row
+        for (int r = wave; r < MLP_R; r += 2) {
+          float a0 = lane < N ? b[r][lane] : 0.f, a1 = (lane + 64) < N ? b[r][lane + 64] : 0.f;
+          const float mean = wave_sum(a0 + a1) / (float)N;
+          const float d0 = lane < N ? a0 - mean : 0.f, d1 = (lane + 64) < N ? a1 - mean : 0.f;
+          const float var = wave_sum(d0 * d0 + d1 * d1) / (float)N;
+          const float rstd = 1.f / sqrtf(var + eps);
+          if (lane < N) b[r][lane] = fmaxf(fmaf(d0 * rstd, m.lnw[l][lane], m.lnb[l][lane]), 0.f);
+          if (lane + 64 < N) b[r][lane + 64] = fmaxf(fmaf(d1 * rstd, m.lnw[l][lane + 64], m.lnb[l][lane + 64]), 0.f);
+        }
+      } else {
+        for (int r = 0; r < MLP_R; ++r)
+          for (int i = tid; i < N; i += 128) b[r][i] = fmaxf(b[r][i], 0.f);
+      }
+      __syncthreads();
+    }
+    for (int r = 0; r < MLP_R; ++r)
+      for (int i = tid; i < N; i += 128) a[r][i] = b[r][i];
+    __syncthreads();
+  }
+  for (int r = 0; r < nr; ++r)
+    for (int i = tid; i < m.dims[m.n]; i += 128) out[(size_t)(row0 + r) * out_stride + i] = a[r][i];
 }
 
 // _autoregressive_obs_fusion (attn_fusion.py:175-203, MODEL.OBS_UPDATE.FUSION 'mlp'): the agent token of this replan =
