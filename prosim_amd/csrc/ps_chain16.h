@@ -822,7 +822,8 @@ __device__ __noinline__ void c16_node_phase(const ChainStep* __restrict__ post, 
             u[i] = agg[i] + g * (sv[i] - agg[i]);
           }
         }
-        __syncthreads();   // every thread has read its gate columns of C and P0 is no longer an operand
+        // (no barrier between the gate and the store: the barrier behind the Fga GEMM already retired P0 as an operand, and C is
+        // not written again before the one below)
       C16_MARK(19);
         if (epi) planes_store8(P0h + er * ND_AS + ec, P0l + er * ND_AS + ec, u);
       }
@@ -845,7 +846,7 @@ __device__ __noinline__ void c16_node_phase(const ChainStep* __restrict__ post, 
           }
           row16_ln(xv, sp + SP_LN_FFPRE_W, sp + SP_LN_FFPRE_B, ec, eps);
         }
-        __syncthreads();
+        // (no barrier here either: P0 retired with the barrier behind the Fout GEMM; X is read and written by its own thread)
       C16_MARK(22);
         if (epi) planes_store8(P0h + er * ND_AS + ec, P0l + er * ND_AS + ec, xv);
       }
