@@ -351,21 +351,25 @@ __device__ __forceinline__ void c16_edge_body(const ChainStep* __restrict__ stp,
       const float* qtp = DIRECT ? io.qt + (size_t)r * 1024 + hB * 128 + 8 * kq : QA + ((W == 1 ? 0 : 8) + lr) * C16_QSL + hB * C16_QH + 8 * kq;
       const float* qp = DIRECT ? io.q + (size_t)r * 128 + 8 * kq : AG + lr * ND_XS + 8 * kq;
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        if (ks < 3) {
-          const float4 v0 = *reinterpret_cast<const float4*>(qtp + 32 * ks), v1 = *reinterpret_cast<const float4*>(qtp + 32 * ks + 4);
-          const float qv_[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+      for (int ks = 0; ks < 3; ++ks) {
+        const float4 v0 = *reinterpret_cast<const float4*>(qtp + 32 * ks), v1 = *reinterpret_cast<const float4*>(qtp + 32 * ks + 4);
+        const float qv_[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
-          for (int j = 0; j < 8; ++j) bq[ks < 3 ? ks : 0][j] = loA ? f16_lo(qv_[j]) : f16_hi(qv_[j]);
-        }
-        const bool mine = (2 * ks + (kq >> 1)) == hB;   // the 8 columns 32 ks + 8 kq lie inside head 2 ks + (kq >> 1)
-        const float4 w0 = *reinterpret_cast<const float4*>(qp + 32 * ks), w1 = *reinterpret_cast<const float4*>(qp + 32 * ks + 4);
+        for (int j = 0; j < 8; ++j) bq[ks][j] = loA ? f16_lo(qv_[j]) : f16_hi(qv_[j]);
+      }
+      // q masked to head hB: the 8 columns 32 ks + 8 kq lie inside head 2 ks + (kq >> 1), so of a lane's four k-blocks only ks = hB >> 1
+      // can be non-zero, and only in the lanes with (kq >> 1) == (hB & 1): one block converted, three zeros (round 4: all four were)
+      {
+        const int ksel = hB >> 1;
+        const bool mine = (kq >> 1) == (hB & 1);
+        const float4 w0 = *reinterpret_cast<const float4*>(qp + 32 * ksel), w1 = *reinterpret_cast<const float4*>(qp + 32 * ksel + 4);
         const float kv_[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+        half8 bkv;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float kk = mine ? kv_[j] : 0.f;
-          bk[ks][j] = loA ? f16_lo(kk) : f16_hi(kk);
-        }
+        for (int j = 0; j < 8; ++j) bkv[j] = loA ? f16_lo(kv_[j]) : f16_hi(kv_[j]);
+        const half8 zero = {};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) bk[ks] = (mine && ks == ksel) ? bkv : zero;
       }
       cqm = DIRECT ? io.cq[(size_t)r * 8 + hB] : CQ[lr * 8 + hB];
     }
@@ -481,7 +485,8 @@ __device__ __forceinline__ void c16_edge_body(const ChainStep* __restrict__ stp,
       float tmax = fmaxf(fmaxf(sreg[0], sreg[1]), fmaxf(sreg[2], sreg[3]));
       tmax = kq_max(tmax);
       const float m_new = fmaxf(m_run, tmax);   // finite: the tile has at least one edge
-      const float scale = (m_run == -INFINITY) ? 0.f : exp2f(m_run - m_new);
+      const bool fresh = m_run == -INFINITY;   // this head's first tile of the parity class: its sums are still zero
+      const float scale = fresh ? 0.f : exp2f(m_run - m_new);
       float psum = 0.f;
       float pr[4];
 #pragma unroll
@@ -497,7 +502,8 @@ __device__ __forceinline__ void c16_edge_body(const ChainStep* __restrict__ stp,
       // what is already accumulated shrinks by the head's scale: accumulator row 4 (lane >> 4) + r belongs to head
       // (4 (lane >> 4) + r) & 7; the a_v columns of this lane to head hv.  Skipped while no head's maximum moves
       // (most tiles after a row's first few).
-      if (__any(scale != 1.f)) {
+      // (nor on a class's first tile: scaling zero sums by zero is the identity)
+      if (__any(scale != 1.f && !fresh)) {
         float scl[8];
 #pragma unroll
         for (int h = 0; h < 8; ++h) scl[h] = __shfl(scale, h);
