@@ -447,20 +447,16 @@ __global__ __launch_bounds__(256) void k_tile_transpose(const int* __restrict__ 
 constexpr int KNN_SLOTS = 40;   // up to 64*40 = 2560 candidates per scene (2048 polylines + 256 agents fits)
 // cand_ok (optional): candidate token i takes part iff i < cand_base or cand_ok[i - cand_base] != 0 -- agent rows that
 // are not in the scene at the initial step (they enter with a later fut_obs frame) are no tokens yet.
-__global__ void k_knn(CandSet cs, const float* __restrict__ qpos, const int* __restrict__ qscene, int nq, int k,
-                      const int* __restrict__ eoff, int* __restrict__ esrc, int* __restrict__ edst,
-                      const int* __restrict__ cand_ok, int cand_base) {
-  const int q = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  if (q >= nq) return;
-  const float qx = qpos[2 * q], qy = qpos[2 * q + 1];
-  const int b = qscene[q];
-  const int b1 = cs.r1[2 * b], n1 = cs.r1[2 * b + 1] - b1;
-  const int b2 = cs.r2 ? cs.r2[2 * b] : 0, n2 = cs.r2 ? cs.r2[2 * b + 1] - b2 : 0;
-  const int n = n1 + n2;
-  unsigned key[KNN_SLOTS];
+// (SLOTS: 64-candidate slots a lane holds -- the smallest of 4 / 20 / KNN_SLOTS that covers the query's scene, chosen by a wave-uniform
+// branch: every counting pass runs over the slots, and a fully unrolled pass over 20 is half the work of one over 40.  A per-slot
+// guard inside ONE 40-slot body was slower than no guard at all: the branches break the batches of compares and ballots.)
+template <int SLOTS>
+__device__ __forceinline__ void knn_select(const CandSet& cs, float qx, float qy, int b1, int n1, int b2, int n, int q, int lane, int k,
+                                           const int* __restrict__ eoff, int* __restrict__ esrc, int* __restrict__ edst,
+                                           const int* __restrict__ cand_ok, int cand_base) {
+  unsigned key[SLOTS];
 #pragma unroll
-  for (int s = 0; s < KNN_SLOTS; ++s) {
+  for (int s = 0; s < SLOTS; ++s) {
     const int j = s * 64 + lane;   // candidate order = global index order (range 1 then range 2)
     unsigned kk = 0xffffffffu;     // padding sorts last (real keys are finite floats < 0x7f800000)
     if (j < n) {
@@ -474,7 +470,7 @@ __global__ void k_knn(CandSet cs, const float* __restrict__ qpos, const int* __r
   if (cand_ok) {
     n_ok = 0;
 #pragma unroll
-    for (int s = 0; s < KNN_SLOTS; ++s) n_ok += __popcll(__ballot(key[s] != 0xffffffffu));
+    for (int s = 0; s < SLOTS; ++s) n_ok += __popcll(__ballot(key[s] != 0xffffffffu));
   }
   const int kk_ = k < n_ok ? k : n_ok;
   // v_k = largest x with count(key < x) < k
@@ -483,19 +479,16 @@ __global__ void k_knn(CandSet cs, const float* __restrict__ qpos, const int* __r
     const unsigned trial = vk | (1u << bit);
     int c = 0;
 #pragma unroll
-    for (int s = 0; s < KNN_SLOTS; ++s)
-      if (s * 64 < n) c += __popcll(__ballot(key[s] < trial));   // (wave-uniform guard: slots past the scene's candidates hold padding)
+    for (int s = 0; s < SLOTS; ++s) c += __popcll(__ballot(key[s] < trial));
     if (c < kk_) vk = trial;
   }
   int c_lt = 0;
 #pragma unroll
-  for (int s = 0; s < KNN_SLOTS; ++s)
-    if (s * 64 < n) c_lt += __popcll(__ballot(key[s] < vk));
+  for (int s = 0; s < SLOTS; ++s) c_lt += __popcll(__ballot(key[s] < vk));
   int ties_left = kk_ - c_lt;   // how many keys == v_k still go out, in index order
   int out = eoff[q];
 #pragma unroll
-  for (int s = 0; s < KNN_SLOTS; ++s) {
-    if (s * 64 >= n) continue;
+  for (int s = 0; s < SLOTS; ++s) {
     const int j = s * 64 + lane;
     const bool lt = key[s] < vk, eq = key[s] == vk && j < n && key[s] != 0xffffffffu;
     const unsigned long long meq = __ballot(eq);
@@ -512,6 +505,21 @@ __global__ void k_knn(CandSet cs, const float* __restrict__ qpos, const int* __r
     ties_left -= neq < ties_left ? neq : ties_left;
   }
 }
+__global__ void k_knn(CandSet cs, const float* __restrict__ qpos, const int* __restrict__ qscene, int nq, int k,
+                      const int* __restrict__ eoff, int* __restrict__ esrc, int* __restrict__ edst,
+                      const int* __restrict__ cand_ok, int cand_base) {
+  const int q = blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (wave-uniform: so is n below)
+  const int lane = threadIdx.x & 63;
+  if (q >= nq) return;
+  const float qx = qpos[2 * q], qy = qpos[2 * q + 1];
+  const int b = qscene[q];
+  const int b1 = cs.r1[2 * b], n1 = cs.r1[2 * b + 1] - b1;
+  const int b2 = cs.r2 ? cs.r2[2 * b] : 0, n2 = cs.r2 ? cs.r2[2 * b + 1] - b2 : 0;
+  const int n = n1 + n2;
+  if (n <= 64 * 4) knn_select<4>(cs, qx, qy, b1, n1, b2, n, q, lane, k, eoff, esrc, edst, cand_ok, cand_base);
+  else if (n <= 64 * 20) knn_select<20>(cs, qx, qy, b1, n1, b2, n, q, lane, k, eoff, esrc, edst, cand_ok, cand_base);
+  else knn_select<KNN_SLOTS>(cs, qx, qy, b1, n1, b2, n, q, lane, k, eoff, esrc, edst, cand_ok, cand_base);
+}
 
 // MODEL.REL_POS_EDGE_FUNC 'knn' (decoder/sym_coord.py:85-96, policy/act_decoder.py:249-261): the generator's and the policy's edge
 // sets from the `cap` NEAREST candidates of the query's scene (torch_cluster.knn; knn_graph(loop = False) for the prompt graph: the
@@ -522,7 +530,7 @@ template <int MODE>
 __global__ void k_knn_sets(RadSets sets, const float* __restrict__ qpos, const int* __restrict__ qscene, int nq) {
   const RadSet& S = sets.s[blockIdx.y];
   const CandSet cs = S.cs;
-  const int q = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int q = blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63;
   if (q >= nq) return;
   const int* __restrict__ cand_ok = S.cand_ok;
@@ -567,18 +575,15 @@ __global__ void k_knn_sets(RadSets sets, const float* __restrict__ qpos, const i
     const unsigned trial = vk | (1u << bit);
     int c = 0;
 #pragma unroll
-    for (int s = 0; s < KNN_SLOTS; ++s)
-      if (s * 64 < n) c += __popcll(__ballot(key[s] < trial));
+    for (int s = 0; s < KNN_SLOTS; ++s) c += __popcll(__ballot(key[s] < trial));
     if (c < kk_) vk = trial;
   }
   int c_lt = 0;
 #pragma unroll
-  for (int s = 0; s < KNN_SLOTS; ++s)
-    if (s * 64 < n) c_lt += __popcll(__ballot(key[s] < vk));
+  for (int s = 0; s < KNN_SLOTS; ++s) c_lt += __popcll(__ballot(key[s] < vk));
   int ties_left = kk_ - c_lt;
 #pragma unroll
   for (int s = 0; s < KNN_SLOTS; ++s) {
-    if (s * 64 >= n) continue;
     const int j = s * 64 + lane;
     const int i = j < n1 ? b1 + j : b2 + (j - n1);
     const bool lt = key[s] < vk, eq = key[s] == vk && j < n && key[s] != 0xffffffffu;
