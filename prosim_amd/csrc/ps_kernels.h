@@ -308,18 +308,29 @@ __global__ void k_radius(RadSets sets, const float* __restrict__ qpos, const int
     const int* rr = rg == 0 ? cs.r1 : cs.r2;
     if (!rr) break;
     const int beg = rr[2 * b], end = rr[2 * b + 1];
-    for (int i0 = beg; i0 < end && run < capx; i0 += 64) {
-      const int i = i0 + lane;
-      bool ok = false;
-      if (i < end) ok = dist2(cs.pos[2 * i], cs.pos[2 * i + 1], qx, qy) < r2 && (!cand_ok || i < cand_base || cand_ok[i - cand_base]);
-      const unsigned long long m = __ballot(ok);
-      const int rank = run + __popcll(m & ((1ull << lane) - 1ull));
-      if (MODE == 1 && ok && rank < capx && i != self) {
-        const int o = base_out + rank - ((self >= 0 && self < i) ? 1 : 0);
-        esrc[o] = i;
-        edst[o] = q;
+    // four 64-candidate chunks per trip: their position loads leave together (the loop was one dependent load -> ballot round trip
+    // per chunk), the chunks are then ranked in index order as before
+    for (int i0 = beg; i0 < end && run < capx; i0 += 256) {
+      bool okv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + 64 * u + lane;
+        okv[u] = false;
+        if (i < end) okv[u] = dist2(cs.pos[2 * i], cs.pos[2 * i + 1], qx, qy) < r2 && (!cand_ok || i < cand_base || cand_ok[i - cand_base]);
       }
-      run += __popcll(m);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + 64 * u + lane;
+        const bool ok = okv[u] && run < capx;   // (a chunk behind a full list takes nobody, as when the loop stopped there)
+        const unsigned long long m = __ballot(ok);
+        const int rank = run + __popcll(m & ((1ull << lane) - 1ull));
+        if (MODE == 1 && ok && rank < capx && i != self) {
+          const int o = base_out + rank - ((self >= 0 && self < i) ? 1 : 0);
+          esrc[o] = i;
+          edst[o] = q;
+        }
+        run += __popcll(m);
+      }
     }
   }
   if (MODE == 0 && lane == 0) {
