@@ -132,16 +132,30 @@ __global__ __launch_bounds__(GEO_THREADS) void k_edge_geo(GeoSets sets, const fl
     // torch's two passes bit for bit -- a last-bit change of rstd re-rolled the workload's near-cut edges; with the quieter GEMM
     // operands of round 4 the parity table holds either way, and the pass was a third of this kernel: 96 LDS round trips per edge.)
     float sm = 0.f;
+    if (__builtin_expect(fast, 1)) {   // (the two forms in branches of their own: sharing one loop, libm's sincosf kept the kernel at 145 registers)
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      float part = 0.f;
+      for (int i = 0; i < 3; ++i) {
+        float part = 0.f;
 #pragma unroll
-      for (int k = 0; k < 16; ++k) {
-        float sv, cv;
-        fourier_pair(xs[i], dv[k], rdv[k], fast, sv, cv);
-        part += sv + cv;
+        for (int k = 0; k < 16; ++k) {
+          float sv, cv;
+          fourier_pair(xs[i], dv[k], rdv[k], true, sv, cv);
+          part += sv + cv;
+        }
+        sm += (i == 2) ? 2.f * part : part;
       }
-      sm += (i == 2) ? 2.f * part : part;
+    } else {
+#pragma unroll 1
+      for (int i = 0; i < 3; ++i) {
+        float part = 0.f;
+#pragma unroll 1
+        for (int k = 0; k < 16; ++k) {
+          float sv, cv;
+          fourier_pair(xs[i], dv[k], rdv[k], false, sv, cv);
+          part += sv + cv;
+        }
+        sm += (i == 2) ? 2.f * part : part;
+      }
     }
     const float mean = sm * (1.f / 128.f);
     const float sq = 64.f - 128.f * mean * mean;
