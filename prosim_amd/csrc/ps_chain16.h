@@ -186,9 +186,10 @@ constexpr size_t C16_WAVE_BYTES = C16_STASH_OFF + 512 + 64;
 // the banks two deep.
 constexpr int C16_QH = 100, C16_QSL = 8 * C16_QH + 8;
 constexpr size_t C16_QA_BYTES = (size_t)16 * C16_QSL * 4;
+constexpr int C16_CTR_INTS = 52;   // [0] row counter, [1..16] rows in queue order, [17..32] their edge counts, [36..51] their first edges
 template <int NWV>
 constexpr size_t c16_lds_bytes() {
-  return (NWV * C16_WAVE_BYTES > C16_PLANES_BYTES ? NWV * C16_WAVE_BYTES - C16_PLANES_BYTES : 0) + C16_NODE_BYTES + 16 * 8 * 4 + 144 + C16_QA_BYTES;
+  return (NWV * C16_WAVE_BYTES > C16_PLANES_BYTES ? NWV * C16_WAVE_BYTES - C16_PLANES_BYTES : 0) + C16_NODE_BYTES + 16 * 8 * 4 + C16_CTR_INTS * 4 + C16_QA_BYTES;
 }
 
 typedef __fp16 fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
@@ -338,8 +339,9 @@ __device__ __forceinline__ void c16_edge_body(const ChainStep* __restrict__ stp,
     if (lr >= nrows) break;
     const int r = row0 + lr;
     float* park = DIRECT ? reinterpret_cast<float*>(wbase + C16_WAVE_BYTES) : QA + lr * C16_QSL;   // the even tiles' a_r (ONEW)
-    const int e_beg = __builtin_amdgcn_readfirstlane(ldgi(st.eoff + r));   // (wave-uniform: the tile loop's control stays on the scalar unit)
-    const int deg = __builtin_amdgcn_readfirstlane(ldgi(st.eoff + r + 1)) - e_beg;
+    // (wave-uniform: the tile loop's control stays on the scalar unit; the workgroup form reads what its PRE half left in LDS)
+    const int e_beg = __builtin_amdgcn_readfirstlane(DIRECT ? ldgi(st.eoff + r) : ctr[36 + lr]);
+    const int deg = DIRECT ? __builtin_amdgcn_readfirstlane(ldgi(st.eoff + r + 1)) - e_beg : __builtin_amdgcn_readfirstlane(ctr[17 + lr]);
     const int tstep = ONEW ? 32 : 16 * W;
     const bool two = ONEW && deg > 16;   // the row has odd tiles: two partial sums
     // Tiles of 16 edges (one score block).  A tile's geometry and source rows are requested one tile ahead (registers).
@@ -698,7 +700,7 @@ __device__ __noinline__ void c16_node_phase(const ChainStep* __restrict__ post, 
   float* sp = AG + ND_ROWS * ND_XS;      // [SP_SIZE] the layer's small vectors
   float* CQ = sp + SP_SIZE;              // [16][8] <q_h, kb_h>
   int* ctr = reinterpret_cast<int*>(CQ + 16 * 8);   // [0] row counter, [1..16] the rows in queue order (longest edge list first), [17..32] their edge counts
-  float* QA = reinterpret_cast<float*>(ctr + 36);   // [16 slots][C16_QSL] q~ / a_r
+  float* QA = reinterpret_cast<float*>(ctr + C16_CTR_INTS);   // [16 slots][C16_QSL] q~ / a_r
   constexpr int C16_DEPTH = 3;   // fragment groups in flight per wave (k_node, alone on its CU with 512 registers: 4)
   typedef FragRingT<C16_DEPTH> Ring;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -905,7 +907,11 @@ __device__ __noinline__ void c16_node_phase(const ChainStep* __restrict__ post, 
       const AttnW& w = st.w;
     // =========================================================== PRE: LN_dst, q | s | g, q~, <q, kb>   (:61-69, :106-107, :114)
     stage_sp(w.sp);
-    if (tid < 16) ctr[17 + tid] = tid < nrows ? ldgi(st.eoff + row0 + tid + 1) - ldgi(st.eoff + row0 + tid) : -1;   // (for the row queue)
+    if (tid < 16) {   // (for the row queue, and so that a row's wave finds its edge range in LDS instead of behind two global loads)
+      const int eb = tid < nrows ? ldgi(st.eoff + row0 + tid) : 0;
+      ctr[17 + tid] = tid < nrows ? ldgi(st.eoff + row0 + tid + 1) - eb : -1;
+      ctr[36 + tid] = eb;
+    }
     if (!post) frag_prefetch<4, Ring, NWV>(R, w.Fqsg, 8, wave, lane);   // (later layers: requested at the end of the previous POST)
     __syncthreads();
     C16_MARK(32);
@@ -1012,7 +1018,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) __attribute__((disable_
   float* sp = AG + ND_ROWS * ND_XS;      // [SP_SIZE] the layer's small vectors
   float* CQ = sp + SP_SIZE;              // [16][8] <q_h, kb_h>
   int* ctr = reinterpret_cast<int*>(CQ + 16 * 8);   // [0] row counter, [1..16] the rows in queue order (longest edge list first), [17..32] their edge counts
-  float* QA = reinterpret_cast<float*>(ctr + 36);   // [16 slots][C16_QSL] q~ / a_r
+  float* QA = reinterpret_cast<float*>(ctr + C16_CTR_INTS);   // [16 slots][C16_QSL] q~ / a_r
 
   const int row0 = xcd_block(blockIdx.x, gridDim.x, !xcd) * rows;
   const int nrows = min(rows, Nd - row0);          // rows of this workgroup that exist (> 0: the grid is ceil(Nd / rows))
@@ -1048,14 +1054,14 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) __attribute__((disable_
 // workgroup: q / q~ / <q, kb> come from the PRE half's EdgeIO rows into the slots the fused chain keeps them in, the sums go back the
 // same way.  Same arithmetic as a one-step k_chain16 launch's edge phase.
 constexpr size_t C16_EDGE_WAVES_BYTES = 8 * C16_WAVE_BYTES;
-constexpr size_t c16_edge_lds_bytes() { return C16_EDGE_WAVES_BYTES + (size_t)ND_ROWS * ND_XS * 4 + 16 * 8 * 4 + 144 + C16_QA_BYTES; }
+constexpr size_t c16_edge_lds_bytes() { return C16_EDGE_WAVES_BYTES + (size_t)ND_ROWS * ND_XS * 4 + 16 * 8 * 4 + C16_CTR_INTS * 4 + C16_QA_BYTES; }
 __global__ __launch_bounds__(512, 1) __attribute__((disable_tail_calls)) void k_edge16(int Nd, const ChainStep* __restrict__ step, EdgeIO io,
                                                                                      const float* __restrict__ div32) {
   extern __shared__ __attribute__((aligned(16))) unsigned char c16_smem[];
   float* AG = reinterpret_cast<float*>(c16_smem + C16_EDGE_WAVES_BYTES);   // [16][ND_XS] q rows, then a_v
   float* CQ = AG + ND_ROWS * ND_XS;                                        // [16][8]
   int* ctr = reinterpret_cast<int*>(CQ + 16 * 8);                          // [0] counter, [1..16] queue, [17..32] degrees
-  float* QA = reinterpret_cast<float*>(ctr + 36);                          // [16 slots][C16_QSL] q~ in, a_r | l out
+  float* QA = reinterpret_cast<float*>(ctr + C16_CTR_INTS);                          // [16 slots][C16_QSL] q~ in, a_r | l out
   const int tid = threadIdx.x;
   const int row0 = blockIdx.x * 16;
   const int nrows = min(16, Nd - row0);
@@ -1072,7 +1078,11 @@ __global__ __launch_bounds__(512, 1) __attribute__((disable_tail_calls)) void k_
     *reinterpret_cast<float4*>(QA + r * C16_QSL + h * C16_QH + c) = v;
   }
   if (tid < 128) CQ[tid] = (tid >> 3) < nrows ? ldg1(io.cq + (size_t)row0 * 8 + tid) : 0.f;
-  if (tid < 16) ctr[17 + tid] = tid < nrows ? ldgi(step->eoff + row0 + tid + 1) - ldgi(step->eoff + row0 + tid) : -1;
+  if (tid < 16) {
+    const int eb = tid < nrows ? ldgi(step->eoff + row0 + tid) : 0;
+    ctr[17 + tid] = tid < nrows ? ldgi(step->eoff + row0 + tid + 1) - eb : -1;
+    ctr[36 + tid] = eb;
+  }
   __syncthreads();
   if (tid == 0) ctr[0] = 0;
   if (tid < 16) {   // queue order: rows by falling edge count (as the fused chain's PRE half)
