@@ -184,8 +184,13 @@ constexpr size_t C16_WAVE_BYTES = C16_STASH_OFF + 512 + 64;
 // wave per row: the row's a_r overwrites its q~ (slot = row).  W waves per row (rows <= 4): a_r slots row * W + part (8 at
 // most), q~ of row r in slot 8 + r.  Slot stride 808 floats = 8 mod 64: the 16 rows of a fold A-fragment read spread over
 // the banks two deep.
+#ifdef PS_C16_ABL_ONE_SLOT   // (timing experiment, wrong results: every row shares ONE q~ / a_r slot, which aliases the small vectors -- 77 KB: two 4-wave workgroups of 16 rows per CU)
+constexpr int C16_QH = 100, C16_QSL = 0;
+constexpr size_t C16_QA_BYTES = 0;
+#else
 constexpr int C16_QH = 100, C16_QSL = 8 * C16_QH + 8;
 constexpr size_t C16_QA_BYTES = (size_t)16 * C16_QSL * 4;
+#endif
 constexpr int C16_CTR_INTS = 52;   // [0] row counter, [1..16] rows in queue order, [17..32] their edge counts, [36..51] their first edges
 template <int NWV>
 constexpr size_t c16_lds_bytes() {
@@ -700,7 +705,11 @@ __device__ __noinline__ void c16_node_phase(const ChainStep* __restrict__ post, 
   float* sp = AG + ND_ROWS * ND_XS;      // [SP_SIZE] the layer's small vectors
   float* CQ = sp + SP_SIZE;              // [16][8] <q_h, kb_h>
   int* ctr = reinterpret_cast<int*>(CQ + 16 * 8);   // [0] row counter, [1..16] the rows in queue order (longest edge list first), [17..32] their edge counts
-  float* QA = reinterpret_cast<float*>(ctr + C16_CTR_INTS);   // [16 slots][C16_QSL] q~ / a_r
+  #ifdef PS_C16_ABL_ONE_SLOT
+  float* QA = sp;
+#else
+  float* QA = reinterpret_cast<float*>(ctr + C16_CTR_INTS);
+#endif   // [16 slots][C16_QSL] q~ / a_r
   constexpr int C16_DEPTH = 3;   // fragment groups in flight per wave (k_node, alone on its CU with 512 registers: 4)
   typedef FragRingT<C16_DEPTH> Ring;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1038,7 +1047,11 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) __attribute__((disable_
   float* sp = AG + ND_ROWS * ND_XS;      // [SP_SIZE] the layer's small vectors
   float* CQ = sp + SP_SIZE;              // [16][8] <q_h, kb_h>
   int* ctr = reinterpret_cast<int*>(CQ + 16 * 8);   // [0] row counter, [1..16] the rows in queue order (longest edge list first), [17..32] their edge counts
-  float* QA = reinterpret_cast<float*>(ctr + C16_CTR_INTS);   // [16 slots][C16_QSL] q~ / a_r
+  #ifdef PS_C16_ABL_ONE_SLOT
+  float* QA = sp;
+#else
+  float* QA = reinterpret_cast<float*>(ctr + C16_CTR_INTS);
+#endif   // [16 slots][C16_QSL] q~ / a_r
 
   const int row0 = xcd_block(blockIdx.x, gridDim.x, !xcd) * rows;
   const int nrows = min(rows, Nd - row0);          // rows of this workgroup that exist (> 0: the grid is ceil(Nd / rows))
@@ -1081,7 +1094,7 @@ __global__ __launch_bounds__(512, 1) __attribute__((disable_tail_calls)) void k_
   float* AG = reinterpret_cast<float*>(c16_smem + C16_EDGE_WAVES_BYTES);   // [16][ND_XS] q rows, then a_v
   float* CQ = AG + ND_ROWS * ND_XS;                                        // [16][8]
   int* ctr = reinterpret_cast<int*>(CQ + 16 * 8);                          // [0] counter, [1..16] queue, [17..32] degrees
-  float* QA = reinterpret_cast<float*>(ctr + C16_CTR_INTS);                          // [16 slots][C16_QSL] q~ in, a_r | l out
+    float* QA = reinterpret_cast<float*>(ctr + C16_CTR_INTS);                          // [16 slots][C16_QSL] q~ in, a_r | l out
   const int tid = threadIdx.x;
   const int row0 = blockIdx.x * 16;
   const int nrows = min(16, Nd - row0);
