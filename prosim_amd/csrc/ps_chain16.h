@@ -407,7 +407,11 @@ __device__ __forceinline__ void c16_edge_body(const ChainStep* __restrict__ stp,
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int rr = 4 * i + dr;
+#ifdef PS_C16_ABL_ONEROW   // (timing experiment: every k row of a tile from ONE source row -- L1 hits; wrong results)
+        kp[i] = (unsigned)Ss[16 * buf] * 512u + 16u * (ds_ ^ rr);
+#else
         kp[i] = (unsigned)Ss[16 * buf + rr] * 512u + 16u * (ds_ ^ rr);
+#endif
       }
     };
     if (t0 < deg) {
@@ -500,7 +504,11 @@ __device__ __forceinline__ void c16_edge_body(const ChainStep* __restrict__ stp,
       for (int j = 0; j < 8; ++j) vv[j] = make_float4(sreg[0], sreg[1], sreg[2], sreg[3]);
 #else
 #pragma unroll
+#ifdef PS_C16_ABL_ONEROW
+      for (int j = 0; j < 8; ++j) vv[j] = c16_bld4(rs_v, (unsigned)Sc[0] * 1024u + vcol);
+#else
       for (int j = 0; j < 8; ++j) vv[j] = c16_bld4(rs_v, (unsigned)Sc[2 * j + eh] * 1024u + vcol);
+#endif
 #endif
       // ---- online softmax over the tile (torch_geometric.utils.softmax: max-shift, exp, / (sum + 1e-16))
       float tmax = fmaxf(fmaxf(sreg[0], sreg[1]), fmaxf(sreg[2], sreg[3]));
