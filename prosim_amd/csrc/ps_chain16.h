@@ -200,19 +200,72 @@ constexpr size_t c16_lds_bytes() {
 typedef __fp16 fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
 typedef _Float16 half4v __attribute__((ext_vector_type(4)));
 
-// this lane's 8 consecutive features (4 pairs) of input block xs, normalised and split: A-fragment order of the
-// score MFMAs (lane = edge + 16 kq holds features 8 kq .. 8 kq + 7 of the 32-feature block)
-__device__ __forceinline__ void feat8(float xs, float rstd, float nmr, const float (&dv)[4], const float (&rdv)[4], half8& hi, half8& lo) {
+// ---- packed fp32 (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32: two results per issue slot) and the split straight from the packed
+// hi halves.  Round 5: the tile loop of the edge phase is bound by VALU issue, and hipcc's own
+// vectoriser packed only the normalise and the lo subtraction of a (sin, cos) pair; here two FREQUENCIES go through the exact
+// division and the reduction to revolutions together (9 instead of 16 instructions per two pairs), and a lo half is ONE
+// v_fma_mix{lo,hi}_f16 (f16(y - float(hi)) with the f16 operand read in place: the difference is exact in fp32, so the single
+// conversion rounds like cvt(sub)) instead of v_cvt_f32_f16 + v_sub_f32 + v_cvt_f16_f32.  Same operations on the same values
+// in the same order as the scalar form: the bits do not change (tools/mb/mb_feat.hip checks that on the GPU).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+// (hi0 | hi1) = fp16 of two floats, round to nearest even: v_cvt_pk_f16_f32
+__device__ __forceinline__ unsigned f16_hi_pk(float y0, float y1) {
+  const half2v h = {(_Float16)y0, (_Float16)y1};
+  return __builtin_bit_cast(unsigned, h);
+}
+// (lo0 | lo1) with lo = fp16(y - float(hi)), hi read from the packed dword
+__device__ __forceinline__ unsigned f16_lo_pk(unsigned hi_pk, float y0, float y1) {
+  unsigned lo;
+  asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(hi_pk), "v"(y0));
+  asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(hi_pk), "v"(y1));
+  return lo;
+}
+// per lane and lane-uniformly chosen half: m = -1 gives the lo halves fp16(y - float(hi)), m = -0 the hi halves fp16(y - 0) -- the
+// (p hi | p lo) and (q hi | q lo) operands whose half depends on the lane take ONE instruction per value instead of both halves + a select
+__device__ __forceinline__ unsigned f16_sel_pk(unsigned hi_pk, float y0, float y1, float m) {
+  unsigned r;
+  asm("v_fma_mixlo_f16 %0, %1, %3, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hi_pk), "v"(y0), "v"(m));
+  asm("v_fma_mixhi_f16 %0, %1, %3, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(r) : "v"(hi_pk), "v"(y1), "v"(m));
+  return r;
+}
+// 8 floats -> the lane's half (hi or lo by m) as an MFMA operand
+__device__ __forceinline__ half8 f16_sel8(const float (&v)[8], float m) {
+  unsigned r[4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    float s, c;
-    sincos_hw(fdiv16(xs, dv[j], rdv[j]), s, c);
-    const float ys = fmaf(s, rstd, nmr), yc = fmaf(c, rstd, nmr);
-    hi[2 * j] = f16_hi(ys);
-    lo[2 * j] = f16_lo(ys);
-    hi[2 * j + 1] = f16_hi(yc);
-    lo[2 * j + 1] = f16_lo(yc);
+  for (int j = 0; j < 4; ++j) r[j] = f16_sel_pk(f16_hi_pk(v[2 * j], v[2 * j + 1]), v[2 * j], v[2 * j + 1], m);
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  return __builtin_bit_cast(half8, u32x4{r[0], r[1], r[2], r[3]});
+}
+
+// this lane's 8 consecutive features (4 pairs) of input block xs, normalised and split: A-fragment order of the
+// score MFMAs (lane = edge + 16 kq holds features 8 kq .. 8 kq + 7 of the 32-feature block).  dv / rdv: the lane's four
+// divisors and their reciprocals as two packed pairs.
+__device__ __forceinline__ void feat8(float xs, float rstd, float nmr, const f32x2 (&dv)[2], const f32x2 (&rdv)[2], half8& hi, half8& lo) {
+  constexpr float C1 = 0.15915494309189535f;
+  constexpr float C2 = (float)(0.15915494309189535 - (double)0.15915494309189535f);
+  const f32x2 x2 = {xs, xs}, c1 = {C1, C1}, c2 = {C2, C2}, rs = {rstd, rstd}, nm = {nmr, nmr};
+  unsigned h[4], l[4];
+#pragma unroll
+  for (int jj = 0; jj < 2; ++jj) {
+    // fdiv16 (x / d exactly) and sincos_hw's reduction to revolutions, two frequencies at a time
+    const f32x2 q0 = x2 * rdv[jj];
+    const f32x2 rem = pk_fma(-q0, dv[jj], x2);
+    const f32x2 q = pk_fma(rem, rdv[jj], q0);
+    const f32x2 u = q * c1;
+    const f32x2 n = {rintf(u.x), rintf(u.y)};
+    const f32x2 f = pk_fma(q, c1, -n) + q * c2;
+    const f32x2 sc0 = {__builtin_amdgcn_sinf(f.x), __builtin_amdgcn_cosf(f.x)}, sc1 = {__builtin_amdgcn_sinf(f.y), __builtin_amdgcn_cosf(f.y)};
+    const f32x2 y0 = pk_fma(sc0, rs, nm), y1 = pk_fma(sc1, rs, nm);
+    h[2 * jj] = f16_hi_pk(y0.x, y0.y);
+    h[2 * jj + 1] = f16_hi_pk(y1.x, y1.y);
+    l[2 * jj] = f16_lo_pk(h[2 * jj], y0.x, y0.y);
+    l[2 * jj + 1] = f16_lo_pk(h[2 * jj + 1], y1.x, y1.y);
   }
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  hi = __builtin_bit_cast(half8, u32x4{h[0], h[1], h[2], h[3]});
+  lo = __builtin_bit_cast(half8, u32x4{l[0], l[1], l[2], l[3]});
 }
 // the same outside fdiv16's checked range (a distance beyond 10 km): true division, libm sincos.  Rolled, and through LDS
 // (this lane's 24 halfs of the feature tile row; `lo` selects which halves are written): the rare path must not cost the
@@ -243,6 +296,20 @@ __device__ __forceinline__ void c16_blds16(unsigned voff, __amdgpu_buffer_rsrc_t
   unsigned keep;   // MUBUF form: 32-bit per-lane byte offset; `soff` (SGPR) moves the memory address only -- an instruction offset would move the LDS side too
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_dst) : "memory");
+}
+// One round = four DMAs behind ONE m0 swap (round 5; round 3 saved / set / restored m0 and spent an s_nop per DMA): the instruction
+// offset 1024 i moves the LDS side to row group i -- and the memory side with it, which the caller takes back out of the per-lane
+// offset (kaddr: + C16_DMA_BIAS - 1024 i against a descriptor based C16_DMA_BIAS bytes below the array).
+constexpr unsigned C16_DMA_BIAS = 3072;
+__device__ __forceinline__ void c16_blds16x4(const unsigned (&voff)[4], __amdgpu_buffer_rsrc_t rsrc, unsigned soff, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %7\n\ts_nop 0\n\t"
+               "buffer_load_dwordx4 %1, %5, %6 offen lds\n\t"
+               "buffer_load_dwordx4 %2, %5, %6 offen offset:1024 lds\n\t"
+               "buffer_load_dwordx4 %3, %5, %6 offen offset:2048 lds\n\t"
+               "buffer_load_dwordx4 %4, %5, %6 offen offset:3072 lds\n\t"
+               "s_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]), "s"(rsrc), "s"(soff), "s"(lds_dst) : "memory");
 }
 // raw buffer over a device array (stride 0, no format conversion): 32-bit offsets instead of 64-bit pointer arithmetic per lane
 // (the pointer goes through readfirstlane: a descriptor that hipcc cannot prove wave-uniform costs a waterfall loop per load)
@@ -308,6 +375,7 @@ __device__ __forceinline__ void c16_edge_body(const ChainStep* __restrict__ stp,
     dv[j] = ldg1(div32 + 2 * (4 * kq + j));
     rdv[j] = 1.0f / dv[j];
   }
+  const f32x2 dvp[2] = {{dv[0], dv[1]}, {dv[2], dv[3]}}, rdvp[2] = {{rdv[0], rdv[1]}, {rdv[2], rdv[3]}};
   unsigned char* wbase = c16_smem + (size_t)wave * WSTRIDE;
   const half8* stg = reinterpret_cast<const half8*>(wbase);                    // k staging: [16 rows][16 slots of 16 B], hi or lo halves
   float* Pt = reinterpret_cast<float*>(wbase + 4096);                         // [16 edges][8 heads] probabilities (for a_v)
@@ -315,13 +383,14 @@ __device__ __forceinline__ void c16_edge_body(const ChainStep* __restrict__ stp,
   int* Ss = reinterpret_cast<int*>(wbase + 4096 + 512 + 16 * C16_FS * 2);     // [2][16] source rows of this tile and the next
   float* stash = reinterpret_cast<float*>(wbase + C16_STASH_OFF);
   const unsigned stg_lds = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)wbase);   // LDS byte address of the staging area
-  const __amdgpu_buffer_rsrc_t rs_geo = c16_rsrc(st.geo), rs_k = c16_rsrc(st.khl), rs_v = c16_rsrc(st.kv);
+  const __amdgpu_buffer_rsrc_t rs_geo = c16_rsrc(st.geo), rs_k = c16_rsrc(reinterpret_cast<const unsigned char*>(st.khl) - C16_DMA_BIAS), rs_v = c16_rsrc(st.kv);
   // fragment reads of the staging area: row mi, piece 4 ks + kq at slot (4 ks + kq) ^ mi
   const half8* str = stg + mi * 16 + (kq ^ (mi & 3));
   const int sra = mi >> 2;
   // DMA sources: row 4 i + (lane >> 4), piece (lane & 15) ^ row
   const int dr = lane >> 4, ds_ = lane & 15;
   const bool loA = mi >= 8;
+  const float selm = loA ? -1.f : -0.f;   // f16_sel_pk: lanes of the lo columns take fp16(y - float(hi)), the others fp16(y - 0)
   const int hv = (lane & 31) >> 2, eh = lane >> 5;
   for (int it = 0;; ++it) {
     int lr, part;
@@ -338,7 +407,7 @@ __device__ __forceinline__ void c16_edge_body(const ChainStep* __restrict__ stp,
       if (lane == 0) lr = atomicAdd(ctr, 1);
       lr = __builtin_amdgcn_readfirstlane(lr);
       if (lr >= nrows) break;
-      lr = ctr[1 + lr];
+      lr = __builtin_amdgcn_readfirstlane(ctr[1 + lr]);   // (wave-uniform by construction; said so, the tile loop's control stays on the scalar unit)
       part = 0;
     }
     if (lr >= nrows) break;
@@ -375,8 +444,7 @@ __device__ __forceinline__ void c16_edge_body(const ChainStep* __restrict__ stp,
       for (int ks = 0; ks < 3; ++ks) {
         const float4 v0 = *reinterpret_cast<const float4*>(qtp + 32 * ks), v1 = *reinterpret_cast<const float4*>(qtp + 32 * ks + 4);
         const float qv_[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-#pragma unroll
-        for (int j = 0; j < 8; ++j) bq[ks][j] = loA ? f16_lo(qv_[j]) : f16_hi(qv_[j]);
+        bq[ks] = f16_sel8(qv_, selm);
       }
       // q masked to head hB: the 8 columns 32 ks + 8 kq lie inside head 2 ks + (kq >> 1), so of a lane's four k-blocks only ks = hB >> 1
       // can be non-zero, and only in the lanes with (kq >> 1) == (hB & 1): one block converted, three zeros (round 4: all four were)
@@ -385,9 +453,7 @@ __device__ __forceinline__ void c16_edge_body(const ChainStep* __restrict__ stp,
         const bool mine = (kq >> 1) == (hB & 1);
         const float4 w0 = *reinterpret_cast<const float4*>(qp + 32 * ksel), w1 = *reinterpret_cast<const float4*>(qp + 32 * ksel + 4);
         const float kv_[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
-        half8 bkv;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) bkv[j] = loA ? f16_lo(kv_[j]) : f16_hi(kv_[j]);
+        const half8 bkv = f16_sel8(kv_, selm);
         const half8 zero = {};
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) bk[ks] = (mine && ks == ksel) ? bkv : zero;
@@ -408,9 +474,9 @@ __device__ __forceinline__ void c16_edge_body(const ChainStep* __restrict__ stp,
       for (int i = 0; i < 4; ++i) {
         const int rr = 4 * i + dr;
 #ifdef PS_C16_ABL_ONEROW   // (timing experiment: every k row of a tile from ONE source row -- L1 hits; wrong results)
-        kp[i] = (unsigned)Ss[16 * buf] * 512u + 16u * (ds_ ^ rr);
+        kp[i] = (unsigned)Ss[16 * buf] * 512u + 16u * (ds_ ^ rr) + (C16_DMA_BIAS - 1024u * i);
 #else
-        kp[i] = (unsigned)Ss[16 * buf + rr] * 512u + 16u * (ds_ ^ rr);
+        kp[i] = (unsigned)Ss[16 * buf + rr] * 512u + 16u * (ds_ ^ rr) + (C16_DMA_BIAS - 1024u * i);
 #endif
       }
     };
@@ -418,8 +484,7 @@ __device__ __forceinline__ void c16_edge_body(const ChainStep* __restrict__ stp,
       if (lane < 16) Ss[lane] = nsrc;   // (prefetch(t0)'s loads are hipcc's own: it waits for them here)
       kaddr(0);
       c16_wait_lgkm0();                 // the previous row's last reads of the staging area are done
-#pragma unroll
-      for (int i = 0; i < 4; ++i) c16_blds16(kp[i], rs_k, 0u, stg_lds + 1024 * i);
+      c16_blds16x4(kp, rs_k, 0u, stg_lds);
     }
 #ifdef PS_C16_ABL_NOEDGE
     t0 = deg;
@@ -431,6 +496,7 @@ __device__ __forceinline__ void c16_edge_body(const ChainStep* __restrict__ stp,
       tn = t0 + tstep;
       const bool turn = two && tn >= deg && (t0 & 16) == 0;
       if (turn) tn = 16;
+      tn = __builtin_amdgcn_readfirstlane(tn);   // (uniform already; hipcc kept the tile counter in a VGPR and its compares on the VALU)
       // this tile's records (requested a tile ago)
       const float4 g0 = ng;
       const float nmr = nn;
@@ -444,8 +510,7 @@ __device__ __forceinline__ void c16_edge_body(const ChainStep* __restrict__ stp,
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) ak[ks] = str[4 * (ks ^ sra)];
         c16_wait_lgkm0();
-#pragma unroll
-        for (int i = 0; i < 4; ++i) c16_blds16(kp[i], rs_k, 256u, stg_lds + 1024 * i);
+        c16_blds16x4(kp, rs_k, 256u, stg_lds);
         prefetch(tn);   // the next tile's records leave now (past the row's end: its last edge again, unused)
         floatx4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -456,9 +521,9 @@ __device__ __forceinline__ void c16_edge_body(const ChainStep* __restrict__ stp,
 #pragma unroll
         for (int ks = 0; ks < 3; ++ks) { fh[ks] = __builtin_bit_cast(half8, ng); fl[ks] = fh[ks]; }
 #else
-        feat8(g0.x, g0.w, nmr, dv, rdv, fh[0], fl[0]);
-        feat8(g0.y, g0.w, nmr, dv, rdv, fh[1], fl[1]);
-        feat8(g0.z, g0.w, nmr, dv, rdv, fh[2], fl[2]);
+        feat8(g0.x, g0.w, nmr, dvp, rdvp, fh[0], fl[0]);
+        feat8(g0.y, g0.w, nmr, dvp, rdvp, fh[1], fl[1]);
+        feat8(g0.z, g0.w, nmr, dvp, rdvp, fh[2], fl[2]);
 #endif
         if (__builtin_expect(__any(!(fdiv16_ok(g0.x) && fdiv16_ok(g0.y) && fdiv16_ok(g0.z))), 0)) {
           // (a distance beyond 10 km, outside fdiv16's checked range: true division + libm, rolled, through the feature
@@ -483,8 +548,7 @@ __device__ __forceinline__ void c16_edge_body(const ChainStep* __restrict__ stp,
         if (tn < deg) {   // the next tile's source rows arrived with the prefetch: publish them, start the DMA of its k hi halves
           if (lane < 16) Ss[16 * (sb ^ 1) + lane] = nsrc;
           kaddr(sb ^ 1);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) c16_blds16(kp[i], rs_k, 0u, stg_lds + 1024 * i);
+          c16_blds16x4(kp, rs_k, 0u, stg_lds);
         }
 #pragma unroll
         for (int ks = 0; ks < 3; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl[ks], bq[ks], acc, 0, 0, 0);
@@ -494,7 +558,11 @@ __device__ __forceinline__ void c16_edge_body(const ChainStep* __restrict__ stp,
 #pragma unroll
         for (int r4 = 0; r4 < 4; ++r4) {
           const float v = acc[r4] + dpp_xor8(acc[r4]);   // columns h and h + 8 (q hi | q lo)
-          sreg[r4] = (4 * kq + r4 < n) ? (v + cqm) * (0.25f * 1.44269504088896341f) : -INFINITY;   // in units of log2: exp(x) = exp2(x log2 e)
+          sreg[r4] = (v + cqm) * (0.25f * 1.44269504088896341f);   // in units of log2: exp(x) = exp2(x log2 e)
+        }
+        if (n < 16) {   // (wave-uniform: only a parity class's last tile is short)
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4) sreg[r4] = (4 * kq + r4 < n) ? sreg[r4] : -INFINITY;
         }
       }
       // v rows of the tile leave now and fly under the softmax and the a_r MFMAs: gathered by source, two rows per load instruction
@@ -512,18 +580,22 @@ __device__ __forceinline__ void c16_edge_body(const ChainStep* __restrict__ stp,
 #endif
       // ---- online softmax over the tile (torch_geometric.utils.softmax: max-shift, exp, / (sum + 1e-16))
       float tmax = fmaxf(fmaxf(sreg[0], sreg[1]), fmaxf(sreg[2], sreg[3]));
-      tmax = kq_max(tmax);
-      const float m_new = fmaxf(m_run, tmax);   // finite: the tile has at least one edge
+      const float m_new = kq_max3(tmax, m_run);   // max(m_run, the tile's maximum over the four kq lanes); finite: the tile has at least one edge
       const bool fresh = m_run == -INFINITY;   // this head's first tile of the parity class: its sums are still zero
-      const float scale = fresh ? 0.f : exp2f(m_run - m_new);
+      // (v_exp_f32 itself: libm's exp2f wraps it in a range check + ldexp for results below 2^-126, which max-shifted
+      // probabilities and scales do not need -- such a term adds nothing to sums that hold a 1)
+      const float scale = fresh ? 0.f : __builtin_amdgcn_exp2f(m_run - m_new);
       float psum = 0.f;
       float pr[4];
 #pragma unroll
       for (int r4 = 0; r4 < 4; ++r4) {
-        const float p = exp2f(sreg[r4] - m_new);   // 2^-inf = 0 for the slots past the edge list
+        const float p = __builtin_amdgcn_exp2f(sreg[r4] - m_new);   // 2^-inf = 0 for the slots past the edge list
         pr[r4] = p;
         psum += p;
-        if (mi < 8) Pt[(4 * kq + r4) * 8 + mi] = p;
+      }
+      if (mi < 8) {
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) Pt[(4 * kq + r4) * 8 + mi] = pr[r4];
       }
       psum = kq_sum(psum);
       l_run = l_run * scale + psum;
@@ -548,9 +620,9 @@ __device__ __forceinline__ void c16_edge_body(const ChainStep* __restrict__ stp,
       // ---- a_r[h][c] += sum_e p_e,h r~_e[c] on the matrix cores (16x16x16): A = (p hi | p lo) x head, straight from this
       //      lane's probabilities (row 4 kq + j of column mi = edge 4 kq + j of head mi & 7), B = the feature tile read back
       //      transposed (4 consecutive EDGES of one feature per lane: one ds_read_b64_tr_b16), hi pass then lo pass
-      half4v ap;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) ap[j] = loA ? f16_lo(pr[j]) : f16_hi(pr[j]);
+      typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+      const half4v ap = __builtin_bit_cast(half4v, u32x2{f16_sel_pk(f16_hi_pk(pr[0], pr[1]), pr[0], pr[1], selm),
+                                                         f16_sel_pk(f16_hi_pk(pr[2], pr[3]), pr[2], pr[3], selm)});
       const _Float16* tp = Ft + (kq * 4 + (mi >> 2)) * C16_FS + (lane & 3) * 4;
 #ifdef PS_C16_ABL_NOAR
       ar[0][0] += (float)ap[0] + (float)fl[0][0] + (float)fl[1][0] + (float)fl[2][0];
