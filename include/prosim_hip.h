@@ -272,6 +272,18 @@ int ps_set_state(ps_engine* e, int32_t steps, const float* traj, const float* ve
  *   "edge_counts" [8] (a2a, s2s, p2p, s2p, a2p, m2p of the last step, cond, 0) as float.
  * Returns the number of floats written, or a negative error. */
 int64_t ps_get(ps_engine* e, const char* name, float* dst, int64_t capacity);
+/* Serving a stream of new batches (no counterpart in the reference, which runs its batches one after the other,
+ * rollout/callbacks.py:76): ps_get without its two synchronisations.  The copy of a per-agent result ("traj", "vel",
+ * "motion_pred", "reconst_pred", "policy_emd", "fused", "goal_prob", "goal_point") is enqueued on the engine's stream behind
+ * whatever the stream holds -- call it right after ps_rollout -- into memory the caller owns (pinned host memory makes the call
+ * return at once); the caller waits for the stream, or for an event it records on ps_stream(), before reading.  Together with
+ * the upload staging of ps_set_scene (two pinned arenas in turn, no synchronisation) this lets a caller queue batch n + 1
+ * behind batch n on one engine.  Returns the number of floats that will be written, or a negative error. */
+int64_t ps_get_async(ps_engine* e, const char* name, float* dst, int64_t capacity);
+/* out[0] = rollouts that had to capture and instantiate their hipGraph, out[1] = rollouts that followed a setter
+ * (ps_set_scene, ps_set_conditions, ...) and could keep the graph they had because nothing their launch sequence is made
+ * of -- row counts, flags, device pointers -- had changed (a stream of batches of one shape replays one graph). */
+int ps_graph_stats(ps_engine* e, int64_t* out);
 /* Closed-loop displacement metric on the device: per agent row the mean distance between the rolled-out xy and a
  * ground-truth future over the steps whose ground truth is finite, and the distance at the LAST such step (the
  * NaN-masked target / last-valid-index conventions of metrics/motion_pred.py:31-76).  gt_dev [A, max_steps, 2] is a

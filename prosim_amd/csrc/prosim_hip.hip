@@ -11,6 +11,7 @@
 #include <cstring>
 #include <initializer_list>
 #include <string>
+#include <mutex>
 #include <unordered_map>
 #include <vector>
 
@@ -57,6 +58,8 @@ static int fail(int code, const std::string& msg) {
 
 namespace {
 
+thread_local hipStream_t g_free_sync = nullptr;   // see DevBuf::ensure
+
 template <class T>
 struct DevBuf {   // owning device allocation: freed by release() or at scope exit; movable, not copyable
   T* p = nullptr;
@@ -72,6 +75,9 @@ struct DevBuf {   // owning device allocation: freed by release() or at scope ex
   ~DevBuf() { release(); }
   int ensure(size_t count) {
     if (count <= n && p) return 0;
+    // (round 5: a setter may run while the engine's previous rollout is still in flight -- a buffer that has to grow is freed only
+    // after the stream has drained; StageScope names the stream)
+    if (p && g_free_sync) (void)hipStreamSynchronize(g_free_sync);
     if (p) (void)hipFree(p);
     p = nullptr;
     n = 0;
@@ -97,6 +103,150 @@ struct EdgeSet {  // CSR by destination + normalised rel-PE
 };
 
 struct Stage { float ms = 0; };
+
+// Upload staging of an engine (round 5: serving a stream of NEW batches).  hipMemcpyAsync from pageable memory stages and waits inside
+// the call, and ~25 separate copies on the engine's stream are ~0.5 ms during which that stream runs no rollout.  Here a setter's
+// uploads are copied into a PINNED host arena (the caller's arrays are free when the setter returns), cross PCIe as ONE copy into the
+// arena's device mirror on a separate upload stream -- concurrently with the rollout the engine may still have in flight, whose
+// inputs must not be touched yet --, and reach their destinations through one scatter kernel on the engine's stream behind that
+// rollout.  No stream synchronisation ends the setter.  Two arenas per engine in turn (ps_set_scene switches): `done` marks the
+// last scatter of an arena; begin() -- two ps_set_scene calls later -- waits for that mark; take(): a request that does not fit
+// flushes, drains the stream, starts over and grows if it must.
+struct UpSeg { unsigned char* dst; const unsigned char* src; unsigned long long bytes; };
+constexpr int UP_SEGS = 24;
+struct UpSegs { UpSeg s[UP_SEGS]; };
+__global__ __launch_bounds__(256) void k_upload_scatter(UpSegs g) {   // blockIdx.y = segment; 16-byte pieces (arena slices and hipMalloc blocks are 256-byte aligned)
+  const UpSeg sg = g.s[blockIdx.y];
+  const size_t n16 = sg.bytes >> 4;
+  const uint4* s4 = reinterpret_cast<const uint4*>(sg.src);
+  uint4* d4 = reinterpret_cast<uint4*>(sg.dst);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) d4[i] = s4[i];
+  if (blockIdx.x == 0 && threadIdx.x < (sg.bytes & 15)) sg.dst[(n16 << 4) + threadIdx.x] = sg.src[(n16 << 4) + threadIdx.x];
+}
+// one upload stream per device and process (an extra stream PER ENGINE costs the pipelined loop more than it hides: DESIGN.md section 7, round 3)
+hipStream_t upload_stream(int device) {
+  static std::mutex mu;
+  static std::unordered_map<int, hipStream_t> streams;
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = streams.find(device);
+  if (it != streams.end()) return it->second;
+  hipStream_t st = nullptr;
+  if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) st = nullptr;
+  streams[device] = st;
+  return st;
+}
+// Engine streams are pooled per device and live as long as the process: how the runtime spreads streams over the hardware queues
+// depends on the ORDER in which a process created them, and four rollouts in flight on streams created after a few others had come
+// and gone measured 20 M agent-steps/s instead of 26 M (tools/gpu_pipeline_depth.py with PS_DEPTHS=3,4 against 4, round 5).  With
+// the pool -- and the upload stream always created first -- the k-th engine alive gets the k-th stream the process ever made.
+struct EngineStreams {
+  std::mutex mu;
+  std::unordered_map<int, std::vector<std::pair<hipStream_t, bool>>> by_dev;   // (stream, in use)
+};
+EngineStreams& engine_streams() { static EngineStreams es; return es; }
+hipStream_t engine_stream_acquire(int device) {
+  (void)upload_stream(device);
+  EngineStreams& es = engine_streams();
+  std::lock_guard<std::mutex> lock(es.mu);
+  auto& v = es.by_dev[device];
+  for (auto& s : v)
+    if (!s.second) { s.second = true; return s.first; }
+  hipStream_t st = nullptr;
+  // non-blocking: the legacy null stream (synchronous hipMemcpy, another library's default-stream work) does not
+  // serialise against an engine's stream -- two engines on one GPU overlap; every read-back syncs explicitly
+  if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return nullptr;
+  v.push_back({st, true});
+  return st;
+}
+void engine_stream_release(int device, hipStream_t st) {
+  EngineStreams& es = engine_streams();
+  std::lock_guard<std::mutex> lock(es.mu);
+  for (auto& s : es.by_dev[device])
+    if (s.first == st) s.second = false;
+}
+struct PinStage {
+  unsigned char *p = nullptr, *dev = nullptr;   // the pinned host arena and its device mirror
+  size_t cap = 0, used = 0, flushed = 0;
+  hipEvent_t done = nullptr, h2d = nullptr;
+  bool pending = false;
+  int device = 0;
+  std::vector<UpSeg> segs;   // slices taken since the last flush: (destination, OFFSET in the arena, bytes)
+  int begin(hipStream_t st) {
+    if (pending) { if (hipEventSynchronize(done) != hipSuccess) return -1; }
+    else if (used) { if (hipStreamSynchronize(st) != hipSuccess) return -1; }   // (a setter that failed half-way left no mark)
+    pending = false;
+    used = flushed = 0;
+    segs.clear();
+    return 0;
+  }
+  int flush(hipStream_t st) {
+    if (segs.empty()) return 0;
+    hipStream_t up = upload_stream(device);
+    if (!up) return -1;
+    if (!h2d && hipEventCreateWithFlags(&h2d, hipEventDisableTiming) != hipSuccess) return -1;
+    if (hipMemcpyAsync(dev + flushed, p + flushed, used - flushed, hipMemcpyHostToDevice, up) != hipSuccess) return -1;
+    if (hipEventRecord(h2d, up) != hipSuccess || hipStreamWaitEvent(st, h2d, 0) != hipSuccess) return -1;
+    for (size_t i0 = 0; i0 < segs.size(); i0 += UP_SEGS) {
+      UpSegs g{};
+      const int n = (int)std::min<size_t>(UP_SEGS, segs.size() - i0);
+      for (int i = 0; i < n; ++i) g.s[i] = UpSeg{segs[i0 + i].dst, dev + (size_t)(uintptr_t)segs[i0 + i].src, segs[i0 + i].bytes};
+      hipLaunchKernelGGL(k_upload_scatter, dim3(48, n), dim3(256), 0, st, g);
+    }
+    segs.clear();
+    flushed = used;
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+  }
+  void* take(size_t bytes, hipStream_t st) {
+    const size_t need = (bytes + 255) & ~size_t(255);
+    if (used + need > cap) {
+      if (flush(st) || hipStreamSynchronize(st) != hipSuccess) return nullptr;   // every earlier copy out of this arena is complete
+      pending = false;
+      used = flushed = 0;
+      if (need > cap) {
+        if (p) (void)hipHostFree(p);
+        if (dev) (void)hipFree(dev);
+        p = dev = nullptr;
+        cap = 0;
+        const size_t want = std::max(need * 2, (size_t)1 << 24);
+        if (hipHostMalloc((void**)&p, want, hipHostMallocDefault) != hipSuccess) { p = nullptr; return nullptr; }
+        if (hipMalloc((void**)&dev, want) != hipSuccess) { (void)hipHostFree(p); p = dev = nullptr; return nullptr; }
+        cap = want;
+      }
+    }
+    void* r = p + used;
+    used += need;
+    return r;
+  }
+  int stage(void* dst, const void* h, size_t bytes, hipStream_t st) {
+    unsigned char* pin = static_cast<unsigned char*>(take(bytes, st));
+    if (!pin) return -1;
+    std::memcpy(pin, h, bytes);
+    segs.push_back(UpSeg{static_cast<unsigned char*>(dst), reinterpret_cast<const unsigned char*>((uintptr_t)(pin - p)), bytes});
+    return 0;
+  }
+  int mark(hipStream_t st) {
+    if (flush(st)) return -1;
+    if (!done && hipEventCreateWithFlags(&done, hipEventDisableTiming) != hipSuccess) return -1;
+    if (hipEventRecord(done, st) != hipSuccess) return -1;
+    pending = true;
+    return 0;
+  }
+  void release() {
+    if (p) (void)hipHostFree(p);
+    if (dev) (void)hipFree(dev);
+    if (done) (void)hipEventDestroy(done);
+    if (h2d) (void)hipEventDestroy(h2d);
+    p = dev = nullptr; done = h2d = nullptr; cap = used = flushed = 0; pending = false;
+    segs.clear();
+  }
+};
+thread_local PinStage* g_stage = nullptr;   // the arena upload() stages through while a StageScope is alive (the setters of one engine)
+struct StageScope {
+  PinStage* prev;
+  hipStream_t prev_sync;
+  StageScope(PinStage* s, hipStream_t st) : prev(g_stage), prev_sync(g_free_sync) { g_stage = s; g_free_sync = st; }
+  ~StageScope() { g_stage = prev; g_free_sync = prev_sync; }
+};
 
 }  // namespace
 
@@ -201,10 +351,17 @@ struct ps_engine {
   // (the rollout is then launched eagerly), so the launch durations of a PIPELINED run can be read afterwards
   bool policy_events = false;
   std::vector<hipEvent_t> pev;
+  // round 5: serving a stream of new batches -- pinned upload staging, the captured graph kept across scenes of one shape, results
+  // copied back behind the rollout
+  PinStage stage[2];                                  // two arenas in turn (ps_set_scene switches): a batch can be uploaded behind a rollout still in flight
+  int stage_cur = 0;
+  std::vector<uint64_t> graph_sig;                    // what the captured launch sequence depends on (rollout_signature)
+  int64_t graph_captures = 0, graph_reuses = 0;       // (ps_graph_stats: how often ps_rollout had to capture / could keep the graph)
 };
 
 namespace {
-void drop_graph(ps_engine* e);
+void drop_graph(ps_engine* e);      // the captured rollout must be re-checked against rollout_signature() before its next replay
+void destroy_graph(ps_engine* e);
 int io_for(ps_engine* e, int Nd, EdgeIO& io);
 // the learnable rel-PE embedding that makes the rows of edge set `es`, or nullptr (fixed Fourier rows)
 const PeLearnW* pe_of(const ps_engine* e, const EdgeSet* es) {
@@ -756,13 +913,12 @@ extern "C" int ps_create(const ps_config* cfg, int32_t n_tensors, const char* co
     ps_destroy(e);   // releases whatever was built so far
     return fail(PS_E_HIP, "layer table upload failed");
   }
-  // non-blocking: the legacy null stream (synchronous hipMemcpy, another library's default-stream work) does not
-  // serialise against this engine's stream -- two engines on one GPU overlap; every read-back below syncs explicitly
-  if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&e->ev0) != hipSuccess ||
+  if ((e->stream = engine_stream_acquire(e->cfg.device)) == nullptr || hipEventCreate(&e->ev0) != hipSuccess ||
       hipEventCreate(&e->ev1) != hipSuccess) {
     ps_destroy(e);   // releases whatever was built so far
     return fail(PS_E_HIP, "stream/event creation failed");
   }
+  e->stage[0].device = e->stage[1].device = e->cfg.device;
   // the chain kernel may use up to ~140 KiB of dynamic LDS
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_kv_proj), hipFuncAttributeMaxDynamicSharedMemorySize, (int)KV_LDS_BYTES);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pointnet_mfma), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PN_LDS_BYTES);
@@ -822,13 +978,15 @@ extern "C" void ps_destroy(ps_engine* e) {
   e->d_obs_new.release(); e->d_kv_um.release(); e->d_kh_um.release();
   e->io_q.release(); e->io_qt.release(); e->io_cq.release(); e->io_ar.release(); e->io_av.release(); e->io_l.release();
   e->io_s.release(); e->io_g.release(); e->io_m.release();
-  drop_graph(e);
+  destroy_graph(e);
+  e->stage[0].release();
+  e->stage[1].release();
   if (e->arena_d) (void)hipFree(e->arena_d);
   if (e->d_layers) (void)hipFree(e->d_layers);
   for (auto ev : e->pev) if (ev) (void)hipEventDestroy(ev);
   if (e->ev0) (void)hipEventDestroy(e->ev0);
   if (e->ev1) (void)hipEventDestroy(e->ev1);
-  if (e->stream) (void)hipStreamDestroy(e->stream);
+  if (e->stream) engine_stream_release(e->cfg.device, e->stream);   // (drained by the hipDeviceSynchronize above; pooled, not destroyed)
   delete e;
 }
 
@@ -839,8 +997,10 @@ template <class T>
 int upload(DevBuf<T>& b, const T* h, size_t n, hipStream_t s) {
   if (b.ensure(n)) return -1;
   if (n == 0) return 0;
+  if (g_stage) return g_stage->stage(b.p, h, n * sizeof(T), s);   // through the engine's arena: delivered when the setter ends (PinStage)
   return hipMemcpyAsync(b.p, h, n * sizeof(T), hipMemcpyHostToDevice, s) == hipSuccess ? 0 : -1;
 }
+
 
 // k_chain16 gathers geometry records, k rows and v rows through raw buffer descriptors with 32-bit byte offsets (edge * 32,
 // source row * 512, source row * 1024 + 512; ps_chain16.h): beyond 2^31 bytes a buffer load returns 0 silently, so sizes that
@@ -883,6 +1043,10 @@ extern "C" int ps_set_scene(ps_engine* e, int32_t B, int32_t M, int32_t P, int32
   // graph (or read results) over buffers this call has already resized
   e->have_scene = e->encoded = e->generated = e->reset = false;
   drop_graph(e);
+  // uploads go through the engine's pinned arena and this call ends without a stream synchronisation (PinStage)
+  e->stage_cur ^= 1;   // (the other arena may still feed the uploads of a batch whose rollout is in flight)
+  if (e->stage[e->stage_cur].begin(e->stream)) return fail(PS_E_HIP, "upload staging: the previous uploads did not complete");
+  StageScope stage_scope(&e->stage[e->stage_cur], e->stream);
   struct DeclaredGuard {   // ps_declare_agent_rows is consumed by this call on EVERY exit path
     std::vector<uint8_t> rows;
     std::vector<uint8_t>& ref;
@@ -1008,7 +1172,7 @@ extern "C" int ps_set_scene(ps_engine* e, int32_t B, int32_t M, int32_t P, int32
       upload(e->d_r_map, r_map.data(), r_map.size(), st) || upload(e->d_r_agent, r_agent.data(), r_agent.size(), st) ||
       upload(e->d_r_zero, r_zero.data(), r_zero.size(), st))
     return fail(PS_E_HIP, "geometry upload failed");
-  // staging vectors of the asynchronous uploads below live until the hipStreamSynchronize that ends this call
+  // (the uploads copy out of these vectors into the pinned arena before they return)
   std::vector<float> stat;
   std::vector<uint8_t> mrows;
   std::vector<int> off, tof, tds, off2, tof2, tds2;
@@ -1155,7 +1319,7 @@ extern "C" int ps_set_scene(ps_engine* e, int32_t B, int32_t M, int32_t P, int32
   e->ents_pair.clear();
   e->n_drag = 0;
   e->cond_present_gt = e->cond_present_drag = e->cond_present_pair = false;
-  HIPCHK(hipStreamSynchronize(st));
+  if (e->stage[e->stage_cur].mark(st)) return fail(PS_E_HIP, "upload staging: event record failed");
   e->have_scene = true;
   e->encoded = e->generated = e->reset = false;
   drop_graph(e);
@@ -1254,6 +1418,7 @@ static int rebuild_conditions(ps_engine* e) {
   e->have_cond = e->cond_present_gt || e->cond_present_drag || e->cond_present_pair;
   e->edge_counts[6] = (float)e->n_cond_edges;
   hipStream_t st = e->stream;
+  StageScope stage_scope(&e->stage[e->stage_cur], e->stream);   // (appends to the arena ps_set_scene started; no stream synchronisation at the end)
   // (the set was sized for one self loop per prompt; binary conditions add edges: grow, and re-point the layers' steps)
   const _Float16 *oa = e->e_cnd.rtA.p, *ot = e->e_cnd.rtT.p;
   const int *oo = e->e_cnd.eoff.p, *os_ = e->e_cnd.esrc.p, *of = e->e_cnd.toff.p;
@@ -1272,7 +1437,7 @@ static int rebuild_conditions(ps_engine* e) {
     }
     if (upload(e->d_steps, e->h_steps.data(), e->h_steps.size(), st)) return fail(PS_E_HIP, "step table upload failed");
   }
-  HIPCHK(hipStreamSynchronize(st));
+  if (e->stage[e->stage_cur].mark(st)) return fail(PS_E_HIP, "upload staging: event record failed");
   e->generated = false;
   drop_graph(e);
   return PS_OK;
@@ -2207,12 +2372,64 @@ int rollout_eager(ps_engine* e) {
     if ((rc = ps_policy_step(e, t))) return rc;
   return PS_OK;
 }
-void drop_graph(ps_engine* e) {
+// Round 5: a setter no longer DESTROYS the captured rollout, it only marks it unchecked.  The next ps_rollout compares the signature
+// of what its launch sequence would be made of NOW -- every count, flag and device pointer a launch of rollout_eager() takes from
+// the host -- with the signature taken at capture; equal means the recorded launches are the ones a new capture would record (the
+// DATA behind the pointers is read by the kernels, grids that depend on data read their counts on the device), so a stream of
+// batches of one shape replays one graph.  Anything that moved (a buffer that grew, another row count, a condition type that
+// appeared) re-captures as before.
+void drop_graph(ps_engine* e) { e->graph_ok = false; }
+void destroy_graph(ps_engine* e) {
   if (e->graph_exec) (void)hipGraphExecDestroy(e->graph_exec);
   if (e->graph) (void)hipGraphDestroy(e->graph);
   e->graph_exec = nullptr;
   e->graph = nullptr;
   e->graph_ok = false;
+  e->graph_sig.clear();
+}
+std::vector<uint64_t> rollout_signature(const ps_engine* e) {
+  std::vector<uint64_t> g;
+  g.reserve(256);
+  auto I = [&](long long v) { g.push_back((uint64_t)v); };
+  auto Pp = [&](const void* p) { g.push_back((uint64_t)(uintptr_t)p); };
+  // shapes and row counts
+  for (long long v : {(long long)e->B, (long long)e->M, (long long)e->P, (long long)e->N, (long long)e->Mv, (long long)e->A, (long long)e->Ap,
+                      (long long)e->replicas, (long long)e->maxA_scene, (long long)e->maxM_scene, (long long)e->n_policy, (long long)e->stride_steps})
+    I(v);
+  // flags that choose launches, pointers or NULLs
+  for (long long v : {(long long)e->all_policy, (long long)e->have_log, (long long)e->have_dead0, (long long)e->have_fut, (long long)e->have_noise,
+                      (long long)e->have_cond, (long long)e->n_cond_edges, (long long)e->n_cond_tiles, (long long)e->n_drag, (long long)e->drag_T,
+                      (long long)e->node_mt, (long long)e->wg_edges, (long long)e->legacy_rows, (long long)e->chain_rows, (long long)e->chain_impl,
+                      (long long)g_force_mt, (long long)e->step_a2a, (long long)e->step_s2s, (long long)e->step_dec, (long long)e->step_cnd,
+                      (long long)e->step_pol, (long long)e->step_upd})
+    I(v);
+  I((long long)e->h_steps.size());
+  for (const ChainStep& st : e->h_steps) I(st.kr);
+  // every device buffer a launch can name
+  for (const void* p : {(const void*)e->io_q.p, (const void*)e->io_qt.p, (const void*)e->io_cq.p, (const void*)e->io_ar.p, (const void*)e->io_av.p,
+                        (const void*)e->io_l.p, (const void*)e->io_s.p, (const void*)e->io_g.p, (const void*)e->io_m.p,
+                        (const void*)e->d_obs_new.p, (const void*)e->d_kv_um.p, (const void*)e->d_kh_um.p,
+                        (const void*)e->d_map_input.p, (const void*)e->d_obs_input.p, (const void*)e->d_prompt.p, (const void*)e->d_fut.p,
+                        (const void*)e->d_map_mask.p, (const void*)e->d_obs_mask.p, (const void*)e->d_map_rows.p, (const void*)e->d_agent_rows.p,
+                        (const void*)e->d_tok_scene.p, (const void*)e->d_agent_type.p, (const void*)e->d_r_map.p, (const void*)e->d_r_agent.p,
+                        (const void*)e->d_r_zero.p, (const void*)e->d_tok.p, (const void*)e->d_tok_pos.p, (const void*)e->d_tok_ori.p,
+                        (const void*)e->d_init_pos.p, (const void*)e->d_init_head.p, (const void*)e->d_cur_pos.p, (const void*)e->d_cur_ori.p,
+                        (const void*)e->d_prompt_pos.p, (const void*)e->d_prompt_ori.p, (const void*)e->d_xp.p, (const void*)e->d_emd.p,
+                        (const void*)e->d_xc.p, (const void*)e->d_fused.p, (const void*)e->d_obs_in.p, (const void*)e->d_static_in.p,
+                        (const void*)e->d_kv.p, (const void*)e->d_kv_s2p.p, (const void*)e->d_kv_m2p.p, (const void*)e->d_kv_a2p.p,
+                        (const void*)e->d_traj.p, (const void*)e->d_vel.p, (const void*)e->d_motion.p, (const void*)e->d_reconst.p,
+                        (const void*)e->d_goal_prob.p, (const void*)e->d_goal_point.p, (const void*)e->d_choice.p, (const void*)e->d_noise.p,
+                        (const void*)e->d_kh.p, (const void*)e->d_kh_s2p.p, (const void*)e->d_kh_m2p.p, (const void*)e->d_kh_a2p.p,
+                        (const void*)e->d_steps.p, (const void*)e->d_ent_off.p, (const void*)e->d_ent_type.p, (const void*)e->d_ent_val.p,
+                        (const void*)e->d_cond_edges.p, (const void*)e->d_drag_in.p, (const void*)e->d_drag_emd.p, (const void*)e->d_drag_mask.p,
+                        (const void*)e->d_is_policy.p, (const void*)e->d_tok_live.p, (const void*)e->d_live0.p, (const void*)e->d_obs_in_mask.p,
+                        (const void*)e->d_fut_mask.p, (const void*)e->d_obs_mask_rows.p, (const void*)e->d_fut_pos.p, (const void*)e->d_fut_head.p})
+    Pp(p);
+  for (const EdgeSet* es : {&e->e_a2a, &e->e_s2s, &e->e_p2p, &e->e_s2p, &e->e_a2p, &e->e_m2p, &e->e_cnd, &e->e_ua, &e->e_um}) {
+    Pp(es->cnt.p); Pp(es->eoff.p); Pp(es->toff.p); Pp(es->tdst.p); Pp(es->esrc.p); Pp(es->edst.p); Pp(es->rtA.p); Pp(es->rtT.p); Pp(es->geo.p);
+    I((long long)es->cap_edges); I(es->nq); I(es->maxdeg);
+  }
+  return g;
 }
 }  // namespace
 
@@ -2225,8 +2442,14 @@ extern "C" int ps_rollout(ps_engine* e) {
   // (event pairs do not survive graph capture on ROCm 7.2 -- hipEventElapsedTime rejects events recorded by graph nodes --
   // so a rollout with policy events enabled is launched eagerly: ~200 launches, ~1 ms of host time per rollout)
   if (!e->use_graph || e->time_chain || e->policy_events) return rollout_eager(e);
+  if (!e->graph_ok && e->graph_exec) {   // a setter ran since the last replay: does the recorded launch sequence still stand?
+    if (rollout_signature(e) == e->graph_sig) {
+      e->graph_ok = true;
+      e->graph_reuses++;
+    }
+  }
   if (!e->graph_ok) {
-    drop_graph(e);
+    destroy_graph(e);
     HIPCHK(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
     const int rc = rollout_eager(e);
     hipGraph_t g = nullptr;
@@ -2239,12 +2462,14 @@ extern "C" int ps_rollout(ps_engine* e) {
     }
     e->graph = g;
     if (hipGraphInstantiate(&e->graph_exec, g, nullptr, nullptr, 0) != hipSuccess) {
-      drop_graph(e);
+      destroy_graph(e);
       e->use_graph = false;
       (void)hipGetLastError();
       return rollout_eager(e);
     }
     e->graph_ok = true;
+    e->graph_sig = rollout_signature(e);   // (after the capture: rollout_eager may have grown an exchange buffer)
+    e->graph_captures++;
   }
   HIPCHK(hipGraphLaunch(e->graph_exec, e->stream));
   e->encoded = e->generated = e->reset = true;
@@ -2504,6 +2729,52 @@ extern "C" int64_t ps_get(ps_engine* e, const char* name, float* dst, int64_t ca
     return 8;
   }
   return fail(PS_E_ARG, "unknown result name '" + n + "'");
+}
+
+// ps_get without the two synchronisations: the copy of a per-agent result is ENQUEUED on the engine's stream behind whatever the
+// stream holds (typically right after ps_rollout) into memory the caller owns; with pinned host memory the call returns at once and
+// the caller waits for the stream (or an event it records on ps_stream) before reading.  What a serving loop needs to keep an
+// engine's stream non-empty: results of batch n leave while batch n + 1 is already queued behind them.
+extern "C" int64_t ps_get_async(ps_engine* e, const char* name, float* dst, int64_t capacity) {
+  if (!e || !name || !dst) return fail(PS_E_ARG, "null argument");
+  if (!e->have_scene) return fail(PS_E_STATE, "ps_get_async before ps_set_scene");
+  if (hipSetDevice(e->cfg.device) != hipSuccess) return fail(PS_E_HIP, "hipSetDevice");
+  const ps_config& c = e->cfg;
+  const int A = e->A;
+  const int R = (c.max_steps + c.replan_freq - 1) / c.replan_freq;
+  const std::string n(name);
+  const float* src = nullptr;
+  int64_t count = 0;
+  int w2d = 0;   // traj / vel: rows of stride_steps steps, the history cut off
+  if (n == "traj" || n == "vel") {
+    w2d = n == "traj" ? 4 : 2;
+    count = (int64_t)A * R * c.replan_freq * w2d;
+    src = (n == "traj" ? e->d_traj.p : e->d_vel.p) + (size_t)c.hist_steps * w2d;
+  } else if (n == "motion_pred") { src = e->d_motion.p; count = (int64_t)R * A * c.motion_k * c.target_steps * c.state_dim; }
+  else if (n == "reconst_pred" && !c.no_reconst_pred) { src = e->d_reconst.p; count = (int64_t)A * 2; }
+  else if (n == "policy_emd") { src = e->d_emd.p; count = (int64_t)A * D; }
+  else if (n == "fused") { src = e->d_fused.p; count = (int64_t)A * D; }
+  else if (n == "goal_prob" && c.goal_pred_k > 0) { src = e->d_goal_prob.p; count = (int64_t)A * c.goal_pred_k; }
+  else if (n == "goal_point" && c.goal_pred_k > 0) { src = e->d_goal_point.p; count = (int64_t)A * 2 * c.goal_pred_k; }
+  else return fail(PS_E_ARG, "ps_get_async: '" + n + "' is not a per-agent result of this engine");
+  if (count > capacity) return fail(PS_E_ARG, "destination too small for '" + n + "'");
+  if (w2d) {
+    const int64_t steps = (int64_t)R * c.replan_freq;
+    if (hipMemcpy2DAsync(dst, sizeof(float) * w2d * steps, src, sizeof(float) * w2d * e->stride_steps, sizeof(float) * w2d * steps, A,
+                         hipMemcpyDeviceToHost, e->stream) != hipSuccess)
+      return fail(PS_E_HIP, "hipMemcpy2DAsync D2H");
+  } else if (hipMemcpyAsync(dst, src, sizeof(float) * (size_t)count, hipMemcpyDeviceToHost, e->stream) != hipSuccess) {
+    return fail(PS_E_HIP, "hipMemcpyAsync D2H");
+  }
+  return count;
+}
+
+// out[0] = rollouts that captured and instantiated a graph, out[1] = rollouts after a setter that could keep the graph they had
+extern "C" int ps_graph_stats(ps_engine* e, int64_t* out) {
+  if (!e || !out) return fail(PS_E_ARG, "null argument");
+  out[0] = e->graph_captures;
+  out[1] = e->graph_reuses;
+  return PS_OK;
 }
 
 extern "C" int ps_time_rollout(ps_engine* e, int32_t warmup, int32_t iters, float* ms_rollout, float* stage_ms) {

@@ -100,6 +100,9 @@ def load_library():
     lib.ps_set_state.argtypes = [vp, C.c_int32, fp, fp]
     lib.ps_get.argtypes = [vp, C.c_char_p, fp, C.c_int64]
     lib.ps_get.restype = C.c_int64
+    lib.ps_get_async.argtypes = [vp, C.c_char_p, vp, C.c_int64]
+    lib.ps_get_async.restype = C.c_int64
+    lib.ps_graph_stats.argtypes = [vp, C.POINTER(C.c_int64)]
     lib.ps_rollout_metric.argtypes = [vp, vp, vp]
     lib.ps_pair_metric.argtypes = [vp, vp, vp, vp, vp]
     lib.ps_num_agents.argtypes = [vp]
@@ -120,7 +123,7 @@ def load_library():
 
 EXPORTS = ["ps_create", "ps_destroy", "ps_last_error", "ps_set_scene", "ps_set_prompt", "ps_policy_forward", "ps_set_conditions", "ps_set_drag_points", "ps_set_pair_conditions", "ps_set_future_obs", "ps_set_future_log", "ps_set_mode_choice", "ps_set_action_noise", "ps_set_replicas", "ps_num_replicas", "ps_world_trajs", "ps_num_policy_agents", "ps_policy_flags",
            "ps_encode_scene", "ps_generate_policy", "ps_reset_rollout", "ps_policy_step", "ps_rollout", "ps_sync", "ps_stream", "ps_set_chain_rows", "ps_set_chain_impl", "ps_set_row_impl", "ps_graph_nodes", "ps_enable_policy_events", "ps_policy_event_times", "ps_update_obs", "ps_set_map_tokens", "ps_declare_agent_rows",
-           "ps_set_state", "ps_get", "ps_rollout_metric", "ps_pair_metric", "ps_num_agents", "ps_num_map_tokens", "ps_time_rollout", "ps_time_policy_kernel",
+           "ps_set_state", "ps_get", "ps_get_async", "ps_graph_stats", "ps_rollout_metric", "ps_pair_metric", "ps_num_agents", "ps_num_map_tokens", "ps_time_rollout", "ps_time_policy_kernel",
            "ps_test_pointnet", "ps_test_pointnet_mt", "ps_test_fourier", "ps_test_wrap", "ps_test_attn", "ps_test_get_edges", "ps_test_stream"]
 
 
@@ -241,7 +244,7 @@ class Engine:
         self.live0_rows = np.tile(seen0.reshape(-1)[in_slots], Mrep)
         # with replicas the rows are replica-major and slot r * N + n is agent n of replica r
         self._slots = in_slots if Mrep == 1 else (np.arange(Mrep)[:, None] * N + in_slots[None, :]).reshape(-1)
-        self.set_conditions(s.get("cond"))
+        self.set_conditions(s.get("cond"), _fresh_scene=True)
         if s.get("mode_choice") is not None:
             self.set_mode_choice(s["mode_choice"])
         if s.get("action_noise") is not None:
@@ -302,7 +305,7 @@ class Engine:
             raise ValueError(f"action noise must be {want}, got {a.shape}")
         self._check(self.lib.ps_set_action_noise(self.h, _f(a)))
 
-    def set_conditions(self, cond):
+    def set_conditions(self, cond, _fresh_scene: bool = False):
         """``cond`` = {'goal' | 'v_action_tag' | 'drag_point': {'input', 'mask', 'prompt_idx' [B,C,1] = prompt SLOT},
         'v2v_tag': {'input' [B,C,3], 'mask', 'prompt_idx' [B,C,2] = the SLOTS of (source, target)}} or None; replaces every
         condition of the uploaded batch (batch.extras['condition'] after the id -> slot mapping)."""
@@ -320,9 +323,15 @@ class Engine:
                 cp = np.ascontiguousarray(np.asarray(c["prompt_idx"])[..., 0], dtype=np.int32)
                 keep += [ci, cm, cp]
                 args += [ci.shape[1], _f(ci), _u8(cm), _i32(cp)]
-        self._check(self.lib.ps_set_conditions(self.h, *args))
-        self.set_drag_points(cond.get("drag_point"))
-        self.set_pair_conditions(cond.get("v2v_tag"))
+        # (ps_set_scene has just cleared every condition: a type the batch does not carry needs no call -- each one rebuilds and
+        # uploads the condition graph)
+        absent = lambda c: c is None or np.asarray(c["input"]).shape[1] == 0
+        if not (_fresh_scene and absent(cond.get("goal")) and absent(cond.get("v_action_tag"))):
+            self._check(self.lib.ps_set_conditions(self.h, *args))
+        if not (_fresh_scene and absent(cond.get("drag_point"))):
+            self.set_drag_points(cond.get("drag_point"))
+        if not (_fresh_scene and absent(cond.get("v2v_tag"))):
+            self.set_pair_conditions(cond.get("v2v_tag"))
 
     def set_pair_conditions(self, c):
         """``c`` = {'input' [B,C,3] (V2V tag value, t0, t1), 'mask' [B,C], 'prompt_idx' [B,C,2] (source, target slots)} or None."""
@@ -455,6 +464,31 @@ class Engine:
         if n < 0:
             self._check(int(n))
         return out
+
+    ASYNC_RESULTS = ("traj", "vel", "motion_pred", "reconst_pred", "policy_emd", "fused", "goal_prob", "goal_point")
+
+    def result_shape(self, name: str):
+        sp, A = self.spec, self.num_agents
+        R, S = sp.n_replans, sp.n_replans * sp.replan_freq
+        return {"traj": (A, S, 4), "vel": (A, S, 2), "motion_pred": (R, A, sp.motion_k, sp.target_steps, sp.state_dim),
+                "reconst_pred": (A, 2), "policy_emd": (A, sp.hidden), "fused": (A, sp.hidden),
+                "goal_prob": (A, max(sp.goal_pred_k, 1)), "goal_point": (A, max(sp.goal_pred_k, 1), 2)}[name]
+
+    def get_async(self, name: str, host_ptr: int, capacity: int) -> int:
+        """``ps_get`` without its synchronisations: enqueue the copy of a per-agent result behind the work already on the engine's
+        stream (call right after ``rollout()``) into caller-owned memory of ``capacity`` floats at ``host_ptr`` -- pinned memory
+        (``torch.empty(n, pin_memory=True).data_ptr()``) makes the call return at once.  Wait for the stream (``sync()``) or for an
+        event recorded on ``stream_handle`` before reading.  Returns the number of floats that will arrive."""
+        n = self.lib.ps_get_async(self.h, name.encode(), C.c_void_p(host_ptr), capacity)
+        if n < 0:
+            self._check(int(n))
+        return int(n)
+
+    def graph_stats(self):
+        """(rollouts that captured a graph, rollouts after a setter that kept the graph they had)."""
+        out = (C.c_int64 * 2)()
+        self._check(self.lib.ps_graph_stats(self.h, out))
+        return int(out[0]), int(out[1])
 
     def padded(self, name: str) -> np.ndarray:
         """Per-agent result scattered back to the padded [B, N, ...] slot layout of the inputs."""

@@ -1,0 +1,105 @@
+"""Round 5: serving a stream of NEW batches -- the captured hipGraph is kept across scenes of one shape (ps_rollout compares the
+signature of its launch sequence instead of re-capturing after every setter), uploads go through pinned staging without a stream
+synchronisation, results are copied back behind the rollout (ps_prefetch).  Every shortcut must return the bits of a fresh engine."""
+import numpy as np
+import pytest
+
+from prosim_amd import synth, weights
+from prosim_amd.spec import SMALL_SPEC
+
+pytestmark = pytest.mark.gpu
+
+
+def _fresh(spec, w, scene, rows):
+    from prosim_amd.engine import Engine
+    eng = Engine(spec, w)
+    eng.set_chain_rows(rows)
+    eng.set_scene(scene)
+    eng.rollout()
+    out = (eng.padded("traj"), eng.get("motion_pred"), eng.padded("vel"))
+    eng.close()
+    return out
+
+
+@pytest.mark.parametrize("rows", [0, 16])
+def test_graph_is_kept_across_scenes_of_one_shape_and_recaptured_when_the_shape_moves(rows):
+    from prosim_amd.engine import Engine
+    spec = SMALL_SPEC
+    w = weights.init_weights(spec, 0)
+    same = [synth.make_scene(spec, 12, 40, batch=2, seed=70 + i, goal=True) for i in range(3)]       # one shape, three contents
+    other = synth.make_scene(spec, 9, 33, batch=3, seed=80, goal=True, ragged=True)                   # another shape
+    nogoal = synth.make_scene(spec, 12, 40, batch=2, seed=81, goal=False)                             # the shape of `same` without conditions
+    eng = Engine(spec, w)
+    eng.set_chain_rows(rows)
+    seq = [same[0], same[1], same[2], other, same[0], nogoal, same[1]]
+    for k, sc in enumerate(seq):
+        eng.set_scene(sc)
+        eng.rollout()
+        got = (eng.padded("traj"), eng.get("motion_pred"), eng.padded("vel"))
+        want = _fresh(spec, w, sc, rows)
+        for g, x in zip(got, want):
+            assert np.array_equal(g, x), (rows, k)
+    cap, reuse = eng.graph_stats()
+    # captures: same[0], other, same[0] again (buffers may have grown for `other`: then its pointers moved), nogoal (no condition
+    # layers), same[1] (conditions back); the two batches right behind same[0] replay its graph
+    assert reuse >= 2, (cap, reuse)
+    assert cap + reuse == len(seq), (cap, reuse)
+    assert cap >= 3, (cap, reuse)
+    # a second rollout of the resident scene neither captures nor counts as a re-check
+    eng.rollout()
+    assert eng.graph_stats() == (cap, reuse)
+    eng.close()
+
+
+def test_get_async_delivers_the_bits_of_get_and_a_batch_can_queue_behind_a_rollout_in_flight():
+    import torch
+    from prosim_amd.engine import Engine
+    spec = SMALL_SPEC
+    w = weights.init_weights(spec, 0)
+    a = synth.make_scene(spec, 10, 30, batch=2, seed=90, goal=True, tags=True)
+    b = synth.make_scene(spec, 10, 30, batch=2, seed=91, goal=True, tags=True)
+    names = ("traj", "vel", "motion_pred", "policy_emd", "fused")
+    want = {}
+    for key, sc in (("a", a), ("b", b)):
+        eng = Engine(spec, w)
+        eng.set_scene(sc)
+        eng.rollout()
+        want[key] = {n: eng.get(n) for n in names}
+        eng.close()
+    eng = Engine(spec, w)
+    bufs = {}
+    for key, sc in (("a", a), ("b", b)):   # b is uploaded and launched while a's rollout may still be running: no sync in between
+        eng.set_scene(sc)
+        eng.rollout()
+        for n in names:
+            shp = eng.result_shape(n)
+            t = torch.empty(int(np.prod(shp)), dtype=torch.float32, pin_memory=True)
+            assert eng.get_async(n, t.data_ptr(), t.numel()) == t.numel()
+            bufs[(key, n)] = (t, shp)
+    eng.sync()
+    for (key, n), (t, shp) in bufs.items():
+        assert np.array_equal(t.numpy().reshape(shp), want[key][n]), (key, n)
+    assert eng.graph_stats() == (1, 1)
+    with pytest.raises(RuntimeError, match="not a per-agent result"):
+        eng.get_async("scene_tokens", bufs[("a", "traj")][0].data_ptr(), 16)
+    with pytest.raises(RuntimeError, match="too small"):
+        eng.get_async("traj", bufs[("a", "traj")][0].data_ptr(), 16)
+    eng.close()
+
+
+def test_a_batch_type_without_conditions_right_after_one_with_them_runs_without_the_condition_layers():
+    """Engine.set_scene skips the condition setters for types the batch does not carry (ps_set_scene cleared them): the result must
+    be that of an engine that never saw a condition."""
+    from prosim_amd.engine import Engine
+    spec = SMALL_SPEC
+    w = weights.init_weights(spec, 0)
+    withc = synth.make_scene(spec, 8, 24, batch=2, seed=95, goal=True, tags=True)
+    without = synth.make_scene(spec, 8, 24, batch=2, seed=96, goal=False)
+    eng = Engine(spec, w)
+    eng.set_scene(withc)
+    eng.rollout()
+    eng.set_scene(without)
+    eng.rollout()
+    got = eng.padded("traj")
+    eng.close()
+    assert np.array_equal(got, _fresh(spec, w, without, 0)[0])

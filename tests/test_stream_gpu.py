@@ -36,12 +36,17 @@ def test_pipeline_equals_single_engine_and_keeps_order():
             assert [i for i, _ in got] == list(range(len(scenes)))
             for (i, out), (traj, mp) in zip(got, want):
                 assert np.array_equal(out["traj"], traj) and np.array_equal(out["motion_pred"], mp), (depth, i)
-            # tickets keep counting across run() calls; an engine that is busy refuses another batch
+            # tickets keep counting across run() calls; a full pipeline (queue batches per engine) refuses another batch
             t0 = pipe.submit(scenes[0])
-            for _ in range(depth - 1):
+            for _ in range(pipe.capacity - 1):
                 pipe.submit(scenes[1])
             with pytest.raises(RuntimeError, match="collect it"):
                 pipe.submit(scenes[2])
             assert np.array_equal(pipe.collect(t0)["traj"], want[0][0])
             with pytest.raises(RuntimeError, match="not in flight"):
                 pipe.collect(t0)
+            if depth > 1:   # (t0 + 1 + depth is the second batch of the next engine: t0 + 1 is ahead of it)
+                with pytest.raises(RuntimeError, match="not the oldest"):
+                    pipe.collect(t0 + 1 + depth)
+            for k in range(1, pipe.capacity):   # every queued batch -- uploaded behind a rollout in flight on its engine -- is scenes[1]'s result
+                assert np.array_equal(pipe.collect(t0 + k)["traj"], want[1][0]), (depth, k)
