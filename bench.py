@@ -23,8 +23,11 @@ import time
 
 # The HIP runtime multiplexes its streams onto 4 hardware queues by default; the pipelined steps use one stream per engine
 # plus torch's, and with 4 queues the engines' graph replays serialise behind one another (4 engines in flight: 9.5 M
-# agent-steps/s with 4 queues, 16.7 M with 8).  Must be set before the runtime initialises.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# agent-steps/s with 4 queues, 16.7 M with 8).  Round 5: 16 -- every stream beyond the queue count SHARES a queue, and a job with
+# RCCL's streams beside the engines', the upload stream and torch's own crosses 8 (the forced-distributed line fell from 26.8 to
+# 15.4 M at 8 queues; prosim_amd/__init__.py sets the same default for every user of the package).  Must be set before the runtime
+# initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 import numpy as np
 import torch
@@ -133,6 +136,14 @@ def run_empty_rank(args, spec, n_scenes, world, backend, dev_index, multi):
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     agents = torch.tensor([0], device=dev, dtype=torch.float64)
     dist.all_reduce(agents)
+    # the per-rank diagnostic of the ranks that own scenes (main: `per_rank`): the same collectives, nothing to roll out
+    dist.barrier()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    gather(empty)
+    torch.cuda.synchronize()
+    mine = torch.tensor([0.0, 1e3 * (time.perf_counter() - t2)], device=dev, dtype=torch.float64)
+    dist.all_gather([torch.zeros_like(mine) for _ in range(world)], mine)
     gather(empty)                      # the final metric computation after the event-timed rollouts
     dist.barrier()
     dist.destroy_process_group()
@@ -290,6 +301,32 @@ def main():
     else:
         total_agents = A
     ms_per_step = 1e3 * dt / args.steps
+    graph_nodes = engines[0].graph_nodes   # (read while engine 0 still holds the graph it replayed in the timed region)
+    per_rank = None
+    if multi:
+        # Outside the timed region, for the reader of an N > 1 line: every rank's OWN step time with no collective in the loop
+        # (host launch contention between the ranks of a node shows up here) and what one metric all-gather costs it (the
+        # collective itself; the ranks enter it together).  A shortfall from N x the 1-GPU value is one or the other.
+        for e_ in engines:
+            e_.sync()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        for e_ in engines:
+            e_.sync()
+        local_ms = 1e3 * (time.perf_counter() - t1) / args.steps
+        dist.barrier()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        compute_metrics()
+        engines[state["last"][0]].sync()
+        torch.cuda.synchronize()
+        mine = torch.tensor([local_ms, 1e3 * (time.perf_counter() - t2)], device=red_dev, dtype=torch.float64)
+        allv = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allv, mine)
+        per_rank = {"local_ms_per_step_no_collective": [float(v[0]) for v in allv], "metric_all_gather_ms": [float(v[1]) for v in allv],
+                    "note": "measured after the timed region; a rank without a scene reports 0 for its step time"}
     # launch durations of the dominant kernel while the pipeline is full: the same loop again for 2 rounds of the engines with
     # an event pair around every policy launch (such rollouts are launched eagerly -- events do not survive graph replay
     # on ROCm 7.2 -- at ~1 ms of host time each against a 6 ms step), read after the last one
@@ -316,7 +353,6 @@ def main():
     if rank == 0:
         # dominant kernel: the fused policy attention chain (one launch per replan), timed with HIP
         # events on the engine's own stream
-        graph_nodes = eng.graph_nodes
         ms_chain = eng.time_policy_kernel(3)
         ec = eng.get("edge_counts")
         ms_roll, stages = eng.time_rollout(1, 5)
@@ -401,7 +437,7 @@ def main():
                 for _ in pipe.run(new_batches[:depth]):
                     pass
                 t_s = time.perf_counter()
-                n_b = sum(1 for _ in pipe.run(new_batches * 2))
+                n_b = sum(1 for _ in pipe.run(new_batches * 8))   # (48 batches: the pipeline's fill and drain -- 2 x depth batches deep -- stay a small part)
                 dt_s = time.perf_counter() - t_s
             streaming["agent_steps_per_s_by_depth"][str(depth)] = n_b * A * spec.max_steps / dt_s
             streaming["ms_per_batch_by_depth"][str(depth)] = 1e3 * dt_s / n_b
@@ -490,6 +526,8 @@ def main():
             "streaming": streaming,
             "rollout_metrics": metrics,
         }
+        if per_rank is not None:
+            out["per_rank"] = per_rank
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(spec, w, parts[0])
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]

@@ -8,9 +8,10 @@ from .spec import ModelSpec, DEMO_SPEC, SMALL_SPEC  # noqa: F401
 
 import os as _os
 
-# One hardware queue per engine stream.  The HIP runtime folds streams onto GPU_MAX_HW_QUEUES (default 4) hardware queues; a serving
-# process runs several engines (non-blocking streams) beside torch's own streams, and engines that share a queue serialise their
-# rollouts: 16 M instead of 27 M agent-steps/s with four rollouts in flight (tools/gpu_stream_variants.py, round 5).  Read by the
+# One hardware queue per stream.  The HIP runtime folds streams onto GPU_MAX_HW_QUEUES (default 4) hardware queues; a serving
+# process runs several engines (non-blocking streams) beside the upload stream, torch's own streams and RCCL's, and engines that
+# share a queue serialise their rollouts: 15 - 16 M instead of 27 M agent-steps/s with four rollouts in flight as soon as the
+# process holds more streams than queues (tools/gpu_stream_variants.py; four idle engines beside a depth-4 pipeline at 8 queues).  Read by the
 # runtime when the process makes its first HIP call, so it has to be in the environment before that -- importing this package first
 # is enough; a value the caller exported wins.
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")

@@ -123,6 +123,48 @@ __global__ __launch_bounds__(256) void k_upload_scatter(UpSegs g) {   // blockId
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) d4[i] = s4[i];
   if (blockIdx.x == 0 && threadIdx.x < (sg.bytes & 15)) sg.dst[(n16 << 4) + threadIdx.x] = sg.src[(n16 << 4) + threadIdx.x];
 }
+// Device-to-device copies and zero fills INSIDE a rollout are kernels, not hipMemcpyAsync / hipMemsetAsync (round 5).  As graph nodes
+// the runtime's copy / memset nodes proved fragile: an instantiated rollout graph replayed with the results of a rollout whose
+// resets had not run (agent poses not back at their initial values, trajectory state not cleared: deterministic, and wrong) after
+// an unrelated torch index_copy_ on the default stream of a process that had used RCCL -- while the same stages launched eagerly
+// stayed right (bench.py PS_BENCH_FORCE_DIST with the per-rank diagnostic; tools/gpu_race_hunt.py).  A graph of kernel nodes only
+// has nothing but in-queue ordering to rely on, and a 12-byte-per-agent copy is cheaper as a kernel than as an SDMA hop anyway.
+__global__ __launch_bounds__(256) void k_dev_copy(uint32_t* __restrict__ dst, const uint32_t* __restrict__ src, size_t n16, size_t n4) {
+  const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+  if (n16) {
+    const uint4* s4 = reinterpret_cast<const uint4*>(src);
+    uint4* d4 = reinterpret_cast<uint4*>(dst);
+    for (size_t i = i0; i < n16; i += stride) d4[i] = s4[i];
+  } else {
+    for (size_t i = i0; i < n4; i += stride) dst[i] = src[i];
+  }
+}
+__global__ __launch_bounds__(256) void k_dev_zero(uint32_t* __restrict__ dst, size_t n16, size_t n4) {
+  const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+  if (n16) {
+    uint4* d4 = reinterpret_cast<uint4*>(dst);
+    for (size_t i = i0; i < n16; i += stride) d4[i] = make_uint4(0u, 0u, 0u, 0u);
+  } else {
+    for (size_t i = i0; i < n4; i += stride) dst[i] = 0u;
+  }
+}
+// bytes: a multiple of 4 (every caller moves floats, ints or pairs of halfs); 16-byte pieces when pointers and size allow
+int dev_copy(hipStream_t st, void* dst, const void* src, size_t bytes) {
+  if (!bytes) return 0;
+  const bool v16 = ((uintptr_t)dst % 16 == 0) && ((uintptr_t)src % 16 == 0) && (bytes % 16 == 0);
+  const size_t n = v16 ? bytes / 16 : bytes / 4;
+  const unsigned grid = (unsigned)std::min<size_t>(512, (n + 255) / 256);
+  hipLaunchKernelGGL(k_dev_copy, dim3(grid), dim3(256), 0, st, static_cast<uint32_t*>(dst), static_cast<const uint32_t*>(src), v16 ? n : 0, v16 ? 0 : n);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+int dev_zero(hipStream_t st, void* dst, size_t bytes) {
+  if (!bytes) return 0;
+  const bool v16 = ((uintptr_t)dst % 16 == 0) && (bytes % 16 == 0);
+  const size_t n = v16 ? bytes / 16 : bytes / 4;
+  const unsigned grid = (unsigned)std::min<size_t>(512, (n + 255) / 256);
+  hipLaunchKernelGGL(k_dev_zero, dim3(grid), dim3(256), 0, st, static_cast<uint32_t*>(dst), v16 ? n : 0, v16 ? 0 : n);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
 // one upload stream per device and process (an extra stream PER ENGINE costs the pipelined loop more than it hides: DESIGN.md section 7, round 3)
 hipStream_t upload_stream(int device) {
   static std::mutex mu;
@@ -1207,7 +1249,7 @@ extern "C" int ps_set_scene(ps_engine* e, int32_t B, int32_t M, int32_t P, int32
       e->d_choice.ensure((size_t)R * A) || e->d_goal_prob.ensure((size_t)A * std::max(1, c.goal_pred_k)) ||
       e->d_goal_point.ensure((size_t)A * 2 * std::max(1, c.goal_pred_k)))
     return fail(PS_E_HIP, "device allocation failed");
-  HIPCHK(hipMemsetAsync(e->d_choice.p, 0, sizeof(int) * (size_t)R * A, st));   // mode 0 until ps_set_mode_choice
+  if (dev_zero(st, e->d_choice.p, sizeof(int) * (size_t)R * A)) return fail(PS_E_HIP, "device fill launch failed");   // mode 0 until ps_set_mode_choice
   e->have_noise = false;                                                        // no action noise until ps_set_action_noise
   // ---- edge sets: capacities from worst-case degrees
   auto mn = [](int a, int b) { return a < b ? a : b; };
@@ -2075,8 +2117,8 @@ extern "C" int ps_encode_scene(ps_engine* e) {
   hipStream_t st = e->stream;
   float* tok = e->d_tok.p;
   // agent token geometry back to the init poses (a previous rollout moved them)
-  HIPCHK(hipMemcpyAsync(e->d_tok_pos.p + 2 * (size_t)Mv, e->d_init_pos.p, sizeof(float) * 2 * A, hipMemcpyDeviceToDevice, st));
-  HIPCHK(hipMemcpyAsync(e->d_tok_ori.p + Mv, e->d_init_head.p, sizeof(float) * A, hipMemcpyDeviceToDevice, st));
+  if (dev_copy(st, e->d_tok_pos.p + 2 * (size_t)Mv, e->d_init_pos.p, sizeof(float) * 2 * A)) return fail(PS_E_HIP, "device copy launch failed");
+  if (dev_copy(st, e->d_tok_ori.p + Mv, e->d_init_head.p, sizeof(float) * A)) return fail(PS_E_HIP, "device copy launch failed");
   launch_pointnet(e, e->pn_map, e->d_map_input.p, e->d_map_mask.p, e->d_map_rows.p, Mv, e->P, 0, tok);
   launch_pointnet(e, e->pn_obs, e->d_obs_input.p, e->d_obs_mask.p, e->d_agent_rows.p, Ap, c.hist_steps, c.obs_dim, tok + (size_t)Mv * D);
   // knn graphs (attn_fusion.py:107-109) + rel-PE (:111-112).  Agent rows that only enter the scene with a later fut_obs
@@ -2174,15 +2216,15 @@ extern "C" int ps_generate_policy(ps_engine* e) {
   const int* pscene = e->d_tok_scene.p + Mv;
   // p2p: radius_graph over prompts, loop=False (sym_coord.py:86); candidates = the scene's agents,
   // positions taken from the prompt poses -> stage them as the agent token geometry
-  HIPCHK(hipMemcpyAsync(e->d_tok_pos.p + 2 * (size_t)Mv, ppos, sizeof(float) * 2 * A, hipMemcpyDeviceToDevice, st));
-  HIPCHK(hipMemcpyAsync(e->d_tok_ori.p + Mv, pori, sizeof(float) * A, hipMemcpyDeviceToDevice, st));
+  if (dev_copy(st, e->d_tok_pos.p + 2 * (size_t)Mv, ppos, sizeof(float) * 2 * A)) return fail(PS_E_HIP, "device copy launch failed");
+  if (dev_copy(st, e->d_tok_ori.p + Mv, pori, sizeof(float) * A)) return fail(PS_E_HIP, "device copy launch failed");
   // (with log-replay agents in the scene only the policy agents are prompts: candidate filter)
   const int pe_gen = use_c16(e, Ap, 1) ? 2 : 1;   // k_chain16 rebuilds the rel-PE rows from geometry records, k_attn_chain streams operand images
   launch_radius(e, e->e_p2p, e->d_r_agent.p, nullptr, ppos, pscene, Ap, c.dec_prompt_radius, c.dec_max_neigh, Mv, e->d_tok_ori.p, pori,
                 e->all_policy ? nullptr : (const int*)e->d_is_policy.p, Mv, pe_gen, pe_of(e, &e->e_p2p), c.rel_pos_knn != 0);
   // restore observed agent poses for the scene tokens, then s2p: radius over all scene tokens (:94)
-  HIPCHK(hipMemcpyAsync(e->d_tok_pos.p + 2 * (size_t)Mv, e->d_init_pos.p, sizeof(float) * 2 * A, hipMemcpyDeviceToDevice, st));
-  HIPCHK(hipMemcpyAsync(e->d_tok_ori.p + Mv, e->d_init_head.p, sizeof(float) * A, hipMemcpyDeviceToDevice, st));
+  if (dev_copy(st, e->d_tok_pos.p + 2 * (size_t)Mv, e->d_init_pos.p, sizeof(float) * 2 * A)) return fail(PS_E_HIP, "device copy launch failed");
+  if (dev_copy(st, e->d_tok_ori.p + Mv, e->d_init_head.p, sizeof(float) * A)) return fail(PS_E_HIP, "device copy launch failed");
   launch_radius(e, e->e_s2p, e->d_r_map.p, e->d_r_agent.p, ppos, pscene, Ap, c.dec_scene_radius, c.dec_max_neigh, -1,
                 e->d_tok_ori.p, pori, e->have_dead0 ? (const int*)e->d_live0.p : nullptr, Mv, pe_gen, pe_of(e, &e->e_s2p), c.rel_pos_knn != 0);
   // k|v of the (fixed) scene tokens for all s2p layers in one launch
@@ -2195,7 +2237,7 @@ extern "C" int ps_generate_policy(ps_engine* e) {
       if (launch_chain16(e, e->d_xp.p, Ap, e->d_steps.p + e->step_dec + 2 * i, 2, false, nullptr, false)) return PS_E_HIP;
     } else if (launch_chain(e, e->d_xp.p, Ap, e->step_dec + 2 * i, 2, md, false, nullptr, 0, 0, nullptr, xcd_on(2, false))) return PS_E_HIP;
   }
-  HIPCHK(hipMemcpyAsync(e->d_emd.p, e->d_xp.p, sizeof(float) * (size_t)Ap * D, hipMemcpyDeviceToDevice, st));
+  if (dev_copy(st, e->d_emd.p, e->d_xp.p, sizeof(float) * (size_t)Ap * D)) return fail(PS_E_HIP, "device copy launch failed");
   if (c.goal_pred_k > 0) {   // Decoder._goal_pred on the decoder's embedding (decoder/base.py:22-58, sym_coord.py:133-136)
     hipLaunchKernelGGL(k_mlp_rows, gmlp, dim3(128), 0, st, e->mlp_goal_prob, (const float*)e->d_xp.p, (const int*)nullptr, D,
                        e->d_goal_prob.p, c.goal_pred_k, c.ln_eps, Ap);
@@ -2207,13 +2249,13 @@ extern "C" int ps_generate_policy(ps_engine* e) {
     if (e->n_drag > 0)
       launch_pointnet(e, e->pn_drag, e->d_drag_in.p, e->d_drag_mask.p, nullptr, e->n_drag, e->drag_T, 0, e->d_drag_emd.p);
     if (e->n_cond_edges > 0) {   // (a present type whose entries are all masked off: the layers still run, without edges)
-      HIPCHK(hipMemsetAsync(e->e_cnd.rtA.p, 0, sizeof(_Float16) * (size_t)e->n_cond_tiles * 8192, st));
-      HIPCHK(hipMemsetAsync(e->e_cnd.rtT.p, 0, sizeof(_Float16) * (size_t)e->n_cond_tiles * 8192, st));
+      if (dev_zero(st, e->e_cnd.rtA.p, sizeof(_Float16) * (size_t)e->n_cond_tiles * 8192)) return fail(PS_E_HIP, "device fill launch failed");
+      if (dev_zero(st, e->e_cnd.rtT.p, sizeof(_Float16) * (size_t)e->n_cond_tiles * 8192)) return fail(PS_E_HIP, "device fill launch failed");
       hipLaunchKernelGGL(k_cond_edges, dim3(e->n_cond_edges), dim3(128), 0, st, e->cond, (const int*)e->d_ent_off.p,
                          (const int*)e->d_ent_type.p, (const float*)e->d_ent_val.p, (const float*)e->d_drag_emd.p, e->n_cond_edges,
                          (const CondEdge*)e->d_cond_edges.p, ppos, pori, e->e_cnd.rtA.p, e->e_cnd.rtT.p, c.ln_eps);
     }
-    HIPCHK(hipMemcpyAsync(e->d_xc.p, e->d_emd.p, sizeof(float) * (size_t)Ap * D, hipMemcpyDeviceToDevice, st));
+    if (dev_copy(st, e->d_xc.p, e->d_emd.p, sizeof(float) * (size_t)Ap * D)) return fail(PS_E_HIP, "device copy launch failed");
     for (int i = 0; i < c.cond_layers; ++i) {
       launch_kv(e, e->d_xc.p, Ap, e->L_cnd + i, 1, e->d_kv.p, e->d_kh.p, 0);
       if (launch_chain(e, e->d_xc.p, Ap, e->step_cnd + i, 1, e->e_cnd.maxdeg)) return PS_E_HIP;
@@ -2246,8 +2288,8 @@ extern "C" int ps_reset_rollout(ps_engine* e) {
   HIPCHK(hipSetDevice(e->cfg.device));
   const ps_config& c = e->cfg;
   hipStream_t st = e->stream;
-  HIPCHK(hipMemsetAsync(e->d_traj.p, 0, sizeof(float) * (size_t)e->A * e->stride_steps * 4, st));
-  HIPCHK(hipMemsetAsync(e->d_vel.p, 0, sizeof(float) * (size_t)e->A * e->stride_steps * 2, st));
+  if (dev_zero(st, e->d_traj.p, sizeof(float) * (size_t)e->A * e->stride_steps * 4)) return fail(PS_E_HIP, "device fill launch failed");
+  if (dev_zero(st, e->d_vel.p, sizeof(float) * (size_t)e->A * e->stride_steps * 2)) return fail(PS_E_HIP, "device fill launch failed");
   const int n = e->A * c.hist_steps;
   hipLaunchKernelGGL(k_init_state, dim3((n + 255) / 256), dim3(256), 0, st, (const float*)e->d_obs_input.p, (const int*)e->d_agent_rows.p,
                      e->A, c.hist_steps, c.obs_dim, e->stride_steps, e->d_traj.p, e->d_vel.p);
@@ -2529,8 +2571,8 @@ extern "C" int ps_update_obs(ps_engine* e, const float* obs_input, const uint8_t
       upload(d_ori, ori.data(), ori.size(), st))
     return fail(PS_E_HIP, "ps_update_obs upload failed");
   launch_pointnet(e, e->pn_obs, d_in.p, d_mk.p, nullptr, A, c.hist_steps, c.obs_dim, e->d_tok.p + (size_t)Mv * D);
-  HIPCHK(hipMemcpyAsync(e->d_tok_pos.p + 2 * (size_t)Mv, d_pos.p, sizeof(float) * 2 * A, hipMemcpyDeviceToDevice, st));
-  HIPCHK(hipMemcpyAsync(e->d_tok_ori.p + Mv, d_ori.p, sizeof(float) * A, hipMemcpyDeviceToDevice, st));
+  if (dev_copy(st, e->d_tok_pos.p + 2 * (size_t)Mv, d_pos.p, sizeof(float) * 2 * A)) return fail(PS_E_HIP, "device copy launch failed");
+  if (dev_copy(st, e->d_tok_ori.p + Mv, d_ori.p, sizeof(float) * A)) return fail(PS_E_HIP, "device copy launch failed");
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(st));
   d_in.release(); d_mk.release(); d_pos.release(); d_ori.release();
@@ -2547,7 +2589,7 @@ extern "C" int ps_set_map_tokens(ps_engine* e, const float* tokens, int64_t coun
   if (!tokens || count != (int64_t)e->Mv * D) return fail(PS_E_ARG, "ps_set_map_tokens: expected [map tokens, hidden] floats");
   HIPCHK(hipSetDevice(e->cfg.device));
   HIPCHK(hipMemcpyAsync(e->d_tok.p, tokens, sizeof(float) * (size_t)count, hipMemcpyHostToDevice, e->stream));
-  HIPCHK(hipMemsetAsync(e->d_tok.p + (size_t)e->Mv * D, 0, sizeof(float) * (size_t)e->A * D, e->stream));
+  if (dev_zero(e->stream, e->d_tok.p + (size_t)e->Mv * D, sizeof(float) * (size_t)e->A * D)) return fail(PS_E_HIP, "device fill launch failed");
   HIPCHK(hipStreamSynchronize(e->stream));
   e->encoded = true;
   e->generated = false;
@@ -3028,7 +3070,7 @@ extern "C" int ps_test_stream(ps_engine* e, int32_t mbytes, int32_t nwg, int32_t
   DevBuf<float> buf, out;
   const size_t n = (size_t)mbytes * 1024 * 1024 / 4;
   if (buf.ensure(n) || out.ensure(4096)) return fail(PS_E_HIP, "alloc");
-  HIPCHK(hipMemsetAsync(buf.p, 0, n * 4, e->stream));
+  if (dev_zero(e->stream, buf.p, n * 4)) return fail(PS_E_HIP, "device fill launch failed");
   hipEvent_t a, b;
   HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
   for (int it = -1; it < iters; ++it) {

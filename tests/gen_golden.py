@@ -104,7 +104,19 @@ FULL_CASES = {
     "small_nogoalloss_b2": ("small_nogoalloss", dict(n_agents=16, n_polylines=128, batch=2, seed=27, goal=True, tags=True, ragged=True), 0),
     "small_cluster_b2": ("small_cluster", dict(n_agents=16, n_polylines=128, batch=2, seed=21, goal=True, ragged=True, replay=0.3), 0),
     "small_mlphead_b2": ("small_mlphead", dict(n_agents=16, n_polylines=128, batch=2, seed=22, goal=True, tags=True, ragged=True), 0),
+    # Round 5 (missing 2): the REFERENCE itself at the sizes of the other BASELINE configs -- configs[1] (64 / 512,
+    # unconditional), configs[3] seed 0's two scenes (the ones tests/test_hip_parity.py rolls out), configs[4] (256 agents on a 100 m
+    # square, goal + tag prompts) and its no-truncation variant.  These are the workloads whose cut agents (#25 of cfg3 seed 0, #204 of
+    # the no-truncation scene, #254 of cfg4 seed 0 in round 4) had only the ORACLE to say that an fp32 run tosses a coin there: the
+    # fixtures keep the reference's own per-agent distance from the fp64 oracle (`ref_err_per_agent`), so a GPU test can say which
+    # side the reference's fp32 run landed on.  REPORT_ONLY: a reference run that leaves the fp64 trajectory at such a row is a
+    # finding to record, not a reason to refuse the fixture.
+    "demo_cfg1_seed0": ("demo", dict(n_agents=64, n_polylines=512, batch=1, seed=0), 0),
+    "demo_cfg3_seed0_b2": ("demo", dict(n_agents=128, n_polylines=1024, batch=2, seed=0, goal=True), 0),
+    "demo_cfg4_seed0": ("demo", dict(n_agents=256, n_polylines=1024, batch=1, seed=0, goal=True, tags=True, square=100.0), 0),
+    "demo_cfg4_notrunc": ("demo_notrunc4", dict(n_agents=256, n_polylines=1024, batch=1, seed=0, goal=True, tags=True, square=100.0), 0),
 }
+REPORT_ONLY = {"demo_cfg1_seed0", "demo_cfg3_seed0_b2", "demo_cfg4_seed0", "demo_cfg4_notrunc"}
 SPECS = {"small": SMALL_SPEC, "demo": DEMO_SPEC, "small_mlp": SMALL_SPEC.replace(obs_fusion="mlp"),
          "small_mlp_attn": SMALL_SPEC.replace(obs_fusion="mlp", obs_attn_update=True),
          "small_k3": SMALL_SPEC.replace(motion_k=3, rollout_top_k=3),
@@ -117,7 +129,9 @@ SPECS = {"small": SMALL_SPEC, "demo": DEMO_SPEC, "small_mlp": SMALL_SPEC.replace
          "small_novel": SMALL_SPEC.replace(pred_vel=False),
          "small_nogoalloss": SMALL_SPEC.replace(use_goal_pred_loss=False),
          "small_cluster": SMALL_SPEC.replace(k_pred_mode="cluster", motion_k=3, rollout_top_k=3),
-         "small_mlphead": SMALL_SPEC.replace(k_pred_mode="mlp", motion_k=2, rollout_top_k=2)}
+         "small_mlphead": SMALL_SPEC.replace(k_pred_mode="mlp", motion_k=2, rollout_top_k=2),
+         # tests/test_round2_gpu.py::test_no_truncation_variant's spec for configs[4]: caps >= every candidate count (256 + 1024)
+         "demo_notrunc4": DEMO_SPEC.replace(dec_max_neigh=1280, pol_max_neigh=max(DEMO_SPEC.pol_max_neigh, 1280))}
 TOPK_SEED = 777   # torch.manual_seed before a forward whose rollout draws modes
 
 
@@ -256,8 +270,15 @@ def gen_full():
         A0 = int(scene["prompt_mask"].sum())
         assert np.abs(ref["motion_pred"][:A0] - o["motion_pred"][:A0].numpy()).max() < 1e-4
         for k in floor:
-            assert ref64[k] < 3 * floor[k] + 1e-4, (k, ref64[k], floor[k])
-        np.savez_compressed(os.path.join(GOLD, f"ref_standins_{name}.npz"),
+            assert name in REPORT_ONLY or ref64[k] < 3 * floor[k] + 1e-4, (k, ref64[k], floor[k])
+        extra = {}
+        if name in REPORT_ONLY:   # per policy agent: the reference's and the fp32 oracle's closed-loop distance from the fp64 oracle
+            pmk = scene["prompt_mask"].astype(bool)
+            extra["ref_err_per_agent"] = np.abs(ref["traj"] - o64["traj"].numpy())[pmk].reshape(A, -1).max(1).astype(np.float32)
+            extra["oracle32_err_per_agent"] = np.abs(o["traj"].numpy() - o64["traj"].numpy())[pmk].reshape(A, -1).max(1).astype(np.float32)
+            print(name, "reference agents outside 1e-4 of the fp64 oracle:", np.nonzero(extra["ref_err_per_agent"] >= 1e-4)[0].tolist(),
+                  "| fp32 oracle:", np.nonzero(extra["oracle32_err_per_agent"] >= 1e-4)[0].tolist())
+        np.savez_compressed(os.path.join(GOLD, f"ref_standins_{name}.npz"), **extra,
                             traj=ref["traj"], vel=ref["vel"], motion_pred=ref["motion_pred"],
                             reconst_pred=ref["reconst_pred"][:A],
                             fp32_floor=np.array([floor["traj"], floor["vel"], floor["motion_pred"]]),
@@ -721,11 +742,12 @@ def write_manifest():
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
-    import atexit
-    atexit.register(write_manifest)
+    # (the manifest is written when a branch below has FINISHED -- an exception half-way must not bless what is there)
     if len(sys.argv) > 2 and sys.argv[1] == "only":
         FULL_CASES = {k: v for k, v in FULL_CASES.items() if k in sys.argv[2:]}
         gen_full()
+    elif len(sys.argv) > 1 and sys.argv[1] == "manifest":
+        pass   # (after a hand edit of known_cut_agents.json: only the manifest below)
     elif len(sys.argv) > 1 and sys.argv[1] == "near_cut":
         gen_near_cut()
     elif len(sys.argv) > 2 and sys.argv[1] == "cfg2_scenes":
@@ -761,3 +783,4 @@ if __name__ == "__main__":
         gen_goal_heads()
         gen_format("scene_1")
         gen_format("scene_0")
+    write_manifest()

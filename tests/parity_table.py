@@ -1,5 +1,5 @@
-"""Closed-loop parity numbers, collected by the -m gpu tests and written as ONE JSON table: gpurun_out/r04_parity.json on
-the GPU box (merged back by gpurun), copied to profiles/r04_parity.json for the record.  Per entry: replan-0 max error
+"""Closed-loop parity numbers, collected by the -m gpu tests and written as ONE JSON table: gpurun_out/r05_parity.json on
+the GPU box (merged back by gpurun), copied to profiles/r05_parity.json for the record.  Per entry: replan-0 max error
 (open loop), per-agent closed-loop max error of the trajectories: median / 99th percentile / max, the fraction of agents
 within 1e-4, and -- where the test computed it -- the fp32 floor (fp32 oracle against the fp64 oracle on the same scene)."""
 import json
@@ -30,18 +30,22 @@ def known_cut_agents(workload: str) -> set:
         return set(json.load(f).get(workload, []))
 
 
+PARITY_TABLE = "r05_parity.json"   # the table of this round: gpurun_out/ on the GPU box, profiles/ for the record
+
+
 def closed_loop_gate(workload: str, d: np.ndarray, tol: float = 1e-4):
-    """The closed-loop bar at what is measured: >= 99.5 % of the agents within 1e-4 (more outside only where the workload's committed cut list is that long), median below
-    2e-5 on the timed workload (3e-5 elsewhere), nobody beyond 2e-3, and every agent outside the band is on the committed list of that workload's cut agents."""
+    """The closed-loop bar at what is measured: every agent outside the 1e-4 band is on the committed list of that workload's cut
+    agents, AND at most 0.5 % of the agents are outside -- a bound of its own, which the list cannot widen (round 4's form,
+    max(0.5 %, len(list)), could never fail once the first assertion held: ADVICE round 4) --, median below 2e-5 on the timed
+    workload (3e-5 elsewhere), nobody beyond 2e-3.  No workload needs an exception today: the two listed agents (cfg3 seed 0 #25,
+    no-truncation cfg4 #204) are 1 of 256 each."""
     d = np.asarray(d, np.float64)
     outside = set(int(i) for i in np.nonzero(d >= tol)[0])
-    new = outside - known_cut_agents(workload)
-    assert not new, f"{workload}: agents {sorted(new)} left the {tol:g} band (errors {[float(d[i]) for i in sorted(new)]}); known cut agents: {sorted(known_cut_agents(workload))}"
-    # >= 99.5 % inside the band.  The only workloads that may have more outside are the ones whose COMMITTED list is itself longer than
-    # 0.5 % of their agents (today one: the dense 256-agent no-truncation configs[4] scene, agents 79 and 204 -- its fp64 rollout has 16
-    # relative angles within 2e-5 rad of a cut, one of 204's own edges passes 4.7e-7 rad from it; tests/golden/near_cut_rows.json) --
-    # a per-workload exception that lives in known_cut_agents.json, not a rule about small workloads.
-    assert len(outside) <= max(int(0.005 * d.size), len(known_cut_agents(workload))), (workload, sorted(outside), float((d < tol).mean()))
+    known = known_cut_agents(workload)
+    new = outside - known
+    assert not new, f"{workload}: agents {sorted(new)} left the {tol:g} band (errors {[float(d[i]) for i in sorted(new)]}); known cut agents: {sorted(known)}"
+    assert len(outside) <= int(0.005 * d.size), (workload, sorted(outside), float((d < tol).mean()))
+    assert len(known) <= max(1, int(0.005 * d.size)), (workload, sorted(known))   # the list itself stays within the bar it excuses
     # median: 2e-5 on the timed workload (measured 1.5e-5); the 64-agent config sits at 2.5e-5 (its fp32 oracle: 2.4e-5)
     med_bar = 2e-5 if workload.startswith("bench_workload") else 3e-5
     assert np.median(d) < med_bar and d.max() < 2e-3, (workload, float(np.median(d)), float(d.max()))
@@ -51,7 +55,7 @@ def record(name: str, **fields):
     _ROWS[name] = fields
     out_dir = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out_dir, exist_ok=True)
-    path = os.path.join(out_dir, "r04_parity.json")
+    path = os.path.join(out_dir, PARITY_TABLE)
     table = {}
     if os.path.exists(path):
         try:

@@ -31,7 +31,22 @@ def test_every_fixture_matches_the_manifest():
     assert sorted(set(want) - set(have)) == [], "listed in MANIFEST.sha256 but missing"
     assert sorted(set(have) - set(want)) == [], "under tests/golden/ but not in MANIFEST.sha256 (run tests/gen_golden.py)"
     changed = sorted(k for k in want if want[k] != have[k])
-    assert changed == [], f"fixtures differ from what gen_golden.py last wrote: {changed}"
+    assert changed == [], ("fixtures differ from what gen_golden.py last wrote: " +
+                           "; ".join(f"{k} (owner: {_owner(k)})" for k in changed))
+
+
+def _owner(rel: str) -> str:
+    """Which command rewrites a fixture -- and with it the manifest (the failure should say where to look)."""
+    if rel.endswith(".json") and not rel.startswith("oracle_cache/"):
+        return ("hand-edited list: re-run `python tests/gen_golden.py manifest` after editing"
+                if rel == "known_cut_agents.json" else "python tests/gen_golden.py near_cut")
+    if rel.startswith("oracle_cache/"):
+        return "python tests/gen_golden.py oracle_cache"
+    if rel.startswith("ref_standins_"):
+        return "python tests/gen_golden.py only " + rel[len("ref_standins_"):-len(".npz")]
+    if rel.startswith("ref_format_") or rel.startswith("demo_"):
+        return "python tests/gen_golden.py format | tracks | map"
+    return "python tests/gen_golden.py (the branch that writes it; no argument = the pure primitives)"
 
 
 def test_agent_tables_carry_every_column_the_script_writes():

@@ -17,7 +17,7 @@ import torch
 from prosim_amd import synth, weights
 from prosim_amd.spec import DEMO_SPEC, SMALL_SPEC
 from oracle import prosim_oracle as orc
-from gen_golden import FULL_CASES, SPECS, digest
+from gen_golden import FULL_CASES, REPORT_ONLY, SPECS, digest
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
@@ -143,7 +143,8 @@ def test_radius_cap_truncation_index_order():
 
 
 # ------------------------------------------------------------------ full rollouts vs golden fixtures
-@pytest.mark.parametrize("name", list(FULL_CASES))
+# (the four full-size REPORT_ONLY fixtures of round 5 have their own test with the cut-agent gate: tests/test_round5_gpu.py)
+@pytest.mark.parametrize("name", [n for n in FULL_CASES if n not in REPORT_ONLY])
 def test_rollout_vs_reference_fixture(name):
     from prosim_amd.engine import Engine
     sname, kw, wseed = FULL_CASES[name]

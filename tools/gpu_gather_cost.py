@@ -2,7 +2,7 @@
 4-engines-in-flight loop with (a) nothing, (b) the slot scatter, (c) the gather's copies, on the default stream and on a
 side stream.  Prints ms per step and the host time spent inside the gather calls."""
 import os, sys, time
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from prosim_amd import synth, weights

@@ -3,7 +3,7 @@ whose CU-time table (tools/prof_cu_time.py) holds this workload only.  PS_IMPL=3
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 import numpy as np
 from prosim_amd import synth, weights
 from prosim_amd.spec import DEMO_SPEC
