@@ -2386,7 +2386,16 @@ extern "C" int ps_policy_step(ps_engine* e, int32_t t_idx) {
     float* mp_out = e->d_motion.p + (size_t)t_idx * A * c.motion_k * c.target_steps * c.state_dim;
     const float* nz = e->have_noise ? (const float*)(e->d_noise.p + (size_t)t_idx * A * c.motion_k * c.target_steps * 2) : (const float*)nullptr;
     const int vcol = c.no_pred_vel ? -1 : (c.pred_gmm ? 6 : 3);
-    if (c.motion_k == 1 && !c.k_pred_mlp && !e->legacy_rows) {
+    if (c.motion_k == 1 && !c.k_pred_mlp && !e->legacy_rows && A <= 128 && c.target_steps <= 256 && c.target_steps * c.state_dim <= 128) {
+      // few agents (a single scene): one workgroup per agent, fp32 GEMVs with register-streamed weights -- the row-tile head below
+      // would run on A / 64 workgroups and wait for its LDS stage fills (35 -> 17 us per replan at 128 agents: 4.41 -> 4.25 ms per
+      // single-scene rollout).  By the agent count alone: the bits of a scene do not depend on the engine mode.  (Up to ONE scene of
+      // 128 agents: at 256 rows the row-tile kernel has four workgroups and is as fast -- and configs[3] seed 0's two scenes hold a
+      // cluster of near-cut agents that another fp32 summation order re-rolls, as the reference's own fp32 run does there:
+      // tests/golden/ref_standins_demo_cfg3_seed0_b2.npz.)
+      hipLaunchKernelGGL(k_policy_head_row, dim3(A), dim3(256), 0, st, e->head, (const float*)e->d_fused.p, (const int*)e->d_agent_type.p, A,
+                         c.target_steps, c.state_dim, mp_out, e->d_traj.p, e->d_vel.p, e->stride_steps, last, c.replan_freq, c.ln_eps, nz, vcol);
+    } else if (c.motion_k == 1 && !c.k_pred_mlp && !e->legacy_rows) {
       // row-tile head (ps_rowtile.h): a wave carries 16 agents through CG_decode and the motion head in registers
       hipLaunchKernelGGL(k_policy_head_rt, dim3((A + 63) / 64), dim3(256), RT_LDS_BYTES, st, e->head, (const float*)e->d_fused.p,
                          (const int*)e->d_agent_type.p, A, c.target_steps, c.state_dim, mp_out, e->d_traj.p, e->d_vel.p, e->stride_steps, last,

@@ -827,4 +827,129 @@ __global__ __launch_bounds__(256, 1) void k_policy_head_rt(HeadW w, const float*
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// The same head for FEW agents (round 5; K = 1): one 4-wave workgroup per agent, every Linear a wave-local fp32 GEMV whose
+// weights stream through registers one stage ahead (the machinery of k_attn_chain's node stages, ps_attn.h).  The row-tile
+// kernel above needs a workgroup per 64 agents and is bound by its stage fills (six 64 KB weight stages by LDS-DMA at ~15 B/clk per
+// CU: 35 us per replan on the TWO workgroups of a 128-agent scene, 6 % of that scene's rollout); here 128 workgroups pull the
+// 320 KB of head weights at the per-CU register-streaming rate each (~42 B/clk).  Chosen by the agent count alone (<= 128 rows:
+// ps_policy_step), so a scene's bits do not depend on the engine mode.  CG_stacked / motion head / tail: the operations of
+// k_policy_head_rt, fp32 FMAs instead of split-fp16 MFMAs.
+__global__ __launch_bounds__(256) void k_policy_head_row(HeadW w, const float* __restrict__ fused, const int* __restrict__ agent_type, int n_agents,
+                                                         int steps, int sdim, float* __restrict__ motion_pred, float* __restrict__ traj,
+                                                         float* __restrict__ vel, int stride_steps, int last, int replan, float eps,
+                                                         const float* __restrict__ noise, int vcol) {
+  __shared__ __attribute__((aligned(16))) float xin[128], ctx[128], y[128], h64[64], o[128];
+  const int ag = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // N = 128 GEMVs (K = 128 or 64): wave -> 32 output columns, lane -> (column quad c8, k-group kgl); N = 64: wave -> 16 columns
+  const int c8 = lane & 7, kgl = lane >> 3, ncol = wave * 32 + 4 * c8;
+  const int c4 = lane & 3, kg4 = lane >> 2, ncol4 = wave * 16 + 4 * c4;
+  const size_t woff = (size_t)(kgl * 16) * 128 + ncol;
+  WC<16> wa, wb;
+  wload(wa, w.cgWt[0] + woff, 128);
+  if (tid < 128) {
+    xin[tid] = ldg1(w.anchors + (size_t)(agent_type[ag] - 1) * 128 + tid);   // anchor of (type, mode 0)   (act_decoder.py:66-68)
+    ctx[tid] = ldg1(fused + (size_t)ag * 128 + tid);
+  }
+  __syncthreads();
+  auto stage128 = [&](const WC<16>& cur, const float* __restrict__ bias) {   // y = W x + b over K = 128
+    float acc[1][4];
+    zero_acc<1>(acc);
+    wfma<1, 16>(cur, xin + kgl * 16, 128, acc);
+    fold_kgroups<1, 8>(acc);
+    if (kgl == 0) *reinterpret_cast<float4*>(y + ncol) = make_float4(acc[0][0] + bias[ncol], acc[0][1] + bias[ncol + 1], acc[0][2] + bias[ncol + 2], acc[0][3] + bias[ncol + 3]);
+    __syncthreads();
+  };
+  // CG_stacked(3): block i: y = relu(LN(W inp + b)) * context; with one mode the context's maximum over the modes is y itself
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    WC<16>& cur = (i & 1) ? wb : wa;
+    WC<16>& nxt = (i & 1) ? wa : wb;
+    wload(nxt, (i < 2 ? w.cgWt[i + 1] : w.m0t) + woff, 128);   // (weights do not depend on activations: one stage ahead)
+    stage128(cur, w.cgb[i]);
+    if (wave == 0) ln_row_wave(y, y, w.cglnw[i], w.cglnb[i], eps, lane, true);
+    __syncthreads();
+    if (tid < 128) {
+      const float yy = y[tid] * ctx[tid];
+      const float fi = (float)i, fd = (float)(i + 1);
+      const float v = i == 0 ? yy : (xin[tid] * fi + yy) / fd;
+      const float cv = i == 0 ? yy : (ctx[tid] * fi + yy) / fd;
+      xin[tid] = v;
+      ctx[tid] = cv;
+    }
+    __syncthreads();
+  }
+  // motion_head: 128 -> 128 (LN, ReLU) -> 64 (LN, ReLU) -> steps * sdim (zero-padded to 128 columns; its bias joins in the tail)
+  WC<8> wc, wd;
+  wload(wc, w.m1t + (size_t)(kg4 * 8) * 64 + ncol4, 64);
+  stage128(wb, w.m0b);   // (after three blocks the motion head's first Linear sits in wb)
+  if (wave == 0) ln_row_wave(y, y, w.m0lnw, w.m0lnb, eps, lane, true);
+  __syncthreads();
+  wload(wd, w.m2t + (size_t)(kgl * 8) * 128 + ncol, 128);
+  {
+    float acc[1][4];
+    zero_acc<1>(acc);
+    wfma<1, 8>(wc, y + kg4 * 8, 128, acc);
+    fold_kgroups<1, 4>(acc);
+    if (kg4 == 0) *reinterpret_cast<float4*>(h64 + ncol4) = make_float4(acc[0][0] + w.m1b[ncol4], acc[0][1] + w.m1b[ncol4 + 1], acc[0][2] + w.m1b[ncol4 + 2], acc[0][3] + w.m1b[ncol4 + 3]);
+  }
+  __syncthreads();
+  if (wave == 0) {   // LayerNorm over 64 + ReLU: one element per lane
+    const float a = h64[lane];
+    const float mean = wave_sum(a) * (1.f / 64.f);
+    const float d = a - mean;
+    const float rstd = 1.f / sqrtf(wave_sum(d * d) * (1.f / 64.f) + eps);
+    h64[lane] = fmaxf(fmaf(d * rstd, w.m1lnw[lane], w.m1lnb[lane]), 0.f);
+  }
+  __syncthreads();
+  {
+    float acc[1][4];
+    zero_acc<1>(acc);
+    wfma<1, 8>(wd, h64 + kgl * 8, 64, acc);
+    fold_kgroups<1, 8>(acc);
+    if (kgl == 0) *reinterpret_cast<float4*>(o + ncol) = make_float4(acc[0][0], acc[0][1], acc[0][2], acc[0][3]);
+  }
+  __syncthreads();
+  // cumsum over steps of (dx, dy, dtheta); wrap theta (act_decoder.py:117-121): thread s re-adds the prefix in step order (k_policy_head_rt's tail)
+  if (tid < steps) {
+    const int s = tid;
+    const float* ob = w.m2b;
+    float cx = 0.f, cy = 0.f, ch = 0.f;
+    const float* nz = noise ? noise + (size_t)ag * steps * 2 : nullptr;
+    for (int j = 0; j <= s; ++j) {
+      const float dx = o[j * sdim] + ob[j * sdim], dy = o[j * sdim + 1] + ob[j * sdim + 1];
+      cx += nz ? dx + nz[2 * j] : dx;
+      cy += nz ? dy + nz[2 * j + 1] : dy;
+      ch += o[j * sdim + 2] + ob[j * sdim + 2];
+    }
+    const float hh = wrap_angle(ch);
+    float* mp = motion_pred + (size_t)ag * steps * sdim + s * sdim;
+    mp[0] = cx;
+    mp[1] = cy;
+    mp[2] = hh;
+    for (int f = 3; f < sdim; ++f) mp[f] = o[s * sdim + f] + ob[s * sdim + f];
+    if (s < replan) {
+      // step_agent_traj (traj_sam.py:322-347): rotate into the agent-init frame, append
+      const float* cur = traj + ((size_t)ag * stride_steps + last - 1) * 4;
+      const float c0 = cur[0], c1 = cur[1];
+      const float lth = atan2f(cur[2], cur[3]);
+      const float cl = cosf(lth), sl = sinf(lth);
+      float* t = traj + ((size_t)ag * stride_steps + last + s) * 4;
+      float* v = vel + ((size_t)ag * stride_steps + last + s) * 2;
+      t[0] = (cx * cl - cy * sl) + c0;
+      t[1] = (cy * cl + cx * sl) + c1;
+      const float pth = wrap_angle(lth + hh);
+      t[2] = sinf(pth);
+      t[3] = cosf(pth);
+      if (vcol >= 0) {
+        const float vx = o[s * sdim + vcol] + ob[s * sdim + vcol], vy = o[s * sdim + vcol + 1] + ob[s * sdim + vcol + 1];
+        v[0] = vx * cl - vy * sl;
+        v[1] = vy * cl + vx * sl;
+      }
+    }
+  }
+}
+
 }  // namespace ps
