@@ -382,6 +382,7 @@ struct ps_engine {
   // whole-rollout hipGraph (captured on the first ps_rollout after a scene / condition change)
   hipGraph_t graph = nullptr;
   hipGraphExec_t graph_exec = nullptr;
+  int force_mt = 0;           // ps_test_pointnet_mt (test hook): row tiles per wave of the row-tile PointNet, -1 = the staged kernel
   int node_mt = 0;            // ps_set_row_impl(10 + mt): row tiles per wave of the row-tile node kernels forced to mt (experiments, tests)
   bool wg_edges = false;      // ps_set_row_impl(2): the split path's edge half on the 16-row workgroup kernel (k_edge16) instead of k_edge_rows (A/B, cross-check)
   bool legacy_rows = false;   // ps_set_row_impl(1): the round-3 staged row kernels (k_pointnet_mfma, k_node) instead of the row-tile ones (A/B and parity tools)
@@ -968,11 +969,14 @@ extern "C" int ps_create(const ps_config* cfg, int32_t n_tensors, const char* co
   PS_RT_ATTR((k_pointnet_rt<1, 4>)); PS_RT_ATTR((k_pointnet_rt<1, 8>)); PS_RT_ATTR((k_pointnet_rt<1, 16>)); PS_RT_ATTR((k_pointnet_rt<2, 8>));
   PS_RT_ATTR((k_pointnet_rt<2, 16>)); PS_RT_ATTR((k_pointnet_rt<3, 4>)); PS_RT_ATTR((k_pointnet_rt<3, 8>)); PS_RT_ATTR((k_pointnet_rt<4, 8>));
   PS_RT_ATTR((k_pointnet_rt<5, 4>));
-  PS_RT_ATTR(k_node_pre_rt<1>); PS_RT_ATTR(k_node_pre_rt<2>); PS_RT_ATTR(k_node_pre_rt<3>);
+  PS_RT_ATTR(k_node_pre_rt<1>); PS_RT_ATTR(k_node_pre_rt<2>);
+#ifdef PS_EXPERIMENTS   // (cross-check builds only, round 5: the 3-tile node halves spill 292 - 656 B per lane and k_edge16 is never selected)
+  PS_RT_ATTR(k_node_pre_rt<3>); PS_RT_ATTR(k_node_post_rt<3>);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_edge16), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c16_edge_lds_bytes());
+#endif
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_edge_rows), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ER_LDS_BYTES);
   PS_RT_ATTR(k_policy_head_rt);
-  PS_RT_ATTR(k_node_post_rt<1>); PS_RT_ATTR(k_node_post_rt<2>); PS_RT_ATTR(k_node_post_rt<3>);
+  PS_RT_ATTR(k_node_post_rt<1>); PS_RT_ATTR(k_node_post_rt<2>);
 #undef PS_RT_ATTR
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pe_learn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PL_LDS_BYTES);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_node<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ND_LDS_BYTES);
@@ -1778,16 +1782,24 @@ int launch_split_layer(ps_engine* e, float* x, int Nd, const ChainStep* stp, int
     const dim3 gr((unsigned)(((tiles + mt - 1) / mt + 3) / 4));
     if (mt == 1) hipLaunchKernelGGL(k_node_pre_rt<1>, gr, dim3(256), RT_LDS_BYTES, st, (const float*)x, Nd, stp, io, eps, kv_out, khl_out);
     else if (mt == 2) hipLaunchKernelGGL(k_node_pre_rt<2>, gr, dim3(256), RT_LDS_BYTES, st, (const float*)x, Nd, stp, io, eps, kv_out, khl_out);
+#ifdef PS_EXPERIMENTS
     else hipLaunchKernelGGL(k_node_pre_rt<3>, gr, dim3(256), RT_LDS_BYTES, st, (const float*)x, Nd, stp, io, eps, kv_out, khl_out);
+#else
+    else return fail(PS_E_ARG, "3 row tiles per wave: experiments builds only");
+#endif
     static const bool skip_edge = exp_env("PS_SKIP_S2S_EDGE") != nullptr;   // experiments only (timing; wrong results)
     if (skip_edge) {}
+#ifdef PS_EXPERIMENTS
     else if (geo_edges && e->wg_edges) hipLaunchKernelGGL(k_edge16, dim3((unsigned)tiles), dim3(512), c16_edge_lds_bytes(), st, Nd, stp, io, (const float*)e->div32);
+#endif
     else if (geo_edges) hipLaunchKernelGGL(k_edge_rows, dim3((unsigned)((Nd + ER_WAVES - 1) / ER_WAVES)), dim3(64 * ER_WAVES), ER_LDS_BYTES, st, Nd, stp, io, (const float*)e->div32, xcd_on(3, true) ? 1 : 0);
     else if (maxdeg <= 32) hipLaunchKernelGGL((k_edge_small<3, 2>), ge, dim3(256), es_lds_bytes<2>(), st, Nd, stp, io);
     else hipLaunchKernelGGL((k_edge_small<3, 8>), ge, dim3(256), es_lds_bytes<8>(), st, Nd, stp, io);
     if (mt == 1) hipLaunchKernelGGL(k_node_post_rt<1>, gr, dim3(256), RT_LDS_BYTES, st, x, Nd, stp, io, eps);
     else if (mt == 2) hipLaunchKernelGGL(k_node_post_rt<2>, gr, dim3(256), RT_LDS_BYTES, st, x, Nd, stp, io, eps);
+#ifdef PS_EXPERIMENTS
     else hipLaunchKernelGGL(k_node_post_rt<3>, gr, dim3(256), RT_LDS_BYTES, st, x, Nd, stp, io, eps);
+#endif
   } else if (kr == 3) {
     hipLaunchKernelGGL(k_node<3>, gn, dim3(256), ND_LDS_BYTES, st, x, Nd, none, stp, io, eps, kv_out, khl_out);
     if (maxdeg <= 32) hipLaunchKernelGGL((k_edge_small<3, 2>), ge, dim3(256), es_lds_bytes<2>(), st, Nd, stp, io);
@@ -1902,14 +1914,15 @@ void launch_kv(ps_engine* e, const float* x, int Ns, int layer0, int nlayers, fl
 // Row-tile PointNet (ps_rowtile.h): a polyline's P points take L lanes x MT row tiles (MT L >= P), a wave G = 16 / L polylines.
 // (MT, L) by the row count: enough waves for the chip's 1024 SIMDs first, then the layout that wastes the fewest slots
 // (P = 19: 5 tiles x 4 lanes = 20 slots; P = 11: 3 x 4 = 12 when there are many polylines, 1 x 16 when there are few).
-int g_force_mt = 0;   // test hook (ps_test_pointnet_mt): row tiles per wave, -1 = the staged kernel
+// (force_mt: ps_engine::force_mt, the test hook of ps_test_pointnet_mt -- row tiles per wave, -1 = the staged kernel; per ENGINE since
+// round 5: as a process global a test call on one engine changed the PointNet of every engine of the process)
 struct RtShape { int mt, l; };
 constexpr RtShape kRtShapes[] = {{1, 4}, {1, 8}, {1, 16}, {2, 8}, {2, 16}, {3, 4}, {3, 8}, {4, 8}, {5, 4}};   // the builds in the library: every P <= 32 fits (2, 16)
-RtShape pointnet_shape(int n_rows, int P, bool throughput) {
+RtShape pointnet_shape(int n_rows, int P, bool throughput, int force_mt) {
   RtShape best{0, 0};
   double best_cost = 0;
   for (const RtShape& sh : kRtShapes) {
-    if (g_force_mt >= 1 && sh.mt != g_force_mt) continue;
+    if (force_mt >= 1 && sh.mt != force_mt) continue;
     if (sh.mt * sh.l < P) continue;
     const long waves = (n_rows + 16 / sh.l - 1) / (16 / sh.l);
     const long rounds = (waves + 1023) / 1024;   // one 4-wave workgroup per CU (128 KB of weight stages)
@@ -1931,8 +1944,8 @@ void launch_pointnet_rt(ps_engine* e, const PointNetW& w, const float* pts, cons
 void launch_pointnet(ps_engine* e, const PointNetW& w, const float* pts, const uint8_t* mask, const int* rows, int n_rows,
                      int P, int feat_mask_dim, float* out) {
   if (n_rows <= 0) return;
-  if (!e->legacy_rows && g_force_mt >= 0 && w.n_pre >= 1 && w.n_mid >= 1 && w.in_dim <= 32) {
-    const RtShape sh = pointnet_shape(n_rows, P, e->chain_rows >= 8);
+  if (!e->legacy_rows && e->force_mt >= 0 && w.n_pre >= 1 && w.n_mid >= 1 && w.in_dim <= 32) {
+    const RtShape sh = pointnet_shape(n_rows, P, e->chain_rows >= 8, e->force_mt);
 #define PS_RT(MT_, L_) if (sh.mt == MT_ && sh.l == L_) { launch_pointnet_rt<MT_, L_>(e, w, pts, mask, rows, n_rows, P, feat_mask_dim, out); return; }
     PS_RT(1, 4) PS_RT(1, 8) PS_RT(1, 16) PS_RT(2, 8) PS_RT(2, 16) PS_RT(3, 4) PS_RT(3, 8) PS_RT(4, 8) PS_RT(5, 4)
 #undef PS_RT
@@ -2073,8 +2086,10 @@ void launch_radius(ps_engine* e, const RadArgs* a, int nsets, const float* qpos,
   }
   const int wpb = 4, grid = (nq + wpb - 1) / wpb;
   hipStream_t st = e->stream;
+  rs.scanned = nq > CSR_PREFIX_MAX_Q ? 1 : 0;
   if (knn) {   // MODEL.REL_POS_EDGE_FUNC 'knn': the cap nearest instead of the first cap inside the radius (same CSR plumbing)
     hipLaunchKernelGGL(k_knn_sets<0>, dim3(grid, nsets), dim3(64 * wpb), 0, st, rs, qpos, qscene, nq);
+    if (rs.scanned) hipLaunchKernelGGL(k_exclusive_scan, dim3(nsets), dim3(1024), 0, st, rs, nq);
     hipLaunchKernelGGL(k_knn_sets<1>, dim3(grid, nsets), dim3(64 * wpb), 0, st, rs, qpos, qscene, nq);
   } else {
     hipLaunchKernelGGL(k_radius<0>, dim3(grid, nsets), dim3(64 * wpb), 0, st, rs, qpos, qscene, nq);
@@ -2082,7 +2097,8 @@ void launch_radius(ps_engine* e, const RadArgs* a, int nsets, const float* qpos,
       if (a[i].self_base >= 0)
         hipLaunchKernelGGL(k_radius_selfrank, dim3(grid), dim3(64 * wpb), 0, st, rs.s[i].cs, qpos, qscene, nq, rs.s[i].r2, a[i].cap,
                            a[i].self_base, a[i].es->cnt.p, a[i].cand_ok, a[i].cand_base);
-    // (no scan launch: the fill pass computes its own prefix, csr_prefix)
+    // (no scan launch up to CSR_PREFIX_MAX_Q queries: the fill pass computes its own prefix, csr_prefix)
+    if (rs.scanned) hipLaunchKernelGGL(k_exclusive_scan, dim3(nsets), dim3(1024), 0, st, rs, nq);
     hipLaunchKernelGGL(k_radius<1>, dim3(grid, nsets), dim3(64 * wpb), 0, st, rs, qpos, qscene, nq);
   }
   PeArgs pe[2];
@@ -2451,7 +2467,7 @@ std::vector<uint64_t> rollout_signature(const ps_engine* e) {
   for (long long v : {(long long)e->all_policy, (long long)e->have_log, (long long)e->have_dead0, (long long)e->have_fut, (long long)e->have_noise,
                       (long long)e->have_cond, (long long)e->n_cond_edges, (long long)e->n_cond_tiles, (long long)e->n_drag, (long long)e->drag_T,
                       (long long)e->node_mt, (long long)e->wg_edges, (long long)e->legacy_rows, (long long)e->chain_rows, (long long)e->chain_impl,
-                      (long long)g_force_mt, (long long)e->step_a2a, (long long)e->step_s2s, (long long)e->step_dec, (long long)e->step_cnd,
+                      (long long)e->force_mt, (long long)e->step_a2a, (long long)e->step_s2s, (long long)e->step_dec, (long long)e->step_cnd,
                       (long long)e->step_pol, (long long)e->step_upd})
     I(v);
   I((long long)e->h_steps.size());
@@ -2631,7 +2647,13 @@ extern "C" int ps_set_row_impl(ps_engine* e, int32_t impl) {
   if (!e) return fail(PS_E_ARG, "null engine");
   if (impl != 0 && impl != 1 && impl != 2 && !(impl >= 11 && impl <= 13))
     return fail(PS_E_ARG, "ps_set_row_impl: 0 = row-tile kernels (default), 1 = the round-3 staged kernels, 2 = row-tile kernels with the workgroup edge kernel, 11..13 = row-tile kernels with 1..3 row tiles per wave in the node halves");
+#ifndef PS_EXPERIMENTS
+  // round 5: the kernels behind 2 (k_edge16) and 13 (the 3-tile node halves: 292 - 656 B of scratch per lane) exist
+  // for cross-checks only and are compiled into experiments builds (hipcc -DPS_EXPERIMENTS), not into the product library
+  if (impl == 2 || impl == 13) return fail(PS_E_ARG, "ps_set_row_impl(2 | 13): experiments build only (hipcc -DPS_EXPERIMENTS, tools/README.md)");
+#endif
   drop_graph(e);
+  e->encoded = e->generated = false;   // (as ps_set_chain_impl: the s2s path of the encoder depends on it)
   e->legacy_rows = impl == 1;
   e->wg_edges = impl == 2;
   e->node_mt = impl >= 11 ? impl - 10 : 0;
@@ -2916,7 +2938,9 @@ extern "C" int ps_test_pointnet_mt(ps_engine* e, int32_t which, int32_t n_poly, 
   if (upload(dx, x, (size_t)n_poly * P * w.in_dim, e->stream) || upload(dm, point_mask, (size_t)n_poly * P, e->stream) ||
       dout.ensure((size_t)n_poly * D))
     return fail(PS_E_HIP, "test upload failed");
-  g_force_mt = mt;
+  if (mt >= 1 && !pointnet_shape(n_poly, P, false, mt).mt)   // (a forced tiling without a build for this P used to fall back to the staged kernel silently)
+    return fail(PS_E_ARG, "ps_test_pointnet_mt: no row-tile build with " + std::to_string(mt) + " tiles per wave holds " + std::to_string(P) + " points");
+  e->force_mt = mt;
   launch_pointnet(e, w, dx.p, dm.p, nullptr, n_poly, P, 0, dout.p);
   HIPCHK(hipStreamSynchronize(e->stream));
   if (iters > 0 && ms_out) {
@@ -2933,7 +2957,7 @@ extern "C" int ps_test_pointnet_mt(ps_engine* e, int32_t which, int32_t n_poly, 
     (void)hipEventDestroy(a);
     (void)hipEventDestroy(b);
   }
-  g_force_mt = 0;
+  e->force_mt = 0;
 #ifdef PS_RT_PROF
   {
     unsigned long long h[32];

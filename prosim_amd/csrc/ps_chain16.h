@@ -1166,6 +1166,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) __attribute__((disable_
 // k_edge16 runs c16_edge_phase -- geometry records, rows rebuilt in registers, k rows by LDS-DMA -- on 16 destination rows per 8-wave
 // workgroup: q / q~ / <q, kb> come from the PRE half's EdgeIO rows into the slots the fused chain keeps them in, the sums go back the
 // same way.  Same arithmetic as a one-step k_chain16 launch's edge phase.
+#ifdef PS_EXPERIMENTS   // (cross-check of k_edge_rows: ps_set_row_impl(2) in experiments builds; the product library does not carry it)
 constexpr size_t C16_EDGE_WAVES_BYTES = 8 * C16_WAVE_BYTES;
 constexpr size_t c16_edge_lds_bytes() { return C16_EDGE_WAVES_BYTES + (size_t)ND_ROWS * ND_XS * 4 + 16 * 8 * 4 + C16_CTR_INTS * 4 + C16_QA_BYTES; }
 __global__ __launch_bounds__(512, 1) __attribute__((disable_tail_calls)) void k_edge16(int Nd, const ChainStep* __restrict__ step, EdgeIO io,
@@ -1220,6 +1221,7 @@ __global__ __launch_bounds__(512, 1) __attribute__((disable_tail_calls)) void k_
   }
   if (tid < 128 && (tid >> 3) < nrows) io.l[(size_t)row0 * 8 + tid] = QA[(tid >> 3) * C16_QSL + (tid & 7) * C16_QH + 96];
 }
+#endif   // PS_EXPERIMENTS
 
 
 // The edge phase with NO workgroup structure (round 4): one wave per destination row, four waves per workgroup, three workgroups per CU

@@ -246,12 +246,22 @@ struct RadSet {
 };
 struct RadSets {
   RadSet s[2];
+  int scanned;   // != 0: k_exclusive_scan already made eoff / toff (large query counts, CSR_PREFIX_MAX_Q); the fill pass reads them
 };
+// up to this many queries the fill pass sweeps cnt[0..q) itself (one graph node less per search); beyond, the sweep's O(nq^2) loads
+// (3e7 at 8192 queries, 5e9 at the 100 k rows check_c16_offsets still admits: ADVICE round 4) cost more than the scan launch
+constexpr int CSR_PREFIX_MAX_Q = 16384;
 // A query's CSR and tile offsets from the counts of the queries before it (round 4: the fill pass computes its own exclusive prefix --
 // one strided sweep of cnt[0..q) per wave, a few thousand integers at most -- and writes eoff / toff itself; the separate one-workgroup
 // scan launch between the count and the fill pass is gone: one dependent graph node less per neighbour search).
 __device__ __forceinline__ void csr_prefix(const int* __restrict__ cnt, int q, int nq, int lane, int* __restrict__ eoff, int* __restrict__ toff,
-                                           int& e0, int& t0, int& mine) {
+                                           int& e0, int& t0, int& mine, int scanned = 0) {
+  if (scanned) {   // (k_exclusive_scan ran between the count and the fill pass)
+    mine = cnt[q];
+    e0 = eoff[q];
+    t0 = toff[q];
+    return;
+  }
   int se = 0, stl = 0;
   for (int i = lane; i < q; i += 64) {
     const int c = cnt[i];
@@ -293,7 +303,7 @@ __global__ void k_radius(RadSets sets, const float* __restrict__ qpos, const int
   int base_e = 0;
   if (MODE == 1) {   // this query's offsets, and the tile -> destination map of the rel-PE operand images (<= 25 tiles per destination)
     int t0, mine;
-    csr_prefix(cnt, q, nq, lane, S.eoff, S.toff, base_e, t0, mine);
+    csr_prefix(cnt, q, nq, lane, S.eoff, S.toff, base_e, t0, mine, sets.scanned);
     const int nt = (mine + 31) >> 5;
     if (lane < nt) tdst[t0 + lane] = q;
   }
@@ -535,7 +545,7 @@ __global__ void k_knn(CandSet cs, const float* __restrict__ qpos, const int* __r
 // MODEL.REL_POS_EDGE_FUNC 'knn' (decoder/sym_coord.py:85-96, policy/act_decoder.py:249-261): the generator's and the policy's edge
 // sets from the `cap` NEAREST candidates of the query's scene (torch_cluster.knn; knn_graph(loop = False) for the prompt graph: the
 // cap + 1 nearest, then without the query itself) instead of the first `cap` inside a radius.  Same RadSets plumbing as k_radius --
-// MODE 0 counts (cnt), k_exclusive_scan makes the CSR and tile offsets, MODE 1 selects and fills (k_knn's bisection: the k-th
+// MODE 0 counts (cnt), MODE 1 makes its own CSR / tile offsets (csr_prefix; k_exclusive_scan beyond CSR_PREFIX_MAX_Q queries), selects and fills (k_knn's bisection: the k-th
 // smallest (d2, index) key, ties in index order) -- so everything downstream of the edge lists is shared.
 template <int MODE>
 __global__ void k_knn_sets(RadSets sets, const float* __restrict__ qpos, const int* __restrict__ qscene, int nq) {
@@ -569,15 +579,26 @@ __global__ void k_knn_sets(RadSets sets, const float* __restrict__ qpos, const i
   }
   const int want = S.cap + (S.self_base >= 0 ? 1 : 0);
   const int kk_ = want < n_ok ? want : n_ok;
+  // Is the query itself among the kk_ selected?  Its key is 0, the smallest -- but ties at distance 0 (candidates at the query's exact
+  // position) are broken by index like every other tie, so with >= kk_ of them ahead of it the query is NOT selected, and
+  // knn_graph(loop = False) then keeps all cap + 1 neighbours (MODE 0 assumed "always selected" and sized the CSR
+  // range one short of what MODE 1 filled).  Both modes decide it with the selection's own (key, index) ranking.
+  bool self_sel = false;
+  if (self >= 0) {
+    const int js = (self >= b1 && self < b1 + n1) ? self - b1 : n1 + (self - b2);
+    int ahead = 0;
+#pragma unroll
+    for (int s = 0; s < KNN_SLOTS; ++s) ahead += __popcll(__ballot(key[s] == 0u && s * 64 + lane < js));
+    self_sel = ahead < kk_;
+  }
   if (MODE == 0) {
-    // (the query's own key is 0, the smallest: it is among the kk_ selected whenever it is a candidate)
-    if (lane == 0) S.cnt[q] = kk_ - ((self >= 0 && kk_ > 0) ? 1 : 0);
+    if (lane == 0) S.cnt[q] = kk_ - (self_sel ? 1 : 0);
     return;
   }
   int out;
   {
     int t0, mine;
-    csr_prefix(S.cnt, q, nq, lane, S.eoff, S.toff, out, t0, mine);
+    csr_prefix(S.cnt, q, nq, lane, S.eoff, S.toff, out, t0, mine, sets.scanned);
     const int nt = (mine + 31) >> 5;
     for (int t = lane; t < nt; t += 64) S.tdst[t0 + t] = q;
   }

@@ -65,6 +65,11 @@ def test_row_tile_pointnet_equals_the_staged_kernel_for_every_tiling():
             for mt in (0, 1, 2, 3, 4, 5):
                 if mt and 16 * mt < P:
                     continue
+                builds = {1: 16, 2: 16, 3: 8, 4: 8, 5: 4}   # widest lane count of the builds with mt tiles per wave (kRtShapes)
+                if mt and mt * builds[mt] < P:   # (round 5: a forced tiling without a build for this P is an error, not a silent fall-back)
+                    with pytest.raises(RuntimeError, match="no row-tile build"):
+                        eng.test_pointnet_mt(which, x, m, mt)
+                    continue
                 y, _ = eng.test_pointnet_mt(which, x, m, mt)
                 assert (y[0] == 0).all()
                 assert err(y, ref) < 2e-6, (which, n, P, mt, err(y, ref))
@@ -88,7 +93,11 @@ def test_row_impls_agree_on_the_benchmark_batch(rows):
     try:
         ref = exact = None
         for impl in (1, 0, 2, 11, 12, 13):
-            eng.set_row_impl(impl)
+            try:
+                eng.set_row_impl(impl)
+            except RuntimeError as ex:       # (2 and 13 exist in -DPS_EXPERIMENTS builds of the library only: round 5)
+                assert impl in (2, 13) and "experiments build" in str(ex), (impl, str(ex))
+                continue
             eng.set_chain_impl(2)            # (k_chain16 with the SPLIT s2s path in either mode: the node halves + edge kernel under test)
             eng.set_chain_rows(rows)
             eng.set_scene(scene)
