@@ -437,7 +437,8 @@ def main():
                 for _ in pipe.run(new_batches[:depth]):
                     pass
                 t_s = time.perf_counter()
-                n_b = sum(1 for _ in pipe.run(new_batches * 8))   # (48 batches: the pipeline's fill and drain -- 2 x depth batches deep -- stay a small part)
+                # (the pipeline's fill and drain -- 2 x depth batches deep, one rollout latency each way -- stay a small part of the timed region)
+                n_b = sum(1 for _ in pipe.run(new_batches * (8 if depth < 3 else 24)))
                 dt_s = time.perf_counter() - t_s
             streaming["agent_steps_per_s_by_depth"][str(depth)] = n_b * A * spec.max_steps / dt_s
             streaming["ms_per_batch_by_depth"][str(depth)] = 1e3 * dt_s / n_b

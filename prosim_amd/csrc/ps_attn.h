@@ -139,14 +139,19 @@ __device__ __forceinline__ void zero_acc(float (&acc)[T][4]) {
   for (int t = 0; t < T; ++t) acc[t][0] = acc[t][1] = acc[t][2] = acc[t][3] = 0.f;
 }
 // sum the partials of the lanes that share output columns: lane bits >= LOWBITS index the k-group
+// (round 5: the xor steps as VALU instructions -- xor_add, ps_device.h -- instead of ds_bpermute round trips; the same butterfly, the same bits)
 template <int T, int LOW>
 __device__ __forceinline__ void fold_kgroups(float (&acc)[T][4]) {
 #pragma unroll
-  for (int o = LOW; o < 64; o <<= 1) {
+  for (int t = 0; t < T; ++t) {
 #pragma unroll
-    for (int t = 0; t < T; ++t) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[t][j] += __shfl_xor(acc[t][j], o);
+    for (int j = 0; j < 4; ++j) {
+      float v = acc[t][j];
+      if (LOW <= 4) v = xor_add<4>(v);
+      if (LOW <= 8) v = xor_add<8>(v);
+      if (LOW <= 16) v = xor_add<16>(v);
+      if (LOW <= 32) v = xor_add<32>(v);
+      acc[t][j] = v;
     }
   }
 }
@@ -607,7 +612,7 @@ __global__ __launch_bounds__(64 * NW, ((!BIG && NW == 4) ? 2 : 1)) void k_attn_c
         }
       }
       {   // even-edge and odd-edge halves meet; lanes 0-31 publish the wave's a_v partial
-        av.x += __shfl_xor(av.x, 32); av.y += __shfl_xor(av.y, 32); av.z += __shfl_xor(av.z, 32); av.w += __shfl_xor(av.w, 32);
+        av.x = xor_add<32>(av.x); av.y = xor_add<32>(av.y); av.z = xor_add<32>(av.z); av.w = xor_add<32>(av.w);
         if (lane < 32) *reinterpret_cast<float4*>(avp + wave * 128 + 4 * lane) = av;
       }
       if (lane < 8) {
@@ -958,8 +963,8 @@ __device__ __forceinline__ void gemm16(RingT& R, const _Float16* __restrict__ Ah
 __device__ __forceinline__ float row16_sum(float v) {
   v += dpp_xor1(v);
   v += dpp_xor2(v);
-  v += __shfl_xor(v, 4);
-  v += __shfl_xor(v, 8);
+  v = xor_add<4>(v);
+  v = xor_add<8>(v);
   return v;
 }
 // y = LayerNorm(a[0..8)) over a 128-wide row held by 16 lanes x 8 columns (columns c0..c0+7)
@@ -1354,8 +1359,8 @@ __global__ __launch_bounds__(256, (MAXB <= 2 ? 4 : 2)) void k_edge_small(int Nd,
   for (int b = 0; b < MAXB; ++b)
 #pragma unroll
     for (int r4 = 0; r4 < 4; ++r4) m = fmaxf(m, sreg[b][r4]);
-  m = fmaxf(m, __shfl_xor(m, 16));
-  m = fmaxf(m, __shfl_xor(m, 32));
+  m = xor_max<16>(m);
+  m = xor_max<32>(m);
   float lsum = 0.f;
 #pragma unroll
   for (int b = 0; b < MAXB; ++b) {
@@ -1369,8 +1374,8 @@ __global__ __launch_bounds__(256, (MAXB <= 2 ? 4 : 2)) void k_edge_small(int Nd,
       }
     }
   }
-  lsum += __shfl_xor(lsum, 16);
-  lsum += __shfl_xor(lsum, 32);
+  lsum = xor_add<16>(lsum);
+  lsum = xor_add<32>(lsum);
   if (lane < 8) io.l[(size_t)r * 8 + lane] = lsum;
   // ---- aggregation: a_r on the matrix cores per 32-edge tile (A = p hi | lo x head, B = rtT), a_v on the VALU
   floatx4 ar[2 * KR];
@@ -1420,7 +1425,7 @@ __global__ __launch_bounds__(256, (MAXB <= 2 ? 4 : 2)) void k_edge_small(int Nd,
         av.w = fmaf(ph, vv[j].w, av.w);
       }
     }
-    av.x += __shfl_xor(av.x, 32); av.y += __shfl_xor(av.y, 32); av.z += __shfl_xor(av.z, 32); av.w += __shfl_xor(av.w, 32);
+    av.x = xor_add<32>(av.x); av.y = xor_add<32>(av.y); av.z = xor_add<32>(av.z); av.w = xor_add<32>(av.w);
     if (lane < 32) *reinterpret_cast<float4*>(io.av + (size_t)r * 128 + 4 * lane) = av;
   }
   // rows h (p hi) and h + 8 (p lo) sit 32 lanes apart: one half-wave swap folds two column blocks at a time

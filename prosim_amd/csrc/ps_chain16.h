@@ -660,7 +660,7 @@ __device__ __forceinline__ void c16_edge_body(const ChainStep* __restrict__ stp,
 #endif
       sb ^= 1;
       if (ONEW && turn) {   // the even tiles are done: park their sums, start the odd tiles' from zero
-        av.x += __shfl_xor(av.x, 32); av.y += __shfl_xor(av.y, 32); av.z += __shfl_xor(av.z, 32); av.w += __shfl_xor(av.w, 32);
+        av.x = xor_add<32>(av.x); av.y = xor_add<32>(av.y); av.z = xor_add<32>(av.z); av.w = xor_add<32>(av.w);
         if (lane < 32) *reinterpret_cast<float4*>(stash + 4 * lane) = av;
         if (lane < 8) { stash[128 + 2 * lane] = m_run; stash[128 + 2 * lane + 1] = l_run; }
 #pragma unroll
@@ -684,7 +684,7 @@ __device__ __forceinline__ void c16_edge_body(const ChainStep* __restrict__ stp,
     float* oar = DIRECT ? io.ar + (size_t)r * 1024 : QA + aslot * C16_QSL;   // [8 heads][oh]: the row's a_r
     const int oh = DIRECT ? 128 : C16_QH;
     float* ol = DIRECT ? io.l + (size_t)r * 8 : nullptr;
-    av.x += __shfl_xor(av.x, 32); av.y += __shfl_xor(av.y, 32); av.z += __shfl_xor(av.z, 32); av.w += __shfl_xor(av.w, 32);
+    av.x = xor_add<32>(av.x); av.y = xor_add<32>(av.y); av.z = xor_add<32>(av.z); av.w = xor_add<32>(av.w);
     if (ONEW && two) {   // merge (even, odd) with the operations of the POST half's merge of two waves' partials
       const float m0 = stash[128 + 2 * (lane & 7)], l0 = stash[128 + 2 * (lane & 7) + 1];   // head lane & 7
       const float mh = __shfl(m_run, lane & 7), lh = __shfl(l_run, lane & 7);              // (lane h holds head h)

@@ -107,14 +107,72 @@ __device__ __forceinline__ float dpp_xor2(float v) {   // quad_perm [2,3,0,1]
 __device__ __forceinline__ float dpp_xor1(float v) {   // quad_perm [1,0,3,2]
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true));
 }
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+// ---- xor butterflies on the VALU (round 5).  __shfl_xor compiles to ds_bpermute_b32: an LDS-pipe round trip of ~100 cycles per step,
+// six dependent steps per wave reduction -- the LayerNorms, GEMV folds and softmax reductions of a k_attn_chain layer are ~250 of them
+// (13 % of a single-scene policy launch was waiting for them).  On gfx950 every step of an xor butterfly exists as a VALU instruction:
+// lane ^ 32 / ^ 16 through v_permlane32_swap / v_permlane16_swap, ^ 8 = row_ror:8, ^ 2 / ^ 1 quad permutes; ^ 4 is row_ror:4 once the
+// data has period 8 inside a row (after the ^ 8 step of a descending butterfly), two rotations and a select otherwise.  a + partner is
+// commutative, so every form below returns the bits of `v + __shfl_xor(v, O)` / fmaxf(v, __shfl_xor(v, O)).
+__device__ __forceinline__ float dpp_ror4(float v) {   // row_ror:4
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float dpp_ror12(float v) {   // row_ror:12
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x12C, 0xf, 0xf, true));
+}
+template <int O>
+__device__ __forceinline__ float xor_add(float v) {   // v + (the value of lane ^ O)
+  static_assert(O == 32 || O == 16 || O == 8 || O == 4 || O == 2 || O == 1, "xor_add: one bit");
+  if (O == 32) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  } else if (O == 16) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  } else if (O == 8) {
+    return v + dpp_xor8(v);
+  } else if (O == 4) {   // (general form: lanes with bit 2 clear take lane + 4, the others lane - 4)
+    // row_ror:n hands lane i the value of lane (i - n) mod 16 (probed on the GPU): lanes 4-7 / 12-15 (banks 1 and 3 of the row) take
+    // ror 4 = lane - 4, the others keep ror 12 = lane + 4 -- the second mov writes only those banks over the first one's result.  (As
+    // a select of two full DPP moves hipcc folded the pair into one masked mov whose other lanes read 0.)
+    const int up = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x12C, 0xf, 0xf, true);
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(up, __float_as_int(v), 0x124, 0xf, 0xa, false));
+  } else if (O == 2) {
+    return v + dpp_xor2(v);
+  } else {
+    return v + dpp_xor1(v);
+  }
+}
+template <int O>
+__device__ __forceinline__ float xor_max(float v) {   // fmaxf(v, the value of lane ^ O), O = 16 | 32
+  static_assert(O == 32 || O == 16, "xor_max: 16 | 32");
+  const auto r = O == 32 ? __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false)
+                         : __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+// the same step once the data already has period 8 inside each row of 16 (lanes i and i ^ 8 hold the same value): one rotation
+__device__ __forceinline__ float xor4_add_periodic8(float v) { return v + dpp_ror4(v); }
+__device__ __forceinline__ float wave_sum(float v) {   // butterfly 32, 16, 8, 4, 2, 1: the order (and the bits) of the __shfl_xor loop it replaces
+  v = xor_add<32>(v);
+  v = xor_add<16>(v);
+  v = xor_add<8>(v);
+  v = xor4_add_periodic8(v);
+  v = xor_add<2>(v);
+  v = xor_add<1>(v);
   return v;
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+  }
+  {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+  }
+  v = fmaxf(v, dpp_xor8(v));
+  v = fmaxf(v, dpp_ror4(v));
+  v = fmaxf(v, dpp_xor2(v));
+  v = fmaxf(v, dpp_xor1(v));
   return v;
 }
 

@@ -718,7 +718,7 @@ __global__ __launch_bounds__(256) void k_relpe_tiles(PeSets sets, const float* _
       for (int j = 0; j < 16; ++j) sm += f[j];
       sm += dpp_xor1(sm);
       sm += dpp_xor2(sm);
-      sm += __shfl_xor(sm, 4);
+      sm = xor_add<4>(sm);
       const float mean = sm * (1.f / 128.f);
       float sq = 0.f;
 #pragma unroll
@@ -728,7 +728,7 @@ __global__ __launch_bounds__(256) void k_relpe_tiles(PeSets sets, const float* _
       }
       sq += dpp_xor1(sq);
       sq += dpp_xor2(sq);
-      sq += __shfl_xor(sq, 4);
+      sq = xor_add<4>(sq);
       const float rstd = (r < n) ? 1.f / sqrtf(sq * (1.f / 128.f) + eps) : 0.f;
       half8 h0, h1, l0, l1;
 #pragma unroll

@@ -58,6 +58,27 @@ __global__ void k_check(const float* xs, const float* rstd, const float* nmr, co
   if (nb) atomicAdd(bad, (unsigned long long)nb);
 }
 
+// the VALU xor butterflies of ps_device.h (round 5) against the __shfl_xor forms they replace, bit for bit
+__global__ void k_check_xor(const float* x, int n, unsigned long long* bad) {   // bad[4 + k]: mismatches of check k
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const float v = x[i % n] * (1.f + 0.37f * (threadIdx.x & 63));
+  auto chk = [&](int k, float a, float b) { if (__float_as_uint(a) != __float_as_uint(b)) atomicAdd(bad + 4 + k, 1ull); };
+  chk(0, xor_add<32>(v), v + __shfl_xor(v, 32)); chk(1, xor_add<16>(v), v + __shfl_xor(v, 16)); chk(2, xor_add<8>(v), v + __shfl_xor(v, 8));
+  chk(3, xor_add<4>(v), v + __shfl_xor(v, 4)); chk(4, xor_add<2>(v), v + __shfl_xor(v, 2)); chk(5, xor_add<1>(v), v + __shfl_xor(v, 1));
+  chk(6, xor_max<32>(v), fmaxf(v, __shfl_xor(v, 32))); chk(7, xor_max<16>(v), fmaxf(v, __shfl_xor(v, 16)));
+  float s = v, m = v;
+  for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); m = fmaxf(m, __shfl_xor(m, o)); }
+  chk(8, wave_sum(v), s); chk(9, wave_max(v), m);
+  float acc[1][4] = {{v, -v * 0.5f, v * v, 1.f / (1.f + fabsf(v))}}, ref[4];
+  for (int j = 0; j < 4; ++j) { ref[j] = acc[0][j]; for (int o = 8; o < 64; o <<= 1) ref[j] += __shfl_xor(ref[j], o); }
+  fold_kgroups<1, 8>(acc);
+  for (int j = 0; j < 4; ++j) chk(10, acc[0][j], ref[j]);
+  float acc4[1][4] = {{v, v + 1.f, v - 2.f, 3.f * v}}, ref4[4];
+  for (int j = 0; j < 4; ++j) { ref4[j] = acc4[0][j]; for (int o = 4; o < 64; o <<= 1) ref4[j] += __shfl_xor(ref4[j], o); }
+  fold_kgroups<1, 4>(acc4);
+  for (int j = 0; j < 4; ++j) chk(11, acc4[0][j], ref4[j]);
+}
+
 int main() {
   const int n = 1 << 22;
   float *hx = (float*)malloc(4 * n), *hr = (float*)malloc(4 * n), *hn = (float*)malloc(4 * n), hd[32];
@@ -71,12 +92,22 @@ int main() {
     hn[i] = (float)(-0.8 + 1.2 * w);
   }
   float *dx, *dr, *dn, *dd; unsigned long long *db, hb = 0;
-  hipMalloc(&dx, 4 * n); hipMalloc(&dr, 4 * n); hipMalloc(&dn, 4 * n); hipMalloc(&dd, 128); hipMalloc(&db, 32);
+  hipMalloc(&dx, 4 * n); hipMalloc(&dr, 4 * n); hipMalloc(&dn, 4 * n); hipMalloc(&dd, 128); hipMalloc(&db, 256);
   hipMemcpy(dx, hx, 4 * n, hipMemcpyHostToDevice); hipMemcpy(dr, hr, 4 * n, hipMemcpyHostToDevice); hipMemcpy(dn, hn, 4 * n, hipMemcpyHostToDevice);
-  hipMemcpy(dd, hd, 128, hipMemcpyHostToDevice); hipMemset(db, 0, 32);
+  hipMemcpy(dd, hd, 128, hipMemcpyHostToDevice); hipMemset(db, 0, 256);
   hipLaunchKernelGGL(k_check, dim3(n / 256), dim3(256), 0, 0, dx, dr, dn, dd, n, db);
   hipDeviceSynchronize();
   hipMemcpy(&hb, db, 8, hipMemcpyDeviceToHost);
   printf("mb_feat: %d lanes x (16 feature halves + 2 selected pairs), mismatching values: %llu\n", n, hb);
-  return hb != 0;
+  hipLaunchKernelGGL(k_check_xor, dim3(4096), dim3(256), 0, 0, dx, n, db);
+  hipDeviceSynchronize();
+  unsigned long long h4[32] = {0};
+  hipMemcpy(h4, db, 256, hipMemcpyDeviceToHost);
+  unsigned long long tot = 0;
+  static const char* nm[12] = {"xor_add<32>", "xor_add<16>", "xor_add<8>", "xor_add<4>", "xor_add<2>", "xor_add<1>", "xor_max<32>", "xor_max<16>", "wave_sum", "wave_max", "fold_kgroups<1,8>", "fold_kgroups<1,4>"};
+  printf("mb_feat: xor butterflies against __shfl_xor, mismatching values:");
+  for (int k = 0; k < 12; ++k) { printf(" %s %llu", nm[k], h4[4 + k]); tot += h4[4 + k]; }
+  printf("\n");
+  h4[3] = tot;
+  return hb != 0 || h4[3] != 0;
 }
