@@ -460,13 +460,13 @@ def main():
         # HBM-side traffic of the launch comes from separate rocprofv3 --pmc passes (tools/gpu_round_profile.sh; counters
         # cannot be read from inside this process): offline, valid for the default workload only, stamped with its source
         traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", "r04_pmc_policy_chain.json")
+        pmc = os.path.join(ROOT, "profiles", "r05_pmc_policy_chain.json")
         if os.path.exists(pmc) and S == 8 and args.config == 2:
             with open(pmc) as f:
                 pj = json.load(f)
             if pj.get("chain_rows") == chain_rows:
                 traffic = pj["hbm_bytes_per_launch"]
-                traffic_src = {"file": "profiles/r04_pmc_policy_chain.json", "git": pj.get("git"), "measured": "offline rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), not in this run"}
+                traffic_src = {"file": "profiles/r05_pmc_policy_chain.json", "git": pj.get("git"), "measured": "offline rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), not in this run"}
         achieved = fl_alg / (ms_launch * 1e-3) / 1e12
         kern = (f"k_chain16<8, policy> (12 fused attention layers per launch, {chain_rows} rows per 8-wave workgroup, {n_wg} workgroups)" if c16
                 else f"k_attn_chain (policy: 12 fused attention layers per launch; {chain_rows or 2} rows per workgroup)")
@@ -495,8 +495,9 @@ def main():
                                  "instruction; the PMC pass SQ_INSTS_VALU_MFMA_MOPS_F16 under profiles/ counts the same instructions).  "
                                  "A launch occupies `workgroups` of the 256 CUs and `rollouts_in_flight` launches overlap, so the per-launch "
                                  "rate understates the chip: chip_algorithmic_tflops = all policy launches of the timed region / its wall time.  "
-                                 "What bounds the launch: DESIGN.md section 4 (edge phase: fp32 VALU issue -- the recomputed Fourier rows are 58 % of it -- "
-                                 "and the dependent LDS / MFMA chain of a 16-edge tile at two waves per SIMD; node phase: the dependent stage chain of a 16-row layer -- GEMM, LDS, barrier, epilogue, 17 barriers per layer; with every weight-fragment load an L1 hit it is only 10 % faster).",
+                                 "What bounds the launch: DESIGN.md section 0a / 4 (edge phase: the dependent LDS / MFMA / cross-lane chain of a 16-edge tile at two waves per SIMD "
+                                 "over a VALU floor that round 5 cut from 448 to 348 static instructions per tile -- 51.6 M -> 41.1 M VALU instructions per launch for 5 % of its time, "
+                                 "so issue count is no longer the first limiter; node phase: the dependent stage chain of a 16-row layer -- GEMM, LDS, barrier, epilogue, 17 barriers per layer; with every weight-fragment load an L1 hit it is only 10 % faster).",
                          "algorithmic_flops_per_launch": fl_alg,
                          "executed_mfma_flops_per_launch": fl_mfma,
                          "executed_mfma_tflops": (fl_mfma / (ms_launch * 1e-3) / 1e12) if fl_mfma else None,
