@@ -1907,7 +1907,8 @@ int launch_chain(ps_engine* e, float* x, int Nd, int step0, int nsteps, int maxd
 
 void launch_kv(ps_engine* e, const float* x, int Ns, int layer0, int nlayers, float* kv, _Float16* khl, size_t layer_stride) {
   if (Ns <= 0 || nlayers <= 0) return;
-  hipLaunchKernelGGL(k_kv_proj, dim3((Ns + PN_ROWS - 1) / PN_ROWS, nlayers), dim3(WG), KV_LDS_BYTES, e->stream, x, Ns,
+  const unsigned gx = (Ns + PN_ROWS - 1) / PN_ROWS;
+  hipLaunchKernelGGL(k_kv_proj, dim3(gx, nlayers, gx * nlayers <= 128 ? 2 : 1), dim3(WG), KV_LDS_BYTES, e->stream, x, Ns,
                      (const AttnW*)(e->d_layers + layer0), kv, khl, layer_stride, e->cfg.ln_eps);
 }
 

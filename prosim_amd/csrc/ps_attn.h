@@ -831,7 +831,10 @@ __global__ __launch_bounds__(WG) void k_kv_proj(const float* __restrict__ x, int
   __syncthreads();
   float* out = kv + blockIdx.y * layer_stride;
   _Float16* outh = khl + blockIdx.y * layer_stride;
-  for (int half = 0; half < 2; ++half) {
+  // (round 5: a launch with few workgroups -- one scene's 128 rows are two -- puts the k half and the v half on workgroups of their own,
+  // gridDim.z = 2: the same arithmetic, half the dependent work per workgroup; 12.5 -> ~9 us for the 25 such launches of a single-scene rollout)
+  const int half0 = gridDim.z == 2 ? (int)blockIdx.z : 0, half1 = gridDim.z == 2 ? half0 + 1 : 2;
+  for (int half = half0; half < half1; ++half) {
     pn_gemm<4>(Ah, Al, 4, w.Wkv_F + (size_t)half * 8 * 4 * 1024, C, PN_CS, PN_ROWS, wave, lane);
     __syncthreads();
     for (int i = tid; i < PN_ROWS * 32; i += WG) {   // 64 rows x 32 float4
