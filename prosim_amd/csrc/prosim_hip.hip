@@ -994,6 +994,8 @@ extern "C" int ps_create(const ps_config* cfg, int32_t n_tensors, const char* co
   PS_ATTR(1, 3, false); PS_ATTR(2, 3, false); PS_ATTR(4, 3, false);
   PS_ATTR(1, 4, false); PS_ATTR(2, 4, false); PS_ATTR(4, 4, false);
 #undef PS_ATTR
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_chain<1, 4, 3, false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_chain<1, 4, 3, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   *out = e;
   return PS_OK;
 }
@@ -1820,7 +1822,8 @@ static bool xcd_on(int bit, bool dflt) {
 }
 int launch_chain(ps_engine* e, float* x, int Nd, int step0, int nsteps, int maxdeg, bool timed = false,
                  const ChainStep* steps_override = nullptr, int force_T = 0, int kr_override = 0, const float* x_in = nullptr,
-                 bool xcd = false) {
+                 bool xcd = false, bool geo = false) {
+  // geo: the steps' edge sets carry geometry records and NO operand images (use_geo1 below): the one-row build with k_chain16's edge body
   if (!x_in) x_in = x;   // in place unless the caller has the input rows elsewhere (saves a copy launch)
   // rel-PE width of the launch's steps: condition steps (and the test hook's arbitrary rows) use all 128 columns
   const int steps_host_kr = kr_override ? kr_override : (steps_override ? 3 : e->h_steps[step0].kr);
@@ -1867,10 +1870,15 @@ int launch_chain(ps_engine* e, float* x, int Nd, int step0, int nsteps, int maxd
   // the policy launch under its own symbol.  (Round 3 dropped the builds that were measured, parity-tested and never
   // selected: 1 row on 8 waves, 4 rows on 8 waves, 1 row with the whole register file.)
   if (T != 11 && T != 2 && T != 4) return fail(PS_E_ARG, "k_attn_chain takes 1 (code 11), 2 or 4 rows per workgroup");
+  if (geo && (T != 11 || kr != 3)) return fail(PS_E_STATE, "the geometry-record edge phase of k_attn_chain is the one-row build's (no operand images were made for this launch)");
 #define PS_LAUNCH(TT, KRR, POL, GRID, LDS) \
-  hipLaunchKernelGGL((k_attn_chain<TT, 4, KRR, false, POL>), dim3(GRID), dim3(WG), LDS, st, x, x_in, Nd, steps, nsteps, maxdeg, eps, flags, prof)
+  hipLaunchKernelGGL((k_attn_chain<TT, 4, KRR, false, POL>), dim3(GRID), dim3(WG), LDS, st, x, x_in, Nd, steps, nsteps, maxdeg, eps, flags, prof, (const float*)e->div32)
   const bool pol = timed && kr == 3;
-  if (T == 11) {
+  if (T == 11 && geo && kr == 3) {   // one row per workgroup, edge phase on geometry records (k_chain16's edge body)
+    const size_t ldsg = lds1 + G1_FLOATS * sizeof(float);
+    if (pol) hipLaunchKernelGGL((k_attn_chain<1, 4, 3, false, true, true>), dim3(Nd), dim3(WG), ldsg, st, x, x_in, Nd, steps, nsteps, maxdeg, eps, flags, prof, (const float*)e->div32);
+    else hipLaunchKernelGGL((k_attn_chain<1, 4, 3, false, false, true>), dim3(Nd), dim3(WG), ldsg, st, x, x_in, Nd, steps, nsteps, maxdeg, eps, flags, prof, (const float*)e->div32);
+  } else if (T == 11) {
     if (pol) PS_LAUNCH(1, 3, true, Nd, lds1);
     else if (kr == 3) PS_LAUNCH(1, 3, false, Nd, lds1);
     else PS_LAUNCH(1, 4, false, Nd, lds1);
@@ -2006,6 +2014,15 @@ void launch_pe_learn(ps_engine* e, EdgeSet& es, const PeLearnW& w) {
 bool use_c16(const ps_engine* e, int Nd, int part) {
   if (e->pe_on[part]) return false;
   return e->chain_impl >= 2 || (e->chain_impl == 0 && (e->chain_rows >= 8 || (e->chain_rows == 0 && Nd >= 1024)));
+}
+// do the fused chains over Nd rows run on the ONE-ROW k_attn_chain with k_chain16's edge body (round 5)?  Where launch_chain picks one
+// row per workgroup (below 512 rows: a single scene) in the default implementation; ps_set_chain_impl(1) keeps the operand-image edge
+// phase (the cross-check path of the tests), PS_NO_GEO1: experiments.
+bool use_geo1(const ps_engine* e, int Nd, int part) {
+  static const bool off = exp_env("PS_NO_GEO1") != nullptr;
+  static const bool t1 = exp_env("PS_CHAIN_T1") != nullptr;
+  if (off || t1 || e->pe_on[part] || use_c16(e, Nd, part)) return false;
+  return e->chain_impl == 0 && Nd < 512;
 }
 int chain16_rows(ps_engine* e, int Nd) {
   static const int env_rows = exp_env("PS_C16_ROWS") ? atoi(exp_env("PS_C16_ROWS")) : 0;   // experiments only
@@ -2170,7 +2187,7 @@ extern "C" int ps_encode_scene(ps_engine* e) {
       launch_pe_learn(e, e->e_a2a, e->pe_learn[0]);
       launch_pe_learn(e, e->e_s2s, e->pe_learn[1]);
     } else {   // per set: geometry records for the layers whose edge phase rebuilds its rows (k_chain16, k_edge16), operand images for the others
-      const bool ga = use_c16(e, Ap, 0);
+      const bool ga = use_c16(e, Ap, 0) || use_geo1(e, Ap, 0);
       const bool gs = s2s_c16 || (s2s_split_geo);
       if (ga && gs) launch_geo(e, pe, 2);
       else if (!ga && !gs) launch_relpe(e, pe, 2);
@@ -2192,7 +2209,7 @@ extern "C" int ps_encode_scene(ps_engine* e) {
     launch_kv(e, tok + (size_t)Mv * D, Ap, e->L_a2a + i, 1, e->d_kv.p + (size_t)Mv * 256, e->d_kh.p + (size_t)Mv * 256, 0);
     if (use_c16(e, Ap, 0)) {
       if (launch_chain16(e, tok + (size_t)Mv * D, Ap, e->d_steps.p + e->step_a2a + i, 1, false, nullptr, false)) return PS_E_HIP;
-    } else if (launch_chain(e, tok + (size_t)Mv * D, Ap, e->step_a2a + i, 1, e->e_a2a.maxdeg, false, nullptr, 0, 0, nullptr, xcd_on(1, false))) return PS_E_HIP;
+    } else if (launch_chain(e, tok + (size_t)Mv * D, Ap, e->step_a2a + i, 1, e->e_a2a.maxdeg, false, nullptr, 0, 0, nullptr, xcd_on(1, false), use_geo1(e, Ap, 0))) return PS_E_HIP;
     if (s2s_c16) {
       launch_kv(e, tok, Mv + Ap, e->L_s2s + i, 1, e->d_kv.p, e->d_kh.p, 0);
       if (launch_chain16(e, tok, Mv + Ap, e->d_steps.p + e->step_s2s + i, 1, false, nullptr, xcd_on(3, true))) return PS_E_HIP;
@@ -2236,7 +2253,7 @@ extern "C" int ps_generate_policy(ps_engine* e) {
   if (dev_copy(st, e->d_tok_pos.p + 2 * (size_t)Mv, ppos, sizeof(float) * 2 * A)) return fail(PS_E_HIP, "device copy launch failed");
   if (dev_copy(st, e->d_tok_ori.p + Mv, pori, sizeof(float) * A)) return fail(PS_E_HIP, "device copy launch failed");
   // (with log-replay agents in the scene only the policy agents are prompts: candidate filter)
-  const int pe_gen = use_c16(e, Ap, 1) ? 2 : 1;   // k_chain16 rebuilds the rel-PE rows from geometry records, k_attn_chain streams operand images
+  const int pe_gen = (use_c16(e, Ap, 1) || use_geo1(e, Ap, 1)) ? 2 : 1;   // k_chain16 rebuilds the rel-PE rows from geometry records, k_attn_chain streams operand images
   launch_radius(e, e->e_p2p, e->d_r_agent.p, nullptr, ppos, pscene, Ap, c.dec_prompt_radius, c.dec_max_neigh, Mv, e->d_tok_ori.p, pori,
                 e->all_policy ? nullptr : (const int*)e->d_is_policy.p, Mv, pe_gen, pe_of(e, &e->e_p2p), c.rel_pos_knn != 0);
   // restore observed agent poses for the scene tokens, then s2p: radius over all scene tokens (:94)
@@ -2252,7 +2269,7 @@ extern "C" int ps_generate_policy(ps_engine* e) {
     launch_kv(e, e->d_xp.p, Ap, e->L_p2p + i, 1, e->d_kv.p + (size_t)Mv * 256, e->d_kh.p + (size_t)Mv * 256, 0);
     if (use_c16(e, Ap, 1)) {
       if (launch_chain16(e, e->d_xp.p, Ap, e->d_steps.p + e->step_dec + 2 * i, 2, false, nullptr, false)) return PS_E_HIP;
-    } else if (launch_chain(e, e->d_xp.p, Ap, e->step_dec + 2 * i, 2, md, false, nullptr, 0, 0, nullptr, xcd_on(2, false))) return PS_E_HIP;
+    } else if (launch_chain(e, e->d_xp.p, Ap, e->step_dec + 2 * i, 2, md, false, nullptr, 0, 0, nullptr, xcd_on(2, false), use_geo1(e, Ap, 1))) return PS_E_HIP;
   }
   if (dev_copy(st, e->d_emd.p, e->d_xp.p, sizeof(float) * (size_t)Ap * D)) return fail(PS_E_HIP, "device copy launch failed");
   if (c.goal_pred_k > 0) {   // Decoder._goal_pred on the decoder's embedding (decoder/base.py:22-58, sym_coord.py:133-136)
@@ -2380,14 +2397,14 @@ extern "C" int ps_policy_step(ps_engine* e, int32_t t_idx) {
     const RadArgs ra[2] = {{&e->e_a2p, e->d_r_agent.p, nullptr, c.pol_agent_radius, c.pol_max_neigh, -1,
                             e->all_policy ? nullptr : (const int*)e->d_tok_live.p, Mv, pe_of(e, &e->e_a2p)},
                            {&e->e_m2p, e->d_r_map.p, nullptr, c.pol_map_radius, c.pol_max_neigh, -1, nullptr, 0, pe_of(e, &e->e_m2p)}};
-    launch_radius(e, ra, 2, e->d_cur_pos.p, pscene, A, e->d_tok_ori.p, e->d_cur_ori.p, use_c16(e, A, 2) ? 2 : 1, c.rel_pos_knn != 0);
+    launch_radius(e, ra, 2, e->d_cur_pos.p, pscene, A, e->d_tok_ori.p, e->d_cur_ori.p, (use_c16(e, A, 2) || use_geo1(e, A, 2)) ? 2 : 1, c.rel_pos_knn != 0);
   }
   const int md = std::max(e->e_a2p.maxdeg, e->e_m2p.maxdeg);
   if (e->policy_events && (int)e->pev.size() >= 2 * R) HIPCHK(hipEventRecord(e->pev[2 * t_idx], st));
   // the policy tokens enter every replan unchanged (d_emd); the fused features leave to d_fused
   if (use_c16(e, A, 2)) {
     if (launch_chain16(e, e->d_fused.p, A, e->d_steps.p + e->step_pol, 2 * c.pol_layers, true, e->d_emd.p, xcd_on(0, true))) return PS_E_HIP;
-  } else if (launch_chain(e, e->d_fused.p, A, e->step_pol, 2 * c.pol_layers, md, true, nullptr, 0, 0, e->d_emd.p, xcd_on(0, true))) return PS_E_HIP;
+  } else if (launch_chain(e, e->d_fused.p, A, e->step_pol, 2 * c.pol_layers, md, true, nullptr, 0, 0, e->d_emd.p, xcd_on(0, true), use_geo1(e, A, 2))) return PS_E_HIP;
   if (e->policy_events && (int)e->pev.size() >= 2 * R) HIPCHK(hipEventRecord(e->pev[2 * t_idx + 1], st));
   {
     static const bool probe = exp_env("PS_POL_EDGE_PROBE") != nullptr;   // experiments only (timing: what the many-waves edge kernel needs for one a2p + m2p layer pair)

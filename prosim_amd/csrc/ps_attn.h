@@ -181,10 +181,29 @@ __device__ __forceinline__ void fold_kgroups(float (&acc)[T][4]) {
 // row mapping (xcd_block): the rows of one scene share an XCD, whose L2 then holds that scene's a2p / m2p k|v rows
 // (measured at 8 scenes x 128 agents: 546 -> 525 us).  The generator's launches are left on the plain mapping: with
 // 512-neighbour s2p rows the same mapping costs 6 % (every workgroup of an XCD gathers the same rows at once).
-template <int T, int NW = 4, int KR = 3, bool BIG = (T == 1), bool POLICY = false>
-__global__ __launch_bounds__(64 * NW, ((!BIG && NW == 4) ? 2 : 1)) void k_attn_chain(float* __restrict__ x, const float* __restrict__ x_in, int Nd,
+// GEO (round 5; T = 1, KR = 3 only): the edge phase works on the 32-byte GEOMETRY RECORDS of k_edge_geo like k_chain16's -- the rel-PE rows are
+// rebuilt in registers instead of read from two 384-byte operand images per edge (k_relpe_tiles is not launched for such a set), the k rows of a
+// tile arrive by LDS-DMA, every wave runs its own online softmax over the tiles 4 j + wave with no workgroup barrier inside the edge loop, and a
+// tile's loads all leave one tile (the first tile's: a whole node stage) ahead: c16_lat_* in ps_chain16.h.  (Phase clocks of the image form on one
+// 128-agent scene: the edge phase was 42 % of the launch, one exposed L2 round trip per pass and 16-edge block, and the 1.4 MB of images per layer
+// and XCD pushed the layer's weights out of L2.)  The node stages stay the fp32 GEMVs on register-streamed weights; the four waves' partial sums
+// are merged like k_chain16's POST half merges them (common maximum, rescale, add).  One workgroup per CU (122 KB of LDS, up to 512 registers).
+// LDS behind the kernel's own buffers: [4 wave areas: k staging hi | lo, probability tile, feature tile, source rows][5 slots: the waves' a_r
+// (+ l, m), q~][5 rows: q, the waves' a_v].
+constexpr int G1_WAVE_FLOATS = 3104, G1_QSL = 808, G1_QH = 100, G1_AGS = 132;
+constexpr size_t G1_FLOATS = (size_t)4 * G1_WAVE_FLOATS + 5 * G1_QSL + 5 * G1_AGS;
+struct GeoRec { float4 g; float nn; int src; };          // an edge's record as loaded: (a0, a1, a2, rstd), -mean rstd, source row
+struct C16LatState { GeoRec r0, r1; float4 vv[8]; };     // a wave's requests in flight between the calls below
+template <int TAG> __device__ void c16_lat_request(const ChainStep* __restrict__ stp, float* g1, int e_beg, int deg, C16LatState& S);
+template <int TAG> __device__ void c16_lat_pre(const ChainStep* __restrict__ stp, float* g1, int e_beg, int deg, C16LatState& S);
+template <int TAG> __device__ void c16_lat_main(const ChainStep* __restrict__ stp, float* g1, const float* cq, const float* __restrict__ div32, int e_beg, int deg,
+                                                C16LatState& S);
+
+template <int T, int NW = 4, int KR = 3, bool BIG = (T == 1), bool POLICY = false, bool GEO = false>
+__global__ __launch_bounds__(64 * NW, ((!BIG && NW == 4 && !GEO) ? 2 : 1)) void k_attn_chain(float* __restrict__ x, const float* __restrict__ x_in, int Nd,
                                                      const ChainStep* __restrict__ steps, int nsteps, int maxdeg, float eps, int flags,
-                                                     unsigned long long* __restrict__ prof) {
+                                                     unsigned long long* __restrict__ prof, const float* __restrict__ div32) {
+  static_assert(!GEO || (T == 1 && NW == 4 && KR == 3), "the geometry-record edge phase is built for one row on four waves");
   // flags: ablation switches of tools/gpu_ablate.py / gpu_profile.sh (0 in every product launch; results are wrong
   // when set): 1 no edges, 8 skip the aggregation pass, 16 skip the score pass, 32 read the rel-PE images from a
   // cache-resident region, 128 no k staging; 512 plain blockIdx -> row mapping in the policy launch
@@ -211,7 +230,7 @@ __global__ __launch_bounds__(64 * NW, ((!BIG && NW == 4) ? 2 : 1)) void k_attn_c
   // T == 1: one workgroup per CU with the full register file -> software prefetch (weights one chunk ahead,
   // edge rows one tile ahead).  T >= 2: compiled for 2 workgroups per CU (__launch_bounds__(256, 2), <= 256
   // registers): the co-resident workgroup hides the latency instead and nothing is double-buffered.
-  constexpr bool PF = BIG;                     // weight chunks one stage ahead (second register set)
+  constexpr bool PF = BIG;                     // weight chunks one stage ahead (second register set; GEO with its 512 registers: measured slower, 0.227 against 0.221 ms)
   constexpr bool PFE = BIG;                    // edge rows one tile ahead
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* xs = smem;                 // [T][128] residual stream
@@ -228,6 +247,9 @@ __global__ __launch_bounds__(64 * NW, ((!BIG && NW == 4) ? 2 : 1)) void k_attn_c
   float* cq = ml + NW * 16;         // [T][8]
   float* spb = cq + 8 * T + 56;     // [2][SP_SIZE] small per-layer vectors, double-buffered
   int* esl = reinterpret_cast<int*>(spb + 2 * SP_SIZE);  // [T][CH] source rows of the current chunk of each edge list
+  float* g1 = smem + attn_lds_floats<T, NW>(0);          // GEO: k_chain16's edge-phase areas (G1_FLOATS)
+  float* g1qa = g1 + 4 * G1_WAVE_FLOATS;                 //   [5][G1_QSL] slots 0-3: the waves' a_r (+ l, m), 4: q~
+  float* g1ag = g1qa + 5 * G1_QSL;                       //   [5][G1_AGS] row 0: q, rows 1-4: the waves' a_v
 
   const int tid_o = threadIdx.x, wave_o = tid_o >> 6, lane_o = tid_o & 63;
   const int c8_o = lane_o % LQ, kgl_o = lane_o / LQ;
@@ -238,6 +260,16 @@ __global__ __launch_bounds__(64 * NW, ((!BIG && NW == 4) ? 2 : 1)) void k_attn_c
   // chunks in flight measured no faster -- a CU's 4 waves already pull ~100 GB/s, the per-CU
   // L2->register ceiling measured by ps_test_stream -- and spill at T = 4.)
   WC<RK> wA, wB;
+  // GEO: this row's edge range in the current layer's set (and the next layer's, loaded a layer early), the edge phase's requests in flight
+  C16LatState lat;
+  int g_eb = 0, g_dg = 0, g_ebn = 0, g_dgn = 0;
+  if constexpr (GEO) {
+    if (row0 < Nd && !(flags & 1)) {
+      g_eb = ldgi(steps[0].eoff + row0);
+      g_dg = ldgi(steps[0].eoff + row0 + 1) - g_eb;
+    }
+    c16_lat_request<POLICY ? 1 : 2>(steps, g1, g_eb, g_dg, lat);
+  }
   if (PF) wload(wA, steps[0].w.Wq_t + woff_o, 128);
   // small vectors of layer 0 -> LDS buffer 0 (608 float4: threads take float4 tid, tid+NT, ...)
   constexpr int NSP = (SP_SIZE / 4 + NT - 1) / NT;
@@ -284,10 +316,20 @@ __global__ __launch_bounds__(64 * NW, ((!BIG && NW == 4) ? 2 : 1)) void k_attn_c
     // ---- edge list of each destination -> LDS (source rows), so the row gathers below never wait on an index
     const int t = wave / W, wi = wave % W;
     const int r = row0 + t;
-    const int e_beg = (r < Nd) ? ldgi(st.eoff + r) : 0;
-    const int deg = ((r < Nd) && !(flags & 1)) ? (ldgi(st.eoff + r + 1) - e_beg) : 0;
+    const int e_beg = GEO ? g_eb : ((r < Nd) ? ldgi(st.eoff + r) : 0);
+    const int deg = GEO ? g_dg : (((r < Nd) && !(flags & 1)) ? (ldgi(st.eoff + r + 1) - e_beg) : 0);
+    if constexpr (GEO) {
+      c16_lat_pre<POLICY ? 1 : 2>(&st, g1, e_beg, deg, lat);   // the first tile's k / v rows and the second tile's records leave now
+      g_ebn = g_dgn = 0;
+      if (s + 1 < nsteps && r < Nd && !(flags & 1)) {
+        g_ebn = ldgi(steps[s + 1].eoff + r);
+        g_dgn = ldgi(steps[s + 1].eoff + r + 1) - g_ebn;
+      }
+    }
     int* el = esl + t * CH;
-    for (int e = wi * 64 + lane; e < deg && e < CH; e += 64 * W) el[e] = ldgi(st.esrc + e_beg + e);   // first chunk
+    if (!GEO)
+      for (int e = wi * 64 + lane; e < deg && e < CH; e += 64 * W) el[e] = ldgi(st.esrc + e_beg + e);   // first chunk
+
     // ---- q / s / gate(x) projections of the pre-normed rows (:61-69, :106-107, :114); xn = LN_dst(x)
     {
       float acc[T][4];
@@ -298,9 +340,12 @@ __global__ __launch_bounds__(64 * NW, ((!BIG && NW == 4) ? 2 : 1)) void k_attn_c
       if (kgl == 0) {
 #pragma unroll
         for (int tt = 0; tt < T; ++tt)
-          *reinterpret_cast<float4*>(qb + tt * 128 + ncol) =
-              make_float4(acc[tt][0] + sp[SP_BQ + ncol], acc[tt][1] + sp[SP_BQ + ncol + 1], acc[tt][2] + sp[SP_BQ + ncol + 2],
-                          acc[tt][3] + sp[SP_BQ + ncol + 3]);
+        {
+          const float4 qv = make_float4(acc[tt][0] + sp[SP_BQ + ncol], acc[tt][1] + sp[SP_BQ + ncol + 1], acc[tt][2] + sp[SP_BQ + ncol + 2],
+                                        acc[tt][3] + sp[SP_BQ + ncol + 3]);
+          *reinterpret_cast<float4*>(qb + tt * 128 + ncol) = qv;
+          if (GEO) *reinterpret_cast<float4*>(g1ag + ncol) = qv;
+        }
       }
       zero_acc<T>(acc);
       PS_STAGE(wB, w.Ws_t + woff, 128, wA, w.Wgx_t + woff, 128, xn + kgl * RK, 128);   // Ws
@@ -338,9 +383,14 @@ __global__ __launch_bounds__(64 * NW, ((!BIG && NW == 4) ? 2 : 1)) void k_attn_c
       if (NW == 8) fold_kgroups<T, 32>(acc);
       if (NW == 4 || k2 == 0) {
 #pragma unroll
-        for (int tt = 0; tt < T; ++tt)
-          *reinterpret_cast<float4*>(big + (size_t)(tt * 8 + h) * QP + 4 * c32) =
-              make_float4(acc[tt][0], acc[tt][1], acc[tt][2], acc[tt][3]);
+        for (int tt = 0; tt < T; ++tt) {
+          if (GEO) {
+            if (c32 < 24) *reinterpret_cast<float4*>(g1qa + 4 * G1_QSL + h * G1_QH + 4 * c32) = make_float4(acc[tt][0], acc[tt][1], acc[tt][2], acc[tt][3]);
+          } else {
+            *reinterpret_cast<float4*>(big + (size_t)(tt * 8 + h) * QP + 4 * c32) =
+                make_float4(acc[tt][0], acc[tt][1], acc[tt][2], acc[tt][3]);
+          }
+        }
       }
       if (tid < 8 * T) {
         const int tt = tid >> 3, hh = tid & 7;
@@ -355,7 +405,13 @@ __global__ __launch_bounds__(64 * NW, ((!BIG && NW == 4) ? 2 : 1)) void k_attn_c
     // ---- edge phase: wave -> (destination t, sub-wave wi); lane -> columns (2*lane, 2*lane+1)
     // Chunks of CH edges; per chunk: scores (pass 1) -> running max / rescale -> exp -> weighted sums (pass 2).
     // Every row read is a fully coalesced 512-byte line per wave (r~ rows, k rows, v rows).
-    {
+    if constexpr (GEO) {
+      c16_lat_main<POLICY ? 1 : 2>(&st, g1, cq, div32, e_beg, deg, lat);
+      wload(wA, w.Wvr_gt3 + woff, 128);
+      if (s + 1 < nsteps) c16_lat_request<POLICY ? 1 : 2>(steps + s + 1, g1, g_ebn, g_dgn, lat);   // the next layer's first records
+      g_eb = g_ebn;
+      g_dg = g_dgn;
+    } else {
       float* sc = un + (size_t)t * CH * 8;
       const int t_beg = (r < Nd) ? ldgi(st.toff + r) : 0;
       constexpr bool k4 = KR != 3;   // the fourth rel-PE column block exists (condition rows)
@@ -626,7 +682,35 @@ __global__ __launch_bounds__(64 * NW, ((!BIG && NW == 4) ? 2 : 1)) void k_attn_c
     PS_MARK(8);
     __syncthreads();
     PS_MARK(9);
-    if (W > 1) {  // sum the W sub-wave partials of each destination into its first slot
+    if constexpr (GEO) {   // the four waves' partial softmax sums: common maximum, rescale, add (c16_node_phase's merge).  32 threads per head.
+      const int h = tid >> 5, l5 = tid & 31;
+      float sc[4];
+      {
+        float mp[4], mm = -INFINITY;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) { mp[p] = g1qa[p * G1_QSL + h * G1_QH + 97]; mm = fmaxf(mm, mp[p]); }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) sc[p] = (mp[p] == -INFINITY) ? 0.f : exp2f(mp[p] - mm);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int c = l5 + 32 * k;
+        float a = 0.f;
+        if (k < 3) {
+#pragma unroll
+          for (int p = 0; p < 4; ++p) a = fmaf(g1qa[p * G1_QSL + h * G1_QH + c], sc[p], a);
+        }
+        big[(size_t)h * QP + c] = a;   // (columns 96 .. 127: the fold's weights there are folded onto 64 .. 95)
+      }
+      if (l5 <= 16) {   // a_v columns of head h, and its l
+        float a = 0.f;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) a = fmaf(l5 < 16 ? g1ag[(1 + p) * G1_AGS + h * 16 + l5] : g1qa[p * G1_QSL + h * G1_QH + 96], sc[p], a);
+        if (l5 < 16) avp[h * 16 + l5] = a;
+        else { ml[8 + h] = a; ml[16 + 8 + h] = 0.f; ml[32 + 8 + h] = 0.f; ml[48 + 8 + h] = 0.f; }
+      }
+      __syncthreads();
+    } else if (W > 1) {  // sum the W sub-wave partials of each destination into its first slot
       for (int i = tid; i < T * 8 * 128; i += NT) {
         const int tt = i / 1024, hc = i % 1024, h = hc >> 7, c = hc & 127;
         float a = 0.f;

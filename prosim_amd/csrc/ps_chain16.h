@@ -746,6 +746,277 @@ __device__ __noinline__ void c16_edge_phase(const ChainStep* __restrict__ stp, u
   c16_edge_body<NWV, ONEW, false>(stp, c16_smem, AG, CQ, ctr, QA, div32, row0, nrows, W, none);
 }
 
+// ---- k_attn_chain<1, 4, 3, ., ., GEO>'s edge phase (ps_attn.h; round 5): c16_edge_body's arithmetic for FOUR waves on ONE row (wave w takes
+// the 16-edge tiles w, w + 4, ...; every wave its own online softmax, k_attn_chain merges the four partials like c16_node_phase's POST half
+// merges W partial sums), rescheduled for LATENCY: a wave is alone on its SIMD there (one workgroup per CU, 128 workgroups), so nothing hides a
+// dependent round trip but the wave's own independent work.  c16_edge_body keeps its loads short-lived (248 registers, two waves per SIMD hide
+// each other): the lo halves of a tile's k rows are requested when its hi halves have landed, the v rows after its scores.  Here a tile's
+// k rows (hi AND lo halves, staging areas of their own), v rows (registers) and the NEXT tile's geometry records are all requested ONE TILE AHEAD,
+// the first tile's during the layer's q | s | g stages (c16_lat_pre, called at the top of the layer; the records of that tile are requested
+// at the end of the PREVIOUS layer's edge phase: c16_lat_request), so that a tile waits once, for loads that left a tile ago.
+static_assert(G1_QSL == C16_QSL && G1_QH == C16_QH && G1_AGS == ND_XS && G1_WAVE_FLOATS * 4 == 8192 + 512 + 16 * C16_FS * 2 + 128, "ps_attn.h's GEO layout");
+struct C16LatCtx {   // a wave's addressing (cheap to rebuild: made where it is used)
+  __amdgpu_buffer_rsrc_t rs_geo, rs_k, rs_v;
+  unsigned stg_lds, vcol;
+  int* Ss;
+  int mi, kq, dr, ds_, eh;
+};
+__device__ __forceinline__ C16LatCtx c16_lat_ctx(const ChainStep& st, float* g1) {
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  unsigned char* wbase = reinterpret_cast<unsigned char*>(g1) + (size_t)wave * (G1_WAVE_FLOATS * 4);
+  C16LatCtx c;
+  c.rs_geo = c16_rsrc(st.geo);
+  c.rs_k = c16_rsrc(reinterpret_cast<const unsigned char*>(st.khl) - C16_DMA_BIAS);
+  c.rs_v = c16_rsrc(st.kv);
+  c.stg_lds = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)wbase);
+  c.vcol = 512u + 16u * (lane & 31);
+  c.Ss = reinterpret_cast<int*>(wbase + 8192 + 512 + 16 * C16_FS * 2);
+  c.mi = lane & 15; c.kq = lane >> 4; c.dr = lane >> 4; c.ds_ = lane & 15; c.eh = lane >> 5;
+  return c;
+}
+__device__ __forceinline__ GeoRec c16_lat_rec(const C16LatCtx& c, int e_beg, int deg, int tt) {   // lane mi: edge tt + mi (past the end: the row's last edge)
+  GeoRec r;
+  const unsigned off = (unsigned)(e_beg + max(min(tt + c.mi, deg - 1), 0)) * 32u;
+  r.g = c16_bld4(c.rs_geo, off);
+  const float2 g2 = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(c.rs_geo, off + 16, 0, 0));
+  r.nn = g2.x;
+  r.src = __float_as_int(g2.y);
+  return r;
+}
+// a tile's source rows -> LDS, its k rows (hi | lo halves) by LDS-DMA, its v rows into registers
+__device__ __forceinline__ void c16_lat_issue(const C16LatCtx& c, int buf, int nsrc, float4 (&vv)[8]) {
+  if ((threadIdx.x & 63) < 16) c.Ss[16 * buf + (threadIdx.x & 63)] = nsrc;
+  unsigned kp[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int rr = 4 * i + c.dr;
+    kp[i] = (unsigned)c.Ss[16 * buf + rr] * 512u + 16u * (c.ds_ ^ rr) + (C16_DMA_BIAS - 1024u * i);
+  }
+  c16_wait_lgkm0();   // (the staging areas' last fragment reads are done)
+  c16_blds16x4(kp, c.rs_k, 0u, c.stg_lds);
+  c16_blds16x4(kp, c.rs_k, 256u, c.stg_lds + 4096u);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) vv[j] = c16_bld4(c.rs_v, (unsigned)c.Ss[16 * buf + 2 * j + c.eh] * 1024u + c.vcol);
+}
+template <int TAG>
+__device__ __forceinline__ void c16_lat_request(const ChainStep* __restrict__ stp, float* g1, int e_beg, int deg, C16LatState& S) {
+  const C16LatCtx c = c16_lat_ctx(*stp, g1);
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  if (16 * wave < deg) S.r0 = c16_lat_rec(c, e_beg, deg, 16 * wave);
+}
+template <int TAG>
+__device__ __forceinline__ void c16_lat_pre(const ChainStep* __restrict__ stp, float* g1, int e_beg, int deg, C16LatState& S) {
+  const C16LatCtx c = c16_lat_ctx(*stp, g1);
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  if (16 * wave < deg) {
+    c16_lat_issue(c, 0, S.r0.src, S.vv);
+    S.r1 = c16_lat_rec(c, e_beg, deg, 16 * wave + 64);
+  }
+}
+template <int TAG>
+__device__ __forceinline__ void c16_lat_main(const ChainStep* __restrict__ stp, float* g1, const float* cq, const float* __restrict__ div32, int e_beg, int deg,
+                                             C16LatState& S) {
+  const ChainStep& st = *stp;
+  const C16LatCtx c = c16_lat_ctx(st, g1);
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int mi = c.mi, kq = c.kq;
+  float dv[4], rdv[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    dv[j] = ldg1(div32 + 2 * (4 * kq + j));
+    rdv[j] = 1.0f / dv[j];
+  }
+  const f32x2 dvp[2] = {{dv[0], dv[1]}, {dv[2], dv[3]}}, rdvp[2] = {{rdv[0], rdv[1]}, {rdv[2], rdv[3]}};
+  unsigned char* wbase = reinterpret_cast<unsigned char*>(g1) + (size_t)wave * (G1_WAVE_FLOATS * 4);
+  const half8* stg = reinterpret_cast<const half8*>(wbase);                    // k staging: hi halves [16 rows][16 slots of 16 B], lo halves 4 KB further
+  float* Pt = reinterpret_cast<float*>(wbase + 8192);                          // [16 edges][8 heads] probabilities (for a_v)
+  _Float16* Ft = reinterpret_cast<_Float16*>(wbase + 8192 + 512);              // [16 edges][C16_FS] feature tile (hi, then lo)
+  float* QA = g1 + 4 * G1_WAVE_FLOATS;   // slots 0-3: the waves' a_r (+ l, m), slot 4: q~
+  float* AG = QA + 5 * G1_QSL;           // row 0: q, rows 1-4: the waves' a_v
+  const half8* str = stg + mi * 16 + (kq ^ (mi & 3));
+  const int sra = mi >> 2;
+  const bool loA = mi >= 8;
+  const float selm = loA ? -1.f : -0.f;
+  const int hv = (lane & 31) >> 2, eh = lane >> 5;
+  // B operands of the score MFMAs: lane -> column n = mi (head mi & 7, hi | lo half), k-block kq
+  half8 bq[3], bk[4];
+  float cqm;
+  {
+    const int hB = mi & 7;
+    const float* qtp = QA + 4 * G1_QSL + hB * G1_QH + 8 * kq;
+    const float* qp = AG + 8 * kq;
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks) {
+      const float4 v0 = *reinterpret_cast<const float4*>(qtp + 32 * ks), v1 = *reinterpret_cast<const float4*>(qtp + 32 * ks + 4);
+      const float qv_[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+      bq[ks] = f16_sel8(qv_, selm);
+    }
+    const int ksel = hB >> 1;
+    const bool mine = (kq >> 1) == (hB & 1);
+    const float4 w0 = *reinterpret_cast<const float4*>(qp + 32 * ksel), w1 = *reinterpret_cast<const float4*>(qp + 32 * ksel + 4);
+    const float kv_[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+    const half8 bkv = f16_sel8(kv_, selm);
+    const half8 zero = {};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) bk[ks] = (mine && ks == ksel) ? bkv : zero;
+    cqm = cq[hB];
+  }
+  float m_run = -INFINITY, l_run = 0.f;
+  floatx4 ar[6];
+#pragma unroll
+  for (int cb = 0; cb < 6; ++cb) ar[cb] = floatx4{0.f, 0.f, 0.f, 0.f};
+  float4 av = make_float4(0.f, 0.f, 0.f, 0.f);
+  GeoRec cur = S.r0, nxt = S.r1;
+  float4 vv[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) vv[j] = S.vv[j];
+  int sb = 0;
+#pragma unroll 1
+  for (int t0 = 16 * wave; t0 < deg;) {
+    const int n = min(16, deg - t0);
+    const int tn = __builtin_amdgcn_readfirstlane(t0 + 64);
+    // ---- everything this tile reads left a tile ago: one wait, the fragments, then the NEXT tile's requests
+    half8 akh[4], akl[4];
+    c16_wait_vm0();
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) { akh[ks] = str[4 * (ks ^ sra)]; akl[ks] = str[256 + 4 * (ks ^ sra)]; }
+    float4 vvn[8];
+    GeoRec far = nxt;
+    if (tn < deg) {
+      c16_lat_issue(c, sb ^ 1, nxt.src, vvn);
+      far = c16_lat_rec(c, e_beg, deg, tn + 64);
+    } else {
+      c16_wait_lgkm0();
+#pragma unroll
+      for (int j = 0; j < 8; ++j) vvn[j] = vv[j];
+    }
+    const float4 g0 = cur.g;
+    const float nmr = cur.nn;
+    float sreg[4];
+    half8 fl[3];
+    {
+      floatx4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) acc2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(akh[ks], bk[ks], acc2, 0, 0, 0);
+      half8 fh[3];
+      feat8(g0.x, g0.w, nmr, dvp, rdvp, fh[0], fl[0]);
+      feat8(g0.y, g0.w, nmr, dvp, rdvp, fh[1], fl[1]);
+      feat8(g0.z, g0.w, nmr, dvp, rdvp, fh[2], fl[2]);
+      if (__builtin_expect(__any(!(fdiv16_ok(g0.x) && fdiv16_ok(g0.y) && fdiv16_ok(g0.z))), 0)) {
+        _Float16* frow = Ft + mi * C16_FS;
+        feat_slow_row(g0.x, g0.y, g0.z, g0.w, nmr, dv, kq, frow, true);
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) fl[ks] = *reinterpret_cast<const half8*>(frow + 32 * ks + 8 * kq);
+        feat_slow_row(g0.x, g0.y, g0.z, g0.w, nmr, dv, kq, frow, false);
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) fh[ks] = *reinterpret_cast<const half8*>(frow + 32 * ks + 8 * kq);
+      }
+#pragma unroll
+      for (int ks = 0; ks < 3; ++ks) *reinterpret_cast<half8*>(Ft + mi * C16_FS + 32 * ks + 8 * kq) = fh[ks];
+#pragma unroll
+      for (int ks = 0; ks < 3; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[ks], bq[ks], acc, 0, 0, 0);
+#pragma unroll
+      for (int ks = 0; ks < 3; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl[ks], bq[ks], acc, 0, 0, 0);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) acc2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(akl[ks], bk[ks], acc2, 0, 0, 0);
+      acc += acc2;
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const float v = acc[r4] + dpp_xor8(acc[r4]);
+        sreg[r4] = (v + cqm) * (0.25f * 1.44269504088896341f);
+      }
+      if (n < 16) {
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) sreg[r4] = (4 * kq + r4 < n) ? sreg[r4] : -INFINITY;
+      }
+    }
+    // ---- online softmax over the tile (as c16_edge_body)
+    float tmax = fmaxf(fmaxf(sreg[0], sreg[1]), fmaxf(sreg[2], sreg[3]));
+    const float m_new = kq_max3(tmax, m_run);
+    const bool fresh = m_run == -INFINITY;
+    const float scale = fresh ? 0.f : __builtin_amdgcn_exp2f(m_run - m_new);
+    float psum = 0.f;
+    float pr[4];
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+      const float p = __builtin_amdgcn_exp2f(sreg[r4] - m_new);
+      pr[r4] = p;
+      psum += p;
+    }
+    if (mi < 8) {
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) Pt[(4 * kq + r4) * 8 + mi] = pr[r4];
+    }
+    psum = kq_sum(psum);
+    l_run = l_run * scale + psum;
+    m_run = m_new;
+    if (__any(scale != 1.f && !fresh)) {
+      float scl[8];
+#pragma unroll
+      for (int h = 0; h < 8; ++h) scl[h] = __shfl(scale, h);
+      const bool up = kq & 1;
+      const float s0 = up ? scl[4] : scl[0], s1 = up ? scl[5] : scl[1], s2 = up ? scl[6] : scl[2], s3 = up ? scl[7] : scl[3];
+#pragma unroll
+      for (int cb = 0; cb < 6; ++cb) { ar[cb][0] *= s0; ar[cb][1] *= s1; ar[cb][2] *= s2; ar[cb][3] *= s3; }
+      float sh = scl[0];
+#pragma unroll
+      for (int h = 1; h < 8; ++h) sh = (hv == h) ? scl[h] : sh;
+      av.x *= sh; av.y *= sh; av.z *= sh; av.w *= sh;
+    }
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const half4v ap = __builtin_bit_cast(half4v, u32x2{f16_sel_pk(f16_hi_pk(pr[0], pr[1]), pr[0], pr[1], selm),
+                                                       f16_sel_pk(f16_hi_pk(pr[2], pr[3]), pr[2], pr[3], selm)});
+    const _Float16* tp = Ft + (kq * 4 + (mi >> 2)) * C16_FS + (lane & 3) * 4;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      if (pass == 1) {
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) *reinterpret_cast<half8*>(Ft + mi * C16_FS + 32 * ks + 8 * kq) = fl[ks];
+      }
+      fp16x4 tv[6];
+#pragma unroll
+      for (int cb = 0; cb < 6; ++cb) tv[cb] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)(tp + cb * 16));
+#pragma unroll
+      for (int cb = 0; cb < 6; ++cb) {
+        half4v bfr;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bfr[j] = (_Float16)tv[cb][j];
+        ar[cb] = __builtin_amdgcn_mfma_f32_16x16x16f16(ap, bfr, ar[cb], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float ph = Pt[(2 * j + eh) * 8 + hv];
+      av.x = fmaf(ph, vv[j].x, av.x);
+      av.y = fmaf(ph, vv[j].y, av.y);
+      av.z = fmaf(ph, vv[j].z, av.z);
+      av.w = fmaf(ph, vv[j].w, av.w);
+    }
+    cur = nxt;
+    nxt = far;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) vv[j] = vvn[j];
+    sb ^= 1;
+    t0 = tn;
+  }
+  // ---- the wave's partial sums -> LDS (slot = wave)
+  float* oar = QA + wave * G1_QSL;
+  av.x = xor_add<32>(av.x); av.y = xor_add<32>(av.y); av.z = xor_add<32>(av.z); av.w = xor_add<32>(av.w);
+  if (lane < 8) {
+    oar[lane * G1_QH + 96] = l_run;
+    oar[lane * G1_QH + 97] = m_run;
+  }
+  if (lane < 32) *reinterpret_cast<float4*>(AG + (1 + wave) * G1_AGS + 4 * lane) = av;
+#pragma unroll
+  for (int cb = 0; cb < 6; cb += 2) {
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+      const float v = swap_add32(ar[cb][r4], ar[cb + 1][r4]);
+      oar[(4 * ((lane >> 4) & 1) + r4) * G1_QH + (cb + (lane >> 5)) * 16 + (lane & 15)] = v;
+    }
+  }
+}
+
 // phase clocks of the node phases (tools only: build with -DPS_C16_PROF and run with PS_CHAIN_PROF=1; compiled out of the
 // product library -- the marks split basic blocks)
 #ifdef PS_C16_PROF
