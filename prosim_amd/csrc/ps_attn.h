@@ -161,15 +161,18 @@ __device__ __forceinline__ void fold_kgroups(float (&acc)[T][4]) {
 // register sets live.  Otherwise (two workgroups per CU, <= 256 registers): it is requested right AFTER this
 // chunk's FMAs, into registers that just died -- one set live, and the request still flies under the fold, the
 // LDS write and the barrier that close the stage.  CURP/CURN are kept for readability only.
-#define PS_STAGE(CUR, CURP, CURN, NXT, NXTP, NXTN, X, XS) \
+#define PS_STAGE_(EARLY, CUR, CURP, CURN, NXT, NXTP, NXTN, X, XS) \
   do {                                                    \
-    if (PF) wload(NXT, NXTP, NXTN);                       \
+    if (EARLY) wload(NXT, NXTP, NXTN);                    \
     wfma<T, RK>(CUR, X, XS, acc);                         \
-    if (!PF) {                                            \
+    if (!(EARLY)) {                                       \
       __builtin_amdgcn_sched_barrier(0);                  \
       wload(NXT, NXTP, NXTN);                             \
     }                                                     \
   } while (0)
+#define PS_STAGE(CUR, CURP, CURN, NXT, NXTP, NXTN, X, XS) PS_STAGE_(PF, CUR, CURP, CURN, NXT, NXTP, NXTN, X, XS)
+// the one-chunk stages (q, s, g, the fold, the gate, to_out): GEO requests their next chunk early too (PFN)
+#define PS_STAGE_N(CUR, CURP, CURN, NXT, NXTP, NXTN, X, XS) PS_STAGE_(PFN, CUR, CURP, CURN, NXT, NXTP, NXTN, X, XS)
 
 // KR: distinct rel-PE column blocks of 32 (3 for geometric edge sets, 4 for condition rows / the test hook); a
 // launch only ever chains steps of one kind, so it is a compile-time parameter (ChainStep::kr must agree).
@@ -230,7 +233,11 @@ __global__ __launch_bounds__(64 * NW, ((!BIG && NW == 4 && !GEO) ? 2 : 1)) void 
   // T == 1: one workgroup per CU with the full register file -> software prefetch (weights one chunk ahead,
   // edge rows one tile ahead).  T >= 2: compiled for 2 workgroups per CU (__launch_bounds__(256, 2), <= 256
   // registers): the co-resident workgroup hides the latency instead and nothing is double-buffered.
-  constexpr bool PF = BIG;                     // weight chunks one stage ahead (second register set; GEO with its 512 registers: measured slower, 0.227 against 0.221 ms)
+  constexpr bool PF = BIG;                     // weight chunks one stage ahead (second register set)
+  // ... in the one-chunk stages (q, s, g, fold, gate, to_out).  Not for GEO either: a lane addresses 256 registers, what the launch bound adds
+  // beyond them are AGPRs the allocator spills into -- with early requests anywhere (all stages: 0.227 ms, these stages: 0.224) the FFN loop
+  // pays v_accvgpr moves per weight register (its phase 137 k -> 160 k cycles) and the launch loses against 0.221 ms
+  constexpr bool PFN = BIG;
   constexpr bool PFE = BIG;                    // edge rows one tile ahead
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* xs = smem;                 // [T][128] residual stream
@@ -270,7 +277,7 @@ __global__ __launch_bounds__(64 * NW, ((!BIG && NW == 4 && !GEO) ? 2 : 1)) void 
     }
     c16_lat_request<POLICY ? 1 : 2>(steps, g1, g_eb, g_dg, lat);
   }
-  if (PF) wload(wA, steps[0].w.Wq_t + woff_o, 128);
+  if (PFN) wload(wA, steps[0].w.Wq_t + woff_o, 128);
   // small vectors of layer 0 -> LDS buffer 0 (608 float4: threads take float4 tid, tid+NT, ...)
   constexpr int NSP = (SP_SIZE / 4 + NT - 1) / NT;
   float4 spr[NSP];
@@ -334,8 +341,8 @@ __global__ __launch_bounds__(64 * NW, ((!BIG && NW == 4 && !GEO) ? 2 : 1)) void 
     {
       float acc[T][4];
       zero_acc<T>(acc);
-      if (!PF) wload(wA, w.Wq_t + woff, 128);   // (late mode keeps no weights in registers across the layer boundary)
-      PS_STAGE(wA, w.Wq_t + woff, 128, wB, w.Ws_t + woff, 128, xn + kgl * RK, 128);    // Wq
+      if (!PFN) wload(wA, w.Wq_t + woff, 128);   // (late mode keeps no weights in registers across the layer boundary)
+      PS_STAGE_N(wA, w.Wq_t + woff, 128, wB, w.Ws_t + woff, 128, xn + kgl * RK, 128);    // Wq
       fold_kgroups<T, LQ>(acc);
       if (kgl == 0) {
 #pragma unroll
@@ -348,7 +355,7 @@ __global__ __launch_bounds__(64 * NW, ((!BIG && NW == 4 && !GEO) ? 2 : 1)) void 
         }
       }
       zero_acc<T>(acc);
-      PS_STAGE(wB, w.Ws_t + woff, 128, wA, w.Wgx_t + woff, 128, xn + kgl * RK, 128);   // Ws
+      PS_STAGE_N(wB, w.Ws_t + woff, 128, wA, w.Wgx_t + woff, 128, xn + kgl * RK, 128);   // Ws
       fold_kgroups<T, LQ>(acc);
       if (kgl == 0) {
 #pragma unroll
@@ -361,7 +368,7 @@ __global__ __launch_bounds__(64 * NW, ((!BIG && NW == 4 && !GEO) ? 2 : 1)) void 
       // q~ chunk: NW = 4: wave -> heads 2*wave + k2, all 16 rows of the head; NW = 8: wave -> head `wave`,
       // k2 -> its 8-row half.  lane & 31 -> 4 columns.
       const float* wkr = (KR == 3 ? w.Wkr_g3 : w.Wkr_g) + (size_t)(NW == 4 ? (2 * wave + k2) * 16 : wave * 16 + 8 * k2) * 128 + 4 * c32;
-      PS_STAGE(wA, w.Wgx_t + woff, 128, wB, wkr, 128, xn + kgl * RK, 128);   // Wgx
+      PS_STAGE_N(wA, w.Wgx_t + woff, 128, wB, wkr, 128, xn + kgl * RK, 128);   // Wgx
       fold_kgroups<T, LQ>(acc);
       if (kgl == 0) {
 #pragma unroll
@@ -731,7 +738,7 @@ __global__ __launch_bounds__(64 * NW, ((!BIG && NW == 4 && !GEO) ? 2 : 1)) void 
     {
       float acc[T][4];
       zero_acc<T>(acc);
-      PS_STAGE(wA, (KR == 3 ? w.Wvr_gt3 : w.Wvr_gt) + woff, 128, wB, w.Wga_t + woff, 128, big + (size_t)(ncol >> 4) * QP + kgl * RK, W * 8 * QP);   // Wvr
+      PS_STAGE_N(wA, (KR == 3 ? w.Wvr_gt3 : w.Wvr_gt) + woff, 128, wB, w.Wga_t + woff, 128, big + (size_t)(ncol >> 4) * QP + kgl * RK, W * 8 * QP);   // Wvr
       fold_kgroups<T, LQ>(acc);
       if (kgl == 0) {
         const int h = ncol >> 4;
@@ -753,7 +760,7 @@ __global__ __launch_bounds__(64 * NW, ((!BIG && NW == 4 && !GEO) ? 2 : 1)) void 
     {
       float acc[T][4];
       zero_acc<T>(acc);
-      PS_STAGE(wB, w.Wga_t + woff, 128, wA, w.Wout_t + woff, 128, ag + kgl * RK, 128);   // Wga
+      PS_STAGE_N(wB, w.Wga_t + woff, 128, wA, w.Wout_t + woff, 128, ag + kgl * RK, 128);   // Wga
       fold_kgroups<T, LQ>(acc);
       if (kgl == 0) {
 #pragma unroll
@@ -776,7 +783,7 @@ __global__ __launch_bounds__(64 * NW, ((!BIG && NW == 4 && !GEO) ? 2 : 1)) void 
     {
       float acc[T][4];
       zero_acc<T>(acc);
-      PS_STAGE(wA, w.Wout_t + woff, 128, wB, w.W1_t + (size_t)(k5 * 4 * RK) * 512 + ncol5, 512, f1 + kgl * RK, 128);   // Wout
+      PS_STAGE_N(wA, w.Wout_t + woff, 128, wB, w.W1_t + (size_t)(k5 * 4 * RK) * 512 + ncol5, 512, f1 + kgl * RK, 128);   // Wout
       fold_kgroups<T, LQ>(acc);
       if (kgl == 0) {
 #pragma unroll
@@ -831,7 +838,7 @@ __global__ __launch_bounds__(64 * NW, ((!BIG && NW == 4 && !GEO) ? 2 : 1)) void 
       PS_STAGE(wB, w2 + (size_t)2 * RK * 128, 128, wA, w2 + (size_t)3 * RK * 128, 128, fk + 2 * RK, 512);
       wfma<T, RK>(wA, fk + 3 * RK, 512, acc);
       // the next layer's first chunk leaves now; it lands during the fold and the two norms
-      if (PF && s + 1 < nsteps) wload(wA, steps[s + 1].w.Wq_t + woff, 128);
+      if (PFN && s + 1 < nsteps) wload(wA, steps[s + 1].w.Wq_t + woff, 128);
       fold_kgroups<T, LQ>(acc);
       if (kgl == 0) {
 #pragma unroll
