@@ -165,6 +165,19 @@ int dev_zero(hipStream_t st, void* dst, size_t bytes) {
   hipLaunchKernelGGL(k_dev_zero, dim3(grid), dim3(256), 0, st, static_cast<uint32_t*>(dst), v16 ? n : 0, v16 ? 0 : n);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
+// two small segments in ONE launch (a launch is ~5 us of a single-scene rollout whatever it moves): copy, or zero fill where the source is null
+struct CopySeg { uint32_t* dst; const uint32_t* src; size_t n4; };
+__global__ __launch_bounds__(256) void k_dev_copy2(CopySeg a, CopySeg b) {
+  const CopySeg& s = blockIdx.y ? b : a;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < s.n4; i += (size_t)gridDim.x * blockDim.x) s.dst[i] = s.src ? s.src[i] : 0u;
+}
+int dev_copy2(hipStream_t st, void* d0, const void* s0, size_t b0, void* d1, const void* s1, size_t b1) {
+  const CopySeg a{static_cast<uint32_t*>(d0), static_cast<const uint32_t*>(s0), b0 / 4}, b{static_cast<uint32_t*>(d1), static_cast<const uint32_t*>(s1), b1 / 4};
+  const size_t n = std::max(a.n4, b.n4);
+  if (!n) return 0;
+  hipLaunchKernelGGL(k_dev_copy2, dim3((unsigned)std::min<size_t>(256, (n + 255) / 256), 2), dim3(256), 0, st, a, b);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
 // one upload stream per device and process (an extra stream PER ENGINE costs the pipelined loop more than it hides: DESIGN.md section 7, round 3)
 hipStream_t upload_stream(int device) {
   static std::mutex mu;
@@ -2151,8 +2164,8 @@ extern "C" int ps_encode_scene(ps_engine* e) {
   hipStream_t st = e->stream;
   float* tok = e->d_tok.p;
   // agent token geometry back to the init poses (a previous rollout moved them)
-  if (dev_copy(st, e->d_tok_pos.p + 2 * (size_t)Mv, e->d_init_pos.p, sizeof(float) * 2 * A)) return fail(PS_E_HIP, "device copy launch failed");
-  if (dev_copy(st, e->d_tok_ori.p + Mv, e->d_init_head.p, sizeof(float) * A)) return fail(PS_E_HIP, "device copy launch failed");
+  if (dev_copy2(st, e->d_tok_pos.p + 2 * (size_t)Mv, e->d_init_pos.p, sizeof(float) * 2 * A, e->d_tok_ori.p + Mv, e->d_init_head.p, sizeof(float) * A))
+    return fail(PS_E_HIP, "device copy launch failed");
   launch_pointnet(e, e->pn_map, e->d_map_input.p, e->d_map_mask.p, e->d_map_rows.p, Mv, e->P, 0, tok);
   launch_pointnet(e, e->pn_obs, e->d_obs_input.p, e->d_obs_mask.p, e->d_agent_rows.p, Ap, c.hist_steps, c.obs_dim, tok + (size_t)Mv * D);
   // knn graphs (attn_fusion.py:107-109) + rel-PE (:111-112).  Agent rows that only enter the scene with a later fut_obs
@@ -2233,6 +2246,14 @@ extern "C" int ps_encode_scene(ps_engine* e) {
   return PS_OK;
 }
 
+namespace {
+// k_mlp_rows over n_rows rows (the last argument of every call): one row per workgroup up to 256 rows, eight beyond
+void launch_mlp_rows(hipStream_t st, const Mlp3W& m, const float* in, const int* rows, int in_stride, float* out, int out_stride, float eps, int n_rows) {
+  if (n_rows <= 256) hipLaunchKernelGGL(k_mlp_rows<1>, dim3((unsigned)n_rows), dim3(128), 0, st, m, in, rows, in_stride, out, out_stride, eps, n_rows);
+  else hipLaunchKernelGGL(k_mlp_rows<8>, dim3((unsigned)((n_rows + 7) / 8)), dim3(128), 0, st, m, in, rows, in_stride, out, out_stride, eps, n_rows);
+}
+}  // namespace
+
 extern "C" int ps_generate_policy(ps_engine* e) {
   if (!e || !e->encoded) return fail(PS_E_STATE, "ps_generate_policy before ps_encode_scene");
   HIPCHK(hipSetDevice(e->cfg.device));
@@ -2241,8 +2262,7 @@ extern "C" int ps_generate_policy(ps_engine* e) {
   const int Ap = e->Ap;   // rows the generator computes (== A without replicas)
   hipStream_t st = e->stream;
   // prompt encoder (prompt_encoder/base.py:36-46)
-  const dim3 gmlp((unsigned)((Ap + MLP_R - 1) / MLP_R));
-  hipLaunchKernelGGL(k_mlp_rows, gmlp, dim3(128), 0, st, e->mlp_prompt, (const float*)e->d_prompt.p, (const int*)e->d_agent_rows.p,
+  launch_mlp_rows(st, e->mlp_prompt, (const float*)e->d_prompt.p, (const int*)e->d_agent_rows.p,
                      c.prompt_dim, e->d_xp.p, D, c.ln_eps, Ap);
   // prompt poses (== the observed poses in the reference's batches; kept separate for generality)
   const float* ppos = e->d_prompt_pos.p;
@@ -2250,15 +2270,14 @@ extern "C" int ps_generate_policy(ps_engine* e) {
   const int* pscene = e->d_tok_scene.p + Mv;
   // p2p: radius_graph over prompts, loop=False (sym_coord.py:86); candidates = the scene's agents,
   // positions taken from the prompt poses -> stage them as the agent token geometry
-  if (dev_copy(st, e->d_tok_pos.p + 2 * (size_t)Mv, ppos, sizeof(float) * 2 * A)) return fail(PS_E_HIP, "device copy launch failed");
-  if (dev_copy(st, e->d_tok_ori.p + Mv, pori, sizeof(float) * A)) return fail(PS_E_HIP, "device copy launch failed");
+  if (dev_copy2(st, e->d_tok_pos.p + 2 * (size_t)Mv, ppos, sizeof(float) * 2 * A, e->d_tok_ori.p + Mv, pori, sizeof(float) * A)) return fail(PS_E_HIP, "device copy launch failed");
   // (with log-replay agents in the scene only the policy agents are prompts: candidate filter)
   const int pe_gen = (use_c16(e, Ap, 1) || use_geo1(e, Ap, 1)) ? 2 : 1;   // k_chain16 rebuilds the rel-PE rows from geometry records, k_attn_chain streams operand images
   launch_radius(e, e->e_p2p, e->d_r_agent.p, nullptr, ppos, pscene, Ap, c.dec_prompt_radius, c.dec_max_neigh, Mv, e->d_tok_ori.p, pori,
                 e->all_policy ? nullptr : (const int*)e->d_is_policy.p, Mv, pe_gen, pe_of(e, &e->e_p2p), c.rel_pos_knn != 0);
   // restore observed agent poses for the scene tokens, then s2p: radius over all scene tokens (:94)
-  if (dev_copy(st, e->d_tok_pos.p + 2 * (size_t)Mv, e->d_init_pos.p, sizeof(float) * 2 * A)) return fail(PS_E_HIP, "device copy launch failed");
-  if (dev_copy(st, e->d_tok_ori.p + Mv, e->d_init_head.p, sizeof(float) * A)) return fail(PS_E_HIP, "device copy launch failed");
+  if (dev_copy2(st, e->d_tok_pos.p + 2 * (size_t)Mv, e->d_init_pos.p, sizeof(float) * 2 * A, e->d_tok_ori.p + Mv, e->d_init_head.p, sizeof(float) * A))
+    return fail(PS_E_HIP, "device copy launch failed");
   launch_radius(e, e->e_s2p, e->d_r_map.p, e->d_r_agent.p, ppos, pscene, Ap, c.dec_scene_radius, c.dec_max_neigh, -1,
                 e->d_tok_ori.p, pori, e->have_dead0 ? (const int*)e->d_live0.p : nullptr, Mv, pe_gen, pe_of(e, &e->e_s2p), c.rel_pos_knn != 0);
   // k|v of the (fixed) scene tokens for all s2p layers in one launch
@@ -2267,15 +2286,17 @@ extern "C" int ps_generate_policy(ps_engine* e) {
   for (int i = 0; i < c.dec_layers; ++i) {
     // p2p edges carry GLOBAL agent rows (Mv + j): project into rows Mv.. of the shared kv buffer
     launch_kv(e, e->d_xp.p, Ap, e->L_p2p + i, 1, e->d_kv.p + (size_t)Mv * 256, e->d_kh.p + (size_t)Mv * 256, 0);
+    // (the last pair leaves its rows in d_emd, the policy embedding: rows in from d_xp, out to d_emd -- no copy launch)
+    float* xo = i + 1 == c.dec_layers ? e->d_emd.p : e->d_xp.p;
     if (use_c16(e, Ap, 1)) {
-      if (launch_chain16(e, e->d_xp.p, Ap, e->d_steps.p + e->step_dec + 2 * i, 2, false, nullptr, false)) return PS_E_HIP;
-    } else if (launch_chain(e, e->d_xp.p, Ap, e->step_dec + 2 * i, 2, md, false, nullptr, 0, 0, nullptr, xcd_on(2, false), use_geo1(e, Ap, 1))) return PS_E_HIP;
+      if (launch_chain16(e, xo, Ap, e->d_steps.p + e->step_dec + 2 * i, 2, false, e->d_xp.p, false)) return PS_E_HIP;
+    } else if (launch_chain(e, xo, Ap, e->step_dec + 2 * i, 2, md, false, nullptr, 0, 0, e->d_xp.p, xcd_on(2, false), use_geo1(e, Ap, 1))) return PS_E_HIP;
   }
-  if (dev_copy(st, e->d_emd.p, e->d_xp.p, sizeof(float) * (size_t)Ap * D)) return fail(PS_E_HIP, "device copy launch failed");
+  if (c.dec_layers <= 0 && dev_copy(st, e->d_emd.p, e->d_xp.p, sizeof(float) * (size_t)Ap * D)) return fail(PS_E_HIP, "device copy launch failed");
   if (c.goal_pred_k > 0) {   // Decoder._goal_pred on the decoder's embedding (decoder/base.py:22-58, sym_coord.py:133-136)
-    hipLaunchKernelGGL(k_mlp_rows, gmlp, dim3(128), 0, st, e->mlp_goal_prob, (const float*)e->d_xp.p, (const int*)nullptr, D,
+    launch_mlp_rows(st, e->mlp_goal_prob, (const float*)e->d_emd.p, (const int*)nullptr, D,
                        e->d_goal_prob.p, c.goal_pred_k, c.ln_eps, Ap);
-    hipLaunchKernelGGL(k_mlp_rows, gmlp, dim3(128), 0, st, e->mlp_goal_point, (const float*)e->d_xp.p, (const int*)nullptr, D,
+    launch_mlp_rows(st, e->mlp_goal_point, (const float*)e->d_emd.p, (const int*)nullptr, D,
                        e->d_goal_point.p, 2 * c.goal_pred_k, c.ln_eps, Ap);
   }
   // condition transformer at 'policy_decoder' (traj_sam.py:129-137)
@@ -2298,7 +2319,7 @@ extern "C" int ps_generate_policy(ps_engine* e) {
   }
   // reconst_pred = pred_mlp(policy_emd) (act_decoder.py:133-135) -- constant over the replans
   if (!c.no_reconst_pred)   // (USE_GOAL_PRED_LOSS)
-    hipLaunchKernelGGL(k_mlp_rows, gmlp, dim3(128), 0, st, e->mlp_pred, (const float*)e->d_emd.p, (const int*)nullptr, D,
+    launch_mlp_rows(st, e->mlp_pred, (const float*)e->d_emd.p, (const int*)nullptr, D,
                        e->d_reconst.p, 2, c.ln_eps, Ap);
   if (e->replicas > 1) {   // the replicas share the prompts' embeddings (gpu_utils.py:73-82): fan the Ap computed rows out
     auto fan = [&](float* p, int w) {
@@ -2322,8 +2343,8 @@ extern "C" int ps_reset_rollout(ps_engine* e) {
   HIPCHK(hipSetDevice(e->cfg.device));
   const ps_config& c = e->cfg;
   hipStream_t st = e->stream;
-  if (dev_zero(st, e->d_traj.p, sizeof(float) * (size_t)e->A * e->stride_steps * 4)) return fail(PS_E_HIP, "device fill launch failed");
-  if (dev_zero(st, e->d_vel.p, sizeof(float) * (size_t)e->A * e->stride_steps * 2)) return fail(PS_E_HIP, "device fill launch failed");
+  if (dev_copy2(st, e->d_traj.p, nullptr, sizeof(float) * (size_t)e->A * e->stride_steps * 4, e->d_vel.p, nullptr, sizeof(float) * (size_t)e->A * e->stride_steps * 2))
+    return fail(PS_E_HIP, "device fill launch failed");
   const int n = e->A * c.hist_steps;
   hipLaunchKernelGGL(k_init_state, dim3((n + 255) / 256), dim3(256), 0, st, (const float*)e->d_obs_input.p, (const int*)e->d_agent_rows.p,
                      e->A, c.hist_steps, c.obs_dim, e->stride_steps, e->d_traj.p, e->d_vel.p);

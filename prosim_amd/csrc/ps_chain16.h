@@ -133,14 +133,27 @@ __global__ __launch_bounds__(GEO_THREADS) void k_edge_geo(GeoSets sets, const fl
     // operands of round 4 the parity table holds either way, and the pass was a third of this kernel: 96 LDS round trips per edge.)
     float sm = 0.f;
     if (__builtin_expect(fast, 1)) {   // (the two forms in branches of their own: sharing one loop, libm's sincosf kept the kernel at 145 registers)
+      // two frequencies per packed instruction through the exact division and the reduction to revolutions (round 5: feat8's scheme, the
+      // operations of fourier_pair / sincos_hw in the same order on the same values -- the sums keep their order, the records their bits)
+      constexpr float C1 = 0.15915494309189535f;
+      constexpr float C2 = (float)(0.15915494309189535 - (double)0.15915494309189535f);
+      typedef float f32x2_ __attribute__((ext_vector_type(2)));
+      const f32x2_ c1 = {C1, C1}, c2 = {C2, C2};
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
         float part = 0.f;
+        const f32x2_ x2 = {xs[i], xs[i]};
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-          float sv, cv;
-          fourier_pair(xs[i], dv[k], rdv[k], true, sv, cv);
-          part += sv + cv;
+        for (int k = 0; k < 16; k += 2) {
+          const f32x2_ d2 = {dv[k], dv[k + 1]}, rd2 = {rdv[k], rdv[k + 1]};
+          const f32x2_ q0 = x2 * rd2;
+          const f32x2_ rem = __builtin_elementwise_fma(-q0, d2, x2);
+          const f32x2_ q = __builtin_elementwise_fma(rem, rd2, q0);
+          const f32x2_ u = q * c1;
+          const f32x2_ n = {rintf(u.x), rintf(u.y)};
+          const f32x2_ f = __builtin_elementwise_fma(q, c1, -n) + q * c2;
+          part += __builtin_amdgcn_sinf(f.x) + __builtin_amdgcn_cosf(f.x);
+          part += __builtin_amdgcn_sinf(f.y) + __builtin_amdgcn_cosf(f.y);
         }
         sm += (i == 2) ? 2.f * part : part;
       }

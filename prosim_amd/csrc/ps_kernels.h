@@ -808,7 +808,9 @@ __device__ __forceinline__ void mlp3_rows1(const Mlp3W& m, float* bufA, float* b
 // MLP_R rows per workgroup (round 4; one row per workgroup before): thread n still owns output n and walks k in order -- per row the
 // same fma chain, the same LayerNorm reduction (one wave per row), so the results are bit-identical -- but a weight element is loaded
 // once for MLP_R rows instead of once per row (1024 prompt rows: 34 -> 24 us; staging the weights through LDS as well was slower: the loop is bound by its LDS reads of the rows).  n_rows: rows of `out`; dims <= 128.
-constexpr int MLP_R = 8;
+// (round 5: MLP_R = 1 again for up to 256 rows -- a single scene's 128 prompts are 16 workgroups of 8 rows on 16 of 256 CUs, 31 us per launch,
+// against 128 one-row workgroups; the same fma chain per output either way)
+template <int MLP_R>
 __global__ __launch_bounds__(128) void k_mlp_rows(Mlp3W m, const float* __restrict__ in, const int* __restrict__ rows,
                                                   int in_stride, float* __restrict__ out, int out_stride, float eps, int n_rows) {
   __shared__ float a[MLP_R][128], b[MLP_R][128];
