@@ -2035,7 +2035,9 @@ bool use_geo1(const ps_engine* e, int Nd, int part) {
   static const bool off = exp_env("PS_NO_GEO1") != nullptr;
   static const bool t1 = exp_env("PS_CHAIN_T1") != nullptr;
   if (off || t1 || e->pe_on[part] || use_c16(e, Nd, part)) return false;
-  return e->chain_impl == 0 && Nd < 512;
+  // (up to 256 rows: the build holds 122 KB of LDS, one workgroup per CU -- 257 .. 511 rows would take two rounds of the chip where the
+  // operand-image build co-locates two workgroups per CU)
+  return e->chain_impl == 0 && Nd <= 256;
 }
 int chain16_rows(ps_engine* e, int Nd) {
   static const int env_rows = exp_env("PS_C16_ROWS") ? atoi(exp_env("PS_C16_ROWS")) : 0;   // experiments only

@@ -196,7 +196,7 @@ __device__ __forceinline__ void fold_kgroups(float (&acc)[T][4]) {
 constexpr int G1_WAVE_FLOATS = 3104, G1_QSL = 808, G1_QH = 100, G1_AGS = 132;
 constexpr size_t G1_FLOATS = (size_t)4 * G1_WAVE_FLOATS + 5 * G1_QSL + 5 * G1_AGS;
 struct GeoRec { float4 g; float nn; int src; };          // an edge's record as loaded: (a0, a1, a2, rstd), -mean rstd, source row
-struct C16LatState { GeoRec r0, r1; float4 vv[8]; };     // a wave's requests in flight between the calls below
+struct C16LatState { GeoRec r0, r1; float4 vv[8]; float dv[4], rdv[4]; };     // a wave's requests in flight between the calls below; this lane's four Fourier divisors and their reciprocals (made once per launch)
 template <int TAG> __device__ void c16_lat_request(const ChainStep* __restrict__ stp, float* g1, int e_beg, int deg, C16LatState& S);
 template <int TAG> __device__ void c16_lat_pre(const ChainStep* __restrict__ stp, float* g1, int e_beg, int deg, C16LatState& S);
 template <int TAG> __device__ void c16_lat_main(const ChainStep* __restrict__ stp, float* g1, const float* cq, const float* __restrict__ div32, int e_beg, int deg,
@@ -276,6 +276,11 @@ __global__ __launch_bounds__(64 * NW, ((!BIG && NW == 4 && !GEO) ? 2 : 1)) void 
       g_dg = ldgi(steps[0].eoff + row0 + 1) - g_eb;
     }
     c16_lat_request<POLICY ? 1 : 2>(steps, g1, g_eb, g_dg, lat);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      lat.dv[j] = ldg1(div32 + 2 * (4 * (lane_o >> 4) + j));
+      lat.rdv[j] = 1.0f / lat.dv[j];
+    }
   }
   if (PFN) wload(wA, steps[0].w.Wq_t + woff_o, 128);
   // small vectors of layer 0 -> LDS buffer 0 (608 float4: threads take float4 tid, tid+NT, ...)

@@ -833,12 +833,8 @@ __device__ __forceinline__ void c16_lat_main(const ChainStep* __restrict__ stp, 
   const C16LatCtx c = c16_lat_ctx(st, g1);
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int mi = c.mi, kq = c.kq;
-  float dv[4], rdv[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    dv[j] = ldg1(div32 + 2 * (4 * kq + j));
-    rdv[j] = 1.0f / dv[j];
-  }
+  // (the divisors: loaded and inverted once per launch by the caller -- per layer their load was an exposed round trip in front of the first tile)
+  const float (&dv)[4] = S.dv, (&rdv)[4] = S.rdv;
   const f32x2 dvp[2] = {{dv[0], dv[1]}, {dv[2], dv[3]}}, rdvp[2] = {{rdv[0], rdv[1]}, {rdv[2], rdv[3]}};
   unsigned char* wbase = reinterpret_cast<unsigned char*>(g1) + (size_t)wave * (G1_WAVE_FLOATS * 4);
   const half8* stg = reinterpret_cast<const half8*>(wbase);                    // k staging: hi halves [16 rows][16 slots of 16 B], lo halves 4 KB further

@@ -18,6 +18,7 @@ python tools/prof_by_grid.py $DBH > gpurun_out/${TAG}_headline_by_grid.txt 2>&1
 head -14 gpurun_out/${TAG}_headline_cu_time.txt
 rm -rf /tmp/prof_s && rocprofv3 --kernel-trace --stats -d /tmp/prof_s -o t -- python tools/gpu_single_timeline.py > /tmp/prof_s.log 2>&1
 python tools/prof_rollout_gaps.py $(find /tmp/prof_s -name '*.db' | head -1) 0 > gpurun_out/${TAG}_single_scene_launches.txt 2>&1
+tools/gpu_pmc_single_chain.sh ${TAG} > /dev/null 2>&1
 bash tools/gpu_pmc_chain16.sh ${TAG} 16 > /dev/null 2>&1
 cat gpurun_out/${TAG}_pmc_chain16.txt
 tools/gpu_pmc_by_grid.sh ${TAG}_c16_other "k_chain16<8, false" > /dev/null 2>&1

@@ -7,6 +7,7 @@ from prosim_amd.spec import DEMO_SPEC
 from prosim_amd.engine import Engine
 spec = DEMO_SPEC
 eng = Engine(spec, weights.init_weights(spec, 0))
+if os.environ.get("PS_IMPL"): eng.set_chain_impl(int(os.environ["PS_IMPL"]))   # 1: the operand-image chains (the cross-check path)
 eng.set_scene(synth.baseline_scene(spec, 2, seed=0, batch=int(os.environ.get("PS_SCENES", "1"))))
 for _ in range(4):
     eng.rollout(); eng.sync()
