@@ -158,3 +158,59 @@ def test_engine_against_the_reference_made_fixture_at_full_size(name):
     # (rows where the REFERENCE's own fp32 run left the fp64 trajectory -- eight of configs[3] seed 0's 256 agents, up to 3.4e-3; none
     # on the other three workloads -- are not the engine's to match: it tracks the fp64 oracle there, tests/test_hip_parity.py)
     assert len(eng_out - ref_out) <= max(1, int(0.005 * A)) and np.median(d) < 4e-5
+
+
+# ------------------------------------------------------------------ single-scene chains on geometry records (k_attn_chain<1, 4, 3, GEO>)
+@pytest.mark.parametrize("case", ["cfg2", "cfg1", "cfg3_b2", "isolated", "replay"])
+def test_geometry_record_chains_against_the_operand_image_chains_and_the_oracle(case):
+    """Up to 256 rows the default implementation runs the fused chains of the encoder's a2a layers, the generator and the policy on
+    k_attn_chain<1, 4, 3, GEO>: k_chain16's edge arithmetic on 32-byte geometry records behind fp32 GEMV node stages (ps_attn.h,
+    c16_lat_* in ps_chain16.h).  ps_set_chain_impl(1) keeps the operand-image edge phase (k_relpe_tiles) it replaced: two summation
+    orders of one layer.  Replan 0 of both within 1e-4 of the fp64 oracle and 2e-5 of each other; closed loop within the band (or the
+    scene's own fp32 floor on the small chaotic specs); rows without any edge (an agent alone in its scene) take the empty-softmax
+    path of both; 257 rows and more stay on the operand-image build (two workgroups per CU)."""
+    import torch
+    from prosim_amd.engine import Engine
+    from prosim_amd.spec import DEMO_SPEC
+    from oracle import prosim_oracle as orc
+    if case.startswith("cfg"):
+        spec = DEMO_SPEC
+        cfg = int(case[3])
+        scene = synth.baseline_scene(spec, cfg, seed=0, batch=2 if case.endswith("b2") else (1 if cfg == 2 else None))
+    elif case == "isolated":   # one or two agents per scene, far apart: rows with no a2a / p2p / a2p edge at all
+        spec = SMALL_SPEC
+        scene = synth.make_scene(spec, 2, 40, batch=3, seed=5, goal=True, ragged=True, square=400.0)
+    else:                       # log-replay agents leave and enter: candidate filters and dead rows in the searches that feed the records
+        spec = SMALL_SPEC
+        scene = synth.make_scene(spec, 24, 60, batch=2, seed=6, tags=True, replay=0.4, enter=0.5)
+    w = weights.init_weights(spec, 0)
+    out = {}
+    eng = Engine(spec, w)
+    try:
+        for impl in (0, 1):
+            eng.set_chain_impl(impl)
+            eng.set_scene(scene)
+            eng.rollout()
+            pol = eng.policy_rows
+            out[impl] = (eng.get("motion_pred")[:, pol].copy(), eng.padded("traj").copy())
+            rows = eng.num_agents
+            A = int(pol.sum())
+    finally:
+        eng.close()
+    assert rows <= 256
+    pm = scene["prompt_mask"].astype(bool)   # (log-replay agents are rows of the engine but no policy agents: compared through the masks)
+    with torch.no_grad():
+        o64 = orc.rollout(w, spec, scene, dtype=torch.float64)
+        o32 = orc.rollout(w, spec, scene) if spec is SMALL_SPEC else None
+    ref_mp = o64["motion_pred"][:A].numpy()
+    ref_traj = o64["traj"].numpy()
+    for impl in (0, 1):
+        assert np.isfinite(out[impl][1][pm]).all()
+        assert np.abs(out[impl][0][0] - ref_mp).max() < 1e-4, (case, impl)
+    assert np.abs(out[0][0][0] - out[1][0][0]).max() < 2e-5, case   # replan 0: two summation orders of the same layers
+    err = np.abs(out[0][1] - ref_traj)[pm].max()
+    if o32 is None:
+        assert err < 1e-4, (case, err)            # BASELINE-size scenes: the band itself (cfg3 seed 0: all 256 agents, tests/golden/known_cut_agents.json)
+    else:
+        floor = float(np.abs(o32["traj"].numpy() - ref_traj)[pm].max())
+        assert err < 3 * floor + 1e-4, (case, err, floor)
