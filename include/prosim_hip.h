@@ -240,6 +240,12 @@ int ps_set_chain_impl(ps_engine* e, int32_t impl);
  * 2 = as 0 with the split layers' edge half on the 16-row workgroup kernel (k_edge16) instead of the one-wave-per-row kernel
  * (k_edge_rows); 11..13 = as 0 with 1..3 row tiles per wave forced in the node halves -- both bit-identical to 0 (tests, A/B timing). */
 int ps_set_row_impl(ps_engine* e, int32_t impl);
+/* How a radius search whose edges feed a geometry-record chain is launched: 0 (default) = ONE launch (k_radius_geo: one scan of the
+ * candidates per query, the CSR prefix taken from counts the waves publish to each other, esrc / edst and the 32-byte records written by the
+ * search's own waves), 1 = the count / fill / k_edge_geo launches of rounds 1-4.  Same edges in the same order, same records: bit-identical
+ * results (tests/test_round5_gpu.py).  Replaces torch_cluster.radius / radius_graph + the rel-PE construction of act_decoder.py:203-221,
+ * sym_coord.py:86-110 for those edge sets; searches with a learnable rel-PE, kNN edge functions or operand-image chains keep their launches. */
+int ps_set_search_impl(ps_engine* e, int32_t impl);
 /* Nodes (kernel launches and copies) of the captured rollout graph; 0 before the first ps_rollout or when the rollout runs eagerly. */
 int64_t ps_graph_nodes(ps_engine* e);
 /* The engine's hipStream_t (every entry point enqueues on it), so a host can order its own streams against the

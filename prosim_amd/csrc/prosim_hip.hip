@@ -97,6 +97,7 @@ struct EdgeSet {  // CSR by destination + normalised rel-PE
   DevBuf<int> cnt, eoff, toff, tdst, esrc, edst;   // toff: offsets in 32-edge tiles (sum of ceil(deg/32)); tdst: tile -> destination
   DevBuf<_Float16> rtA, rtT;                  // rel-PE rows (split fp16) as the two MFMA operand images (32-edge tiles)
   DevBuf<EdgeGeo> geo;                        // per-edge geometry records: what k_chain16 rebuilds the rel-PE rows from
+  DevBuf<int> sync;                           // k_radius_geo: published counts per query (64 bits each) + the done counter (zero between launches)
   size_t cap_edges = 0;
   int nq = 0;
   int maxdeg = 0;
@@ -398,6 +399,7 @@ struct ps_engine {
   int force_mt = 0;           // ps_test_pointnet_mt (test hook): row tiles per wave of the row-tile PointNet, -1 = the staged kernel
   int node_mt = 0;            // ps_set_row_impl(10 + mt): row tiles per wave of the row-tile node kernels forced to mt (experiments, tests)
   bool wg_edges = false;      // ps_set_row_impl(2): the split path's edge half on the 16-row workgroup kernel (k_edge16) instead of k_edge_rows (A/B, cross-check)
+  int search_impl = 0;        // ps_set_search_impl: 0 = a radius search with geometry records is ONE launch (k_radius_geo), 1 = count / fill / record launches (rounds 1-4; A/B, cross-check)
   bool legacy_rows = false;   // ps_set_row_impl(1): the round-3 staged row kernels (k_pointnet_mfma, k_node) instead of the row-tile ones (A/B and parity tools)
   int chain_rows = 0;   // ps_set_chain_rows: 0 = latency-optimal choice, else rows per workgroup of the fused attention launches
   int chain_impl = 0;   // ps_set_chain_impl: 0 = by mode (k_chain16 in throughput mode: chain_rows >= 8; k_attn_chain otherwise), 1 = k_attn_chain, 2 = k_chain16, 3 = k_chain16 + the encoder's s2s layers on it
@@ -1085,6 +1087,11 @@ int edge_alloc(EdgeSet& s, int nq, size_t cap_edges, int maxdeg) {
       s.rtA.ensure((cap_edges / 32 + (size_t)nq + 1) * 8192) || s.rtT.ensure((cap_edges / 32 + (size_t)nq + 1) * 8192) ||
       s.geo.ensure(cap_edges + 1))
     return -1;
+  {   // the one-launch search's flags: zero when made, kept zero by the kernel itself
+    const int* before = s.sync.p;
+    if (s.sync.ensure(2 * (size_t)nq + 8)) return -1;   // 64 bits per query + the counter
+    if (s.sync.p != before && hipMemset(s.sync.p, 0, s.sync.n * sizeof(int)) != hipSuccess) return -1;
+  }
   return 0;
 }
 
@@ -2100,6 +2107,9 @@ int launch_chain16(ps_engine* e, float* x, int Nd, const ChainStep* steps, int n
 
 // radius search + CSR + rel-PE for one or two edge sets over the same queries (count -> scan -> fill -> rel-PE: one
 // launch each for all sets).  pe_mode: 1 = the operand images of k_attn_chain, 2 = the geometry records of k_chain16.
+// up to this many queries a search with geometry records is ONE launch of a workgroup per query (k_radius_geo); beyond, the count / fill /
+// record launches (measured: 128 queries 20.6 -> 11 us per search; at 1024 queries x 2 sets the one-launch form costs the pipelined headline 2 %)
+constexpr int SEARCH_WG_MAX_Q = 256;
 struct RadArgs {
   EdgeSet* es;
   const int *r1, *r2;
@@ -2120,6 +2130,30 @@ void launch_radius(ps_engine* e, const RadArgs* a, int nsets, const float* qpos,
   const int wpb = 4, grid = (nq + wpb - 1) / wpb;
   hipStream_t st = e->stream;
   rs.scanned = nq > CSR_PREFIX_MAX_Q ? 1 : 0;
+  {
+    // round 5: search + CSR + geometry records in ONE launch (k_radius_geo, ps_chain16.h) where the records are all the rel-PE work of the
+    // sets (fixed Fourier rows on the geometry-record chains) -- every search of a rollout in throughput mode and of a single scene
+    bool learn_any = false;
+    int capx = 1;
+    bool flags_ok = true;
+    for (int i = 0; i < nsets; ++i) {
+      learn_any |= a[i].learn != nullptr;
+      capx = std::max(capx, a[i].cap + 1);
+      flags_ok = flags_ok && a[i].es->sync.p && a[i].es->sync.n >= 2 * (size_t)nq + 8;
+    }
+    if (e->search_impl == 0 && nq <= SEARCH_WG_MAX_Q && flags_ok && !knn && !learn_any && pe_mode == 2 && !rs.scanned && (size_t)capx * sizeof(int) <= 64 * 1024) {
+      GeoSets gs{};
+      RadSyncs sy{};
+      for (int i = 0; i < nsets; ++i) {
+        EdgeSet& es = *a[i].es;
+        gs.s[i] = GeoSet{es.esrc.p, es.edst.p, es.eoff.p, es.nq, src_ori, qpos, dst_ori, es.geo.p};
+        sy.flag[i] = reinterpret_cast<unsigned long long*>(es.sync.p);
+      }
+      hipLaunchKernelGGL(k_radius_geo, dim3(nq, nsets), dim3(64 * RG_WAVES), (size_t)capx * sizeof(int), st, rs, gs, sy, qpos, qscene, nq,
+                         (const float*)e->d_tok_pos.p, (const float*)e->div32, e->cfg.ln_eps);
+      return;
+    }
+  }
   if (knn) {   // MODEL.REL_POS_EDGE_FUNC 'knn': the cap nearest instead of the first cap inside the radius (same CSR plumbing)
     hipLaunchKernelGGL(k_knn_sets<0>, dim3(grid, nsets), dim3(64 * wpb), 0, st, rs, qpos, qscene, nq);
     if (rs.scanned) hipLaunchKernelGGL(k_exclusive_scan, dim3(nsets), dim3(1024), 0, st, rs, nq);
@@ -2508,7 +2542,7 @@ std::vector<uint64_t> rollout_signature(const ps_engine* e) {
   for (long long v : {(long long)e->all_policy, (long long)e->have_log, (long long)e->have_dead0, (long long)e->have_fut, (long long)e->have_noise,
                       (long long)e->have_cond, (long long)e->n_cond_edges, (long long)e->n_cond_tiles, (long long)e->n_drag, (long long)e->drag_T,
                       (long long)e->node_mt, (long long)e->wg_edges, (long long)e->legacy_rows, (long long)e->chain_rows, (long long)e->chain_impl,
-                      (long long)e->force_mt, (long long)e->step_a2a, (long long)e->step_s2s, (long long)e->step_dec, (long long)e->step_cnd,
+                      (long long)e->force_mt, (long long)e->search_impl, (long long)e->step_a2a, (long long)e->step_s2s, (long long)e->step_dec, (long long)e->step_cnd,
                       (long long)e->step_pol, (long long)e->step_upd})
     I(v);
   I((long long)e->h_steps.size());
@@ -2534,7 +2568,7 @@ std::vector<uint64_t> rollout_signature(const ps_engine* e) {
                         (const void*)e->d_fut_mask.p, (const void*)e->d_obs_mask_rows.p, (const void*)e->d_fut_pos.p, (const void*)e->d_fut_head.p})
     Pp(p);
   for (const EdgeSet* es : {&e->e_a2a, &e->e_s2s, &e->e_p2p, &e->e_s2p, &e->e_a2p, &e->e_m2p, &e->e_cnd, &e->e_ua, &e->e_um}) {
-    Pp(es->cnt.p); Pp(es->eoff.p); Pp(es->toff.p); Pp(es->tdst.p); Pp(es->esrc.p); Pp(es->edst.p); Pp(es->rtA.p); Pp(es->rtT.p); Pp(es->geo.p);
+    Pp(es->cnt.p); Pp(es->eoff.p); Pp(es->toff.p); Pp(es->tdst.p); Pp(es->esrc.p); Pp(es->edst.p); Pp(es->rtA.p); Pp(es->rtT.p); Pp(es->geo.p); Pp(es->sync.p);
     I((long long)es->cap_edges); I(es->nq); I(es->maxdeg);
   }
   return g;
@@ -2698,6 +2732,14 @@ extern "C" int ps_set_row_impl(ps_engine* e, int32_t impl) {
   e->legacy_rows = impl == 1;
   e->wg_edges = impl == 2;
   e->node_mt = impl >= 11 ? impl - 10 : 0;
+  return PS_OK;
+}
+
+extern "C" int ps_set_search_impl(ps_engine* e, int32_t impl) {
+  if (!e) return fail(PS_E_ARG, "null engine");
+  if (impl != 0 && impl != 1) return fail(PS_E_ARG, "ps_set_search_impl: 0 = one launch per radius search with geometry records (default), 1 = count / fill / record launches");
+  drop_graph(e);
+  e->search_impl = impl;
   return PS_OK;
 }
 

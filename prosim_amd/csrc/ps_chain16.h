@@ -91,6 +91,85 @@ struct GeoSets {
 // wave's 64 lanes on 64 banks); round 2 recomputed them for the second pass (half of the kernel's instructions).
 constexpr int GEO_THREADS = 128;
 constexpr size_t GEO_LDS_BYTES = 16;   // (round 3 kept the 96 values of an edge in LDS between two LayerNorm passes)
+// the record of ONE edge: source token s seen from a destination at (px, py) with heading od (cx = cosf(od), cy = sinf(od): the caller's, once per
+// destination where it can).  Shared by k_edge_geo (one thread per edge of a finished CSR) and k_radius_geo (the search's own waves): same
+// operations on the same values in the same order, so the records do not depend on which kernel made them.
+__device__ __forceinline__ EdgeGeo geo_record(int s, float px, float py, float od, float cx, float cy, const float* __restrict__ src_pos,
+                                              const float* __restrict__ src_ori, const float (&dv)[16], const float (&rdv)[16], float eps, int raw) {
+  const float dx = src_pos[2 * s] - px, dy = src_pos[2 * s + 1] - py;
+  float xin[3];
+  xin[0] = sqrtf(dx * dx + dy * dy);
+  xin[1] = wrap_angle(src_ori[s] - od);
+  // torch's .sum(dim=-1) accumulates from +0, so a dot of (-0, -0) is +0 there: keep the explicit 0.f + ...
+  const float dot = (0.f + cx * dx) + cy * dy;
+  xin[2] = atan2f(cx * dy - cy * dx, dot);
+  EdgeGeo g;
+  if (raw) {
+    g.a0 = xin[0]; g.a1 = xin[1]; g.a2 = xin[2];
+    g.rstd = 0.f; g.nmr = 0.f;
+    g.src = s; g.pad0 = 0; g.pad1 = 0;
+    return g;
+  }
+  float xs[3];
+  bool fast = true;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    xs[i] = xin[i] * PS_TWO_PI_F;
+    fast = fast && fdiv16_ok(xs[i]);
+  }
+  // mean of the 128 features; their second moment needs no second pass: every (sin, cos) pair contributes sin^2 + cos^2 = 1, so the
+  // sum of squares of the 64 pairs (the angle block counts twice) is 64 and sum (f - mean)^2 = 64 - 128 mean^2.  (Round 2 kept
+  // torch's two passes bit for bit -- a last-bit change of rstd re-rolled the workload's near-cut edges; with the quieter GEMM
+  // operands of round 4 the parity table holds either way, and the pass was a third of this kernel: 96 LDS round trips per edge.)
+  float sm = 0.f;
+  if (__builtin_expect(fast, 1)) {   // (the two forms in branches of their own: sharing one loop, libm's sincosf kept the kernel at 145 registers)
+    // two frequencies per packed instruction through the exact division and the reduction to revolutions (round 5: feat8's scheme, the
+    // operations of fourier_pair / sincos_hw in the same order on the same values -- the sums keep their order, the records their bits)
+    constexpr float C1 = 0.15915494309189535f;
+    constexpr float C2 = (float)(0.15915494309189535 - (double)0.15915494309189535f);
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+    const f32x2_ c1 = {C1, C1}, c2 = {C2, C2};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      float part = 0.f;
+      const f32x2_ x2 = {xs[i], xs[i]};
+#pragma unroll
+      for (int k = 0; k < 16; k += 2) {
+        const f32x2_ d2 = {dv[k], dv[k + 1]}, rd2 = {rdv[k], rdv[k + 1]};
+        const f32x2_ q0 = x2 * rd2;
+        const f32x2_ rem = __builtin_elementwise_fma(-q0, d2, x2);
+        const f32x2_ q = __builtin_elementwise_fma(rem, rd2, q0);
+        const f32x2_ u = q * c1;
+        const f32x2_ n = {rintf(u.x), rintf(u.y)};
+        const f32x2_ f = __builtin_elementwise_fma(q, c1, -n) + q * c2;
+        part += __builtin_amdgcn_sinf(f.x) + __builtin_amdgcn_cosf(f.x);
+        part += __builtin_amdgcn_sinf(f.y) + __builtin_amdgcn_cosf(f.y);
+      }
+      sm += (i == 2) ? 2.f * part : part;
+    }
+  } else {
+#pragma unroll 1
+    for (int i = 0; i < 3; ++i) {
+      float part = 0.f;
+#pragma unroll 1
+      for (int k = 0; k < 16; ++k) {
+        float sv, cv;
+        fourier_pair(xs[i], dv[k], rdv[k], false, sv, cv);
+        part += sv + cv;
+      }
+      sm += (i == 2) ? 2.f * part : part;
+    }
+  }
+  const float mean = sm * (1.f / 128.f);
+  const float sq = 64.f - 128.f * mean * mean;
+  const float rstd = 1.f / sqrtf(sq * (1.f / 128.f) + eps);
+  g.a0 = xs[0]; g.a1 = xs[1]; g.a2 = xs[2];
+  g.rstd = rstd;
+  g.nmr = -mean * rstd;
+  g.src = s;
+  g.pad0 = g.pad1 = 0;
+  return g;
+}
 __global__ __launch_bounds__(GEO_THREADS) void k_edge_geo(GeoSets sets, const float* __restrict__ src_pos, const float* __restrict__ div32,
                                                          float eps, int raw) {
   const GeoSet& S = sets.s[blockIdx.y];
@@ -105,81 +184,162 @@ __global__ __launch_bounds__(GEO_THREADS) void k_edge_geo(GeoSets sets, const fl
     const int d = S.edst[e], s = S.esrc[e];
     const float px = S.dst_pos[2 * d], py = S.dst_pos[2 * d + 1], od = S.dst_ori[d];
     const float cx = cosf(od), cy = sinf(od);
-    const float dx = src_pos[2 * s] - px, dy = src_pos[2 * s + 1] - py;
-    float xin[3];
-    xin[0] = sqrtf(dx * dx + dy * dy);
-    xin[1] = wrap_angle(S.src_ori[s] - od);
-    // torch's .sum(dim=-1) accumulates from +0, so a dot of (-0, -0) is +0 there: keep the explicit 0.f + ...
-    const float dot = (0.f + cx * dx) + cy * dy;
-    xin[2] = atan2f(cx * dy - cy * dx, dot);
-    if (raw) {
-      EdgeGeo g;
-      g.a0 = xin[0]; g.a1 = xin[1]; g.a2 = xin[2];
-      g.rstd = 0.f; g.nmr = 0.f;
-      g.src = s; g.pad0 = 0; g.pad1 = 0;
-      S.geo[e] = g;
-      continue;
-    }
-    float xs[3];
-    bool fast = true;
+    S.geo[e] = geo_record(s, px, py, od, cx, cy, src_pos, S.src_ori, dv, rdv, eps, raw);
+  }
+}
+
+// ---- Round 5: a radius search with geometry records as ONE launch (was: count pass, fill pass, k_edge_geo -- three dependent graph nodes per
+// search, 8 + 3 searches per rollout).  One WORKGROUP of four waves per query:
+//   1. ONE scan of the scene's candidates (k_radius scanned them twice, once per pass), 256 candidates per trip, wave w ranking the trip's chunk w
+//      behind the chunks before it (counts exchanged through LDS): the first cap (+ 1 with a self match to drop) hits in index order go to the
+//      workgroup's LDS list -- the order k_radius's single wave gives;
+//   2. the workgroup publishes its edge count (one 64-bit agent-scope atomic: bit 63 | tiles | edges) and its first wave sums the counts of the
+//      queries before it straight from the flags, waiting for those not published yet: a workgroup publishes BEFORE it waits, only ever waits for
+//      lower indices, and workgroups are dispatched in index order, so the lowest unfinished workgroup never waits for an undispatched one (the
+//      decoupled look-back argument, without the chain: nothing is forwarded from workgroup to workgroup);
+//   3. CSR / tile offsets, esrc / edst and the 32-byte record of every edge (geo_record: k_edge_geo's arithmetic), 256 edges at a time.
+// The last workgroup through its look-back (a counter behind the flags) zeroes flags and counter for the next launch -- the replays of a captured
+// graph carry no launch-specific argument.  Results are bit-identical to the three-launch form (tests/test_round5_gpu.py; ps_set_search_impl(1)
+// keeps that form).
+struct RadSyncs {
+  unsigned long long* flag[2];   // [nq] per query: bit 63 = published | 32-edge tiles << 32 | edges; then one int: the done counter
+};
+// For FEW queries (a single scene: latency; the host's SEARCH_WG_MAX_Q): with thousands of queries the three-launch form is faster -- measured on
+// the 8-scene batch (1024 queries x 2 sets): this kernel costs the pipelined headline 2 % (the records of a 60-edge row keep three quarters of a
+// four-wave workgroup's lanes idle: 2.3 x the wave-instructions of the balanced k_edge_geo launch), a one-wave-per-query form that leaves the
+// records to k_edge_geo 3.7 % (four dependent trips of agent-scope flag loads per look-back against one cached sweep).
+constexpr int RG_WAVES = 4;
+constexpr bool GEO = true;
+__global__ __launch_bounds__(64 * RG_WAVES) void k_radius_geo(RadSets sets, GeoSets gsets, RadSyncs sy, const float* __restrict__ qpos,
+                                                             const int* __restrict__ qscene, int nq, const float* __restrict__ src_pos,
+                                                             const float* __restrict__ div32, float eps) {
+  extern __shared__ int rg_lst[];   // [cap + 1] the query's hits, in index order
+  __shared__ int wc[2][RG_WAVES];
+  __shared__ int sh_self, sh_pre[2];
+  const RadSet& S = sets.s[blockIdx.y];
+  const GeoSet& G = gsets.s[blockIdx.y];
+  unsigned long long* __restrict__ flag = sy.flag[blockIdx.y];
+  const CandSet cs = S.cs;
+  const float r2 = S.r2;
+  const int cap = S.cap, self_base = S.self_base;
+  const int* __restrict__ cand_ok = S.cand_ok;
+  const int cand_base = S.cand_base;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int q = blockIdx.x;
+  const int capx = cap + (self_base >= 0 ? 1 : 0);
+  // (the records' divisors and the destination's pose: requested before the scan, used after it)
+  float dv[16], rdv[16];
+  float px = 0.f, py = 0.f, od = 0.f;
+  if (GEO) {
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      xs[i] = xin[i] * PS_TWO_PI_F;
-      fast = fast && fdiv16_ok(xs[i]);
-    }
-    // mean of the 128 features; their second moment needs no second pass: every (sin, cos) pair contributes sin^2 + cos^2 = 1, so the
-    // sum of squares of the 64 pairs (the angle block counts twice) is 64 and sum (f - mean)^2 = 64 - 128 mean^2.  (Round 2 kept
-    // torch's two passes bit for bit -- a last-bit change of rstd re-rolled the workload's near-cut edges; with the quieter GEMM
-    // operands of round 4 the parity table holds either way, and the pass was a third of this kernel: 96 LDS round trips per edge.)
-    float sm = 0.f;
-    if (__builtin_expect(fast, 1)) {   // (the two forms in branches of their own: sharing one loop, libm's sincosf kept the kernel at 145 registers)
-      // two frequencies per packed instruction through the exact division and the reduction to revolutions (round 5: feat8's scheme, the
-      // operations of fourier_pair / sincos_hw in the same order on the same values -- the sums keep their order, the records their bits)
-      constexpr float C1 = 0.15915494309189535f;
-      constexpr float C2 = (float)(0.15915494309189535 - (double)0.15915494309189535f);
-      typedef float f32x2_ __attribute__((ext_vector_type(2)));
-      const f32x2_ c1 = {C1, C1}, c2 = {C2, C2};
+    for (int k = 0; k < 16; ++k) dv[k] = div32[2 * k];
+    px = G.dst_pos[2 * q]; py = G.dst_pos[2 * q + 1]; od = G.dst_ori[q];
+  }
+  const float qx = qpos[2 * q], qy = qpos[2 * q + 1];
+  const int b = qscene[q];
+  const int self = (self_base >= 0 && (!cand_ok || cand_ok[self_base + q - cand_base])) ? self_base + q : -1;
+  if (tid == 0) sh_self = 0;
+  int run = 0, trip = 0;
+  for (int rg = 0; rg < 2 && run < capx; ++rg) {
+    const int* rr = rg == 0 ? cs.r1 : cs.r2;
+    if (!rr) break;
+    const int beg = rr[2 * b], end = rr[2 * b + 1];
+    for (int i0 = beg; i0 < end && run < capx; i0 += 64 * RG_WAVES, ++trip) {
+      const int i = i0 + 64 * wave + lane;
+      bool ok = false;
+      if (i < end) ok = dist2(cs.pos[2 * i], cs.pos[2 * i + 1], qx, qy) < r2 && (!cand_ok || i < cand_base || cand_ok[i - cand_base]);
+      const unsigned long long m = __ballot(ok);
+      int* w = wc[trip & 1];   // (two buffers: a wave may write the next trip's count while a slower one still reads this trip's)
+      if (lane == 0) w[wave] = __popcll(m);
+      __syncthreads();
+      int base = run, tot = 0;
 #pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        float part = 0.f;
-        const f32x2_ x2 = {xs[i], xs[i]};
-#pragma unroll
-        for (int k = 0; k < 16; k += 2) {
-          const f32x2_ d2 = {dv[k], dv[k + 1]}, rd2 = {rdv[k], rdv[k + 1]};
-          const f32x2_ q0 = x2 * rd2;
-          const f32x2_ rem = __builtin_elementwise_fma(-q0, d2, x2);
-          const f32x2_ q = __builtin_elementwise_fma(rem, rd2, q0);
-          const f32x2_ u = q * c1;
-          const f32x2_ n = {rintf(u.x), rintf(u.y)};
-          const f32x2_ f = __builtin_elementwise_fma(q, c1, -n) + q * c2;
-          part += __builtin_amdgcn_sinf(f.x) + __builtin_amdgcn_cosf(f.x);
-          part += __builtin_amdgcn_sinf(f.y) + __builtin_amdgcn_cosf(f.y);
-        }
-        sm += (i == 2) ? 2.f * part : part;
+      for (int u = 0; u < RG_WAVES; ++u) {
+        const int c = w[u];
+        tot += c;
+        if (u < wave) base += c;
       }
-    } else {
-#pragma unroll 1
-      for (int i = 0; i < 3; ++i) {
-        float part = 0.f;
-#pragma unroll 1
-        for (int k = 0; k < 16; ++k) {
-          float sv, cv;
-          fourier_pair(xs[i], dv[k], rdv[k], false, sv, cv);
-          part += sv + cv;
+      const int rank = base + __popcll(m & ((1ull << lane) - 1ull));
+      if (ok && rank < capx) {   // (a chunk behind a full list takes nobody)
+        rg_lst[rank] = i;
+        if (i == self) sh_self = 1;
+      }
+      run += tot;
+    }
+  }
+  __syncthreads();
+  const int total = run < capx ? run : capx;
+  const bool selfhit = sh_self != 0;
+  const int mine = total - (selfhit ? 1 : 0);
+  const int nt = (mine + 31) >> 5;
+  if (wave == 0) {
+    if (lane == 0) {
+      S.cnt[q] = mine;
+      __hip_atomic_store(flag + q, (1ull << 63) | ((unsigned long long)(unsigned)nt << 32) | (unsigned long long)(unsigned)mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // the sums of the queries before this one: their flags are requested four at a time, then waited for one by one
+    int pe = 0, pt = 0;
+    for (int i0 = 0; i0 < q; i0 += 256) {
+      unsigned long long f[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + 64 * u + lane;
+        f[u] = i < q ? __hip_atomic_load(flag + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (1ull << 63);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + 64 * u + lane;
+        while (!(f[u] >> 63)) {
+          __builtin_amdgcn_s_sleep(1);
+          f[u] = __hip_atomic_load(flag + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        sm += (i == 2) ? 2.f * part : part;
+        pe += (int)(unsigned)(f[u] & 0xffffffffull);
+        pt += (int)(unsigned)((f[u] >> 32) & 0x7fffffffull);
       }
     }
-    const float mean = sm * (1.f / 128.f);
-    const float sq = 64.f - 128.f * mean * mean;
-    const float rstd = 1.f / sqrtf(sq * (1.f / 128.f) + eps);
-    EdgeGeo g;
-    g.a0 = xs[0]; g.a1 = xs[1]; g.a2 = xs[2];
-    g.rstd = rstd;
-    g.nmr = -mean * rstd;
-    g.src = s;
-    g.pad0 = g.pad1 = 0;
-    S.geo[e] = g;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      pe += __shfl_xor(pe, o);
+      pt += __shfl_xor(pt, o);
+    }
+    if (lane == 0) {
+      sh_pre[0] = pe;
+      sh_pre[1] = pt;
+      S.eoff[q] = pe;
+      S.toff[q] = pt;
+      if (q == nq - 1) {
+        S.eoff[nq] = pe + mine;
+        S.toff[nq] = pt + nt;
+      }
+    }
+    if (lane < nt) S.tdst[pt + lane] = q;
+    // every look-back of the launch done -> the last one out clears flags and counter for the next launch
+    int* done = reinterpret_cast<int*>(flag + nq);
+    int last = 0;
+    if (lane == 0) last = __hip_atomic_fetch_add(done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nq - 1 ? 1 : 0;
+    last = __builtin_amdgcn_readfirstlane(last);
+    if (last) {
+      for (int i = lane; i < nq; i += 64) __hip_atomic_store(flag + i, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (lane == 0) __hip_atomic_store(done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  float cx = 0.f, cy = 0.f;
+  if (GEO) {
+    cx = cosf(od);
+    cy = sinf(od);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) rdv[k] = 1.0f / dv[k];
+  }
+  __syncthreads();
+  const int se = sh_pre[0];
+  for (int j = tid; j < total; j += 64 * RG_WAVES) {
+    const int i = rg_lst[j];
+    if (i == self) continue;
+    const int o = se + j - ((selfhit && self < i) ? 1 : 0);
+    S.esrc[o] = i;
+    S.edst[o] = q;
+    if (GEO) G.geo[o] = geo_record(i, px, py, od, cx, cy, src_pos, G.src_ori, dv, rdv, eps, 0);
   }
 }
 

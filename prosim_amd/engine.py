@@ -87,6 +87,7 @@ def load_library():
     lib.ps_set_chain_rows.argtypes = [vp, C.c_int32]
     lib.ps_set_chain_impl.argtypes = [vp, C.c_int32]
     lib.ps_set_row_impl.argtypes = [vp, C.c_int32]
+    lib.ps_set_search_impl.argtypes = [vp, C.c_int32]
     lib.ps_graph_nodes.argtypes = [vp]
     lib.ps_graph_nodes.restype = C.c_int64
     lib.ps_enable_policy_events.argtypes = [vp, C.c_int32]
@@ -122,7 +123,7 @@ def load_library():
 
 
 EXPORTS = ["ps_create", "ps_destroy", "ps_last_error", "ps_set_scene", "ps_set_prompt", "ps_policy_forward", "ps_set_conditions", "ps_set_drag_points", "ps_set_pair_conditions", "ps_set_future_obs", "ps_set_future_log", "ps_set_mode_choice", "ps_set_action_noise", "ps_set_replicas", "ps_num_replicas", "ps_world_trajs", "ps_num_policy_agents", "ps_policy_flags",
-           "ps_encode_scene", "ps_generate_policy", "ps_reset_rollout", "ps_policy_step", "ps_rollout", "ps_sync", "ps_stream", "ps_set_chain_rows", "ps_set_chain_impl", "ps_set_row_impl", "ps_graph_nodes", "ps_enable_policy_events", "ps_policy_event_times", "ps_update_obs", "ps_set_map_tokens", "ps_declare_agent_rows",
+           "ps_encode_scene", "ps_generate_policy", "ps_reset_rollout", "ps_policy_step", "ps_rollout", "ps_sync", "ps_stream", "ps_set_chain_rows", "ps_set_chain_impl", "ps_set_row_impl", "ps_set_search_impl", "ps_graph_nodes", "ps_enable_policy_events", "ps_policy_event_times", "ps_update_obs", "ps_set_map_tokens", "ps_declare_agent_rows",
            "ps_set_state", "ps_get", "ps_get_async", "ps_graph_stats", "ps_rollout_metric", "ps_pair_metric", "ps_num_agents", "ps_num_map_tokens", "ps_time_rollout", "ps_time_policy_kernel",
            "ps_test_pointnet", "ps_test_pointnet_mt", "ps_test_fourier", "ps_test_wrap", "ps_test_attn", "ps_test_get_edges", "ps_test_stream"]
 
@@ -428,6 +429,11 @@ class Engine:
         """0: the row-tile kernels (default); 1: the staged row kernels of rounds 1-3 (cross-checks, A/B measurements); 2: as 0 with
         the workgroup edge kernel (k_edge16) in the split layers; 11..13: as 0 with 1..3 row tiles per wave forced (2, 11..13: same bits as 0)."""
         self._check(self.lib.ps_set_row_impl(self.h, impl))
+
+    def set_search_impl(self, impl: int):
+        """0: a radius search whose edges feed a geometry-record chain is ONE launch (k_radius_geo, default); 1: the count / fill /
+        record launches of rounds 1-4 (cross-checks, A/B measurements) -- same bits."""
+        self._check(self.lib.ps_set_search_impl(self.h, impl))
 
     @property
     def stream_handle(self) -> int:

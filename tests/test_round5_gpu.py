@@ -214,3 +214,53 @@ def test_geometry_record_chains_against_the_operand_image_chains_and_the_oracle(
     else:
         floor = float(np.abs(o32["traj"].numpy() - ref_traj)[pm].max())
         assert err < 3 * floor + 1e-4, (case, err, floor)
+
+
+# ------------------------------------------------------------------ one launch per radius search (k_radius_geo)
+@pytest.mark.parametrize("case", ["cfg2", "cfg3_b2_rows16", "small_conditions", "isolated", "replay", "cap_hit"])
+def test_one_launch_search_returns_the_bits_of_the_three_launch_search(case):
+    """ps_set_search_impl(0) (default): a radius search whose edges feed a geometry-record chain is ONE launch -- one scan per query, the CSR
+    prefix from counts the workgroups publish to each other, esrc / edst and the 32-byte records written by the search's own waves
+    (k_radius_geo, ps_chain16.h).  ps_set_search_impl(1): the count / fill / k_edge_geo launches of rounds 1-4.  Same edges in the same
+    order and the same record arithmetic: the closed-loop results must be EQUAL bit for bit -- with self matches to drop (p2p), candidate
+    filters (log-replay agents), rows without any edge, a neighbour cap that every query hits, in latency and in throughput mode, and
+    over REPLAYS of the captured graph (the kernel clears its own flags: a stale flag would show up as a different CSR)."""
+    from prosim_amd.engine import Engine
+    from prosim_amd.spec import DEMO_SPEC
+    import dataclasses
+    rows = 0
+    if case == "cfg2":
+        spec, scene = DEMO_SPEC, synth.baseline_scene(DEMO_SPEC, 2, seed=3, batch=1)
+    elif case == "cfg3_b2_rows16":
+        spec, scene, rows = DEMO_SPEC, synth.baseline_scene(DEMO_SPEC, 3, seed=1, batch=2), 16
+    elif case == "small_conditions":
+        spec, scene, rows = SMALL_SPEC, synth.make_scene(SMALL_SPEC, 24, 160, batch=3, seed=5, goal=True, tags=True, ragged=True), 16
+    elif case == "isolated":
+        spec, scene = SMALL_SPEC, synth.make_scene(SMALL_SPEC, 2, 40, batch=3, seed=5, goal=True, ragged=True, square=400.0)
+    elif case == "replay":
+        spec, scene = SMALL_SPEC, synth.make_scene(SMALL_SPEC, 24, 60, batch=2, seed=6, tags=True, replay=0.4, enter=0.5)
+    else:   # every policy / generator query runs into its cap: the list is cut in index order
+        spec = dataclasses.replace(SMALL_SPEC, pol_max_neigh=5, dec_max_neigh=7)
+        scene = synth.make_scene(spec, 20, 90, batch=2, seed=9, goal=True)
+    w = weights.init_weights(spec, 0)
+    eng = Engine(spec, w)
+    try:
+        out, nodes = {}, {}
+        for impl in (1, 0):
+            eng.set_search_impl(impl)
+            eng.set_chain_rows(rows)
+            eng.set_scene(scene)
+            got = []
+            for _ in range(3):   # a capture and two replays
+                eng.rollout()
+                got.append((eng.padded("traj").copy(), eng.get("motion_pred").copy(), eng.padded("vel").copy()))
+            for g in got[1:]:
+                for a, b in zip(g, got[0]):
+                    assert np.array_equal(a, b), (case, impl, "replay differs from capture")
+            out[impl], nodes[impl] = got[0], eng.graph_nodes
+    finally:
+        eng.close()
+    for a, b in zip(out[0], out[1]):
+        assert np.array_equal(a, b), case
+    assert np.isfinite(out[0][0][scene["prompt_mask"].astype(bool)]).all()
+    assert nodes[0] < nodes[1], nodes   # two launches less per search

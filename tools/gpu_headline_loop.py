@@ -1,5 +1,5 @@
 """The headline loop of bench.py alone (4 engines x 8 configs[2] scenes, throughput mode, rollouts in turn) -- for a kernel trace
-whose CU-time table (tools/prof_cu_time.py) holds this workload only.  PS_IMPL=3: the fast_encoder variant; PS_ROW_IMPL: ps_set_row_impl (1 = the staged row kernels, 11..13 = forced row tiles per wave)."""
+whose CU-time table (tools/prof_cu_time.py) holds this workload only.  PS_IMPL=3: the fast_encoder variant; PS_ROW_IMPL: ps_set_row_impl (1 = the staged row kernels, 11..13 = forced row tiles per wave); PS_SEARCH_IMPL: ps_set_search_impl (1 = count / fill / record launches)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -17,6 +17,7 @@ scene = {k: (np.concatenate([p[k] for p in parts]) if not isinstance(parts[0][k]
 engines = [Engine(spec, w) for _ in range(n_fl)]
 for e in engines:
     e.set_row_impl(int(os.environ.get("PS_ROW_IMPL", "0")))
+    e.set_search_impl(int(os.environ.get("PS_SEARCH_IMPL", "0")))
     e.set_chain_impl(int(os.environ.get("PS_IMPL", "0")))
     e.set_chain_rows(int(os.environ.get("PS_ROWS", "16")))
     e.set_scene(scene)
