@@ -399,6 +399,7 @@ struct ps_engine {
   int force_mt = 0;           // ps_test_pointnet_mt (test hook): row tiles per wave of the row-tile PointNet, -1 = the staged kernel
   int node_mt = 0;            // ps_set_row_impl(10 + mt): row tiles per wave of the row-tile node kernels forced to mt (experiments, tests)
   bool wg_edges = false;      // ps_set_row_impl(2): the split path's edge half on the 16-row workgroup kernel (k_edge16) instead of k_edge_rows (A/B, cross-check)
+  int env_ready = -1;         // the replan whose step_env already ran in the previous replan's head launch (k_policy_head_row's tail), or -1
   int search_impl = 0;        // ps_set_search_impl: 0 = a radius search with geometry records is ONE launch (k_radius_geo), 1 = count / fill / record launches (rounds 1-4; A/B, cross-check)
   bool legacy_rows = false;   // ps_set_row_impl(1): the round-3 staged row kernels (k_pointnet_mfma, k_node) instead of the row-tile ones (A/B and parity tools)
   int chain_rows = 0;   // ps_set_chain_rows: 0 = latency-optimal choice, else rows per workgroup of the fused attention launches
@@ -1088,9 +1089,9 @@ int edge_alloc(EdgeSet& s, int nq, size_t cap_edges, int maxdeg) {
       s.geo.ensure(cap_edges + 1))
     return -1;
   {   // the one-launch search's flags: zero when made, kept zero by the kernel itself
-    const int* before = s.sync.p;
+    const size_t before = s.sync.p ? s.sync.n : 0;   // (by size, not by pointer: a block that grows can come back at the address it had)
     if (s.sync.ensure(2 * (size_t)nq + 8)) return -1;   // 64 bits per query + the counter
-    if (s.sync.p != before && hipMemset(s.sync.p, 0, s.sync.n * sizeof(int)) != hipSuccess) return -1;
+    if (s.sync.n != before && hipMemset(s.sync.p, 0, s.sync.n * sizeof(int)) != hipSuccess) return -1;
   }
   return 0;
 }
@@ -2386,6 +2387,7 @@ extern "C" int ps_reset_rollout(ps_engine* e) {
                      e->A, c.hist_steps, c.obs_dim, e->stride_steps, e->d_traj.p, e->d_vel.p);
   HIPCHK(hipGetLastError());
   e->reset = true;
+  e->env_ready = -1;
   return PS_OK;
 }
 
@@ -2412,7 +2414,10 @@ extern "C" int ps_policy_step(ps_engine* e, int32_t t_idx) {
     lg.obs_mask = e->d_obs_in_mask.p;
     lg.live = e->d_tok_live.p;
   }
-  // step_env (traj_sam.py:205-274)
+  // step_env (traj_sam.py:205-274) -- unless the previous replan's head launch already ran it for this replan (k_policy_head_row's tail)
+  const bool env_done = t_idx > 0 && e->env_ready == t_idx;
+  e->env_ready = -1;
+  if (!env_done)
   hipLaunchKernelGGL(k_step_env, dim3(A), dim3(64), 0, st, (const float*)e->d_traj.p, (const float*)e->d_vel.p, e->stride_steps, last,
                      c.hist_steps, c.dt, (const float*)e->d_init_pos.p, (const float*)e->d_init_head.p, stat, c.obs_dim, e->d_obs_in.p,
                      e->d_cur_pos.p, e->d_cur_ori.p, t_idx > 0 ? 1 : 0, t_idx > 0 ? e->d_tok_pos.p + 2 * (size_t)Mv : (float*)nullptr,
@@ -2484,8 +2489,31 @@ extern "C" int ps_policy_step(ps_engine* e, int32_t t_idx) {
       // 128 agents: at 256 rows the row-tile kernel has four workgroups and is as fast -- and configs[3] seed 0's two scenes hold a
       // cluster of near-cut agents that another fp32 summation order re-rolls, as the reference's own fp32 run does there:
       // tests/golden/ref_standins_demo_cfg3_seed0_b2.npz.)
+      StepNext nx{};
+      if (t_idx + 1 < R && e->search_impl == 0) {   // the next replan's step_env rides in this launch's tail (ps_set_search_impl(1): the launches of rounds 1-4)
+        const int t1 = t_idx + 1;
+        const size_t arow = (size_t)c.hist_steps * c.obs_dim;
+        nx.on = 1;
+        nx.last = c.hist_steps + t1 * c.replan_freq;
+        nx.hist = c.hist_steps; nx.obs_dim = c.obs_dim; nx.fd_vel = c.no_pred_vel ? 1 : 0; nx.dt = c.dt;
+        nx.init_pos = e->d_init_pos.p; nx.init_head = e->d_init_head.p;
+        nx.static_in = e->have_fut ? e->d_fut.p + (size_t)(t1 - 1) * A * arow : e->d_static_in.p;
+        nx.obs_in = e->d_obs_in.p; nx.cur_pos = e->d_cur_pos.p; nx.cur_ori = e->d_cur_ori.p;
+        nx.tok_pos = e->d_tok_pos.p + 2 * (size_t)Mv; nx.tok_ori = e->d_tok_ori.p + Mv;
+        if (!e->all_policy) {
+          nx.lg.is_policy = e->d_is_policy.p;
+          nx.lg.frame_in = e->have_fut ? e->d_fut.p + (size_t)(t1 - 1) * A * arow : nullptr;
+          nx.lg.frame_mask = e->have_log ? e->d_fut_mask.p + (size_t)(t1 - 1) * A * arow : nullptr;
+          nx.lg.frame_pos = e->have_log ? e->d_fut_pos.p + (size_t)(t1 - 1) * A * 2 : nullptr;
+          nx.lg.frame_head = e->have_log ? e->d_fut_head.p + (size_t)(t1 - 1) * A : nullptr;
+          nx.lg.init_mask = e->d_obs_mask_rows.p;
+          nx.lg.obs_mask = e->d_obs_in_mask.p;
+          nx.lg.live = e->d_tok_live.p;
+        }
+        e->env_ready = t1;
+      }
       hipLaunchKernelGGL(k_policy_head_row, dim3(A), dim3(256), 0, st, e->head, (const float*)e->d_fused.p, (const int*)e->d_agent_type.p, A,
-                         c.target_steps, c.state_dim, mp_out, e->d_traj.p, e->d_vel.p, e->stride_steps, last, c.replan_freq, c.ln_eps, nz, vcol);
+                         c.target_steps, c.state_dim, mp_out, e->d_traj.p, e->d_vel.p, e->stride_steps, last, c.replan_freq, c.ln_eps, nz, vcol, nx);
     } else if (c.motion_k == 1 && !c.k_pred_mlp && !e->legacy_rows) {
       // row-tile head (ps_rowtile.h): a wave carries 16 agents through CG_decode and the motion head in registers
       hipLaunchKernelGGL(k_policy_head_rt, dim3((A + 63) / 64), dim3(256), RT_LDS_BYTES, st, e->head, (const float*)e->d_fused.p,
@@ -2520,7 +2548,7 @@ int rollout_eager(ps_engine* e) {
 // DATA behind the pointers is read by the kernels, grids that depend on data read their counts on the device), so a stream of
 // batches of one shape replays one graph.  Anything that moved (a buffer that grew, another row count, a condition type that
 // appeared) re-captures as before.
-void drop_graph(ps_engine* e) { e->graph_ok = false; }
+void drop_graph(ps_engine* e) { e->graph_ok = false; e->env_ready = -1; }   // (every setter comes through here: whatever a fused step_env read may have changed)
 void destroy_graph(ps_engine* e) {
   if (e->graph_exec) (void)hipGraphExecDestroy(e->graph_exec);
   if (e->graph) (void)hipGraphDestroy(e->graph);
@@ -2778,6 +2806,7 @@ extern "C" int ps_set_state(ps_engine* e, int32_t steps, const float* traj, cons
                           e->A, hipMemcpyHostToDevice, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
   e->reset = true;
+  e->env_ready = -1;   // (the next replan's step_env must see the edited states)
   return PS_OK;
 }
 

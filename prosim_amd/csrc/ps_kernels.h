@@ -1035,20 +1035,21 @@ struct StepLog {                 // all null when every observed agent is a poli
   uint8_t* obs_mask;             // [A][hist][obs_dim] OUT: validity of obs_in for the agent encoder
   int* live;                     // [A] OUT: the agent is a scene token at this replan
 };
-__global__ __launch_bounds__(64) void k_step_env(const float* __restrict__ traj, const float* __restrict__ vel, int stride_steps,
-                                                 int last, int hist, float dt, const float* __restrict__ init_pos,
-                                                 const float* __restrict__ init_head, const float* __restrict__ static_in,
-                                                 int obs_dim, float* __restrict__ obs_in, float* __restrict__ cur_pos,
-                                                 float* __restrict__ cur_ori, int write_obs, float* __restrict__ tok_pos,
-                                                 float* __restrict__ tok_ori, StepLog lg,
-                                                 int fd_vel /*PRED_VEL False: velocities from position differences (traj_sam.py:259, :553-554)*/) {
-  const int a = blockIdx.x, tid = threadIdx.x;
+// (the body: called by k_step_env with one 64-thread workgroup per agent, and by k_policy_head_row's tail -- 256 threads, the first wave
+// works, every thread meets the barriers -- for the NEXT replan's step_env of the same agent: round 5, one launch less per replan)
+__device__ __forceinline__ void step_env_body(const int a, const int tid, const float* traj, const float* vel, int stride_steps,
+                                              int last, int hist, float dt, const float* __restrict__ init_pos,
+                                              const float* __restrict__ init_head, const float* __restrict__ static_in,
+                                              int obs_dim, float* __restrict__ obs_in, float* __restrict__ cur_pos,
+                                              float* __restrict__ cur_ori, int write_obs, float* __restrict__ tok_pos,
+                                              float* __restrict__ tok_ori, const StepLog& lg, int fd_vel) {
+  const bool on = tid < 64;   // (the first wave works)
   if (lg.is_policy && !lg.is_policy[a]) {
     // log-replay agent (observed, not policy-controlled): observation, validity and pose of this replan come from
     // the log (batch.extras['fut_obs'][t], traj_sam.py:221-270), nothing from the simulated trajectories
     const int n = hist * obs_dim;
     int any_valid = 0;
-    for (int i = tid; i < n; i += 64) {
+    for (int i = on ? tid : n; i < n; i += 64) {
       const size_t o = (size_t)a * n + i;
       const bool ok = lg.frame_mask ? lg.frame_mask[o] != 0 : lg.init_mask[o] != 0;
       if (write_obs) {
@@ -1058,7 +1059,7 @@ __global__ __launch_bounds__(64) void k_step_env(const float* __restrict__ traj,
       lg.obs_mask[o] = ok ? 1 : 0;
     }
     // a token exists iff some history step is fully valid (obs_encoder.py:84, mask.any)
-    for (int s = tid; s < hist; s += 64) {
+    for (int s = on ? tid : hist; s < hist; s += 64) {
       bool all = true;
       for (int f = 0; f < obs_dim; ++f) {
         const size_t o = ((size_t)a * hist + s) * obs_dim + f;
@@ -1083,7 +1084,7 @@ __global__ __launch_bounds__(64) void k_step_env(const float* __restrict__ traj,
     return;
   }
   if (lg.obs_mask) {   // policy agent in a scene that also has log-replay agents: its simulated history is all valid
-    for (int i = tid; i < hist * obs_dim; i += 64) lg.obs_mask[(size_t)a * hist * obs_dim + i] = 1;
+    for (int i = on ? tid : hist * obs_dim; i < hist * obs_dim; i += 64) lg.obs_mask[(size_t)a * hist * obs_dim + i] = 1;
     if (tid == 0) lg.live[a] = 1;
   }
   const float* tr = traj + (size_t)a * stride_steps * 4;
@@ -1106,25 +1107,25 @@ __global__ __launch_bounds__(64) void k_step_env(const float* __restrict__ traj,
   const float ct = cosf(-th_last), st = sinf(-th_last);
   const int nv = hist + 1;  // rel_vel over the last hist+1 steps
   if (fd_vel) {   // positions of the last hist + 2 steps in the last step's frame, then their differences / dt
-    if (tid < hist + 2) {
+    if (on && tid < hist + 2) {
       const int s = last - hist - 2 + tid;
       const float dx = tr[s * 4] - lx, dy = tr[s * 4 + 1] - ly;
       rpx[tid] = dx * ct - dy * st;
       rpy[tid] = dy * ct + dx * st;
     }
     __syncthreads();
-    if (tid < nv) {
+    if (on && tid < nv) {
       rvx[tid] = (rpx[tid + 1] - rpx[tid]) / dt;
       rvy[tid] = (rpy[tid + 1] - rpy[tid]) / dt;
     }
-  } else if (tid < nv) {
+  } else if (on && tid < nv) {
     const int s = last - nv + tid;
     const float vx = vl[s * 2], vy = vl[s * 2 + 1];
     rvx[tid] = vx * ct - vy * st;
     rvy[tid] = vy * ct + vx * st;
   }
   __syncthreads();
-  if (tid < hist) {
+  if (on && tid < hist) {
     const int s = last - hist + tid;
     const float dx = tr[s * 4] - lx, dy = tr[s * 4 + 1] - ly;
     const float th = atan2f(tr[s * 4 + 2], tr[s * 4 + 3]);
@@ -1142,6 +1143,24 @@ __global__ __launch_bounds__(64) void k_step_env(const float* __restrict__ traj,
     for (int f = 8; f < obs_dim; ++f) o[f] = si[f];
   }
 }
+__global__ __launch_bounds__(64) void k_step_env(const float* __restrict__ traj, const float* __restrict__ vel, int stride_steps,
+                                                 int last, int hist, float dt, const float* __restrict__ init_pos,
+                                                 const float* __restrict__ init_head, const float* __restrict__ static_in,
+                                                 int obs_dim, float* __restrict__ obs_in, float* __restrict__ cur_pos,
+                                                 float* __restrict__ cur_ori, int write_obs, float* __restrict__ tok_pos,
+                                                 float* __restrict__ tok_ori, StepLog lg,
+                                                 int fd_vel /*PRED_VEL False: velocities from position differences (traj_sam.py:259, :553-554)*/) {
+  step_env_body(blockIdx.x, threadIdx.x, traj, vel, stride_steps, last, hist, dt, init_pos, init_head, static_in, obs_dim, obs_in, cur_pos, cur_ori,
+                write_obs, tok_pos, tok_ori, lg, fd_vel);
+}
+// what k_policy_head_row needs to run the next replan's step_env in its tail (on == 0: not this launch)
+struct StepNext {
+  int on, last, hist, obs_dim, fd_vel;
+  float dt;
+  const float *init_pos, *init_head, *static_in;
+  float *obs_in, *cur_pos, *cur_ori, *tok_pos, *tok_ori;
+  StepLog lg;
+};
 
 // init_agent_trajs (traj_sam.py:597-633): history -> state buffers (NaN -> 0).
 __global__ void k_init_state(const float* __restrict__ obs_input, const int* __restrict__ rows, int n_agents, int hist,

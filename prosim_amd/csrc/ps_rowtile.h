@@ -839,7 +839,7 @@ __global__ __launch_bounds__(256, 1) void k_policy_head_rt(HeadW w, const float*
 __global__ __launch_bounds__(256) void k_policy_head_row(HeadW w, const float* __restrict__ fused, const int* __restrict__ agent_type, int n_agents,
                                                          int steps, int sdim, float* __restrict__ motion_pred, float* __restrict__ traj,
                                                          float* __restrict__ vel, int stride_steps, int last, int replan, float eps,
-                                                         const float* __restrict__ noise, int vcol) {
+                                                         const float* __restrict__ noise, int vcol, StepNext nx) {
   __shared__ __attribute__((aligned(16))) float xin[128], ctx[128], y[128], h64[64], o[128];
   const int ag = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -949,6 +949,16 @@ __global__ __launch_bounds__(256) void k_policy_head_row(HeadW w, const float* _
         v[1] = vy * cl + vx * sl;
       }
     }
+  }
+  // Round 5: the NEXT replan's step_env of this agent (traj_sam.py:205-274) -- it reads nothing but this agent's own states, the last `replan`
+  // of them written just above.  Workgroup-scope release / acquire around the barrier: writers and readers share the CU's vector cache (an
+  // agent-scope fence pair here writes the XCD's L2 back and costs 12 us per launch: measured).
+  if (nx.on) {
+    __threadfence_block();
+    __syncthreads();
+    __threadfence_block();
+    step_env_body(ag, tid, traj, vel, stride_steps, nx.last, nx.hist, nx.dt, nx.init_pos, nx.init_head, nx.static_in, nx.obs_dim, nx.obs_in,
+                  nx.cur_pos, nx.cur_ori, 1, nx.tok_pos, nx.tok_ori, nx.lg, nx.fd_vel);
   }
 }
 
