@@ -190,8 +190,8 @@ __global__ __launch_bounds__(GEO_THREADS) void k_edge_geo(GeoSets sets, const fl
 
 // ---- Round 5: a radius search with geometry records as ONE launch (was: count pass, fill pass, k_edge_geo -- three dependent graph nodes per
 // search, 8 + 3 searches per rollout).  One WORKGROUP of four waves per query:
-//   1. ONE scan of the scene's candidates (k_radius scanned them twice, once per pass), 256 candidates per trip, wave w ranking the trip's chunk w
-//      behind the chunks before it (counts exchanged through LDS): the first cap (+ 1 with a self match to drop) hits in index order go to the
+//   1. ONE scan of the scene's candidates (k_radius scanned them twice, once per pass), 1024 candidates per trip, wave w ranking the trip's chunks
+//      4 w .. 4 w + 3 behind the chunks before them (counts exchanged through LDS): the first cap (+ 1 with a self match to drop) hits in index order go to the
 //      workgroup's LDS list -- the order k_radius's single wave gives;
 //   2. the workgroup publishes its edge count (one 64-bit agent-scope atomic: bit 63 | tiles | edges) and its first wave sums the counts of the
 //      queries before it straight from the flags, waiting for those not published yet: a workgroup publishes BEFORE it waits, only ever waits for
@@ -208,7 +208,7 @@ struct RadSyncs {
 // the 8-scene batch (1024 queries x 2 sets): this kernel costs the pipelined headline 2 % (the records of a 60-edge row keep three quarters of a
 // four-wave workgroup's lanes idle: 2.3 x the wave-instructions of the balanced k_edge_geo launch), a one-wave-per-query form that leaves the
 // records to k_edge_geo 3.7 % (four dependent trips of agent-scope flag loads per look-back against one cached sweep).
-constexpr int RG_WAVES = 4;
+constexpr int RG_WAVES = 4, RG_CH = 4;
 constexpr bool GEO = true;
 __global__ __launch_bounds__(64 * RG_WAVES) void k_radius_geo(RadSets sets, GeoSets gsets, RadSyncs sy, const float* __restrict__ qpos,
                                                              const int* __restrict__ qscene, int nq, const float* __restrict__ src_pos,
@@ -245,13 +245,24 @@ __global__ __launch_bounds__(64 * RG_WAVES) void k_radius_geo(RadSets sets, GeoS
     const int* rr = rg == 0 ? cs.r1 : cs.r2;
     if (!rr) break;
     const int beg = rr[2 * b], end = rr[2 * b + 1];
-    for (int i0 = beg; i0 < end && run < capx; i0 += 64 * RG_WAVES, ++trip) {
-      const int i = i0 + 64 * wave + lane;
-      bool ok = false;
-      if (i < end) ok = dist2(cs.pos[2 * i], cs.pos[2 * i + 1], qx, qy) < r2 && (!cand_ok || i < cand_base || cand_ok[i - cand_base]);
-      const unsigned long long m = __ballot(ok);
+    // a trip = RG_CH consecutive 64-candidate chunks per wave (wave w: candidates i0 + 64 RG_CH w ..), all position loads of a trip in flight together
+    for (int i0 = beg; i0 < end && run < capx; i0 += 64 * RG_CH * RG_WAVES, ++trip) {
+      unsigned long long m[RG_CH];
+      int mycnt = 0;
+      bool okv[RG_CH];
+#pragma unroll
+      for (int u = 0; u < RG_CH; ++u) {
+        const int i = i0 + 64 * (RG_CH * wave + u) + lane;
+        okv[u] = false;
+        if (i < end) okv[u] = dist2(cs.pos[2 * i], cs.pos[2 * i + 1], qx, qy) < r2 && (!cand_ok || i < cand_base || cand_ok[i - cand_base]);
+      }
+#pragma unroll
+      for (int u = 0; u < RG_CH; ++u) {
+        m[u] = __ballot(okv[u]);
+        mycnt += __popcll(m[u]);
+      }
       int* w = wc[trip & 1];   // (two buffers: a wave may write the next trip's count while a slower one still reads this trip's)
-      if (lane == 0) w[wave] = __popcll(m);
+      if (lane == 0) w[wave] = mycnt;
       __syncthreads();
       int base = run, tot = 0;
 #pragma unroll
@@ -260,10 +271,15 @@ __global__ __launch_bounds__(64 * RG_WAVES) void k_radius_geo(RadSets sets, GeoS
         tot += c;
         if (u < wave) base += c;
       }
-      const int rank = base + __popcll(m & ((1ull << lane) - 1ull));
-      if (ok && rank < capx) {   // (a chunk behind a full list takes nobody)
-        rg_lst[rank] = i;
-        if (i == self) sh_self = 1;
+#pragma unroll
+      for (int u = 0; u < RG_CH; ++u) {
+        const int i = i0 + 64 * (RG_CH * wave + u) + lane;
+        const int rank = base + __popcll(m[u] & ((1ull << lane) - 1ull));
+        if (okv[u] && rank < capx) {   // (a chunk behind a full list takes nobody)
+          rg_lst[rank] = i;
+          if (i == self) sh_self = 1;
+        }
+        base += __popcll(m[u]);
       }
       run += tot;
     }

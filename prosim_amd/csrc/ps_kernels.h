@@ -263,10 +263,16 @@ __device__ __forceinline__ void csr_prefix(const int* __restrict__ cnt, int q, i
     return;
   }
   int se = 0, stl = 0;
-  for (int i = lane; i < q; i += 64) {
-    const int c = cnt[i];
-    se += c;
-    stl += (c + 31) >> 5;
+  // (eight independent loads per trip: rolled one by one, the sweep was up to sixteen exposed L2 round trips per wave at 1024 queries)
+  for (int i0 = lane; i0 < q; i0 += 512) {
+    int c[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) c[u] = i0 + 64 * u < q ? cnt[i0 + 64 * u] : 0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      se += c[u];
+      stl += (c[u] + 31) >> 5;
+    }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -285,6 +291,7 @@ __device__ __forceinline__ void csr_prefix(const int* __restrict__ cnt, int q, i
     }
   }
 }
+constexpr int RAD_U = 4;
 template <int MODE>
 __global__ void k_radius(RadSets sets, const float* __restrict__ qpos, const int* __restrict__ qscene, int nq) {
   const RadSet& S = sets.s[blockIdx.y];
@@ -318,18 +325,18 @@ __global__ void k_radius(RadSets sets, const float* __restrict__ qpos, const int
     const int* rr = rg == 0 ? cs.r1 : cs.r2;
     if (!rr) break;
     const int beg = rr[2 * b], end = rr[2 * b + 1];
-    // four 64-candidate chunks per trip: their position loads leave together (the loop was one dependent load -> ballot round trip
-    // per chunk), the chunks are then ranked in index order as before
-    for (int i0 = beg; i0 < end && run < capx; i0 += 256) {
-      bool okv[4];
+    // RAD_U 64-candidate chunks per trip: their position loads leave together (the loop was one dependent load -> ballot round trip
+    // per chunk; round 5: sixteen chunks per trip measured slower -- the ballots of chunks past a short range are not free), the chunks are then ranked in index order as before
+    for (int i0 = beg; i0 < end && run < capx; i0 += 64 * RAD_U) {
+      bool okv[RAD_U];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < RAD_U; ++u) {
         const int i = i0 + 64 * u + lane;
         okv[u] = false;
         if (i < end) okv[u] = dist2(cs.pos[2 * i], cs.pos[2 * i + 1], qx, qy) < r2 && (!cand_ok || i < cand_base || cand_ok[i - cand_base]);
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < RAD_U; ++u) {
         const int i = i0 + 64 * u + lane;
         const bool ok = okv[u] && run < capx;   // (a chunk behind a full list takes nobody, as when the loop stopped there)
         const unsigned long long m = __ballot(ok);
