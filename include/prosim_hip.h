@@ -242,7 +242,9 @@ int ps_set_chain_impl(ps_engine* e, int32_t impl);
 int ps_set_row_impl(ps_engine* e, int32_t impl);
 /* How a radius search whose edges feed a geometry-record chain is launched: 0 (default) = ONE launch (k_radius_geo: one scan of the
  * candidates per query, the CSR prefix taken from counts the waves publish to each other, esrc / edst and the 32-byte records written by the
- * search's own waves), 1 = the count / fill / k_edge_geo launches of rounds 1-4.  Same edges in the same order, same records: bit-identical
+ * search's own waves), 1 = the count / fill / k_edge_geo launches of rounds 1-4, 2 = as 0 with a look-back that never waits: a count that is
+ * not published yet is recomputed by the waiting wave -- the path that makes the kernel independent of the order workgroups are dispatched in,
+ * taken in normal operation only after ~0.5 ms of polling (tests).  Same edges in the same order, same records: bit-identical
  * results (tests/test_round5_gpu.py).  Replaces torch_cluster.radius / radius_graph + the rel-PE construction of act_decoder.py:203-221,
  * sym_coord.py:86-110 for those edge sets; searches with a learnable rel-PE, kNN edge functions or operand-image chains keep their launches. */
 int ps_set_search_impl(ps_engine* e, int32_t impl);

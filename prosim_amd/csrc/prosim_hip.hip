@@ -400,7 +400,7 @@ struct ps_engine {
   int node_mt = 0;            // ps_set_row_impl(10 + mt): row tiles per wave of the row-tile node kernels forced to mt (experiments, tests)
   bool wg_edges = false;      // ps_set_row_impl(2): the split path's edge half on the 16-row workgroup kernel (k_edge16) instead of k_edge_rows (A/B, cross-check)
   int env_ready = -1;         // the replan whose step_env already ran in the previous replan's head launch (k_policy_head_row's tail), or -1
-  int search_impl = 0;        // ps_set_search_impl: 0 = a radius search with geometry records is ONE launch (k_radius_geo), 1 = count / fill / record launches (rounds 1-4; A/B, cross-check)
+  int search_impl = 0;        // ps_set_search_impl: 0 = a radius search with geometry records is ONE launch (k_radius_geo), 1 = count / fill / record launches (rounds 1-4; A/B, cross-check), 2 = as 0, the look-back recomputes instead of waiting (tests)
   bool legacy_rows = false;   // ps_set_row_impl(1): the round-3 staged row kernels (k_pointnet_mfma, k_node) instead of the row-tile ones (A/B and parity tools)
   int chain_rows = 0;   // ps_set_chain_rows: 0 = latency-optimal choice, else rows per workgroup of the fused attention launches
   int chain_impl = 0;   // ps_set_chain_impl: 0 = by mode (k_chain16 in throughput mode: chain_rows >= 8; k_attn_chain otherwise), 1 = k_attn_chain, 2 = k_chain16, 3 = k_chain16 + the encoder's s2s layers on it
@@ -2142,7 +2142,7 @@ void launch_radius(ps_engine* e, const RadArgs* a, int nsets, const float* qpos,
       capx = std::max(capx, a[i].cap + 1);
       flags_ok = flags_ok && a[i].es->sync.p && a[i].es->sync.n >= 2 * (size_t)nq + 8;
     }
-    if (e->search_impl == 0 && nq <= SEARCH_WG_MAX_Q && flags_ok && !knn && !learn_any && pe_mode == 2 && !rs.scanned && (size_t)capx * sizeof(int) <= 64 * 1024) {
+    if (e->search_impl != 1 && nq <= SEARCH_WG_MAX_Q && flags_ok && !knn && !learn_any && pe_mode == 2 && !rs.scanned && (size_t)capx * sizeof(int) <= 64 * 1024) {
       GeoSets gs{};
       RadSyncs sy{};
       for (int i = 0; i < nsets; ++i) {
@@ -2151,7 +2151,7 @@ void launch_radius(ps_engine* e, const RadArgs* a, int nsets, const float* qpos,
         sy.flag[i] = reinterpret_cast<unsigned long long*>(es.sync.p);
       }
       hipLaunchKernelGGL(k_radius_geo, dim3(nq, nsets), dim3(64 * RG_WAVES), (size_t)capx * sizeof(int), st, rs, gs, sy, qpos, qscene, nq,
-                         (const float*)e->d_tok_pos.p, (const float*)e->div32, e->cfg.ln_eps);
+                         (const float*)e->d_tok_pos.p, (const float*)e->div32, e->cfg.ln_eps, e->search_impl == 2 ? 0 : 256);
       return;
     }
   }
@@ -2490,7 +2490,7 @@ extern "C" int ps_policy_step(ps_engine* e, int32_t t_idx) {
       // cluster of near-cut agents that another fp32 summation order re-rolls, as the reference's own fp32 run does there:
       // tests/golden/ref_standins_demo_cfg3_seed0_b2.npz.)
       StepNext nx{};
-      if (t_idx + 1 < R && e->search_impl == 0) {   // the next replan's step_env rides in this launch's tail (ps_set_search_impl(1): the launches of rounds 1-4)
+      if (t_idx + 1 < R && e->search_impl != 1) {   // the next replan's step_env rides in this launch's tail (ps_set_search_impl(1): the launches of rounds 1-4)
         const int t1 = t_idx + 1;
         const size_t arow = (size_t)c.hist_steps * c.obs_dim;
         nx.on = 1;
@@ -2765,7 +2765,8 @@ extern "C" int ps_set_row_impl(ps_engine* e, int32_t impl) {
 
 extern "C" int ps_set_search_impl(ps_engine* e, int32_t impl) {
   if (!e) return fail(PS_E_ARG, "null engine");
-  if (impl != 0 && impl != 1) return fail(PS_E_ARG, "ps_set_search_impl: 0 = one launch per radius search with geometry records (default), 1 = count / fill / record launches");
+  if (impl != 0 && impl != 1 && impl != 2)
+    return fail(PS_E_ARG, "ps_set_search_impl: 0 = one launch per radius search with geometry records (default), 1 = count / fill / record launches, 2 = as 0 with a look-back that never waits (tests)");
   drop_graph(e);
   e->search_impl = impl;
   return PS_OK;

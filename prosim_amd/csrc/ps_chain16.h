@@ -196,11 +196,43 @@ __global__ __launch_bounds__(GEO_THREADS) void k_edge_geo(GeoSets sets, const fl
 //   2. the workgroup publishes its edge count (one 64-bit agent-scope atomic: bit 63 | tiles | edges) and its first wave sums the counts of the
 //      queries before it straight from the flags, waiting for those not published yet: a workgroup publishes BEFORE it waits, only ever waits for
 //      lower indices, and workgroups are dispatched in index order, so the lowest unfinished workgroup never waits for an undispatched one (the
-//      decoupled look-back argument, without the chain: nothing is forwarded from workgroup to workgroup);
+//      decoupled look-back argument, without the chain: nothing is forwarded from workgroup to workgroup).  The argument holds per launch; with
+//      SEVERAL such launches in flight on a full GPU (engines side by side) one launch's waiting workgroups can hold the slots another launch's
+//      lowest workgroup needs, and in-order dispatch is an observation, not a contract -- so the wait is BOUNDED (spin_limit polls, ~0.5 ms) and a
+//      count that has not appeared by then is computed by the waiting wave itself (rg_count_query): no workgroup depends on another one's progress;
 //   3. CSR / tile offsets, esrc / edst and the 32-byte record of every edge (geo_record: k_edge_geo's arithmetic), 256 edges at a time.
 // The last workgroup through its look-back (a counter behind the flags) zeroes flags and counter for the next launch -- the replays of a captured
 // graph carry no launch-specific argument.  Results are bit-identical to the three-launch form (tests/test_round5_gpu.py; ps_set_search_impl(1)
 // keeps that form).
+// the edge count of query qi by ONE wave (k_radius<0> + k_radius_selfrank in one scan): what the look-back falls back to for a workgroup that has not
+// published in time -- the kernel then needs no forward-progress guarantee between workgroups (see k_radius_geo)
+__device__ __forceinline__ int rg_count_query(const RadSet& S, const float* __restrict__ qpos, const int* __restrict__ qscene, int qi, int lane) {
+  const CandSet cs = S.cs;
+  const int* __restrict__ cand_ok = S.cand_ok;
+  const int cand_base = S.cand_base, self_base = S.self_base;
+  const float r2 = S.r2;
+  const int capx = S.cap + (self_base >= 0 ? 1 : 0);
+  const float qx = qpos[2 * qi], qy = qpos[2 * qi + 1];
+  const int b = qscene[qi];
+  const int self = (self_base >= 0 && (!cand_ok || cand_ok[self_base + qi - cand_base])) ? self_base + qi : -1;
+  int run = 0;
+  bool selfhit = false;
+  for (int rg = 0; rg < 2 && run < capx; ++rg) {
+    const int* rr = rg == 0 ? cs.r1 : cs.r2;
+    if (!rr) break;
+    const int beg = rr[2 * b], end = rr[2 * b + 1];
+    for (int i0 = beg; i0 < end && run < capx; i0 += 64) {
+      const int i = i0 + lane;
+      bool ok = false;
+      if (i < end) ok = dist2(cs.pos[2 * i], cs.pos[2 * i + 1], qx, qy) < r2 && (!cand_ok || i < cand_base || cand_ok[i - cand_base]);
+      const unsigned long long m = __ballot(ok);
+      const int rank = run + __popcll(m & ((1ull << lane) - 1ull));
+      selfhit = selfhit || __ballot(ok && rank < capx && i == self) != 0ull;
+      run += __popcll(m);
+    }
+  }
+  return (run < capx ? run : capx) - (selfhit ? 1 : 0);
+}
 struct RadSyncs {
   unsigned long long* flag[2];   // [nq] per query: bit 63 = published | 32-edge tiles << 32 | edges; then one int: the done counter
 };
@@ -212,7 +244,7 @@ constexpr int RG_WAVES = 4, RG_CH = 4;
 constexpr bool GEO = true;
 __global__ __launch_bounds__(64 * RG_WAVES) void k_radius_geo(RadSets sets, GeoSets gsets, RadSyncs sy, const float* __restrict__ qpos,
                                                              const int* __restrict__ qscene, int nq, const float* __restrict__ src_pos,
-                                                             const float* __restrict__ div32, float eps) {
+                                                             const float* __restrict__ div32, float eps, int spin_limit) {
   extern __shared__ int rg_lst[];   // [cap + 1] the query's hits, in index order
   __shared__ int wc[2][RG_WAVES];
   __shared__ int sh_self, sh_pre[2];
@@ -306,9 +338,18 @@ __global__ __launch_bounds__(64 * RG_WAVES) void k_radius_geo(RadSets sets, GeoS
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int i = i0 + 64 * u + lane;
-        while (!(f[u] >> 63)) {
+        for (int spins = 0; !(f[u] >> 63) && spins < spin_limit; ++spins) {
           __builtin_amdgcn_s_sleep(1);
           f[u] = __hip_atomic_load(flag + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // not published within the budget (a workgroup that could not be dispatched yet on a full GPU, or a dispatch order other than the one
+        // argued above): the wave counts that query's edges itself -- no workgroup ever depends on another one's progress
+        unsigned long long pend = __ballot(!(f[u] >> 63));
+        while (pend) {
+          const int l = (int)__ffsll((long long)pend) - 1;
+          const int c = rg_count_query(S, qpos, qscene, i0 + 64 * u + l, lane);
+          if (lane == l) f[u] = (1ull << 63) | ((unsigned long long)(unsigned)((c + 31) >> 5) << 32) | (unsigned long long)(unsigned)c;
+          pend &= pend - 1ull;
         }
         pe += (int)(unsigned)(f[u] & 0xffffffffull);
         pt += (int)(unsigned)((f[u] >> 32) & 0x7fffffffull);

@@ -432,7 +432,8 @@ class Engine:
 
     def set_search_impl(self, impl: int):
         """0: a radius search whose edges feed a geometry-record chain is ONE launch (k_radius_geo, default); 1: the count / fill /
-        record launches of rounds 1-4 (cross-checks, A/B measurements) -- same bits."""
+        record launches of rounds 1-4 (cross-checks, A/B measurements); 2: as 0 with a look-back that recomputes unpublished counts instead of
+        waiting for them (the no-forward-progress fallback, forced: tests) -- same bits."""
         self._check(self.lib.ps_set_search_impl(self.h, impl))
 
     @property
