@@ -276,7 +276,8 @@ int ps_set_state(ps_engine* e, int32_t steps, const float* traj, const float* ve
  *   "vel" [A, max_steps, 2]; "motion_pred" [R, A, K, target_steps, state_dim] (K = motion_k modes);
  *   "reconst_pred" [A, 2]; "policy_emd" [A, hidden];
  *   "goal_prob" [A, goal_pred_k], "goal_point" [A, goal_pred_k, 2] (decoder goal heads, when enabled); "scene_tokens" [Mv + A, hidden];
- *   "fused" [A, hidden] (last policy step); "obs_in" [A, hist, obs_dim] (last step_env);
+ *   "fused" [A, hidden] (last policy step); "obs_in" [A, hist, obs_dim] (last step_env -- with up to 128 agents the step_env of replan t + 1
+ *   runs in the tail of replan t's head launch, so after ps_policy_step(t), t < R - 1, this is already the observation of replan t + 1);
  *   "edge_counts" [8] (a2a, s2s, p2p, s2p, a2p, m2p of the last step, cond, 0) as float.
  * Returns the number of floats written, or a negative error. */
 int64_t ps_get(ps_engine* e, const char* name, float* dst, int64_t capacity);
