@@ -532,6 +532,15 @@ __device__ __forceinline__ void c16_blds16(unsigned voff, __amdgpu_buffer_rsrc_t
 // offset (kaddr: + C16_DMA_BIAS - 1024 i against a descriptor based C16_DMA_BIAS bytes below the array).
 constexpr unsigned C16_DMA_BIAS = 3072;
 __device__ __forceinline__ void c16_blds16x4(const unsigned (&voff)[4], __amdgpu_buffer_rsrc_t rsrc, unsigned soff, unsigned lds_dst) {
+#ifdef PS_C16_NO_DMA   // (diagnostic build: the same bytes through registers and ds_write_b128 -- a run-to-run difference under load was NOT the DMA's: ps_device.h kq_max3)
+  typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const u32x4_ v = __builtin_bit_cast(u32x4_, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[i] + 1024u * i, soff, 0));
+    *reinterpret_cast<__attribute__((address_space(3))) u32x4_*>((__attribute__((address_space(3))) unsigned char*)(size_t)(lds_dst + 1024u * i + 16u * (threadIdx.x & 63))) = v;
+  }
+  return;
+#endif
   unsigned keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %7\n\ts_nop 0\n\t"
                "buffer_load_dwordx4 %1, %5, %6 offen lds\n\t"
