@@ -14,7 +14,7 @@ spec = DEMO_SPEC
 w = weights.init_weights(spec, 0)
 load = []
 for k in range(3):
-    e = Engine(spec, w); e.set_scene(synth.baseline_scene(spec, 2, seed=10 + k, batch=1)); e.rollout(); load.append(e)
+    e = Engine(spec, w); e.set_chain_impl(int(os.environ.get("PS_LOAD_IMPL", "0"))); e.set_scene(synth.baseline_scene(spec, 2, seed=10 + k, batch=1)); e.rollout(); load.append(e)
 probe = []
 for k in range(3):
     e = Engine(spec, w)
