@@ -25,7 +25,7 @@ import time
 # plus torch's, and with 4 queues the engines' graph replays serialise behind one another (4 engines in flight: 9.5 M
 # agent-steps/s with 4 queues, 16.7 M with 8).  Round 5: 16 -- every stream beyond the queue count SHARES a queue, and a job with
 # RCCL's streams beside the engines', the upload stream and torch's own crosses 8 (the forced-distributed line fell from 26.8 to
-# 15.4 M at 8 queues; prosim_amd/__init__.py sets the same default for every user of the package).  Must be set before the runtime
+# 15.4 M at 8 queues; prosim_amd.configure_runtime() does the same for other users of the package).  Must be set before the runtime
 # initialises.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 

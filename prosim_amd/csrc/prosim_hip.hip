@@ -297,11 +297,25 @@ struct PinStage {
   }
 };
 thread_local PinStage* g_stage = nullptr;   // the arena upload() stages through while a StageScope is alive (the setters of one engine)
+// (round 6, ADVICE round 5: a setter that FAILS after it staged slices must not leave them in the arena -- the next successful mark() would
+// scatter them to destinations that may have been re-allocated since.  A scope that is not commit()ted drops what was staged inside it; scopes
+// nest on one arena: ps_set_drag_points opens one around its own uploads and rebuild_conditions' inner scope appends to the same arena.)
 struct StageScope {
   PinStage* prev;
   hipStream_t prev_sync;
-  StageScope(PinStage* s, hipStream_t st) : prev(g_stage), prev_sync(g_free_sync) { g_stage = s; g_free_sync = st; }
-  ~StageScope() { g_stage = prev; g_free_sync = prev_sync; }
+  PinStage* mine;
+  size_t segs0, flushed0;
+  bool ok = false;
+  StageScope(PinStage* s, hipStream_t st) : prev(g_stage), prev_sync(g_free_sync), mine(s), segs0(s->segs.size()), flushed0(s->flushed) { g_stage = s; g_free_sync = st; }
+  void commit() { ok = true; }
+  ~StageScope() {
+    if (!ok) {   // slices staged since entry and not yet flushed: forget them (a flush in between restarted the list: everything in it is ours)
+      const size_t keep = mine->flushed == flushed0 ? std::min(segs0, mine->segs.size()) : 0;
+      mine->segs.resize(keep);
+    }
+    g_stage = prev;
+    g_free_sync = prev_sync;
+  }
 };
 
 }  // namespace
@@ -1389,6 +1403,7 @@ extern "C" int ps_set_scene(ps_engine* e, int32_t B, int32_t M, int32_t P, int32
   e->n_drag = 0;
   e->cond_present_gt = e->cond_present_drag = e->cond_present_pair = false;
   if (e->stage[e->stage_cur].mark(st)) return fail(PS_E_HIP, "upload staging: event record failed");
+  stage_scope.commit();
   e->have_scene = true;
   e->encoded = e->generated = e->reset = false;
   drop_graph(e);
@@ -1507,6 +1522,7 @@ static int rebuild_conditions(ps_engine* e) {
     if (upload(e->d_steps, e->h_steps.data(), e->h_steps.size(), st)) return fail(PS_E_HIP, "step table upload failed");
   }
   if (e->stage[e->stage_cur].mark(st)) return fail(PS_E_HIP, "upload staging: event record failed");
+  stage_scope.commit();
   e->generated = false;
   drop_graph(e);
   return PS_OK;
@@ -1590,13 +1606,18 @@ extern "C" int ps_set_drag_points(ps_engine* e, int32_t C_drag, int32_t T, const
   e->n_drag = (int)ents.size();
   e->drag_T = T;
   e->cond_present_drag = true;   // DragPointEncoder emits its entry whenever the type has rows (:164-191)
+  // (round 6, ADVICE round 5: through the engine's arena like every other setter -- outside a StageScope upload() fell to hipMemcpyAsync from
+  // these pageable stack vectors on the engine's stream, safe only while the runtime keeps such copies host-synchronous, and behind an in-flight rollout)
+  StageScope stage_scope(&e->stage[e->stage_cur], e->stream);
   if (e->n_drag > 0) {
     if (upload(e->d_drag_in, pts.data(), pts.size(), e->stream) || upload(e->d_drag_mask, pm.data(), pm.size(), e->stream) ||
         e->d_drag_emd.ensure((size_t)e->n_drag * D))
       return fail(PS_E_HIP, "drag-point upload failed");
   }
   e->ents_drag.swap(ents);
-  return rebuild_conditions(e);
+  const int rc = rebuild_conditions(e);   // (its mark() flushes the slices staged above with its own)
+  if (rc == PS_OK) stage_scope.commit();
+  return rc;
 }
 
 // Binary (agent-pair) tag conditions: 'v2v_tag' (condition_encoders.py:148-150; condition_attns.py:141-166).
@@ -2205,6 +2226,10 @@ extern "C" int ps_encode_scene(ps_engine* e) {
     return fail(PS_E_HIP, "device copy launch failed");
   launch_pointnet(e, e->pn_map, e->d_map_input.p, e->d_map_mask.p, e->d_map_rows.p, Mv, e->P, 0, tok);
   launch_pointnet(e, e->pn_obs, e->d_obs_input.p, e->d_obs_mask.p, e->d_agent_rows.p, Ap, c.hist_steps, c.obs_dim, tok + (size_t)Mv * D);
+  // (experiments builds: PS_DBG_STOP = k ends the encoder after its k-th stage, read on EVERY call -- tools/gpu_stage_bisect.py digests what the stage left)
+  const int dbg_stop = exp_env("PS_DBG_STOP") ? atoi(exp_env("PS_DBG_STOP")) : 0;
+#define PS_DBG_STOP_AT(k) do { if (dbg_stop == (k)) { HIPCHK(hipGetLastError()); return PS_OK; } } while (0)
+  PS_DBG_STOP_AT(1);
   // knn graphs (attn_fusion.py:107-109) + rel-PE (:111-112).  Agent rows that only enter the scene with a later fut_obs
   // frame are no tokens yet: not a candidate of any query (their own rows are computed and ignored).
   const int* live0 = e->have_dead0 ? (const int*)e->d_live0.p : nullptr;
@@ -2247,6 +2272,7 @@ extern "C" int ps_encode_scene(ps_engine* e) {
       }
     }
   }
+  PS_DBG_STOP_AT(2);
   // 6 x (a2a on the agent rows in place, s2s on all rows)  (attn_fusion.py:117-119).  kv is indexed by
   // GLOBAL token row for both (the a2a projection fills rows Mv.. of the shared kv buffer).
   static const bool no_split = exp_env("PS_NO_SPLIT") != nullptr;   // experiments only
@@ -2257,9 +2283,11 @@ extern "C" int ps_encode_scene(ps_engine* e) {
   const bool split_s2s = !no_split && Mv + Ap >= split_min && e->e_s2s.maxdeg <= ES_MAXDEG;
   for (int i = 0; i < c.scene_layers; ++i) {
     launch_kv(e, tok + (size_t)Mv * D, Ap, e->L_a2a + i, 1, e->d_kv.p + (size_t)Mv * 256, e->d_kh.p + (size_t)Mv * 256, 0);
+    PS_DBG_STOP_AT(3 + 3 * i);
     if (use_c16(e, Ap, 0)) {
       if (launch_chain16(e, tok + (size_t)Mv * D, Ap, e->d_steps.p + e->step_a2a + i, 1, false, nullptr, false)) return PS_E_HIP;
     } else if (launch_chain(e, tok + (size_t)Mv * D, Ap, e->step_a2a + i, 1, e->e_a2a.maxdeg, false, nullptr, 0, 0, nullptr, xcd_on(1, false), use_geo1(e, Ap, 0))) return PS_E_HIP;
+    PS_DBG_STOP_AT(4 + 3 * i);
     if (s2s_c16) {
       launch_kv(e, tok, Mv + Ap, e->L_s2s + i, 1, e->d_kv.p, e->d_kh.p, 0);
       if (launch_chain16(e, tok, Mv + Ap, e->d_steps.p + e->step_s2s + i, 1, false, nullptr, xcd_on(3, true))) return PS_E_HIP;
@@ -2272,7 +2300,9 @@ extern "C" int ps_encode_scene(ps_engine* e) {
       launch_kv(e, tok, Mv + Ap, e->L_s2s + i, 1, e->d_kv.p, e->d_kh.p, 0);
       if (launch_chain(e, tok, Mv + Ap, e->step_s2s + i, 1, e->e_s2s.maxdeg)) return PS_E_HIP;
     }
+    PS_DBG_STOP_AT(5 + 3 * i);
   }
+#undef PS_DBG_STOP_AT
   if (live0)   // rows outside the scene keep a zero token (what FUSION 'mlp' takes as the previous token when they enter)
     hipLaunchKernelGGL(k_zero_dead_rows, dim3((Ap * D + 255) / 256), dim3(256), 0, st, tok + (size_t)Mv * D, live0, Ap);
   if (e->replicas > 1)   // replica_batch_for_parallel_rollout (rollout/gpu_utils.py:59-123): every replica starts from the same tokens
@@ -2914,6 +2944,20 @@ extern "C" int64_t ps_get(ps_engine* e, const char* name, float* dst, int64_t ca
     dst[6] = e->edge_counts[6]; dst[7] = 0.f;
     return 8;
   }
+#ifdef PS_EXPERIMENTS   // (tools/gpu_stage_bisect.py: raw intermediate buffers of the encoder, as float words)
+  if (n == "dbg_kv_agents") return copy(e->d_kv.p + (size_t)Mv * 256, (int64_t)e->Ap * 256);
+  if (n == "dbg_kh_agents") return copy(reinterpret_cast<const float*>(e->d_kh.p + (size_t)Mv * 256), (int64_t)e->Ap * 128);
+  if (n == "dbg_kv_all") return copy(e->d_kv.p, (int64_t)(Mv + e->Ap) * 256);
+  if (n == "dbg_kh_all") return copy(reinterpret_cast<const float*>(e->d_kh.p), (int64_t)(Mv + e->Ap) * 128);
+  if (n == "dbg_geo_a2a" || n == "dbg_geo_s2s" || n == "dbg_esrc_a2a" || n == "dbg_esrc_s2s") {
+    const bool a2a = n.back() == 'a';
+    EdgeSet& es = a2a ? e->e_a2a : e->e_s2s;
+    int E = 0;
+    (void)hipMemcpy(&E, es.eoff.p + es.nq, sizeof(int), hipMemcpyDeviceToHost);
+    if (n[4] == 'g') return es.geo.p ? copy(reinterpret_cast<const float*>(es.geo.p), (int64_t)E * 8) : fail(PS_E_STATE, "no records");
+    return copy(reinterpret_cast<const float*>(es.esrc.p), (int64_t)E);
+  }
+#endif
   return fail(PS_E_ARG, "unknown result name '" + n + "'");
 }
 
@@ -3235,6 +3279,580 @@ extern "C" int ps_test_stream(ps_engine* e, int32_t mbytes, int32_t nwg, int32_t
   return PS_OK;
 }
 
+
+#ifdef PS_EXPERIMENTS
+// ---- the "poison" load: every workgroup fills the 160 KB of LDS of its CU and the vector / accumulator registers of its
+// waves with one bit pattern and leaves.  A kernel of ANOTHER stream that reads LDS or registers it never wrote then finds this pattern instead
+// of its own leftovers: a run-to-run difference that only shows under load becomes deterministic (tools/gpu_stage_stress.py PS_POISON=1).
+namespace {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_poison(unsigned pat, unsigned* sink) {
+  extern __shared__ unsigned poison_lds[];
+  for (int i = threadIdx.x; i < 160 * 1024 / 4; i += 256) poison_lds[i] = pat;
+  __syncthreads();
+  if (poison_lds[(threadIdx.x * 97) % (160 * 1024 / 4)] != pat) sink[0] = 1;   // (keeps the stores)
+  asm volatile("v_mov_b32 v8, %0\n\t"
+               "v_mov_b32 v9, %0\n\t"
+               "v_mov_b32 v10, %0\n\t"
+               "v_mov_b32 v11, %0\n\t"
+               "v_mov_b32 v12, %0\n\t"
+               "v_mov_b32 v13, %0\n\t"
+               "v_mov_b32 v14, %0\n\t"
+               "v_mov_b32 v15, %0\n\t"
+               "v_mov_b32 v16, %0\n\t"
+               "v_mov_b32 v17, %0\n\t"
+               "v_mov_b32 v18, %0\n\t"
+               "v_mov_b32 v19, %0\n\t"
+               "v_mov_b32 v20, %0\n\t"
+               "v_mov_b32 v21, %0\n\t"
+               "v_mov_b32 v22, %0\n\t"
+               "v_mov_b32 v23, %0\n\t"
+               "v_mov_b32 v24, %0\n\t"
+               "v_mov_b32 v25, %0\n\t"
+               "v_mov_b32 v26, %0\n\t"
+               "v_mov_b32 v27, %0\n\t"
+               "v_mov_b32 v28, %0\n\t"
+               "v_mov_b32 v29, %0\n\t"
+               "v_mov_b32 v30, %0\n\t"
+               "v_mov_b32 v31, %0\n\t"
+               "v_mov_b32 v32, %0\n\t"
+               "v_mov_b32 v33, %0\n\t"
+               "v_mov_b32 v34, %0\n\t"
+               "v_mov_b32 v35, %0\n\t"
+               "v_mov_b32 v36, %0\n\t"
+               "v_mov_b32 v37, %0\n\t"
+               "v_mov_b32 v38, %0\n\t"
+               "v_mov_b32 v39, %0\n\t"
+               "v_mov_b32 v40, %0\n\t"
+               "v_mov_b32 v41, %0\n\t"
+               "v_mov_b32 v42, %0\n\t"
+               "v_mov_b32 v43, %0\n\t"
+               "v_mov_b32 v44, %0\n\t"
+               "v_mov_b32 v45, %0\n\t"
+               "v_mov_b32 v46, %0\n\t"
+               "v_mov_b32 v47, %0\n\t"
+               "v_mov_b32 v48, %0\n\t"
+               "v_mov_b32 v49, %0\n\t"
+               "v_mov_b32 v50, %0\n\t"
+               "v_mov_b32 v51, %0\n\t"
+               "v_mov_b32 v52, %0\n\t"
+               "v_mov_b32 v53, %0\n\t"
+               "v_mov_b32 v54, %0\n\t"
+               "v_mov_b32 v55, %0\n\t"
+               "v_mov_b32 v56, %0\n\t"
+               "v_mov_b32 v57, %0\n\t"
+               "v_mov_b32 v58, %0\n\t"
+               "v_mov_b32 v59, %0\n\t"
+               "v_mov_b32 v60, %0\n\t"
+               "v_mov_b32 v61, %0\n\t"
+               "v_mov_b32 v62, %0\n\t"
+               "v_mov_b32 v63, %0\n\t"
+               "v_mov_b32 v64, %0\n\t"
+               "v_mov_b32 v65, %0\n\t"
+               "v_mov_b32 v66, %0\n\t"
+               "v_mov_b32 v67, %0\n\t"
+               "v_mov_b32 v68, %0\n\t"
+               "v_mov_b32 v69, %0\n\t"
+               "v_mov_b32 v70, %0\n\t"
+               "v_mov_b32 v71, %0\n\t"
+               "v_mov_b32 v72, %0\n\t"
+               "v_mov_b32 v73, %0\n\t"
+               "v_mov_b32 v74, %0\n\t"
+               "v_mov_b32 v75, %0\n\t"
+               "v_mov_b32 v76, %0\n\t"
+               "v_mov_b32 v77, %0\n\t"
+               "v_mov_b32 v78, %0\n\t"
+               "v_mov_b32 v79, %0\n\t"
+               "v_mov_b32 v80, %0\n\t"
+               "v_mov_b32 v81, %0\n\t"
+               "v_mov_b32 v82, %0\n\t"
+               "v_mov_b32 v83, %0\n\t"
+               "v_mov_b32 v84, %0\n\t"
+               "v_mov_b32 v85, %0\n\t"
+               "v_mov_b32 v86, %0\n\t"
+               "v_mov_b32 v87, %0\n\t"
+               "v_mov_b32 v88, %0\n\t"
+               "v_mov_b32 v89, %0\n\t"
+               "v_mov_b32 v90, %0\n\t"
+               "v_mov_b32 v91, %0\n\t"
+               "v_mov_b32 v92, %0\n\t"
+               "v_mov_b32 v93, %0\n\t"
+               "v_mov_b32 v94, %0\n\t"
+               "v_mov_b32 v95, %0\n\t"
+               "v_mov_b32 v96, %0\n\t"
+               "v_mov_b32 v97, %0\n\t"
+               "v_mov_b32 v98, %0\n\t"
+               "v_mov_b32 v99, %0\n\t"
+               "v_mov_b32 v100, %0\n\t"
+               "v_mov_b32 v101, %0\n\t"
+               "v_mov_b32 v102, %0\n\t"
+               "v_mov_b32 v103, %0\n\t"
+               "v_mov_b32 v104, %0\n\t"
+               "v_mov_b32 v105, %0\n\t"
+               "v_mov_b32 v106, %0\n\t"
+               "v_mov_b32 v107, %0\n\t"
+               "v_mov_b32 v108, %0\n\t"
+               "v_mov_b32 v109, %0\n\t"
+               "v_mov_b32 v110, %0\n\t"
+               "v_mov_b32 v111, %0\n\t"
+               "v_mov_b32 v112, %0\n\t"
+               "v_mov_b32 v113, %0\n\t"
+               "v_mov_b32 v114, %0\n\t"
+               "v_mov_b32 v115, %0\n\t"
+               "v_mov_b32 v116, %0\n\t"
+               "v_mov_b32 v117, %0\n\t"
+               "v_mov_b32 v118, %0\n\t"
+               "v_mov_b32 v119, %0\n\t"
+               "v_mov_b32 v120, %0\n\t"
+               "v_mov_b32 v121, %0\n\t"
+               "v_mov_b32 v122, %0\n\t"
+               "v_mov_b32 v123, %0\n\t"
+               "v_mov_b32 v124, %0\n\t"
+               "v_mov_b32 v125, %0\n\t"
+               "v_mov_b32 v126, %0\n\t"
+               "v_mov_b32 v127, %0\n\t"
+               "v_mov_b32 v128, %0\n\t"
+               "v_mov_b32 v129, %0\n\t"
+               "v_mov_b32 v130, %0\n\t"
+               "v_mov_b32 v131, %0\n\t"
+               "v_mov_b32 v132, %0\n\t"
+               "v_mov_b32 v133, %0\n\t"
+               "v_mov_b32 v134, %0\n\t"
+               "v_mov_b32 v135, %0\n\t"
+               "v_mov_b32 v136, %0\n\t"
+               "v_mov_b32 v137, %0\n\t"
+               "v_mov_b32 v138, %0\n\t"
+               "v_mov_b32 v139, %0\n\t"
+               "v_mov_b32 v140, %0\n\t"
+               "v_mov_b32 v141, %0\n\t"
+               "v_mov_b32 v142, %0\n\t"
+               "v_mov_b32 v143, %0\n\t"
+               "v_mov_b32 v144, %0\n\t"
+               "v_mov_b32 v145, %0\n\t"
+               "v_mov_b32 v146, %0\n\t"
+               "v_mov_b32 v147, %0\n\t"
+               "v_mov_b32 v148, %0\n\t"
+               "v_mov_b32 v149, %0\n\t"
+               "v_mov_b32 v150, %0\n\t"
+               "v_mov_b32 v151, %0\n\t"
+               "v_mov_b32 v152, %0\n\t"
+               "v_mov_b32 v153, %0\n\t"
+               "v_mov_b32 v154, %0\n\t"
+               "v_mov_b32 v155, %0\n\t"
+               "v_mov_b32 v156, %0\n\t"
+               "v_mov_b32 v157, %0\n\t"
+               "v_mov_b32 v158, %0\n\t"
+               "v_mov_b32 v159, %0\n\t"
+               "v_mov_b32 v160, %0\n\t"
+               "v_mov_b32 v161, %0\n\t"
+               "v_mov_b32 v162, %0\n\t"
+               "v_mov_b32 v163, %0\n\t"
+               "v_mov_b32 v164, %0\n\t"
+               "v_mov_b32 v165, %0\n\t"
+               "v_mov_b32 v166, %0\n\t"
+               "v_mov_b32 v167, %0\n\t"
+               "v_mov_b32 v168, %0\n\t"
+               "v_mov_b32 v169, %0\n\t"
+               "v_mov_b32 v170, %0\n\t"
+               "v_mov_b32 v171, %0\n\t"
+               "v_mov_b32 v172, %0\n\t"
+               "v_mov_b32 v173, %0\n\t"
+               "v_mov_b32 v174, %0\n\t"
+               "v_mov_b32 v175, %0\n\t"
+               "v_mov_b32 v176, %0\n\t"
+               "v_mov_b32 v177, %0\n\t"
+               "v_mov_b32 v178, %0\n\t"
+               "v_mov_b32 v179, %0\n\t"
+               "v_mov_b32 v180, %0\n\t"
+               "v_mov_b32 v181, %0\n\t"
+               "v_mov_b32 v182, %0\n\t"
+               "v_mov_b32 v183, %0\n\t"
+               "v_mov_b32 v184, %0\n\t"
+               "v_mov_b32 v185, %0\n\t"
+               "v_mov_b32 v186, %0\n\t"
+               "v_mov_b32 v187, %0\n\t"
+               "v_mov_b32 v188, %0\n\t"
+               "v_mov_b32 v189, %0\n\t"
+               "v_mov_b32 v190, %0\n\t"
+               "v_mov_b32 v191, %0\n\t"
+               "v_mov_b32 v192, %0\n\t"
+               "v_mov_b32 v193, %0\n\t"
+               "v_mov_b32 v194, %0\n\t"
+               "v_mov_b32 v195, %0\n\t"
+               "v_mov_b32 v196, %0\n\t"
+               "v_mov_b32 v197, %0\n\t"
+               "v_mov_b32 v198, %0\n\t"
+               "v_mov_b32 v199, %0\n\t"
+               "v_mov_b32 v200, %0\n\t"
+               "v_mov_b32 v201, %0\n\t"
+               "v_mov_b32 v202, %0\n\t"
+               "v_mov_b32 v203, %0\n\t"
+               "v_mov_b32 v204, %0\n\t"
+               "v_mov_b32 v205, %0\n\t"
+               "v_mov_b32 v206, %0\n\t"
+               "v_mov_b32 v207, %0\n\t"
+               "v_mov_b32 v208, %0\n\t"
+               "v_mov_b32 v209, %0\n\t"
+               "v_mov_b32 v210, %0\n\t"
+               "v_mov_b32 v211, %0\n\t"
+               "v_mov_b32 v212, %0\n\t"
+               "v_mov_b32 v213, %0\n\t"
+               "v_mov_b32 v214, %0\n\t"
+               "v_mov_b32 v215, %0\n\t"
+               "v_mov_b32 v216, %0\n\t"
+               "v_mov_b32 v217, %0\n\t"
+               "v_mov_b32 v218, %0\n\t"
+               "v_mov_b32 v219, %0\n\t"
+               "v_mov_b32 v220, %0\n\t"
+               "v_mov_b32 v221, %0\n\t"
+               "v_mov_b32 v222, %0\n\t"
+               "v_mov_b32 v223, %0\n\t"
+               "v_mov_b32 v224, %0\n\t"
+               "v_mov_b32 v225, %0\n\t"
+               "v_mov_b32 v226, %0\n\t"
+               "v_mov_b32 v227, %0\n\t"
+               "v_mov_b32 v228, %0\n\t"
+               "v_mov_b32 v229, %0\n\t"
+               "v_mov_b32 v230, %0\n\t"
+               "v_mov_b32 v231, %0\n\t"
+               "v_mov_b32 v232, %0\n\t"
+               "v_mov_b32 v233, %0\n\t"
+               "v_mov_b32 v234, %0\n\t"
+               "v_mov_b32 v235, %0\n\t"
+               "v_mov_b32 v236, %0\n\t"
+               "v_mov_b32 v237, %0\n\t"
+               "v_mov_b32 v238, %0\n\t"
+               "v_mov_b32 v239, %0\n\t"
+               "v_mov_b32 v240, %0\n\t"
+               "v_mov_b32 v241, %0\n\t"
+               "v_mov_b32 v242, %0\n\t"
+               "v_mov_b32 v243, %0\n\t"
+               "v_mov_b32 v244, %0\n\t"
+               "v_mov_b32 v245, %0\n\t"
+               "v_mov_b32 v246, %0\n\t"
+               "v_mov_b32 v247, %0\n\t"
+               "v_mov_b32 v248, %0\n\t"
+               "v_mov_b32 v249, %0\n\t"
+               "v_mov_b32 v250, %0\n\t"
+               "v_mov_b32 v251, %0\n\t"
+               "v_mov_b32 v252, %0\n\t"
+               "v_mov_b32 v253, %0\n\t"
+               "v_mov_b32 v254, %0\n\t"
+               "v_mov_b32 v255, %0\n\t"
+               "v_accvgpr_write_b32 a0, %0\n\t"
+               "v_accvgpr_write_b32 a1, %0\n\t"
+               "v_accvgpr_write_b32 a2, %0\n\t"
+               "v_accvgpr_write_b32 a3, %0\n\t"
+               "v_accvgpr_write_b32 a4, %0\n\t"
+               "v_accvgpr_write_b32 a5, %0\n\t"
+               "v_accvgpr_write_b32 a6, %0\n\t"
+               "v_accvgpr_write_b32 a7, %0\n\t"
+               "v_accvgpr_write_b32 a8, %0\n\t"
+               "v_accvgpr_write_b32 a9, %0\n\t"
+               "v_accvgpr_write_b32 a10, %0\n\t"
+               "v_accvgpr_write_b32 a11, %0\n\t"
+               "v_accvgpr_write_b32 a12, %0\n\t"
+               "v_accvgpr_write_b32 a13, %0\n\t"
+               "v_accvgpr_write_b32 a14, %0\n\t"
+               "v_accvgpr_write_b32 a15, %0\n\t"
+               "v_accvgpr_write_b32 a16, %0\n\t"
+               "v_accvgpr_write_b32 a17, %0\n\t"
+               "v_accvgpr_write_b32 a18, %0\n\t"
+               "v_accvgpr_write_b32 a19, %0\n\t"
+               "v_accvgpr_write_b32 a20, %0\n\t"
+               "v_accvgpr_write_b32 a21, %0\n\t"
+               "v_accvgpr_write_b32 a22, %0\n\t"
+               "v_accvgpr_write_b32 a23, %0\n\t"
+               "v_accvgpr_write_b32 a24, %0\n\t"
+               "v_accvgpr_write_b32 a25, %0\n\t"
+               "v_accvgpr_write_b32 a26, %0\n\t"
+               "v_accvgpr_write_b32 a27, %0\n\t"
+               "v_accvgpr_write_b32 a28, %0\n\t"
+               "v_accvgpr_write_b32 a29, %0\n\t"
+               "v_accvgpr_write_b32 a30, %0\n\t"
+               "v_accvgpr_write_b32 a31, %0\n\t"
+               "v_accvgpr_write_b32 a32, %0\n\t"
+               "v_accvgpr_write_b32 a33, %0\n\t"
+               "v_accvgpr_write_b32 a34, %0\n\t"
+               "v_accvgpr_write_b32 a35, %0\n\t"
+               "v_accvgpr_write_b32 a36, %0\n\t"
+               "v_accvgpr_write_b32 a37, %0\n\t"
+               "v_accvgpr_write_b32 a38, %0\n\t"
+               "v_accvgpr_write_b32 a39, %0\n\t"
+               "v_accvgpr_write_b32 a40, %0\n\t"
+               "v_accvgpr_write_b32 a41, %0\n\t"
+               "v_accvgpr_write_b32 a42, %0\n\t"
+               "v_accvgpr_write_b32 a43, %0\n\t"
+               "v_accvgpr_write_b32 a44, %0\n\t"
+               "v_accvgpr_write_b32 a45, %0\n\t"
+               "v_accvgpr_write_b32 a46, %0\n\t"
+               "v_accvgpr_write_b32 a47, %0\n\t"
+               "v_accvgpr_write_b32 a48, %0\n\t"
+               "v_accvgpr_write_b32 a49, %0\n\t"
+               "v_accvgpr_write_b32 a50, %0\n\t"
+               "v_accvgpr_write_b32 a51, %0\n\t"
+               "v_accvgpr_write_b32 a52, %0\n\t"
+               "v_accvgpr_write_b32 a53, %0\n\t"
+               "v_accvgpr_write_b32 a54, %0\n\t"
+               "v_accvgpr_write_b32 a55, %0\n\t"
+               "v_accvgpr_write_b32 a56, %0\n\t"
+               "v_accvgpr_write_b32 a57, %0\n\t"
+               "v_accvgpr_write_b32 a58, %0\n\t"
+               "v_accvgpr_write_b32 a59, %0\n\t"
+               "v_accvgpr_write_b32 a60, %0\n\t"
+               "v_accvgpr_write_b32 a61, %0\n\t"
+               "v_accvgpr_write_b32 a62, %0\n\t"
+               "v_accvgpr_write_b32 a63, %0\n\t"
+               "v_accvgpr_write_b32 a64, %0\n\t"
+               "v_accvgpr_write_b32 a65, %0\n\t"
+               "v_accvgpr_write_b32 a66, %0\n\t"
+               "v_accvgpr_write_b32 a67, %0\n\t"
+               "v_accvgpr_write_b32 a68, %0\n\t"
+               "v_accvgpr_write_b32 a69, %0\n\t"
+               "v_accvgpr_write_b32 a70, %0\n\t"
+               "v_accvgpr_write_b32 a71, %0\n\t"
+               "v_accvgpr_write_b32 a72, %0\n\t"
+               "v_accvgpr_write_b32 a73, %0\n\t"
+               "v_accvgpr_write_b32 a74, %0\n\t"
+               "v_accvgpr_write_b32 a75, %0\n\t"
+               "v_accvgpr_write_b32 a76, %0\n\t"
+               "v_accvgpr_write_b32 a77, %0\n\t"
+               "v_accvgpr_write_b32 a78, %0\n\t"
+               "v_accvgpr_write_b32 a79, %0\n\t"
+               "v_accvgpr_write_b32 a80, %0\n\t"
+               "v_accvgpr_write_b32 a81, %0\n\t"
+               "v_accvgpr_write_b32 a82, %0\n\t"
+               "v_accvgpr_write_b32 a83, %0\n\t"
+               "v_accvgpr_write_b32 a84, %0\n\t"
+               "v_accvgpr_write_b32 a85, %0\n\t"
+               "v_accvgpr_write_b32 a86, %0\n\t"
+               "v_accvgpr_write_b32 a87, %0\n\t"
+               "v_accvgpr_write_b32 a88, %0\n\t"
+               "v_accvgpr_write_b32 a89, %0\n\t"
+               "v_accvgpr_write_b32 a90, %0\n\t"
+               "v_accvgpr_write_b32 a91, %0\n\t"
+               "v_accvgpr_write_b32 a92, %0\n\t"
+               "v_accvgpr_write_b32 a93, %0\n\t"
+               "v_accvgpr_write_b32 a94, %0\n\t"
+               "v_accvgpr_write_b32 a95, %0\n\t"
+               "v_accvgpr_write_b32 a96, %0\n\t"
+               "v_accvgpr_write_b32 a97, %0\n\t"
+               "v_accvgpr_write_b32 a98, %0\n\t"
+               "v_accvgpr_write_b32 a99, %0\n\t"
+               "v_accvgpr_write_b32 a100, %0\n\t"
+               "v_accvgpr_write_b32 a101, %0\n\t"
+               "v_accvgpr_write_b32 a102, %0\n\t"
+               "v_accvgpr_write_b32 a103, %0\n\t"
+               "v_accvgpr_write_b32 a104, %0\n\t"
+               "v_accvgpr_write_b32 a105, %0\n\t"
+               "v_accvgpr_write_b32 a106, %0\n\t"
+               "v_accvgpr_write_b32 a107, %0\n\t"
+               "v_accvgpr_write_b32 a108, %0\n\t"
+               "v_accvgpr_write_b32 a109, %0\n\t"
+               "v_accvgpr_write_b32 a110, %0\n\t"
+               "v_accvgpr_write_b32 a111, %0\n\t"
+               "v_accvgpr_write_b32 a112, %0\n\t"
+               "v_accvgpr_write_b32 a113, %0\n\t"
+               "v_accvgpr_write_b32 a114, %0\n\t"
+               "v_accvgpr_write_b32 a115, %0\n\t"
+               "v_accvgpr_write_b32 a116, %0\n\t"
+               "v_accvgpr_write_b32 a117, %0\n\t"
+               "v_accvgpr_write_b32 a118, %0\n\t"
+               "v_accvgpr_write_b32 a119, %0\n\t"
+               "v_accvgpr_write_b32 a120, %0\n\t"
+               "v_accvgpr_write_b32 a121, %0\n\t"
+               "v_accvgpr_write_b32 a122, %0\n\t"
+               "v_accvgpr_write_b32 a123, %0\n\t"
+               "v_accvgpr_write_b32 a124, %0\n\t"
+               "v_accvgpr_write_b32 a125, %0\n\t"
+               "v_accvgpr_write_b32 a126, %0\n\t"
+               "v_accvgpr_write_b32 a127, %0\n\t"
+               "v_accvgpr_write_b32 a128, %0\n\t"
+               "v_accvgpr_write_b32 a129, %0\n\t"
+               "v_accvgpr_write_b32 a130, %0\n\t"
+               "v_accvgpr_write_b32 a131, %0\n\t"
+               "v_accvgpr_write_b32 a132, %0\n\t"
+               "v_accvgpr_write_b32 a133, %0\n\t"
+               "v_accvgpr_write_b32 a134, %0\n\t"
+               "v_accvgpr_write_b32 a135, %0\n\t"
+               "v_accvgpr_write_b32 a136, %0\n\t"
+               "v_accvgpr_write_b32 a137, %0\n\t"
+               "v_accvgpr_write_b32 a138, %0\n\t"
+               "v_accvgpr_write_b32 a139, %0\n\t"
+               "v_accvgpr_write_b32 a140, %0\n\t"
+               "v_accvgpr_write_b32 a141, %0\n\t"
+               "v_accvgpr_write_b32 a142, %0\n\t"
+               "v_accvgpr_write_b32 a143, %0\n\t"
+               "v_accvgpr_write_b32 a144, %0\n\t"
+               "v_accvgpr_write_b32 a145, %0\n\t"
+               "v_accvgpr_write_b32 a146, %0\n\t"
+               "v_accvgpr_write_b32 a147, %0\n\t"
+               "v_accvgpr_write_b32 a148, %0\n\t"
+               "v_accvgpr_write_b32 a149, %0\n\t"
+               "v_accvgpr_write_b32 a150, %0\n\t"
+               "v_accvgpr_write_b32 a151, %0\n\t"
+               "v_accvgpr_write_b32 a152, %0\n\t"
+               "v_accvgpr_write_b32 a153, %0\n\t"
+               "v_accvgpr_write_b32 a154, %0\n\t"
+               "v_accvgpr_write_b32 a155, %0\n\t"
+               "v_accvgpr_write_b32 a156, %0\n\t"
+               "v_accvgpr_write_b32 a157, %0\n\t"
+               "v_accvgpr_write_b32 a158, %0\n\t"
+               "v_accvgpr_write_b32 a159, %0\n\t"
+               "v_accvgpr_write_b32 a160, %0\n\t"
+               "v_accvgpr_write_b32 a161, %0\n\t"
+               "v_accvgpr_write_b32 a162, %0\n\t"
+               "v_accvgpr_write_b32 a163, %0\n\t"
+               "v_accvgpr_write_b32 a164, %0\n\t"
+               "v_accvgpr_write_b32 a165, %0\n\t"
+               "v_accvgpr_write_b32 a166, %0\n\t"
+               "v_accvgpr_write_b32 a167, %0\n\t"
+               "v_accvgpr_write_b32 a168, %0\n\t"
+               "v_accvgpr_write_b32 a169, %0\n\t"
+               "v_accvgpr_write_b32 a170, %0\n\t"
+               "v_accvgpr_write_b32 a171, %0\n\t"
+               "v_accvgpr_write_b32 a172, %0\n\t"
+               "v_accvgpr_write_b32 a173, %0\n\t"
+               "v_accvgpr_write_b32 a174, %0\n\t"
+               "v_accvgpr_write_b32 a175, %0\n\t"
+               "v_accvgpr_write_b32 a176, %0\n\t"
+               "v_accvgpr_write_b32 a177, %0\n\t"
+               "v_accvgpr_write_b32 a178, %0\n\t"
+               "v_accvgpr_write_b32 a179, %0\n\t"
+               "v_accvgpr_write_b32 a180, %0\n\t"
+               "v_accvgpr_write_b32 a181, %0\n\t"
+               "v_accvgpr_write_b32 a182, %0\n\t"
+               "v_accvgpr_write_b32 a183, %0\n\t"
+               "v_accvgpr_write_b32 a184, %0\n\t"
+               "v_accvgpr_write_b32 a185, %0\n\t"
+               "v_accvgpr_write_b32 a186, %0\n\t"
+               "v_accvgpr_write_b32 a187, %0\n\t"
+               "v_accvgpr_write_b32 a188, %0\n\t"
+               "v_accvgpr_write_b32 a189, %0\n\t"
+               "v_accvgpr_write_b32 a190, %0\n\t"
+               "v_accvgpr_write_b32 a191, %0\n\t"
+               "v_accvgpr_write_b32 a192, %0\n\t"
+               "v_accvgpr_write_b32 a193, %0\n\t"
+               "v_accvgpr_write_b32 a194, %0\n\t"
+               "v_accvgpr_write_b32 a195, %0\n\t"
+               "v_accvgpr_write_b32 a196, %0\n\t"
+               "v_accvgpr_write_b32 a197, %0\n\t"
+               "v_accvgpr_write_b32 a198, %0\n\t"
+               "v_accvgpr_write_b32 a199, %0\n\t"
+               "v_accvgpr_write_b32 a200, %0\n\t"
+               "v_accvgpr_write_b32 a201, %0\n\t"
+               "v_accvgpr_write_b32 a202, %0\n\t"
+               "v_accvgpr_write_b32 a203, %0\n\t"
+               "v_accvgpr_write_b32 a204, %0\n\t"
+               "v_accvgpr_write_b32 a205, %0\n\t"
+               "v_accvgpr_write_b32 a206, %0\n\t"
+               "v_accvgpr_write_b32 a207, %0\n\t"
+               "v_accvgpr_write_b32 a208, %0\n\t"
+               "v_accvgpr_write_b32 a209, %0\n\t"
+               "v_accvgpr_write_b32 a210, %0\n\t"
+               "v_accvgpr_write_b32 a211, %0\n\t"
+               "v_accvgpr_write_b32 a212, %0\n\t"
+               "v_accvgpr_write_b32 a213, %0\n\t"
+               "v_accvgpr_write_b32 a214, %0\n\t"
+               "v_accvgpr_write_b32 a215, %0\n\t"
+               "v_accvgpr_write_b32 a216, %0\n\t"
+               "v_accvgpr_write_b32 a217, %0\n\t"
+               "v_accvgpr_write_b32 a218, %0\n\t"
+               "v_accvgpr_write_b32 a219, %0\n\t"
+               "v_accvgpr_write_b32 a220, %0\n\t"
+               "v_accvgpr_write_b32 a221, %0\n\t"
+               "v_accvgpr_write_b32 a222, %0\n\t"
+               "v_accvgpr_write_b32 a223, %0\n\t"
+               "v_accvgpr_write_b32 a224, %0\n\t"
+               "v_accvgpr_write_b32 a225, %0\n\t"
+               "v_accvgpr_write_b32 a226, %0\n\t"
+               "v_accvgpr_write_b32 a227, %0\n\t"
+               "v_accvgpr_write_b32 a228, %0\n\t"
+               "v_accvgpr_write_b32 a229, %0\n\t"
+               "v_accvgpr_write_b32 a230, %0\n\t"
+               "v_accvgpr_write_b32 a231, %0\n\t"
+               "v_accvgpr_write_b32 a232, %0\n\t"
+               "v_accvgpr_write_b32 a233, %0\n\t"
+               "v_accvgpr_write_b32 a234, %0\n\t"
+               "v_accvgpr_write_b32 a235, %0\n\t"
+               "v_accvgpr_write_b32 a236, %0\n\t"
+               "v_accvgpr_write_b32 a237, %0\n\t"
+               "v_accvgpr_write_b32 a238, %0\n\t"
+               "v_accvgpr_write_b32 a239, %0\n\t"
+               "v_accvgpr_write_b32 a240, %0\n\t"
+               "v_accvgpr_write_b32 a241, %0\n\t"
+               "v_accvgpr_write_b32 a242, %0\n\t"
+               "v_accvgpr_write_b32 a243, %0\n\t"
+               "v_accvgpr_write_b32 a244, %0\n\t"
+               "v_accvgpr_write_b32 a245, %0\n\t"
+               "v_accvgpr_write_b32 a246, %0\n\t"
+               "v_accvgpr_write_b32 a247, %0\n\t"
+               "v_accvgpr_write_b32 a248, %0\n\t"
+               "v_accvgpr_write_b32 a249, %0\n\t"
+               "v_accvgpr_write_b32 a250, %0\n\t"
+               "v_accvgpr_write_b32 a251, %0\n\t"
+               "v_accvgpr_write_b32 a252, %0\n\t"
+               "v_accvgpr_write_b32 a253, %0\n\t"
+               "v_accvgpr_write_b32 a254, %0\n\t"
+               "v_accvgpr_write_b32 a255, %0\n\t"
+               ""
+               :: "s"(pat) : "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143", "v144", "v145", "v146", "v147", "v148", "v149", "v150", "v151", "v152", "v153", "v154", "v155", "v156", "v157", "v158", "v159", "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167", "v168", "v169", "v170", "v171", "v172", "v173", "v174", "v175", "v176", "v177", "v178", "v179", "v180", "v181", "v182", "v183", "v184", "v185", "v186", "v187", "v188", "v189", "v190", "v191", "v192", "v193", "v194", "v195", "v196", "v197", "v198", "v199", "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209", "v210", "v211", "v212", "v213", "v214", "v215", "v216", "v217", "v218", "v219", "v220", "v221", "v222", "v223", "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255", "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159", "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191", "a192", "a193", "a194", "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207", "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220", "a221", "a222", "a223", "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239", "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255");
+}
+}  // namespace
+extern "C" int ps_test_poison(ps_engine* e, int32_t n_wg, uint32_t pattern, int32_t launches) {
+  if (!e) return fail(PS_E_ARG, "null engine");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  static unsigned* sink = nullptr;
+  if (!sink) HIPCHK(hipMalloc(&sink, 256));
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_poison), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  for (int i = 0; i < launches; ++i) hipLaunchKernelGGL(k_poison, dim3(n_wg), dim3(256), 160 * 1024, e->stream, pattern, sink);
+  HIPCHK(hipGetLastError());
+  return PS_OK;
+}
+#endif
+
+#ifdef PS_EXPERIMENTS
+// ---- round 6 hunt: geo_record itself as a probe.  Every thread makes the record of ONE fixed (source, destination) pair again and again and counts the
+// iterations whose bits differ from its first one, by lane quarter: [0..3] statistics (rstd | nmr), [4..7] the three inputs.  Launched beside real
+// rollouts of other engines (tools/gpu_geo_probe.py): k_edge_geo's records were found to differ under load, lanes 48-63 only, packed form only.
+namespace {
+__global__ __launch_bounds__(GEO_THREADS) void k_geo_probe(const float* __restrict__ src_pos, const float* __restrict__ src_ori, int ns,
+                                                           const float* __restrict__ div32, float eps, int iters, unsigned long long* cnt) {
+  float dv[16], rdv[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    dv[k] = div32[2 * k];
+    rdv[k] = 1.0f / dv[k];
+  }
+  const int t = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63;
+  const int s = (t * 7 + 3) % ns, d = (t * 13 + 5) % ns;
+  float px = src_pos[2 * d], py = src_pos[2 * d + 1], od = src_ori[d];
+  const EdgeGeo first = geo_record(s, px, py, od, cosf(od), sinf(od), src_pos, src_ori, dv, rdv, eps, 0);
+  unsigned bad_stat = 0, bad_in = 0;
+  for (int it = 0; it < iters; ++it) {
+    asm volatile("" : "+v"(px), "+v"(py), "+v"(od));
+    const EdgeGeo g = geo_record(s, px, py, od, cosf(od), sinf(od), src_pos, src_ori, dv, rdv, eps, 0);
+    bad_stat += (__float_as_uint(g.rstd) != __float_as_uint(first.rstd) || __float_as_uint(g.nmr) != __float_as_uint(first.nmr)) ? 1u : 0u;
+    bad_in += (__float_as_uint(g.a0) != __float_as_uint(first.a0) || __float_as_uint(g.a1) != __float_as_uint(first.a1) || __float_as_uint(g.a2) != __float_as_uint(first.a2)) ? 1u : 0u;
+  }
+  if (bad_stat) atomicAdd(cnt + (lane >> 4), (unsigned long long)bad_stat);
+  if (bad_in) atomicAdd(cnt + 4 + (lane >> 4), (unsigned long long)bad_in);
+}
+}  // namespace
+extern "C" int ps_test_geo_probe(ps_engine* e, int32_t n_wg, int32_t iters, int32_t launches, uint64_t* counts8) {
+  if (!e || !e->have_scene) return fail(PS_E_STATE, "ps_test_geo_probe needs a scene (its token poses are the inputs)");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  DevBuf<unsigned long long> cnt;
+  if (cnt.ensure(8)) return fail(PS_E_HIP, "alloc");
+  if (dev_zero(e->stream, cnt.p, 8 * sizeof(unsigned long long))) return fail(PS_E_HIP, "device fill launch failed");
+  for (int i = 0; i < launches; ++i)
+    hipLaunchKernelGGL(k_geo_probe, dim3(n_wg), dim3(GEO_THREADS), GEO_LDS_BYTES, e->stream, (const float*)e->d_tok_pos.p, (const float*)e->d_tok_ori.p, e->Mv + e->A,
+                       e->div32, e->cfg.ln_eps, iters, cnt.p);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(e->stream));
+  HIPCHK(hipMemcpy(counts8, cnt.p, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  return PS_OK;
+}
+#endif
 // ------------------------------------------------------------------------------------------
 // Stateless policy.forward: Policy_RelPE_Temporal.forward(policy_emd, batch_obs, batch_map, batch_pos,
 // pair_names, latent_state) (policy/base.py:19 -> temporal_ar.py:75-92 -> act_decoder.py:239-283, :78-140)

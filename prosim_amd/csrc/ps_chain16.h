@@ -28,6 +28,9 @@
 namespace ps {
 
 // geometry of one edge, made once per edge set (k_edge_geo) and read by every layer of the set
+#ifndef PS_GEO_VARIANT
+#define PS_GEO_VARIANT 0
+#endif
 struct EdgeGeo {
   float a0, a1, a2;   // 2 pi * (dist, rel_ori, angle): the three distinct FourierEmbeddingFix inputs, already scaled (:66)
   float rstd, nmr;    // affine-free LayerNorm of the 128-feature row: y = f * rstd + nmr (nmr = -mean * rstd)
@@ -122,28 +125,60 @@ __device__ __forceinline__ EdgeGeo geo_record(int s, float px, float py, float o
   // torch's two passes bit for bit -- a last-bit change of rstd re-rolled the workload's near-cut edges; with the quieter GEMM
   // operands of round 4 the parity table holds either way, and the pass was a third of this kernel: 96 LDS round trips per edge.)
   float sm = 0.f;
+#if PS_GEO_VARIANT == 1   // (hunt: scalar form -- fourier_pair per frequency, no packed instructions)
+  if (fast) {
+    for (int i = 0; i < 3; ++i) {
+      float part = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        float sv, cv;
+        fourier_pair(xs[i], dv[k], rdv[k], true, sv, cv);
+        part += sv + cv;
+      }
+      sm += (i == 2) ? 2.f * part : part;
+    }
+  } else
+#endif
   if (__builtin_expect(fast, 1)) {   // (the two forms in branches of their own: sharing one loop, libm's sincosf kept the kernel at 145 registers)
     // two frequencies per packed instruction through the exact division and the reduction to revolutions (round 5: feat8's scheme, the
     // operations of fourier_pair / sincos_hw in the same order on the same values -- the sums keep their order, the records their bits)
     constexpr float C1 = 0.15915494309189535f;
     constexpr float C2 = (float)(0.15915494309189535 - (double)0.15915494309189535f);
     typedef float f32x2_ __attribute__((ext_vector_type(2)));
-    const f32x2_ c1 = {C1, C1}, c2 = {C2, C2};
+    f32x2_ c1 = {C1, C1}, c2 = {C2, C2};
+#if PS_GEO_VARIANT == 6 || PS_GEO_VARIANT == 7   // (hunt: the packed constants in VECTOR registers)
+    asm volatile("" : "+v"(c1), "+v"(c2));
+#endif
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       float part = 0.f;
       const f32x2_ x2 = {xs[i], xs[i]};
 #pragma unroll
       for (int k = 0; k < 16; k += 2) {
-        const f32x2_ d2 = {dv[k], dv[k + 1]}, rd2 = {rdv[k], rdv[k + 1]};
+        f32x2_ d2 = {dv[k], dv[k + 1]}, rd2 = {rdv[k], rdv[k + 1]};
+#if PS_GEO_VARIANT == 5 || PS_GEO_VARIANT == 6   // (hunt: the divisors in VECTOR registers -- no scalar-pair operand in a packed instruction)
+        asm volatile("" : "+v"(d2), "+v"(rd2));
+#endif
         const f32x2_ q0 = x2 * rd2;
         const f32x2_ rem = __builtin_elementwise_fma(-q0, d2, x2);
         const f32x2_ q = __builtin_elementwise_fma(rem, rd2, q0);
         const f32x2_ u = q * c1;
         const f32x2_ n = {rintf(u.x), rintf(u.y)};
         const f32x2_ f = __builtin_elementwise_fma(q, c1, -n) + q * c2;
+#if PS_GEO_VARIANT == 2   // (hunt: the trans sources stay live until the sums that read the results are made)
         part += __builtin_amdgcn_sinf(f.x) + __builtin_amdgcn_cosf(f.x);
         part += __builtin_amdgcn_sinf(f.y) + __builtin_amdgcn_cosf(f.y);
+        asm volatile("" : "+v"(part) : "v"(f.x), "v"(f.y));
+#elif PS_GEO_VARIANT == 4   // (hunt: sin, cos and the add that consumes both in ONE asm block -- nothing can overwrite the source before the results are read)
+        float sc0_, sc1_, t0_, t1_;
+        asm volatile("v_sin_f32 %0, %2\n\tv_cos_f32 %1, %2\n\ts_nop 1\n\tv_add_f32 %0, %0, %1" : "=&v"(sc0_), "=&v"(t0_) : "v"(f.x));
+        asm volatile("v_sin_f32 %0, %2\n\tv_cos_f32 %1, %2\n\ts_nop 1\n\tv_add_f32 %0, %0, %1" : "=&v"(sc1_), "=&v"(t1_) : "v"(f.y));
+        part += sc0_;
+        part += sc1_;
+#else
+        part += __builtin_amdgcn_sinf(f.x) + __builtin_amdgcn_cosf(f.x);
+        part += __builtin_amdgcn_sinf(f.y) + __builtin_amdgcn_cosf(f.y);
+#endif
       }
       sm += (i == 2) ? 2.f * part : part;
     }
@@ -374,6 +409,11 @@ __global__ __launch_bounds__(64 * RG_WAVES) void k_radius_geo(RadSets sets, GeoS
     // every look-back of the launch done -> the last one out clears flags and counter for the next launch
     int* done = reinterpret_cast<int*>(flag + nq);
     int last = 0;
+    // (round 6, ADVICE round 5: this workgroup's publish must be COMPLETE before its increment can be seen -- else the last workgroup could
+    // zero the flags before a late publish lands and the next replay would read a stale count.  Both are agent-scope atomics (no dirty line
+    // in this XCD's L2 to write back), so waiting for the store's acknowledgement orders them; a release fence here writes the whole L2 back
+    // (+ 12 us per launch, measured in round 5).  The look-back's loads above were issued after the store: the wait is over when they are.)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (lane == 0) last = __hip_atomic_fetch_add(done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nq - 1 ? 1 : 0;
     last = __builtin_amdgcn_readfirstlane(last);
     if (last) {

@@ -44,6 +44,11 @@ class RolloutPipeline:
         bad = [n for n in outputs if n not in Engine.ASYNC_RESULTS]
         if bad:
             raise ValueError(f"outputs {bad}: the pipeline reads results back asynchronously, which covers {Engine.ASYNC_RESULTS}")
+        from . import hw_queues_configured
+        if depth > 1 and hw_queues_configured() < depth + 2:   # (engine streams + the upload stream + the default stream)
+            import warnings
+            warnings.warn(f"RolloutPipeline(depth={depth}): GPU_MAX_HW_QUEUES is {hw_queues_configured()} -- engines that share a hardware queue "
+                          "serialise their rollouts; call prosim_amd.configure_runtime() before the first GPU call of the process", RuntimeWarning, stacklevel=2)
         self.engines: List[Engine] = [Engine(spec, weights, device=device) for _ in range(depth)]
         if depth > 1:   # throughput mode (k_chain16, 16 rows per workgroup): the launches of the rollouts in flight share the chip
             for e in self.engines:

@@ -10,6 +10,10 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # one hardware queue per stream for the multi-engine tests: before anything touches the GPU (prosim_amd.configure_runtime;
+    # importing the package no longer sets it)
+    import prosim_amd
+    prosim_amd.configure_runtime()
 
 
 def has_gpu() -> bool:
