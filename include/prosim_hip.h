@@ -81,6 +81,10 @@ typedef struct ps_config {
    * (a2p, m2p) edge sets are the *_max_neigh NEAREST tokens of the scene (torch_cluster.knn / knn_graph: sym_coord.py:85-96,
    * act_decoder.py:249-261) instead of the first *_max_neigh inside the radii; at most 2560 candidate tokens per scene */
   int32_t rel_pos_knn;
+  /* MODEL.SCENE_ENCODER.MAP_TYPE / OBS_TYPE == 'mlp' (scene_encoder/map_encoder.py:5, obs_encoder.py:19, selected at
+   * scene_encoder/base.py:20-21; 'pointnet' in every released yaml): the flat-MLP encoders have NO engine counterpart -- ps_create
+   * refuses such a config with PS_E_ARG and says so, instead of running the PointNet kernels over another model's weights. */
+  int32_t map_encoder_mlp, obs_encoder_mlp;
 } ps_config;
 
 /* Create an engine and upload weights.  names[i] are reference state_dict keys

@@ -833,6 +833,9 @@ extern "C" int ps_create(const ps_config* cfg, int32_t n_tensors, const char* co
       cfg->target_steps * cfg->state_dim * (cfg->k_pred_mlp ? cfg->motion_k : 1) > 128 || cfg->map_pre_layers > 4 || cfg->obs_pre_layers > 4 ||
       cfg->map_mlp_layers - cfg->map_pre_layers > 4 || cfg->obs_mlp_layers - cfg->obs_pre_layers > 4)
     return fail(PS_E_ARG, "unsupported config (hist<=15, obs_dim<=24, map_dim<=24, 1<=motion_k<=16, steps*state (x motion_k with PRED_MODE mlp) <=128)");
+  if (cfg->map_encoder_mlp || cfg->obs_encoder_mlp)
+    return fail(PS_E_ARG, std::string("MODEL.SCENE_ENCODER.") + (cfg->map_encoder_mlp ? "MAP_TYPE" : "OBS_TYPE") +
+                          " 'mlp' (scene_encoder/map_encoder.py:5, obs_encoder.py:19) is not built: this engine runs the 'pointnet' encoders only");
   if (cfg->goal_pred_k < 0 || cfg->goal_pred_k > 64) return fail(PS_E_ARG, "goal_pred_k must be in 0..64");
   if (cfg->no_pred_vel && cfg->replan_freq < 2)
     return fail(PS_E_ARG, "PRED_VEL False needs replan_freq >= 2 (velocities from position differences over hist_steps + 2 steps)");

@@ -41,6 +41,7 @@ class PsConfig(C.Structure):
         ("enc_learnable_pe", C.c_int32), ("dec_learnable_pe", C.c_int32), ("pol_learnable_pe", C.c_int32),
         ("pe_num_freq", C.c_int32), ("v2v_tag_mask", C.c_int32), ("pred_gmm", C.c_int32), ("k_pred_mlp", C.c_int32),
         ("no_pred_vel", C.c_int32), ("no_reconst_pred", C.c_int32), ("rel_pos_knn", C.c_int32),
+        ("map_encoder_mlp", C.c_int32), ("obs_encoder_mlp", C.c_int32),
     ]
 
 
@@ -177,7 +178,8 @@ class Engine:
                        pe_num_freq=64 if spec.pe_num_freq <= 64 else spec.pe_num_freq,   # (fewer bands: zero-padded by weights.engine_tensors)
                        v2v_tag_mask=sum(1 << V2V_TAGS.index(t) for t in spec.used_v2v_tags), pred_gmm=int(spec.pred_gmm),
                        k_pred_mlp=int(spec.k_pred_mode == "mlp"), no_pred_vel=int(not spec.pred_vel),
-                       no_reconst_pred=int(not spec.use_goal_pred_loss), rel_pos_knn=int(spec.rel_pos_edge_func == "knn"))
+                       no_reconst_pred=int(not spec.use_goal_pred_loss), rel_pos_knn=int(spec.rel_pos_edge_func == "knn"),
+                       map_encoder_mlp=int(spec.map_encoder_type == "mlp"), obs_encoder_mlp=int(spec.obs_encoder_type == "mlp"))
         from .weights import engine_tensors
         tensors = dict(engine_tensors(spec, weights))   # ('cluster' anchors folded into the anchor table)
         tensors.update(fourier_tables())

@@ -69,6 +69,11 @@ class ModelSpec:
     obs_dim: int = 24
     # DATASET.FORMAT.MAP: 4 coords + type + tl + 3 type one-hot + 2 dir (format_utils.py:249-261)
     map_dim: int = 11
+    # MODEL.SCENE_ENCODER.MAP_TYPE / OBS_TYPE (scene_encoder/base.py:20-21 picks map_encoders[...] / obs_encoders[...]; 'pointnet' in every
+    # released yaml).  'mlp' (map_encoder.py:5, obs_encoder.py:19: a flat MLP over the concatenated points) is a legal value of the
+    # reference's registry that this engine does NOT build: Engine / ps_create refuse it loudly (round 6)
+    map_encoder_type: str = "pointnet"
+    obs_encoder_type: str = "pointnet"
     # MODEL.{MAP,OBS}_ENCODER.POINTNET (default.py:488-497)
     map_pre_layers: int = 3
     map_mlp_layers: int = 5
@@ -129,6 +134,9 @@ class ModelSpec:
     def __post_init__(self):
         if self.state_dim != 3 + 2 * self.pred_vel + 3 * self.pred_gmm:
             raise ValueError(f"state_dim {self.state_dim}: 3 (x, y, h) + 2 with pred_vel + 3 with pred_gmm (use ModelSpec.replace, which keeps it in step)")
+        for k in (self.map_encoder_type, self.obs_encoder_type):
+            if k not in ("pointnet", "mlp"):
+                raise ValueError(f"map_encoder_type / obs_encoder_type {k!r}: 'pointnet' or 'mlp' (the reference's registry keys)")
         if self.rel_pos_edge_func not in ("radius", "knn"):
             raise ValueError(f"rel_pos_edge_func {self.rel_pos_edge_func!r}: 'radius' or 'knn'")
         if self.k_pred_mode not in ("anchor", "cluster", "mlp"):

@@ -24,115 +24,14 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 from prosim_amd import synth, weights  # noqa: E402
 from prosim_amd.spec import SMALL_SPEC, DEMO_SPEC, ModelSpec, USED_V_ACTION_TAGS  # noqa: E402
 from oracle import prosim_oracle as orc, ref_harness as rh  # noqa: E402
 
-GOLD = os.path.join(ROOT, "tests", "golden")
-
-
-def digest(d) -> str:
-    h = hashlib.sha256()
-    for k in sorted(d):
-        v = d[k]
-        if isinstance(v, dict):
-            h.update(digest(v).encode())
-        else:
-            a = np.ascontiguousarray(v)
-            h.update(k.encode())
-            h.update(str(a.dtype).encode())
-            h.update(np.nan_to_num(a.astype(np.float64), nan=-12345.0).tobytes())
-    return h.hexdigest()
-
-
-FULL_CASES = {
-    # name: (spec name, scene kwargs, weight seed)
-    "small_ragged_b2": ("small", dict(n_agents=16, n_polylines=128, batch=2, seed=0, goal=True, tags=True, ragged=True), 0),
-    "small_plain_b1": ("small", dict(n_agents=16, n_polylines=128, batch=1, seed=1), 1),
-    "small_goal_64a": ("small", dict(n_agents=64, n_polylines=512, batch=1, seed=2, goal=True), 0),
-    "demo_16a_128p": ("demo", dict(n_agents=16, n_polylines=128, batch=1, seed=3, goal=True), 0),
-    # the reference ITSELF at a BASELINE size: one configs[2] scene (128 agents, 1024 polylines, goal prompts; generator seed 0 = scene 0
-    # of bench.py's batch) through the full-depth demo model
-    "demo_cfg2_b1": ("demo", dict(n_agents=128, n_polylines=1024, batch=1, seed=0, goal=True), 0),
-    # ... and scene 5 of that batch, whose fp64 rollout passes 2.4e-6 / 3.9e-6 / 5.6e-6 rad from a +-pi cut (tools/cut_margin.py): the
-    # reference's own fp32 run stays on the fp64 side; so must the engine (its fused s2s kernels did not: tools/gpu_cut_paths.py)
-    "demo_cfg2_seed5": ("demo", dict(n_agents=128, n_polylines=1024, batch=1, seed=5, goal=True), 0),
-    # ... and the other six scenes of the batch: the engine's single-scene path against the REFERENCE on every scene bench.py times
-    **{f"demo_cfg2_seed{s_}": ("demo", dict(n_agents=128, n_polylines=1024, batch=1, seed=s_, goal=True), 0) for s_ in (1, 2, 3, 4, 6, 7)},
-    # policy agents are a SUBSET of the observed agents: the others replay a log (fut_obs frames)
-    "small_replay_b2": ("small", dict(n_agents=16, n_polylines=128, batch=2, seed=5, goal=True, ragged=True, replay=0.4), 0),
-    # all three condition types of the demo config (PROMPT.CONDITION.TYPES): goal, v_action_tag, drag_point
-    "small_drag_b2": ("small", dict(n_agents=16, n_polylines=128, batch=2, seed=6, goal=True, tags=True, drag=True, ragged=True), 0),
-    # MODEL.OBS_UPDATE variants (attn_fusion.py:136-203): observation tokens fused by obs_update_mlp instead of
-    # replaced; agents re-attend to each other and to the map after every update.  With log-replay agents that
-    # drop out of the log (their previous token counts as zeros when they come back).
-    "small_fuse_mlp_b2": ("small_mlp", dict(n_agents=16, n_polylines=128, batch=2, seed=7, goal=True, ragged=True, replay=0.4), 0),
-    # log-replay agents that ENTER the scene after the initial step (no history at t0, listed from a later frame on)
-    "small_enter_b2": ("small", dict(n_agents=16, n_polylines=128, batch=2, seed=11, goal=True, ragged=True, replay=0.6, enter=0.6), 0),
-    "small_attn_update_b2": ("small_mlp_attn", dict(n_agents=16, n_polylines=128, batch=2, seed=8, ragged=True, replay=0.3), 0),
-    # TRAJ.K = 3 motion modes, ROLLOUT.POLICY.TOP_K = 3: every replan follows a randomly drawn mode (traj_sam.py:300-313);
-    # the fixture keeps the reference's draws (mode_choice) and the torch seed they came from
-    "small_topk3_b2": ("small_k3", dict(n_agents=16, n_polylines=128, batch=2, seed=12, goal=True, ragged=True, replay=0.3), 0),
-    # binary (agent-pair) conditions: 'v2v_tag' beside the unary types (condition_attns.py:114-188: edges s -> t and t -> s)
-    # MODEL.REL_POS_EDGE_FUNC 'knn': the generator's and the policy's edge sets from the nearest tokens (small caps, so that the k
-    # nearest are a proper subset: 6 prompts, 40 scene tokens, 10 agents / 24 polylines per policy agent)
-    "small_knn_b2": ("small_knn", dict(n_agents=16, n_polylines=128, batch=2, seed=17, goal=True, tags=True, ragged=True), 0),
-    # ... and the same V2V tag on a pair in BOTH directions: the reference's second assignment pass overwrites the first (condition_attns.py:155-162)
-    "small_v2vrev_b2": ("small_v2v", dict(n_agents=16, n_polylines=128, batch=2, seed=16, goal=True, v2v=True, v2v_reverse=True, ragged=True), 0),
-    "small_v2v_b2": ("small_v2v", dict(n_agents=16, n_polylines=128, batch=2, seed=15, goal=True, tags=True, v2v=True, ragged=True), 0),
-    # *.ATTN.LEARNABLE_PE: the relative-PE rows of all six edge sets from learnable FourierEmbedding modules
-    "small_lpe_b2": ("small_lpe", dict(n_agents=16, n_polylines=128, batch=2, seed=13, goal=True, tags=True, ragged=True), 0),
-    # TRAJ.PRED_GMM (state_dim 8: the rollout's velocity sits in columns 6:8) with RANDOM_NOISE_STD > 0 (act_decoder.py:113-115):
-    # the fixture keeps the reference's noise draws (action_noise) and the torch seed they came from
-    # two entries of one action tag on one prompt (the reference's edge matrix is written by assignment: the later one survives)
-    # beside prompts with two DIFFERENT tags (both count in the mean pool)
-    "small_duptag_b2": ("small", dict(n_agents=16, n_polylines=128, batch=2, seed=19, goal=True, tags=True, dup_tags=True, ragged=True), 0),
-    "small_noise_gmm_b2": ("small_noise_gmm", dict(n_agents=16, n_polylines=128, batch=2, seed=17, goal=True, ragged=True, replay=0.3), 0),
-    # TRAJ.PRED_MODE 'cluster' (act_decoder.py:70-74, :103-105: the K anchors from a goal-cluster file through cluster_mlp) and
-    # 'mlp' (:57-58, :90-91: no anchors, no CG_decode, all K modes from motion_head) -- default.py:650's default is 'mlp',
-    # every released yaml says 'anchor'.  Both with K > 1 and TOP_K = K, so the recorded mode draws pick every column block.
-    # OBS_UPDATE.ATTN_UPDATE with SCENE_ENCODER.ATTN.LEARNABLE_PE: the re-attention's two edge sets take their rows from the
-    # scene encoder's learnable embeddings (attn_fusion.py:158-159: a2a_rel_pe_emb / s2s_rel_pe_emb)
-    "small_attn_update_lpe_b2": ("small_attn_lpe", dict(n_agents=16, n_polylines=128, batch=2, seed=24, goal=True, ragged=True, replay=0.3), 0),
-    # LEARNABLE_PE with PE_NUM_FREQ = 16 (the engine's kernel has 64 bands: zero-padded on the host)
-    "small_lpe16_b2": ("small_lpe16", dict(n_agents=16, n_polylines=128, batch=2, seed=25, goal=True, tags=True, ragged=True), 0),
-    # TRAJ.PRED_VEL False (default.py:652's default; every released yaml says True): 3-wide states, no velocity track, the
-    # observation's velocity / acceleration columns from position differences over hist + 2 steps
-    "small_novel_b2": ("small_novel", dict(n_agents=16, n_polylines=128, batch=2, seed=26, goal=True, ragged=True, replay=0.3), 0),
-    # LOSS.ROLLOUT_TRAJ.USE_GOAL_PRED_LOSS False (default.py:440's default): no pred_mlp in the checkpoint, no reconst_pred in the output
-    "small_nogoalloss_b2": ("small_nogoalloss", dict(n_agents=16, n_polylines=128, batch=2, seed=27, goal=True, tags=True, ragged=True), 0),
-    "small_cluster_b2": ("small_cluster", dict(n_agents=16, n_polylines=128, batch=2, seed=21, goal=True, ragged=True, replay=0.3), 0),
-    "small_mlphead_b2": ("small_mlphead", dict(n_agents=16, n_polylines=128, batch=2, seed=22, goal=True, tags=True, ragged=True), 0),
-    # Round 5 (missing 2): the REFERENCE itself at the sizes of the other BASELINE configs -- configs[1] (64 / 512,
-    # unconditional), configs[3] seed 0's two scenes (the ones tests/test_hip_parity.py rolls out), configs[4] (256 agents on a 100 m
-    # square, goal + tag prompts) and its no-truncation variant.  These are the workloads whose cut agents (#25 of cfg3 seed 0, #204 of
-    # the no-truncation scene, #254 of cfg4 seed 0 in round 4) had only the ORACLE to say that an fp32 run tosses a coin there: the
-    # fixtures keep the reference's own per-agent distance from the fp64 oracle (`ref_err_per_agent`), so a GPU test can say which
-    # side the reference's fp32 run landed on.  REPORT_ONLY: a reference run that leaves the fp64 trajectory at such a row is a
-    # finding to record, not a reason to refuse the fixture.
-    "demo_cfg1_seed0": ("demo", dict(n_agents=64, n_polylines=512, batch=1, seed=0), 0),
-    "demo_cfg3_seed0_b2": ("demo", dict(n_agents=128, n_polylines=1024, batch=2, seed=0, goal=True), 0),
-    "demo_cfg4_seed0": ("demo", dict(n_agents=256, n_polylines=1024, batch=1, seed=0, goal=True, tags=True, square=100.0), 0),
-    "demo_cfg4_notrunc": ("demo_notrunc4", dict(n_agents=256, n_polylines=1024, batch=1, seed=0, goal=True, tags=True, square=100.0), 0),
-}
-REPORT_ONLY = {"demo_cfg1_seed0", "demo_cfg3_seed0_b2", "demo_cfg4_seed0", "demo_cfg4_notrunc"}
-SPECS = {"small": SMALL_SPEC, "demo": DEMO_SPEC, "small_mlp": SMALL_SPEC.replace(obs_fusion="mlp"),
-         "small_mlp_attn": SMALL_SPEC.replace(obs_fusion="mlp", obs_attn_update=True),
-         "small_k3": SMALL_SPEC.replace(motion_k=3, rollout_top_k=3),
-         "small_knn": SMALL_SPEC.replace(rel_pos_edge_func="knn", dec_max_neigh=40, pol_max_neigh=24),
-         "small_v2v": SMALL_SPEC.replace(used_v2v_tags=("Following", "Merging", "Overtaking")),
-         "small_lpe": SMALL_SPEC.replace(enc_learnable_pe=True, dec_learnable_pe=True, pol_learnable_pe=True, pe_num_freq=64),
-         "small_noise_gmm": SMALL_SPEC.replace(pred_gmm=True, action_noise_std=0.05),
-         "small_attn_lpe": SMALL_SPEC.replace(obs_attn_update=True, enc_learnable_pe=True, pe_num_freq=64),
-         "small_lpe16": SMALL_SPEC.replace(enc_learnable_pe=True, dec_learnable_pe=True, pol_learnable_pe=True, pe_num_freq=16),
-         "small_novel": SMALL_SPEC.replace(pred_vel=False),
-         "small_nogoalloss": SMALL_SPEC.replace(use_goal_pred_loss=False),
-         "small_cluster": SMALL_SPEC.replace(k_pred_mode="cluster", motion_k=3, rollout_top_k=3),
-         "small_mlphead": SMALL_SPEC.replace(k_pred_mode="mlp", motion_k=2, rollout_top_k=2),
-         # tests/test_round2_gpu.py::test_no_truncation_variant's spec for configs[4]: caps >= every candidate count (256 + 1024)
-         "demo_notrunc4": DEMO_SPEC.replace(dec_max_neigh=1280, pol_max_neigh=max(DEMO_SPEC.pol_max_neigh, 1280))}
-TOPK_SEED = 777   # torch.manual_seed before a forward whose rollout draws modes
+from golden_cases import (GOLD, digest, FULL_CASES, REPORT_ONLY, SPECS, TOPK_SEED, GOAL_CASE, make_pair_metric_inputs, make_world_inputs,  # noqa: E402,F401
+                          format_inputs)
 
 
 def ref_overrides(spec: ModelSpec):
@@ -288,8 +187,6 @@ def gen_full():
                             label=np.array("reference Python + builder stand-ins for torch_cluster/torch_geometric"))
 
 
-GOAL_CASE = ("small_goal_heads_b2", SMALL_SPEC.replace(goal_pred_k=4),
-             dict(n_agents=16, n_polylines=128, batch=2, seed=14, goal=True, ragged=True), 0)
 
 
 def gen_goal_heads():
@@ -444,25 +341,6 @@ def gen_demo_map(scene: str = "scene_1", map_name: str = "waymo_train_1", compre
     print("demo map written:", map_name, "; tls rows", t.num_rows)
 
 
-def make_world_inputs(seed: int, n_scenes: int = 3, n_agents: int = 7, T: int = 80):
-    """Seeded inputs of the world-frame output step: per (replica, agent) a rolled-out trajectory in the agent-init frame,
-    the init pose in the scene-centre frame, and a centre -> world matrix at Waymo-like coordinates.  A few headings sit
-    next to the +-pi cut on purpose."""
-    g = np.random.default_rng(seed)
-    n = n_scenes * n_agents
-    step = g.normal(0.8, 0.4, (n, T, 1)) * np.stack([np.ones((n, T)), 0.1 * g.normal(size=(n, T))], -1)
-    xy = np.cumsum(step, 1)
-    h = np.cumsum(0.02 * g.normal(size=(n, T)), 1)
-    h[::5] += np.pi - 0.01
-    traj = np.concatenate([xy, np.sin(h)[..., None], np.cos(h)[..., None]], -1).astype(np.float32)
-    init_pos = g.uniform(-150, 150, (n, 2)).astype(np.float32)
-    init_head = g.uniform(-np.pi, np.pi, (n, 1)).astype(np.float32)
-    a = g.uniform(-np.pi, np.pi)
-    tf = np.array([[np.cos(a), -np.sin(a), 3418.7], [np.sin(a), np.cos(a), -1650.2], [0, 0, 1]], np.float32)
-    return dict(traj=traj, init_pos=init_pos, init_head=init_head, tf=tf, batch_ids=np.repeat(np.arange(n_scenes), n_agents),
-                object_ids=np.tile(np.arange(100, 100 + n_agents), n_scenes))
-
-
 def gen_world():
     """tests/golden/ref_world_trajs.npz: the reference's own obtain_rollout_trajs_in_world (rollout/gpu_utils.py:230-281)
     on seeded inputs (fp32, as the rollout hands them over), and the oracle (oracle/world_oracle.py) checked on the way."""
@@ -491,7 +369,6 @@ def gen_world():
     print("ref_world_trajs written:", ref.shape)
 
 
-make_pair_metric_inputs = synth.make_pair_metric_inputs
 
 
 def gen_pair_metric():
@@ -534,32 +411,6 @@ def gen_pair_metric():
     out["after_updates"] = np.array(scal, np.float64)     # [2 updates][ade, fde, min_ade, min_fde, rollout_ade]
     np.savez_compressed(os.path.join(GOLD, "ref_pair_metric.npz"), **out)
     print("ref_pair_metric written:", out["after_updates"])
-
-
-def format_inputs(scene: str = "scene_1", t0: int = 10):
-    """The common input of the formatter fixtures (shared with tests/test_format_ref_cpu.py): the demo scene's track table in
-    the frame of its ego at ``t0`` (what a scene-centric trajdata batch holds), the agents' types, the decoded map lanes."""
-    import lzma
-    from prosim_amd import formatting as fmt, vecmap as vm
-    g = np.load(os.path.join(GOLD, f"demo_{scene}_agent_table.npz"))
-    tr = fmt.tracks_from_table({k: g[k] for k in g.files if k != "origin"})
-    f = fmt.ego_frame(tr, t0)
-    tre = fmt.tracks_in_frame(tr, f)
-    ego = list(tr["agent_ids"]).index("ego")
-    order = [ego] + [i for i in range(len(tr["agent_ids"])) if i != ego]
-    meta = fmt.agent_types_from_scene_metadata(os.path.join(GOLD, f"demo_{scene}_metadata.dill"))
-    types = np.array([meta[a] for a in tr["agent_ids"]], np.int64)
-    origin = g["origin"].astype(np.float64)
-    world = np.array([f[0] + origin[0], f[1] + origin[1], f[2]])
-    name = {"scene_1": "demo_waymo_train_1_map.pb", "scene_0": "demo_waymo_train_0_map.pb.xz"}[scene]
-    with open(os.path.join(GOLD, name), "rb") as fh:
-        pb = fh.read()
-    if name.endswith(".xz"):
-        pb = lzma.decompress(pb)
-    tl = np.load(os.path.join(GOLD, f"demo_{scene}_tls_table.npz"))
-    tls = vm.tls_at(tl["lane_id"], tl["scene_ts"], tl["status"], t0)
-    z = float(g["z"][(g["agent_id"] == "ego") & (g["scene_ts"] == t0)][0]) if "z" in g.files else 0.0
-    return dict(tracks=tre, order=order, types=types, world=world, z=z, lanes=vm.decode_vector_map(pb)["lanes"], tls=tls)
 
 
 def gen_format(scene: str = "scene_1", t0: int = 10):

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from gen_golden import format_inputs, GOLD  # noqa: E402
+from golden_cases import format_inputs, GOLD  # noqa: E402
 from prosim_amd import formatting as fmt, vecmap as vm  # noqa: E402
 from prosim_amd.spec import DEMO_SPEC  # noqa: E402
 

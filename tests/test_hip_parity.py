@@ -17,7 +17,7 @@ import torch
 from prosim_amd import synth, weights
 from prosim_amd.spec import DEMO_SPEC, SMALL_SPEC
 from oracle import prosim_oracle as orc
-from gen_golden import FULL_CASES, REPORT_ONLY, SPECS, digest
+from golden_cases import FULL_CASES, REPORT_ONLY, SPECS, digest
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")

@@ -9,8 +9,8 @@ import torch
 from prosim_amd import synth, weights
 from prosim_amd.spec import SMALL_SPEC
 from oracle import prosim_oracle as orc
-from oracle.ref_harness import make_batch
-from gen_golden import FULL_CASES, SPECS
+from oracle.ref_batch import make_batch
+from golden_cases import FULL_CASES, SPECS
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")

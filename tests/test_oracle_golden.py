@@ -9,7 +9,7 @@ import torch
 from prosim_amd import synth, weights
 from prosim_amd.spec import DEMO_SPEC, SMALL_SPEC
 from oracle import prosim_oracle as orc
-from gen_golden import FULL_CASES, SPECS, digest
+from golden_cases import FULL_CASES, SPECS, digest
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
@@ -113,7 +113,7 @@ def test_pair_metric_oracle_vs_reference_fixture():
     (metrics/motion_pred.py:111-199 over loss/loss_func.py:215-313) produced from the same seeded inputs: the five logged
     scalars per batch, the accumulated values after two updates, and the chained trajectories bit for bit."""
     import torch
-    from gen_golden import make_pair_metric_inputs, digest
+    from golden_cases import make_pair_metric_inputs, digest
     from oracle import metric_oracle as mo
     g = np.load(os.path.join(GOLD, "ref_pair_metric.npz"))
     keys = ("ade", "fde", "min_ade", "min_fde", "rollout_ade")

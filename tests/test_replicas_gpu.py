@@ -12,7 +12,7 @@ from prosim_amd import synth, weights
 from prosim_amd.engine import Engine
 from prosim_amd.postprocess import replicate_scene
 from prosim_amd.spec import SMALL_SPEC
-from gen_golden import SPECS
+from golden_cases import SPECS
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")

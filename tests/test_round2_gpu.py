@@ -15,7 +15,7 @@ from prosim_amd.spec import DEMO_SPEC, SMALL_SPEC
 from oracle import prosim_oracle as orc
 from oracle import metric_oracle as mo
 from parity_table import per_agent, record, closed_loop_gate
-from gen_golden import make_pair_metric_inputs
+from golden_cases import make_pair_metric_inputs
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -215,7 +215,7 @@ def test_pair_metric_device_vs_oracle():
 def test_goal_heads_vs_reference_fixture():
     """MODEL.DECODER.GOAL_PRED (decoder/base.py:22-58): goal_prob / goal_point of the reference's own decoder."""
     from prosim_amd.engine import Engine
-    from gen_golden import GOAL_CASE, digest
+    from golden_cases import GOAL_CASE, digest
     name, spec, kw, wseed = GOAL_CASE
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", f"ref_standins_{name}.npz"))
     w = weights.init_weights(spec, wseed)
@@ -246,8 +246,8 @@ def test_top_k_draw_replays_the_reference_stream():
     """ROLLOUT.POLICY.TOP_K = 3 through the registry-level model: ProSimHip draws the modes with the reference's own
     torch.topk / torch.randint calls, so the fixture's seed reproduces the fixture's draws -- and its trajectories."""
     from prosim_amd import modules
-    from oracle import ref_harness as rh
-    from gen_golden import FULL_CASES, SPECS, TOPK_SEED
+    from oracle import ref_batch as rh
+    from golden_cases import FULL_CASES, SPECS, TOPK_SEED
     sname, kw, wseed = FULL_CASES["small_topk3_b2"]
     spec = SPECS[sname]
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_standins_small_topk3_b2.npz"))
@@ -330,7 +330,7 @@ def test_learnable_rel_pe_vs_oracle(shape):
     pinned to the reference by tests/golden/ref_standins_small_lpe_b2.npz, which test_hip_parity checks as well).
     'split_s2s': >= 2048 scene tokens, the s2s layers take the split launches with 128-column rows; 'policy_only': the
     flags are independent per part of the model."""
-    from gen_golden import SPECS
+    from golden_cases import SPECS
     from prosim_amd.engine import Engine
     spec = SPECS["small_lpe"]
     if shape == "policy_only":
@@ -396,7 +396,7 @@ def test_pair_conditions_vs_oracle(shape):
     condition layers' graph, pooled with the unary keys that share an edge.  'hub': one prompt is the target of 40 pairs
     (two 32-edge tiles into one destination); masked rows and tag values outside the used list make no edge.  The oracle
     is pinned to the reference by tests/golden/ref_standins_small_v2v_b2.npz (test_hip_parity checks the engine on it)."""
-    from gen_golden import SPECS
+    from golden_cases import SPECS
     from prosim_amd.engine import Engine
     spec = SPECS["small_v2v"]
     w = weights.init_weights(spec, 0)

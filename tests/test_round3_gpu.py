@@ -10,8 +10,8 @@ import torch
 from prosim_amd import synth, weights
 from prosim_amd.spec import DEMO_SPEC, SMALL_SPEC
 from oracle import prosim_oracle as orc
-from oracle import ref_harness as rh
-from gen_golden import FULL_CASES, SPECS, GOLD
+from oracle import ref_batch as rh
+from golden_cases import FULL_CASES, SPECS, GOLD
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4

@@ -8,7 +8,7 @@ import torch
 from prosim_amd import synth, weights
 from prosim_amd.spec import DEMO_SPEC, SMALL_SPEC
 from oracle import prosim_oracle as orc
-from gen_golden import SPECS
+from golden_cases import SPECS
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
