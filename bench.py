@@ -52,6 +52,52 @@ def algorithmic_flops_chain(A: int, e_a2p: float, e_m2p: float, layers: int) -> 
     return layers * (per(e_a2p) + per(e_m2p))
 
 
+def algorithmic_bytes_chain(A: int, n_src_a2p: int, n_src_m2p: int, e_a2p: float, e_m2p: float, layers: int) -> dict:
+    """Bytes one policy launch HAS to move: every layer's weights once (what the kernel streams per layer: the pre-split
+    fp16 hi | lo fragments + small vectors, 960 KB), the k | v rows of every source token once per layer (k as split fp16 512 B + v as fp32
+    512 B), the 32-byte geometry record of every edge once (the six layers of a set re-read the same records: a workgroup's share stays in
+    its XCD's L2), and the destination rows in and out.  Gathers that revisit a source row (62 a2p / 160 m2p edges per destination) are
+    served by L2 and do not count either."""
+    w = 2 * layers * 960 * 1024
+    kv_a = layers * n_src_a2p * 1024
+    kv_m = layers * n_src_m2p * 1024
+    rec = int(e_a2p + e_m2p) * 32
+    xio = 2 * A * 128 * 4
+    return {"weights": w, "kv_rows_a2p": kv_a, "kv_rows_m2p": kv_m, "geometry_records": rec, "rows_in_out": xio, "total": w + kv_a + kv_m + rec + xio}
+
+
+def newest_pmc_json():
+    """profiles/r??_pmc_policy_chain.json of the latest round (tools/make_pmc_json.py): the offline counter passes behind roofline.traffic."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_policy_chain.json")))
+    return files[-1] if files else None
+
+
+def pin_to_gpu_numa_node(dev_index: int):
+    """N > 1 ranks on one node: keep this rank's host threads (its graph launches: one every ~0.75 ms per engine) on the CPUs of its GPU's NUMA
+    node -- eight ranks x four engines launching from anywhere contend for the same cores and cross the socket link.
+    Best effort: the PCI address of the device -> /sys/bus/pci/devices/<addr>/numa_node -> that node's cpulist; returns what it did."""
+    try:
+        pr = torch.cuda.get_device_properties(dev_index)
+        addr = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+        with open(f"/sys/bus/pci/devices/{addr}/numa_node") as f:
+            node = int(f.read().strip())
+        if node < 0:
+            return {"numa_node": node, "pinned": False, "why": "the platform reports no NUMA node for the device"}
+        with open(f"/sys/devices/system/node/node{node}/cpulist") as f:
+            cpus = set()
+            for part in f.read().strip().split(","):
+                a, _, b = part.partition("-")
+                cpus.update(range(int(a), int(b or a) + 1))
+        cpus &= os.sched_getaffinity(0)
+        if not cpus:
+            return {"numa_node": node, "pinned": False, "why": "none of the node's CPUs is in this process's affinity mask"}
+        os.sched_setaffinity(0, cpus)
+        return {"numa_node": node, "pinned": True, "cpus": len(cpus), "pci": addr}
+    except Exception as ex:   # (an unknown sysfs layout must not cost the run)
+        return {"pinned": False, "why": f"{type(ex).__name__}: {ex}"}
+
+
 def executed_flops_chain(A: int, e_a2p: float, e_m2p: float, layers: int) -> float:
     """FLOPs the factored kernel actually executes: per destination 26 D^2 + 2 D^2 (q~) + 2 D^2
     (to_v_r fold); per edge 2*(8*128) score + 2*(8*128) aggregate + 4 D."""
@@ -179,6 +225,7 @@ def main():
     backend = os.environ.get("PS_BENCH_BACKEND", "nccl")
     dev_index = 0 if os.environ.get("PS_BENCH_SAME_DEVICE") else local_rank
     torch.cuda.set_device(dev_index)
+    numa = pin_to_gpu_numa_node(dev_index) if (world > 1 and "LOCAL_RANK" in os.environ and not os.environ.get("PS_BENCH_NO_PIN")) else None
     # test hook: PS_BENCH_FORCE_DIST=1 takes the N > 1 code path (process group, RCCL gather at metric-compute time) with ONE
     # rank, so the collective path can be exercised with the real nccl backend on a 1-GPU box
     multi = world > 1 or bool(os.environ.get("PS_BENCH_FORCE_DIST"))
@@ -325,7 +372,8 @@ def main():
         mine = torch.tensor([local_ms, 1e3 * (time.perf_counter() - t2)], device=red_dev, dtype=torch.float64)
         allv = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allv, mine)
-        per_rank = {"local_ms_per_step_no_collective": [float(v[0]) for v in allv], "metric_all_gather_ms": [float(v[1]) for v in allv],
+        per_rank = {"host_affinity_rank0": numa,
+                    "local_ms_per_step_no_collective": [float(v[0]) for v in allv], "metric_all_gather_ms": [float(v[1]) for v in allv],
                     "note": "measured after the timed region; a rank without a scene reports 0 for its step time"}
     # launch durations of the dominant kernel while the pipeline is full: the same loop again for 2 rounds of the engines with
     # an event pair around every policy launch (such rollouts are launched eagerly -- events do not survive graph replay
@@ -460,13 +508,15 @@ def main():
         # HBM-side traffic of the launch comes from separate rocprofv3 --pmc passes (tools/gpu_round_profile.sh; counters
         # cannot be read from inside this process): offline, valid for the default workload only, stamped with its source
         traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", "r05_pmc_policy_chain.json")
-        if os.path.exists(pmc) and S == 8 and args.config == 2:
+        pmc = newest_pmc_json()
+        if pmc and S == 8 and args.config == 2:
             with open(pmc) as f:
                 pj = json.load(f)
             if pj.get("chain_rows") == chain_rows:
                 traffic = pj["hbm_bytes_per_launch"]
-                traffic_src = {"file": "profiles/r05_pmc_policy_chain.json", "git": pj.get("git"), "measured": "offline rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), not in this run"}
+                traffic_src = {"file": os.path.relpath(pmc, ROOT), "git": pj.get("git"), "measured": "offline rocprofv3 --pmc passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), not in this run"}
+        Mv_b = int(np.asarray(scene["map_mask"]).any(-1).sum())   # map tokens with a valid point: the m2p sources
+        alg_bytes = algorithmic_bytes_chain(A, A, Mv_b, float(ec[4]), float(ec[5]), spec.pol_layers)
         achieved = fl_alg / (ms_launch * 1e-3) / 1e12
         kern = (f"k_chain16<8, policy> (12 fused attention layers per launch, {chain_rows} rows per 8-wave workgroup, {n_wg} workgroups)" if c16
                 else f"k_attn_chain (policy: 12 fused attention layers per launch; {chain_rows or 2} rows per workgroup)")
@@ -498,6 +548,8 @@ def main():
                                  "What bounds the launch: DESIGN.md section 0a / 4 (edge phase: the dependent LDS / MFMA / cross-lane chain of a 16-edge tile at two waves per SIMD "
                                  "over a VALU floor that round 5 cut from 448 to 348 static instructions per tile -- 51.6 M -> 41.1 M VALU instructions per launch for 5 % of its time, "
                                  "so issue count is no longer the first limiter; node phase: the dependent stage chain of a 16-row layer -- GEMM, LDS, barrier, epilogue, 17 barriers per layer; with every weight-fragment load an L1 hit it is only 10 % faster).",
+                         "algorithmic_bytes": alg_bytes["total"], "algorithmic_bytes_parts": alg_bytes,
+                         "traffic_over_algorithmic_bytes": (traffic / alg_bytes["total"]) if traffic else None,
                          "algorithmic_flops_per_launch": fl_alg,
                          "executed_mfma_flops_per_launch": fl_mfma,
                          "executed_mfma_tflops": (fl_mfma / (ms_launch * 1e-3) / 1e12) if fl_mfma else None,
