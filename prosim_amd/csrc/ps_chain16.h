@@ -461,6 +461,7 @@ constexpr size_t C16_QA_BYTES = 0;
 constexpr int C16_QH = 100, C16_QSL = 8 * C16_QH + 8;
 constexpr size_t C16_QA_BYTES = (size_t)16 * C16_QSL * 4;
 #endif
+constexpr float C16_TAU = 6.f;   // (-DPS_C16_LAZY experiment only: a class's sums are rescaled when a score exceeds the reference by more than 2^6)
 constexpr int C16_CTR_INTS = 52;   // [0] row counter, [1..16] rows in queue order, [17..32] their edge counts, [36..51] their first edges
 template <int NWV>
 constexpr size_t c16_lds_bytes() {
@@ -789,7 +790,9 @@ __device__ __forceinline__ void c16_edge_body(const ChainStep* __restrict__ stp,
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) ak[ks] = str[4 * (ks ^ sra)];
         c16_wait_lgkm0();
+#ifndef PS_C16_ABL_NOKLO
         c16_blds16x4(kp, rs_k, 256u, stg_lds);
+#endif
         prefetch(tn);   // the next tile's records leave now (past the row's end: its last edge again, unused)
         floatx4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -820,19 +823,23 @@ __device__ __forceinline__ void c16_edge_body(const ChainStep* __restrict__ stp,
 #pragma unroll
         for (int ks = 0; ks < 3; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[ks], bq[ks], acc, 0, 0, 0);
         // ---- k lo halves
+#ifndef PS_C16_ABL_NOKLO   // (timing experiment: no wait for the lo halves, the stale hi fragments twice; wrong results)
         c16_wait_vm0();
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) ak[ks] = str[4 * (ks ^ sra)];
         c16_wait_lgkm0();
+#endif
         if (tn < deg) {   // the next tile's source rows arrived with the prefetch: publish them, start the DMA of its k hi halves
           if (lane < 16) Ss[16 * (sb ^ 1) + lane] = nsrc;
           kaddr(sb ^ 1);
           c16_blds16x4(kp, rs_k, 0u, stg_lds);
         }
+#ifndef PS_C16_ABL_NOSCORE2   // (timing experiment: the second half of the score MFMAs dropped; wrong results)
 #pragma unroll
         for (int ks = 0; ks < 3; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl[ks], bq[ks], acc, 0, 0, 0);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) acc2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ak[ks], bk[ks], acc2, 0, 0, 0);
+#endif
         acc += acc2;
 #pragma unroll
         for (int r4 = 0; r4 < 4; ++r4) {
@@ -859,8 +866,23 @@ __device__ __forceinline__ void c16_edge_body(const ChainStep* __restrict__ stp,
 #endif
       // ---- online softmax over the tile (torch_geometric.utils.softmax: max-shift, exp, / (sum + 1e-16))
       float tmax = fmaxf(fmaxf(sreg[0], sreg[1]), fmaxf(sreg[2], sreg[3]));
-      const float m_new = kq_max3(tmax, m_run);   // max(m_run, the tile's maximum over the four kq lanes); finite: the tile has at least one edge
+#ifdef PS_C16_ABL_NOSOFT   // (timing experiment: no cross-lane maximum; wrong results)
+      const float m_cand = fmaxf(tmax, m_run);
+#else
+      const float m_cand = kq_max3(tmax, m_run);   // max(m_run, the tile's maximum over the four kq lanes); finite: the tile has at least one edge
+#endif
       const bool fresh = m_run == -INFINITY;   // this head's first tile of the parity class: its sums are still zero
+      // Round 6, measured and NOT adopted (-DPS_C16_LAZY builds it): moving the reference point of a class's sums lazily -- while a tile's
+      // maximum stays within C16_TAU (in log2 units) above the reference, keep it, let the tile's probabilities reach 2^C16_TAU and rescale
+      // nothing.  Any head's maximum moving (8 heads: 99 % of a class's second tiles, 83 % of its fifth) costs the wave 8 cross-lane
+      // broadcasts and 28 multiplies, 3.7 % of the policy launch by ablation; the lazy rule took the launch from 0.665 to 0.652 ms -- and, being
+      // another rounding of the same sums, re-rolled configs[3] seed 0's near-cut agent #25 (1.4e-6 rad from a +-pi cut) onto the other
+      // side.  Two per cent of one kernel do not buy a row of the parity table (profiles/r06_f_policy_launch_ablation.txt).
+#ifdef PS_C16_LAZY   // (experiment, NOT the product's rule: see the comment above)
+      const float m_new = (fresh || m_cand > m_run + C16_TAU) ? m_cand : m_run;
+#else
+      const float m_new = m_cand;
+#endif
       // (v_exp_f32 itself: libm's exp2f wraps it in a range check + ldexp for results below 2^-126, which max-shifted
       // probabilities and scales do not need -- such a term adds nothing to sums that hold a 1)
       const float scale = fresh ? 0.f : __builtin_amdgcn_exp2f(m_run - m_new);
@@ -876,14 +898,21 @@ __device__ __forceinline__ void c16_edge_body(const ChainStep* __restrict__ stp,
 #pragma unroll
         for (int r4 = 0; r4 < 4; ++r4) Pt[(4 * kq + r4) * 8 + mi] = pr[r4];
       }
+#ifndef PS_C16_ABL_NOSOFT
       psum = kq_sum(psum);
+#endif
       l_run = l_run * scale + psum;
       m_run = m_new;
       // what is already accumulated shrinks by the head's scale: accumulator row 4 (lane >> 4) + r belongs to head
       // (4 (lane >> 4) + r) & 7; the a_v columns of this lane to head hv.  Skipped while no head's maximum moves
       // (most tiles after a row's first few).
       // (nor on a class's first tile: scaling zero sums by zero is the identity)
+#ifdef PS_C16_ABL_NORESCALE   // (timing experiment: the accumulated sums are never rescaled; wrong results)
+      if (false) {
+#else
       if (__any(scale != 1.f && !fresh)) {
+#endif
+#ifdef PS_C16_RESCALE_R5   // (the round-5 form, for the A/B: eight ds_bpermute round trips, 7 selects, 28 multiplies -- same bits)
         float scl[8];
 #pragma unroll
         for (int h = 0; h < 8; ++h) scl[h] = __shfl(scale, h);
@@ -895,6 +924,23 @@ __device__ __forceinline__ void c16_edge_body(const ChainStep* __restrict__ stp,
 #pragma unroll
         for (int h = 1; h < 8; ++h) sh = (hv == h) ? scl[h] : sh;
         av.x *= sh; av.y *= sh; av.z *= sh; av.w *= sh;
+#else
+        // Round 6: head h's scale sits in lane h (mi = h, kq = 0) -- v_readlane_b32 into scalar registers instead of eight cross-lane
+        // round trips through the LDS crossbar; the a_v lanes take theirs with ONE of those (it flies under the multiplies); the
+        // accumulators two rows per v_pk_mul_f32 (natural lane order: no op_sel).  Same values, same products: the bits do not change.
+        float scl[8];
+#pragma unroll
+        for (int h = 0; h < 8; ++h) scl[h] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(scale), h));
+        const float sh = __shfl(scale, hv);
+        const bool up = kq & 1;
+        const f32x2 s01 = {up ? scl[4] : scl[0], up ? scl[5] : scl[1]}, s23 = {up ? scl[6] : scl[2], up ? scl[7] : scl[3]};
+#pragma unroll
+        for (int cb = 0; cb < 6; ++cb) {
+          const f32x2 lo = f32x2{ar[cb][0], ar[cb][1]} * s01, hi = f32x2{ar[cb][2], ar[cb][3]} * s23;
+          ar[cb] = floatx4{lo.x, lo.y, hi.x, hi.y};
+        }
+        av.x *= sh; av.y *= sh; av.z *= sh; av.w *= sh;
+#endif
       }
       // ---- a_r[h][c] += sum_e p_e,h r~_e[c] on the matrix cores (16x16x16): A = (p hi | p lo) x head, straight from this
       //      lane's probabilities (row 4 kq + j of column mi = edge 4 kq + j of head mi & 7), B = the feature tile read back
@@ -1207,8 +1253,13 @@ __device__ __forceinline__ void c16_lat_main(const ChainStep* __restrict__ stp, 
     }
     // ---- online softmax over the tile (as c16_edge_body)
     float tmax = fmaxf(fmaxf(sreg[0], sreg[1]), fmaxf(sreg[2], sreg[3]));
-    const float m_new = kq_max3(tmax, m_run);
+    const float m_cand = kq_max3(tmax, m_run);
     const bool fresh = m_run == -INFINITY;
+#ifdef PS_C16_LAZY   // (experiment: c16_edge_body)
+    const float m_new = (fresh || m_cand > m_run + C16_TAU) ? m_cand : m_run;
+#else
+    const float m_new = m_cand;
+#endif
     const float scale = fresh ? 0.f : __builtin_amdgcn_exp2f(m_run - m_new);
     float psum = 0.f;
     float pr[4];
