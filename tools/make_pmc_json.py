@@ -1,4 +1,4 @@
-"""gpurun_out/<tag>_pmc_chain16.txt (tools/gpu_pmc_chain16.sh) -> profiles/r05_pmc_policy_chain.json: the HBM-side bytes of
+"""gpurun_out/<tag>_pmc_chain16.txt (tools/gpu_pmc_chain16.sh) -> profiles/<round>_pmc_policy_chain.json (round = the tag up to its first underscore): the HBM-side bytes of
 one k_chain16 policy launch behind bench.py's roofline.traffic, stamped with its source.
 usage: python tools/make_pmc_json.py <tag> <rows> <git hash>"""
 import json, os, re, sys
@@ -24,6 +24,7 @@ out = {
             "through global scratch) 0.28 GB of which 77 MB were writes.",
     "counters": {k: v[1] for k, v in vals.items()},
 }
-with open(os.path.join(ROOT, "profiles", "r05_pmc_policy_chain.json"), "w") as f:
+rnd = tag.split("_")[0]
+with open(os.path.join(ROOT, "profiles", f"{rnd}_pmc_policy_chain.json"), "w") as f:
     json.dump(out, f, indent=1)
 print(json.dumps({k: out[k] for k in ("chain_rows", "fetch_size_kb_avg", "write_size_kb_avg", "hbm_bytes_per_launch")}))
