@@ -1,5 +1,5 @@
-"""Closed-loop parity numbers, collected by the -m gpu tests and written as ONE JSON table: gpurun_out/r05_parity.json on
-the GPU box (merged back by gpurun), copied to profiles/r05_parity.json for the record.  Per entry: replan-0 max error
+"""Closed-loop parity numbers, collected by the -m gpu tests and written as ONE JSON table: gpurun_out/r06_parity.json on
+the GPU box (merged back by gpurun), copied to profiles/r06_parity.json for the record.  Per entry: replan-0 max error
 (open loop), per-agent closed-loop max error of the trajectories: median / 99th percentile / max, the fraction of agents
 within 1e-4, and -- where the test computed it -- the fp32 floor (fp32 oracle against the fp64 oracle on the same scene)."""
 import json
@@ -30,7 +30,7 @@ def known_cut_agents(workload: str) -> set:
         return set(json.load(f).get(workload, []))
 
 
-PARITY_TABLE = "r05_parity.json"   # the table of this round: gpurun_out/ on the GPU box, profiles/ for the record
+PARITY_TABLE = "r06_parity.json"   # the table of this round: gpurun_out/ on the GPU box, profiles/ for the record
 
 
 def closed_loop_gate(workload: str, d: np.ndarray, tol: float = 1e-4):
