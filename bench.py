@@ -195,6 +195,12 @@ def run_empty_rank(args, spec, n_scenes, world, backend, dev_index, multi):
     dist.destroy_process_group()
 
 
+def trace(msg: str):
+    """PS_BENCH_TRACE=1: progress marks on stderr (which section of rank 0's extra measurements a fault belongs to)."""
+    if os.environ.get("PS_BENCH_TRACE"):
+        print(f"[bench rank {os.environ.get('RANK', '0')}] {msg}", file=sys.stderr, flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -378,6 +384,7 @@ def main():
     # launch durations of the dominant kernel while the pipeline is full: the same loop again for 2 rounds of the engines with
     # an event pair around every policy launch (such rollouts are launched eagerly -- events do not survive graph replay
     # on ROCm 7.2 -- at ~1 ms of host time each against a 6 ms step), read after the last one
+    trace("timed region done; event-timed policy launches")
     for e_ in engines:
         e_.enable_policy_events(True)
     for _ in range(2 * n_fl):
@@ -401,16 +408,19 @@ def main():
     if rank == 0:
         # dominant kernel: the fused policy attention chain (one launch per replan), timed with HIP
         # events on the engine's own stream
+        trace("rank-0 extras: policy kernel alone")
         ms_chain = eng.time_policy_kernel(3)
         ec = eng.get("edge_counts")
         ms_roll, stages = eng.time_rollout(1, 5)
         # one rollout alone on the GPU in the engine's latency mode (2 rows per workgroup, two workgroups per CU)
+        trace("latency mode")
         eng.set_chain_rows(0)
         ms_roll_lat, stages_lat = eng.time_rollout(1, 5)
         ms_chain_lat = eng.time_policy_kernel(3)
         eng.set_chain_rows(chain_rows)
         # single-scene latency of the same workload (S = 1), same engine, same run, latency mode
         eng.set_chain_rows(0)
+        trace("single scene")
         eng.set_scene(parts[0])
         eng.rollout(); eng.sync()
         graph_nodes_single = eng.graph_nodes
@@ -421,6 +431,7 @@ def main():
         # 128 agents are 128 workgroups on 256 CUs (two of them fit a CU), so rollouts in flight fill the rest of the chip;
         # beyond two in flight the host's graph launches (one per ~2 ms rollout) become the limit
         pipe1 = {}
+        trace("single scene pipelined")
         for nfl1 in (2, 6):
             es1 = [Engine(spec, w, device=dev_index) for _ in range(nfl1)]
             for e_ in es1:
@@ -439,6 +450,7 @@ def main():
         # the Sim-Agents shape: ONE scene x 32 replicas, parallel_rollout_batch (rollout/gpu_utils.py:179-228).
         # ps_set_replicas computes the scene encoder and the generator once and keeps the map once; the reference's way
         # (the 32-fold replicated batch through the whole path) runs on the same engine beside it.
+        trace("replicas")
         MREP = 32
         eng.set_chain_rows(0)
         eng.set_replicas(MREP)
@@ -459,6 +471,7 @@ def main():
             eng.world_trajs(tf, world_buf.data_ptr())
         eng.sync()
         ms_world = 1e3 * (time.perf_counter() - t_w) / 20
+        trace("replicated batch")
         eng.set_replicas(1)
         eng.set_scene(replicate_scene(parts[0], MREP))
         ms_tiled, st_tiled = eng.time_rollout(1, 3)
@@ -481,6 +494,7 @@ def main():
         streaming = {"workload": f"stream of NEW {S}-scene batches (host arrays -> ps_set_scene -> rollout -> traj / vel read back), RolloutPipeline, "
                                  "16 rows per workgroup from depth 2", "agent_steps_per_s_by_depth": {}, "ms_per_batch_by_depth": {}}
         for depth in (1, 2, 3, 4):
+            trace(f"streaming depth {depth}")
             with RolloutPipeline(spec, w, device=dev_index, depth=depth) as pipe:
                 for _ in pipe.run(new_batches[:depth]):
                     pass
@@ -491,6 +505,7 @@ def main():
             streaming["agent_steps_per_s_by_depth"][str(depth)] = n_b * A * spec.max_steps / dt_s
             streaming["ms_per_batch_by_depth"][str(depth)] = 1e3 * dt_s / n_b
         streaming["agent_steps_per_s"] = max(streaming["agent_steps_per_s_by_depth"].values())
+        trace("tiles of the last replan")
         fl_alg = algorithmic_flops_chain(A, float(ec[4]), float(ec[5]), spec.pol_layers)
         # per-destination degrees of the last replan's edge sets -> 16-edge tiles the edge phase walked
         eng.set_chain_rows(chain_rows)
@@ -585,6 +600,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(spec, w, parts[0])
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
+        trace("line")
         print(json.dumps(out), flush=True)
     eng.close()
     if multi:

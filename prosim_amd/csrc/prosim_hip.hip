@@ -84,6 +84,14 @@ struct DevBuf {   // owning device allocation: freed by release() or at scope ex
     size_t c = std::max<size_t>(count, 16);
     if (hipMalloc((void**)&p, c * sizeof(T)) != hipSuccess) return -1;
     n = c;
+#ifdef PS_EXPERIMENTS   // (round 6: PS_POISON_ALLOC=<byte> fills every new device buffer with that byte -- a kernel that reads a buffer before anything
+    // wrote it then finds 0x7f7f7f7f-class indices / 3e38-class floats instead of whatever the block held before: tools/gpu_r6_poison_alloc.sh)
+    if (const char* pz = getenv("PS_POISON_ALLOC")) {   // (hipMemset runs on the null stream and does not wait: drain the device around it)
+      (void)hipDeviceSynchronize();
+      (void)hipMemset(p, (int)strtol(pz, nullptr, 0) & 0xff, c * sizeof(T));
+      (void)hipDeviceSynchronize();
+    }
+#endif
     return 0;
   }
   void release() {
@@ -1029,6 +1037,9 @@ extern "C" int ps_create(const ps_config* cfg, int32_t n_tensors, const char* co
 #undef PS_ATTR
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_chain<1, 4, 3, false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_chain<1, 4, 3, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  // (round 6: the weight uploads above went through the null stream, which is not ordered against the engine's non-blocking stream --
+  // the engine's first launch must find them complete whatever the runtime's hipMemcpy waits for: drain the device once, here)
+  if (hipDeviceSynchronize() != hipSuccess) { ps_destroy(e); return fail(PS_E_HIP, "device synchronisation after the weight upload failed"); }
   *out = e;
   return PS_OK;
 }
@@ -1095,7 +1106,9 @@ int check_c16_offsets(size_t token_rows, std::initializer_list<size_t> edge_caps
       return fail(PS_E_ARG, "an edge set's capacity exceeds the fused chain's 32-bit record offsets (edges * 32 bytes must stay below 2^31: < 67 108 863 edges per set)");
   return 0;
 }
-int edge_alloc(EdgeSet& s, int nq, size_t cap_edges, int maxdeg) {
+// up to this many queries a search with geometry records is ONE launch of a workgroup per query (k_radius_geo, launch_radius below)
+constexpr int SEARCH_WG_MAX_Q = 256;
+int edge_alloc(EdgeSet& s, int nq, size_t cap_edges, int maxdeg, hipStream_t st) {
   s.nq = nq;
   s.cap_edges = cap_edges;
   s.maxdeg = std::max(1, maxdeg);
@@ -1105,11 +1118,14 @@ int edge_alloc(EdgeSet& s, int nq, size_t cap_edges, int maxdeg) {
       s.rtA.ensure((cap_edges / 32 + (size_t)nq + 1) * 8192) || s.rtT.ensure((cap_edges / 32 + (size_t)nq + 1) * 8192) ||
       s.geo.ensure(cap_edges + 1))
     return -1;
-  {   // the one-launch search's flags: zero when made, kept zero by the kernel itself
-    const size_t before = s.sync.p ? s.sync.n : 0;   // (by size, not by pointer: a block that grows can come back at the address it had)
-    if (s.sync.ensure(2 * (size_t)nq + 8)) return -1;   // 64 bits per query + the counter
-    if (s.sync.n != before && hipMemset(s.sync.p, 0, s.sync.n * sizeof(int)) != hipSuccess) return -1;
-  }
+  // The one-launch search's flags (k_radius_geo): zero before the set's first search, kept zero by the kernel itself.
+  // Round 6: zeroed by a KERNEL ON THE ENGINE'S STREAM, for every new scene of a size that takes the one-launch search.  Until now a
+  // (re)allocated block was cleared with hipMemset -- which runs on the null stream, is not ordered against the engine's NON-BLOCKING
+  // stream and does not wait for the host either: with the GPU shared by eight processes it could land after the set's first searches had
+  // started, wipe published counts and the done counter in mid-flight, and leave the next replay stale flags -- wrong CSR offsets, edge
+  // lists out of their ranges, a GPU memory fault (rank 0 of the 8-processes-on-one-GPU bench test, 1 run in 4: profiles/r06_k_*).
+  if (s.sync.ensure(2 * (size_t)nq + 8)) return -1;   // 64 bits per query + the counter
+  if (nq <= SEARCH_WG_MAX_Q && dev_zero(st, s.sync.p, (2 * (size_t)nq + 8) * sizeof(int))) return -1;
   return 0;
 }
 
@@ -1306,7 +1322,7 @@ extern "C" int ps_set_scene(ps_engine* e, int32_t B, int32_t M, int32_t P, int32
   if (c.obs_fusion_mlp && e->d_obs_new.ensure((size_t)A * D)) return fail(PS_E_HIP, "device allocation failed");
   if (c.obs_attn_update) {
     const int d_ua = mn(c.scene_knn + 1, std::max(1, e->maxA_scene - 1)), d_um = mn(c.scene_knn, std::max(1, e->maxM_scene));
-    if (edge_alloc(e->e_ua, A, (size_t)A * d_ua, d_ua) || edge_alloc(e->e_um, A, (size_t)A * d_um, d_um) ||
+    if (edge_alloc(e->e_ua, A, (size_t)A * d_ua, d_ua, e->stream) || edge_alloc(e->e_um, A, (size_t)A * d_um, d_um, e->stream) ||
         e->d_kv_um.ensure((size_t)c.scene_layers * std::max(Mv, 1) * 256) || e->d_kh_um.ensure((size_t)c.scene_layers * std::max(Mv, 1) * 256))
       return fail(PS_E_HIP, "edge allocation failed");
   }
@@ -1314,10 +1330,10 @@ extern "C" int ps_set_scene(ps_engine* e, int32_t B, int32_t M, int32_t P, int32
                                           (size_t)A * d_a2p, (size_t)A * d_m2p}))
     return PS_E_ARG;
   // (the scene encoder's and the generator's sets have Ap destination rows: with replicas they run once)
-  if (edge_alloc(e->e_a2a, Ap, (size_t)Ap * d_a2a, d_a2a) || edge_alloc(e->e_s2s, Mv + Ap, (size_t)(Mv + Ap) * d_s2s, d_s2s) ||
-      edge_alloc(e->e_p2p, Ap, (size_t)Ap * d_p2p, d_p2p) || edge_alloc(e->e_s2p, Ap, (size_t)Ap * d_s2p, d_s2p) ||
-      edge_alloc(e->e_a2p, A, (size_t)A * d_a2p, d_a2p) || edge_alloc(e->e_m2p, A, (size_t)A * d_m2p, d_m2p) ||
-      edge_alloc(e->e_cnd, A, (size_t)A, 1))
+  if (edge_alloc(e->e_a2a, Ap, (size_t)Ap * d_a2a, d_a2a, e->stream) || edge_alloc(e->e_s2s, Mv + Ap, (size_t)(Mv + Ap) * d_s2s, d_s2s, e->stream) ||
+      edge_alloc(e->e_p2p, Ap, (size_t)Ap * d_p2p, d_p2p, e->stream) || edge_alloc(e->e_s2p, Ap, (size_t)Ap * d_s2p, d_s2p, e->stream) ||
+      edge_alloc(e->e_a2p, A, (size_t)A * d_a2p, d_a2p, e->stream) || edge_alloc(e->e_m2p, A, (size_t)A * d_m2p, d_m2p, e->stream) ||
+      edge_alloc(e->e_cnd, A, (size_t)A, 1, e->stream))
     return fail(PS_E_HIP, "edge allocation failed");
   {   // split-path exchange buffers for the largest destination set (allocated here, never inside a captured rollout)
     EdgeIO io_;
@@ -2134,7 +2150,6 @@ int launch_chain16(ps_engine* e, float* x, int Nd, const ChainStep* steps, int n
 // launch each for all sets).  pe_mode: 1 = the operand images of k_attn_chain, 2 = the geometry records of k_chain16.
 // up to this many queries a search with geometry records is ONE launch of a workgroup per query (k_radius_geo); beyond, the count / fill /
 // record launches (measured: 128 queries 20.6 -> 11 us per search; at 1024 queries x 2 sets the one-launch form costs the pipelined headline 2 %)
-constexpr int SEARCH_WG_MAX_Q = 256;
 struct RadArgs {
   EdgeSet* es;
   const int *r1, *r2;
@@ -3928,7 +3943,7 @@ extern "C" int ps_policy_forward(ps_engine* e, int32_t n_scenes, int32_t Na, con
       d_kva.ensure((size_t)L * std::max(Na, 1) * 256) || d_kvm.ensure((size_t)L * std::max(Nm, 1) * 256) ||
       d_kha.ensure((size_t)L * std::max(Na, 1) * 256) || d_khm.ensure((size_t)L * std::max(Nm, 1) * 256) ||
       d_motion.ensure((size_t)A * OUT) || d_traj.ensure((size_t)A * 16 * 4) || d_vel.ensure((size_t)A * 16 * 2) ||
-      edge_alloc(ea, A, (size_t)A * da, da) || edge_alloc(em, A, (size_t)A * dm, dm))
+      edge_alloc(ea, A, (size_t)A * da, da, e->stream) || edge_alloc(em, A, (size_t)A * dm, dm, e->stream))
     return fail(PS_E_HIP, "ps_policy_forward: upload/alloc failed");
   // the launch helpers read token geometry from the engine: swap in the caller's arrays for this call
   std::swap(e->d_tok_pos, d_pos);
