@@ -28,7 +28,7 @@ static thread_local std::string g_err;
 // (-DPS_EXPERIMENTS: tools/README.md).  The product library compiles them out -- a stray PS_* variable cannot change which kernel
 // runs or corrupt a rollout -- and says so once, loudly, when it finds one set.
 static const char* const kExpEnv[] = {"PS_C16_ABL", "PS_XCD", "PS_CHAIN_T", "PS_CHAIN_TP", "PS_CHAIN_T1", "PS_CHAIN_FLAGS", "PS_CHAIN_PROF",
-                                      "PS_C16_ROWS", "PS_S2S_C16", "PS_NO_SPLIT", "PS_SPLIT_MIN", "PS_SKIP_S2S_EDGE", "PS_POL_EDGE_PROBE", "PS_C16_NW"};
+                                      "PS_C16_ROWS", "PS_C16_ROWS_SMALL", "PS_C16_ROWS_S2S", "PS_S2S_C16", "PS_NO_SPLIT", "PS_SPLIT_MIN", "PS_SKIP_S2S_EDGE", "PS_POL_EDGE_PROBE", "PS_C16_NW"};
 #ifdef PS_EXPERIMENTS
 static const char* exp_env(const char* name) { return getenv(name); }
 #else
@@ -2097,7 +2097,12 @@ int chain16_rows(ps_engine* e, int Nd) {
 int launch_chain16(ps_engine* e, float* x, int Nd, const ChainStep* steps, int nsteps, bool timed, const float* x_in, bool xcd) {
   if (!x_in) x_in = x;
   const int nw = 8;   // eight waves per workgroup, one workgroup per CU (the two-workgroups-of-four build of round 2 was never selected: dropped)
-  const int rows = chain16_rows(e, Nd);
+  int rows = chain16_rows(e, Nd);
+  {   // experiments: another tiling for the non-policy launches of the throughput mode (PS_C16_ROWS_SMALL: up to 1024 rows -- generator pairs, a2a; PS_C16_ROWS_S2S: beyond)
+    static const int rs = exp_env("PS_C16_ROWS_SMALL") ? atoi(exp_env("PS_C16_ROWS_SMALL")) : 0, rb = exp_env("PS_C16_ROWS_S2S") ? atoi(exp_env("PS_C16_ROWS_S2S")) : 0;
+    if (!timed && Nd <= 1024 && rs) rows = rs;
+    if (!timed && Nd > 1024 && rb) rows = rb;
+  }
   const int W = rows < nw ? nw / rows : 1;   // waves per row: each leaves its own partial sums (slot = part * Nd + row)
   const dim3 grid((Nd + rows - 1) / rows);   // (no exchange buffers: the phases of k_chain16 meet in LDS)
   hipStream_t st = e->stream;
