@@ -82,19 +82,12 @@ __device__ __forceinline__ float kq_max(float v) {
   const auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
   return fmaxf(__uint_as_float(q[0]), __uint_as_float(q[1]));
 }
-// max(m, v over the four kq lanes): the same, with the maxima as the instructions themselves -- fmaxf of a permlane result makes hipcc
-// canonicalise both halves first (v_max_f32 x, x twice per step; the values are finite scores, never signalling NaNs).
-// (Late round 5: the plain-fmaxf form `fmaxf(m, kq_max(v))` -- every instruction visible to the hazard recogniser, which does not look inside
-// inline asm -- returns the same bits at the same launch times and was tried as a cure for the run-to-run differences under load, DESIGN.md
-// section 7: they stayed.  This form is the one the GPU suite passed twice in full; kept.)
-__device__ __forceinline__ float kq_max3(float v, float m) {
-  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-  float a, o;
-  asm("v_max_f32 %0, %1, %2" : "=v"(a) : "v"(r[0]), "v"(r[1]));
-  const auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(a), false, false);
-  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(o) : "v"(m), "v"(q[0]), "v"(q[1]));
-  return o;
-}
+// max(m, v over the four kq lanes).  Round 6: plain fmaxf on the permlane results -- every instruction visible to hipcc's hazard recogniser.
+// Rounds 4 - 5 wrote the two maxima as inline asm (v_max_f32 / v_max3_f32: hipcc canonicalises both halves of a permlane result before an
+// fmaxf, two v_max_f32 x, x per step); an inline-asm VALU write feeding v_permlane32_swap is exactly the producer the recogniser cannot see
+// (gfx950 wants two wait states there), and the builtin form returns the same bits at the same launch time (measured in round 5 and again in
+// round 6: profiles/r06_n_digest.txt) -- so the form that cannot be wrong stays.
+__device__ __forceinline__ float kq_max3(float v, float m) { return fmaxf(m, kq_max(v)); }
 __device__ __forceinline__ float kq_sum(float v) {
   const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
   const float m = __uint_as_float(r[0]) + __uint_as_float(r[1]);
