@@ -299,6 +299,7 @@ def main():
     t_tgt = torch.from_numpy(np.ascontiguousarray(tgt_all[:, slots_np])).cuda()
     t_msk = torch.from_numpy(np.ascontiguousarray(msk_all[:, slots_np].astype(np.uint8))).cuda()
     slots = torch.from_numpy(slots_np).cuda()
+    torch.cuda.synchronize()   # (these tensors were filled on torch's default stream and are read on the engines' non-blocking streams: order them once)
 
     def step():
         i = state["k"] % n_fl

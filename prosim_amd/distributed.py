@@ -50,6 +50,10 @@ class SceneMetricGather:
         # scene ids never change between calls: gather them once, keep the scatter index on the device
         self.index = torch.where(all_ids >= 0, all_ids, torch.full_like(all_ids, n_scenes)).to(device)
         self.all_buf = torch.empty((self.world * per, max_agents, n_metrics), dtype=dtype, device=device)
+        # (round 6: the fills and copies above ran on torch's default stream; the gather is later enqueued on an ENGINE's stream, which is
+        # non-blocking -- nothing orders the two.  Built once, so drain once.)
+        if torch.device(device).type == "cuda":
+            torch.cuda.synchronize()
 
     def __call__(self, local: torch.Tensor) -> torch.Tensor:
         """``local`` [n_local, max_agents, M] -> [n_scenes, max_agents, M] on every rank, in scene order."""
