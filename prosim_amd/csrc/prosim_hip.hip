@@ -28,7 +28,7 @@ static thread_local std::string g_err;
 // (-DPS_EXPERIMENTS: tools/README.md).  The product library compiles them out -- a stray PS_* variable cannot change which kernel
 // runs or corrupt a rollout -- and says so once, loudly, when it finds one set.
 static const char* const kExpEnv[] = {"PS_C16_ABL", "PS_XCD", "PS_CHAIN_T", "PS_CHAIN_TP", "PS_CHAIN_T1", "PS_CHAIN_FLAGS", "PS_CHAIN_PROF",
-                                      "PS_C16_ROWS", "PS_C16_ROWS_SMALL", "PS_C16_ROWS_S2S", "PS_S2S_C16", "PS_NO_SPLIT", "PS_SPLIT_MIN", "PS_SKIP_S2S_EDGE", "PS_POL_EDGE_PROBE", "PS_C16_NW"};
+                                      "PS_C16_ROWS", "PS_C16_ROWS_SMALL", "PS_C16_ROWS_S2S", "PS_S2S_C16", "PS_NO_SPLIT", "PS_SPLIT_MIN", "PS_SKIP_S2S_EDGE", "PS_POL_EDGE_PROBE"};
 #ifdef PS_EXPERIMENTS
 static const char* exp_env(const char* name) { return getenv(name); }
 #else
@@ -1025,9 +1025,6 @@ extern "C" int ps_create(const ps_config* cfg, int32_t n_tensors, const char* co
 #define PS_C16_ATTR(NWW, POL, ONE) \
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_chain16<NWW, POL, ONE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c16_lds_bytes<NWW>())
   PS_C16_ATTR(8, true, true); PS_C16_ATTR(8, true, false); PS_C16_ATTR(8, false, true); PS_C16_ATTR(8, false, false);
-#ifdef PS_C16_ABL_ONE_SLOT
-  PS_C16_ATTR(4, true, true); PS_C16_ATTR(4, false, true);
-#endif
 #undef PS_C16_ATTR
 #define PS_ATTR(TT, KRR, POL) \
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_chain<TT, 4, KRR, false, POL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
@@ -2118,11 +2115,6 @@ int launch_chain16(ps_engine* e, float* x, int Nd, const ChainStep* steps, int n
 #define PS_C16_(NWW, POL, ONE) \
   hipLaunchKernelGGL((k_chain16<NWW, POL, ONE>), grid, dim3(64 * NWW), c16_lds_bytes<NWW>(), st, x, x_in, Nd, rows, steps, nsteps, e->div32, e->cfg.ln_eps, xcd ? 1 : 0, prof)
 #define PS_C16(NWW, POL) do { if (W == 1) PS_C16_(NWW, POL, true); else PS_C16_(NWW, POL, false); } while (0)
-#ifdef PS_C16_ABL_ONE_SLOT
-  static const int env_nw = exp_env("PS_C16_NW") ? atoi(exp_env("PS_C16_NW")) : 8;
-  if (env_nw == 4 && W == 1) { if (timed) PS_C16_(4, true, true); else PS_C16_(4, false, true); }
-  else
-#endif
   if (timed) PS_C16(8, true); else PS_C16(8, false);
 #undef PS_C16_
 #undef PS_C16

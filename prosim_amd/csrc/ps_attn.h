@@ -991,11 +991,17 @@ __device__ __forceinline__ void frag_issue(RingT& R, int slot, const _Float16* _
 #else
   const _Float16* f = F + ((size_t)(wave + NWV * (g / KG)) * K32 + (g % KG) * KB) * 1024 + lane * 8;
 #endif
+#ifdef PS_ABL_NOFRAG   // timing ablation: no fragment loads at all (the ring's registers keep what they hold)
+  (void)f;
+#pragma unroll
+  for (int j = 0; j < KB; ++j) asm volatile("" : "+v"(R.h[slot][j]), "+v"(R.l[slot][j]));
+#else
 #pragma unroll
   for (int j = 0; j < KB; ++j) {
     R.h[slot][j] = ldgh8(f + j * 1024);
     R.l[slot][j] = ldgh8(f + j * 1024 + 512);
   }
+#endif
 }
 template <int K32, class RingT, int NWV = 4>
 __device__ __forceinline__ void frag_prefetch(RingT& R, const _Float16* __restrict__ F, int ntiles, int wave, int lane) {
@@ -1056,6 +1062,61 @@ __device__ __forceinline__ void gemm16(RingT& R, const _Float16* __restrict__ Ah
       }
     }
   }
+}
+
+// ---- round 6: the same GEMM with everything about the fragment traffic known at compile time.  The node phases of k_chain16 see a layer's
+// weights as ONE stream of fragment groups ("items": <= 8 loads of 16 B per lane each) through a ring of DEPTH slots -- item i lives in slot
+// i % DEPTH, and consuming item i requests item i + DEPTH whatever GEMM that belongs to (issue(integral_constant<i + DEPTH>)).  With the
+// group count a constant the loops unroll into straight-line code, and hipcc's waits become exact (`s_waitcnt vmcnt(16)`: this group is in,
+// the two behind it stay in flight).  With a run-time group count every consumption sat behind `s_waitcnt vmcnt(0)`: the ring drained in
+// bursts of DEPTH groups and a burst's last request had the whole L2 round trip exposed.  Same MFMAs in the same order: same bits as gemm16.
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+template <int K32, int NTC, int NWV, int ITEM0, class RingT, class Issue>
+__device__ __forceinline__ void gemm16s(RingT& R, const _Float16* __restrict__ Ah, const _Float16* __restrict__ Al, int as, float* __restrict__ C, int cs,
+                                        int wave, int lane, Issue&& issue, _Float16* __restrict__ ph = nullptr, _Float16* __restrict__ pl = nullptr,
+                                        int ps = 0, const float* __restrict__ bias = nullptr) {
+  constexpr int KB = K32 < 4 ? K32 : 4, KG = (K32 + KB - 1) / KB, G = NTC / NWV * KG, DEPTH = RingT::DEPTH;
+  static_assert(NTC % NWV == 0, "every wave makes the same number of tiles");
+  const int mi = lane & 15, kq = lane >> 4;
+  floatx4 acc = {0.f, 0.f, 0.f, 0.f}, acc1 = acc, acc2 = acc;
+  static_for<0, G>([&](auto gc) {
+    constexpr int g = decltype(gc)::value, slot = (ITEM0 + g) % DEPTH, kg = g % KG;
+    half8 ch[KB], cl[KB];
+#pragma unroll
+    for (int j = 0; j < KB; ++j) { ch[j] = R.h[slot][j]; cl[j] = R.l[slot][j]; }
+    issue(std::integral_constant<int, ITEM0 + g + DEPTH>{});
+    if (kg == 0) { acc = floatx4{0.f, 0.f, 0.f, 0.f}; acc1 = acc; acc2 = acc; }
+#pragma unroll
+    for (int j = 0; j < KB; ++j) {
+      const half8 ah = *reinterpret_cast<const half8*>(Ah + mi * as + (kg * KB + j) * 32 + kq * 8);
+      const half8 al = *reinterpret_cast<const half8*>(Al + mi * as + (kg * KB + j) * 32 + kq * 8);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, ch[j], acc, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, cl[j], acc1, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, ch[j], acc2, 0, 0, 0);
+    }
+    if (kg == KG - 1) {
+      acc += (acc1 + acc2) * PS_LO_INV;   // (the cross products carry the lo halves' 2^11)
+      const int nt = wave + NWV * (g / KG);
+      if (ph) {
+        const float bv = bias[nt * 16 + mi];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = fmaxf(acc[r] + bv, 0.f);
+          ph[(4 * kq + r) * ps + nt * 16 + mi] = f16_hi(v);
+          pl[(4 * kq + r) * ps + nt * 16 + mi] = f16_los(v);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) C[(4 * kq + r) * cs + nt * 16 + mi] = acc[r];
+      }
+    }
+  });
 }
 
 // sum over the 16 lanes that share an epilogue row (lanes tid & 15 vary)

@@ -454,13 +454,9 @@ constexpr size_t C16_WAVE_BYTES = C16_STASH_OFF + 512 + 64;
 // wave per row: the row's a_r overwrites its q~ (slot = row).  W waves per row (rows <= 4): a_r slots row * W + part (8 at
 // most), q~ of row r in slot 8 + r.  Slot stride 808 floats = 8 mod 64: the 16 rows of a fold A-fragment read spread over
 // the banks two deep.
-#ifdef PS_C16_ABL_ONE_SLOT   // (timing experiment, wrong results: every row shares ONE q~ / a_r slot, which aliases the small vectors -- 77 KB: two 4-wave workgroups of 16 rows per CU)
-constexpr int C16_QH = 100, C16_QSL = 0;
-constexpr size_t C16_QA_BYTES = 0;
-#else
 constexpr int C16_QH = 100, C16_QSL = 8 * C16_QH + 8;
 constexpr size_t C16_QA_BYTES = (size_t)16 * C16_QSL * 4;
-#endif
+constexpr size_t C16_EDGE_WAVES_BYTES = 8 * C16_WAVE_BYTES;   // (k_edge16's wave areas)
 constexpr float C16_TAU = 6.f;   // (-DPS_C16_LAZY experiment only: a class's sums are rescaled when a score exceeds the reference by more than 2^6)
 constexpr int C16_CTR_INTS = 52;   // [0] row counter, [1..16] rows in queue order, [17..32] their edge counts, [36..51] their first edges
 template <int NWV>
@@ -1067,10 +1063,15 @@ __device__ __forceinline__ void c16_edge_body(const ChainStep* __restrict__ stp,
 template <int NWV, bool ONEW, int TAG = 0>
 __device__ __noinline__ void c16_edge_phase(const ChainStep* __restrict__ stp, unsigned char* c16_smem, float* AG,
                                             const float* CQ, int* ctr, float* QA, const float* __restrict__ div32, int row0, int nrows, int W) {
+  // (plain pointers into the caller's LDS, unlike the node phase's opaque LDS address: hipcc propagates the kernel's `extern __shared__` symbol into
+  // this function and pays ONE look-up of the dynamic-LDS base per call for it.  Handing the wave areas over as an opaque address -- round 6 tried --
+  // returned wrong sums for every row in the one-wave-per-row form, for a reason not found: profiles/r06_q_node_phase.txt)
   const EdgeIO none{};
   c16_edge_body<NWV, ONEW, false>(stp, c16_smem, AG, CQ, ctr, QA, div32, row0, nrows, W, none);
+  // nothing of this phase may still be in flight when the node phase reuses the wave areas as its operand planes (the workgroup barrier does
+  // not wait for vmcnt; until round 6 the node phase happened to begin with a pointer load behind s_waitcnt vmcnt(0))
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
-
 // ---- k_attn_chain<1, 4, 3, ., ., GEO>'s edge phase (ps_attn.h; round 5): c16_edge_body's arithmetic for FOUR waves on ONE row (wave w takes
 // the 16-edge tiles w, w + 4, ...; every wave its own online softmax, k_attn_chain merges the four partials like c16_node_phase's POST half
 // merges W partial sums), rescheduled for LATENCY: a wave is alone on its SIMD there (one workgroup per CU, 128 workgroups), so nothing hides a
@@ -1360,12 +1361,13 @@ __device__ __forceinline__ void c16_lat_main(const ChainStep* __restrict__ stp, 
 
 // The node phases between two edge phases: POST of layer `post` (to_v_r fold, gate, to_out, norms, FFN) and PRE of layer
 // `pre` (LN_dst, q | s | g, q~, <q, kb>, the row queue); either may be null.  Out of line like the edge phase, so that the
-// weight-fragment ring gets a register allocation that no other phase's pressure can push into scratch.  x_out: where the
-// residual rows go after the last layer (null otherwise).
+// weight-fragment ring gets a register allocation that no other phase's pressure can push into scratch.  (The
+// residual rows leave in the kernel, after the last call.)
 template <int NWV>
 __device__ __noinline__ void c16_node_phase(const ChainStep* __restrict__ post, const ChainStep* __restrict__ pre,
-                                            unsigned char* c16_smem, float* __restrict__ x_out, int row0, int nrows, int W,
+                                            unsigned smem_a, int row0, int nrows, int W,
                                             float eps, unsigned long long* __restrict__ prof) {
+  unsigned char* c16_smem = lds_ptr<unsigned char>(smem_a);   // (an LDS address, not a pointer: ps_device.h lds_addr)
   long long tprev = (prof && threadIdx.x == 0) ? clock64() : 0;
   constexpr int NT = 64 * NWV;
   constexpr size_t EXTRA = NWV * C16_WAVE_BYTES > C16_PLANES_BYTES ? NWV * C16_WAVE_BYTES - C16_PLANES_BYTES : 0;
@@ -1382,11 +1384,7 @@ __device__ __noinline__ void c16_node_phase(const ChainStep* __restrict__ post, 
   float* sp = AG + ND_ROWS * ND_XS;      // [SP_SIZE] the layer's small vectors
   float* CQ = sp + SP_SIZE;              // [16][8] <q_h, kb_h>
   int* ctr = reinterpret_cast<int*>(CQ + 16 * 8);   // [0] row counter, [1..16] the rows in queue order (longest edge list first), [17..32] their edge counts
-  #ifdef PS_C16_ABL_ONE_SLOT
-  float* QA = sp;
-#else
-  float* QA = reinterpret_cast<float*>(ctr + C16_CTR_INTS);
-#endif   // [16 slots][C16_QSL] q~ / a_r
+  float* QA = reinterpret_cast<float*>(ctr + C16_CTR_INTS);   // [16 slots][C16_QSL] q~ / a_r
   constexpr int C16_DEPTH = 3;   // fragment groups in flight per wave (k_node, alone on its CU with 512 registers: 4)
   typedef FragRingT<C16_DEPTH> Ring;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1394,12 +1392,64 @@ __device__ __noinline__ void c16_node_phase(const ChainStep* __restrict__ post, 
   const int mi = lane & 15, kq = lane >> 4;
   const bool epi = tid < 256;                      // the 16 x 128 epilogues take 256 threads: row er, 8 columns from ec
   const int er = (tid >> 4) & 15, ec = (tid & 15) * 8;
-  const int grow = row0 + er;
   const bool live = epi && er < nrows;
   auto stage_sp = [&](const float* __restrict__ src) {
     for (int i = tid; i < SP_SIZE / 4; i += NT) *reinterpret_cast<float4*>(sp + 4 * i) = ldg4(src + 4 * i);
   };
   Ring R;
+  // every pointer this call takes out of the two steps, fetched HERE in one batch and made wave-uniform: `post` / `pre` arrive in vector registers
+  // (a device-function argument), so each `w.F..` below used to be a flat load of the pointer behind an s_waitcnt vmcnt(0) -- which drained the
+  // fragment ring in the middle of every stage and put the pointer's own round trip on the stage chain (eight times per layer)
+  const _Float16 *pFqsg = nullptr, *pFvr3 = nullptr, *pFga = nullptr, *pFout = nullptr, *pF1 = nullptr, *pF2 = nullptr, *nFqsg = nullptr, *nFkr3 = nullptr;
+  const float* nsp = nullptr;
+  const int* neoff = nullptr;
+  if (post) {
+    const auto cs = uni_const(post);
+    pFqsg = cs->w.Fqsg; pFvr3 = cs->w.Fvr3; pFga = cs->w.Fga; pFout = cs->w.Fout; pF1 = cs->w.F1; pF2 = cs->w.F2;
+  }
+  if (pre) {
+    const auto cs = uni_const(pre);
+    nFqsg = cs->w.Fqsg; nFkr3 = cs->w.Fkr3; nsp = cs->w.sp; neoff = cs->eoff;
+  }
+  // The layer's fragment stream, one item = one ring slot's worth (item i in slot i % 3; consuming item i requests item i + 3: gemm16s):
+  //   0 1   to_s | to_g of LN_dst(x) (two tiles per wave)      2   the fold's to_v_r fragments (one head per wave)      3   gate      4   to_out
+  //   5..8  FFN up (four tiles per wave)      9..12  FFN down (K = 512 in four groups)      13  the NEXT layer's to_q      14 15  its to_k_r (2 x 3 tiles)
+  static_assert(NWV == 8 && C16_DEPTH == 3, "the item table below is written for eight waves and a ring of three");
+  auto issue = [&](auto ic) {
+    constexpr int item = decltype(ic)::value, slot = item % C16_DEPTH;
+    if constexpr (item <= 1) frag_issue<4, Ring, NWV>(R, slot, pFqsg + (size_t)8 * 4 * 1024, item, wave, lane);
+    else if constexpr (item == 2) {
+#pragma unroll
+      for (int ks = 0; ks < 3; ++ks) {
+        const _Float16* f = pFvr3 + ((size_t)(wave * 3 + ks) * 2) * 512 + lane * 8;
+        R.h[slot][ks] = ldgh8(f);
+        R.l[slot][ks] = ldgh8(f + 512);
+      }
+    }
+    else if constexpr (item == 3) frag_issue<4, Ring, NWV>(R, slot, pFga, 0, wave, lane);
+    else if constexpr (item == 4) frag_issue<4, Ring, NWV>(R, slot, pFout, 0, wave, lane);
+    else if constexpr (item <= 8) frag_issue<4, Ring, NWV>(R, slot, pF1, item - 5, wave, lane);
+    else if constexpr (item <= 12) frag_issue<16, Ring, NWV>(R, slot, pF2, item - 9, wave, lane);
+    else if constexpr (item == 13) { if (pre) frag_issue<4, Ring, NWV>(R, slot, nFqsg, 0, wave, lane); }
+    else if constexpr (item <= 15) {
+      if (pre) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {   // tiles wave + 8 g, g = 3 (item - 14) + j: frag_issue<1>'s addresses
+          const _Float16* f = nFkr3 + (size_t)(wave + NWV * (3 * (item - 14) + j)) * 1024 + lane * 8;
+          R.h[slot][j] = ldgh8(f);
+          R.l[slot][j] = ldgh8(f + 512);
+        }
+      }
+    }
+  };
+  typedef std::integral_constant<int, 0> I0;
+  typedef std::integral_constant<int, 1> I1;
+  typedef std::integral_constant<int, 2> I2;
+  typedef std::integral_constant<int, 5> I5;
+  typedef std::integral_constant<int, 13> I13;
+  typedef std::integral_constant<int, 14> I14;
+  typedef std::integral_constant<int, 15> I15;
+  typedef std::integral_constant<int, 16> I16;
   // the NEXT layer's small vectors leave for registers at the top of this POST half (they do not depend on activations; two float4 per
   // thread at most) and land in LDS when the PRE half starts: the 3.3 k cycles per layer the PRE half spent waiting for them are gone
   constexpr int NSPR = (SP_SIZE / 4 + NT - 1) / NT;
@@ -1408,22 +1458,20 @@ __device__ __noinline__ void c16_node_phase(const ChainStep* __restrict__ post, 
   if (sp_early) {
 #pragma unroll
     for (int i = 0; i < NSPR; ++i)
-      if (tid + i * NT < SP_SIZE / 4) spr[i] = ldg4(pre->w.sp + 4 * (tid + i * NT));
+      if (tid + i * NT < SP_SIZE / 4) spr[i] = ldg4(nsp + 4 * (tid + i * NT));
   }
   int eb_pre = 0, ee_pre = 0;   // (and the rows' edge ranges of the next layer's set, for the same reason)
   if (pre && tid < 16 && tid < nrows) {
-    eb_pre = ldgi(pre->eoff + row0 + tid);
-    ee_pre = ldgi(pre->eoff + row0 + tid + 1);
+    eb_pre = ldgi(neoff + row0 + tid);
+    ee_pre = ldgi(neoff + row0 + tid + 1);
   }
   if (post) {
-      const ChainStep& st = *post;
-      const AttnW& w = st.w;
     // =========================================================== POST: to_v_r fold, gate, to_out, norms, FFN   (:76-77, :100-107)
     {
       // to_s / to_g's x_dst half of LN_dst(x) (:106-107): x has not changed since this layer's PRE half made q from the same
       // rows, so the two projections are made HERE, next to their only use, instead of crossing the edge phase (round 2: 1 KB
       // per row and layer through a global scratch buffer).  Same GEMM, same operands, same bits.
-      frag_prefetch<4, Ring, NWV>(R, w.Fqsg + (size_t)8 * 4 * 1024, 16, wave, lane);
+      issue(I0{}); issue(I1{}); issue(I2{});
       if (epi) {
         float xn[8];
 #pragma unroll
@@ -1432,8 +1480,7 @@ __device__ __noinline__ void c16_node_phase(const ChainStep* __restrict__ post, 
         planes_store8(P0h + er * ND_AS + ec, P0l + er * ND_AS + ec, xn);
       }
       __syncthreads();
-      gemm16<4, Ring, NWV>(R, P0h, P0l, ND_AS, w.Fqsg + (size_t)8 * 4 * 1024, 16, Cw, ND_CW, wave, lane);
-      frag_prefetch<4, Ring, NWV>(R, w.Fga, 8, wave, lane);
+      gemm16s<4, 16, NWV, 0>(R, P0h, P0l, ND_AS, Cw, ND_CW, wave, lane, issue);   // (requests the gate's and to_out's fragments)
       // (no barrier here: the fold below reads the edge phase's sums and writes C, neither of which this GEMM touches)
       {   // fold: C[row][16h + d] = sum_c a_r[row][h][c] * Wvr_g3[c][16h + d]; one head at a time, 8 / NWV heads per wave
 #pragma unroll 1
@@ -1445,10 +1492,10 @@ __device__ __noinline__ void c16_node_phase(const ChainStep* __restrict__ post, 
           for (int ks = 0; ks < 3; ++ks) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) av_[ks][j] = 0.f;
-            const _Float16* f = w.Fvr3 + ((size_t)(h * 3 + ks) * 2) * 512 + lane * 8;
-            bh[ks] = ldgh8(f);
-            bl[ks] = ldgh8(f + 512);
+            bh[ks] = R.h[2][ks];   // (item 2)
+            bl[ks] = R.l[2][ks];
           }
+          issue(I5{});
           if (mi < nrows && W == 1) {   // one wave per row: the row's sums as they are (all six loads in flight at once)
             const float* ap_ = QA + mi * C16_QSL + h * C16_QH + kq * 8;
             float4 a0[3], a1[3];
@@ -1530,8 +1577,7 @@ __device__ __noinline__ void c16_node_phase(const ChainStep* __restrict__ post, 
       }
       __syncthreads();
       C16_MARK(17);
-      gemm16<4, Ring, NWV>(R, P0h, P0l, ND_AS, w.Fga, 8, C, ND_CS, wave, lane);
-      frag_prefetch<4, Ring, NWV>(R, w.Fout, 8, wave, lane);
+      gemm16s<4, 8, NWV, 3>(R, P0h, P0l, ND_AS, C, ND_CS, wave, lane, issue);
       __syncthreads();
       C16_MARK(18);
       {   // gated update (:106-107): g = sigmoid(Wg [agg | x_dst] + bg); u = agg + g * (to_s(x_dst) - agg)
@@ -1552,8 +1598,7 @@ __device__ __noinline__ void c16_node_phase(const ChainStep* __restrict__ post, 
       }
       __syncthreads();
       C16_MARK(20);
-      gemm16<4, Ring, NWV>(R, P0h, P0l, ND_AS, w.Fout, 8, C, ND_CS, wave, lane);
-      frag_prefetch<4, Ring, NWV>(R, w.F1, 32, wave, lane);
+      gemm16s<4, 8, NWV, 4>(R, P0h, P0l, ND_AS, C, ND_CS, wave, lane, issue);
       __syncthreads();
       C16_MARK(21);
       {   // x = x + LN_post(to_out(u))  (:76), then LN_ffpre(x)  (:77)
@@ -1575,12 +1620,10 @@ __device__ __noinline__ void c16_node_phase(const ChainStep* __restrict__ post, 
       }
       __syncthreads();
       C16_MARK(23);
-      gemm16<4, Ring, NWV>(R, P0h, P0l, ND_AS, w.F1, 32, nullptr, 0, wave, lane, P1h, P1l, ND_AS5, sp + SP_B1);
-      frag_prefetch<16, Ring, NWV>(R, w.F2, 8, wave, lane);
+      gemm16s<4, 32, NWV, 5>(R, P0h, P0l, ND_AS, nullptr, 0, wave, lane, issue, P1h, P1l, ND_AS5, sp + SP_B1);
       __syncthreads();
       C16_MARK(24);
-      gemm16<16, Ring, NWV>(R, P1h, P1l, ND_AS5, w.F2, 8, C, ND_CS, wave, lane);
-      if (pre) frag_prefetch<4, Ring, NWV>(R, pre->w.Fqsg, 8, wave, lane);   // (the next PRE's first GEMM)
+      gemm16s<16, 8, NWV, 9>(R, P1h, P1l, ND_AS5, C, ND_CS, wave, lane, issue);   // (requests the next PRE's fragments)
       __syncthreads();
       C16_MARK(25);
       if (epi) {   // x = x + LN_ffpost(FFN)
@@ -1593,10 +1636,6 @@ __device__ __noinline__ void c16_node_phase(const ChainStep* __restrict__ post, 
           y[i] += X[er * ND_XS + ec + i];
           X[er * ND_XS + ec + i] = y[i];
         }
-        if (live && x_out) {
-          *reinterpret_cast<float4*>(x_out + (size_t)grow * 128 + ec) = make_float4(y[0], y[1], y[2], y[3]);
-          *reinterpret_cast<float4*>(x_out + (size_t)grow * 128 + ec + 4) = make_float4(y[4], y[5], y[6], y[7]);
-        }
       }
       __syncthreads();   // X is final for this layer; sp may be restaged
       C16_MARK(26);
@@ -1604,21 +1643,31 @@ __device__ __noinline__ void c16_node_phase(const ChainStep* __restrict__ post, 
     }
     C16_MARK(2);
   if (pre) {
-      const ChainStep& st = *pre;
-      const AttnW& w = st.w;
     // =========================================================== PRE: LN_dst, q | s | g, q~, <q, kb>   (:61-69, :106-107, :114)
     if (sp_early) {
 #pragma unroll
       for (int i = 0; i < NSPR; ++i)
         if (tid + i * NT < SP_SIZE / 4) *reinterpret_cast<float4*>(sp + 4 * (tid + i * NT)) = spr[i];
     } else {
-      stage_sp(w.sp);
+      stage_sp(nsp);
     }
-    if (tid < 16) {   // (for the row queue, and so that a row's wave finds its edge range in LDS instead of behind two global loads)
-      ctr[17 + tid] = tid < nrows ? ee_pre - eb_pre : -1;
-      ctr[36 + tid] = eb_pre;
+    if (wave == 0) {   // (for the row queue, and so that a row's wave finds its edge range in LDS instead of behind two global loads)
+      // queue order of the edge phase: rows by falling edge count, long rows first -- ranked across the 16 lanes that hold the counts
+      const int mine = (tid < 16 && tid < nrows) ? ee_pre - eb_pre : -1;
+      int rank = 0;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int dj = __builtin_amdgcn_readlane(mine, j);
+        rank += (dj > mine || (dj == mine && j < tid)) ? 1 : 0;
+      }
+      if (tid < 16) {
+        ctr[17 + tid] = mine;
+        ctr[36 + tid] = eb_pre;
+        ctr[1 + rank] = tid;
+      }
+      if (tid == 0) ctr[0] = 0;
     }
-    if (!post) frag_prefetch<4, Ring, NWV>(R, w.Fqsg, 8, wave, lane);   // (later layers: requested at the end of the previous POST)
+    if (!post) { issue(I13{}); issue(I14{}); issue(I15{}); }   // (later layers: requested during the previous POST's FFN)
     __syncthreads();
     C16_MARK(32);
     if (epi) {
@@ -1630,8 +1679,7 @@ __device__ __noinline__ void c16_node_phase(const ChainStep* __restrict__ post, 
     }
     __syncthreads();
     C16_MARK(33);
-    gemm16<4, Ring, NWV>(R, P0h, P0l, ND_AS, w.Fqsg, 8, C, ND_CS, wave, lane);   // q (to_s / to_g: the POST half)
-    frag_prefetch<1, Ring, NWV>(R, w.Fkr3, 8 * 6, wave, lane);
+    gemm16s<4, 8, NWV, 13>(R, P0h, P0l, ND_AS, C, ND_CS, wave, lane, issue);   // q (to_s / to_g: the POST half)
     __syncthreads();
     C16_MARK(34);
     if (epi) {
@@ -1642,49 +1690,34 @@ __device__ __noinline__ void c16_node_phase(const ChainStep* __restrict__ post, 
         AG[er * ND_XS + ec + i] = q[i];
       }
       planes_store8(P0h + er * ND_AS + ec, P0l + er * ND_AS + ec, q);
+      // cq[row][h] = <q_h, kb_h>: 16 fmas in column order; the even thread of a head's pair takes columns 0..7, the odd one goes on from its sum
+      float a0 = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) a0 = fmaf(q[i], sp[SP_KB + ec + i], a0);
+      float a1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a0), 0x111, 0xf, 0xf, true));   // row_shr:1
+#pragma unroll
+      for (int i = 0; i < 8; ++i) a1 = fmaf(q[i], sp[SP_KB + ec + i], a1);
+      if (tid & 1) CQ[er * 8 + (ec >> 4)] = a1;
     }
     __syncthreads();
     C16_MARK(35);
     // q~[row][h][c] = sum_d q[row][16h + d] * Wkr_g3[16h + d][c]: (head, 16-column tile) pairs over the waves
     {
       constexpr int NTQ = 6;
-      const int G = (8 * NTQ - wave + NWV - 1) / NWV;   // one k-block per tile: group g = tile wave + NWV g
-      for (int g0 = 0; g0 < G; g0 += C16_DEPTH) {
+      static_for<0, NTQ>([&](auto gc) {   // tile t = wave + 8 g: items 14 (g < 3) and 15
+        constexpr int g = decltype(gc)::value, slot = (14 + g / 3) % C16_DEPTH, j = g % 3;
+        const half8 bh = R.h[slot][j], bl = R.l[slot][j];
+        const int t = wave + NWV * g, h = t / NTQ, nt = t - h * NTQ;
+        const half8 ah = *reinterpret_cast<const half8*>(P0h + mi * ND_AS + (h >> 1) * 32 + kq * 8);
+        const half8 al = *reinterpret_cast<const half8*>(P0l + mi * ND_AS + (h >> 1) * 32 + kq * 8);
+        floatx4 acc = {0.f, 0.f, 0.f, 0.f}, acx = acc;
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc, 0, 0, 0);
+        acx = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acx, 0, 0, 0);
+        acx = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acx, 0, 0, 0);
 #pragma unroll
-        for (int d = 0; d < C16_DEPTH; ++d) {
-          const int g = g0 + d;
-          if (g < G) {
-            const half8 bh = R.h[d][0], bl = R.l[d][0];
-            if (g + C16_DEPTH < G) frag_issue<1, Ring, NWV>(R, d, w.Fkr3, g + C16_DEPTH, wave, lane);
-            const int t = wave + NWV * g, h = t / NTQ, nt = t - h * NTQ;
-            const half8 ah = *reinterpret_cast<const half8*>(P0h + mi * ND_AS + (h >> 1) * 32 + kq * 8);
-            const half8 al = *reinterpret_cast<const half8*>(P0l + mi * ND_AS + (h >> 1) * 32 + kq * 8);
-            floatx4 acc = {0.f, 0.f, 0.f, 0.f}, acx = acc;
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc, 0, 0, 0);
-            acx = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acx, 0, 0, 0);
-            acx = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acx, 0, 0, 0);
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              if (4 * kq + r < nrows) QA[((W == 1 ? 0 : 8) + 4 * kq + r) * C16_QSL + h * C16_QH + nt * 16 + mi] = fmaf(acx[r], PS_LO_INV, acc[r]);
-          }
-        }
-      }
-      if (tid < 128) {   // cq[row][h] = <q_h, kb_h>
-        const int r = tid >> 3, h = tid & 7;
-        float a = 0.f;
-        for (int d = 0; d < DH; ++d) a = fmaf(AG[r * ND_XS + h * DH + d], sp[SP_KB + h * DH + d], a);
-        CQ[r * 8 + h] = a;
-      }
-      if (tid == 0) ctr[0] = 0;
-      if (tid < 16) {   // queue order of the edge phase: rows by falling edge count (read at the top of this PRE), long rows first
-        const int mine = ctr[17 + tid];
-        int rank = 0;
-        for (int j = 0; j < 16; ++j) {
-          const int dj = ctr[17 + j];
-          rank += (dj > mine || (dj == mine && j < tid)) ? 1 : 0;
-        }
-        ctr[1 + rank] = tid;
-      }
+        for (int r = 0; r < 4; ++r)
+          if (4 * kq + r < nrows) QA[((W == 1 ? 0 : 8) + 4 * kq + r) * C16_QSL + h * C16_QH + nt * 16 + mi] = fmaf(acx[r], PS_LO_INV, acc[r]);
+      });
     }
     __syncthreads();   // q~ rows, cq, the row queue: visible to every wave
     C16_MARK(36);
@@ -1724,11 +1757,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) __attribute__((disable_
   float* sp = AG + ND_ROWS * ND_XS;      // [SP_SIZE] the layer's small vectors
   float* CQ = sp + SP_SIZE;              // [16][8] <q_h, kb_h>
   int* ctr = reinterpret_cast<int*>(CQ + 16 * 8);   // [0] row counter, [1..16] the rows in queue order (longest edge list first), [17..32] their edge counts
-  #ifdef PS_C16_ABL_ONE_SLOT
-  float* QA = sp;
-#else
-  float* QA = reinterpret_cast<float*>(ctr + C16_CTR_INTS);
-#endif   // [16 slots][C16_QSL] q~ / a_r
+  float* QA = reinterpret_cast<float*>(ctr + C16_CTR_INTS);   // [16 slots][C16_QSL] q~ / a_r
 
   const int row0 = xcd_block(blockIdx.x, gridDim.x, !xcd) * rows;
   const int nrows = min(rows, Nd - row0);          // rows of this workgroup that exist (> 0: the grid is ceil(Nd / rows))
@@ -1745,15 +1774,24 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) __attribute__((disable_
   // PRE(0); then per layer EDGE(s), POST(s) + PRE(s + 1).  Every phase is a function of its own: the phases' register
   // needs differ (the edge phase's accumulators and operands, the node phases' weight-fragment ring) and inlined into one
   // body each pushed the other's into scratch.
-  c16_node_phase<NWV>(nullptr, steps, c16_smem, nullptr, row0, nrows, W, eps, prof);
+  const unsigned smem_a = lds_addr(c16_smem);
+  c16_node_phase<NWV>(nullptr, steps, smem_a, row0, nrows, W, eps, prof);
   C16_MARK(0);
   for (int s = 0; s < nsteps; ++s) {
     c16_edge_phase<NWV, ONEW>(steps + s, c16_smem, AG, CQ, ctr, QA, div32, row0, nrows, W);
     __syncthreads();   // every row's sums are in place; the wave-private areas are dead
     C16_MARK(1);
     const bool last = s + 1 == nsteps;
-    c16_node_phase<NWV>(steps + s, last ? nullptr : steps + s + 1, c16_smem, last ? x : nullptr, row0, nrows, W, eps, prof);
+    c16_node_phase<NWV>(steps + s, last ? nullptr : steps + s + 1, smem_a, row0, nrows, W, eps, prof);
     C16_MARK(2);
+  }
+  {   // the residual rows leave (the last POST half ends behind a barrier).  Here and not in the node phase: on gfx9 a store counts on vmcnt like
+      // the fragment loads, and with one possibly pending hipcc turns every wait behind it into s_waitcnt vmcnt(0)
+    const int tid0 = threadIdx.x, er0 = (tid0 >> 4) & 15, ec0 = (tid0 & 15) * 8;
+    if (tid0 < 256 && er0 < nrows) {
+      *reinterpret_cast<float4*>(x + (size_t)(row0 + er0) * 128 + ec0) = *reinterpret_cast<const float4*>(X + er0 * ND_XS + ec0);
+      *reinterpret_cast<float4*>(x + (size_t)(row0 + er0) * 128 + ec0 + 4) = *reinterpret_cast<const float4*>(X + er0 * ND_XS + ec0 + 4);
+    }
   }
 }
 
@@ -1764,7 +1802,6 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) __attribute__((disable_
 // workgroup: q / q~ / <q, kb> come from the PRE half's EdgeIO rows into the slots the fused chain keeps them in, the sums go back the
 // same way.  Same arithmetic as a one-step k_chain16 launch's edge phase.
 #ifdef PS_EXPERIMENTS   // (cross-check of k_edge_rows: ps_set_row_impl(2) in experiments builds; the product library does not carry it)
-constexpr size_t C16_EDGE_WAVES_BYTES = 8 * C16_WAVE_BYTES;
 constexpr size_t c16_edge_lds_bytes() { return C16_EDGE_WAVES_BYTES + (size_t)ND_ROWS * ND_XS * 4 + 16 * 8 * 4 + C16_CTR_INTS * 4 + C16_QA_BYTES; }
 __global__ __launch_bounds__(512, 1) __attribute__((disable_tail_calls)) void k_edge16(int Nd, const ChainStep* __restrict__ step, EdgeIO io,
                                                                                      const float* __restrict__ div32) {

@@ -4,6 +4,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace ps {
 
@@ -301,4 +302,34 @@ __device__ __forceinline__ void pn_gemm(const _Float16* __restrict__ Ah, const _
   pn_mma<MT>(f, Ah, Al, k32, C, cs, row_lim, wave, lane, ntiles);
 }
 
+// LDS addresses as function arguments.  A __noinline__ phase function that is handed `extern __shared__` memory as a pointer gets the SYMBOL
+// propagated into it by hipcc (every caller passes the same one), and the module-LDS lowering then turns each use into a look-up of the kernel's
+// dynamic-LDS base in a table in MEMORY -- k_chain16's node phase did 14 of them per call, five as vector loads behind s_waitcnt vmcnt(0) in the
+// middle of its GEMM stages.  So the kernels pass the 32-bit LDS address through an opaque register, and the callee rebuilds its pointers from it.
+typedef __attribute__((address_space(3))) unsigned char lds_u8;
+__device__ __forceinline__ unsigned lds_addr(const void* p) {   // p: a pointer into LDS
+  unsigned o = (unsigned)reinterpret_cast<uintptr_t>((const lds_u8*)p);
+  asm volatile("" : "+s"(o));
+  return o;
+}
+template <class T>
+__device__ __forceinline__ T* lds_ptr(unsigned o) {   // (the address-space inference follows the cast: accesses stay ds_ instructions)
+  return (T*)reinterpret_cast<lds_u8*>((uintptr_t)o);
+}
+// a pointer known to be the same in every lane, as a scalar-register value (what comes out of a device-function argument or a struct in memory is a
+// vector-register pair to the compiler: loads through it are flat loads with per-lane addresses)
+// ... and a struct in memory that no launch writes, read through the scalar cache: a wave-uniform address in the constant address space makes every
+// field access an s_load (lgkmcnt, ~200 cycles) instead of a flat load (vmcnt AND lgkmcnt: it waits behind every fragment load in flight)
+template <class T>
+__device__ __forceinline__ const __attribute__((address_space(4))) T* uni_const(const T* p) {
+  const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return (const __attribute__((address_space(4))) T*)(((unsigned long long)hi << 32) | lo);
+}
+template <class T>
+__device__ __forceinline__ T* uni_ptr(T* p) {
+  const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return reinterpret_cast<T*>(((unsigned long long)hi << 32) | lo);
+}
 }  // namespace ps
