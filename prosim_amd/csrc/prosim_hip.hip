@@ -3989,3 +3989,21 @@ extern "C" int ps_policy_forward(ps_engine* e, int32_t n_scenes, int32_t Na, con
   d_steps.release();
   return rc;
 }
+
+#ifdef PS_C16_DBG
+extern "C" int ps_test_c16_dbg(float* out_host, int rows) {   // out_host == nullptr: arm (allocate + zero); else copy the planes back
+  static float* d = nullptr;
+  static int n = 0;
+  if (!out_host) {
+    if (d) (void)hipFree(d);
+    n = rows;
+    if (hipMalloc(&d, (size_t)6 * rows * 128 * 4) != hipSuccess) return -1;
+    (void)hipMemset(d, 0, (size_t)6 * rows * 128 * 4);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(ps::g_c16_dbg), &d, sizeof(d));
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(ps::g_c16_dbg_rows), &n, sizeof(n));
+    return (int)hipDeviceSynchronize();
+  }
+  (void)hipDeviceSynchronize();
+  return (int)hipMemcpy(out_host, d, (size_t)6 * n * 128 * 4, hipMemcpyDeviceToHost);
+}
+#endif

@@ -1077,10 +1077,11 @@ __device__ __forceinline__ void static_for(F&& f) {
     static_for<I + 1, N>(f);
   }
 }
-template <int K32, int NTC, int NWV, int ITEM0, class RingT, class Issue>
-__device__ __forceinline__ void gemm16s(RingT& R, const _Float16* __restrict__ Ah, const _Float16* __restrict__ Al, int as, float* __restrict__ C, int cs,
-                                        int wave, int lane, Issue&& issue, _Float16* __restrict__ ph = nullptr, _Float16* __restrict__ pl = nullptr,
-                                        int ps = 0, const float* __restrict__ bias = nullptr) {
+// tile(integral_constant<j>, nt, acc): the wave's j-th finished tile (columns 16 nt .. 16 nt + 15; acc[r] = row 4 kq + r, column 16 nt + mi) -- the
+// elementwise epilogues of the node phases work on the accumulators where they are (no C round trip, no barrier)
+template <int K32, int NTC, int NWV, int ITEM0, class RingT, class Issue, class Tile>
+__device__ __forceinline__ void gemm16t(RingT& R, const _Float16* __restrict__ Ah, const _Float16* __restrict__ Al, int as, int wave, int lane,
+                                        Issue&& issue, Tile&& tile) {
   constexpr int KB = K32 < 4 ? K32 : 4, KG = (K32 + KB - 1) / KB, G = NTC / NWV * KG, DEPTH = RingT::DEPTH;
   static_assert(NTC % NWV == 0, "every wave makes the same number of tiles");
   const int mi = lane & 15, kq = lane >> 4;
@@ -1100,21 +1101,29 @@ __device__ __forceinline__ void gemm16s(RingT& R, const _Float16* __restrict__ A
       acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, cl[j], acc1, 0, 0, 0);
       acc2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, ch[j], acc2, 0, 0, 0);
     }
-    if (kg == KG - 1) {
+    if constexpr (kg == KG - 1) {
       acc += (acc1 + acc2) * PS_LO_INV;   // (the cross products carry the lo halves' 2^11)
-      const int nt = wave + NWV * (g / KG);
-      if (ph) {
-        const float bv = bias[nt * 16 + mi];
+      tile(std::integral_constant<int, g / KG>{}, wave + NWV * (g / KG), acc);
+    }
+  });
+}
+template <int K32, int NTC, int NWV, int ITEM0, class RingT, class Issue>
+__device__ __forceinline__ void gemm16s(RingT& R, const _Float16* __restrict__ Ah, const _Float16* __restrict__ Al, int as, float* __restrict__ C, int cs,
+                                        int wave, int lane, Issue&& issue, _Float16* __restrict__ ph = nullptr, _Float16* __restrict__ pl = nullptr,
+                                        int ps = 0, const float* __restrict__ bias = nullptr) {
+  const int mi = lane & 15, kq = lane >> 4;
+  gemm16t<K32, NTC, NWV, ITEM0>(R, Ah, Al, as, wave, lane, issue, [&](auto, int nt, const floatx4& acc) {
+    if (ph) {   // relu(acc + bias) as split-fp16 planes: the FFN-up result is the FFN-down GEMM's A operand
+      const float bv = bias[nt * 16 + mi];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float v = fmaxf(acc[r] + bv, 0.f);
-          ph[(4 * kq + r) * ps + nt * 16 + mi] = f16_hi(v);
-          pl[(4 * kq + r) * ps + nt * 16 + mi] = f16_los(v);
-        }
-      } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) C[(4 * kq + r) * cs + nt * 16 + mi] = acc[r];
+      for (int r = 0; r < 4; ++r) {
+        const float v = fmaxf(acc[r] + bv, 0.f);
+        ph[(4 * kq + r) * ps + nt * 16 + mi] = f16_hi(v);
+        pl[(4 * kq + r) * ps + nt * 16 + mi] = f16_los(v);
       }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) C[(4 * kq + r) * cs + nt * 16 + mi] = acc[r];
     }
   });
 }

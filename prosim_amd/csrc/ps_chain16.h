@@ -456,12 +456,14 @@ constexpr size_t C16_WAVE_BYTES = C16_STASH_OFF + 512 + 64;
 // the banks two deep.
 constexpr int C16_QH = 100, C16_QSL = 8 * C16_QH + 8;
 constexpr size_t C16_QA_BYTES = (size_t)16 * C16_QSL * 4;
+constexpr size_t C16_PB_BYTES = (size_t)2 * ND_ROWS * ND_AS * 2 + 256 * 4;   // k_chain16: the PB operand planes + the next layer's LN_dst vectors (behind QA)
 constexpr size_t C16_EDGE_WAVES_BYTES = 8 * C16_WAVE_BYTES;   // (k_edge16's wave areas)
 constexpr float C16_TAU = 6.f;   // (-DPS_C16_LAZY experiment only: a class's sums are rescaled when a score exceeds the reference by more than 2^6)
 constexpr int C16_CTR_INTS = 52;   // [0] row counter, [1..16] rows in queue order, [17..32] their edge counts, [36..51] their first edges
 template <int NWV>
 constexpr size_t c16_lds_bytes() {
-  return (NWV * C16_WAVE_BYTES > C16_PLANES_BYTES ? NWV * C16_WAVE_BYTES - C16_PLANES_BYTES : 0) + C16_NODE_BYTES + 16 * 8 * 4 + C16_CTR_INTS * 4 + C16_QA_BYTES;
+  return (NWV * C16_WAVE_BYTES > C16_PLANES_BYTES ? NWV * C16_WAVE_BYTES - C16_PLANES_BYTES : 0) + C16_NODE_BYTES + 16 * 8 * 4 + C16_CTR_INTS * 4 + C16_QA_BYTES +
+         C16_PB_BYTES;
 }
 
 typedef __fp16 fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
@@ -1359,6 +1361,18 @@ __device__ __forceinline__ void c16_lat_main(const ChainStep* __restrict__ stp, 
 #define C16_MARK(i) do { (void)prof; (void)tprev; } while (0)
 #endif
 
+
+#ifdef PS_C16_DBG   // (tools only: six [rows][128] planes of the FIRST layer of the last k_chain16 launch: agg, u, q, s, g, fold)
+__device__ float* g_c16_dbg = nullptr;
+__device__ int g_c16_dbg_rows = 0;
+#define C16_DBG(plane, row, colx, val) do { if (g_c16_dbg && dbg_layer == 0 && (row) < nrows) g_c16_dbg[((size_t)(plane) * g_c16_dbg_rows + row0 + (row)) * 128 + (colx)] = (val); } while (0)
+#define C16_DBG_PARAM , int dbg_layer
+#define C16_DBG_ARG(l) , (l)
+#else
+#define C16_DBG(plane, row, colx, val) do { } while (0)
+#define C16_DBG_PARAM
+#define C16_DBG_ARG(l)
+#endif
 // The node phases between two edge phases: POST of layer `post` (to_v_r fold, gate, to_out, norms, FFN) and PRE of layer
 // `pre` (LN_dst, q | s | g, q~, <q, kb>, the row queue); either may be null.  Out of line like the edge phase, so that the
 // weight-fragment ring gets a register allocation that no other phase's pressure can push into scratch.  (The
@@ -1366,7 +1380,7 @@ __device__ __forceinline__ void c16_lat_main(const ChainStep* __restrict__ stp, 
 template <int NWV>
 __device__ __noinline__ void c16_node_phase(const ChainStep* __restrict__ post, const ChainStep* __restrict__ pre,
                                             unsigned smem_a, int row0, int nrows, int W,
-                                            float eps, unsigned long long* __restrict__ prof) {
+                                            float eps, unsigned long long* __restrict__ prof C16_DBG_PARAM) {
   unsigned char* c16_smem = lds_ptr<unsigned char>(smem_a);   // (an LDS address, not a pointer: ps_device.h lds_addr)
   long long tprev = (prof && threadIdx.x == 0) ? clock64() : 0;
   constexpr int NT = 64 * NWV;
@@ -1385,6 +1399,9 @@ __device__ __noinline__ void c16_node_phase(const ChainStep* __restrict__ post, 
   float* CQ = sp + SP_SIZE;              // [16][8] <q_h, kb_h>
   int* ctr = reinterpret_cast<int*>(CQ + 16 * 8);   // [0] row counter, [1..16] the rows in queue order (longest edge list first), [17..32] their edge counts
   float* QA = reinterpret_cast<float*>(ctr + C16_CTR_INTS);   // [16 slots][C16_QSL] q~ / a_r
+  _Float16* PBh = reinterpret_cast<_Float16*>(QA + 16 * C16_QSL);   // [16][ND_AS] x 2: a second pair of operand planes, OUTSIDE the wave areas
+  _Float16* PBl = PBh + ND_ROWS * ND_AS;
+  float* NLN = reinterpret_cast<float*>(PBl + ND_ROWS * ND_AS);   // [256] LN_dst weight | bias of the next layer
   constexpr int C16_DEPTH = 3;   // fragment groups in flight per wave (k_node, alone on its CU with 512 registers: 4)
   typedef FragRingT<C16_DEPTH> Ring;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1459,146 +1476,146 @@ __device__ __noinline__ void c16_node_phase(const ChainStep* __restrict__ post, 
 #pragma unroll
     for (int i = 0; i < NSPR; ++i)
       if (tid + i * NT < SP_SIZE / 4) spr[i] = ldg4(nsp + 4 * (tid + i * NT));
+    if (tid < 64) *reinterpret_cast<float4*>(NLN + 4 * tid) = ldg4(nsp + SP_LN_DST_W + 4 * tid);   // LN_dst weight | bias of the next layer (the last epilogue below)
   }
   int eb_pre = 0, ee_pre = 0;   // (and the rows' edge ranges of the next layer's set, for the same reason)
   if (pre && tid < 16 && tid < nrows) {
     eb_pre = ldgi(neoff + row0 + tid);
     ee_pre = ldgi(neoff + row0 + tid + 1);
   }
+  const int col = 16 * wave + mi;   // this lane's column of the wave's 128-column tile (accumulator element r: row 4 kq + r)
+  const float bq_n = pre ? ldg1(nsp + SP_BQ + col) : 0.f;   // the next layer's to_q bias where the q GEMM's accumulators will want it
+  auto planes_put = [&](_Float16* __restrict__ Ph, _Float16* __restrict__ Pl, const float (&v)[4]) {   // accumulator layout -> split-fp16 operand planes
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      // the value as an fp32 NUMBER first: left to itself hipcc folds the multiply that made it into the conversion (v_fma_mixlo_f16 x, y, 0 rounds the
+      // exact product to fp16 once; planes_store8's packed conversions round the fp32 product) -- another hi | lo pair for the same value, other bits
+      float x = v[r];
+      asm("" : "+v"(x));
+      Ph[(4 * kq + r) * ND_AS + col] = f16_hi(x);
+      Pl[(4 * kq + r) * ND_AS + col] = f16_los(x);
+    }
+  };
+  // Round 6: the elementwise steps between two GEMMs (agg, gate, q) are made on the GEMM's accumulators by the lane that holds them -- wave w owns
+  // columns 16 w .. 16 w + 15 (= head w) of EVERY 128-column result, so s, g, the fold and the gate's GEMM meet in the same registers -- and
+  // LN_dst(x) of the next layer is made by the thread that finishes x.  9 workgroup barriers per layer where there were 15; same operations on the
+  // same values in the same order.  Operand planes: PB (outside the wave areas: LN_dst(x) survives the edge phase, so the POST half starts with its
+  // GEMM), P0.
   if (post) {
     // =========================================================== POST: to_v_r fold, gate, to_out, norms, FFN   (:76-77, :100-107)
+    float sv[4], gv[4], agg[4];
     {
-      // to_s / to_g's x_dst half of LN_dst(x) (:106-107): x has not changed since this layer's PRE half made q from the same
-      // rows, so the two projections are made HERE, next to their only use, instead of crossing the edge phase (round 2: 1 KB
-      // per row and layer through a global scratch buffer).  Same GEMM, same operands, same bits.
+      // to_s / to_g's x_dst half of LN_dst(x) (:106-107): x has not changed since this layer's PRE half made q from the same rows, so the two
+      // projections are made HERE, next to their only use, from the planes the PRE half left in PB.
       issue(I0{}); issue(I1{}); issue(I2{});
-      if (epi) {
-        float xn[8];
+      gemm16t<4, 16, NWV, 0>(R, PBh, PBl, ND_AS, wave, lane, issue, [&](auto jc, int, const floatx4& acc) {   // tile w: s, tile w + 8: g
+        constexpr int j = decltype(jc)::value;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) xn[i] = X[er * ND_XS + ec + i];
-        row16_ln(xn, sp + SP_LN_DST_W, sp + SP_LN_DST_B, ec, eps);
-        planes_store8(P0h + er * ND_AS + ec, P0l + er * ND_AS + ec, xn);
-      }
-      __syncthreads();
-      gemm16s<4, 16, NWV, 0>(R, P0h, P0l, ND_AS, Cw, ND_CW, wave, lane, issue);   // (requests the gate's and to_out's fragments)
-      // (no barrier here: the fold below reads the edge phase's sums and writes C, neither of which this GEMM touches)
-      {   // fold: C[row][16h + d] = sum_c a_r[row][h][c] * Wvr_g3[c][16h + d]; one head at a time, 8 / NWV heads per wave
-#pragma unroll 1
-        for (int t = 0; t < 8 / NWV; ++t) {
-          const int h = (8 / NWV) * wave + t;
-          float av_[3][8];
-          half8 bh[3], bl[3];
+        for (int r = 0; r < 4; ++r) {
+          if constexpr (j == 0) { sv[r] = acc[r] + sp[SP_BS + col]; C16_DBG(3, 4 * kq + r, col, sv[r]); }
+          else { gv[r] = acc[r] + sp[SP_BG + col]; C16_DBG(4, 4 * kq + r, col, gv[r]); }
+        }
+      });
+      {   // fold: f[row][16h + d] = sum_c a_r[row][h][c] * Wvr_g3[c][16h + d], head h = wave; then agg = (a_v + f + l * vb) / (l + 1e-16)   (:89, :100)
+        const int h = wave;
+        float av_[3][8];
+        half8 bh[3], bl[3];
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) av_[ks][j] = 0.f;
+          bh[ks] = R.h[2][ks];   // (item 2)
+          bl[ks] = R.l[2][ks];
+        }
+        issue(I5{});
+        if (mi < nrows && W == 1) {   // one wave per row: the row's sums as they are (all six loads in flight at once)
+          const float* ap_ = QA + mi * C16_QSL + h * C16_QH + kq * 8;
+          float4 a0[3], a1[3];
+#pragma unroll
+          for (int ks = 0; ks < 3; ++ks) { a0[ks] = *reinterpret_cast<const float4*>(ap_ + ks * 32); a1[ks] = *reinterpret_cast<const float4*>(ap_ + ks * 32 + 4); }
 #pragma unroll
           for (int ks = 0; ks < 3; ++ks) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) av_[ks][j] = 0.f;
-            bh[ks] = R.h[2][ks];   // (item 2)
-            bl[ks] = R.l[2][ks];
+            av_[ks][0] = a0[ks].x; av_[ks][1] = a0[ks].y; av_[ks][2] = a0[ks].z; av_[ks][3] = a0[ks].w;
+            av_[ks][4] = a1[ks].x; av_[ks][5] = a1[ks].y; av_[ks][6] = a1[ks].z; av_[ks][7] = a1[ks].w;
           }
-          issue(I5{});
-          if (mi < nrows && W == 1) {   // one wave per row: the row's sums as they are (all six loads in flight at once)
-            const float* ap_ = QA + mi * C16_QSL + h * C16_QH + kq * 8;
-            float4 a0[3], a1[3];
-#pragma unroll
-            for (int ks = 0; ks < 3; ++ks) { a0[ks] = *reinterpret_cast<const float4*>(ap_ + ks * 32); a1[ks] = *reinterpret_cast<const float4*>(ap_ + ks * 32 + 4); }
+        } else if (mi < nrows) {      // W partial sums: common maximum, rescale, add
+          float mm = -INFINITY;
+          for (int p = 0; p < W; ++p) mm = fmaxf(mm, QA[(mi * W + p) * C16_QSL + h * C16_QH + 97]);
+          for (int p = 0; p < W; ++p) {
+            const float mp = QA[(mi * W + p) * C16_QSL + h * C16_QH + 97];
+            const float sc = (mp == -INFINITY) ? 0.f : exp2f(mp - mm);
 #pragma unroll
             for (int ks = 0; ks < 3; ++ks) {
-              av_[ks][0] = a0[ks].x; av_[ks][1] = a0[ks].y; av_[ks][2] = a0[ks].z; av_[ks][3] = a0[ks].w;
-              av_[ks][4] = a1[ks].x; av_[ks][5] = a1[ks].y; av_[ks][6] = a1[ks].z; av_[ks][7] = a1[ks].w;
+              const float* ap_ = QA + (mi * W + p) * C16_QSL + h * C16_QH + ks * 32 + kq * 8;
+              const float4 a0 = *reinterpret_cast<const float4*>(ap_), a1 = *reinterpret_cast<const float4*>(ap_ + 4);
+              av_[ks][0] = fmaf(a0.x, sc, av_[ks][0]); av_[ks][1] = fmaf(a0.y, sc, av_[ks][1]);
+              av_[ks][2] = fmaf(a0.z, sc, av_[ks][2]); av_[ks][3] = fmaf(a0.w, sc, av_[ks][3]);
+              av_[ks][4] = fmaf(a1.x, sc, av_[ks][4]); av_[ks][5] = fmaf(a1.y, sc, av_[ks][5]);
+              av_[ks][6] = fmaf(a1.z, sc, av_[ks][6]); av_[ks][7] = fmaf(a1.w, sc, av_[ks][7]);
             }
-          } else if (mi < nrows) {      // W partial sums: common maximum, rescale, add
-            float mm = -INFINITY;
-            for (int p = 0; p < W; ++p) mm = fmaxf(mm, QA[(mi * W + p) * C16_QSL + h * C16_QH + 97]);
-            for (int p = 0; p < W; ++p) {
-              const float mp = QA[(mi * W + p) * C16_QSL + h * C16_QH + 97];
-              const float sc = (mp == -INFINITY) ? 0.f : exp2f(mp - mm);
+          }
+        }
+        // the row's a_v and l for this lane's four (row, column) elements (rows beyond the workgroup's: zeros, as the epilogue threads had them)
+        float av4[4], l4[4];
 #pragma unroll
-              for (int ks = 0; ks < 3; ++ks) {
-                const float* ap_ = QA + (mi * W + p) * C16_QSL + h * C16_QH + ks * 32 + kq * 8;
-                const float4 a0 = *reinterpret_cast<const float4*>(ap_), a1 = *reinterpret_cast<const float4*>(ap_ + 4);
-                av_[ks][0] = fmaf(a0.x, sc, av_[ks][0]); av_[ks][1] = fmaf(a0.y, sc, av_[ks][1]);
-                av_[ks][2] = fmaf(a0.z, sc, av_[ks][2]); av_[ks][3] = fmaf(a0.w, sc, av_[ks][3]);
-                av_[ks][4] = fmaf(a1.x, sc, av_[ks][4]); av_[ks][5] = fmaf(a1.y, sc, av_[ks][5]);
-                av_[ks][6] = fmaf(a1.z, sc, av_[ks][6]); av_[ks][7] = fmaf(a1.w, sc, av_[ks][7]);
+        for (int r = 0; r < 4; ++r) {
+          const int row = 4 * kq + r;
+          av4[r] = 0.f;
+          l4[r] = 0.f;
+          if (row < nrows) {
+            if (W == 1) {
+              l4[r] = QA[row * C16_QSL + h * C16_QH + 96];
+              av4[r] = AG[row * ND_XS + col];
+            } else {   // merge the W partial softmax sums of the row: common maximum, rescale, add
+              float mm = -INFINITY;
+              for (int p = 0; p < W; ++p) mm = fmaxf(mm, QA[(row * W + p) * C16_QSL + h * C16_QH + 97]);
+              for (int p = 0; p < W; ++p) {
+                const int slot = row * W + p;
+                const float mp = QA[slot * C16_QSL + h * C16_QH + 97];
+                const float sc = (mp == -INFINITY) ? 0.f : exp2f(mp - mm);
+                l4[r] = fmaf(QA[slot * C16_QSL + h * C16_QH + 96], sc, l4[r]);
+                av4[r] = fmaf(AG[(8 + slot) * ND_XS + col], sc, av4[r]);
               }
             }
           }
-          floatx4 acc = {0.f, 0.f, 0.f, 0.f}, acx = acc;
-#pragma unroll
-          for (int ks = 0; ks < 3; ++ks) {
-            half8 ah, al;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { ah[j] = f16_hi(av_[ks][j]); al[j] = f16_los(av_[ks][j]); }
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[ks], acc, 0, 0, 0);
-            acx = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[ks], acx, 0, 0, 0);
-            acx = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[ks], acx, 0, 0, 0);
-          }
-#pragma unroll
-          for (int r = 0; r < 4; ++r) C[(4 * kq + r) * ND_CS + h * 16 + mi] = fmaf(acx[r], PS_LO_INV, acc[r]);
         }
+        floatx4 acc = {0.f, 0.f, 0.f, 0.f}, acx = acc;
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) {
+          half8 ah, al;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { ah[j] = f16_hi(av_[ks][j]); al[j] = f16_los(av_[ks][j]); }
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[ks], acc, 0, 0, 0);
+          acx = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[ks], acx, 0, 0, 0);
+          acx = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[ks], acx, 0, 0, 0);
+        }
+        const float vb = sp[SP_VB + col];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float f = fmaf(acx[r], PS_LO_INV, acc[r]);
+          const float l = l4[r];
+          const float inv = 1.f / (l + 1e-16f);
+          agg[r] = (av4[r] + f + l * vb) * inv;
+          C16_DBG(0, 4 * kq + r, col, agg[r]); C16_DBG(5, 4 * kq + r, col, f);
+        }
+        planes_put(P0h, P0l, agg);
       }
       __syncthreads();
       C16_MARK(16);
-      float4 in_av0 = make_float4(0.f, 0.f, 0.f, 0.f), in_av1 = in_av0, in_g0 = in_av0, in_g1 = in_av0, in_s0 = in_av0, in_s1 = in_av0;
-      float in_l = 0.f;
-      if (live) {
-        const float* cs_ = Cw + er * ND_CW + ec;
-        in_s0 = make_float4(cs_[0] + sp[SP_BS + ec], cs_[1] + sp[SP_BS + ec + 1], cs_[2] + sp[SP_BS + ec + 2], cs_[3] + sp[SP_BS + ec + 3]);
-        in_s1 = make_float4(cs_[4] + sp[SP_BS + ec + 4], cs_[5] + sp[SP_BS + ec + 5], cs_[6] + sp[SP_BS + ec + 6], cs_[7] + sp[SP_BS + ec + 7]);
-        in_g0 = make_float4(cs_[128] + sp[SP_BG + ec], cs_[129] + sp[SP_BG + ec + 1], cs_[130] + sp[SP_BG + ec + 2], cs_[131] + sp[SP_BG + ec + 3]);
-        in_g1 = make_float4(cs_[132] + sp[SP_BG + ec + 4], cs_[133] + sp[SP_BG + ec + 5], cs_[134] + sp[SP_BG + ec + 6], cs_[135] + sp[SP_BG + ec + 7]);
-        const int hd = ec >> 4;
-        if (W == 1) {
-          in_l = QA[er * C16_QSL + hd * C16_QH + 96];
-          in_av0 = *reinterpret_cast<const float4*>(AG + er * ND_XS + ec); in_av1 = *reinterpret_cast<const float4*>(AG + er * ND_XS + ec + 4);
-        } else {   // merge the W partial softmax sums of the row (head ec >> 4): common maximum, rescale, add
-          float mm = -INFINITY;
-          for (int p = 0; p < W; ++p) mm = fmaxf(mm, QA[(er * W + p) * C16_QSL + hd * C16_QH + 97]);
-          for (int p = 0; p < W; ++p) {
-            const int slot = er * W + p;
-            const float mp = QA[slot * C16_QSL + hd * C16_QH + 97];
-            const float sc = (mp == -INFINITY) ? 0.f : exp2f(mp - mm);
-            in_l = fmaf(QA[slot * C16_QSL + hd * C16_QH + 96], sc, in_l);
-            const float* avp = AG + (8 + slot) * ND_XS + ec;
-            const float4 a0 = *reinterpret_cast<const float4*>(avp), a1 = *reinterpret_cast<const float4*>(avp + 4);
-            in_av0.x = fmaf(a0.x, sc, in_av0.x); in_av0.y = fmaf(a0.y, sc, in_av0.y); in_av0.z = fmaf(a0.z, sc, in_av0.z); in_av0.w = fmaf(a0.w, sc, in_av0.w);
-            in_av1.x = fmaf(a1.x, sc, in_av1.x); in_av1.y = fmaf(a1.y, sc, in_av1.y); in_av1.z = fmaf(a1.z, sc, in_av1.z); in_av1.w = fmaf(a1.w, sc, in_av1.w);
-          }
-        }
-      }
-      float agg[8];
-      if (epi) {   // agg = (a_v + fold + l * vb) / (l + 1e-16)   (:89, :100)
-        const float l = in_l;
-        const float inv = 1.f / (l + 1e-16f);
-        const float avv[8] = {in_av0.x, in_av0.y, in_av0.z, in_av0.w, in_av1.x, in_av1.y, in_av1.z, in_av1.w};
+      // gated update (:106-107): g = sigmoid(Wg [agg | x_dst] + bg); u = agg + g * (to_s(x_dst) - agg), on the gate GEMM's accumulators
+      gemm16t<4, 8, NWV, 3>(R, P0h, P0l, ND_AS, wave, lane, issue, [&](auto, int, const floatx4& acc) {
+        float u[4];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) agg[i] = (avv[i] + C[er * ND_CS + ec + i] + l * sp[SP_VB + ec + i]) * inv;
-        planes_store8(P0h + er * ND_AS + ec, P0l + er * ND_AS + ec, agg);
-      }
-      __syncthreads();
-      C16_MARK(17);
-      gemm16s<4, 8, NWV, 3>(R, P0h, P0l, ND_AS, C, ND_CS, wave, lane, issue);
+        for (int r = 0; r < 4; ++r) {
+          const float g = 1.f / (1.f + expf(-(acc[r] + gv[r])));
+          u[r] = agg[r] + g * (sv[r] - agg[r]);
+          C16_DBG(1, 4 * kq + r, col, u[r]);
+        }
+        planes_put(PBh, PBl, u);   // (PB retired as an operand with the barrier above)
+      });
       __syncthreads();
       C16_MARK(18);
-      {   // gated update (:106-107): g = sigmoid(Wg [agg | x_dst] + bg); u = agg + g * (to_s(x_dst) - agg)
-        const float gv[8] = {in_g0.x, in_g0.y, in_g0.z, in_g0.w, in_g1.x, in_g1.y, in_g1.z, in_g1.w};
-        const float sv[8] = {in_s0.x, in_s0.y, in_s0.z, in_s0.w, in_s1.x, in_s1.y, in_s1.z, in_s1.w};
-        float u[8];
-        if (epi) {
-#pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            const float g = 1.f / (1.f + expf(-(C[er * ND_CS + ec + i] + gv[i])));
-            u[i] = agg[i] + g * (sv[i] - agg[i]);
-          }
-        }
-        // (no barrier between the gate and the store: the barrier behind the Fga GEMM already retired P0 as an operand, and C is
-        // not written again before the one below)
-      C16_MARK(19);
-        if (epi) planes_store8(P0h + er * ND_AS + ec, P0l + er * ND_AS + ec, u);
-      }
-      __syncthreads();
-      C16_MARK(20);
-      gemm16s<4, 8, NWV, 4>(R, P0h, P0l, ND_AS, C, ND_CS, wave, lane, issue);
+      gemm16s<4, 8, NWV, 4>(R, PBh, PBl, ND_AS, C, ND_CS, wave, lane, issue);
       __syncthreads();
       C16_MARK(21);
       {   // x = x + LN_post(to_out(u))  (:76), then LN_ffpre(x)  (:77)
@@ -1613,10 +1630,8 @@ __device__ __noinline__ void c16_node_phase(const ChainStep* __restrict__ post, 
             X[er * ND_XS + ec + i] = xv[i];
           }
           row16_ln(xv, sp + SP_LN_FFPRE_W, sp + SP_LN_FFPRE_B, ec, eps);
+          planes_store8(P0h + er * ND_AS + ec, P0l + er * ND_AS + ec, xv);
         }
-        // (no barrier here either: P0 retired with the barrier behind the Fout GEMM; X is read and written by its own thread)
-      C16_MARK(22);
-        if (epi) planes_store8(P0h + er * ND_AS + ec, P0l + er * ND_AS + ec, xv);
       }
       __syncthreads();
       C16_MARK(23);
@@ -1626,7 +1641,7 @@ __device__ __noinline__ void c16_node_phase(const ChainStep* __restrict__ post, 
       gemm16s<16, 8, NWV, 9>(R, P1h, P1l, ND_AS5, C, ND_CS, wave, lane, issue);   // (requests the next PRE's fragments)
       __syncthreads();
       C16_MARK(25);
-      if (epi) {   // x = x + LN_ffpost(FFN)
+      if (epi) {   // x = x + LN_ffpost(FFN); and, its rows in hand, LN_dst(x) of the next layer into PB (:61 of the next layer)
         float y[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) y[i] = C[er * ND_CS + ec + i] + sp[SP_B2 + ec + i];
@@ -1636,14 +1651,18 @@ __device__ __noinline__ void c16_node_phase(const ChainStep* __restrict__ post, 
           y[i] += X[er * ND_XS + ec + i];
           X[er * ND_XS + ec + i] = y[i];
         }
+        if (pre) {
+          row16_ln(y, NLN, NLN + 128, ec, eps);
+          planes_store8(PBh + er * ND_AS + ec, PBl + er * ND_AS + ec, y);
+        }
       }
       __syncthreads();   // X is final for this layer; sp may be restaged
       C16_MARK(26);
     }
-    }
-    C16_MARK(2);
+  }
+  C16_MARK(2);
   if (pre) {
-    // =========================================================== PRE: LN_dst, q | s | g, q~, <q, kb>   (:61-69, :106-107, :114)
+    // =========================================================== PRE: LN_dst, q, q~, <q, kb>, the row queue   (:61-69, :114)
     if (sp_early) {
 #pragma unroll
       for (int i = 0; i < NSPR; ++i)
@@ -1667,40 +1686,35 @@ __device__ __noinline__ void c16_node_phase(const ChainStep* __restrict__ post, 
       }
       if (tid == 0) ctr[0] = 0;
     }
-    if (!post) { issue(I13{}); issue(I14{}); issue(I15{}); }   // (later layers: requested during the previous POST's FFN)
-    __syncthreads();
-    C16_MARK(32);
-    if (epi) {
-      float xn[8];
+    if (!post) {   // the launch's first layer: LN_dst(x) of the rows the kernel loaded
+      issue(I13{}); issue(I14{}); issue(I15{});   // (later layers: requested during the previous POST's FFN)
+      __syncthreads();
+      C16_MARK(32);
+      if (epi) {
+        float xn[8];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) xn[i] = X[er * ND_XS + ec + i];
-      row16_ln(xn, sp + SP_LN_DST_W, sp + SP_LN_DST_B, ec, eps);
-      planes_store8(P0h + er * ND_AS + ec, P0l + er * ND_AS + ec, xn);
-    }
-    __syncthreads();
-    C16_MARK(33);
-    gemm16s<4, 8, NWV, 13>(R, P0h, P0l, ND_AS, C, ND_CS, wave, lane, issue);   // q (to_s / to_g: the POST half)
-    __syncthreads();
-    C16_MARK(34);
-    if (epi) {
-      float q[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        q[i] = C[er * ND_CS + ec + i] + sp[SP_BQ + ec + i];
-        AG[er * ND_XS + ec + i] = q[i];
+        for (int i = 0; i < 8; ++i) xn[i] = X[er * ND_XS + ec + i];
+        row16_ln(xn, sp + SP_LN_DST_W, sp + SP_LN_DST_B, ec, eps);
+        planes_store8(PBh + er * ND_AS + ec, PBl + er * ND_AS + ec, xn);
       }
-      planes_store8(P0h + er * ND_AS + ec, P0l + er * ND_AS + ec, q);
-      // cq[row][h] = <q_h, kb_h>: 16 fmas in column order; the even thread of a head's pair takes columns 0..7, the odd one goes on from its sum
-      float a0 = 0.f;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) a0 = fmaf(q[i], sp[SP_KB + ec + i], a0);
-      float a1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a0), 0x111, 0xf, 0xf, true));   // row_shr:1
-#pragma unroll
-      for (int i = 0; i < 8; ++i) a1 = fmaf(q[i], sp[SP_KB + ec + i], a1);
-      if (tid & 1) CQ[er * 8 + (ec >> 4)] = a1;
+      __syncthreads();
+      C16_MARK(33);
     }
-    __syncthreads();
-    C16_MARK(35);
+    // q on the GEMM's accumulators: the fp32 rows for the edge phase (AG) and the operand planes of q~ (P0)
+    gemm16t<4, 8, NWV, 13>(R, PBh, PBl, ND_AS, wave, lane, issue, [&](auto, int, const floatx4& acc) {
+      float q[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        q[r] = acc[r] + bq_n;
+#ifdef PS_C16_DBG
+        if (g_c16_dbg && dbg_layer == 100 && 4 * kq + r < nrows) g_c16_dbg[((size_t)2 * g_c16_dbg_rows + row0 + 4 * kq + r) * 128 + col] = q[r];
+#endif
+        AG[(4 * kq + r) * ND_XS + col] = q[r];
+      }
+      planes_put(P0h, P0l, q);
+    });
+    __syncthreads();   // (... and the small vectors, the row queue)
+    C16_MARK(34);
     // q~[row][h][c] = sum_d q[row][16h + d] * Wkr_g3[16h + d][c]: (head, 16-column tile) pairs over the waves
     {
       constexpr int NTQ = 6;
@@ -1718,10 +1732,17 @@ __device__ __noinline__ void c16_node_phase(const ChainStep* __restrict__ post, 
         for (int r = 0; r < 4; ++r)
           if (4 * kq + r < nrows) QA[((W == 1 ? 0 : 8) + 4 * kq + r) * C16_QSL + h * C16_QH + nt * 16 + mi] = fmaf(acx[r], PS_LO_INV, acc[r]);
       });
+      if (lane < 16) {   // cq[row][h] = <q_h, kb_h>: 16 (row, head) pairs per wave, each its 16 fmas in column order
+        const int idx = 16 * wave + lane, r = idx >> 3, h = idx & 7;
+        float a = 0.f;
+#pragma unroll
+        for (int d = 0; d < DH; ++d) a = fmaf(AG[r * ND_XS + h * DH + d], sp[SP_KB + h * DH + d], a);
+        CQ[r * 8 + h] = a;
+      }
     }
     __syncthreads();   // q~ rows, cq, the row queue: visible to every wave
     C16_MARK(36);
-    }
+  }
 }
 
 // NWV: waves per workgroup (8: one workgroup per CU, two waves per SIMD hide each other's latency; 4: two workgroups per CU).
@@ -1775,14 +1796,14 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) __attribute__((disable_
   // needs differ (the edge phase's accumulators and operands, the node phases' weight-fragment ring) and inlined into one
   // body each pushed the other's into scratch.
   const unsigned smem_a = lds_addr(c16_smem);
-  c16_node_phase<NWV>(nullptr, steps, smem_a, row0, nrows, W, eps, prof);
+  c16_node_phase<NWV>(nullptr, steps, smem_a, row0, nrows, W, eps, prof C16_DBG_ARG(100));
   C16_MARK(0);
   for (int s = 0; s < nsteps; ++s) {
     c16_edge_phase<NWV, ONEW>(steps + s, c16_smem, AG, CQ, ctr, QA, div32, row0, nrows, W);
     __syncthreads();   // every row's sums are in place; the wave-private areas are dead
     C16_MARK(1);
     const bool last = s + 1 == nsteps;
-    c16_node_phase<NWV>(steps + s, last ? nullptr : steps + s + 1, smem_a, row0, nrows, W, eps, prof);
+    c16_node_phase<NWV>(steps + s, last ? nullptr : steps + s + 1, smem_a, row0, nrows, W, eps, prof C16_DBG_ARG(s));
     C16_MARK(2);
   }
   {   // the residual rows leave (the last POST half ends behind a barrier).  Here and not in the node phase: on gfx9 a store counts on vmcnt like
