@@ -1484,6 +1484,9 @@ __device__ __noinline__ void c16_node_phase(const ChainStep* __restrict__ post, 
     ee_pre = ldgi(neoff + row0 + tid + 1);
   }
   const int col = 16 * wave + mi;   // this lane's column of the wave's 128-column tile (accumulator element r: row 4 kq + r)
+  // all 16 rows exist and each has one wave: the common case gets straight-line code (no per-row predicates between the loads, the matrix instructions
+  // and the stores of a stage: a predicate is a basic-block boundary, and hipcc schedules inside basic blocks)
+  const bool full = __builtin_amdgcn_readfirstlane(nrows) == ND_ROWS && __builtin_amdgcn_readfirstlane(W) == 1;
   const float bq_n = pre ? ldg1(nsp + SP_BQ + col) : 0.f;   // the next layer's to_q bias where the q GEMM's accumulators will want it
   auto planes_put = [&](_Float16* __restrict__ Ph, _Float16* __restrict__ Pl, const float (&v)[4]) {   // accumulator layout -> split-fp16 operand planes
 #pragma unroll
@@ -1508,26 +1511,15 @@ __device__ __noinline__ void c16_node_phase(const ChainStep* __restrict__ post, 
       // to_s / to_g's x_dst half of LN_dst(x) (:106-107): x has not changed since this layer's PRE half made q from the same rows, so the two
       // projections are made HERE, next to their only use, from the planes the PRE half left in PB.
       issue(I0{}); issue(I1{}); issue(I2{});
-      gemm16t<4, 16, NWV, 0>(R, PBh, PBl, ND_AS, wave, lane, issue, [&](auto jc, int, const floatx4& acc) {   // tile w: s, tile w + 8: g
-        constexpr int j = decltype(jc)::value;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          if constexpr (j == 0) { sv[r] = acc[r] + sp[SP_BS + col]; C16_DBG(3, 4 * kq + r, col, sv[r]); }
-          else { gv[r] = acc[r] + sp[SP_BG + col]; C16_DBG(4, 4 * kq + r, col, gv[r]); }
-        }
-      });
       {   // fold: f[row][16h + d] = sum_c a_r[row][h][c] * Wvr_g3[c][16h + d], head h = wave; then agg = (a_v + f + l * vb) / (l + 1e-16)   (:89, :100)
+        // (the row sums first: LDS reads and conversions that need no weights, while the layer's first fragments are on their way)
         const int h = wave;
         float av_[3][8];
-        half8 bh[3], bl[3];
 #pragma unroll
         for (int ks = 0; ks < 3; ++ks) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) av_[ks][j] = 0.f;
-          bh[ks] = R.h[2][ks];   // (item 2)
-          bl[ks] = R.l[2][ks];
         }
-        issue(I5{});
         if (mi < nrows && W == 1) {   // one wave per row: the row's sums as they are (all six loads in flight at once)
           const float* ap_ = QA + mi * C16_QSL + h * C16_QH + kq * 8;
           float4 a0[3], a1[3];
@@ -1579,15 +1571,33 @@ __device__ __noinline__ void c16_node_phase(const ChainStep* __restrict__ post, 
             }
           }
         }
+        half8 ah[3], al[3];
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { ah[ks][j] = f16_hi(av_[ks][j]); al[ks][j] = f16_los(av_[ks][j]); }
+        }
+        gemm16t<4, 16, NWV, 0>(R, PBh, PBl, ND_AS, wave, lane, issue, [&](auto jc, int, const floatx4& acc) {   // tile w: s, tile w + 8: g
+          constexpr int j = decltype(jc)::value;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if constexpr (j == 0) { sv[r] = acc[r] + sp[SP_BS + col]; C16_DBG(3, 4 * kq + r, col, sv[r]); }
+            else { gv[r] = acc[r] + sp[SP_BG + col]; C16_DBG(4, 4 * kq + r, col, gv[r]); }
+          }
+        });
+        half8 bh[3], bl[3];
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) {
+          bh[ks] = R.h[2][ks];   // (item 2)
+          bl[ks] = R.l[2][ks];
+        }
+        issue(I5{});
         floatx4 acc = {0.f, 0.f, 0.f, 0.f}, acx = acc;
 #pragma unroll
         for (int ks = 0; ks < 3; ++ks) {
-          half8 ah, al;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) { ah[j] = f16_hi(av_[ks][j]); al[j] = f16_los(av_[ks][j]); }
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[ks], acc, 0, 0, 0);
-          acx = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[ks], acx, 0, 0, 0);
-          acx = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[ks], acx, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ks], bh[ks], acc, 0, 0, 0);
+          acx = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ks], bl[ks], acx, 0, 0, 0);
+          acx = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[ks], bh[ks], acx, 0, 0, 0);
         }
         const float vb = sp[SP_VB + col];
 #pragma unroll
@@ -1718,6 +1728,28 @@ __device__ __noinline__ void c16_node_phase(const ChainStep* __restrict__ post, 
     // q~[row][h][c] = sum_d q[row][16h + d] * Wkr_g3[16h + d][c]: (head, 16-column tile) pairs over the waves
     {
       constexpr int NTQ = 6;
+      if (full) {
+        floatx4 qt[NTQ];
+        static_for<0, NTQ>([&](auto gc) {
+          constexpr int g = decltype(gc)::value, slot = (14 + g / 3) % C16_DEPTH, j = g % 3;
+          const half8 bh = R.h[slot][j], bl = R.l[slot][j];
+          const int t = wave + NWV * g, h = t / NTQ;
+          const half8 ah = *reinterpret_cast<const half8*>(P0h + mi * ND_AS + (h >> 1) * 32 + kq * 8);
+          const half8 al = *reinterpret_cast<const half8*>(P0l + mi * ND_AS + (h >> 1) * 32 + kq * 8);
+          floatx4 acc = {0.f, 0.f, 0.f, 0.f}, acx = acc;
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc, 0, 0, 0);
+          acx = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acx, 0, 0, 0);
+          acx = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acx, 0, 0, 0);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) qt[g][r] = fmaf(acx[r], PS_LO_INV, acc[r]);
+        });
+        static_for<0, NTQ>([&](auto gc) {
+          constexpr int g = decltype(gc)::value;
+          const int t = wave + NWV * g, h = t / NTQ, nt = t - h * NTQ;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) QA[(4 * kq + r) * C16_QSL + h * C16_QH + nt * 16 + mi] = qt[g][r];
+        });
+      } else
       static_for<0, NTQ>([&](auto gc) {   // tile t = wave + 8 g: items 14 (g < 3) and 15
         constexpr int g = decltype(gc)::value, slot = (14 + g / 3) % C16_DEPTH, j = g % 3;
         const half8 bh = R.h[slot][j], bl = R.l[slot][j];
