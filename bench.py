@@ -563,7 +563,7 @@ def main():
                                  "rate understates the chip: chip_algorithmic_tflops = all policy launches of the timed region / its wall time.  "
                                  "What bounds the launch: DESIGN.md section 0a / 4 (edge phase: the dependent LDS / MFMA / cross-lane chain of a 16-edge tile at two waves per SIMD "
                                  "over a VALU floor that round 5 cut from 448 to 348 static instructions per tile -- 51.6 M -> 41.1 M VALU instructions per launch for 5 % of its time, "
-                                 "so issue count is no longer the first limiter; node phase: the dependent stage chain of a 16-row layer -- GEMM, LDS, barrier, epilogue, 17 barriers per layer; with every weight-fragment load an L1 hit it is only 10 % faster).",
+                                 "so issue count is no longer the first limiter; node phase: the dependent stage chain of a 16-row layer -- GEMM, LDS, barrier, epilogue; 9 barriers per layer since round 6 (15 before), the elementwise steps on the GEMMs' accumulators, a layer's 960 KB of weight fragments as one compile-time stream through a ring of three register slots at 64 B/clk per CU).",
                          "algorithmic_bytes": alg_bytes["total"], "algorithmic_bytes_parts": alg_bytes,
                          "traffic_over_algorithmic_bytes": (traffic / alg_bytes["total"]) if traffic else None,
                          "algorithmic_flops_per_launch": fl_alg,
