@@ -25,9 +25,9 @@ import time
 # plus torch's, and with 4 queues the engines' graph replays serialise behind one another (4 engines in flight: 9.5 M
 # agent-steps/s with 4 queues, 16.7 M with 8).  Round 5: 16 -- every stream beyond the queue count SHARES a queue, and a job with
 # RCCL's streams beside the engines', the upload stream and torch's own crosses 8 (the forced-distributed line fell from 26.8 to
-# 15.4 M at 8 queues; prosim_amd.configure_runtime() does the same for other users of the package).  Must be set before the runtime
-# initialises.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+# 15.4 M at 8 queues; prosim_amd.configure_runtime() does the same for other users of the package).  Round 6: 24, for 16 engines in flight
+# (with 16 queues that many engines fell back to 27.7 M; with 24: 30.0 M).  Must be set before the runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 
 import numpy as np
 import torch
@@ -216,9 +216,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--chain-rows", type=int, default=-1, choices=[-1, 0, 1, 2, 4, 8, 9, 10, 11, 12, 13, 14, 15, 16],
                     help="rows per workgroup of the fused attention launches (ps_set_chain_rows); -1: 16 when rollouts are pipelined, else 0")
-    ap.add_argument("--inflight", type=int, default=4,
+    ap.add_argument("--inflight", type=int, default=16,
                     help="rollouts in flight per GPU: consecutive steps alternate between this many engines (own buffers and "
-                         "stream each) that hold the same resident batch, so step k+1 starts while step k drains")
+                         "stream each) that hold the same resident batch, so step k+1 starts while step k drains.  Multiples of 4 "
+                         "(4 policy launches of 64 workgroups fill the 256 CUs); the line reports 4 and 8 beside the default")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -302,7 +303,7 @@ def main():
     torch.cuda.synchronize()   # (these tensors were filled on torch's default stream and are read on the engines' non-blocking streams: order them once)
 
     def step():
-        i = state["k"] % n_fl
+        i = state["k"] % state.get("n_fl", n_fl)
         state["k"] += 1
         engines[i].rollout()
         engines[i].pair_metric(metric_bufs[i].data_ptr(), t_tgt.data_ptr(), t_msk.data_ptr())
@@ -386,14 +387,46 @@ def main():
     # an event pair around every policy launch (such rollouts are launched eagerly -- events do not survive graph replay
     # on ROCm 7.2 -- at ~1 ms of host time each against a 6 ms step), read after the last one
     trace("timed region done; event-timed policy launches")
+    # ... at FOUR rollouts in flight: four 64-workgroup launches have the 256 CUs to themselves.  Deeper than that (the timed region runs 16) a
+    # launch's workgroups queue for CUs behind other engines' launches and the event pair -- like rocprofv3's kernel duration -- times the queue
+    # (ev_full_ms below: reported, not used for the roofline).
+    n_ev = min(n_fl, 4)
     for e_ in engines:
+        e_.sync()
+    state["n_fl"] = n_ev
+    for e_ in engines[:n_ev]:
+        e_.enable_policy_events(True)
+    for _ in range(2 * n_ev):
+        step()
+    ev_ms = np.concatenate([e_.policy_event_times() for e_ in engines[:n_ev]])
+    state.pop("n_fl", None)
+    for e_ in engines:
+        e_.sync()
         e_.enable_policy_events(True)
     for _ in range(2 * n_fl):
         step()
-    ev_ms = np.concatenate([e_.policy_event_times() for e_ in engines])
+    ev_full_ms = np.concatenate([e_.policy_event_times() for e_ in engines])
     for e_ in engines:
         e_.enable_policy_events(False)
     value = total_agents * spec.max_steps / (dt / args.steps)
+    for e_ in engines:
+        e_.sync()
+    # the same loop with fewer rollouts in flight (this rank's own rate, no collective): what the depth of the pipeline is worth
+    by_inflight = {str(n_fl): A * spec.max_steps / (dt / args.steps) if not multi else None}
+    for n_sub in (4, 8):
+        if n_sub < n_fl:
+            state["n_fl"] = n_sub
+            for _ in range(2 * n_sub):
+                step()
+            for e_ in engines:
+                e_.sync()
+            t_sub = time.perf_counter()
+            for _ in range(max(32, args.steps // 2)):
+                step()
+            for e_ in engines:
+                e_.sync()
+            by_inflight[str(n_sub)] = A * spec.max_steps * max(32, args.steps // 2) / (time.perf_counter() - t_sub)
+    state.pop("n_fl", None)
     step()
     compute_metrics()
     for e_ in engines:
@@ -494,14 +527,14 @@ def main():
         new_batches = [synth.baseline_scene(spec, args.config, seed=1000 + i, batch=S) for i in range(6)]
         streaming = {"workload": f"stream of NEW {S}-scene batches (host arrays -> ps_set_scene -> rollout -> traj / vel read back), RolloutPipeline, "
                                  "16 rows per workgroup from depth 2", "agent_steps_per_s_by_depth": {}, "ms_per_batch_by_depth": {}}
-        for depth in (1, 2, 3, 4):
+        for depth in (1, 2, 4, 8, 16):
             trace(f"streaming depth {depth}")
             with RolloutPipeline(spec, w, device=dev_index, depth=depth) as pipe:
                 for _ in pipe.run(new_batches[:depth]):
                     pass
                 t_s = time.perf_counter()
                 # (the pipeline's fill and drain -- 2 x depth batches deep, one rollout latency each way -- stay a small part of the timed region)
-                n_b = sum(1 for _ in pipe.run(new_batches * (8 if depth < 3 else 24)))
+                n_b = sum(1 for _ in pipe.run(new_batches * (8 if depth < 3 else 6 * depth)))
                 dt_s = time.perf_counter() - t_s
             streaming["agent_steps_per_s_by_depth"][str(depth)] = n_b * A * spec.max_steps / dt_s
             streaming["ms_per_batch_by_depth"][str(depth)] = 1e3 * dt_s / n_b
@@ -545,7 +578,8 @@ def main():
             "config": {"workload": f"{S} x BASELINE configs[{args.config}] scenes per GPU ({synth.BASELINE_CONFIGS[args.config]['name']}; "
                                    f"S=8 is configs[3]'s per-GPU share), 80-step closed-loop rollout (8 replans), seeded random-init weights",
                        "agents_per_scene": int(scene['prompt_mask'][0].sum()), "polylines_per_scene": int(scene['map_mask'].shape[1]),
-                       "scenes_per_gpu": S, "scenes_total": n_scenes, "rollouts_in_flight": n_fl, "chain_rows_per_workgroup": chain_rows,
+                       "scenes_per_gpu": S, "scenes_total": n_scenes, "rollouts_in_flight": n_fl, "agent_steps_per_s_by_rollouts_in_flight_rank0": by_inflight,
+                       "chain_rows_per_workgroup": chain_rows,
                        "parallelism": f"scene-sharded x{world}, RCCL all-gather of the per-agent PairMotionPred sums; consecutive steps pipelined over "
                                       f"{n_fl} engine(s) per GPU"},
             # bound: what the counters of the launch say (profiles/r03_*_pmc_chain16.txt: the VALU busy more than half of the SIMD
@@ -574,9 +608,12 @@ def main():
                          "hbm_gbps": (traffic / (ms_launch * 1e-3) / 1e9) if traffic else None, "hbm_peak_gbps": 8000.0,
                          "avg_launch_ms": ms_launch,
                          "launch_timing": f"HIP event pairs around the policy launches on each engine's stream, in the same pipelined loop as the timed "
-                                          f"region (run right after it with {n_fl} rollouts in flight, launched eagerly: events do not survive graph "
-                                          f"replay): the {len(ev_ms)} launches of each engine's last rollout (min {float(ev_ms.min()):.3f} / max "
-                                          f"{float(ev_ms.max()):.3f} ms); alone on the GPU the same launch takes launch_alone_ms",
+                                          f"region, run right after it with {min(n_fl, 4)} rollouts in flight (four 64-workgroup launches share the 256 CUs without queueing; launched "
+                                          f"eagerly: events do not survive graph replay): the {len(ev_ms)} launches of each engine's last rollout (min "
+                                          f"{float(ev_ms.min()):.3f} / max {float(ev_ms.max()):.3f} ms); alone on the GPU the same launch takes launch_alone_ms; with all "
+                                          f"{n_fl} rollouts of the timed region in flight a launch's workgroups wait for CUs and the same event pairs read "
+                                          f"avg_launch_ms_with_cu_queueing",
+                         "avg_launch_ms_with_cu_queueing": float(ev_full_ms.mean()),
                          "launch_alone_ms": ms_chain,
                          "workgroups": n_wg if c16 else None,
                          "occupied_cus": min(n_wg, 256) if c16 else None,

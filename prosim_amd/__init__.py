@@ -10,7 +10,7 @@ import os as _os
 import warnings as _warnings
 
 
-def configure_runtime(hw_queues: int = 16) -> bool:
+def configure_runtime(hw_queues: int = 24) -> bool:
     """One hardware queue per stream: call this BEFORE the process makes its first HIP call (before torch touches the GPU, before the
     first Engine).  The HIP runtime folds streams onto GPU_MAX_HW_QUEUES (default 4) hardware queues; a serving process runs several
     engines (non-blocking streams) beside the upload stream, torch's own streams and RCCL's, and engines that share a queue serialise

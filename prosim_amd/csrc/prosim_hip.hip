@@ -2164,7 +2164,9 @@ void launch_radius(ps_engine* e, const RadArgs* a, int nsets, const float* qpos,
     rs.s[i] = RadSet{CandSet{e->d_tok_pos.p, a[i].r1, a[i].r2}, a[i].r * a[i].r, a[i].cap, a[i].self_base, es.cnt.p,
                      es.eoff.p, es.toff.p, es.tdst.p, es.esrc.p, es.edst.p, a[i].cand_ok, a[i].cand_base};
   }
-  const int wpb = 4, grid = (nq + wpb - 1) / wpb;
+  // a wave per query; from 1024 queries on 16 waves per workgroup instead of 4: the same waves on a quarter of the CUs -- these kernels wait for memory
+  // (a chain of dependent loads per wave), and a CU that holds one of their waves cannot start a k_chain16 workgroup (248 registers x 2 waves per SIMD)
+  const int wpb = nq >= 1024 ? 16 : 4, grid = (nq + wpb - 1) / wpb;
   hipStream_t st = e->stream;
   rs.scanned = nq > CSR_PREFIX_MAX_Q ? 1 : 0;
   {

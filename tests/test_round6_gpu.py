@@ -80,21 +80,27 @@ def test_rollouts_repeat_their_bits_under_load_and_match_the_reference(probe_imp
             e.close()
 
 
-def test_streamed_batches_at_depth_four_against_the_reference():
-    """bench.py's `streaming` leg: RolloutPipeline(depth=4) over 24 DIFFERENT 8-scene configs[2] batches (the eight reference-made scenes
-    in 24 different orders: the model never mixes batch elements, a scene's trajectories do not depend on its place or its neighbours),
-    four batches in flight on four engines -- every returned trajectory against the reference's fp32 forward of its scene."""
+@pytest.mark.parametrize("depth,n_batches", [(4, 24), (16, 48)])
+def test_streamed_batches_against_the_reference(depth, n_batches):
+    """bench.py's `streaming` leg at its deepest setting (16 engines in flight since the end of round 6; 4 until then): RolloutPipeline over DIFFERENT
+    8-scene configs[2] batches (the eight reference-made scenes in as many different orders: the model never mixes batch elements, a scene's
+    trajectories do not depend on its place or its neighbours), `depth` batches in flight on as many engines -- every returned trajectory against
+    the reference's fp32 forward of its scene."""
     from prosim_amd.stream import RolloutPipeline
     from parity_table import record, per_agent
     spec = DEMO_SPEC
     w = weights.init_weights(spec, 0)
     rng = np.random.RandomState(6)
-    orders = [list(range(8))] + [list(np.roll(np.arange(8), r)) for r in range(1, 8)] + [list(rng.permutation(8)) for _ in range(16)]
-    assert len({tuple(o) for o in orders}) == 24
+    orders = [list(range(8))] + [list(np.roll(np.arange(8), r)) for r in range(1, 8)]
+    while len(orders) < n_batches:
+        o = list(rng.permutation(8))
+        if o not in orders:
+            orders.append(o)
+    assert len({tuple(o) for o in orders}) == n_batches
     fixtures = [_fixture(s) for s in range(8)]
     by_scene = {}
     d_all = []
-    with RolloutPipeline(spec, w, depth=4, outputs=("traj",)) as pipe:
+    with RolloutPipeline(spec, w, depth=depth, outputs=("traj",)) as pipe:
         for i, out in pipe.run(_batch(o) for o in orders):
             for b, s in enumerate(orders[i]):
                 g = fixtures[s]
@@ -107,6 +113,6 @@ def test_streamed_batches_at_depth_four_against_the_reference():
                 else:
                     by_scene[s] = out["traj"][b].copy()
     d_all = np.concatenate(d_all)
-    record("bench_workload/streaming_depth4", **per_agent(d_all))
-    print(f"24 streamed batches vs the reference: max {d_all.max():.2e} median {np.median(d_all):.2e} within 1e-4: {(d_all < 1e-4).sum()} / {d_all.size}")
+    record(f"bench_workload/streaming_depth{depth}", **per_agent(d_all))
+    print(f"{n_batches} streamed batches at depth {depth} vs the reference: max {d_all.max():.2e} median {np.median(d_all):.2e} within 1e-4: {(d_all < 1e-4).sum()} / {d_all.size}")
     assert (d_all < 1e-4).mean() >= 0.995 and np.median(d_all) < 3e-5
