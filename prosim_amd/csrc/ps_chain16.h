@@ -1069,6 +1069,9 @@ __device__ __noinline__ void c16_edge_phase(const ChainStep* __restrict__ stp, u
   // this function and pays ONE look-up of the dynamic-LDS base per call for it.  Handing the wave areas over as an opaque address -- round 6 tried --
   // returned wrong sums for every row in the one-wave-per-row form, for a reason not found: profiles/r06_q_node_phase.txt)
   const EdgeIO none{};
+#ifdef PS_EDGE_OPAQUE   // (tools only: the anomaly of DESIGN 7.4 item 6 -- the wave areas from an opaque LDS address, in the policy launch's copy of the function only)
+  if (TAG == 2) c16_smem = lds_ptr<unsigned char>(lds_addr(c16_smem));
+#endif
   c16_edge_body<NWV, ONEW, false>(stp, c16_smem, AG, CQ, ctr, QA, div32, row0, nrows, W, none);
   // nothing of this phase may still be in flight when the node phase reuses the wave areas as its operand planes (the workgroup barrier does
   // not wait for vmcnt; until round 6 the node phase happened to begin with a pointer load behind s_waitcnt vmcnt(0))
@@ -1831,6 +1834,10 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) __attribute__((disable_
   c16_node_phase<NWV>(nullptr, steps, smem_a, row0, nrows, W, eps, prof C16_DBG_ARG(100));
   C16_MARK(0);
   for (int s = 0; s < nsteps; ++s) {
+#ifdef PS_EDGE_OPAQUE
+    if (POLICY) c16_edge_phase<NWV, ONEW, 2>(steps + s, c16_smem, AG, CQ, ctr, QA, div32, row0, nrows, W);
+    else
+#endif
     c16_edge_phase<NWV, ONEW>(steps + s, c16_smem, AG, CQ, ctr, QA, div32, row0, nrows, W);
     __syncthreads();   // every row's sums are in place; the wave-private areas are dead
     C16_MARK(1);
