@@ -91,6 +91,10 @@ def split(line: str):
     raise ValueError("both orders overwrite a source (needs a temporary): " + line.strip())
 
 
+# PS_ASM_NOP_AFTER_SWAP=1 (tools only): two wait states behind every v_permlane16/32_swap_b32 -- does a consumer right behind the swap matter?
+_NOP_AFTER_SWAP = bool(int(__import__("os").environ.get("PS_ASM_NOP_AFTER_SWAP", "0")))
+
+
 def legalize(text: str):
     out, counts, name = [], {}, None
     for line in text.splitlines():
@@ -100,6 +104,8 @@ def legalize(text: str):
         rep = split(line)
         if rep is None:
             out.append(line)
+            if _NOP_AFTER_SWAP and re.match(r"^\s*v_permlane(16|32)_swap_b32", line):   # (experiment switch: see the module's end)
+                out.append("\ts_nop 1")
         else:
             out.extend(rep)
             counts[name] = counts.get(name, 0) + 1

@@ -1584,8 +1584,13 @@ __device__ __noinline__ void c16_node_phase(const ChainStep* __restrict__ post, 
           constexpr int j = decltype(jc)::value;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
+#ifdef PS_C16_DBG_SUMS
+            if constexpr (j == 0) sv[r] = acc[r] + sp[SP_BS + col];
+            else gv[r] = acc[r] + sp[SP_BG + col];
+#else
             if constexpr (j == 0) { sv[r] = acc[r] + sp[SP_BS + col]; C16_DBG(3, 4 * kq + r, col, sv[r]); }
             else { gv[r] = acc[r] + sp[SP_BG + col]; C16_DBG(4, 4 * kq + r, col, gv[r]); }
+#endif
           }
         });
         half8 bh[3], bl[3];
@@ -1610,6 +1615,9 @@ __device__ __noinline__ void c16_node_phase(const ChainStep* __restrict__ post, 
           const float inv = 1.f / (l + 1e-16f);
           agg[r] = (av4[r] + f + l * vb) * inv;
           C16_DBG(0, 4 * kq + r, col, agg[r]); C16_DBG(5, 4 * kq + r, col, f);
+#ifdef PS_C16_DBG_SUMS   // (planes 3 | 4 carry the row's l and a_v instead of s and g)
+          C16_DBG(3, 4 * kq + r, col, l4[r]); C16_DBG(4, 4 * kq + r, col, av4[r]);
+#endif
         }
         planes_put(P0h, P0l, agg);
       }
