@@ -672,6 +672,9 @@ __device__ __forceinline__ void c16_edge_body(const ChainStep* __restrict__ stp,
   const int hv = (lane & 31) >> 2, eh = lane >> 5;
   for (int it = 0;; ++it) {
     int lr, part;
+#ifdef PS_EDGE_ONEWAVE   // (tools only, DESIGN 7.4 item 6: wave 0 walks the whole row queue alone -- does the anomaly need a second wave?)
+    if (ONEW && !DIRECT && wave != 0) break;
+#endif
     if (DIRECT) {  // static: one row per wave
       if (it > 0) break;
       lr = wave;
