@@ -484,28 +484,58 @@ __device__ __forceinline__ unsigned f16_hi_pk(float y0, float y1) {
   const half2v h = {(_Float16)y0, (_Float16)y1};
   return __builtin_bit_cast(unsigned, h);
 }
-// (lo0 | lo1) with lo = fp16(y - float(hi)), hi read from the packed dword
-__device__ __forceinline__ unsigned f16_lo_pk(unsigned hi_pk, float y0, float y1) {
-  unsigned lo;
-  asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(hi_pk), "v"(y0));
-  asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(hi_pk), "v"(y1));
-  return lo;
-}
+// (lo0 | lo1) with lo = fp16(y - float(hi)), hi read from the packed dword -- in GROUPS of N dwords per asm block, closed by two wait states.
+// Round 6: v_fma_mixlo_f16 / v_fma_mixhi_f16 write HALF a register (dst_sel), and gfx950 needs wait states between such a write and
+// an instruction that reads the register -- hipcc inserts them for its own instructions and cannot for inline assembly.  With one asm statement per
+// instruction the compiler was free to put a v_mfma right behind the last v_fma_mixhi of an operand; the shipped builds never did, an experiments build of
+// this round did (its a_r sums were wrong in most rows, differently from run to run: a_r's A operand was read before its second half had landed).  Now:
+// all the lo halves of a group first, then the hi halves (each register's two writes N - 1 instructions apart), then s_nop 1 -- whatever hipcc schedules
+// behind the block is two wait states away.  Same instructions on the same values: the bits do not change; four compiler-inserted s_nop 0 per group are gone.
+template <int N> struct MixAsm;
+template <> struct MixAsm<2> {
+  static __device__ __forceinline__ void run(const unsigned (&h)[2], const float (&y)[4], float m, unsigned (&r)[2]) {
+    asm("v_fma_mixlo_f16 %0, %2, %8, %4 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixlo_f16 %1, %3, %8, %6 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %0, %2, %8, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %1, %3, %8, %7 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "s_nop 1"
+        : "=&v"(r[0]), "=&v"(r[1]) : "v"(h[0]), "v"(h[1]), "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "v"(m));
+  }
+};
+template <> struct MixAsm<4> {
+  static __device__ __forceinline__ void run(const unsigned (&h)[4], const float (&y)[8], float m, unsigned (&r)[4]) {
+    asm("v_fma_mixlo_f16 %0, %4, %16, %8 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixlo_f16 %1, %5, %16, %10 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixlo_f16 %2, %6, %16, %12 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixlo_f16 %3, %7, %16, %14 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %0, %4, %16, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %1, %5, %16, %11 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %2, %6, %16, %13 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %3, %7, %16, %15 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "s_nop 1"
+        : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3])
+        : "v"(h[0]), "v"(h[1]), "v"(h[2]), "v"(h[3]), "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "v"(y[4]), "v"(y[5]), "v"(y[6]), "v"(y[7]), "v"(m));
+  }
+};
 // per lane and lane-uniformly chosen half: m = -1 gives the lo halves fp16(y - float(hi)), m = -0 the hi halves fp16(y - 0) -- the
 // (p hi | p lo) and (q hi | q lo) operands whose half depends on the lane take ONE instruction per value instead of both halves + a select
-__device__ __forceinline__ unsigned f16_sel_pk(unsigned hi_pk, float y0, float y1, float m) {
-  unsigned r;
-  asm("v_fma_mixlo_f16 %0, %1, %3, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hi_pk), "v"(y0), "v"(m));
-  asm("v_fma_mixhi_f16 %0, %1, %3, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(r) : "v"(hi_pk), "v"(y1), "v"(m));
-  return r;
-}
 // 8 floats -> the lane's half (hi or lo by m) as an MFMA operand
 __device__ __forceinline__ half8 f16_sel8(const float (&v)[8], float m) {
-  unsigned r[4];
+  unsigned h[4], r[4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) r[j] = f16_sel_pk(f16_hi_pk(v[2 * j], v[2 * j + 1]), v[2 * j], v[2 * j + 1], m);
+  for (int j = 0; j < 4; ++j) h[j] = f16_hi_pk(v[2 * j], v[2 * j + 1]);
+  MixAsm<4>::run(h, v, m, r);
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
   return __builtin_bit_cast(half8, u32x4{r[0], r[1], r[2], r[3]});
+}
+// 4 floats -> two dwords of the lane's half (the a_r MFMA's A operand)
+__device__ __forceinline__ half4v f16_sel4(const float (&v)[4], float m) {
+  unsigned h[2], r[2];
+  h[0] = f16_hi_pk(v[0], v[1]);
+  h[1] = f16_hi_pk(v[2], v[3]);
+  MixAsm<2>::run(h, v, m, r);
+  typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(half4v, u32x2_{r[0], r[1]});
 }
 
 // this lane's 8 consecutive features (4 pairs) of input block xs, normalised and split: A-fragment order of the
@@ -516,6 +546,7 @@ __device__ __forceinline__ void feat8(float xs, float rstd, float nmr, const f32
   constexpr float C2 = (float)(0.15915494309189535 - (double)0.15915494309189535f);
   const f32x2 x2 = {xs, xs}, c1 = {C1, C1}, c2 = {C2, C2}, rs = {rstd, rstd}, nm = {nmr, nmr};
   unsigned h[4], l[4];
+  float yy[8];
 #pragma unroll
   for (int jj = 0; jj < 2; ++jj) {
     // fdiv16 (x / d exactly) and sincos_hw's reduction to revolutions, two frequencies at a time
@@ -529,9 +560,9 @@ __device__ __forceinline__ void feat8(float xs, float rstd, float nmr, const f32
     const f32x2 y0 = pk_fma(sc0, rs, nm), y1 = pk_fma(sc1, rs, nm);
     h[2 * jj] = f16_hi_pk(y0.x, y0.y);
     h[2 * jj + 1] = f16_hi_pk(y1.x, y1.y);
-    l[2 * jj] = f16_lo_pk(h[2 * jj], y0.x, y0.y);
-    l[2 * jj + 1] = f16_lo_pk(h[2 * jj + 1], y1.x, y1.y);
+    yy[4 * jj] = y0.x; yy[4 * jj + 1] = y0.y; yy[4 * jj + 2] = y1.x; yy[4 * jj + 3] = y1.y;
   }
+  MixAsm<4>::run(h, yy, -1.0f, l);   // lo = fp16(y - float(hi)) (f16_sel8's m = -1)
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
   hi = __builtin_bit_cast(half8, u32x4{h[0], h[1], h[2], h[3]});
   lo = __builtin_bit_cast(half8, u32x4{l[0], l[1], l[2], l[3]});
@@ -947,8 +978,7 @@ __device__ __forceinline__ void c16_edge_body(const ChainStep* __restrict__ stp,
       //      lane's probabilities (row 4 kq + j of column mi = edge 4 kq + j of head mi & 7), B = the feature tile read back
       //      transposed (4 consecutive EDGES of one feature per lane: one ds_read_b64_tr_b16), hi pass then lo pass
       typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-      const half4v ap = __builtin_bit_cast(half4v, u32x2{f16_sel_pk(f16_hi_pk(pr[0], pr[1]), pr[0], pr[1], selm),
-                                                         f16_sel_pk(f16_hi_pk(pr[2], pr[3]), pr[2], pr[3], selm)});
+      const half4v ap = f16_sel4(pr, selm);
       const _Float16* tp = Ft + (kq * 4 + (mi >> 2)) * C16_FS + (lane & 3) * 4;
 #ifdef PS_C16_ABL_NOAR
       ar[0][0] += (float)ap[0] + (float)fl[0][0] + (float)fl[1][0] + (float)fl[2][0];
@@ -1299,8 +1329,7 @@ __device__ __forceinline__ void c16_lat_main(const ChainStep* __restrict__ stp, 
       av.x *= sh; av.y *= sh; av.z *= sh; av.w *= sh;
     }
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-    const half4v ap = __builtin_bit_cast(half4v, u32x2{f16_sel_pk(f16_hi_pk(pr[0], pr[1]), pr[0], pr[1], selm),
-                                                       f16_sel_pk(f16_hi_pk(pr[2], pr[3]), pr[2], pr[3], selm)});
+    const half4v ap = f16_sel4(pr, selm);
     const _Float16* tp = Ft + (kq * 4 + (mi >> 2)) * C16_FS + (lane & 3) * 4;
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
