@@ -49,7 +49,7 @@ def run_stage(e, stage):
     return [raw(e, nm) for nm in names(stage)]
 def kick():
     if poison:
-        rc = lib.ps_test_poison(load[0]._h, 512, pat, 8)
+        rc = lib.ps_test_poison(load[0].h, 512, pat, 8)
         if rc: raise RuntimeError(lib.ps_last_error().decode())
     else:
         for e in load: e.rollout()
