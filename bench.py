@@ -427,6 +427,8 @@ def main():
                 e_.sync()
             by_inflight[str(n_sub)] = A * spec.max_steps * max(32, args.steps // 2) / (time.perf_counter() - t_sub)
     state.pop("n_fl", None)
+    free_b, total_b = torch.cuda.mem_get_info()
+    hbm_in_use_gb = (total_b - free_b) / 1e9   # (the n_fl engines of the timed region with their captured graphs, torch's pools, the metric state)
     step()
     compute_metrics()
     for e_ in engines:
@@ -578,7 +580,7 @@ def main():
             "config": {"workload": f"{S} x BASELINE configs[{args.config}] scenes per GPU ({synth.BASELINE_CONFIGS[args.config]['name']}; "
                                    f"S=8 is configs[3]'s per-GPU share), 80-step closed-loop rollout (8 replans), seeded random-init weights",
                        "agents_per_scene": int(scene['prompt_mask'][0].sum()), "polylines_per_scene": int(scene['map_mask'].shape[1]),
-                       "scenes_per_gpu": S, "scenes_total": n_scenes, "rollouts_in_flight": n_fl, "agent_steps_per_s_by_rollouts_in_flight_rank0": by_inflight,
+                       "scenes_per_gpu": S, "scenes_total": n_scenes, "rollouts_in_flight": n_fl, "hbm_in_use_gb_rank0": hbm_in_use_gb, "agent_steps_per_s_by_rollouts_in_flight_rank0": by_inflight,
                        "chain_rows_per_workgroup": chain_rows,
                        "parallelism": f"scene-sharded x{world}, RCCL all-gather of the per-agent PairMotionPred sums; consecutive steps pipelined over "
                                       f"{n_fl} engine(s) per GPU"},
