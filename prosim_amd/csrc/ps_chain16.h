@@ -485,8 +485,8 @@ __device__ __forceinline__ unsigned f16_hi_pk(float y0, float y1) {
   return __builtin_bit_cast(unsigned, h);
 }
 // (lo0 | lo1) with lo = fp16(y - float(hi)), hi read from the packed dword -- in GROUPS of N dwords per asm block, closed by two wait states.
-// Round 6: v_fma_mixlo_f16 / v_fma_mixhi_f16 write HALF a register (dst_sel), and gfx950 needs wait states between such a write and
-// an instruction that reads the register -- hipcc inserts them for its own instructions and cannot for inline assembly.  With one asm statement per
+// Round 6: on gfx950 a VALU write of a register followed by a v_mfma that reads it needs TWO wait states (tools/mb/mb_mixhi_mfma.hip: no
+// hardware interlock) -- hipcc inserts them for its own instructions and cannot for inline assembly.  With one asm statement per
 // instruction the compiler was free to put a v_mfma right behind the last v_fma_mixhi of an operand; the shipped builds never did, an experiments build of
 // this round did (its a_r sums were wrong in most rows, differently from run to run: a_r's A operand was read before its second half had landed).  Now:
 // all the lo halves of a group first, then the hi halves (each register's two writes N - 1 instructions apart), then s_nop 1 -- whatever hipcc schedules
