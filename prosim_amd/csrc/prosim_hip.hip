@@ -2065,13 +2065,14 @@ void launch_pe_learn(ps_engine* e, EdgeSet& es, const PeLearnW& w) {
 // Fused chain, second generation (ps_chain16.h).  rows per workgroup: the engine's choice keeps >= 256 workgroups in a
 // launch while it can (4 rows at 1024 destinations), ps_set_chain_rows overrides (16 = throughput mode).
 // do the fused chains over Nd destination rows run on k_chain16?  (ps_set_chain_impl; 0 = in throughput mode, and in
-// latency mode from 1024 rows up: 0.47 against 0.53 ms per 1024-row policy launch; below that the round-1 kernel's one
-// small workgroup per row fills the chip better, 0.27 against 0.37 ms at 128 rows)
+// latency mode above 256 rows -- since round 6's node phases: an 8-scene rollout alone 5.7 ms, and 4.6 / 5.2 / 5.4 / 5.5 / 5.6 ms for 3 / 4 / 5 / 6 / 7
+// scenes against 5.6 / 5.9 / 7.2 / 7.5 / 7.7 ms on k_attn_chain's 2- and 4-row builds (tools/gpu_r6_mid_batches.py); up to 256 rows the one-row
+// k_attn_chain with k_chain16's edge body fills the chip better: 3.6 against 4.3 ms for two scenes)
 // (part: 0 scene encoder, 1 generator, 2 policy -- a part with a LEARNABLE rel-PE cannot rebuild its rows from geometry
 // records inside the kernel: it reads the operand images the edge-MLP kernel made, on k_attn_chain)
 bool use_c16(const ps_engine* e, int Nd, int part) {
   if (e->pe_on[part]) return false;
-  return e->chain_impl >= 2 || (e->chain_impl == 0 && (e->chain_rows >= 8 || (e->chain_rows == 0 && Nd >= 1024)));
+  return e->chain_impl >= 2 || (e->chain_impl == 0 && (e->chain_rows >= 8 || (e->chain_rows == 0 && Nd > 256)));
 }
 // do the fused chains over Nd rows run on the ONE-ROW k_attn_chain with k_chain16's edge body (round 5)?  Where launch_chain picks one
 // row per workgroup (below 512 rows: a single scene) in the default implementation; ps_set_chain_impl(1) keeps the operand-image edge

@@ -679,8 +679,10 @@ def test_throughput_mode_rows_per_workgroup(small_engine):
             d = np.abs(small_engine.padded("traj") - o64["traj"].numpy())[pm].reshape(A, -1).max(1)
             assert (d < TOL).mean() >= 0.97 and np.median(d) < 3e-5, (rows, d.max())
             outs[rows] = mp
-        assert np.array_equal(outs[0], outs[2])                       # 0 = the engine's own choice = 2 rows at this size
-        assert err(outs[4][0], outs[0][0]) < 1e-5                     # another tiling, another summation order
+        # 0 = the engine's own choice: k_chain16 above 256 rows since the end of round 6 (the 2- and 4-row builds of k_attn_chain until then), another
+        # kernel, another summation order -- fp32-close, like the two explicit tilings to each other
+        assert err(outs[0][0], outs[2][0]) < 1e-5
+        assert err(outs[4][0], outs[2][0]) < 1e-5
         with pytest.raises(RuntimeError, match="0 .auto., 1, 2, 4, or 8..16"):
             small_engine.set_chain_rows(3)
     finally:
