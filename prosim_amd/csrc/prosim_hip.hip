@@ -2087,7 +2087,9 @@ bool use_geo1(const ps_engine* e, int Nd, int part) {
 }
 int chain16_rows(ps_engine* e, int Nd) {
   static const int env_rows = exp_env("PS_C16_ROWS") ? atoi(exp_env("PS_C16_ROWS")) : 0;   // experiments only
-  int rows = Nd >= 4096 ? 16 : (Nd >= 2048 ? 8 : (Nd >= 512 ? 4 : (Nd >= 256 ? 2 : 1)));
+  // the fewest rows per workgroup that still put the launch on the chip in ONE round of at most 256 workgroups (round 6: a second round of small
+  // workgroups costs more than rows twice as long -- 512 agents: 4.7 against 5.2 ms per rollout with 2 instead of 4 rows, tools/gpu_r6_mid_batches.py)
+  int rows = Nd > 2048 ? 16 : (Nd > 1024 ? 8 : (Nd > 512 ? 4 : (Nd > 256 ? 2 : 1)));
   if (e->chain_rows >= 1 && e->chain_rows <= 16) rows = e->chain_rows;
   if (env_rows) rows = env_rows;
   return rows;

@@ -6,13 +6,13 @@ from prosim_amd.spec import DEMO_SPEC
 from prosim_amd.engine import Engine
 spec = DEMO_SPEC
 w = weights.init_weights(spec, 0)
-for S in (1, 2, 3, 4, 6, 8):
+for S in (10, 12, 16, 20):
     parts = [synth.baseline_scene(spec, 2, seed=i, batch=1) for i in range(S)]
     scene = {k: (np.concatenate([p[k] for p in parts]) if not isinstance(parts[0][k], dict) else
                  {ck: {f: np.concatenate([p[k][ck][f] for p in parts]) for f in parts[0][k][ck]} for ck in parts[0][k]}) for k in parts[0]}
     eng = Engine(spec, w)
     ref = None
-    for impl, rows in ((0, 0), (2, 0), (1, 0)):
+    for impl, rows in ((0, 0),):
         eng.set_chain_impl(impl); eng.set_chain_rows(rows); eng.set_scene(scene); eng.rollout(); eng.sync()
         t = eng.time_rollout(3, 20)
         tr = eng.padded("traj").copy()
